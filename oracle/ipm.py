@@ -1,0 +1,399 @@
+"""Generic sparse primal-dual interior-point solver (IPOPT's published algorithm).
+
+TEST INFRASTRUCTURE ONLY - see oracle/__init__.py.
+
+The reference delegates the solve to a third-party binary that is absent here:
+  casadi.nlpsol('S','ipopt', nlp, opts)    /root/reference/do_mpc/controller/_mpc.py:1326-1328
+  r = self.S(x0=,lbx=,ubx=,lbg=,ubg=,p=)   /root/reference/do_mpc/optimizer.py:754-778
+(PyPI `casadi>=3.6.0`, /root/reference/requirements.txt:1, bundling IPOPT 3.14 + MUMPS).
+This file restates IPOPT's algorithm from its publication
+  A. Waechter, L. T. Biegler, "On the implementation of an interior-point filter
+  line-search algorithm for large-scale nonlinear programming", Math. Prog. 106 (2006)
+with IPOPT 3.14's documented default options (names in comments).  It works on the
+flat NLP (oracle/nlp.py) with a general sparse LU of the augmented system - no
+stage structure - so it is an independent check of the product's Riccati path.
+Parity is pinned on the reference's golden vectors (tests/golden/*.npz), see
+tests/test_oracle_golden.py.
+
+Deviations from IPOPT (documented, none changes the limit point):
+  * inertia is not available from scipy's LU: the inertia-correction loop uses the
+    curvature test d'(W+Sigma+delta I)d >= kappa |d|^2 (IPOPT option neg_curv_test)
+    instead of counting negative pivots;
+  * no restoration phase: if the backtracking line search hits alpha_min the last
+    trial step is taken and the filter is reset (counted in stats['n_ls_fail']).
+"""
+import time
+
+import numpy as np
+import scipy.sparse as sps
+import scipy.sparse.linalg as spla
+
+DEFAULTS = dict(
+    tol=1e-8, max_iter=3000, dual_inf_tol=1.0, constr_viol_tol=1e-4, compl_inf_tol=1e-4,
+    acceptable_tol=1e-6, acceptable_iter=15,
+    mu_init=0.1, mu_target=0.0, kappa_mu=0.2, theta_mu=1.5, kappa_eps=10.0, tau_min=0.99,
+    bound_push=0.01, bound_frac=0.01, bound_relax_factor=1e-8, bound_mult_init_val=1.0,
+    constr_mult_init_max=1000.0, s_max=100.0, kappa_sigma=1e10,
+    eta_phi=1e-8, gamma_theta=1e-5, gamma_phi=1e-8, delta=1.0, s_theta=1.1, s_phi=2.3,
+    theta_max_fact=1e4, theta_min_fact=1e-4, gamma_alpha=0.05, max_soc=4, kappa_soc=0.99,
+    delta_w_min=1e-20, delta_w_0=1e-4, delta_w_max=1e40, kappa_w_minus=1.0 / 3.0,
+    kappa_w_plus=8.0, kappa_w_plus_bar=100.0, delta_c_bar=1e-8, kappa_c=0.25,
+    nlp_scaling_max_gradient=100.0, nlp_scaling_min_value=1e-8, obj_scaling=True, con_scaling=True,
+)
+
+
+class Result(dict):
+    pass
+
+
+def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, lbg=None, ubg=None, trace=None):
+    """Returns dict with x, f, g, lam_g, lam_x and stats (CasADi sign convention
+    L = f + lam_g' g + lam_x' x, /root/reference/do_mpc/differentiator/_nlpdifferentiator.py:287)."""
+    o = dict(DEFAULTS)
+    if opts:
+        o.update(opts)
+    t_start = time.perf_counter()
+    n = nlp.n_opt_x
+    lbx = nlp.lbx if lbx is None else lbx
+    ubx = nlp.ubx if ubx is None else ubx
+    lbg = nlp.lbg if lbg is None else lbg
+    ubg = nlp.ubg if ubg is None else ubg
+    eq = lbg == ubg
+    ineq = ~eq
+    m_e, m_i = int(eq.sum()), int(ineq.sum())
+    m = m_e + m_i
+    idx_e, idx_i = np.where(eq)[0], np.where(ineq)[0]
+
+    # ---- variables v = [x ; s]; bounds with relaxation (bound_relax_factor)
+    vl = np.concatenate([lbx, lbg[idx_i]]).astype(float)
+    vu = np.concatenate([ubx, ubg[idx_i]]).astype(float)
+    relax = o["bound_relax_factor"]
+    has_l, has_u = np.isfinite(vl), np.isfinite(vu)
+    vl[has_l] -= np.minimum(o["constr_viol_tol"], relax * np.maximum(1.0, np.abs(vl[has_l])))
+    vu[has_u] += np.minimum(o["constr_viol_tol"], relax * np.maximum(1.0, np.abs(vu[has_u])))
+    nv = n + m_i
+
+    def push(v, l, u, hl, hu):
+        v = v.copy()
+        both = hl & hu
+        pl = np.zeros_like(v)
+        pu = np.zeros_like(v)
+        pl[hl] = o["bound_push"] * np.maximum(1.0, np.abs(l[hl]))
+        pu[hu] = o["bound_push"] * np.maximum(1.0, np.abs(u[hu]))
+        pl[both] = np.minimum(pl[both], o["bound_frac"] * (u[both] - l[both]))
+        pu[both] = np.minimum(pu[both], o["bound_frac"] * (u[both] - l[both]))
+        v[hl] = np.maximum(v[hl], l[hl] + pl[hl])
+        v[hu] = np.minimum(v[hu], u[hu] - pu[hu])
+        return v
+
+    x = push(np.asarray(x0, float).copy(), vl[:n], vu[:n], has_l[:n], has_u[:n])
+
+    # ---- NLP scaling (gradient based, nlp_scaling_method default)
+    g0 = nlp.grad(x, p)
+    J0 = nlp.jac(x, p)
+    gmax = o["nlp_scaling_max_gradient"]
+    sf = 1.0
+    if o["obj_scaling"]:
+        gn = np.max(np.abs(g0)) if n else 0.0
+        if gn > gmax:
+            sf = max(gmax / gn, o["nlp_scaling_min_value"])
+    sg = np.ones(len(lbg))
+    if o["con_scaling"] and J0.nnz:
+        rn = np.asarray(abs(J0).max(axis=1).todense()).ravel()
+        big = rn > gmax
+        sg[big] = np.maximum(gmax / rn[big], o["nlp_scaling_min_value"])
+    # scaled inequality bounds
+    vl[n:] *= sg[idx_i]
+    vu[n:] *= sg[idx_i]
+    Sg = sps.diags(sg)
+    ce_rhs = lbg[idx_e] * sg[idx_e]
+
+    n_eval = dict(f=0, g=0, jac=0, hess=0)
+
+    def eval_fg(xx):
+        n_eval["f"] += 1
+        n_eval["g"] += 1
+        return sf * nlp.f(xx, p), sg * nlp.g(xx, p)
+
+    def cons(gv, s):
+        c = np.empty(m)
+        c[:m_e] = gv[idx_e] - ce_rhs
+        c[m_e:] = gv[idx_i] - s
+        return c
+
+    fval, gval = eval_fg(x)
+    s = push(gval[idx_i].copy(), vl[n:], vu[n:], has_l[n:], has_u[n:])
+    v = np.concatenate([x, s])
+    zl = np.where(has_l, o["bound_mult_init_val"], 0.0)
+    zu = np.where(has_u, o["bound_mult_init_val"], 0.0)
+
+    def jac_full(xx):
+        n_eval["jac"] += 1
+        J = (Sg @ nlp.jac(xx, p)).tocsr()
+        Je, Ji = J[idx_e], J[idx_i]
+        top = sps.hstack([Je, sps.csr_matrix((m_e, m_i))]) if m_e else sps.csr_matrix((0, nv))
+        bot = sps.hstack([Ji, -sps.identity(m_i)]) if m_i else sps.csr_matrix((0, nv))
+        return sps.vstack([top, bot]).tocsr()
+
+    def grad_full(xx):
+        gfull = np.zeros(nv)
+        gfull[:n] = sf * nlp.grad(xx, p)
+        return gfull
+
+    A = jac_full(x)
+    gf = grad_full(x)
+
+    # ---- least-square multiplier estimate
+    def ls_multipliers():
+        K = sps.bmat([[sps.identity(nv), A.T], [A, None]], format="csc")
+        rhs = np.concatenate([-(gf - zl + zu), np.zeros(m)])
+        try:
+            sol = spla.splu(K).solve(rhs)
+            y = sol[nv:]
+            if not np.all(np.isfinite(y)) or np.max(np.abs(y), initial=0.0) > o["constr_mult_init_max"]:
+                y = np.zeros(m)
+        except RuntimeError:
+            y = np.zeros(m)
+        return y
+
+    y = ls_multipliers() if m else np.zeros(0)
+    mu = o["mu_init"]
+    tau = max(o["tau_min"], 1.0 - mu)
+    # IPOPT's monotone update floors mu at min(tol, compl_inf_tol)/(barrier_tol_factor+1)
+    # (= 1e-8/11 = 9.0909e-10 with defaults).  Visible in the reference's goldens: the CSTR
+    # slack eps sits at -1e-8 + 9.0909e-12 = lower bound(relaxed) + mu/penalty.
+    mu_min = min(o["tol"], o["compl_inf_tol"] * sf) / (o["kappa_eps"] + 1.0)
+
+    def lam_unscaled(yy):
+        lam = np.zeros(len(lbg))
+        lam[idx_e] = yy[:m_e]
+        lam[idx_i] = yy[m_e:]
+        return lam * sg / sf
+
+    def hess_full(xx, yy):
+        n_eval["hess"] += 1
+        lam = np.zeros(len(lbg))
+        lam[idx_e] = yy[:m_e]
+        lam[idx_i] = yy[m_e:]
+        H = nlp.hess(xx, p, sf, lam * sg)
+        return sps.block_diag([H, sps.csr_matrix((m_i, m_i))], format="csr") if m_i else H.tocsr()
+
+    def err(mu_, v_, y_, zl_, zu_, gf_, A_, c_):
+        dl = np.where(has_l, v_ - vl, 1.0)
+        du = np.where(has_u, vu - v_, 1.0)
+        rd = gf_ + A_.T @ y_ - zl_ + zu_
+        sd = max(o["s_max"], (np.abs(y_).sum() + np.abs(zl_).sum() + np.abs(zu_).sum()) / max(1, m + has_l.sum() + has_u.sum())) / o["s_max"]
+        sc = max(o["s_max"], (np.abs(zl_).sum() + np.abs(zu_).sum()) / max(1, has_l.sum() + has_u.sum())) / o["s_max"]
+        e_d = np.max(np.abs(rd), initial=0.0)
+        e_p = np.max(np.abs(c_), initial=0.0)
+        e_c = max(np.max(np.abs(dl * zl_ - mu_)[has_l], initial=0.0), np.max(np.abs(du * zu_ - mu_)[has_u], initial=0.0))
+        return max(e_d / sd, e_p, e_c / sc), e_d, e_p, e_c
+
+    def barrier(fv, v_):
+        return fv - mu * (np.log((v_ - vl)[has_l]).sum() + np.log((vu - v_)[has_u]).sum())
+
+    c = cons(gval, s)
+    filt = []
+    theta0 = np.abs(c).sum()
+    theta_max = o["theta_max_fact"] * max(1.0, theta0)
+    theta_min = o["theta_min_fact"] * max(1.0, theta0)
+    delta_w_last = 0.0
+    stats = dict(n_ls_fail=0, n_reg=0, n_soc=0, iters=[])
+    status = "Maximum_Iterations_Exceeded"
+    success = False
+    acc_count = 0
+    it = 0
+    while True:
+        E0, e_d, e_p, e_c = err(0.0, v, y, zl, zu, gf, A, c)
+        if trace is not None:
+            trace.append(dict(it=it, mu=mu, E0=E0, inf_du=e_d, inf_pr=e_p, compl=e_c, f=fval / sf, x=v[:n].copy()))
+        # unscaled acceptance thresholds are checked on scaled quantities here (scaling is mild)
+        if E0 <= o["tol"] and e_d <= o["dual_inf_tol"] and e_p <= o["constr_viol_tol"] and e_c <= o["compl_inf_tol"]:
+            status, success = "Solve_Succeeded", True
+            break
+        if E0 <= o["acceptable_tol"]:
+            acc_count += 1
+            if acc_count >= o["acceptable_iter"]:
+                status, success = "Solved_To_Acceptable_Level", True
+                break
+        else:
+            acc_count = 0
+        if it >= o["max_iter"]:
+            break
+        # ---- barrier update
+        while True:
+            Emu = err(mu, v, y, zl, zu, gf, A, c)[0]
+            if Emu <= o["kappa_eps"] * mu and mu > mu_min:
+                mu = max(mu_min, min(o["kappa_mu"] * mu, mu ** o["theta_mu"]))
+                tau = max(o["tau_min"], 1.0 - mu)
+                filt = []
+            else:
+                break
+        # ---- search direction
+        W = hess_full(v[:n], y)
+        dl = np.where(has_l, v - vl, 1.0)
+        du = np.where(has_u, vu - v, 1.0)
+        sigma = np.where(has_l, zl / dl, 0.0) + np.where(has_u, zu / du, 0.0)
+        rx = gf + A.T @ y - np.where(has_l, mu / dl, 0.0) + np.where(has_u, mu / du, 0.0)
+        rhs = -np.concatenate([rx, c])
+        delta_w, delta_c = 0.0, 0.0
+        first_try = True
+        while True:
+            Hreg = W + sps.diags(sigma + delta_w)
+            K = sps.bmat([[Hreg, A.T], [A, -delta_c * sps.identity(m) if delta_c > 0 else None]], format="csc")
+            ok = True
+            try:
+                lu = spla.splu(K)
+                sol = lu.solve(rhs)
+                # one step of iterative refinement
+                sol += lu.solve(rhs - K @ sol)
+                ok = np.all(np.isfinite(sol))
+            except RuntimeError:
+                ok = False
+                if delta_c == 0.0:
+                    delta_c = o["delta_c_bar"] * mu ** o["kappa_c"]
+            if ok:
+                dv = sol[:nv]
+                curv = dv @ (Hreg @ dv)
+                if curv >= 1e-11 * (dv @ dv) or (dv @ dv) == 0.0:
+                    break
+            stats["n_reg"] += 1
+            if delta_w == 0.0:
+                delta_w = o["delta_w_0"] if delta_w_last == 0.0 else max(o["delta_w_min"], o["kappa_w_minus"] * delta_w_last)
+            else:
+                delta_w *= o["kappa_w_plus_bar"] if (delta_w_last == 0.0 and first_try) else o["kappa_w_plus"]
+                if delta_w > o["delta_w_max"]:
+                    raise RuntimeError("inertia correction failed")
+            first_try = False
+        if delta_w > 0:
+            delta_w_last = delta_w
+        dv, dy = sol[:nv], sol[nv:]
+        dzl = np.where(has_l, mu / dl - zl - zl / dl * dv, 0.0)
+        dzu = np.where(has_u, mu / du - zu + zu / du * dv, 0.0)
+
+        def ftb(val, d):
+            neg = d < 0
+            if not neg.any():
+                return 1.0
+            return min(1.0, np.min(-tau * val[neg] / d[neg]))
+
+        a_max = min(ftb(dl[has_l], dv[has_l]), ftb(du[has_u], -dv[has_u]))
+        a_z = min(ftb(zl[has_l], dzl[has_l]), ftb(zu[has_u], dzu[has_u]))
+
+        # ---- filter line search
+        theta = np.abs(c).sum()
+        phi = barrier(fval, v)
+        gphi = gf - np.where(has_l, mu / dl, 0.0) + np.where(has_u, mu / du, 0.0)
+        dphi = gphi @ dv
+        if dphi < 0 and theta <= theta_min:
+            a_min = o["gamma_alpha"] * min(o["gamma_theta"], o["gamma_phi"] * theta / (-dphi) if theta > 0 else np.inf,
+                                           o["delta"] * theta ** o["s_theta"] / (-dphi) ** o["s_phi"] if theta > 0 else np.inf)
+            if theta == 0:
+                a_min = o["gamma_alpha"] * o["gamma_theta"]
+        elif dphi < 0:
+            a_min = o["gamma_alpha"] * min(o["gamma_theta"], o["gamma_phi"] * theta / (-dphi))
+        else:
+            a_min = o["gamma_alpha"] * o["gamma_theta"]
+        a_min = max(a_min, 1e-14)
+
+        def acceptable(th_t, ph_t, alpha):
+            if th_t > theta_max:
+                return False, False
+            for (tf, pf) in filt:
+                if th_t >= tf and ph_t >= pf:
+                    return False, False
+            switching = dphi < 0 and alpha * (-dphi) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]
+            if theta <= theta_min and switching:
+                eps_m = 10 * np.finfo(float).eps * abs(phi)
+                return ph_t - phi - eps_m <= o["eta_phi"] * alpha * dphi, True
+            eps_m = 10 * np.finfo(float).eps * abs(phi)
+            return (th_t <= (1 - o["gamma_theta"]) * theta) or (ph_t - phi - eps_m <= -o["gamma_phi"] * theta), False
+
+        alpha = a_max
+        accepted = False
+        n_ls = 0
+        used_dv = dv
+        while alpha >= a_min:
+            v_t = v + alpha * dv
+            f_t, g_t = eval_fg(v_t[:n])
+            c_t = cons(g_t, v_t[n:])
+            th_t = np.abs(c_t).sum()
+            ph_t = barrier(f_t, v_t) if np.isfinite(f_t) else np.inf
+            ok_, armijo = acceptable(th_t, ph_t, alpha) if np.isfinite(ph_t) and np.isfinite(th_t) else (False, False)
+            if ok_:
+                accepted = True
+                break
+            # second-order correction on the first trial point
+            if n_ls == 0 and th_t >= theta and o["max_soc"] > 0:
+                c_soc = alpha * c + c_t
+                th_old = theta
+                for _ in range(o["max_soc"]):
+                    stats["n_soc"] += 1
+                    sol_s = lu.solve(-np.concatenate([rx, c_soc]))
+                    dv_s = sol_s[:nv]
+                    a_s = min(ftb(dl[has_l], dv_s[has_l]), ftb(du[has_u], -dv_s[has_u]))
+                    v_s = v + a_s * dv_s
+                    f_s, g_s = eval_fg(v_s[:n])
+                    c_s = cons(g_s, v_s[n:])
+                    th_s = np.abs(c_s).sum()
+                    ph_s = barrier(f_s, v_s) if np.isfinite(f_s) else np.inf
+                    ok_s, arm_s = acceptable(th_s, ph_s, a_s) if np.isfinite(ph_s) and np.isfinite(th_s) else (False, False)
+                    if ok_s:
+                        accepted, armijo = True, arm_s
+                        v_t, f_t, g_t, c_t, th_t, ph_t = v_s, f_s, g_s, c_s, th_s, ph_s
+                        dy = sol_s[nv:]
+                        alpha_y = a_s
+                        used_dv = dv_s
+                        break
+                    if th_s > o["kappa_soc"] * th_old:
+                        break
+                    th_old = th_s
+                    c_soc = a_s * c_soc + c_s
+                if accepted:
+                    alpha = alpha_y
+                    break
+            alpha *= 0.5
+            n_ls += 1
+        if not accepted:
+            stats["n_ls_fail"] += 1
+            alpha = max(alpha, a_min)
+            v_t = v + alpha * dv
+            f_t, g_t = eval_fg(v_t[:n])
+            c_t = cons(g_t, v_t[n:])
+            filt = []
+            armijo = True
+        # ---- filter augmentation
+        if accepted and not armijo:
+            filt.append(((1 - o["gamma_theta"]) * theta, phi - o["gamma_phi"] * theta))
+        elif accepted and armijo:
+            switching = dphi < 0 and alpha * (-dphi) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]
+            if not (theta <= theta_min and switching):
+                filt.append(((1 - o["gamma_theta"]) * theta, phi - o["gamma_phi"] * theta))
+        # ---- accept
+        v = v_t
+        y = y + alpha * dy
+        zl = zl + a_z * dzl
+        zu = zu + a_z * dzu
+        dl = np.where(has_l, v - vl, 1.0)
+        du = np.where(has_u, vu - v, 1.0)
+        ks = o["kappa_sigma"]
+        zl = np.where(has_l, np.maximum(np.minimum(zl, ks * mu / dl), mu / (ks * dl)), 0.0)
+        zu = np.where(has_u, np.maximum(np.minimum(zu, ks * mu / du), mu / (ks * du)), 0.0)
+        fval, gval, c = f_t, g_t, c_t
+        A = jac_full(v[:n])
+        gf = grad_full(v[:n])
+        stats["iters"].append(dict(alpha=alpha, alpha_z=a_z, mu=mu, delta_w=delta_w, n_ls=n_ls))
+        it += 1
+
+    xs = v[:n]
+    res = Result()
+    res["x"] = xs.copy()
+    res["f"] = fval / sf
+    res["g"] = gval / sg
+    res["lam_g"] = lam_unscaled(y)
+    res["lam_x"] = (zu[:n] - zl[:n]) / sf
+    res["stats"] = dict(success=success, return_status=status, iter_count=it,
+                        t_wall_total=time.perf_counter() - t_start, n_eval=n_eval,
+                        n_ls_fail=stats["n_ls_fail"], n_reg=stats["n_reg"], n_soc=stats["n_soc"], mu=mu,
+                        obj_scaling=sf)
+    return res

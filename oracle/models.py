@@ -1,0 +1,184 @@
+"""SymPy restatement of the four BASELINE example problems (TEST INFRASTRUCTURE).
+
+Independent of the product's own expression DAG (do_mpc_amd/sym.py): derivatives
+here come from sympy.diff, so AD bugs in the product cannot hide in the oracle.
+
+Each `case_*` returns a dict describing exactly what the reference templates
+configure:
+  industrial_poly : /root/reference/examples/industrial_poly/template_model.py:32-134,
+                    template_mpc.py:35-117, main.py:59-73
+  CSTR            : /root/reference/examples/CSTR/template_model.py:34-98,
+                    template_mpc.py:34-105, main.py:58-63
+  batch_reactor   : /root/reference/examples/batch_reactor/template_model.py:34-74,
+                    template_mpc.py:34-88, main.py:56-61
+  oscillating_masses_discrete : /root/reference/examples/oscillating_masses_discrete/
+                    template_model.py:34-73, template_mpc.py:34-74, main.py:57-60
+"""
+import itertools
+
+import numpy as np
+import sympy as sp
+
+INF = np.inf
+
+
+def _base(**kw):
+    d = dict(model_type="continuous", n_robust=0, open_loop=False, collocation_type="radau",
+             collocation_deg=2, collocation_ni=1, cons_check_colloc_points=True,
+             nl_cons_check_colloc_points=False, nl_cons_single_slack=False,
+             use_terminal_bounds=False, nl_cons=[], uncertainty={}, tvp_names=[])
+    d.update(kw)
+    return d
+
+
+def case_industrial_poly(**over):
+    x = sp.symbols("m_W m_A m_P T_R T_S Tout_M T_EK Tout_AWT accum_monom T_adiab")
+    u = sp.symbols("m_dot_f T_in_M T_in_EK")
+    p = sp.symbols("delH_R k_0")
+    m_W, m_A, m_P, T_R, T_S, Tout_M, T_EK, Tout_AWT, accum_monom, T_adiab = x
+    m_dot_f, T_in_M, T_in_EK = u
+    delH_R, k_0 = p
+    R, T_F, E_a, A_tank = 8.314, 25 + 273.15, 8500.0, 65.0
+    k_U2, k_U1, w_WF, w_AF = 32.0, 4.0, .333, .667
+    m_M_KW, fm_M_KW, m_AWT_KW, fm_AWT_KW = 5000.0, 300000.0, 1000.0, 100000.0
+    m_AWT, fm_AWT, m_S = 200.0, 20000.0, 39000.0
+    c_pW, c_pS, c_pF, c_pR = 4.2, .47, 3.0, 5.0
+    k_WS, k_AS, k_PS = 17280.0, 3600.0, 360.0
+    alfa = 5 * 20e4 * 3.6
+    p_1 = 1.0
+    U_m = m_P / (m_A + m_P)
+    m_ges = m_W + m_A + m_P
+    k_R1 = k_0 * sp.exp(-E_a / (R * T_R)) * ((k_U1 * (1 - U_m)) + (k_U2 * U_m))
+    k_R2 = k_0 * sp.exp(-E_a / (R * T_EK)) * ((k_U1 * (1 - U_m)) + (k_U2 * U_m))
+    k_K = ((m_W / m_ges) * k_WS) + ((m_A / m_ges) * k_AS) + ((m_P / m_ges) * k_PS)
+    dot_m_W = m_dot_f * w_WF
+    reac = k_R1 * (m_A - ((m_A * m_AWT) / (m_W + m_A + m_P)))
+    ehe = p_1 * k_R2 * (m_A / m_ges) * m_AWT
+    dot_m_A = (m_dot_f * w_AF) - reac - ehe
+    dot_m_P = reac + ehe
+    dot_T_R = 1. / (c_pR * m_ges) * ((m_dot_f * c_pF * (T_F - T_R)) - (k_K * A_tank * (T_R - T_S))
+                                     - (fm_AWT * c_pR * (T_R - T_EK)) + (delH_R * reac))
+    rhs = [
+        dot_m_W, dot_m_A, dot_m_P, dot_T_R,
+        1. / (c_pS * m_S) * ((k_K * A_tank * (T_R - T_S)) - (k_K * A_tank * (T_S - Tout_M))),
+        1. / (c_pW * m_M_KW) * ((fm_M_KW * c_pW * (T_in_M - Tout_M)) + (k_K * A_tank * (T_S - Tout_M))),
+        1. / (c_pR * m_AWT) * ((fm_AWT * c_pR * (T_R - T_EK)) - (alfa * (T_EK - Tout_AWT)) + (ehe * delH_R)),
+        1. / (c_pW * m_AWT_KW) * ((fm_AWT_KW * c_pW * (T_in_EK - Tout_AWT)) - (alfa * (Tout_AWT - T_EK))),
+        m_dot_f,
+        delH_R / (m_ges * c_pR) * dot_m_A - (dot_m_A + dot_m_W + dot_m_P) * (m_A * delH_R / (m_ges * m_ges * c_pR)) + dot_T_R,
+    ]
+    tr = 2.0
+    x_lb = np.array([0.0, 0.0, 26.0, 363.15 - tr, 298.0, 298.0, 288.0, 288.0, 0.0, -INF])
+    x_ub = np.array([INF, INF, INF, 363.15 + tr, 400.0, 400.0, 400.0, 400.0, 30000.0, 382.15])
+    x0 = np.array([10000.0, 853.0, 26.5, 363.15, 363.15, 363.15, 308.15, 308.15, 300.0, 0.0])
+    x0[9] = x0[1] * 950.0 / ((x0[0] + x0[1] + x0[2]) * 5.0) + x0[3]
+    d = _base(name="industrial_poly", x=x, u=u, p=p, rhs=rhs, lterm=-m_P, mterm=-m_P,
+              rterm=np.array([0.002, 0.004, 0.002]), n_horizon=20, n_robust=1, t_step=50.0 / 3600.0,
+              x_lb=x_lb, x_ub=x_ub, u_lb=np.array([0.0, 333.15, 333.15]), u_ub=np.array([3.0e4, 373.15, 373.15]),
+              x_scaling=np.array([10., 10, 10, 1, 1, 1, 1, 1, 10, 1]), u_scaling=np.array([100., 1, 1]),
+              uncertainty=dict(delH_R=[950.0, 950.0 * 1.30, 950.0 * 0.70], k_0=[7.0 * 1.00, 7.0 * 1.30, 7.0 * 0.70]),
+              x0=x0, aux={})
+    d.update(over)
+    return d
+
+
+def case_CSTR(**over):
+    x = sp.symbols("C_a C_b T_R T_K")
+    u = sp.symbols("F Q_dot")
+    p = sp.symbols("alpha beta")
+    C_a, C_b, T_R, T_K = x
+    F, Q_dot = u
+    alpha, beta = p
+    K0_ab, K0_bc, K0_ad = 1.287e12, 1.287e12, 9.043e9
+    E_A_ab, E_A_bc, E_A_ad = 9758.3, 9758.3, 8560.0
+    H_R_ab, H_R_bc, H_R_ad = 4.2, -11.0, -41.85
+    Rou, Cp, Cp_k, A_R, V_R, m_k, T_in, K_w = 0.9342, 3.01, 2.0, 0.215, 10.01, 5.0, 130.0, 4032.0
+    C_A0 = (5.7 + 4.5) / 2.0
+    T_dif = T_R - T_K
+    K_1 = beta * K0_ab * sp.exp((-E_A_ab) / (T_R + 273.15))
+    K_2 = K0_bc * sp.exp((-E_A_bc) / (T_R + 273.15))
+    K_3 = K0_ad * sp.exp((-alpha * E_A_ad) / (T_R + 273.15))
+    rhs = [
+        F * (C_A0 - C_a) - K_1 * C_a - K_3 * (C_a ** 2),
+        -F * C_b + K_1 * C_a - K_2 * C_b,
+        ((K_1 * C_a * H_R_ab + K_2 * C_b * H_R_bc + K_3 * (C_a ** 2) * H_R_ad) / (-Rou * Cp)) + F * (T_in - T_R)
+        + (((K_w * A_R) * (-T_dif)) / (Rou * Cp * V_R)),
+        (Q_dot + K_w * A_R * T_dif) / (m_k * Cp_k),
+    ]
+    d = _base(name="CSTR", x=x, u=u, p=p, rhs=rhs, lterm=(C_b - 0.6) ** 2, mterm=(C_b - 0.6) ** 2,
+              rterm=np.array([0.1, 1e-3]), n_horizon=20, n_robust=1, t_step=0.005,
+              x_lb=np.array([0.1, 0.1, 50.0, 50.0]), x_ub=np.array([2.0, 2.0, INF, 140.0]),
+              u_lb=np.array([5.0, -8500.0]), u_ub=np.array([100.0, 0.0]),
+              x_scaling=np.array([1.0, 1.0, 100.0, 100.0]), u_scaling=np.array([100.0, 2000.0]),
+              nl_cons=[dict(name="T_R", expr=T_R, ub=140.0, soft=True, penalty=1e2, max_violation=INF)],
+              uncertainty=dict(alpha=[1., 1.05, 0.95], beta=[1., 1.1, 0.9]),
+              x0=np.array([0.8, 0.5, 134.14, 130.0]), aux={"T_dif": T_dif})
+    d.update(over)
+    return d
+
+
+def case_batch_reactor(**over):
+    x = sp.symbols("X_s S_s P_s V_s")
+    u = (sp.Symbol("inp"),)
+    p = sp.symbols("Y_x S_in")
+    X_s, S_s, P_s, V_s = x
+    inp = u[0]
+    Y_x, S_in = p
+    mu_m, K_m, K_i, v_par, Y_p = 0.02, 0.05, 5.0, 0.004, 1.2
+    mu_S = mu_m * S_s / (K_m + S_s + (S_s ** 2 / K_i))
+    rhs = [mu_S * X_s - inp / V_s * X_s,
+           -mu_S * X_s / Y_x - v_par * X_s / Y_p + inp / V_s * (S_in - S_s),
+           v_par * X_s - inp / V_s * P_s,
+           inp]
+    d = _base(name="batch_reactor", x=x, u=u, p=p, rhs=rhs, lterm=-P_s, mterm=-P_s,
+              rterm=np.array([1.0]), n_horizon=20, n_robust=0, t_step=1.0, collocation_ni=2,
+              x_lb=np.array([0.0, -0.01, 0.0, 0.0]), x_ub=np.array([3.7, INF, 3.0, INF]),
+              u_lb=np.array([0.0]), u_ub=np.array([0.2]),
+              x_scaling=np.ones(4), u_scaling=np.ones(1),
+              uncertainty=dict(Y_x=[0.5, 0.4, 0.3], S_in=[200.0, 220.0, 180.0]),
+              x0=np.array([1.0, 0.5, 0.0, 120.0]), aux={})
+    d.update(over)
+    return d
+
+
+def case_oscillating_masses(**over):
+    x = sp.symbols("x_0 x_1 x_2 x_3")
+    u = (sp.Symbol("u"),)
+    A = np.array([[0.763, 0.460, 0.115, 0.020],
+                  [-0.899, 0.763, 0.420, 0.115],
+                  [0.115, 0.020, 0.763, 0.460],
+                  [0.420, 0.115, -0.899, 0.763]])
+    B = np.array([0.014, 0.063, 0.221, 0.367])
+    rhs = [sum(A[i, j] * x[j] for j in range(4)) + B[i] * u[0] for i in range(4)]
+    cost = sum(xi ** 2 for xi in x)
+    mx = np.array([4.0, 10.0, 4.0, 10.0])
+    rng = np.random.RandomState(99)  # reference test: np.random.seed(99); np.random.rand(4)-0.5
+    x0 = rng.rand(4) - 0.5
+    d = _base(name="oscillating_masses", model_type="discrete", x=x, u=u, p=(), rhs=rhs,
+              lterm=cost, mterm=cost, rterm=np.array([1e-4]), n_horizon=7, n_robust=0, t_step=0.5,
+              x_lb=-mx, x_ub=mx, u_lb=np.array([-0.5]), u_ub=np.array([0.5]),
+              x_scaling=np.ones(4), u_scaling=np.ones(1), x0=x0, aux={"cost": cost})
+    d.update(over)
+    return d
+
+
+CASES = {"industrial_poly": case_industrial_poly, "CSTR": case_CSTR,
+         "batch_reactor": case_batch_reactor, "oscillating_masses": case_oscillating_masses}
+
+
+def p_scenarios(case):
+    """All parameter combinations, first keyword varies slowest, first value nominal
+    (/root/reference/do_mpc/controller/_mpc.py:867, itertools.product)."""
+    names = [str(s) for s in case["p"]]
+    unc = case["uncertainty"]
+    if not names:
+        return np.zeros((1, 0))
+    if not unc:
+        return np.zeros((1, len(names)))
+    combos = list(itertools.product(*[unc[k] for k in unc.keys()]))
+    keys = list(unc.keys())
+    out = np.zeros((len(combos), len(names)))
+    for c, combo in enumerate(combos):
+        for k, v in zip(keys, combo):
+            out[c, names.index(k)] = v
+    return out

@@ -1,0 +1,84 @@
+"""Pin the CPU oracle (oracle/) to the reference's own golden vectors.
+
+Golden source: /root/reference/testing/results/results_*.pkl, asserted at 1e-8 by
+/root/reference/testing/test_{industrial_poly,CSTR,batch_reactor,oscillating_masses_discrete}.py
+and extracted to tests/golden/*.npz by tools/extract_golden.py.
+
+Checks, per case:
+  * NLP sizes (n_opt_x, n_g, n_opt_p) equal the reference's;
+  * the golden primal solution satisfies our restated constraints (<= 2e-8) and, with the
+    golden multipliers, stationarity on variables away from their bounds;
+  * open-loop replay: feeding golden x[k], u[k-1] and warm-starting like
+    Optimizer.solve (/root/reference/do_mpc/optimizer.py:754-768) reproduces golden u[k].
+Tolerance for u (stated): 1e-6 relative to max(1,|u|) - the goldens are IPOPT iterates at
+mu = 9.09e-10, and the CSTR optimum moves by 3e-3 relative between mu=1e-9 and mu=0, so
+anything tighter would pin IPOPT's last Newton step rather than the solution.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ipm
+from oracle.models import CASES
+from oracle.nlp import OracleNLP, collocation_coeffs
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+U_RTOL = 1e-6
+
+_cache = {}
+
+
+def _nlp(name):
+    if name not in _cache:
+        _cache[name] = OracleNLP(CASES[name]())
+    return _cache[name]
+
+
+def test_radau_coefficients():
+    # /root/repo/SURVEY.md App. A.6 (validated against the goldens there)
+    tau, C, D = collocation_coeffs(2, "radau")
+    assert np.allclose(tau, [0, 1 / 3, 1])
+    assert np.allclose(C, [[-4, -2, 2], [4.5, 1.5, -4.5], [-0.5, 0.5, 2.5]])
+    assert np.allclose(D, [0, 0, 1])
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly"])
+def test_golden_point_is_kkt_point_of_restated_nlp(name):
+    nlp = _nlp(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    X, LG, P = g["mpc._opt_x_num"], g["mpc._lam_g_num"], g["mpc.opt_p_num"]
+    assert (nlp.n_opt_x, nlp.n_g, nlp.n_opt_p) == (X.shape[1], LG.shape[1], P.shape[1])
+    s = nlp.scaling_vector()
+    for k in range(X.shape[0]):
+        x, p, lam = X[k] / s, P[k], LG[k]
+        gv = nlp.g(x, p)
+        eq = nlp.lbg == nlp.ubg
+        assert np.max(np.abs(gv[eq])) < 2e-8
+        if (~eq).any():
+            assert np.max(gv[~eq] - nlp.ubg[~eq]) < 1e-7
+        r = nlp.grad(x, p) + nlp.jac(x, p).T @ lam
+        interior = (x - nlp.lbx > 1e-3 * np.maximum(1, np.abs(nlp.lbx))) & \
+                   (nlp.ubx - x > 1e-3 * np.maximum(1, np.abs(nlp.ubx)))
+        assert np.max(np.abs(r[interior])) < 2e-5 * max(1.0, np.max(np.abs(lam)))
+
+
+@pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 3),
+                                        ("industrial_poly", 2)])
+def test_open_loop_replay_matches_golden_u(name, steps):
+    case = CASES[name]()
+    nlp = _nlp(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    U, Xs, P, LG = g["mpc._u"], g["mpc._x"], g["mpc.opt_p_num"], g["mpc._lam_g_num"]
+    xg = nlp.initial_guess(case["x0"])
+    u_prev = np.zeros(nlp.nu)
+    for k in range(steps):
+        p = nlp.opt_p(Xs[k], u_prev)
+        assert np.allclose(p, P[k], rtol=0, atol=1e-12)
+        r = ipm.solve(nlp, xg, p)
+        assert r["stats"]["success"]
+        u0 = nlp.u0_of(r["x"])
+        assert np.max(np.abs(u0 - U[k]) / np.maximum(1.0, np.abs(U[k]))) < U_RTOL, (k, u0, U[k])
+        # multipliers: same sign convention as CasADi (L = f + lam_g'g)
+        assert np.max(np.abs(r["lam_g"] - LG[k])) < 1e-2 * max(1.0, np.max(np.abs(LG[k])))
+        xg, u_prev = r["x"], U[k]

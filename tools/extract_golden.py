@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Extract numeric golden vectors from the reference's regression pickles.
+
+Source fixtures (read-only, only present in the build container):
+  /root/reference/testing/results/results_{industrial_poly,CSTR,batch_reactor,oscillatingMasses}.pkl
+They are asserted at 1e-8 by the reference's own tests, e.g.
+  /root/reference/testing/test_industrial_poly.py:122-139.
+
+The pickles hold do_mpc.data.MPCData objects whose classes need CasADi to
+unpickle.  CasADi is not available here, so every non-numpy class is replaced
+by a stub that just records its state; all numeric payloads are plain ndarrays.
+
+Output: tests/golden/<case>.npz  (small, committed).
+Run:    python tools/extract_golden.py
+"""
+import io
+import os
+import pickle
+import sys
+
+import numpy as np
+
+REF = "/root/reference/testing/results"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+CASES = {
+    "industrial_poly": "results_industrial_poly.pkl",
+    "CSTR": "results_CSTR.pkl",
+    "batch_reactor": "results_batch_reactor.pkl",
+    "oscillating_masses": "results_oscillatingMasses.pkl",
+}
+
+
+class _Stub:
+    def __init__(self, *a, **k):
+        self._args = a
+        self._kw = k
+
+    def __setstate__(self, st):
+        self._state = st
+
+    def __reduce_ex__(self, proto):  # never re-pickled
+        raise TypeError
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.startswith("numpy") or module in ("builtins", "collections", "copyreg"):
+            return super().find_class(module, name)
+        return type(name, (_Stub,), {"__module__": module})
+
+
+def _state(obj):
+    st = getattr(obj, "_state", None)
+    if st is None:
+        st = getattr(obj, "__dict__", {})
+    return st
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for case, fn in CASES.items():
+        with open(os.path.join(REF, fn), "rb") as f:
+            res = _Unpickler(io.BytesIO(f.read())).load()
+        out = {}
+        for who in ("mpc", "simulator", "estimator"):
+            if who not in res:
+                continue
+            st = _state(res[who])
+            for key, val in st.items():
+                if isinstance(val, np.ndarray) and val.dtype != object:
+                    out[f"{who}.{key}"] = val
+            meta = st.get("meta_data") or st.get("_meta_data")
+            if isinstance(meta, dict):
+                for mk, mv in meta.items():
+                    if isinstance(mv, (int, float, str, bool)):
+                        out[f"{who}.meta.{mk}"] = np.array(mv)
+                    elif isinstance(mv, np.ndarray) and mv.dtype != object:
+                        out[f"{who}.meta.{mk}"] = mv
+        path = os.path.join(OUT, case + ".npz")
+        np.savez_compressed(path, **out)
+        print(case, "->", path, {k: v.shape for k, v in out.items() if v.ndim > 0})
+
+
+if __name__ == "__main__":
+    sys.exit(main())
