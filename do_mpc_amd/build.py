@@ -1,0 +1,111 @@
+"""Compile the native pieces: the generic runtime (C ABI) and per-model gfx950 code objects.
+
+Everything is built in-tree under do_mpc_amd/_build/ (git-ignored; travels to the GPU box with
+the gpurun snapshot).  hipcc cross-compiles for gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+BUILD = os.path.join(HERE, "_build")
+ARCH = "gfx950"
+
+
+class BuildError(RuntimeError):
+    pass
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise BuildError("hipcc not found: the dompc IPM backend needs the ROCm toolchain to lower models to gfx950")
+
+
+def _run(cmd, what):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise BuildError(f"{what} failed:\n{' '.join(cmd)}\n{r.stdout}")
+    return r.stdout
+
+
+def _sources_digest() -> str:
+    h = hashlib.sha256()
+    for fn in ("dompc_kernel.h", "dompc_kargs.h", "dompc_device.hip", "dompc_runtime.cpp"):
+        with open(os.path.join(CSRC, fn), "rb") as f:
+            h.update(f.read())
+    with open(os.path.join(INCLUDE, "dompc_ipm.h"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def runtime_library(force: bool = False) -> str:
+    """libdompc_ipm.so - the C-ABI host runtime (HIP only; no CPU fallback inside)."""
+    os.makedirs(BUILD, exist_ok=True)
+    out = os.path.join(BUILD, "libdompc_ipm.so")
+    stamp = out + ".stamp"
+    dig = _sources_digest()
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return out
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+           os.path.join(CSRC, "dompc_runtime.cpp"), "-o", out]
+    _run(cmd, "building libdompc_ipm.so")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return out
+
+
+def model_dir(model_hash: str) -> str:
+    d = os.path.join(BUILD, "models", model_hash)
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def model_code_object(header_text: str, model_hash: str, force: bool = False, opt: str = "-O3") -> str:
+    """Per-model gfx950 code object (hsaco) from the generated header + the kernel sources."""
+    d = model_dir(model_hash)
+    hdr = os.path.join(d, "model_gen.h")
+    out = os.path.join(d, f"dompc_{ARCH}.hsaco")
+    stamp = out + ".stamp"
+    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return out
+    with open(hdr, "w") as f:
+        f.write(header_text)
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco",
+           f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC,
+           os.path.join(CSRC, "dompc_device.hip"), "-o", out]
+    _run(cmd, f"lowering model {model_hash} to {ARCH}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return out
+
+
+def hostemu_library(header_text: str, model_hash: str, out_dir: str, force: bool = False) -> str:
+    """TEST-ONLY: runtime + kernels compiled for the host (g++), one workgroup = one thread.
+    Lives outside the package build dir (tests/_hostemu) and is never loaded by the product."""
+    os.makedirs(out_dir, exist_ok=True)
+    hdr = os.path.join(out_dir, f"model_gen_{model_hash}.h")
+    out = os.path.join(out_dir, f"libdompc_hostemu_{model_hash}.so")
+    stamp = out + ".stamp"
+    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12]
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return out
+    with open(hdr, "w") as f:
+        f.write(header_text)
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DDOMPC_HOST_EMU",
+           f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC,
+           os.path.join(CSRC, "dompc_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "dompc_device.hip"),
+           "-o", out, "-lm"]
+    _run(cmd, "building host emulation")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return out

@@ -1,0 +1,81 @@
+// dompc_device.hip - gfx950 entry points of the per-model code object.
+// Built by do_mpc_amd/build.py:  hipcc --offload-arch=gfx950 -O3 --genco -include <model_gen.h> ...
+// The same text is compiled by g++ -DDOMPC_HOST_EMU for the test-only host emulation (one "workgroup"
+// = one host thread); see dompc_kernel.h.
+#ifndef DOMPC_HOST_EMU
+#include <hip/hip_runtime.h>
+#define DOMPC_FN __device__ static inline
+#define DOMPC_CONST __device__ static const
+#define DOMPC_DEV __device__
+#define DOMPC_HD __host__ __device__
+#else
+#define DOMPC_FN static inline
+#define DOMPC_CONST static const
+#define DOMPC_DEV
+#define DOMPC_HD
+#endif
+
+#include DOMPC_MODEL_HEADER
+#include "dompc_kernel.h"
+
+namespace dompc {
+// sizes the generic runtime needs from the model-specific build
+DOMPC_HD inline void model_info(const int32_t* in, int64_t* out) {
+  // in: n_opt_x, n_g, n_edges, e_pad, n_nodes
+  WsLayout L = ws_layout(in[0], in[1], in[2], in[3], in[4]);
+  out[0] = NX; out[1] = NU; out[2] = NP; out[3] = NTVP; out[4] = NE; out[5] = NS;
+  out[6] = DEG; out[7] = NI; out[8] = M;
+  out[9] = L.total;
+  out[10] = SWEEP_BLOCK;
+  out[11] = (int64_t)sizeof(KArgs);
+}
+}  // namespace dompc
+
+#ifndef DOMPC_HOST_EMU
+extern "C" __global__ void dompc_model_info_kernel(const int32_t* in, int64_t* out, char* hash) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    dompc::model_info(in, out);
+    const char h[] = DOMPC_MODEL_HASH;
+    for (int i = 0; i < (int)sizeof(h); ++i) hash[i] = h[i];
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(256) dompc_solve_kernel(dompc::KArgs A) {
+  __shared__ double red[dompc::RED_MAX * 256];
+  __shared__ double filt[2 * dompc::MAX_FILTER];
+  __shared__ int flags[8];
+  __shared__ int s_b;
+  dompc::Thr T{(int)threadIdx.x, (int)blockDim.x, red, filt, flags};
+  if (A.mode == 1) {
+    if (blockIdx.x == 0) dompc::debug_newton(T, A);
+    return;
+  }
+  // persistent workgroups: each pulls problems from a device-wide counter and owns one workspace slot
+  while (true) {
+    if (threadIdx.x == 0) s_b = atomicAdd(A.work_counter, 1);
+    __syncthreads();
+    const int b = s_b;
+    __syncthreads();
+    if (b >= A.batch) break;
+    if (A.mode == 2) dompc::sweep_problem(T, A, b, blockIdx.x);
+    else dompc::solve_problem(T, A, b, blockIdx.x);
+  }
+}
+#else
+extern "C" void dompc_hostemu_model_info(const int32_t* in, int64_t* out, char* hash) {
+  dompc::model_info(in, out);
+  const char h[] = DOMPC_MODEL_HASH;
+  for (int i = 0; i < (int)sizeof(h); ++i) hash[i] = h[i];
+}
+extern "C" void dompc_hostemu_run(const dompc::KArgs* A) {
+  static thread_local double red[dompc::RED_MAX];
+  static thread_local double filt[2 * dompc::MAX_FILTER];
+  static thread_local int flags[8];
+  dompc::Thr T{0, 1, red, filt, flags};
+  if (A->mode == 1) { dompc::debug_newton(T, *A); return; }
+  for (int b = 0; b < A->batch; ++b) {
+    if (A->mode == 2) dompc::sweep_problem(T, *A, b, 0);
+    else dompc::solve_problem(T, *A, b, 0);
+  }
+}
+#endif

@@ -1,0 +1,406 @@
+// dompc_runtime.cpp - generic host runtime behind the C ABI of include/dompc_ipm.h.
+//
+// Owns: the loaded per-model gfx950 code object, device copies of the tree tables, the workspace
+// slots of the persistent workgroups, staging buffers for the host-pointer entry points.
+// It contains no model-dependent code: sizes come from the code object (dompc_model_info_kernel).
+//
+// Build flavours (do_mpc_amd/build.py):
+//   product : hipcc -shared -fPIC dompc_runtime.cpp            -> libdompc_ipm.so   (HIP only)
+//   test    : g++ -DDOMPC_HOST_EMU dompc_runtime.cpp dompc_device.hip(as C++) -> tests/_hostemu/*.so
+//             ("device" memory = host memory, a workgroup = the calling thread).  Never shipped.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dompc_kargs.h"
+
+#ifndef DOMPC_HOST_EMU
+#include <hip/hip_runtime.h>
+#else
+extern "C" void dompc_hostemu_model_info(const int32_t* in, int64_t* out, char* hash);
+extern "C" void dompc_hostemu_run(const dompc::KArgs* A);
+#endif
+
+static thread_local std::string g_create_error;
+
+struct dompc_handle {
+  dompc_problem_desc d;
+  std::string error;
+  std::string code_path;
+  int32_t e_pad = 0, n_slots = 0, block = 256;
+  int64_t ws_stride = 0, sweep_block = 0;
+  dompc::KArgs base;       // tables + workspace filled in, I/O pointers zero
+  std::vector<void*> dev_allocs;
+  // staging for host-pointer calls
+  double *s_x0 = nullptr, *s_lbx = nullptr, *s_ubx = nullptr, *s_lbg = nullptr, *s_ubg = nullptr, *s_p = nullptr;
+  double *s_x = nullptr, *s_g = nullptr, *s_lamx = nullptr, *s_lamg = nullptr, *s_f = nullptr;
+  dompc_stats* s_stats = nullptr;
+  double *s_dbg[8] = {nullptr};
+  int32_t cap_batch = 0;
+#ifndef DOMPC_HOST_EMU
+  hipModule_t module = nullptr;
+  hipFunction_t fn_solve = nullptr, fn_info = nullptr;
+  hipStream_t stream = nullptr;
+#endif
+};
+
+// ------------------------------------------------------------------------------------------------
+#ifndef DOMPC_HOST_EMU
+#define HIPCHK(h, expr)                                                                     \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      (h)->error = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+      return 1;                                                                             \
+    }                                                                                       \
+  } while (0)
+
+static int dev_alloc(dompc_handle* h, void** p, size_t bytes) {
+  if (bytes == 0) bytes = 8;
+  HIPCHK(h, hipMalloc(p, bytes));
+  h->dev_allocs.push_back(*p);
+  return 0;
+}
+static int h2d(dompc_handle* h, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return 0;
+  HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+static int d2h(dompc_handle* h, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return 0;
+  HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  return 0;
+}
+static int dev_sync(dompc_handle* h) {
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+static int dev_zero(dompc_handle* h, void* p, size_t bytes, hipStream_t s) {
+  HIPCHK(h, hipMemsetAsync(p, 0, bytes, s));
+  return 0;
+}
+#else
+static int dev_alloc(dompc_handle* h, void** p, size_t bytes) {
+  if (bytes == 0) bytes = 8;
+  *p = calloc(1, bytes);
+  if (!*p) { h->error = "out of memory"; return 1; }
+  h->dev_allocs.push_back(*p);
+  return 0;
+}
+static int h2d(dompc_handle*, void* dst, const void* src, size_t bytes) { if (bytes) memcpy(dst, src, bytes); return 0; }
+static int d2h(dompc_handle*, void* dst, const void* src, size_t bytes) { if (bytes) memcpy(dst, src, bytes); return 0; }
+static int dev_sync(dompc_handle*) { return 0; }
+#endif
+
+template <typename Tp>
+static int upload(dompc_handle* h, const Tp** dst, const Tp* src, size_t n) {
+  void* p = nullptr;
+  if (dev_alloc(h, &p, n * sizeof(Tp))) return 1;
+  if (n && !src) { h->error = "null table pointer in problem description"; return 1; }
+  if (h2d(h, p, src, n * sizeof(Tp))) return 1;
+  *dst = (const Tp*)p;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" void dompc_default_options(dompc_options* o) {
+  o->tol = 1e-8; o->dual_inf_tol = 1.0; o->constr_viol_tol = 1e-4; o->compl_inf_tol = 1e-4;
+  o->acceptable_tol = 1e-6; o->mu_init = 0.1; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->kappa_eps = 10.0;
+  o->tau_min = 0.99; o->bound_push = 0.01; o->bound_frac = 0.01; o->bound_relax_factor = 1e-8;
+  o->nlp_scaling_max_gradient = 100.0; o->delta_w_0 = 1e-4; o->delta_w_min = 1e-20; o->delta_w_max = 1e20;
+  o->kappa_w_minus = 1.0 / 3.0; o->kappa_w_plus = 8.0; o->kappa_w_plus_bar = 100.0;
+  o->max_iter = 3000; o->acceptable_iter = 15; o->obj_scaling = 1; o->reserved = 0;
+}
+
+extern "C" const char* dompc_status_string(int32_t s) {
+  switch (s) {
+    case 0: return "Solve_Succeeded";
+    case 1: return "Solved_To_Acceptable_Level";
+    case 2: return "Maximum_Iterations_Exceeded";
+    case 3: return "Error_In_Step_Computation";
+    case 4: return "Invalid_Number_Detected";
+    default: return "Internal_Error";
+  }
+}
+
+extern "C" const char* dompc_last_error(const dompc_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+extern "C" void dompc_destroy(dompc_handle* h) {
+  if (!h) return;
+#ifndef DOMPC_HOST_EMU
+  hipSetDevice(h->d.device);
+  for (void* p : h->dev_allocs) hipFree(p);
+  if (h->module) hipModuleUnload(h->module);
+  if (h->stream) hipStreamDestroy(h->stream);
+#else
+  for (void* p : h->dev_allocs) free(p);
+#endif
+  delete h;
+}
+
+static int ensure_staging(dompc_handle* h, int B) {
+  if (B <= h->cap_batch) return 0;
+  const dompc_problem_desc& d = h->d;
+  // (re)allocate; old buffers stay in dev_allocs and are released at destroy
+  if (dev_alloc(h, (void**)&h->s_x0, sizeof(double) * (size_t)B * d.n_opt_x)) return 1;
+  if (dev_alloc(h, (void**)&h->s_p, sizeof(double) * (size_t)B * d.n_opt_p)) return 1;
+  if (dev_alloc(h, (void**)&h->s_x, sizeof(double) * (size_t)B * d.n_opt_x)) return 1;
+  if (dev_alloc(h, (void**)&h->s_g, sizeof(double) * (size_t)B * d.n_g)) return 1;
+  if (dev_alloc(h, (void**)&h->s_lamx, sizeof(double) * (size_t)B * d.n_opt_x)) return 1;
+  if (dev_alloc(h, (void**)&h->s_lamg, sizeof(double) * (size_t)B * d.n_g)) return 1;
+  if (dev_alloc(h, (void**)&h->s_f, sizeof(double) * (size_t)B)) return 1;
+  if (dev_alloc(h, (void**)&h->s_stats, sizeof(dompc_stats) * (size_t)B)) return 1;
+  if (!h->s_lbx) {
+    if (dev_alloc(h, (void**)&h->s_lbx, sizeof(double) * d.n_opt_x)) return 1;
+    if (dev_alloc(h, (void**)&h->s_ubx, sizeof(double) * d.n_opt_x)) return 1;
+    if (dev_alloc(h, (void**)&h->s_lbg, sizeof(double) * d.n_g)) return 1;
+    if (dev_alloc(h, (void**)&h->s_ubg, sizeof(double) * d.n_g)) return 1;
+  }
+  h->cap_batch = B;
+  return 0;
+}
+
+static int launch(dompc_handle* h, dompc::KArgs& A, int grid, void* stream_v) {
+#ifndef DOMPC_HOST_EMU
+  hipStream_t st = stream_v ? (hipStream_t)stream_v : h->stream;
+  if (dev_zero(h, A.work_counter, sizeof(int32_t), st)) return 1;
+  size_t sz = sizeof(A);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIPCHK(h, hipModuleLaunchKernel(h->fn_solve, grid, 1, 1, h->block, 1, 1, 0, st, nullptr, cfg));
+#else
+  (void)grid; (void)stream_v;
+  dompc_hostemu_run(&A);
+#endif
+  return 0;
+}
+
+extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) {
+  if (!desc || !out) { g_create_error = "null argument"; return 1; }
+  dompc_handle* h = new dompc_handle();
+  h->d = *desc;
+  auto fail = [&](int) { g_create_error = h->error; dompc_destroy(h); *out = nullptr; return 1; };
+  const dompc_problem_desc& d = h->d;
+  if (d.n_edges <= 0 || d.n_nodes <= 0 || d.n_opt_x <= 0) { h->error = "empty problem description"; return fail(1); }
+  h->block = d.block_threads > 0 ? d.block_threads : 256;
+#ifndef DOMPC_HOST_EMU
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    h->error = "no HIP device available: the dompc IPM backend requires an AMD GPU (gfx950)";
+    return fail(1);
+  }
+  if (hipSetDevice(d.device) != hipSuccess) { h->error = "hipSetDevice failed"; return fail(1); }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->error = "hipStreamCreate failed"; return fail(1); }
+  if (!d.code_object_path) { h->error = "code_object_path is null"; return fail(1); }
+  h->code_path = d.code_object_path;
+  if (hipModuleLoad(&h->module, h->code_path.c_str()) != hipSuccess) {
+    h->error = "hipModuleLoad failed for " + h->code_path;
+    return fail(1);
+  }
+  if (hipModuleGetFunction(&h->fn_solve, h->module, "dompc_solve_kernel") != hipSuccess ||
+      hipModuleGetFunction(&h->fn_info, h->module, "dompc_model_info_kernel") != hipSuccess) {
+    h->error = "code object lacks dompc kernels: " + h->code_path;
+    return fail(1);
+  }
+#else
+  h->block = 1;
+#endif
+  h->e_pad = ((d.n_edges + 15) / 16) * 16;
+  // ---- model info from the code object
+  int32_t in_h[5] = {d.n_opt_x, d.n_g, d.n_edges, h->e_pad, d.n_nodes};
+  int64_t info[12] = {0};
+  char hash[64] = {0};
+#ifndef DOMPC_HOST_EMU
+  {
+    int32_t* in_d; int64_t* out_d; char* hash_d;
+    if (dev_alloc(h, (void**)&in_d, sizeof(in_h)) || dev_alloc(h, (void**)&out_d, sizeof(info)) ||
+        dev_alloc(h, (void**)&hash_d, sizeof(hash))) return fail(1);
+    if (h2d(h, in_d, in_h, sizeof(in_h))) return fail(1);
+    struct { const int32_t* a; int64_t* b; char* c; } args = {in_d, out_d, hash_d};
+    size_t sz = sizeof(args);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    if (hipModuleLaunchKernel(h->fn_info, 1, 1, 1, 64, 1, 1, 0, h->stream, nullptr, cfg) != hipSuccess) {
+      h->error = "launch of dompc_model_info_kernel failed"; return fail(1);
+    }
+    if (d2h(h, info, out_d, sizeof(info)) || d2h(h, hash, hash_d, sizeof(hash)) || dev_sync(h)) return fail(1);
+  }
+#else
+  dompc_hostemu_model_info(in_h, info, hash);
+#endif
+  const int64_t want[9] = {d.nx, d.nu, d.np, d.ntvp, d.ne, d.ns, d.M == 0 ? 0 : d.deg, d.M == 0 ? 1 : d.ni, d.M};
+  for (int i = 0; i < 9; ++i)
+    if (info[i] != want[i]) {
+      char buf[256];
+      snprintf(buf, sizeof(buf), "code object was built for different model dimensions (field %d: %lld vs %lld)", i,
+               (long long)info[i], (long long)want[i]);
+      h->error = buf;
+      return fail(1);
+    }
+  if (info[11] != (int64_t)sizeof(dompc::KArgs)) { h->error = "KArgs layout mismatch between runtime and code object"; return fail(1); }
+  if (d.model_hash && strncmp(d.model_hash, hash, 63) != 0) {
+    h->error = std::string("model hash mismatch: code object ") + hash + " vs description " + d.model_hash;
+    return fail(1);
+  }
+  h->ws_stride = info[9];
+  h->sweep_block = info[10];
+  // ---- slots
+  int max_batch = d.max_batch > 0 ? d.max_batch : 1;
+  h->n_slots = d.n_slots > 0 ? d.n_slots : (max_batch < 512 ? max_batch : 512);
+#ifdef DOMPC_HOST_EMU
+  h->n_slots = 1;
+#endif
+  // ---- tables
+  dompc::KArgs& A = h->base;
+  memset(&A, 0, sizeof(A));
+  int rc = 0;
+  rc |= upload(h, &A.level_node_start, d.level_node_start, d.N + 2);
+  rc |= upload(h, &A.node_level, d.node_level, d.n_nodes);
+  rc |= upload(h, &A.node_x_off, d.node_x_off, d.n_nodes);
+  rc |= upload(h, &A.node_u_off, d.node_u_off, d.n_nodes);
+  rc |= upload(h, &A.node_eps_off, d.node_eps_off, d.n_nodes);
+  rc |= upload(h, &A.node_child_start, d.node_child_start, d.n_nodes);
+  rc |= upload(h, &A.node_child_count, d.node_child_count, d.n_nodes);
+  rc |= upload(h, &A.node_parent, d.node_parent, d.n_nodes);
+  rc |= upload(h, &A.node_in_edge, d.node_in_edge, d.n_nodes);
+  rc |= upload(h, &A.edge_parent, d.edge_parent, d.n_edges);
+  rc |= upload(h, &A.edge_child, d.edge_child, d.n_edges);
+  rc |= upload(h, &A.edge_pidx, d.edge_pidx, d.n_edges);
+  rc |= upload(h, &A.edge_w_off, d.edge_w_off, d.n_edges);
+  rc |= upload(h, &A.edge_row0, d.edge_row0, d.n_edges);
+  rc |= upload(h, &A.edge_level, d.edge_level, d.n_edges);
+  rc |= upload(h, &A.edge_omega, d.edge_omega, d.n_edges);
+  rc |= upload(h, &A.dummy_idx, d.dummy_idx, d.n_dummy);
+  if (rc) return fail(1);
+  A.N = d.N; A.n_nodes = d.n_nodes; A.n_edges = d.n_edges; A.n_dummy = d.n_dummy;
+  A.n_opt_x = d.n_opt_x; A.n_opt_p = d.n_opt_p; A.n_g = d.n_g; A.e_pad = h->e_pad;
+  A.p_off_tvp = d.p_off_tvp; A.p_off_p = d.p_off_p; A.p_off_uprev = d.p_off_uprev;
+  A.opt = d.opts;
+  A.n_slots = h->n_slots;
+  A.ws_stride = h->ws_stride;
+  if (dev_alloc(h, (void**)&A.ws, sizeof(double) * (size_t)h->ws_stride * h->n_slots)) return fail(1);
+  if (dev_alloc(h, (void**)&A.work_counter, 64)) return fail(1);
+  for (int i = 0; i < 8; ++i)
+    if (dev_alloc(h, (void**)&h->s_dbg[i], sizeof(double) * (size_t)(d.n_opt_x > d.n_g ? d.n_opt_x : d.n_g))) return fail(1);
+  if (dev_sync(h)) return fail(1);
+  // the description's table pointers are not valid after return
+  h->d.level_node_start = nullptr;
+  *out = h;
+  return 0;
+}
+
+extern "C" int64_t dompc_workspace_bytes(const dompc_handle* h) { return h ? (int64_t)sizeof(double) * h->ws_stride * h->n_slots : 0; }
+extern "C" int32_t dompc_num_slots(const dompc_handle* h) { return h ? h->n_slots : 0; }
+extern "C" int64_t dompc_sweep_block_doubles(const dompc_handle* h) { return h ? h->sweep_block : 0; }
+
+extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double* x0, const double* lbx, const double* ubx,
+                                        const double* lbg, const double* ubg, const double* p, double* x, double* g,
+                                        double* lam_x, double* lam_g, double* f, dompc_stats* stats, void* stream) {
+  if (!h) return 1;
+  if (B <= 0) return 0;
+  if (!x0 || !lbx || !ubx || !lbg || !ubg || !p) { h->error = "null input pointer"; return 1; }
+#ifndef DOMPC_HOST_EMU
+  HIPCHK(h, hipSetDevice(h->d.device));
+#endif
+  dompc::KArgs A = h->base;
+  A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.lbg = lbg; A.ubg = ubg; A.p = p;
+  A.x_out = x; A.g_out = g; A.lam_x_out = lam_x; A.lam_g_out = lam_g; A.f_out = f; A.stats = stats;
+  A.batch = B; A.mode = 0;
+  const int grid = B < h->n_slots ? B : h->n_slots;
+  return launch(h, A, grid, stream);
+}
+
+extern "C" int dompc_solve_batch(dompc_handle* h, int32_t B, const double* x0, const double* lbx, const double* ubx,
+                                 const double* lbg, const double* ubg, const double* p, double* x, double* g,
+                                 double* lam_x, double* lam_g, double* f, dompc_stats* stats) {
+  if (!h) return 1;
+  if (B <= 0) return 0;
+  if (!x0 || !lbx || !ubx || !lbg || !ubg || !p) { h->error = "null input pointer"; return 1; }
+  auto t0 = std::chrono::steady_clock::now();
+#ifndef DOMPC_HOST_EMU
+  HIPCHK(h, hipSetDevice(h->d.device));
+#endif
+  const dompc_problem_desc& d = h->d;
+  if (ensure_staging(h, B)) return 1;
+  int rc = 0;
+  rc |= h2d(h, h->s_x0, x0, sizeof(double) * (size_t)B * d.n_opt_x);
+  rc |= h2d(h, h->s_p, p, sizeof(double) * (size_t)B * d.n_opt_p);
+  rc |= h2d(h, h->s_lbx, lbx, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_ubx, ubx, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_lbg, lbg, sizeof(double) * d.n_g);
+  rc |= h2d(h, h->s_ubg, ubg, sizeof(double) * d.n_g);
+  if (rc) return 1;
+  if (dompc_solve_batch_device(h, B, h->s_x0, h->s_lbx, h->s_ubx, h->s_lbg, h->s_ubg, h->s_p, h->s_x, h->s_g, h->s_lamx,
+                               h->s_lamg, h->s_f, h->s_stats, nullptr))
+    return 1;
+  if (x) rc |= d2h(h, x, h->s_x, sizeof(double) * (size_t)B * d.n_opt_x);
+  if (g) rc |= d2h(h, g, h->s_g, sizeof(double) * (size_t)B * d.n_g);
+  if (lam_x) rc |= d2h(h, lam_x, h->s_lamx, sizeof(double) * (size_t)B * d.n_opt_x);
+  if (lam_g) rc |= d2h(h, lam_g, h->s_lamg, sizeof(double) * (size_t)B * d.n_g);
+  if (f) rc |= d2h(h, f, h->s_f, sizeof(double) * (size_t)B);
+  if (stats) rc |= d2h(h, stats, h->s_stats, sizeof(dompc_stats) * (size_t)B);
+  if (rc || dev_sync(h)) return 1;
+  if (stats) {
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int b = 0; b < B; ++b) stats[b].t_wall_total = dt;
+  }
+  return 0;
+}
+
+extern "C" int dompc_solve(dompc_handle* h, const double* x0, const double* lbx, const double* ubx, const double* lbg,
+                           const double* ubg, const double* p, const double* /*lam_x0*/, const double* /*lam_g0*/,
+                           double* x, double* g, double* lam_x, double* lam_g, double* f, dompc_stats* stats) {
+  return dompc_solve_batch(h, 1, x0, lbx, ubx, lbg, ubg, p, x, g, lam_x, lam_g, f, stats);
+}
+
+extern "C" int dompc_sweep_batch_device(dompc_handle* h, int32_t B, const double* x, const double* lam, const double* p,
+                                        double* g, double* blocks, void* stream) {
+  if (!h) return 1;
+  if (B <= 0) return 0;
+  if (!x || !lam || !p || !g || !blocks) { h->error = "null pointer"; return 1; }
+#ifndef DOMPC_HOST_EMU
+  HIPCHK(h, hipSetDevice(h->d.device));
+#endif
+  dompc::KArgs A = h->base;
+  A.p = p; A.sw_x = x; A.sw_lam = lam; A.sw_g = g; A.sw_blocks = blocks;
+  A.batch = B; A.mode = 2;
+  const int grid = B < h->n_slots ? B : h->n_slots;
+  return launch(h, A, grid, stream);
+}
+
+extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const double* lam_g, const double* zl,
+                                       const double* zu, const double* lbx, const double* ubx, const double* lbg,
+                                       const double* ubg, const double* p, double mu, double delta_w, double* dx,
+                                       double* dlam, double* rd, double* c) {
+  if (!h) return 1;
+#ifndef DOMPC_HOST_EMU
+  HIPCHK(h, hipSetDevice(h->d.device));
+#endif
+  const dompc_problem_desc& d = h->d;
+  if (ensure_staging(h, 1)) return 1;
+  int rc = 0;
+  rc |= h2d(h, h->s_x0, x, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_p, p, sizeof(double) * d.n_opt_p);
+  rc |= h2d(h, h->s_lbx, lbx, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_ubx, ubx, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_lbg, lbg, sizeof(double) * d.n_g);
+  rc |= h2d(h, h->s_ubg, ubg, sizeof(double) * d.n_g);
+  rc |= h2d(h, h->s_dbg[0], lam_g, sizeof(double) * d.n_g);
+  rc |= h2d(h, h->s_dbg[1], zl, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_dbg[2], zu, sizeof(double) * d.n_opt_x);
+  if (rc) return 1;
+  dompc::KArgs A = h->base;
+  A.x0 = h->s_x0; A.lbx = h->s_lbx; A.ubx = h->s_ubx; A.lbg = h->s_lbg; A.ubg = h->s_ubg; A.p = h->s_p;
+  A.dbg_lam = h->s_dbg[0]; A.dbg_zl = h->s_dbg[1]; A.dbg_zu = h->s_dbg[2];
+  A.dbg_dx = h->s_dbg[3]; A.dbg_dlam = h->s_dbg[4]; A.dbg_rd = h->s_dbg[5]; A.dbg_c = h->s_dbg[6];
+  A.dbg_mu = mu; A.dbg_delta = delta_w;
+  A.batch = 1; A.mode = 1;
+  if (launch(h, A, 1, nullptr)) return 1;
+  if (dx) rc |= d2h(h, dx, h->s_dbg[3], sizeof(double) * d.n_opt_x);
+  if (dlam) rc |= d2h(h, dlam, h->s_dbg[4], sizeof(double) * d.n_g);
+  if (rd) rc |= d2h(h, rd, h->s_dbg[5], sizeof(double) * d.n_opt_x);
+  if (c) rc |= d2h(h, c, h->s_dbg[6], sizeof(double) * d.n_g);
+  if (rc || dev_sync(h)) return 1;
+  return 0;
+}

@@ -1,0 +1,53 @@
+"""Two oscillating masses, discrete-time linear MPC (BASELINE configs[0], the CPU-plumbing case).
+
+Equations / tuning: /root/reference/examples/oscillating_masses_discrete/template_model.py:34-73,
+template_mpc.py:34-74; test initial state /root/reference/testing/test_oscillating_masses_discrete.py:82-84.
+"""
+import numpy as np
+
+from .. import MPC, Model
+from ..sym import sum1
+
+A_D = np.array([[0.763, 0.460, 0.115, 0.020],
+                [-0.899, 0.763, 0.420, 0.115],
+                [0.115, 0.020, 0.763, 0.460],
+                [0.420, 0.115, -0.899, 0.763]])
+B_D = np.array([[0.014], [0.063], [0.221], [0.367]])
+
+
+def build_model(symvar_type="SX"):
+    mdl = Model("discrete", symvar_type)
+    x = mdl.set_variable(var_type="_x", var_name="x", shape=(4, 1))
+    u = mdl.set_variable(var_type="_u", var_name="u", shape=(1, 1))
+    mdl.set_expression(expr_name="cost", expr=sum1(x ** 2))
+    mdl.set_rhs("x", A_D @ x + B_D @ u)
+    mdl.setup()
+    return mdl
+
+
+def build_mpc(model, silence_solver=True, n_horizon=7, **overrides):
+    mpc = MPC(model)
+    st = mpc.settings
+    st.n_robust, st.n_horizon, st.t_step = 0, n_horizon, 0.5
+    st.store_full_solution = True
+    for k, v in overrides.items():
+        setattr(st, k, v)
+    if silence_solver:
+        st.supress_ipopt_output()
+    mpc.set_objective(mterm=model.aux["cost"], lterm=model.aux["cost"])
+    mpc.set_rterm(u=1e-4)
+    limit = np.array([[4.0], [10.0], [4.0], [10.0]])
+    mpc.bounds["lower", "_x", "x"] = -limit
+    mpc.bounds["upper", "_x", "x"] = limit
+    mpc.bounds["lower", "_u", "u"] = -0.5
+    mpc.bounds["upper", "_u", "u"] = 0.5
+    mpc.setup()
+    return mpc
+
+
+def _x0():
+    rng = np.random.RandomState(99)
+    return rng.rand(4) - 0.5
+
+
+X0 = _x0()

@@ -1,0 +1,170 @@
+"""Lower the model's expression DAG to device functions for the gfx950 IPM kernels.
+
+This takes the slot of CasADi's AD + VM on the hot path (nlp_f, nlp_g, nlp_grad_f,
+nlp_jac_g, nlp_hess_l inside `nlpsol`, /root/reference/do_mpc/controller/_mpc.py:1326-1328)
+and of the reference's own (broken) C-codegen route Optimizer.compile_nlp
+(/root/reference/do_mpc/optimizer.py:678-729): at MPC.setup() the rhs, stage cost,
+terminal cost and nonlinear constraints are differentiated symbolically *per collocation
+point / per stage* (never as one big NLP) and emitted as straight-line
+`__host__ __device__`-able C++ into one generated header that the kernel source includes.
+
+Everything is expressed in the reference's *scaled* variables
+(/root/reference/do_mpc/optimizer.py:804-818, _mpc.py:1152-1157): the generated
+`dompc_dyn` returns  h * rhs(x_s*sx, u_s*su, tvp, p) / sx  (h = t_step/ni; 1 for discrete
+models), so the collocation rows are  dyn(x_ij) - sum_r C[r,j] x_ir.
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+from . import sym
+
+
+def _bind(prefix: str, n: int):
+    syms = [sym.symbol(f"{prefix}{i}") for i in range(n)]
+    binds = {s.idx: f"{prefix}[{i}]" for i, s in enumerate(syms)}
+    return syms, binds
+
+
+def _fmt_array(name: str, vals: Sequence[float], ctype="double") -> str:
+    vals = list(np.asarray(vals).reshape(-1))
+    if not vals:
+        return f"DOMPC_CONST {ctype} {name}[1] = {{0}};"
+    body = ", ".join(sym._cfloat(float(v)) if ctype == "double" else str(int(v)) for v in vals)
+    return f"DOMPC_CONST {ctype} {name}[{len(vals)}] = {{{body}}};"
+
+
+def _sym_hessian_upper(L: sym.Node, v: List[sym.Node]):
+    """Upper triangle (i<=j) of d2L/dv2 as nodes; mirrored by the caller."""
+    g = sym.reverse_gradient(L, v)
+    J = sym.forward_jacobian(g, v)
+    return g, J
+
+
+def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, mterm, nl_exprs,
+                nl_slack_index, eps_penalty, sx, su, rterm, h_scale, deg, ni, discrete, C, D,
+                name="model") -> str:
+    """Return the text of the generated header.
+
+    x_sym/u_sym/tvp_sym/p_sym: lists of sym.Node (the model's own symbols, unscaled).
+    rhs: list[nx] of Node; lterm, mterm: Node; nl_exprs: list[ne] of Node (without the -eps part).
+    """
+    ne = len(nl_exprs)
+    ns = len(eps_penalty)
+    na = nx + nu
+    xs, bx = _bind("xs", nx)
+    us, bu = _bind("us", nu)
+    tv, bt = _bind("tvp", ntvp)
+    pp, bp = _bind("pp", np_)
+    lam, bl = _bind("lam", max(nx, ne, 1))
+    binds = {}
+    for b in (bx, bu, bt, bp, bl):
+        binds.update(b)
+    # unscaled model symbols -> scaled kernel symbols
+    mapping = {}
+    for i, s in enumerate(x_sym):
+        mapping[s.idx] = sym.mul(xs[i], sym.const(sx[i]))
+    for i, s in enumerate(u_sym):
+        mapping[s.idx] = sym.mul(us[i], sym.const(su[i]))
+    for i, s in enumerate(tvp_sym):
+        mapping[s.idx] = tv[i]
+    for i, s in enumerate(p_sym):
+        mapping[s.idx] = pp[i]
+
+    def scaled(nodes):
+        out = sym.substitute_nodes(list(nodes), mapping)
+        free = [s for s in sym.free_symbols(out) if s.idx not in binds]
+        if free:
+            raise Exception(f"expression depends on symbols outside (_x,_u,_tvp,_p): {free}")
+        return out
+
+    v = xs + us
+    f = [sym.mul(sym.div(e, sym.const(sx[i])), sym.const(h_scale)) for i, e in enumerate(scaled(rhs))]
+    Jf = sym.forward_jacobian(f, v)
+    Lf = sym.ZERO
+    for i in range(nx):
+        Lf = sym.add(Lf, sym.mul(lam[i], f[i]))
+    _, Hf = _sym_hessian_upper(Lf, v)
+
+    def emit_fn(sig: str, outs, zero_first=None) -> str:
+        body = sym.emit_c(outs, binds, indent="  ")
+        return f"DOMPC_FN {sig} {{\n{body}\n}}\n"
+
+    def hess_outs(H, n, name="H"):
+        outs = []
+        for i in range(n):
+            for j in range(n):
+                node = H[i][j] if i <= j else H[j][i]
+                outs.append((f"{name}[{i * n + j}]", node))
+        return outs
+
+    parts: List[str] = []
+    sig_dyn_args = "const double* xs, const double* us, const double* tvp, const double* pp"
+    outs = [(f"f[{i}]", f[i]) for i in range(nx)]
+    parts.append(emit_fn(f"void dompc_dyn_f({sig_dyn_args}, double* f)", outs))
+    outs = [(f"f[{i}]", f[i]) for i in range(nx)]
+    outs += [(f"J[{i * na + j}]", Jf[i][j]) for i in range(nx) for j in range(na)]
+    outs += hess_outs(Hf, na)
+    parts.append(emit_fn(f"void dompc_dyn({sig_dyn_args}, const double* lam, double* f, double* J, double* H)", outs))
+
+    # stage cost (unweighted; omega applied by the kernel)
+    lt = scaled([lterm])[0]
+    gl, Hl = _sym_hessian_upper(lt, v)
+    parts.append(emit_fn(f"double dompc_lterm_f({sig_dyn_args})", [("double val", lt)]).replace(
+        "\n}\n", "\n  return val;\n}\n"))
+    outs = [("val[0]", lt)] + [(f"g[{i}]", gl[i]) for i in range(na)] + hess_outs(Hl, na)
+    parts.append(emit_fn(f"void dompc_lterm({sig_dyn_args}, double* val, double* g, double* H)", outs))
+
+    mt = scaled([mterm])[0]
+    if sym.depends_on([mt], us):
+        raise Exception("mterm contains invalid symbolic variables as inputs. Must contain only: _x, _tvp, _p")
+    gm, Hm = _sym_hessian_upper(mt, xs)
+    sig_m = "const double* xs, const double* tvp, const double* pp"
+    parts.append(emit_fn(f"double dompc_mterm_f({sig_m})", [("double val", mt)]).replace(
+        "\n}\n", "\n  return val;\n}\n"))
+    outs = [("val[0]", mt)] + [(f"g[{i}]", gm[i]) for i in range(nx)] + hess_outs(Hm, nx)
+    parts.append(emit_fn(f"void dompc_mterm({sig_m}, double* val, double* g, double* H)", outs))
+
+    # nonlinear constraints (the "- eps" part is linear and handled by the kernel)
+    if ne:
+        d = scaled(nl_exprs)
+        Jd = sym.forward_jacobian(d, v)
+        Ld = sym.ZERO
+        for i in range(ne):
+            Ld = sym.add(Ld, sym.mul(lam[i], d[i]))
+        _, Hd = _sym_hessian_upper(Ld, v)
+        outs = [(f"d[{i}]", d[i]) for i in range(ne)]
+        parts.append(emit_fn(f"void dompc_nlcons_f({sig_dyn_args}, double* d)", outs))
+        outs = [(f"d[{i}]", d[i]) for i in range(ne)]
+        outs += [(f"Jd[{i * na + j}]", Jd[i][j]) for i in range(ne) for j in range(na)]
+        outs += hess_outs(Hd, na)
+        parts.append(emit_fn(f"void dompc_nlcons({sig_dyn_args}, const double* lam, double* d, double* Jd, double* H)", outs))
+    else:
+        parts.append(f"DOMPC_FN void dompc_nlcons_f({sig_dyn_args}, double* d) {{}}\n")
+        parts.append(f"DOMPC_FN void dompc_nlcons({sig_dyn_args}, const double* lam, double* d, double* Jd, double* H) {{}}\n")
+
+    M = 0 if discrete else (deg + 1) * ni
+    hdr = [
+        "// GENERATED by do_mpc_amd/lowering.py - do not edit.",
+        "#pragma once",
+        "#include <math.h>",
+        f"#define DOMPC_MODEL_NAME \"{name}\"",
+        f"#define DOMPC_NX {nx}", f"#define DOMPC_NU {nu}", f"#define DOMPC_NP {np_}",
+        f"#define DOMPC_NTVP {ntvp}", f"#define DOMPC_NE {ne}", f"#define DOMPC_NS {ns}",
+        f"#define DOMPC_DEG {deg if not discrete else 0}", f"#define DOMPC_NI {ni if not discrete else 1}",
+        f"#define DOMPC_M {M}", f"#define DOMPC_DISCRETE {1 if discrete else 0}",
+        _fmt_array("DOMPC_C", np.asarray(C).reshape(-1) if not discrete else [0.0]),
+        _fmt_array("DOMPC_D", D if not discrete else [0.0]),
+        _fmt_array("DOMPC_SX", sx),
+        _fmt_array("DOMPC_SU", su),
+        _fmt_array("DOMPC_RTERM", rterm),
+        _fmt_array("DOMPC_EPS_PEN", eps_penalty),
+        _fmt_array("DOMPC_NL_SLACK", nl_slack_index, "int"),
+        "",
+    ]
+    text = "\n".join(hdr) + "\n" + "\n".join(parts)
+    digest = hashlib.sha256(text.encode()).hexdigest()[:16]
+    return text + f"\n#define DOMPC_MODEL_HASH \"{digest}\"\n"

@@ -1,0 +1,258 @@
+"""ctypes binding of the C ABI (include/dompc_ipm.h) - the object stored in MPC.S.
+
+Drop-in for what `castools.nlpsol('S','ipopt',nlp,opts)` returns at
+/root/reference/do_mpc/controller/_mpc.py:1328: callable with keyword arguments
+x0, lbx, ubx, lbg, ubg, p (lam_x0, lam_g0 accepted and ignored, as IPOPT does with
+warm_start_init_point=no) returning {'x','f','g','lam_x','lam_g'}, plus .stats()
+(/root/reference/do_mpc/optimizer.py:754-778).
+
+There is no CPU fallback: constructing the solver without the HIP runtime / a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import build
+from .structure import ProblemStructure
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+class Options(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "tol", "dual_inf_tol", "constr_viol_tol", "compl_inf_tol", "acceptable_tol", "mu_init", "kappa_mu",
+        "theta_mu", "kappa_eps", "tau_min", "bound_push", "bound_frac", "bound_relax_factor",
+        "nlp_scaling_max_gradient", "delta_w_0", "delta_w_min", "delta_w_max", "kappa_w_minus", "kappa_w_plus",
+        "kappa_w_plus_bar")] + [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "obj_scaling", "reserved")]
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "nx", "nu", "np", "ntvp", "ne", "ns", "deg", "ni", "M", "N", "n_opt_x", "n_opt_p", "n_g", "n_nodes",
+        "n_edges", "n_dummy", "p_off_tvp", "p_off_p", "p_off_uprev")] + \
+        [(n, _i32p) for n in (
+            "level_node_start", "node_level", "node_x_off", "node_u_off", "node_eps_off", "node_child_start",
+            "node_child_count", "node_parent", "node_in_edge", "edge_parent", "edge_child", "edge_pidx",
+            "edge_w_off", "edge_row0", "edge_level")] + \
+        [("edge_omega", _f64p), ("dummy_idx", _i32p), ("code_object_path", C.c_char_p), ("model_hash", C.c_char_p),
+         ("device", C.c_int32), ("max_batch", C.c_int32), ("n_slots", C.c_int32), ("block_threads", C.c_int32),
+         ("opts", Options)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("success", "status", "iter_count", "n_reg", "n_ls_fail", "n_sweeps")] + \
+               [(n, C.c_double) for n in ("mu", "obj", "inf_pr", "inf_du", "inf_compl", "obj_scaling", "t_wall_total")]
+
+
+STATS_DTYPE = np.dtype([("success", "i4"), ("status", "i4"), ("iter_count", "i4"), ("n_reg", "i4"),
+                        ("n_ls_fail", "i4"), ("n_sweeps", "i4"), ("mu", "f8"), ("obj", "f8"), ("inf_pr", "f8"),
+                        ("inf_du", "f8"), ("inf_compl", "f8"), ("obj_scaling", "f8"), ("t_wall_total", "f8")])
+assert STATS_DTYPE.itemsize == C.sizeof(Stats)
+
+# ipopt option name -> field
+_IPOPT_OPTS = {
+    "ipopt.tol": "tol", "ipopt.dual_inf_tol": "dual_inf_tol", "ipopt.constr_viol_tol": "constr_viol_tol",
+    "ipopt.compl_inf_tol": "compl_inf_tol", "ipopt.acceptable_tol": "acceptable_tol", "ipopt.mu_init": "mu_init",
+    "ipopt.mu_linear_decrease_factor": "kappa_mu", "ipopt.mu_superlinear_decrease_power": "theta_mu",
+    "ipopt.barrier_tol_factor": "kappa_eps", "ipopt.tau_min": "tau_min", "ipopt.bound_push": "bound_push",
+    "ipopt.bound_frac": "bound_frac", "ipopt.bound_relax_factor": "bound_relax_factor",
+    "ipopt.nlp_scaling_max_gradient": "nlp_scaling_max_gradient", "ipopt.max_iter": "max_iter",
+    "ipopt.acceptable_iter": "acceptable_iter",
+    "ipopt.first_hessian_perturbation": "delta_w_0", "ipopt.min_hessian_perturbation": "delta_w_min",
+    "ipopt.max_hessian_perturbation": "delta_w_max",
+}
+
+
+def _load(lib_path: str) -> C.CDLL:
+    lib = C.CDLL(lib_path)
+    lib.dompc_default_options.argtypes = [C.POINTER(Options)]
+    lib.dompc_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]
+    lib.dompc_create.restype = C.c_int
+    lib.dompc_destroy.argtypes = [C.c_void_p]
+    lib.dompc_last_error.argtypes = [C.c_void_p]
+    lib.dompc_last_error.restype = C.c_char_p
+    lib.dompc_status_string.argtypes = [C.c_int32]
+    lib.dompc_status_string.restype = C.c_char_p
+    vp = C.c_void_p
+    lib.dompc_solve.argtypes = [vp] + [vp] * 8 + [vp] * 5 + [vp]
+    lib.dompc_solve.restype = C.c_int
+    lib.dompc_solve_batch.argtypes = [vp, C.c_int32] + [vp] * 6 + [vp] * 5 + [vp]
+    lib.dompc_solve_batch.restype = C.c_int
+    lib.dompc_solve_batch_device.argtypes = [vp, C.c_int32] + [vp] * 6 + [vp] * 5 + [vp, vp]
+    lib.dompc_solve_batch_device.restype = C.c_int
+    lib.dompc_sweep_batch_device.argtypes = [vp, C.c_int32] + [vp] * 5 + [vp]
+    lib.dompc_sweep_batch_device.restype = C.c_int
+    lib.dompc_sweep_block_doubles.argtypes = [vp]
+    lib.dompc_sweep_block_doubles.restype = C.c_int64
+    lib.dompc_debug_newton_step.argtypes = [vp] + [vp] * 9 + [C.c_double, C.c_double] + [vp] * 4
+    lib.dompc_debug_newton_step.restype = C.c_int
+    lib.dompc_workspace_bytes.argtypes = [vp]
+    lib.dompc_workspace_bytes.restype = C.c_int64
+    lib.dompc_num_slots.argtypes = [vp]
+    lib.dompc_num_slots.restype = C.c_int32
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, n=None) -> np.ndarray:
+    if hasattr(a, "master"):
+        a = a.master
+    elif hasattr(a, "arr"):
+        a = a.arr
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a
+
+
+class HipIpmSolver:
+    """One handle = one problem class on one GPU."""
+
+    def __init__(self, structure: ProblemStructure, header_text: str, model_hash: str,
+                 nlpsol_opts: Optional[dict] = None, device: int = 0, max_batch: int = 1, n_slots: int = 0,
+                 block_threads: int = 0, _lib_path: Optional[str] = None, _code_object: Optional[str] = None):
+        self.structure = ps = structure
+        self.model_hash = model_hash
+        if _lib_path is None:
+            _lib_path = build.runtime_library()
+            _code_object = build.model_code_object(header_text, model_hash)
+        self._lib = _load(_lib_path)
+        self._keep = []
+        d = ProblemDesc()
+        for k, v in dict(nx=ps.nx, nu=ps.nu, np=ps.np_, ntvp=ps.ntvp, ne=ps.ne, ns=ps.ns, deg=ps.deg, ni=ps.ni,
+                         M=ps.M, N=ps.N, n_opt_x=ps.n_opt_x, n_opt_p=ps.n_opt_p, n_g=ps.n_g, n_nodes=ps.n_nodes,
+                         n_edges=ps.n_edges, n_dummy=len(ps.tables["dummy_idx"]), p_off_tvp=ps.p_off_tvp,
+                         p_off_p=ps.p_off_p, p_off_uprev=ps.p_off_uprev).items():
+            setattr(d, k, int(v))
+        for name in ("level_node_start", "node_level", "node_x_off", "node_u_off", "node_eps_off",
+                     "node_child_start", "node_child_count", "node_parent", "node_in_edge", "edge_parent",
+                     "edge_child", "edge_pidx", "edge_w_off", "edge_row0", "edge_level", "dummy_idx"):
+            arr = np.ascontiguousarray(ps.tables[name], dtype=np.int32)
+            self._keep.append(arr)
+            setattr(d, name, arr.ctypes.data_as(_i32p))
+        om = np.ascontiguousarray(ps.tables["edge_omega"], dtype=np.float64)
+        self._keep.append(om)
+        d.edge_omega = om.ctypes.data_as(_f64p)
+        d.code_object_path = (_code_object or "").encode()
+        d.model_hash = model_hash.encode()
+        d.device, d.max_batch, d.n_slots, d.block_threads = device, max_batch, n_slots, block_threads
+        self._lib.dompc_default_options(C.byref(d.opts))
+        self.ignored_options = []
+        for k, v in (nlpsol_opts or {}).items():
+            f = _IPOPT_OPTS.get(k)
+            if f is not None:
+                setattr(d.opts, f, type(getattr(d.opts, f))(v))
+            elif k == "dompc.obj_scaling":
+                d.opts.obj_scaling = int(v)
+            else:
+                self.ignored_options.append(k)     # print levels, linear solver, ... : no meaning here
+        self.options = d.opts
+        h = C.c_void_p()
+        rc = self._lib.dompc_create(C.byref(d), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("dompc_create failed: " + (self._lib.dompc_last_error(None) or b"?").decode())
+        self._h = h
+        self._stats: Dict = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dompc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("dompc: " + (self._lib.dompc_last_error(self._h) or b"?").decode())
+
+    # ------------------------------------------------------------------ nlpsol-like call
+    def __call__(self, x0, lbx, ubx, lbg, ubg, p, lam_x0=None, lam_g0=None) -> dict:
+        ps = self.structure
+        x0, lbx, ubx = _f64(x0, ps.n_opt_x), _f64(lbx, ps.n_opt_x), _f64(ubx, ps.n_opt_x)
+        lbg, ubg, p = _f64(lbg, ps.n_g), _f64(ubg, ps.n_g), _f64(p, ps.n_opt_p)
+        x = np.empty(ps.n_opt_x)
+        g = np.empty(ps.n_g)
+        lam_x = np.empty(ps.n_opt_x)
+        lam_g = np.empty(ps.n_g)
+        f = np.empty(1)
+        st = np.zeros(1, dtype=STATS_DTYPE)
+        self._check(self._lib.dompc_solve(self._h, _ptr(x0), _ptr(lbx), _ptr(ubx), _ptr(lbg), _ptr(ubg), _ptr(p),
+                                          None, None, _ptr(x), _ptr(g), _ptr(lam_x), _ptr(lam_g), _ptr(f), _ptr(st)))
+        self._stats = self._stats_dict(st[0])
+        return {"x": x, "f": float(f[0]), "g": g, "lam_x": lam_x, "lam_g": lam_g, "lam_p": np.zeros(ps.n_opt_p)}
+
+    def _stats_dict(self, s) -> dict:
+        status = self._lib.dompc_status_string(int(s["status"])).decode()
+        return {"success": bool(s["success"]), "return_status": status, "iter_count": int(s["iter_count"]),
+                "t_wall_total": float(s["t_wall_total"]), "t_proc_total": float(s["t_wall_total"]),
+                "n_reg": int(s["n_reg"]), "n_ls_fail": int(s["n_ls_fail"]), "n_sweeps": int(s["n_sweeps"]),
+                "mu": float(s["mu"]), "obj": float(s["obj"]), "inf_pr": float(s["inf_pr"]),
+                "inf_du": float(s["inf_du"]), "obj_scaling": float(s["obj_scaling"]),
+                "unified_return_status": "SOLVER_RET_SUCCESS" if s["success"] else "SOLVER_RET_UNKNOWN"}
+
+    def stats(self) -> dict:
+        return dict(self._stats)
+
+    # ------------------------------------------------------------------ batch (host buffers)
+    def solve_batch(self, X0, lbx, ubx, lbg, ubg, P):
+        ps = self.structure
+        X0 = np.ascontiguousarray(X0, dtype=np.float64).reshape(-1, ps.n_opt_x)
+        P = np.ascontiguousarray(P, dtype=np.float64).reshape(-1, ps.n_opt_p)
+        B = X0.shape[0]
+        assert P.shape[0] == B
+        lbx, ubx, lbg, ubg = _f64(lbx, ps.n_opt_x), _f64(ubx, ps.n_opt_x), _f64(lbg, ps.n_g), _f64(ubg, ps.n_g)
+        X = np.empty((B, ps.n_opt_x))
+        G = np.empty((B, ps.n_g))
+        LX = np.empty((B, ps.n_opt_x))
+        LG = np.empty((B, ps.n_g))
+        F = np.empty(B)
+        st = np.zeros(B, dtype=STATS_DTYPE)
+        self._check(self._lib.dompc_solve_batch(self._h, B, _ptr(X0), _ptr(lbx), _ptr(ubx), _ptr(lbg), _ptr(ubg),
+                                                _ptr(P), _ptr(X), _ptr(G), _ptr(LX), _ptr(LG), _ptr(F), _ptr(st)))
+        return {"x": X, "f": F, "g": G, "lam_x": LX, "lam_g": LG, "stats": st}
+
+    # ------------------------------------------------------------------ batch (device pointers)
+    def solve_batch_device(self, B, x0, lbx, ubx, lbg, ubg, p, x, g, lam_x, lam_g, f, stats, stream=0):
+        """All arguments are raw device addresses (ints, e.g. torch tensor .data_ptr()); asynchronous."""
+        args = [C.c_void_p(int(a) if a else None) for a in (x0, lbx, ubx, lbg, ubg, p, x, g, lam_x, lam_g, f, stats)]
+        self._check(self._lib.dompc_solve_batch_device(self._h, int(B), *args, C.c_void_p(int(stream) if stream else None)))
+
+    def sweep_batch_device(self, B, x, lam, p, g, blocks, stream=0):
+        args = [C.c_void_p(int(a)) for a in (x, lam, p, g, blocks)]
+        self._check(self._lib.dompc_sweep_batch_device(self._h, int(B), *args, C.c_void_p(int(stream) if stream else None)))
+
+    @property
+    def sweep_block_doubles(self) -> int:
+        return int(self._lib.dompc_sweep_block_doubles(self._h))
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self._lib.dompc_workspace_bytes(self._h))
+
+    @property
+    def num_slots(self) -> int:
+        return int(self._lib.dompc_num_slots(self._h))
+
+    # ------------------------------------------------------------------ parity hook
+    def debug_newton_step(self, x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p, mu, delta_w=0.0):
+        ps = self.structure
+        a = [_f64(v) for v in (x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p)]
+        dx = np.empty(ps.n_opt_x)
+        dlam = np.empty(ps.n_g)
+        rd = np.empty(ps.n_opt_x)
+        c = np.empty(ps.n_g)
+        self._check(self._lib.dompc_debug_newton_step(self._h, *[_ptr(v) for v in a], float(mu), float(delta_w),
+                                                      _ptr(dx), _ptr(dlam), _ptr(rd), _ptr(c)))
+        return dx, dlam, rd, c

@@ -1,0 +1,247 @@
+"""Integer structure of the multi-stage NLP: scenario tree, variable/constraint layout.
+
+Mirrors (as tables instead of symbolic loops):
+  Optimizer._setup_scenario_tree   /root/reference/do_mpc/optimizer.py:998-1048
+  opt_x / opt_p ordering           /root/reference/do_mpc/controller/_mpc.py:1126-1134, 1160-1165
+  constraint ordering              /root/reference/do_mpc/controller/_mpc.py:1189-1245
+  collocation slot layout          /root/reference/do_mpc/optimizer.py:905-935
+The tables are what the HIP kernels index with; opt_x itself stays in the reference's
+canonical order ("stage-major": x[k][s][slot][state]) so vectors cross the C-ABI unchanged.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+
+
+def radau_points(deg: int) -> List[float]:
+    """Right Radau points on (0,1] (casadi.collocation_points(deg,'radau'))."""
+    if deg == 1:
+        return [1.0]
+    from numpy.polynomial import legendre as L
+    c = np.zeros(deg + 1)
+    c[deg], c[deg - 1] = 1.0, -1.0      # P_d - P_{d-1} vanishes at the right-Radau nodes (incl. +1)
+    r = np.sort(np.real(L.legroots(c)))
+    r[-1] = 1.0
+    return list((r + 1.0) / 2.0)
+
+
+def legendre_points(deg: int) -> List[float]:
+    from numpy.polynomial import legendre as L
+    c = np.zeros(deg + 1)
+    c[deg] = 1.0
+    return list((np.sort(np.real(L.legroots(c))) + 1.0) / 2.0)
+
+
+def lagrange_collocation(deg: int, kind: str):
+    """tau (deg+1), C[r,j] = L_r'(tau_j), D[r] = L_r(1) for the Lagrange basis on {0}+points
+    (/root/reference/do_mpc/optimizer.py:844-888).  Closed-form barycentric evaluation."""
+    if kind == "radau":
+        pts = radau_points(deg)
+    elif kind == "legendre":
+        pts = legendre_points(deg)
+    else:
+        raise Exception("Unknown collocation scheme")
+    tau = np.array([0.0] + pts)
+    n = deg + 1
+    C = np.zeros((n, n))
+    D = np.zeros(n)
+    for r in range(n):
+        others = [m for m in range(n) if m != r]
+        denom = np.prod([tau[r] - tau[m] for m in others])
+        D[r] = np.prod([1.0 - tau[m] for m in others]) / denom
+        for j in range(n):
+            acc = 0.0
+            for q in others:
+                acc += np.prod([tau[j] - tau[m] for m in others if m != q])
+            C[r, j] = acc / denom
+    return tau, C, D
+
+
+@dataclass
+class ProblemStructure:
+    nx: int
+    nu: int
+    nz: int
+    np_: int
+    ntvp: int
+    ne: int          # rows of nl_cons per edge
+    ns: int          # slack (eps) entries per (stage, scenario)
+    deg: int
+    ni: int
+    M: int           # stored collocation slots per interval (0: discrete)
+    N: int
+    S: int
+    n_comb: int
+    n_robust: int
+    n_eps: int
+    discrete: bool
+    tables: Dict[str, np.ndarray] = field(default_factory=dict)
+
+    # -- sizes
+    @property
+    def n_x_block(self):
+        return (self.N + 1) * self.S * (self.M + 1) * self.nx
+
+    @property
+    def off_z(self):
+        return self.n_x_block
+
+    @property
+    def n_z_block(self):
+        return self.N * self.S * max(self.M, 1) * self.nz
+
+    @property
+    def off_u(self):
+        return self.off_z + self.n_z_block
+
+    @property
+    def off_eps(self):
+        return self.off_u + self.N * self.S * self.nu
+
+    @property
+    def n_opt_x(self):
+        return self.off_eps + self.n_eps * self.S * self.ns
+
+    @property
+    def p_off_tvp(self):
+        return self.nx
+
+    @property
+    def p_off_p(self):
+        return self.nx + (self.N + 1) * self.ntvp
+
+    @property
+    def p_off_uprev(self):
+        return self.p_off_p + self.n_comb * self.np_
+
+    @property
+    def n_opt_p(self):
+        return self.p_off_uprev + self.nu
+
+    @property
+    def rows_per_edge(self):
+        return self.M * self.nx + self.nx + self.ne
+
+    @property
+    def n_g(self):
+        return self.nx + self.n_edges * self.rows_per_edge
+
+    @property
+    def n_edges(self):
+        return len(self.tables["edge_parent"])
+
+    @property
+    def n_nodes(self):
+        return len(self.tables["node_x_off"])
+
+    def ix(self, k, s, c):
+        return ((k * self.S + s) * (self.M + 1) + c) * self.nx
+
+    def iu(self, k, s):
+        return self.off_u + (k * self.S + s) * self.nu
+
+    def ieps(self, e, s):
+        return self.off_eps + (e * self.S + s) * self.ns
+
+
+def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust, discrete,
+                    open_loop=False, single_slack=False) -> ProblemStructure:
+    if n_robust > N:
+        raise Exception("n_robust must not exceed n_horizon")
+    S = n_comb ** n_robust
+    M = 0 if discrete else (deg + 1) * ni
+    n_eps = 1 if single_slack else N
+    ps = ProblemStructure(nx=nx, nu=nu, nz=nz, np_=np_, ntvp=ntvp, ne=ne, ns=ns, deg=deg, ni=ni, M=M, N=N, S=S,
+                          n_comb=n_comb, n_robust=n_robust, n_eps=n_eps, discrete=discrete)
+    if open_loop and S > 1:
+        raise NotImplementedError("structured HIP backend: open_loop=True couples all scenarios of a stage "
+                                  "(shared input) and is not tree-structured")
+    if single_slack and ns > 0 and N > 1:
+        raise NotImplementedError("structured HIP backend: nl_cons_single_slack couples all stages")
+    if nz > 0:
+        raise NotImplementedError("structured HIP backend: algebraic states (_z) are not lowered yet")
+
+    n_branches = [n_comb if k < n_robust else 1 for k in range(N)]
+    n_scen = [n_comb ** min(k, n_robust) for k in range(N + 1)]
+    level_start = np.zeros(N + 2, dtype=np.int32)
+    for k in range(N + 1):
+        level_start[k + 1] = level_start[k] + n_scen[k]
+    n_nodes = int(level_start[-1])
+
+    node_level = np.zeros(n_nodes, np.int32)
+    node_x_off = np.zeros(n_nodes, np.int32)
+    node_u_off = -np.ones(n_nodes, np.int32)
+    node_eps_off = -np.ones(n_nodes, np.int32)
+    node_child_start = np.zeros(n_nodes, np.int32)
+    node_child_count = np.zeros(n_nodes, np.int32)
+    node_parent = -np.ones(n_nodes, np.int32)
+    node_in_edge = -np.ones(n_nodes, np.int32)
+    e_parent, e_child, e_pidx, e_woff, e_row0, e_level, e_omega = [], [], [], [], [], [], []
+    parent_scenario = -np.ones((N + 1, S), dtype=int)
+    child_scenario = -np.ones((N, S, n_branches[0] if N else 1), dtype=int)
+    branch_offset = -np.ones((N, S), dtype=int)
+    structure_scenario = np.zeros((N + 1, S), dtype=int)
+    rpe = M * nx + nx + ne
+    for k in range(N + 1):
+        for s in range(n_scen[k]):
+            n = level_start[k] + s
+            node_level[n] = k
+            node_x_off[n] = ps.ix(k, s, M)
+            if k < N:
+                node_u_off[n] = ps.iu(k, s)
+                if ns:
+                    node_eps_off[n] = ps.ieps(min(k, n_eps - 1), s)
+    for k in range(N):
+        cnt = 0
+        for s in range(n_scen[k]):
+            n = level_start[k] + s
+            node_child_start[n] = len(e_parent)
+            node_child_count[n] = n_branches[k]
+            boff = 0 if (n_robust == 0 or k < n_robust) else s % n_branches[0]
+            branch_offset[k][s] = boff
+            for b in range(n_branches[k]):
+                c = cnt
+                cnt += 1
+                child_scenario[k][s][b] = c
+                structure_scenario[k][c] = s
+                structure_scenario[k + 1][c] = s
+                parent_scenario[k + 1][c] = s
+                cn = level_start[k + 1] + c
+                node_parent[cn] = n
+                node_in_edge[cn] = len(e_parent)
+                e_row0.append(nx + len(e_parent) * rpe)
+                e_parent.append(n)
+                e_child.append(cn)
+                e_pidx.append(b + boff)
+                e_woff.append(ps.ix(k + 1, c, 0))
+                e_level.append(k)
+                e_omega.append(1.0 / n_scen[k + 1])
+
+    ps.tables = dict(
+        level_node_start=level_start, node_level=node_level, node_x_off=node_x_off, node_u_off=node_u_off,
+        node_eps_off=node_eps_off, node_child_start=node_child_start, node_child_count=node_child_count,
+        node_parent=node_parent, node_in_edge=node_in_edge,
+        edge_parent=np.array(e_parent, np.int32), edge_child=np.array(e_child, np.int32),
+        edge_pidx=np.array(e_pidx, np.int32), edge_w_off=np.array(e_woff, np.int32),
+        edge_row0=np.array(e_row0, np.int32), edge_level=np.array(e_level, np.int32),
+        edge_omega=np.array(e_omega, np.float64),
+    )
+    # variables that appear in no constraint and no cost term
+    used = np.zeros(ps.n_opt_x, bool)
+    for n in range(n_nodes):
+        used[node_x_off[n]:node_x_off[n] + nx] = True
+        if node_u_off[n] >= 0:
+            used[node_u_off[n]:node_u_off[n] + nu] = True
+        if node_eps_off[n] >= 0:
+            used[node_eps_off[n]:node_eps_off[n] + ns] = True
+    for w in e_woff:
+        used[w:w + M * nx] = True
+    ps.tables["dummy_idx"] = np.where(~used)[0].astype(np.int32)
+    ps.scenario_tree = {
+        "structure_scenario": structure_scenario, "n_branches": n_branches, "n_scenarios": n_scen,
+        "parent_scenario": parent_scenario, "branch_offset": branch_offset, "child_scenario": child_scenario,
+    }
+    return ps

@@ -1,0 +1,168 @@
+/*
+ * dompc_ipm.h - C ABI of the MI355X-native structured interior-point backend that replaces
+ * the `nlpsol('ipopt', ...)` call on do-mpc's MPC.make_step() path.
+ *
+ * Reference interfaces replaced (paths relative to the do-mpc source tree):
+ *   do_mpc/controller/_mpc.py:1326-1328   self.S = castools.nlpsol('S', 'ipopt', nlp, opts)   -> dompc_create
+ *   do_mpc/optimizer.py:754-770           r = self.S(x0=, lbx=, ubx=, lbg=, ubg=, p=, ...)    -> dompc_solve
+ *   do_mpc/optimizer.py:772-778           r['x'], r['g'], r['lam_g'], r['lam_x'], S.stats()   -> outputs + dompc_stats
+ *   do_mpc/sampling/_sampler.py:198-228   one make_step per sample, fanned out by processes   -> dompc_solve_batch*
+ * The NLP itself is *not* passed as a symbolic graph: the model functions were lowered to a
+ * gfx950 code object at setup() (do_mpc_amd/lowering.py) and the multi-stage structure
+ * (do_mpc/optimizer.py:998-1048, do_mpc/controller/_mpc.py:1126-1245) is described by the
+ * integer tables below.
+ *
+ * Conventions
+ *   - all vectors are contiguous float64 in the reference's canonical order (opt_x, opt_p, g);
+ *   - multipliers follow CasADi's sign convention  L = f + lam_g'g + lam_x'x;
+ *   - return code 0 = ok, != 0 = infrastructure error (HIP, allocation, bad argument); the text is
+ *     available from dompc_last_error().  Solver non-convergence is NOT an error: it is reported
+ *     in dompc_stats.success / return_status, results are still written (matches optimizer.py:770-778);
+ *   - the caller owns every buffer it passes; the library owns device memory, streams and the loaded
+ *     code object inside the handle; a handle is not thread-safe, distinct handles are independent;
+ *   - create the handle after fork(): no HIP state is touched before dompc_create().
+ */
+#ifndef DOMPC_IPM_H
+#define DOMPC_IPM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dompc_handle dompc_handle;
+
+/* IPOPT-named algorithm options (defaults = IPOPT 3.14 defaults, see dompc_default_options). */
+typedef struct dompc_options {
+  double tol;                /* ipopt.tol                      1e-8  */
+  double dual_inf_tol;       /* ipopt.dual_inf_tol             1.0   */
+  double constr_viol_tol;    /* ipopt.constr_viol_tol          1e-4  */
+  double compl_inf_tol;      /* ipopt.compl_inf_tol            1e-4  */
+  double acceptable_tol;     /* ipopt.acceptable_tol           1e-6  */
+  double mu_init;            /* ipopt.mu_init                  0.1   */
+  double kappa_mu;           /* mu_linear_decrease_factor      0.2   */
+  double theta_mu;           /* mu_superlinear_decrease_power  1.5   */
+  double kappa_eps;          /* barrier_tol_factor             10    */
+  double tau_min;            /* ipopt.tau_min                  0.99  */
+  double bound_push;         /* ipopt.bound_push               0.01  */
+  double bound_frac;         /* ipopt.bound_frac               0.01  */
+  double bound_relax_factor; /* ipopt.bound_relax_factor       1e-8  */
+  double nlp_scaling_max_gradient; /*                          100   */
+  double delta_w_0;          /* first_hessian_perturbation     1e-4  */
+  double delta_w_min;        /* min_hessian_perturbation       1e-20 */
+  double delta_w_max;        /* max_hessian_perturbation       1e20  */
+  double kappa_w_minus;      /* perturb_dec_fact               1/3   */
+  double kappa_w_plus;       /* perturb_inc_fact               8     */
+  double kappa_w_plus_bar;   /* perturb_inc_fact_first         100   */
+  int32_t max_iter;          /* ipopt.max_iter                 3000  */
+  int32_t acceptable_iter;   /* ipopt.acceptable_iter          15    */
+  int32_t obj_scaling;       /* gradient-based objective scaling on/off (1) */
+  int32_t reserved;
+} dompc_options;
+
+/* Description of one multi-stage problem class (fixed at MPC.setup()). All pointers are host
+ * pointers and are copied by dompc_create(). */
+typedef struct dompc_problem_desc {
+  int32_t nx, nu, np, ntvp, ne, ns;     /* model dims; ne = nl_cons rows/edge, ns = slacks/(stage,scenario) */
+  int32_t deg, ni, M;                   /* collocation; M = ni*(deg+1) stored slots, 0 = discrete model     */
+  int32_t N;                            /* horizon                                                         */
+  int32_t n_opt_x, n_opt_p, n_g;        /* canonical vector sizes                                          */
+  int32_t n_nodes, n_edges, n_dummy;
+  int32_t p_off_tvp, p_off_p, p_off_uprev; /* offsets inside opt_p (= [_x0 ; _tvp ; _p ; _u_prev])       */
+  const int32_t* level_node_start;      /* [N+2]  nodes are ordered by (stage k, scenario s)               */
+  const int32_t* node_level;            /* [n_nodes]                                                       */
+  const int32_t* node_x_off;            /* [n_nodes] offset of _x[k,s,-1] in opt_x                          */
+  const int32_t* node_u_off;            /* [n_nodes] offset of _u[k,s]   (-1 at stage N)                    */
+  const int32_t* node_eps_off;          /* [n_nodes] offset of _eps[k,s] (-1 if none)                       */
+  const int32_t* node_child_start;      /* [n_nodes] first outgoing edge                                   */
+  const int32_t* node_child_count;      /* [n_nodes]                                                       */
+  const int32_t* node_parent;           /* [n_nodes] parent node (-1 root)                                 */
+  const int32_t* node_in_edge;          /* [n_nodes] incoming edge (-1 root)                                */
+  const int32_t* edge_parent;           /* [n_edges]                                                       */
+  const int32_t* edge_child;            /* [n_edges]                                                       */
+  const int32_t* edge_pidx;             /* [n_edges] row of opt_p['_p'] used on this edge                   */
+  const int32_t* edge_w_off;            /* [n_edges] offset of _x[k+1,c,0] (collocation slots of the edge)  */
+  const int32_t* edge_row0;             /* [n_edges] first constraint row of the edge in g                  */
+  const int32_t* edge_level;            /* [n_edges] stage k of the parent                                  */
+  const double*  edge_omega;            /* [n_edges] scenario weight 1/n_scenarios[k+1]                     */
+  const int32_t* dummy_idx;             /* [n_dummy] opt_x entries used by no constraint/cost               */
+  const char*    code_object_path;      /* gfx950 code object built from the lowered model                  */
+  const char*    model_hash;            /* must equal the hash embedded in the code object                  */
+  int32_t device;                       /* HIP device ordinal                                              */
+  int32_t max_batch;                    /* largest batch that will be passed to *_batch calls               */
+  int32_t n_slots;                      /* concurrent problem slots (workgroups); 0 = choose                */
+  int32_t block_threads;                /* threads per workgroup; 0 = default (256)                         */
+  dompc_options opts;
+} dompc_problem_desc;
+
+typedef struct dompc_stats {
+  int32_t success;          /* 1 = converged to tol (or acceptable level)                                  */
+  int32_t status;           /* 0 Solve_Succeeded, 1 Solved_To_Acceptable_Level, 2 Maximum_Iterations_Exceeded,
+                               3 Error_In_Step_Computation, 4 Invalid_Number_Detected                      */
+  int32_t iter_count;
+  int32_t n_reg;            /* iterations that needed Hessian regularisation                               */
+  int32_t n_ls_fail;        /* line searches that hit alpha_min (no restoration phase)                     */
+  int32_t n_sweeps;         /* model-evaluation sweeps executed (derivative + trial sweeps)                */
+  double  mu;
+  double  obj;              /* unscaled objective                                                          */
+  double  inf_pr, inf_du, inf_compl; /* scaled errors at exit                                                  */
+  double  obj_scaling;
+  double  t_wall_total;     /* filled by the host side: wall time of the call / batch                      */
+} dompc_stats;
+
+void dompc_default_options(dompc_options* opts);
+
+int  dompc_create(const dompc_problem_desc* desc, dompc_handle** out);
+void dompc_destroy(dompc_handle* h);
+const char* dompc_last_error(const dompc_handle* h);   /* h may be NULL: error of the last failed create */
+const char* dompc_status_string(int32_t status);
+
+/* One solve, host buffers (what Optimizer.solve does). lam_x0/lam_g0 may be NULL (they are ignored,
+ * like IPOPT with warm_start_init_point=no). Any output pointer may be NULL. */
+int dompc_solve(dompc_handle* h,
+                const double* x0, const double* lbx, const double* ubx,
+                const double* lbg, const double* ubg, const double* p,
+                const double* lam_x0, const double* lam_g0,
+                double* x, double* g, double* lam_x, double* lam_g, double* f,
+                dompc_stats* stats);
+
+/* B independent solves, host buffers.  x0 and p are [B][n]; bounds are shared by the batch. */
+int dompc_solve_batch(dompc_handle* h, int32_t B,
+                      const double* x0, const double* lbx, const double* ubx,
+                      const double* lbg, const double* ubg, const double* p,
+                      double* x, double* g, double* lam_x, double* lam_g, double* f,
+                      dompc_stats* stats);
+
+/* Same with DEVICE buffers (inputs already resident in HBM), asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = default stream).  stats is a device pointer [B]. */
+int dompc_solve_batch_device(dompc_handle* h, int32_t B,
+                             const double* x0, const double* lbx, const double* ubx,
+                             const double* lbg, const double* ubg, const double* p,
+                             double* x, double* g, double* lam_x, double* lam_g, double* f,
+                             dompc_stats* stats, void* stream);
+
+/* Model-evaluation sweep only (the "Jacobian sweep" of the IPM iteration): for B iterates evaluate
+ * g(x), and per edge the linearised dynamics [A|B], c and the condensed Lagrangian-Hessian block.
+ * DEVICE buffers: x [B][n_opt_x], lam [B][n_g], p [B][n_opt_p]; outputs g [B][n_g],
+ * blocks [B][n_edges][dompc_sweep_block_doubles()].  Used for roofline measurement and parity. */
+int dompc_sweep_batch_device(dompc_handle* h, int32_t B,
+                             const double* x, const double* lam, const double* p,
+                             double* g, double* blocks, void* stream);
+int64_t dompc_sweep_block_doubles(const dompc_handle* h);
+
+/* Debug/parity entry: one Newton direction at (x, lam_g, z_l, z_u, mu) exactly as given (no push,
+ * no scaling).  Host buffers.  dx [n_opt_x], dlam [n_g].  delta_w = primal regularisation to apply. */
+int dompc_debug_newton_step(dompc_handle* h,
+                            const double* x, const double* lam_g, const double* zl, const double* zu,
+                            const double* lbx, const double* ubx, const double* lbg, const double* ubg,
+                            const double* p, double mu, double delta_w,
+                            double* dx, double* dlam, double* rd, double* c);
+
+int64_t dompc_workspace_bytes(const dompc_handle* h);
+int32_t dompc_num_slots(const dompc_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOMPC_IPM_H */

@@ -38,6 +38,7 @@ DEFAULTS = dict(
     theta_max_fact=1e4, theta_min_fact=1e-4, gamma_alpha=0.05, max_soc=4, kappa_soc=0.99,
     delta_w_min=1e-20, delta_w_0=1e-4, delta_w_max=1e40, kappa_w_minus=1.0 / 3.0,
     kappa_w_plus=8.0, kappa_w_plus_bar=100.0, delta_c_bar=1e-8, kappa_c=0.25,
+    ls_mult_init=True,
     nlp_scaling_max_gradient=100.0, nlp_scaling_min_value=1e-8, obj_scaling=True, con_scaling=True,
 )
 
@@ -156,7 +157,7 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
             y = np.zeros(m)
         return y
 
-    y = ls_multipliers() if m else np.zeros(0)
+    y = ls_multipliers() if (m and o["ls_mult_init"]) else np.zeros(m)
     mu = o["mu_init"]
     tau = max(o["tau_min"], 1.0 - mu)
     # IPOPT's monotone update floors mu at min(tol, compl_inf_tol)/(barrier_tol_factor+1)
