@@ -27,6 +27,9 @@ struct KArgs {
   const double *dbg_lam, *dbg_zl, *dbg_zu;
   double dbg_mu, dbg_delta;
   double *dbg_dx, *dbg_dlam, *dbg_rd, *dbg_c;
+  // optional iteration trace of problem 0: 8 doubles per iteration (it, mu, E0, inf_pr, inf_du, alpha, delta_w, obj)
+  double* trace;
+  int32_t trace_cap, trace_pad;
   // sweep (mode 2)
   const double *sw_x, *sw_lam;
   double *sw_g, *sw_blocks;

@@ -65,7 +65,9 @@ constexpr int ES_RDN = ES_SIGS + NE;         // d - s
 constexpr int ES_RSN = ES_RDN + NE;          // -yd - mu/(s-sl) + mu/(su-s)
 constexpr int ES_TP = ES_RSN + NE;           // NA x NA : P_c * Atilde (y columns)
 constexpr int ES_TV = ES_TP + NA * NA;       // NA : P_c*ctilde + p_c
-constexpr int ES_OBJ = ES_TV + NA;
+constexpr int ES_ACL = ES_TV + NA;          // NA x NA : Atilde * [I;K] (closed-loop map)
+constexpr int ES_CCL = ES_ACL + NA * NA;     // NA : Atilde*[0;kv] + ctilde
+constexpr int ES_OBJ = ES_CCL + NA;
 constexpr int ES_SIZE = ES_OBJ + 1;
 
 // per node -------------------------------------------------------------------------------------
@@ -77,7 +79,9 @@ constexpr int ND_Q = ND_KV + NV;             // NYT x NYT
 constexpr int ND_QV = ND_Q + NYT * NYT;
 constexpr int ND_DXT = ND_QV + NYT;          // NA
 constexpr int ND_L = ND_DXT + NA;            // NV x NV
-constexpr int ND_SIZE = ND_L + NV * NV;
+constexpr int ND_QO = ND_L + NV * NV;        // NYT x NYT : node quadratic without the children's value functions
+constexpr int ND_QOV = ND_QO + NYT * NYT;
+constexpr int ND_SIZE = ND_QOV + NYT;
 
 struct WsLayout {
   int64_t x, zl, zu, lb, ub, dx, gf, rd, xt, dzl, dzu;
@@ -680,7 +684,7 @@ DOMPC_DEV inline int riccati_backward(const Thr& T, const Prob& Q, double mu, do
       const int yi = (i < NX) ? i : ((i >= NA && i < NA + NU) ? NX + (i - NA) : -1);   // y index or -1
       if (j < NYT) {
         const int yj2 = (j < NX) ? j : ((j >= NA && j < NA + NU) ? NX + (j - NA) : -1);
-        double v = 0.0;
+        double v = 0.0, vc = 0.0;
         if (i == j) {
           if (i < NX) v += sigma_of(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], Q.zl[xo + i], Q.zu[xo + i]) + delta;
           else if (i < NA) v += 2.0 * rw * DOMPC_RTERM[i - NX];
@@ -701,7 +705,7 @@ DOMPC_DEV inline int riccati_backward(const Thr& T, const Prob& Q, double mu, do
             double t = 0.0;
             for (int a = 0; a < NX; ++a) t += S_[ES_AB + a * NA + yi] * S_[ES_TP + a * NA + yj2];
             if (yi >= NX) t += S_[ES_TP + (NX + yi - NX) * NA + yj2];
-            v += t;
+            vc += t;
           }
           if (NE > 0) {
             for (int q = 0; q < NE; ++q) {
@@ -715,9 +719,10 @@ DOMPC_DEV inline int riccati_backward(const Thr& T, const Prob& Q, double mu, do
             }
           }
         }
-        Nd[ND_Q + i * NYT + j] = v;
+        Nd[ND_Q + i * NYT + j] = v + vc;
+        Nd[ND_QO + i * NYT + j] = v;
       } else {
-        double v = 0.0;
+        double v = 0.0, vc = 0.0;
         double tmp[NU];
         if (i < NX) {
           const int ie = A.node_in_edge[n];
@@ -743,7 +748,7 @@ DOMPC_DEV inline int riccati_backward(const Thr& T, const Prob& Q, double mu, do
             double t = 0.0;
             for (int a = 0; a < NX; ++a) t += S_[ES_AB + a * NA + yi] * S_[ES_TV + a];
             if (yi >= NX) t += S_[ES_TV + yi];
-            v += t;
+            vc += t;
           }
           if (NE > 0) {
             const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
@@ -756,7 +761,8 @@ DOMPC_DEV inline int riccati_backward(const Thr& T, const Prob& Q, double mu, do
             }
           }
         }
-        Nd[ND_QV + i] = v;
+        Nd[ND_QV + i] = v + vc;
+        Nd[ND_QOV + i] = v;
       }
     }
     T.sync();
@@ -803,18 +809,92 @@ DOMPC_DEV inline int riccati_backward(const Thr& T, const Prob& Q, double mu, do
       }
     }
     T.sync();
-    // (e) P = Qxx + Qxv K ; p = qx + Qxv kv
-    for (int it = T.tid; it < nn * NA * (NA + 1); it += T.nt) {
-      double* Nd = Q.ND(n0 + it / (NA * (NA + 1)));
+    // (e) value function in closed-loop ("Joseph") form.  P = Lc' Qown Lc + sum_e Acl' P_c Acl with
+    //     Lc = [I;K], Acl = Atilde*Lc:  the huge Sigma entries of active state bounds inside P_c are
+    //     multiplied by closed-loop maps that are ~0 in the constrained directions, instead of being
+    //     cancelled against each other as in Qxx - Qxv Qvv^-1 Qvx (which floors the KKT residual at
+    //     ~Sigma_max * eps).
+    // (e1) per child edge: Acl (NA x NA), ccl (NA)
+    for (int it = T.tid; it < ne_ * NA * (NA + 1); it += T.nt) {
+      const int e = e0 + it / (NA * (NA + 1));
       const int r = it % (NA * (NA + 1));
       const int i = r / (NA + 1), j = r % (NA + 1);
+      double* S_ = Q.ES(e);
+      const double* Nd = Q.ND(A.edge_parent[e]);
       if (j < NA) {
-        double t = Nd[ND_Q + i * NYT + j];
-        for (int q = 0; q < NV; ++q) t += Nd[ND_Q + i * NYT + NA + q] * Nd[ND_K + q * NA + j];
+        double t;
+        if (i < NX) {
+          t = (j < NX) ? S_[ES_AB + i * NA + j] : 0.0;
+          for (int u = 0; u < NU; ++u) t += S_[ES_AB + i * NA + NX + u] * Nd[ND_K + u * NA + j];
+        } else {
+          t = Nd[ND_K + (i - NX) * NA + j];
+        }
+        S_[ES_ACL + i * NA + j] = t;
+      } else {
+        double t;
+        if (i < NX) {
+          t = S_[ES_CV + i];
+          for (int u = 0; u < NU; ++u) t += S_[ES_AB + i * NA + NX + u] * Nd[ND_KV + u];
+        } else {
+          t = Nd[ND_KV + i - NX];
+        }
+        S_[ES_CCL + i] = t;
+      }
+    }
+    T.sync();
+    // (e2) per child edge: TP = P_c Acl, TV = P_c ccl + p_c
+    for (int it = T.tid; it < ne_ * NA * (NA + 1); it += T.nt) {
+      const int e = e0 + it / (NA * (NA + 1));
+      const int r = it % (NA * (NA + 1));
+      const int i = r / (NA + 1), j = r % (NA + 1);
+      double* S_ = Q.ES(e);
+      const double* Nc = Q.ND(A.edge_child[e]);
+      if (j < NA) {
+        double t = 0.0;
+        for (int a = 0; a < NA; ++a) t += Nc[ND_P + i * NA + a] * S_[ES_ACL + a * NA + j];
+        S_[ES_TP + i * NA + j] = t;
+      } else {
+        double t = Nc[ND_PV + i];
+        for (int a = 0; a < NA; ++a) t += Nc[ND_P + i * NA + a] * S_[ES_CCL + a];
+        S_[ES_TV + i] = t;
+      }
+    }
+    T.sync();
+    // (e3) per node: P, p
+    for (int it = T.tid; it < nn * NA * (NA + 1); it += T.nt) {
+      const int n = n0 + it / (NA * (NA + 1));
+      double* Nd = Q.ND(n);
+      const int r = it % (NA * (NA + 1));
+      const int i = r / (NA + 1), j = r % (NA + 1);
+      const int cs = A.node_child_start[n], cc = A.node_child_count[n];
+      // column i of Lc = [e_i ; K[:,i]]
+      if (j < NA) {
+        double t = Nd[ND_QO + i * NYT + j];
+        for (int q = 0; q < NV; ++q) {
+          t += Nd[ND_QO + i * NYT + NA + q] * Nd[ND_K + q * NA + j];
+          t += Nd[ND_K + q * NA + i] * Nd[ND_QO + (NA + q) * NYT + j];
+          double t2 = 0.0;
+          for (int w = 0; w < NV; ++w) t2 += Nd[ND_QO + (NA + q) * NYT + NA + w] * Nd[ND_K + w * NA + j];
+          t += Nd[ND_K + q * NA + i] * t2;
+        }
+        for (int c = 0; c < cc; ++c) {
+          const double* S_ = Q.ES(cs + c);
+          for (int a = 0; a < NA; ++a) t += S_[ES_ACL + a * NA + i] * S_[ES_TP + a * NA + j];
+        }
         Nd[ND_P + i * NA + j] = t;
       } else {
-        double t = Nd[ND_QV + i];
-        for (int q = 0; q < NV; ++q) t += Nd[ND_Q + i * NYT + NA + q] * Nd[ND_KV + q];
+        // p = Lc' (Qown l0 + qown) + sum Acl' (P_c ccl + p_c),  l0 = [0; kv]
+        double t = Nd[ND_QOV + i];
+        for (int w = 0; w < NV; ++w) t += Nd[ND_QO + i * NYT + NA + w] * Nd[ND_KV + w];
+        for (int q = 0; q < NV; ++q) {
+          double t2 = Nd[ND_QOV + NA + q];
+          for (int w = 0; w < NV; ++w) t2 += Nd[ND_QO + (NA + q) * NYT + NA + w] * Nd[ND_KV + w];
+          t += Nd[ND_K + q * NA + i] * t2;
+        }
+        for (int c = 0; c < cc; ++c) {
+          const double* S_ = Q.ES(cs + c);
+          for (int a = 0; a < NA; ++a) t += S_[ES_ACL + a * NA + i] * S_[ES_TV + a];
+        }
         Nd[ND_PV + i] = t;
       }
     }
@@ -1304,6 +1384,11 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       }
     }
     for (int r = T.tid; r < A.n_g; r += T.nt) Q.lam[r] += alpha * Q.dlam[r];
+    if (A.trace && b == 0 && T.tid == 0 && it < A.trace_cap) {
+      double* tr = A.trace + 8 * it;
+      tr[0] = it; tr[1] = mu; tr[2] = E0; tr[3] = E.e_p; tr[4] = E.e_d; tr[5] = accepted ? alpha : -alpha;
+      tr[6] = delta; tr[7] = E.obj / Q.sf;
+    }
     T.sync();
     ++it;
     bad = sweep(T, Q, mu);

@@ -39,6 +39,8 @@ struct dompc_handle {
   double *s_x = nullptr, *s_g = nullptr, *s_lamx = nullptr, *s_lamg = nullptr, *s_f = nullptr;
   dompc_stats* s_stats = nullptr;
   double *s_dbg[8] = {nullptr};
+  double* s_trace = nullptr;
+  int32_t trace_cap = 4096;
   int32_t cap_batch = 0;
 #ifndef DOMPC_HOST_EMU
   hipModule_t module = nullptr;
@@ -283,6 +285,8 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   if (dev_alloc(h, (void**)&A.work_counter, 64)) return fail(1);
   for (int i = 0; i < 8; ++i)
     if (dev_alloc(h, (void**)&h->s_dbg[i], sizeof(double) * (size_t)(d.n_opt_x > d.n_g ? d.n_opt_x : d.n_g))) return fail(1);
+  if (dev_alloc(h, (void**)&h->s_trace, sizeof(double) * 8 * h->trace_cap)) return fail(1);
+  A.trace = h->s_trace; A.trace_cap = h->trace_cap;
   if (dev_sync(h)) return fail(1);
   // the description's table pointers are not valid after return
   h->d.level_node_start = nullptr;
@@ -402,5 +406,14 @@ extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const d
   if (rd) rc |= d2h(h, rd, h->s_dbg[5], sizeof(double) * d.n_opt_x);
   if (c) rc |= d2h(h, c, h->s_dbg[6], sizeof(double) * d.n_g);
   if (rc || dev_sync(h)) return 1;
+  return 0;
+}
+
+// Iteration trace of problem 0 of the last solve call: rows of 8 doubles
+// (it, mu, E0, inf_pr, inf_du, +-alpha (negative = line search failed), delta_w, obj).
+extern "C" int dompc_debug_get_trace(dompc_handle* h, double* out, int32_t max_rows) {
+  if (!h || !out) return 1;
+  int rows = max_rows < h->trace_cap ? max_rows : h->trace_cap;
+  if (d2h(h, out, h->s_trace, sizeof(double) * 8 * (size_t)rows) || dev_sync(h)) return 1;
   return 0;
 }

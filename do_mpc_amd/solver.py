@@ -91,6 +91,8 @@ def _load(lib_path: str) -> C.CDLL:
     lib.dompc_sweep_block_doubles.restype = C.c_int64
     lib.dompc_debug_newton_step.argtypes = [vp] + [vp] * 9 + [C.c_double, C.c_double] + [vp] * 4
     lib.dompc_debug_newton_step.restype = C.c_int
+    lib.dompc_debug_get_trace.argtypes = [vp, vp, C.c_int32]
+    lib.dompc_debug_get_trace.restype = C.c_int
     lib.dompc_workspace_bytes.argtypes = [vp]
     lib.dompc_workspace_bytes.restype = C.c_int64
     lib.dompc_num_slots.argtypes = [vp]
@@ -244,6 +246,11 @@ class HipIpmSolver:
     @property
     def num_slots(self) -> int:
         return int(self._lib.dompc_num_slots(self._h))
+
+    def trace(self, n_rows: int) -> np.ndarray:
+        out = np.zeros((max(int(n_rows), 1), 8))
+        self._check(self._lib.dompc_debug_get_trace(self._h, _ptr(out), out.shape[0]))
+        return out[:n_rows]
 
     # ------------------------------------------------------------------ parity hook
     def debug_newton_step(self, x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p, mu, delta_w=0.0):

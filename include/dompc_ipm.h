@@ -159,6 +159,10 @@ int dompc_debug_newton_step(dompc_handle* h,
                             const double* p, double mu, double delta_w,
                             double* dx, double* dlam, double* rd, double* c);
 
+/* Iteration trace of problem 0 of the last solve: rows of 8 doubles (it, mu, E0, inf_pr, inf_du,
+ * +-alpha (negative: line search failed), delta_w, obj). */
+int dompc_debug_get_trace(dompc_handle* h, double* out, int32_t max_rows);
+
 int64_t dompc_workspace_bytes(const dompc_handle* h);
 int32_t dompc_num_slots(const dompc_handle* h);
 
