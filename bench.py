@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py - MPC steps/sec of the make_step hot path on MI355X.
+
+Workload (BASELINE.json configs[3]): industrial_poly robust multi-stage NMPC, 9 scenarios
+(shipped tree: 9 parameter combinations x n_robust=1, N=20, Radau deg 2; the golden-pinned
+variant).  One "step" = one batched make_step: B independent problems (synthetic x0 batch,
+cold-started from MPC.set_initial_guess semantics) solved by one launch of the persistent IPM
+kernel with every input already resident in HBM.  value = B * steps * n_gpus / time.
+
+Multi-GPU: the x0 batch shards across ranks with no data-path collective (weak scaling:
+B problems per GPU); the only collectives are the timing barrier and the max-over-ranks reduce.
+
+Extra fields: `roofline` for the dominant kernel (dompc_solve_kernel; HBM-bound model:
+algorithmic bytes of the derivative sweeps it executed / its HIP-event duration) and
+`cpu_baseline` (the CPU oracle, a port of the reference algorithm, timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synthetic_x0_batch(B: int, seed: int = 99) -> np.ndarray:
+    """x0_i around the example's initial state (seed 99): masses x (1 + 2% U(-1,1)),
+    temperatures +- 1 K U(-1,1) (a 2 % *relative* perturbation of Kelvin temperatures leaves the
+    +-2 K reactor band and makes the robust problem infeasible), T_adiab recomputed."""
+    from do_mpc_amd.examples import industrial_poly as ex
+    rng = np.random.default_rng(seed)
+    X0 = np.tile(ex.X0, (B, 1))
+    xi = rng.uniform(-1, 1, size=(B, 10))
+    X0[:, [0, 1, 2, 8]] *= (1 + 0.02 * xi[:, [0, 1, 2, 8]])
+    X0[:, 3:8] += xi[:, 3:8]
+    X0[:, 9] = X0[:, 1] * 950.0 / ((X0[:, 0] + X0[:, 1] + X0[:, 2]) * 5.0) + X0[:, 3]
+    return X0
+
+
+def shard(B_total: int, rank: int, world: int):
+    """contiguous shard [lo, hi) of a global batch"""
+    per = B_total // world
+    rem = B_total % world
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def sweep_bytes_per_problem(ps) -> int:
+    """Algorithmic bytes of one model-evaluation sweep of one problem (SURVEY.md 8(d) formula)."""
+    nx, nu, nz, np_, ntvp, ne = ps.nx, ps.nu, 0, ps.np_, ps.ntvp, ps.ne
+    M = ps.M
+    d = ps.ni * ps.deg if M else 1
+    n_v = nx + nz + nu
+    T = lambda n: n * (n + 1) // 2  # noqa: E731
+    n_eps_e = ps.ns
+    reads = (M + 2) * nx + M * nz + nu + n_eps_e + (M * (nx + nz) + nx + ne) + (np_ + ntvp)
+    writes = (M * (nx + nz) + nx + ne) + d * (nx + nz) * n_v + d * T(n_v) + T(nx + nu + n_eps_e) + (nx + nu + n_eps_e)
+    return 8 * (reads + writes) * ps.n_edges
+
+
+def cpu_baseline(sample: int = 2) -> dict:
+    """Oracle (numpy/scipy restatement of NLP + IPOPT algorithm) on the same workload, bounded sample."""
+    from oracle import ipm
+    from oracle.models import CASES
+    from oracle.nlp import OracleNLP
+    nlp = OracleNLP(CASES["industrial_poly"]())
+    X0 = synthetic_x0_batch(sample)
+    t0 = time.perf_counter()
+    n_ok = 0
+    for i in range(sample):
+        r = ipm.solve(nlp, nlp.initial_guess(X0[i]), nlp.opt_p(X0[i], np.zeros(nlp.nu)))
+        n_ok += int(r["stats"]["success"])
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "MPC steps/s", "cores": 1, "kind": "port",
+            "sample": f"{sample} cold make_step solves of the same workload (oracle/ipm.py, scipy sparse LU), "
+                      f"{n_ok}/{sample} converged, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DOMPC_BENCH_BATCH", "512")),
+                    help="problems per GPU per step")
+    ap.add_argument("--variant", default="A", choices=["A", "B"],
+                    help="A: shipped 9x1 tree (golden-pinned); B: 3 combinations, n_robust=2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the dompc IPM backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from do_mpc_amd.examples import industrial_poly as ex
+    from do_mpc_amd.solver import STATS_DTYPE
+    kw = {} if args.variant == "A" else {"n_robust": 2, "uncertainty": "paired"}
+    B = args.batch
+    mpc = ex.build_mpc(ex.build_model(), gpu_index=local_rank, max_batch=B, **kw)
+    ps = mpc.structure
+    S = mpc.S
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    lo, hi = shard(B * world, rank, world)
+    X0 = synthetic_x0_batch(B * world)[lo:hi]
+    P = np.tile(mpc.opt_p_num.master, (B, 1))
+    P[:, :ps.nx] = X0
+    P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(0.0).master
+    Xi = np.zeros((B, ps.n_opt_x))
+    Xi[:, :ps.off_u].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
+    dev = torch.device("cuda", local_rank)
+    tX0 = torch.from_numpy(Xi).to(dev)
+    tP = torch.from_numpy(P).to(dev)
+    tlbx = torch.from_numpy(mpc._lb_opt_x.master).to(dev)
+    tubx = torch.from_numpy(mpc._ub_opt_x.master).to(dev)
+    tlbg = torch.from_numpy(mpc._nlp_cons_lb).to(dev)
+    tubg = torch.from_numpy(mpc._nlp_cons_ub).to(dev)
+    tX = torch.empty((B, ps.n_opt_x), dtype=torch.float64, device=dev)
+    tLG = torch.empty((B, ps.n_g), dtype=torch.float64, device=dev)
+    tF = torch.empty(B, dtype=torch.float64, device=dev)
+    tStats = torch.zeros(B * STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        S.solve_batch_device(B, tX0.data_ptr(), tlbx.data_ptr(), tubx.data_ptr(), tlbg.data_ptr(), tubg.data_ptr(),
+                             tP.data_ptr(), tX.data_ptr(), 0, 0, tLG.data_ptr(), tF.data_ptr(), tStats.data_ptr(),
+                             stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    stats = np.frombuffer(tStats.cpu().numpy().tobytes(), dtype=STATS_DTYPE)
+    u0 = (tX[:, ps.iu(0, 0):ps.iu(0, 0) + ps.nu].cpu().numpy() * mpc._u_scaling.master)
+
+    if rank == 0:
+        n_ok = int(stats["success"].sum())
+        sweep_b = sweep_bytes_per_problem(ps)
+        alg_bytes = float(stats["n_sweeps"].astype(np.float64).sum()) * sweep_b
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("batch") == B and rec.get("variant") == args.variant:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MPC steps/sec (make_step wall-time), industrial_poly robust multi-stage",
+            "value": B * world * args.steps / dt, "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"industrial_poly robust multi-stage NMPC, variant {args.variant} "
+                                   f"({'9 combos x n_robust=1' if args.variant == 'A' else '3 combos x n_robust=2'}, "
+                                   f"9 scenarios, N=20, Radau deg 2)",
+                       "batch_per_gpu": B, "n_opt_x": ps.n_opt_x, "n_g": ps.n_g, "edges": ps.n_edges,
+                       "start": "cold (set_initial_guess semantics)", "parallelism": f"x0-batch shards x{world}"},
+            "solve": {"converged": n_ok, "of": B, "iters_mean": float(stats["iter_count"].mean()),
+                      "iters_max": int(stats["iter_count"].max()),
+                      "sweeps_per_solve": float(stats["n_sweeps"].mean()), "trials_per_solve": float(stats["n_trials"].mean()),
+                      "u0_first": [float(v) for v in u0[0]]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "dompc_solve_kernel",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "sweep_bytes_per_problem": sweep_b},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1106,7 +1106,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   Prob Q = make_prob(A, slot, A.p + (int64_t)b * A.n_opt_p);
   const double* x0 = A.x0 + (int64_t)b * A.n_opt_x;
   const int nX = A.n_opt_x, nSl = A.n_edges * NE;
-  int status = 2, it = 0, n_reg = 0, n_ls_fail = 0, n_sweeps = 0;
+  int status = 2, it = 0, n_reg = 0, n_ls_fail = 0, n_sweeps = 0, n_trials = 0;
 
   // ---- bounds (relaxed, bound_relax_factor), starting point pushed inside, z = 1
   double cnt[2] = {0.0, 0.0};
@@ -1316,7 +1316,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         const int ops[3] = {R_SUM, R_SUM, R_SUM};
         wg_reduce(T, r3, ops);
       }
-      ++n_sweeps;
+      ++n_trials;
       obj_t = r3[0]; th_t = r3[1];
       const double ph_t = obj_t + mu * r3[2];
       bool ok = (ph_t == ph_t) && (th_t == th_t) && fabs(ph_t) < INFINITY && th_t <= theta_max;
@@ -1416,7 +1416,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (A.stats) {
       dompc_stats& S = A.stats[b];
       S.success = (status == 0 || status == 1) ? 1 : 0;
-      S.status = status; S.iter_count = it; S.n_reg = n_reg; S.n_ls_fail = n_ls_fail; S.n_sweeps = n_sweeps;
+      S.status = status; S.iter_count = it; S.n_reg = n_reg; S.n_ls_fail = n_ls_fail; S.n_sweeps = n_sweeps; S.n_trials = n_trials; S.reserved = 0;
       S.mu = mu; S.obj = E.obj * isf; S.inf_pr = E.e_p; S.inf_du = E.e_d; S.inf_compl = E.e_c0;
       S.obj_scaling = Q.sf; S.t_wall_total = 0.0;
     }

@@ -45,12 +45,12 @@ class ProblemDesc(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("success", "status", "iter_count", "n_reg", "n_ls_fail", "n_sweeps")] + \
+    _fields_ = [(n, C.c_int32) for n in ("success", "status", "iter_count", "n_reg", "n_ls_fail", "n_sweeps", "n_trials", "reserved")] + \
                [(n, C.c_double) for n in ("mu", "obj", "inf_pr", "inf_du", "inf_compl", "obj_scaling", "t_wall_total")]
 
 
 STATS_DTYPE = np.dtype([("success", "i4"), ("status", "i4"), ("iter_count", "i4"), ("n_reg", "i4"),
-                        ("n_ls_fail", "i4"), ("n_sweeps", "i4"), ("mu", "f8"), ("obj", "f8"), ("inf_pr", "f8"),
+                        ("n_ls_fail", "i4"), ("n_sweeps", "i4"), ("n_trials", "i4"), ("reserved", "i4"), ("mu", "f8"), ("obj", "f8"), ("inf_pr", "f8"),
                         ("inf_du", "f8"), ("inf_compl", "f8"), ("obj_scaling", "f8"), ("t_wall_total", "f8")])
 assert STATS_DTYPE.itemsize == C.sizeof(Stats)
 
@@ -199,7 +199,7 @@ class HipIpmSolver:
         status = self._lib.dompc_status_string(int(s["status"])).decode()
         return {"success": bool(s["success"]), "return_status": status, "iter_count": int(s["iter_count"]),
                 "t_wall_total": float(s["t_wall_total"]), "t_proc_total": float(s["t_wall_total"]),
-                "n_reg": int(s["n_reg"]), "n_ls_fail": int(s["n_ls_fail"]), "n_sweeps": int(s["n_sweeps"]),
+                "n_reg": int(s["n_reg"]), "n_ls_fail": int(s["n_ls_fail"]), "n_sweeps": int(s["n_sweeps"]), "n_trials": int(s["n_trials"]),
                 "mu": float(s["mu"]), "obj": float(s["obj"]), "inf_pr": float(s["inf_pr"]),
                 "inf_du": float(s["inf_du"]), "obj_scaling": float(s["obj_scaling"]),
                 "unified_return_status": "SOLVER_RET_SUCCESS" if s["success"] else "SOLVER_RET_UNKNOWN"}

@@ -21,6 +21,8 @@ column-major flattening, `vertcat`/`horzcat`, elementwise `*`, `@` for matmul.
 from __future__ import annotations
 
 import math
+import struct
+import zlib
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -34,14 +36,15 @@ _BINARY = ("add", "sub", "mul", "div", "pow", "fmin", "fmax", "atan2")
 
 class Node:
     """One scalar operation.  Never construct directly: use the builders below."""
-    __slots__ = ("op", "a", "b", "val", "idx")
+    __slots__ = ("op", "a", "b", "val", "idx", "skey")
 
     def __init__(self, op, a, b, val, idx):
         self.op = op
         self.a = a
         self.b = b
         self.val = val
-        self.idx = idx
+        self.idx = idx          # identity (creation order, process-local)
+        self.skey = _skey(op, a, b, val)   # structural key: same expression -> same key in any process
 
     def is_const(self):
         return self.op == "const"
@@ -54,6 +57,30 @@ class Node:
         if self.b is None:
             return f"{self.op}({self.a!r})"
         return f"{self.op}({self.a!r},{self.b!r})"
+
+
+_M64 = (1 << 64) - 1
+
+
+def _skey(op, a, b, val) -> int:
+    """Deterministic structural hash; used to order commutative operands so that generated code
+    (and therefore the model hash / code-object cache key) does not depend on build history."""
+    if op == "const":
+        h = zlib.crc32(struct.pack("<d", val))
+    elif op == "sym":
+        h = zlib.crc32(str(val).encode())
+    else:
+        h = zlib.crc32(op.encode())
+    h = (h * 0x9E3779B97F4A7C15 + 0x7F4A7C15) & _M64
+    if a is not None:
+        h = ((h ^ a.skey) * 0x100000001B3 + 1) & _M64
+    if b is not None:
+        h = ((h ^ (b.skey * 3 + 7)) * 0x100000001B3 + 2) & _M64
+    return h
+
+
+def _before(a: "Node", b: "Node") -> bool:
+    return (a.skey, a.idx) <= (b.skey, b.idx)
 
 
 _TABLE: Dict[tuple, Node] = {}
@@ -131,7 +158,7 @@ def add(a: Node, b: Node) -> Node:
         return sub(a, b.a)
     if a.op == "neg":
         return sub(b, a.a)
-    if a.idx > b.idx:  # canonical order for commutative ops
+    if not _before(a, b):  # canonical order for commutative ops
         a, b = b, a
     return _mk("add", a, b)
 
@@ -171,7 +198,7 @@ def mul(a: Node, b: Node) -> Node:
         return neg(mul(a, b.a))
     if a is b:
         return unary("sq", a)
-    if a.idx > b.idx:
+    if not _before(a, b):
         a, b = b, a
     return _mk("mul", a, b)
 

@@ -103,7 +103,9 @@ typedef struct dompc_stats {
   int32_t iter_count;
   int32_t n_reg;            /* iterations that needed Hessian regularisation                               */
   int32_t n_ls_fail;        /* line searches that hit alpha_min (no restoration phase)                     */
-  int32_t n_sweeps;         /* model-evaluation sweeps executed (derivative + trial sweeps)                */
+  int32_t n_sweeps;         /* derivative sweeps executed (model evaluation + condensing of every edge)        */
+  int32_t n_trials;         /* function-only trial sweeps of the line search                                 */
+  int32_t reserved;
   double  mu;
   double  obj;              /* unscaled objective                                                          */
   double  inf_pr, inf_du, inf_compl; /* scaled errors at exit                                                  */

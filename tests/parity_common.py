@@ -1,0 +1,180 @@
+"""Parity checks shared by the host-emulation (CPU CI) and the real HIP (-m gpu) test modules.
+
+Every check compares the product path (do_mpc_amd -> C ABI -> kernels) with the CPU oracle
+(oracle/) and/or the reference's golden vectors (tests/golden/*.npz).  Stated tolerances:
+  U_RTOL  = 1e-6   first input u0 vs golden / oracle, relative to max(1,|u|)   (see test_oracle_golden.py)
+  X_RTOL  = 1e-5   full primal solution vs golden (dummy variables excluded)
+  STEP_TOL= 1e-6   Newton direction vs the oracle's sparse KKT solve, relative to max|dx|
+"""
+import os
+
+import numpy as np
+import scipy.sparse as sps
+import scipy.sparse.linalg as spla
+
+from do_mpc_amd.examples import CASES
+from oracle import ipm
+from oracle.models import CASES as ORACLE_CASES
+from oracle.nlp import OracleNLP
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+U_RTOL, X_RTOL, STEP_TOL = 1e-6, 1e-5, 1e-6
+
+_oracle_cache = {}
+
+
+def oracle_nlp(name, **over):
+    key = (name, tuple(sorted(over.items())))
+    if key not in _oracle_cache:
+        _oracle_cache[key] = OracleNLP(ORACLE_CASES[name](**over))
+    return _oracle_cache[key]
+
+
+def golden(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def check_golden_replay(make_mpc, name, steps):
+    """Open-loop replay of the reference's closed-loop test (testing/test_<case>.py): feed golden x[k],
+    u_prev = golden u[k-1], warm start from the previous solution; compare u0, the full primal solution
+    and the constraint multipliers with the goldens."""
+    ex = CASES[name]
+    mpc = make_mpc(name)
+    mpc.x0 = ex.X0
+    mpc.set_initial_guess()
+    g = golden(name)
+    U, Xs, OX, LG = g["mpc._u"], g["mpc._x"], g["mpc._opt_x_num"], g["mpc._lam_g_num"]
+    used = np.ones(mpc.structure.n_opt_x, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    for k in range(steps):
+        u0 = mpc.make_step(Xs[k]).ravel()
+        st = mpc.solver_stats
+        assert st["success"], st
+        assert relerr(u0, U[k]) < U_RTOL, (name, k, u0, U[k])
+        assert relerr(mpc.opt_x_num_unscaled.master[used], OX[k][used]) < X_RTOL
+        assert np.max(np.abs(mpc.lam_g_num - LG[k])) < 1e-2 * max(1.0, np.max(np.abs(LG[k])))
+        assert np.allclose(mpc.opt_p_num.master, g["mpc.opt_p_num"][k], rtol=0, atol=1e-12)
+        mpc.u0 = U[k]
+    # stored records have the reference's shapes
+    assert mpc.data["_u"].shape == (steps, mpc.model.n_u)
+    assert mpc.data["_aux"].shape[1] == g["mpc._aux"].shape[1]
+    if g["mpc._aux"].shape[1] > 1:
+        assert np.allclose(mpc.data["_aux"][:steps], g["mpc._aux"][:steps], rtol=1e-6, atol=1e-8)
+    return mpc
+
+
+def check_against_oracle_solve(make_mpc, name, x0_scale=1.0, **over):
+    """Cold solve from the documented initial guess; compare with the oracle's solve of the same NLP."""
+    ex = CASES[name]
+    mpc = make_mpc(name, **over)
+    o_over = {k: v for k, v in over.items() if k in ("n_horizon", "n_robust", "collocation_deg", "collocation_ni")}
+    nlp = oracle_nlp(name, **o_over)
+    assert (nlp.n_opt_x, nlp.n_g) == (mpc.structure.n_opt_x, mpc.structure.n_g)
+    x0 = ex.X0 * x0_scale
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    u0 = mpc.make_step(x0).ravel()
+    assert mpc.solver_stats["success"], mpc.solver_stats
+    r = ipm.solve(nlp, nlp.initial_guess(x0), nlp.opt_p(x0, np.zeros(nlp.nu)))
+    assert r["stats"]["success"]
+    assert relerr(u0, nlp.u0_of(r["x"])) < U_RTOL, (u0, nlp.u0_of(r["x"]))
+    # solution is a KKT point of the oracle's NLP: feasibility and stationarity with OUR multipliers
+    x = mpc.opt_x_num.master
+    p = mpc.opt_p_num.master
+    gv = nlp.g(x, p)
+    eq = nlp.lbg == nlp.ubg
+    assert np.max(np.abs(gv[eq])) < 1e-7
+    rd = nlp.grad(x, p) + nlp.jac(x, p).T @ mpc.lam_g_num + mpc.lam_x_num
+    assert np.max(np.abs(rd)) < 1e-5 * max(1.0, np.max(np.abs(mpc.lam_g_num)))
+    return mpc
+
+
+def check_newton_step(make_mpc, name, oracle_iters=6):
+    """One Newton direction of the structured solve (condensing + tree Riccati) against a general sparse
+    LU of the same KKT system, at an interior iterate produced by the oracle."""
+    ex = CASES[name]
+    mpc = make_mpc(name)
+    nlp = oracle_nlp(name)
+    assert nlp.ne == 0, "equality-constrained cases only"
+    p = nlp.opt_p(ex.X0, np.zeros(nlp.nu))
+    r = ipm.solve(nlp, nlp.initial_guess(ex.X0), p, opts=dict(max_iter=oracle_iters))
+    x, lam, mu = r["x"], r["lam_g"] * r["stats"]["obj_scaling"], r["stats"]["mu"]
+    lb, ub = nlp.lbx.copy(), nlp.ubx.copy()
+    hl, hu = np.isfinite(lb), np.isfinite(ub)
+    lb[hl] -= 1e-8 * np.maximum(1, np.abs(lb[hl]))
+    ub[hu] += 1e-8 * np.maximum(1, np.abs(ub[hu]))
+    dl, du = np.where(hl, x - lb, 1.0), np.where(hu, ub - x, 1.0)
+    assert dl.min() > 0 and du.min() > 0
+    zl, zu = np.where(hl, mu / dl, 0.0), np.where(hu, mu / du, 0.0)
+    dx, dlam, rd, c = mpc.S.debug_newton_step(x, lam, zl, zu, lb, ub, nlp.lbg, nlp.ubg, p, mu, 0.0)
+    W, A, gf, cv = nlp.hess(x, p, 1.0, lam), nlp.jac(x, p), nlp.grad(x, p), nlp.g(x, p) - nlp.lbg
+    assert np.max(np.abs(c - cv)) < 1e-10 * max(1.0, np.max(np.abs(cv)))
+    assert np.max(np.abs(rd - (gf + A.T @ lam - zl + zu))) < 1e-9 * max(1.0, np.max(np.abs(rd)))
+    sig = zl / dl * hl + zu / du * hu
+    rx = gf + A.T @ lam - np.where(hl, mu / dl, 0.0) + np.where(hu, mu / du, 0.0)
+    dummy = np.asarray(mpc.structure.tables["dummy_idx"])
+    pin = np.zeros(x.size)
+    pin[dummy] = (sig[dummy] == 0)
+    K = sps.bmat([[W + sps.diags(sig + pin), A.T], [A, None]], format="csc")
+    rhs = -np.concatenate([rx, cv])
+    lu = spla.splu(K)
+    sol = lu.solve(rhs)
+    for _ in range(3):
+        sol += lu.solve(rhs - K @ sol)
+    dxo, dlo = sol[:x.size], sol[x.size:]
+    assert np.max(np.abs(dx - dxo)) < STEP_TOL * max(1e-12, np.max(np.abs(dxo))), np.max(np.abs(dx - dxo)) / np.max(np.abs(dxo))
+    res = K @ np.concatenate([dx, dlam]) - rhs
+    assert np.max(np.abs(res)) < 1e-7 * max(1.0, np.max(np.abs(rhs)))
+
+
+def check_sweep_blocks(mpc, name, to_dev, from_dev, B=3, seed=1):
+    """Sweep kernel: g(x) and the per-edge linearised dynamics [A|B], c against the oracle's g and
+    sparse Jacobian (A = -S G_w^-1 G_x computed densely per edge from the oracle's rows)."""
+    ps = mpc.structure
+    nlp = oracle_nlp(name)
+    g = golden(name)
+    rng = np.random.default_rng(seed)
+    s = nlp.scaling_vector()
+    X = np.stack([g["mpc._opt_x_num"][k % 5] / s * (1 + 1e-3 * rng.standard_normal(ps.n_opt_x)) for k in range(B)])
+    LAM = np.stack([g["mpc._lam_g_num"][k % 5] for k in range(B)])
+    P = np.stack([g["mpc.opt_p_num"][k % 5] for k in range(B)])
+    blk = mpc.S.sweep_block_doubles
+    dX, dL, dP = to_dev(X), to_dev(LAM), to_dev(P)
+    dG, dB = to_dev(np.zeros((B, ps.n_g))), to_dev(np.zeros((B, ps.n_edges, blk)))
+    mpc.S.sweep_batch_device(B, dX.ptr, dL.ptr, dP.ptr, dG.ptr, dB.ptr)
+    G, BL = from_dev(dG), from_dev(dB)
+    nx, nu, M = ps.nx, ps.nu, ps.M
+    na = nx + nu
+    for b in range(B):
+        gv = nlp.g(X[b], P[b])
+        assert np.max(np.abs(G[b] - gv)) < 1e-10 * max(1.0, np.max(np.abs(gv)))
+        J = nlp.jac(X[b], P[b]).tocsr()
+        for e in (0, ps.n_edges // 2, ps.n_edges - 1):
+            row0 = ps.tables["edge_row0"][e]
+            n = ps.tables["edge_parent"][e]
+            xo, uo, wo = ps.tables["node_x_off"][n], ps.tables["node_u_off"][n], ps.tables["edge_w_off"][e]
+            AB = BL[b, e, :nx * na].reshape(nx, na)
+            cvec = BL[b, e, nx * na:nx * na + nx]
+            ycols = list(range(xo, xo + nx)) + list(range(uo, uo + nu))
+            if M == 0:
+                Jy = J[row0:row0 + nx][:, ycols].toarray()
+                assert np.allclose(AB, Jy, atol=1e-12)
+                assert np.allclose(cvec, gv[row0:row0 + nx], atol=1e-12)
+            else:
+                nw = M * nx
+                Gw = J[row0:row0 + nw][:, wo:wo + nw].toarray()
+                Gy = J[row0:row0 + nw][:, ycols].toarray()
+                W = -np.linalg.solve(Gw, Gy)
+                w0 = -np.linalg.solve(Gw, gv[row0:row0 + nw])
+                assert np.allclose(AB, W[-nx:], rtol=1e-8, atol=1e-10)
+                assert np.allclose(cvec, w0[-nx:] + gv[row0 + nw:row0 + nw + nx], rtol=1e-8, atol=1e-10)
+
+
+class HostArr:
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a, dtype=np.float64)
+        self.ptr = self.a.ctypes.data

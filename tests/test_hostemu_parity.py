@@ -1,0 +1,85 @@
+"""IPM logic on the TEST-ONLY host emulation of the device code (tests/hostemu.py): the same kernel
+text as the gfx950 code object, one workgroup = one host thread.  Runs in the GPU-less CI container;
+the -m gpu twin of this module (test_gpu_parity.py) runs the real HIP path."""
+import numpy as np
+import pytest
+
+import hostemu
+import parity_common as pc
+from do_mpc_amd.examples import CASES
+
+
+def make_mpc(name, **kw):
+    ex = CASES[name]
+    with hostemu.patched():
+        return ex.build_mpc(ex.build_model(), **kw)
+
+
+@pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 3), ("industrial_poly", 2)])
+def test_golden_replay(name, steps):
+    pc.check_golden_replay(make_mpc, name, steps)
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly"])
+def test_newton_direction_matches_sparse_kkt_solve(name):
+    pc.check_newton_step(make_mpc, name)
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly"])
+def test_sweep_blocks_match_oracle_jacobian(name):
+    mpc = make_mpc(name)
+    pc.check_sweep_blocks(mpc, name, pc.HostArr, lambda d: d.a)
+
+
+def test_baseline_config_cstr_nominal_deg3_vs_oracle():
+    # BASELINE.json configs[1]: CSTR nominal NMPC, N=20, collocation deg 3 (no fixture -> oracle)
+    pc.check_against_oracle_solve(make_mpc, "CSTR", n_robust=0, collocation_deg=3)
+
+
+def test_baseline_config_batch_reactor_n50_vs_oracle():
+    # BASELINE.json configs[2]: batch_reactor economic NMPC, N=50
+    pc.check_against_oracle_solve(make_mpc, "batch_reactor", n_horizon=50)
+
+
+def test_batch_api_equals_single_solves():
+    mpc = make_mpc("batch_reactor", max_batch=4)
+    ex = CASES["batch_reactor"]
+    rng = np.random.default_rng(5)
+    X0 = ex.X0 * (1 + 0.05 * rng.uniform(-1, 1, size=(4, 4)))
+    r = mpc.make_step_batch(X0)
+    assert r["stats"]["success"].all()
+    for i in range(4):
+        m1 = make_mpc("batch_reactor")
+        m1.x0 = X0[i]
+        m1.set_initial_guess()
+        u = m1.make_step(X0[i]).ravel()
+        assert np.allclose(r["u0"][i], u, rtol=1e-12, atol=1e-14)
+
+
+def test_empty_batch_and_bad_arguments():
+    mpc = make_mpc("oscillating_masses")
+    ps = mpc.structure
+    out = mpc.S.solve_batch(np.zeros((0, ps.n_opt_x)), mpc._lb_opt_x.master, mpc._ub_opt_x.master,
+                            mpc._nlp_cons_lb, mpc._nlp_cons_ub, np.zeros((0, ps.n_opt_p)))
+    assert out["x"].shape == (0, ps.n_opt_x)
+    with pytest.raises(ValueError):
+        mpc.S(x0=np.zeros(3), lbx=mpc._lb_opt_x.master, ubx=mpc._ub_opt_x.master, lbg=mpc._nlp_cons_lb,
+              ubg=mpc._nlp_cons_ub, p=mpc.opt_p_num.master)
+    with pytest.raises(AssertionError):
+        mpc.make_step(np.zeros(7))
+
+
+def test_infeasible_problem_reports_failure_not_exception():
+    # x0 far outside the +-2 K reactor band: no feasible robust trajectory.  The reference records
+    # success=False and carries on (optimizer.py:770-778); so do we.
+    mpc = make_mpc("industrial_poly", **{"nlpsol_opts": {"ipopt.max_iter": 60}})
+    ex = CASES["industrial_poly"]
+    x0 = ex.X0.copy()
+    x0[3] += 25.0
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    u0 = mpc.make_step(x0)
+    assert u0.shape == (3, 1)
+    assert mpc.solver_stats["success"] is False
+    assert mpc.solver_stats["return_status"] in ("Maximum_Iterations_Exceeded", "Error_In_Step_Computation",
+                                                 "Invalid_Number_Detected")

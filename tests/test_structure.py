@@ -1,0 +1,60 @@
+"""Integer structure (tree, layouts) and collocation coefficients against the reference's sizes / the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from do_mpc_amd.structure import build_structure, lagrange_collocation
+from oracle.nlp import collocation_coeffs
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("deg,kind", [(1, "radau"), (2, "radau"), (3, "radau"), (4, "radau"), (2, "legendre"), (3, "legendre")])
+def test_collocation_coefficients_agree_with_oracle(deg, kind):
+    tau, C, D = lagrange_collocation(deg, kind)
+    tau_o, C_o, D_o = collocation_coeffs(deg, kind)
+    assert np.allclose(tau, tau_o, atol=1e-13)
+    assert np.allclose(C, C_o, atol=1e-10)
+    assert np.allclose(D, D_o, atol=1e-12)
+
+
+def test_industrial_poly_sizes_and_dummies_match_reference():
+    # /root/repo/SURVEY.md App. D: 8100 / 7210 / 180 edges; App. A.7: 350 + 24 dummy variables
+    ps = build_structure(nx=10, nu=3, nz=0, np_=2, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=20, n_comb=9, n_robust=1, discrete=False)
+    g = np.load(os.path.join(GOLD, "industrial_poly.npz"))
+    assert ps.n_opt_x == g["mpc._opt_x_num"].shape[1] == 8100
+    assert ps.n_g == g["mpc._lam_g_num"].shape[1] == 7210
+    assert ps.n_opt_p == g["mpc.opt_p_num"].shape[1] == 31
+    assert ps.n_edges == 180 and ps.n_nodes == 181
+    assert len(ps.tables["dummy_idx"]) == 350 + 24
+    assert np.array_equal(ps.scenario_tree["structure_scenario"], g["mpc.meta.structure_scenario"])
+
+
+def test_tree_tables_are_consistent_for_deeper_trees():
+    ps = build_structure(nx=10, nu=3, nz=0, np_=2, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=20, n_comb=3, n_robust=2, discrete=False)
+    t = ps.tables
+    assert ps.S == 9 and ps.n_edges == 3 + 9 + 18 * 9 == 174            # SURVEY App. D variant (B)
+    assert ps.n_g == 6970
+    for e in range(ps.n_edges):
+        n, c = t["edge_parent"][e], t["edge_child"][e]
+        assert t["node_parent"][c] == n and t["node_in_edge"][c] == e
+        assert t["node_child_start"][n] <= e < t["node_child_start"][n] + t["node_child_count"][n]
+        assert t["node_level"][c] == t["node_level"][n] + 1 == t["edge_level"][e] + 1
+    # after the robust horizon every chain keeps the realisation of its last branching
+    last = {}
+    for e in range(ps.n_edges):
+        if t["edge_level"][e] >= 2:
+            s = t["edge_child"][e] - t["level_node_start"][t["edge_level"][e] + 1]
+            assert t["edge_pidx"][e] == s % 3
+            last[s] = t["edge_pidx"][e]
+    assert sorted(set(last.values())) == [0, 1, 2]
+    ps5 = build_structure(nx=10, nu=3, nz=0, np_=2, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=20, n_comb=3, n_robust=5, discrete=False)
+    assert (ps5.S, ps5.n_opt_x, ps5.n_g, ps5.n_edges) == (243, 218700, 160330, 4008)   # SURVEY App. D last row
+
+
+def test_unsupported_couplings_are_refused_loudly():
+    with pytest.raises(NotImplementedError):
+        build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=5, n_comb=3, n_robust=1, discrete=False, open_loop=True)
+    with pytest.raises(NotImplementedError):
+        build_structure(nx=2, nu=1, nz=1, np_=1, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=5, n_comb=1, n_robust=0, discrete=False)
