@@ -45,7 +45,11 @@ extern "C" __global__ void __launch_bounds__(256) dompc_solve_kernel(dompc::KArg
   __shared__ double filt[2 * dompc::MAX_FILTER];
   __shared__ int flags[8];
   __shared__ int s_b;
-  dompc::Thr T{(int)threadIdx.x, (int)blockDim.x, red, filt, flags};
+  __shared__ double edge_lds[4 * dompc::EL_SIZE];          // 256 threads = 4 wavefronts, one edge each
+  __shared__ long long prof[8];
+  if (threadIdx.x < 8) prof[threadIdx.x] = 0;
+  __syncthreads();
+  dompc::Thr T{(int)threadIdx.x, (int)blockDim.x, red, filt, flags, edge_lds, prof, 64};
   if (A.mode == 1) {
     if (blockIdx.x == 0) dompc::debug_newton(T, A);
     return;
@@ -71,7 +75,8 @@ extern "C" void dompc_hostemu_run(const dompc::KArgs* A) {
   static thread_local double red[dompc::RED_MAX];
   static thread_local double filt[2 * dompc::MAX_FILTER];
   static thread_local int flags[8];
-  dompc::Thr T{0, 1, red, filt, flags};
+  static thread_local double edge_lds[dompc::EL_SIZE];
+  dompc::Thr T{0, 1, red, filt, flags, edge_lds, nullptr, 1};
   if (A->mode == 1) { dompc::debug_newton(T, *A); return; }
   for (int b = 0; b < A->batch; ++b) {
     if (A->mode == 2) dompc::sweep_problem(T, *A, b, 0);

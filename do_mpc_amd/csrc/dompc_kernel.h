@@ -37,9 +37,14 @@ constexpr int NS1 = NS > 0 ? NS : 1;
 constexpr int NW1 = NW > 0 ? NW : 1;
 constexpr int MAX_FILTER = 48;
 constexpr int RED_MAX = 12;          // values reduced per pass
+#ifndef DOMPC_HOST_EMU
+constexpr int GS_C = 64;             // lanes per edge group: one wavefront
+#else
+constexpr int GS_C = 1;
+#endif
 
 // per-edge interleaved workspace (index [field + i][edge]) -------------------------------------
-constexpr int EW_LU = 0;
+constexpr int EW_LU = 0;                     // NW x NW: G_w^-1 (row-major)
 constexpr int EW_PIV = EW_LU + NW * NW;
 constexpr int EW_W = EW_PIV + NW;            // NW x NA, row-major
 constexpr int EW_W0 = EW_W + NW * NA;
@@ -70,6 +75,15 @@ constexpr int ES_CCL = ES_ACL + NA * NA;     // NA : Atilde*[0;kv] + ctilde
 constexpr int ES_OBJ = ES_CCL + NA;
 constexpr int ES_SIZE = ES_OBJ + 1;
 
+// per-edge model-output record (global): results of the lowered model functions at the current iterate,
+// written by the thread-parallel evaluation phase and copied into LDS by the edge groups
+constexpr int PT_STRIDE = NX + NX * NA + NA * NA;           // f, J, H of one collocation point
+constexpr int MO_PT = 0;
+constexpr int MO_LT = MO_PT + (NI * DEG > 0 ? NI * DEG : 1) * PT_STRIDE;   // lterm: val, g[NA], H[NA*NA]
+constexpr int MO_MT = MO_LT + 1 + NA + NA * NA;                              // mterm: val, g[NX], H[NX*NX]
+constexpr int MO_NL = MO_MT + 1 + NX + NX * NX;                              // nlcons: d[NE], Jd[NE*NA], H[NA*NA]
+constexpr int MO_SIZE = MO_NL + NE + NE * NA + NA * NA;
+
 // per node -------------------------------------------------------------------------------------
 constexpr int ND_P = 0;                      // NA x NA
 constexpr int ND_PV = ND_P + NA * NA;
@@ -87,7 +101,7 @@ struct WsLayout {
   int64_t x, zl, zu, lb, ub, dx, gf, rd, xt, dzl, dzu;
   int64_t lam, dlam, c, ct;
   int64_t s, zsl, zsu, sl, su, ds, st, dzsl, dzsu;
-  int64_t ew, es, nd, total;
+  int64_t ew, es, nd, mo, total;
 };
 
 DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad, int n_nodes) {
@@ -104,6 +118,7 @@ DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad,
   L.ew = take((int64_t)EW_SIZE * e_pad);
   L.es = take((int64_t)ES_SIZE * n_edges);
   L.nd = take((int64_t)ND_SIZE * n_nodes);
+  L.mo = take((int64_t)MO_SIZE * n_edges);
   L.total = o;
   return L;
 }
@@ -115,12 +130,37 @@ struct Thr {
   double* red;      // LDS: RED_MAX * nt doubles
   double* filt;     // LDS: 2*MAX_FILTER doubles
   int* flags;       // LDS: 8 ints
+  double* edge_lds; // LDS: (nt/gs) * EL_SIZE doubles (per-group edge working set)
+  long long* prof;  // optional sub-phase cycle counters (thread 0 only; may be null)
+  int gs;           // lanes cooperating on one edge (64 = one wavefront on the device, 1 in the host emulation)
   DOMPC_DEV void sync() const {
 #ifndef DOMPC_HOST_EMU
     __syncthreads();
 #endif
   }
+  // barrier among the lanes of one edge group.  A group is exactly one wavefront on the device and its
+  // LDS region is private to it: LDS operations of a wavefront execute in order, so a wavefront-scope
+  // fence (keeps the compiler from reordering) is sufficient - no workgroup barrier.
+  DOMPC_DEV void gsync() const {
+#ifndef DOMPC_HOST_EMU
+#ifdef DOMPC_GSYNC_BLOCK
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+#endif
+  }
 };
+
+// phase timer (shader clock on the device, 0 in the host emulation)
+DOMPC_DEV inline long long prof_clock() {
+#ifndef DOMPC_HOST_EMU
+  return (long long)clock64();
+#else
+  return 0;
+#endif
+}
 
 enum RedOp { R_SUM = 0, R_MAX = 1, R_MIN = 2 };
 
@@ -152,13 +192,14 @@ struct Prob {
   double *x, *zl, *zu, *lb, *ub, *dx, *gf, *rd, *xt, *dzl, *dzu;
   double *lam, *dlam, *c, *ct;
   double *s, *zsl, *zsu, *sl, *su, *ds, *st, *dzsl, *dzsu;
-  double *ew, *es, *nd;
+  double *ew, *es, *nd, *mo;
   int e_pad;
   double sf;                                         // objective scaling
   double mu;
   DOMPC_DEV double& EW(int e, int i) const { return ew[(int64_t)i * e_pad + e]; }
   DOMPC_DEV double* ES(int e) const { return es + (int64_t)e * ES_SIZE; }
   DOMPC_DEV double* ND(int n) const { return nd + (int64_t)n * ND_SIZE; }
+  DOMPC_DEV double* MO(int e) const { return mo + (int64_t)e * MO_SIZE; }
 };
 
 DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
@@ -171,7 +212,7 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   p.lam = w + L.lam; p.dlam = w + L.dlam; p.c = w + L.c; p.ct = w + L.ct;
   p.s = w + L.s; p.zsl = w + L.zsl; p.zsu = w + L.zsu; p.sl = w + L.sl; p.su = w + L.su;
   p.ds = w + L.ds; p.st = w + L.st; p.dzsl = w + L.dzsl; p.dzsu = w + L.dzsu;
-  p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd;
+  p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo;
   p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0;
   return p;
 }
@@ -274,270 +315,389 @@ DOMPC_DEV inline double node_rterm_f(const Prob& Q, int n, const double* xv) {
 }
 
 // ================================================================================================
-// Derivative evaluation + condensing of one edge (thread-per-edge).
-//  builds G_w, G_y, residuals; LU of G_w; W = -G_w^-1 G_y, w0 = -G_w^-1 r_g; [A|B] = S W, c;
-//  condensed Hessian/gradient share over y = (x_n,u_n); w-part of the dual residual.
-// `ls_mode`: 0 normal Newton system.
-DOMPC_DEV inline int eval_edge(const Prob& Q, int e, double mu) {
+// Derivative evaluation + condensing of one edge, cooperatively by a group of GS lanes (one wavefront
+// on the device, one thread in the host emulation) with the edge's working set in LDS:
+//   Mx = [G_w | G_y | r_g]  (NW x (NW+NA+1)) is built from the per-point model Jacobians, then inverted
+//   in place by Gauss-Jordan elimination with partial pivoting (every elimination step updates all
+//   NW x NC entries -> evenly spread over the lanes).  Afterwards the first NW columns hold G_w^-1
+//   (kept for the multiplier recovery), the rest -W and -w0.
+// All groups of the workgroup run this function in lock step (same trip counts), so the block-level
+// barrier T.sync() is safe; groups with e < 0 only take part in the barriers.
+constexpr int NC = NW + NA + 1;
+static_assert(NW <= 64, "collocation block larger than 64 unknowns per edge is not supported yet (pivot bitmask)");
+constexpr int EL_MX = 0;
+constexpr int EL_PT = EL_MX + NW * NC;
+constexpr int EL_LT = EL_PT + (NCOLL > 0 ? NCOLL : 1) * PT_STRIDE;   // lterm: val, g[NA], H[NA*NA]
+constexpr int EL_MT = EL_LT + 1 + NA + NA * NA;                        // mterm: val, g[NX], H[NX*NX]
+constexpr int EL_NL = EL_MT + 1 + NX + NX * NX;                        // nlcons: d[NE], Jd[NE*NA], H[NA*NA]
+constexpr int EL_T1 = EL_NL + NE + NE * NA + NA * NA;                  // Hww W  (NW x NA)
+static_assert(EL_T1 - EL_PT == MO_SIZE, "LDS copy of the model-output record");
+constexpr int EL_T0 = EL_T1 + NW * NA;                                 // Hww w0 (NW)
+constexpr int EL_RW = EL_T0 + NW;                                      // Newton-form gradient of w (NW)
+constexpr int EL_SG = EL_RW + NW;                                      // Sigma_w (NW)
+constexpr int EL_U1 = EL_SG + NW;                                      // Huw W (NU x NA), Huw w0 (NU)
+constexpr int EL_PV = EL_U1 + NU * NA + NU;                            // pivot rows (NW)
+constexpr int EL_SIZE = ((EL_PV + NW + 7) / 8) * 8;
+
+DOMPC_DEV inline int point_of_slot(int sl) {
+  for (int i = 0; i < NI; ++i)
+    for (int j = 1; j <= DEG; ++j)
+      if (slot_of(i, j) == sl) return i * DEG + (j - 1);
+  return -1;
+}
+
+// Thread-parallel evaluation of the lowered model functions at the current iterate: one thread per
+// (edge, function instance) - NCOLL collocation points (f, J, lambda-weighted H), stage cost,
+// terminal cost (last stage), nonlinear constraints.  This is nlp_jac_g / nlp_hess_l / nlp_grad_f of
+// the reference, evaluated block-wise.
+DOMPC_DEV inline void eval_models(const Thr& T, const Prob& Q) {
   const KArgs& A = *Q.A;
-  const int n = A.edge_parent[e], cn = A.edge_child[e], k = A.edge_level[e];
+  constexpr int NIT = (M == 0 ? 1 : NCOLL) + 3;
+  for (int it = T.tid; it < A.n_edges * NIT; it += T.nt) {
+    const int e = it / NIT, j = it % NIT;
+    const int n = A.edge_parent[e], cn = A.edge_child[e], k = A.edge_level[e];
+    const double* xn = Q.x + A.node_x_off[n];
+    const double* un = Q.x + A.node_u_off[n];
+    const double* w = Q.x + A.edge_w_off[e];
+    const double* pp = Q.P + A.p_off_p + A.edge_pidx[e] * NP;
+    const double* tvp = Q.P + A.p_off_tvp + k * NTVP;
+    const int row0 = A.edge_row0[e];
+    double* mo = Q.MO(e);
+    if (j < NIT - 3) {
+      double* pt = mo + MO_PT + j * PT_STRIDE;
+      if (M == 0) {
+        dompc_dyn(xn, un, tvp, pp, Q.lam + row0 + NW, pt, pt + NX, pt + NX + NX * NA);
+      } else {
+        const int i = j / DEG, jj = j % DEG + 1;
+        dompc_dyn(w + slot_of(i, jj) * NX, un, tvp, pp, Q.lam + row0 + i * (DEG + 1) * NX + (jj - 1) * NX,
+                  pt, pt + NX, pt + NX + NX * NA);
+      }
+    } else if (j == NIT - 3) {
+      dompc_lterm(xn, un, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NA);
+    } else if (j == NIT - 2) {
+      if (k == A.N - 1)
+        dompc_mterm(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1,
+                    mo + MO_MT + 1 + NX);
+    } else if (NE > 0) {
+      dompc_nlcons(xn, un, tvp, pp, Q.lam + row0 + NW + NX, mo + MO_NL, mo + MO_NL + NE, mo + MO_NL + NE + NE * NA);
+    }
+  }
+}
+
+DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, int lane, int GS, double* Ld) {
+  const KArgs& A = *Q.A;
+  const bool act = e >= 0;
+  const int ee = act ? e : 0;
+  const int n = A.edge_parent[ee], cn = A.edge_child[ee], k = A.edge_level[ee];
   const double* xn = Q.x + A.node_x_off[n];
   const double* un = Q.x + A.node_u_off[n];
   const double* xc = Q.x + A.node_x_off[cn];
-  const int woff = A.edge_w_off[e];
+  const int woff = A.edge_w_off[ee];
   const double* w = Q.x + woff;
-  const double* pp = Q.P + A.p_off_p + A.edge_pidx[e] * NP;
+  const double* pp = Q.P + A.p_off_p + A.edge_pidx[ee] * NP;
   const double* tvp = Q.P + A.p_off_tvp + k * NTVP;
-  const int row0 = A.edge_row0[e];
-  const double om = A.edge_omega[e] * Q.sf;
+  const int row0 = A.edge_row0[ee];
+  const double om = A.edge_omega[ee] * Q.sf;
   const double* lam_e = Q.lam + row0;
   const double* nu_e = Q.lam + row0 + NW;
-  double* S_ = Q.ES(e);
+  const double* yd = Q.lam + row0 + NW + NX;
+  double* S_ = Q.ES(ee);
   int fail = 0;
+  long long pc0 = prof_clock();
+#define DOMPC_PH(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
 
-  double f[NX], J[NX * NA], H[NA * NA];
-  double ry[NA];
-  for (int a = 0; a < NA; ++a) ry[a] = 0.0;
-  for (int a = 0; a < NA * NA; ++a) S_[ES_QT + a] = 0.0;
+  // ---- phase 1: zero Mx, copy the edge's model-output record (eval_models) into LDS
+  if (act) {
+    for (int i = lane; i < NW * NC; i += GS) Ld[EL_MX + i] = 0.0;
+    const double* mo = Q.MO(e);
+    for (int i = lane; i < MO_SIZE; i += GS) Ld[EL_PT + i] = mo[i];
+  }
+  T.gsync();
+  DOMPC_PH(0)
 
   if (M == 0) {
-    // discrete model: x_c = f(x_n,u_n); rows: f - x_c (multiplier nu_e)
-    dompc_dyn(xn, un, tvp, pp, nu_e, f, J, H);
-    for (int a = 0; a < NX; ++a) {
-      Q.c[row0 + a] = f[a] - xc[a];
-      S_[ES_CV + a] = f[a] - xc[a];
-      for (int b = 0; b < NA; ++b) S_[ES_AB + a * NA + b] = J[a * NA + b];
+    // discrete model: x_c = f(x_n,u_n); rows f - x_c with multiplier nu_e; no collocation block
+    if (act) {
+      const double* pt = Ld + EL_PT;
+      for (int a = lane; a < NX; a += GS) {
+        const double r = pt[a] - xc[a];
+        Q.c[row0 + a] = r;
+        S_[ES_CV + a] = r;
+      }
+      for (int i = lane; i < NX * NA; i += GS) S_[ES_AB + i] = pt[NX + i];
+      for (int i = lane; i < NA * NA; i += GS) {
+        double v = pt[NX + NX * NA + i] + om * Ld[EL_LT + 1 + NA + i];
+        if (NE > 0) v += Ld[EL_NL + NE + NE * NA + i];
+        S_[ES_QT + i] = v;
+        S_[ES_WTW + i] = 0.0;
+      }
+      for (int b = lane; b < NA; b += GS) {
+        double t = 0.0;
+        for (int a = 0; a < NX; ++a) t += pt[NX + a * NA + b] * nu_e[a];
+        S_[ES_RY + b] = t;          // completed below
+        S_[ES_QV + b] = 0.0;
+        S_[ES_WTW0 + b] = 0.0;
+      }
     }
-    for (int b = 0; b < NA; ++b) {
-      double t = 0.0;
-      for (int a = 0; a < NX; ++a) t += J[a * NA + b] * nu_e[a];
-      ry[b] = t;
-    }
-    for (int a = 0; a < NA * NA; ++a) { S_[ES_QT + a] = H[a]; S_[ES_WTW + a] = 0.0; }
-    for (int a = 0; a < NA; ++a) { S_[ES_QV + a] = 0.0; S_[ES_WTW0 + a] = 0.0; }
   } else {
-    // ---- zero G_w (-> EW_LU), G_y|r_g (-> EW_W, EW_W0)
-    for (int i = 0; i < NW * NW; ++i) Q.EW(e, EW_LU + i) = 0.0;
-    for (int i = 0; i < NW * NA; ++i) Q.EW(e, EW_W + i) = 0.0;
-    double huu[NU * NU];
-    for (int i = 0; i < NU * NU; ++i) huu[i] = 0.0;
-    for (int i = 0; i < NI; ++i) {
-      const double* xi0 = (i == 0) ? xn : w + slot_of(i, 0) * NX;
-      const int rbl = i * (DEG + 1) * NX;    // local row base
-      for (int j = 1; j <= DEG; ++j) {
-        const int sl = slot_of(i, j);
-        const double* xij = w + sl * NX;
-        const int rb = rbl + (j - 1) * NX;
-        const int pt = i * DEG + (j - 1);
-        dompc_dyn(xij, un, tvp, pp, lam_e + rb, f, J, H);
-        for (int a = 0; a < NA * NA; ++a) Q.EW(e, EW_HP + pt * NA * NA + a) = H[a];
-        for (int a = 0; a < NU; ++a)
-          for (int b = 0; b < NU; ++b) huu[a * NU + b] += H[(NX + a) * NA + NX + b];
-        for (int a = 0; a < NX; ++a) {
+    // ---- phase 2: assemble Mx = [G_w | G_y | r_g] and the residual rows
+    if (act) {
+      for (int it = lane; it < NI * (DEG + 1) * NX; it += GS) {
+        const int i = it / ((DEG + 1) * NX);
+        const int rr = it % ((DEG + 1) * NX);
+        const int jj = rr / NX, a = rr % NX;         // jj = 0..DEG-1: collocation row j=jj+1 ; jj = DEG: continuity row
+        const double* xi0 = (i == 0) ? xn : w + slot_of(i, 0) * NX;
+        const int row = i * (DEG + 1) * NX + jj * NX + a;
+        double* Mr = Ld + EL_MX + row * NC;
+        if (jj < DEG) {
+          const int j = jj + 1, sl = slot_of(i, j), p = i * DEG + jj;
+          const double* pt = Ld + EL_PT + p * PT_STRIDE;
           double xp = DOMPC_C[0 * (DEG + 1) + j] * xi0[a];
           for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + j] * w[slot_of(i, r) * NX + a];
-          const double res = f[a] - xp;
-          Q.c[row0 + rb + a] = res;
-          Q.EW(e, EW_W0 + rb + a) = res;
-          for (int b = 0; b < NX; ++b) Q.EW(e, EW_LU + (rb + a) * NW + sl * NX + b) += J[a * NA + b];
-          for (int b = 0; b < NU; ++b) Q.EW(e, EW_W + (rb + a) * NA + NX + b) = J[a * NA + NX + b];
+          const double res = pt[a] - xp;
+          Q.c[row0 + row] = res;
+          Mr[NW + NA] = res;
+          for (int b = 0; b < NX; ++b) Mr[sl * NX + b] += pt[NX + a * NA + b];
+          for (int b = 0; b < NU; ++b) Mr[NW + NX + b] = pt[NX + a * NA + NX + b];
           for (int r = 0; r <= DEG; ++r) {
             const double cr = DOMPC_C[r * (DEG + 1) + j];
-            if (i == 0 && r == 0) Q.EW(e, EW_W + (rb + a) * NA + a) -= cr;
-            else Q.EW(e, EW_LU + (rb + a) * NW + slot_of(i, r) * NX + a) -= cr;
+            if (i == 0 && r == 0) Mr[NW + a] -= cr;
+            else Mr[slot_of(i, r) * NX + a] -= cr;
           }
-        }
-      }
-      const int rb = rbl + DEG * NX;
-      const int ns_ = next_slot(i);
-      for (int a = 0; a < NX; ++a) {
-        double xf = DOMPC_D[0] * xi0[a];
-        for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * w[slot_of(i, r) * NX + a];
-        const double res = w[ns_ * NX + a] - xf;
-        Q.c[row0 + rb + a] = res;
-        Q.EW(e, EW_W0 + rb + a) = res;
-        Q.EW(e, EW_LU + (rb + a) * NW + ns_ * NX + a) += 1.0;
-        for (int r = 0; r <= DEG; ++r) {
-          if (i == 0 && r == 0) Q.EW(e, EW_W + (rb + a) * NA + a) -= DOMPC_D[0];
-          else Q.EW(e, EW_LU + (rb + a) * NW + slot_of(i, r) * NX + a) -= DOMPC_D[r];
-        }
-      }
-    }
-    // continuity to the child node: xkf - x_c
-    double rc[NX];
-    for (int a = 0; a < NX; ++a) {
-      rc[a] = w[(M - 1) * NX + a] - xc[a];
-      Q.c[row0 + NW + a] = rc[a];
-    }
-    // ---- dual residual pieces that need G_w / G_y before they are overwritten
-    for (int col = 0; col < NW; ++col) {
-      double t = 0.0;
-      for (int r = 0; r < NW; ++r) t += Q.EW(e, EW_LU + r * NW + col) * lam_e[r];
-      if (col >= (M - 1) * NX) t += nu_e[col - (M - 1) * NX];
-      const int gi = woff + col;
-      const double xv = Q.x[gi], l = Q.lb[gi], u = Q.ub[gi];
-      Q.gf[gi] = 0.0;
-      Q.rd[gi] = t - Q.zl[gi] + Q.zu[gi];
-      Q.EW(e, EW_RW + col) = t + bar_grad(xv, l, u, mu);
-      Q.EW(e, EW_SIGW + col) = sigma_of(xv, l, u, Q.zl[gi], Q.zu[gi]);
-    }
-    for (int b = 0; b < NA; ++b) {
-      double t = 0.0;
-      for (int r = 0; r < NW; ++r) t += Q.EW(e, EW_W + r * NA + b) * lam_e[r];
-      ry[b] = t;
-    }
-    // ---- LU with partial pivoting (in place, interleaved storage)
-    for (int kk = 0; kk < NW; ++kk) {
-      int pv = kk;
-      double best = fabs(Q.EW(e, EW_LU + kk * NW + kk));
-      for (int r = kk + 1; r < NW; ++r) {
-        const double v = fabs(Q.EW(e, EW_LU + r * NW + kk));
-        if (v > best) { best = v; pv = r; }
-      }
-      Q.EW(e, EW_PIV + kk) = (double)pv;
-      if (!(best > 1e-300)) { fail = 1; best = 1.0; Q.EW(e, EW_LU + pv * NW + kk) = 1.0; }
-      if (pv != kk) {
-        for (int cix = 0; cix < NW; ++cix) {
-          const double t = Q.EW(e, EW_LU + kk * NW + cix);
-          Q.EW(e, EW_LU + kk * NW + cix) = Q.EW(e, EW_LU + pv * NW + cix);
-          Q.EW(e, EW_LU + pv * NW + cix) = t;
-        }
-        for (int cix = 0; cix < NA; ++cix) {
-          const double t = Q.EW(e, EW_W + kk * NA + cix);
-          Q.EW(e, EW_W + kk * NA + cix) = Q.EW(e, EW_W + pv * NA + cix);
-          Q.EW(e, EW_W + pv * NA + cix) = t;
-        }
-        const double t = Q.EW(e, EW_W0 + kk);
-        Q.EW(e, EW_W0 + kk) = Q.EW(e, EW_W0 + pv);
-        Q.EW(e, EW_W0 + pv) = t;
-      }
-      const double inv = 1.0 / Q.EW(e, EW_LU + kk * NW + kk);
-      for (int r = kk + 1; r < NW; ++r) {
-        const double lf = Q.EW(e, EW_LU + r * NW + kk) * inv;
-        if (lf != 0.0) {
-          Q.EW(e, EW_LU + r * NW + kk) = lf;
-          for (int cix = kk + 1; cix < NW; ++cix)
-            Q.EW(e, EW_LU + r * NW + cix) -= lf * Q.EW(e, EW_LU + kk * NW + cix);
-          // forward elimination of the right-hand sides at the same time
-          for (int cix = 0; cix < NA; ++cix) Q.EW(e, EW_W + r * NA + cix) -= lf * Q.EW(e, EW_W + kk * NA + cix);
-          Q.EW(e, EW_W0 + r) -= lf * Q.EW(e, EW_W0 + kk);
         } else {
-          Q.EW(e, EW_LU + r * NW + kk) = 0.0;
-        }
-      }
-    }
-    // back substitution, then negate:  W = -G_w^-1 G_y,  w0 = -G_w^-1 r_g
-    for (int r = NW - 1; r >= 0; --r) {
-      const double inv = 1.0 / Q.EW(e, EW_LU + r * NW + r);
-      for (int cix = 0; cix < NA; ++cix) {
-        double t = Q.EW(e, EW_W + r * NA + cix);
-        for (int q = r + 1; q < NW; ++q) t -= Q.EW(e, EW_LU + r * NW + q) * Q.EW(e, EW_W + q * NA + cix);
-        Q.EW(e, EW_W + r * NA + cix) = t * inv;
-      }
-      double t = Q.EW(e, EW_W0 + r);
-      for (int q = r + 1; q < NW; ++q) t -= Q.EW(e, EW_LU + r * NW + q) * Q.EW(e, EW_W0 + q);
-      Q.EW(e, EW_W0 + r) = t * inv;
-    }
-    for (int i = 0; i < NW * NA; ++i) Q.EW(e, EW_W + i) = -Q.EW(e, EW_W + i);
-    for (int i = 0; i < NW; ++i) Q.EW(e, EW_W0 + i) = -Q.EW(e, EW_W0 + i);
-    // [A|B] = S W ; c = S w0 + r_c
-    for (int a = 0; a < NX; ++a) {
-      for (int b = 0; b < NA; ++b) S_[ES_AB + a * NA + b] = Q.EW(e, EW_W + ((M - 1) * NX + a) * NA + b);
-      S_[ES_CV + a] = Q.EW(e, EW_W0 + (M - 1) * NX + a) + rc[a];
-    }
-    // ---- condensed Hessian  Qt = Huu-part + Hyw W + (Hyw W)' + W' Hww W ;  Qv = Hyw w0 + W'(rw + Hww w0)
-    //      WTW = W'W, WTW0 = W'w0 (for the delta_w regularisation)
-    for (int a = 0; a < NA * NA; ++a) S_[ES_WTW + a] = 0.0;
-    for (int a = 0; a < NA; ++a) { S_[ES_QV + a] = 0.0; S_[ES_WTW0 + a] = 0.0; }
-    for (int a = 0; a < NU; ++a)
-      for (int b = 0; b < NU; ++b) S_[ES_QT + (NX + a) * NA + NX + b] += huu[a * NU + b];
-    // row-by-row over w: t1 = (Hww W)[row,:], t0 = (Hww w0)[row]
-    for (int row = 0; row < NW; ++row) {
-      double t1[NA];
-      const double sg = Q.EW(e, EW_SIGW + row);
-      for (int b = 0; b < NA; ++b) t1[b] = sg * Q.EW(e, EW_W + row * NA + b);
-      double t0 = sg * Q.EW(e, EW_W0 + row);
-      // which collocation point owns this row's slot?
-      const int sl = row / NX, a = row % NX;
-      int pt = -1;
-      for (int i = 0; i < NI; ++i)
-        for (int j = 1; j <= DEG; ++j)
-          if (slot_of(i, j) == sl) pt = i * DEG + (j - 1);
-      if (pt >= 0) {
-        for (int a2 = 0; a2 < NX; ++a2) {
-          const double h = Q.EW(e, EW_HP + pt * NA * NA + a * NA + a2);
-          if (h != 0.0) {
-            for (int b = 0; b < NA; ++b) t1[b] += h * Q.EW(e, EW_W + (sl * NX + a2) * NA + b);
-            t0 += h * Q.EW(e, EW_W0 + sl * NX + a2);
+          const int ns_ = next_slot(i);
+          double xf = DOMPC_D[0] * xi0[a];
+          for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * w[slot_of(i, r) * NX + a];
+          const double res = w[ns_ * NX + a] - xf;
+          Q.c[row0 + row] = res;
+          Mr[NW + NA] = res;
+          Mr[ns_ * NX + a] += 1.0;
+          for (int r = 0; r <= DEG; ++r) {
+            if (i == 0 && r == 0) Mr[NW + a] -= DOMPC_D[0];
+            else Mr[slot_of(i, r) * NX + a] -= DOMPC_D[r];
           }
         }
-        // Hwu contributions: Qt[u,:] += Hux W[row,:] ; Qt[:,u] += same' ; Qv[u] += Hux w0[row]
-        for (int ub = 0; ub < NU; ++ub) {
-          const double h = Q.EW(e, EW_HP + pt * NA * NA + a * NA + NX + ub);   // H[x_a][u_ub]
-          if (h != 0.0) {
-            for (int b = 0; b < NA; ++b) {
-              const double wv = Q.EW(e, EW_W + row * NA + b);
-              S_[ES_QT + (NX + ub) * NA + b] += h * wv;
-              S_[ES_QT + b * NA + NX + ub] += h * wv;
+      }
+      for (int a = lane; a < NX; a += GS) Q.c[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
+    }
+    T.gsync();
+    // ---- phase 3: dual-residual pieces that need G_w / G_y (before they are overwritten)
+    if (act) {
+      for (int col = lane; col < NW; col += GS) {
+        double t = 0.0;
+        for (int r = 0; r < NW; ++r) t += Ld[EL_MX + r * NC + col] * lam_e[r];
+        if (col >= (M - 1) * NX) t += nu_e[col - (M - 1) * NX];
+        const int gi = woff + col;
+        const double xv = Q.x[gi], l = Q.lb[gi], u = Q.ub[gi];
+        Q.gf[gi] = 0.0;
+        Q.rd[gi] = t - Q.zl[gi] + Q.zu[gi];
+        Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu);
+        Ld[EL_SG + col] = sigma_of(xv, l, u, Q.zl[gi], Q.zu[gi]);
+      }
+      for (int b = lane; b < NA; b += GS) {
+        double t = 0.0;
+        for (int r = 0; r < NW; ++r) t += Ld[EL_MX + r * NC + NW + b] * lam_e[r];
+        S_[ES_RY + b] = t;          // completed below
+      }
+    }
+    T.gsync();
+    DOMPC_PH(1)
+    // ---- phase 4: in-place Gauss-Jordan inversion of [G_w | G_y | r_g], one matrix COLUMN per lane.
+    // Per step every lane reads column kk (the multipliers; same addresses for all lanes -> LDS
+    // broadcast), finds the pivot row redundantly (no cross-lane reduction, no row interchange: the
+    // pivot row of each column is remembered instead) and updates its own column with NW independent
+    // read-FMA-write chains.  In-place: column kk becomes the kk-th column of the inverse, so that
+    // finally  stored[p_k][c] = Ginv[k][p_c]  (p_k = pivot row of column k); the epilogue moves the
+    // entries to canonical positions.
+    {
+      unsigned long long used = 0ull;          // rows already chosen as pivots (uniform)
+      for (int kk = 0; kk < NW; ++kk) {
+        double f[NW1];
+        int pr_ = 0;
+        double best = -1.0;
+#pragma unroll
+        for (int r = 0; r < NW; ++r) {
+          f[r] = act ? Ld[EL_MX + r * NC + kk] : 0.0;
+          const double v = fabs(f[r]);
+          if (!((used >> r) & 1ull) && v > best) { best = v; pr_ = r; }
+        }
+        if (act && !(best > 1e-300)) fail = 1;
+        used |= (1ull << pr_);
+        const double pinv = (best > 1e-300) ? 1.0 / (act ? Ld[EL_MX + pr_ * NC + kk] : 1.0) : 1.0;
+        if (act) {
+          if (lane == 0) Ld[EL_PV + kk] = (double)pr_;
+          for (int c = lane; c < NC; c += GS) {
+            // all loads first (independent, pipelined in the LDS queue), then the FMAs, then all stores
+            double bcol[NW1];
+#pragma unroll
+            for (int r = 0; r < NW; ++r) bcol[r] = Ld[EL_MX + r * NC + c];
+            double prow = pinv, pold = 0.0;
+#pragma unroll
+            for (int r = 0; r < NW; ++r) pold = (r == pr_) ? bcol[r] : pold;
+            if (c != kk) prow = pold * pinv;
+#pragma unroll
+            for (int r = 0; r < NW; ++r) {
+              const double base = (c == kk) ? 0.0 : bcol[r];
+              bcol[r] = (r == pr_) ? prow : base - f[r] * prow;
             }
-            S_[ES_QV + NX + ub] += h * Q.EW(e, EW_W0 + row);
-            // and W' (Hwu du-part) is covered by the symmetric term above; gradient part via rw below
+#pragma unroll
+            for (int r = 0; r < NW; ++r) Ld[EL_MX + r * NC + c] = bcol[r];
           }
         }
+        T.gsync();
       }
-      const double rwv = Q.EW(e, EW_RW + row) + t0;
-      for (int a1 = 0; a1 < NA; ++a1) {
-        const double wa = Q.EW(e, EW_W + row * NA + a1);
-        if (wa != 0.0) {
-          for (int b = 0; b < NA; ++b) {
-            S_[ES_QT + a1 * NA + b] += wa * t1[b];
-            S_[ES_WTW + a1 * NA + b] += wa * Q.EW(e, EW_W + row * NA + b);
-          }
-          S_[ES_QV + a1] += wa * rwv;
-          S_[ES_WTW0 + a1] += wa * Q.EW(e, EW_W0 + row);
+      // epilogue: canonical order.  stored[r][c] -> row kof[r] (the column r was pivot of),
+      // column p_c for the inverse part (c < NW), unchanged for the right-hand sides.
+      constexpr int CPL = (NC + GS_C - 1) / GS_C;
+      double tmp[CPL * NW1];
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          const int c = lane + q * GS;
+#pragma unroll
+          for (int r = 0; r < NW; ++r) tmp[q * NW1 + r] = (c < NC) ? Ld[EL_MX + r * NC + c] : 0.0;
         }
       }
+      if (act)
+        for (int k2 = lane; k2 < NW; k2 += GS) Ld[EL_T0 + (int)Ld[EL_PV + k2]] = (double)k2;   // kof[row] = column it was pivot of
+      T.gsync();
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          const int c = lane + q * GS;
+          if (c >= NC) continue;
+          const int dst = (c < NW) ? (int)Ld[EL_PV + c] : c;
+#pragma unroll
+          for (int rr = 0; rr < NW; ++rr) Ld[EL_MX + (int)Ld[EL_T0 + rr] * NC + dst] = tmp[q * NW1 + rr];
+        }
+      }
+      T.gsync();
     }
-  }
-  // ---- stage cost (weight sf*omega), nl_cons
-  double lval, gl[NA];
-  dompc_lterm(xn, un, tvp, pp, &lval, gl, H);
-  double obj = om * lval;
-  for (int a = 0; a < NA; ++a) {
-    S_[ES_GFY + a] = om * gl[a];
-    ry[a] += om * gl[a];
-    for (int b = 0; b < NA; ++b) S_[ES_QT + a * NA + b] += om * H[a * NA + b];
-  }
-  if (k == A.N - 1) {
-    double mval, gm[NX], Hm[NX * NX];
-    dompc_mterm(xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, &mval, gm, Hm);
-    obj += om * mval;
-    for (int a = 0; a < NX; ++a) S_[ES_MG + a] = om * gm[a];
-    for (int a = 0; a < NX * NX; ++a) S_[ES_MH + a] = om * Hm[a];
-  }
-  if (NE > 0) {
-    const double* yd = Q.lam + row0 + NW + NX;
-    double d[NE1], Jd[NE1 * NA];
-    dompc_nlcons(xn, un, tvp, pp, yd, d, Jd, H);
-    const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
-    for (int a = 0; a < NA * NA; ++a) S_[ES_QT + a] += H[a];
-    for (int i = 0; i < NE; ++i) {
-      if (DOMPC_NL_SLACK[i] >= 0) d[i] -= eps[DOMPC_NL_SLACK[i]];
-      const int si = e * NE1 + i;
-      const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
-      Q.c[row0 + NW + NX + i] = d[i] - sv;
-      S_[ES_RDN + i] = d[i] - sv;
-      S_[ES_SIGS + i] = sigma_of(sv, l, u, Q.zsl[si], Q.zsu[si]);
-      S_[ES_RSN + i] = -yd[i] + bar_grad(sv, l, u, mu);
-      for (int b = 0; b < NA; ++b) {
-        Q.EW(e, EW_JD + i * NA + b) = Jd[i * NA + b];
-        ry[b] += Jd[i * NA + b] * yd[i];
+    // now: Mx[:, :NW] = G_w^-1 ; Mx[:, NW:NW+NA] = G_w^-1 G_y = -W ; Mx[:, NW+NA] = G_w^-1 r_g = -w0
+    if (act) {
+      for (int it = lane; it < NW * (NA + 1); it += GS) {
+        const int r = it / (NA + 1), c = it % (NA + 1);
+        Ld[EL_MX + r * NC + NW + c] = -Ld[EL_MX + r * NC + NW + c];
       }
     }
-    for (int q = 0; q < NS; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
+    T.gsync();
+    DOMPC_PH(2)
+    // ---- phase 5: T1 = Hww W, t0 = Hww w0, U1 = Huw W, u0 = Huw w0
+    if (act) {
+      for (int it = lane; it < NW * (NA + 1); it += GS) {
+        const int row = it / (NA + 1), b = it % (NA + 1);
+        const int sl = row / NX, a = row % NX;
+        const int p = point_of_slot(sl);
+        double t = Ld[EL_SG + row] * Ld[EL_MX + row * NC + NW + b];
+        if (p >= 0) {
+          const double* Hp = Ld + EL_PT + p * PT_STRIDE + NX + NX * NA;
+          for (int a2 = 0; a2 < NX; ++a2) t += Hp[a * NA + a2] * Ld[EL_MX + (sl * NX + a2) * NC + NW + b];
+        }
+        if (b < NA) Ld[EL_T1 + row * NA + b] = t;
+        else Ld[EL_T0 + row] = t;
+      }
+      for (int it = lane; it < NU * (NA + 1); it += GS) {
+        const int ub = it / (NA + 1), b = it % (NA + 1);
+        double t = 0.0;
+        for (int p = 0; p < NCOLL; ++p) {
+          const int sl = slot_of(p / DEG, p % DEG + 1);
+          const double* Hp = Ld + EL_PT + p * PT_STRIDE + NX + NX * NA;
+          for (int a = 0; a < NX; ++a) t += Hp[a * NA + NX + ub] * Ld[EL_MX + (sl * NX + a) * NC + NW + b];
+        }
+        Ld[EL_U1 + (b < NA ? ub * NA + b : NU * NA + ub)] = t;
+      }
+    }
+    T.gsync();
+    // ---- phase 6: condensed blocks to the shared per-edge record; data for the forward pass
+    if (act) {
+      for (int it = lane; it < NA * NA; it += GS) {
+        const int a1 = it / NA, b = it % NA;
+        double q = om * Ld[EL_LT + 1 + NA + it];
+        if (NE > 0) q += Ld[EL_NL + NE + NE * NA + it];
+        double ww = 0.0;
+        for (int row = 0; row < NW; ++row) {
+          const double wa = Ld[EL_MX + row * NC + NW + a1];
+          q += wa * Ld[EL_T1 + row * NA + b];
+          ww += wa * Ld[EL_MX + row * NC + NW + b];
+        }
+        if (a1 >= NX && b >= NX) {
+          double h = 0.0;
+          for (int p = 0; p < NCOLL; ++p) h += Ld[EL_PT + p * PT_STRIDE + NX + NX * NA + a1 * NA + b];
+          q += h;
+        }
+        if (a1 >= NX) q += Ld[EL_U1 + (a1 - NX) * NA + b];
+        if (b >= NX) q += Ld[EL_U1 + (b - NX) * NA + a1];
+        S_[ES_QT + it] = q;
+        S_[ES_WTW + it] = ww;
+      }
+      for (int a1 = lane; a1 < NA; a1 += GS) {
+        double q = 0.0, ww = 0.0;
+        for (int row = 0; row < NW; ++row) {
+          const double wa = Ld[EL_MX + row * NC + NW + a1];
+          q += wa * (Ld[EL_RW + row] + Ld[EL_T0 + row]);
+          ww += wa * Ld[EL_MX + row * NC + NW + NA];
+        }
+        if (a1 >= NX) q += Ld[EL_U1 + NU * NA + a1 - NX];
+        S_[ES_QV + a1] = q;
+        S_[ES_WTW0 + a1] = ww;
+      }
+      for (int it = lane; it < NX * (NA + 1); it += GS) {
+        const int a = it / (NA + 1), b = it % (NA + 1);
+        const double v = Ld[EL_MX + ((M - 1) * NX + a) * NC + NW + b];
+        if (b < NA) S_[ES_AB + a * NA + b] = v;
+        else S_[ES_CV + a] = v + (w[(M - 1) * NX + a] - xc[a]);
+      }
+      // forward-pass data (interleaved per-edge workspace)
+      for (int it = lane; it < NW * NW; it += GS) Q.EW(e, EW_LU + it) = Ld[EL_MX + (it / NW) * NC + it % NW];
+      for (int it = lane; it < NW * NA; it += GS) Q.EW(e, EW_W + it) = Ld[EL_MX + (it / NA) * NC + NW + it % NA];
+      for (int r = lane; r < NW; r += GS) {
+        Q.EW(e, EW_W0 + r) = Ld[EL_MX + r * NC + NW + NA];
+        Q.EW(e, EW_SIGW + r) = Ld[EL_SG + r];
+        Q.EW(e, EW_RW + r) = Ld[EL_RW + r];
+      }
+      for (int it = lane; it < NCOLL * NA * NA; it += GS)
+        Q.EW(e, EW_HP + it) = Ld[EL_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + it % (NA * NA)];
+    }
   }
-  for (int a = 0; a < NA; ++a) S_[ES_RY + a] = ry[a];
-  S_[ES_OBJ] = obj;
+  T.gsync();
+  // ---- phase 7: stage cost / terminal cost / nl_cons shares (few values: lanes 0..)
+  if (act) {
+    for (int a = lane; a < NA; a += GS) {
+      double r = S_[ES_RY + a] + om * Ld[EL_LT + 1 + a];
+      if (NE > 0)
+        for (int i = 0; i < NE; ++i) r += Ld[EL_NL + NE + i * NA + a] * yd[i];
+      S_[ES_GFY + a] = om * Ld[EL_LT + 1 + a];
+      S_[ES_RY + a] = r;
+    }
+    if (k == A.N - 1) {
+      for (int a = lane; a < NX; a += GS) S_[ES_MG + a] = om * Ld[EL_MT + 1 + a];
+      for (int a = lane; a < NX * NX; a += GS) S_[ES_MH + a] = om * Ld[EL_MT + 1 + NX + a];
+    }
+    if (lane == 0) {
+      double obj = om * Ld[EL_LT];
+      if (k == A.N - 1) obj += om * Ld[EL_MT];
+      if (NE > 0) {
+        const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
+        for (int i = 0; i < NE; ++i) {
+          double d = Ld[EL_NL + i];
+          if (DOMPC_NL_SLACK[i] >= 0) d -= eps[DOMPC_NL_SLACK[i]];
+          const int si = e * NE1 + i;
+          const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
+          Q.c[row0 + NW + NX + i] = d - sv;
+          S_[ES_RDN + i] = d - sv;
+          S_[ES_SIGS + i] = sigma_of(sv, l, u, Q.zsl[si], Q.zsu[si]);
+          S_[ES_RSN + i] = -yd[i] + bar_grad(sv, l, u, mu);
+        }
+        for (int q = 0; q < NS; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
+      }
+      S_[ES_OBJ] = obj;
+    }
+    if (NE > 0)
+      for (int it = lane; it < NE * NA; it += GS) Q.EW(e, EW_JD + it) = Ld[EL_NL + NE + it];
+  }
+  T.gsync();
+  DOMPC_PH(3)
+#undef DOMPC_PH
   return fail;
 }
 
@@ -995,21 +1155,13 @@ DOMPC_DEV inline void riccati_forward(const Thr& T, const Prob& Q, double mu, do
           }
         }
       for (int r = 0; r < NW; ++r) rhs[r] = -rhs[r];
-      // solve G_w' dl = rhs with G_w = P^T L U:  U' y = rhs ; L' z = y ; dl = P^T z
+      // d lambda = G_w^-T rhs  (EW_LU holds G_w^-1)
       for (int r = 0; r < NW; ++r) {
-        double t = rhs[r];
-        for (int q = 0; q < r; ++q) t -= Q.EW(e, EW_LU + q * NW + r) * rhs[q];
-        rhs[r] = t / Q.EW(e, EW_LU + r * NW + r);
+        double t = 0.0;
+        for (int q = 0; q < NW; ++q) t += Q.EW(e, EW_LU + q * NW + r) * rhs[q];
+        dw[r] = t;
       }
-      for (int r = NW - 1; r >= 0; --r) {
-        double t = rhs[r];
-        for (int q = r + 1; q < NW; ++q) t -= Q.EW(e, EW_LU + q * NW + r) * rhs[q];
-        rhs[r] = t;
-      }
-      for (int r = NW - 1; r >= 0; --r) {
-        const int pv = (int)Q.EW(e, EW_PIV + r);
-        if (pv != r) { const double t = rhs[r]; rhs[r] = rhs[pv]; rhs[pv] = t; }
-      }
+      for (int r = 0; r < NW; ++r) rhs[r] = dw[r];
       for (int r = 0; r < NW; ++r) Q.dlam[row0 + r] = rhs[r];
     }
     if (NE > 0) {
@@ -1054,8 +1206,17 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   if (T.tid == 0) T.flags[1] = 0;
   T.sync();
   for (int g = T.tid; g < NX; g += T.nt) Q.c[g] = Q.x[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
-  for (int e = T.tid; e < A.n_edges; e += T.nt)
-    if (eval_edge(Q, e, mu)) T.flags[1] = 1;
+  eval_models(T, Q);
+  T.sync();
+  {
+    const int ng = T.nt / T.gs, gid = T.tid / T.gs, lane = T.tid % T.gs;
+    double* Ld = T.edge_lds + (int64_t)gid * EL_SIZE;
+    const int rounds = (A.n_edges + ng - 1) / ng;
+    for (int rd = 0; rd < rounds; ++rd) {
+      const int e = rd * ng + gid;
+      if (eval_edge_coop(T, Q, e < A.n_edges ? e : -1, mu, lane, T.gs, Ld)) T.flags[1] = 1;
+    }
+  }
   T.sync();
   for (int n = T.tid; n < A.n_nodes; n += T.nt) assemble_node(Q, n);
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
@@ -1161,6 +1322,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   // ---- objective scaling from the gradient at the (pushed) starting point
   double mu = O.mu_init;
   Q.sf = 1.0;
+  long long c_sweep = 0, c_bwd = 0, c_fwd = 0, c_ls = 0, c_meas = 0, c_t = 0; const long long c_start = prof_clock();
   int bad = sweep(T, Q, mu);
   ++n_sweeps;
   if (O.obj_scaling) {
@@ -1202,7 +1364,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     // ---- barrier update (monotone Fiacco-McCormick)
     bool mu_changed = false;
     while (true) {
-      Errs Em = measure(T, Q, mu);
+      c_t = prof_clock(); Errs Em = measure(T, Q, mu); c_meas += prof_clock() - c_t;
       const double Emu = fmax(Em.e_d / sd, fmax(Em.e_p, Em.e_c0 / sc));
       if (Emu <= O.kappa_eps * mu && mu > mu_min) {
         mu = fmax(mu_min, fmin(O.kappa_mu * mu, pow(mu, O.theta_mu)));
@@ -1217,7 +1379,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     double delta = 0.0;
     bool first_try = true, dir_ok = true;
     while (true) {
-      const int fail = riccati_backward(T, Q, mu, delta);
+      c_t = prof_clock(); const int fail = riccati_backward(T, Q, mu, delta); c_bwd += prof_clock() - c_t;
       if (!fail) break;
       if (delta == 0.0) {
         delta = (delta_last == 0.0) ? O.delta_w_0 : fmax(O.delta_w_min, O.kappa_w_minus * delta_last);
@@ -1229,7 +1391,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     }
     if (!dir_ok) { status = 3; break; }
     if (delta > 0.0) { delta_last = delta; ++n_reg; }
-    riccati_forward(T, Q, mu, delta);
+    c_t = prof_clock(); riccati_forward(T, Q, mu, delta); c_fwd += prof_clock() - c_t;
 
     // ---- fraction to the boundary, directional derivative of the barrier function
     double r5[5] = {1.0, 1.0, 0.0, 0.0, 0.0};   // a_max, a_z, dphi, barrier-sum, (unused)
@@ -1276,6 +1438,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     const double theta = E.theta;
     const double phi = E.obj + mu * r5[3];
 
+    c_t = prof_clock();
     // ---- filter line search (no second-order correction, no restoration phase)
     const double gamma_theta = 1e-5, gamma_phi = 1e-8, eta_phi = 1e-8, s_theta = 1.1, s_phi = 2.3, gamma_alpha = 0.05;
     double a_min;
@@ -1352,6 +1515,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       if (n_filt < MAX_FILTER) ++n_filt;
       T.sync();
     }
+    c_ls += prof_clock() - c_t;
     // ---- accept the trial point
     const double ks = 1e10;
     for (int g = T.tid; g < nX; g += T.nt) {
@@ -1391,12 +1555,13 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     }
     T.sync();
     ++it;
-    bad = sweep(T, Q, mu);
+    c_t = prof_clock(); bad = sweep(T, Q, mu); c_sweep += prof_clock() - c_t;
     ++n_sweeps;
-    E = measure(T, Q, 0.0);
+    c_t = prof_clock(); E = measure(T, Q, 0.0); c_meas += prof_clock() - c_t;
   }
 
   // ---- outputs (unscaled multipliers, CasADi sign convention)
+  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = 0; tr[7] = 0; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; } }
   const double isf = 1.0 / Q.sf;
   if (A.x_out) for (int g = T.tid; g < nX; g += T.nt) A.x_out[(int64_t)b * nX + g] = Q.x[g];
   if (A.lam_x_out) for (int g = T.tid; g < nX; g += T.nt) A.lam_x_out[(int64_t)b * nX + g] = (Q.zu[g] - Q.zl[g]) * isf;

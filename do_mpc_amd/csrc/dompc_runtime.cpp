@@ -165,9 +165,18 @@ static int ensure_staging(dompc_handle* h, int B) {
   return 0;
 }
 
+static void* own_stream(dompc_handle* h) {
+#ifndef DOMPC_HOST_EMU
+  return (void*)h->stream;
+#else
+  (void)h;
+  return nullptr;
+#endif
+}
+
 static int launch(dompc_handle* h, dompc::KArgs& A, int grid, void* stream_v) {
 #ifndef DOMPC_HOST_EMU
-  hipStream_t st = stream_v ? (hipStream_t)stream_v : h->stream;
+  hipStream_t st = (hipStream_t)stream_v;          // nullptr = HIP default stream
   if (dev_zero(h, A.work_counter, sizeof(int32_t), st)) return 1;
   size_t sz = sizeof(A);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -336,7 +345,7 @@ extern "C" int dompc_solve_batch(dompc_handle* h, int32_t B, const double* x0, c
   rc |= h2d(h, h->s_ubg, ubg, sizeof(double) * d.n_g);
   if (rc) return 1;
   if (dompc_solve_batch_device(h, B, h->s_x0, h->s_lbx, h->s_ubx, h->s_lbg, h->s_ubg, h->s_p, h->s_x, h->s_g, h->s_lamx,
-                               h->s_lamg, h->s_f, h->s_stats, nullptr))
+                               h->s_lamg, h->s_f, h->s_stats, own_stream(h)))
     return 1;
   if (x) rc |= d2h(h, x, h->s_x, sizeof(double) * (size_t)B * d.n_opt_x);
   if (g) rc |= d2h(h, g, h->s_g, sizeof(double) * (size_t)B * d.n_g);
@@ -400,7 +409,7 @@ extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const d
   A.dbg_dx = h->s_dbg[3]; A.dbg_dlam = h->s_dbg[4]; A.dbg_rd = h->s_dbg[5]; A.dbg_c = h->s_dbg[6];
   A.dbg_mu = mu; A.dbg_delta = delta_w;
   A.batch = 1; A.mode = 1;
-  if (launch(h, A, 1, nullptr)) return 1;
+  if (launch(h, A, 1, own_stream(h))) return 1;
   if (dx) rc |= d2h(h, dx, h->s_dbg[3], sizeof(double) * d.n_opt_x);
   if (dlam) rc |= d2h(h, dlam, h->s_dbg[4], sizeof(double) * d.n_g);
   if (rd) rc |= d2h(h, rd, h->s_dbg[5], sizeof(double) * d.n_opt_x);

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of one solve (problem 0) from the kernel's own shader-clock counters."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from do_mpc_amd.examples import CASES  # noqa: E402
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "industrial_poly"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ex = CASES[name]
+    mpc = ex.build_mpc(ex.build_model(), max_batch=max(B, 1))
+    X0 = bench.synthetic_x0_batch(B) if name == "industrial_poly" else np.tile(ex.X0, (B, 1))
+    import time
+    for rep in range(2):
+        t = time.time()
+        r = mpc.make_step_batch(X0)
+        dt = time.time() - t
+    st = r["stats"]
+    tr = mpc.S.trace(4096)[-1]
+    tot = tr[5]
+    print(f"{name} B={B}: wall {dt * 1e3:.1f} ms, iters {st['iter_count'][0]}, sweeps {st['n_sweeps'][0]}, trials {st['n_trials'][0]}")
+    for nm, v in zip(("sweep", "riccati_bwd", "riccati_fwd", "linesearch", "measure"), tr[:5]):
+        print(f"  {nm:12s} {v / 1e6:9.2f} Mcycles  {100 * v / tot:5.1f} %")
+    print(f"  total        {tot / 1e6:9.2f} Mcycles (problem 0)")
+    sub = mpc.S.trace(4096)[-2]
+    for nm, v in zip(("edge:model-eval", "edge:assemble+dual", "edge:gauss-jordan", "edge:condense+store"), sub[:4]):
+        print(f"    {nm:22s} {v / 1e6:9.2f} Mcycles")
+
+
+if __name__ == "__main__":
+    main()
