@@ -40,16 +40,18 @@ extern "C" __global__ void dompc_model_info_kernel(const int32_t* in, int64_t* o
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256) dompc_solve_kernel(dompc::KArgs A) {
-  __shared__ double red[dompc::RED_MAX * 256];
+extern "C" __global__ void __launch_bounds__(256, 2) dompc_solve_kernel(dompc::KArgs A) {
+  // one LDS pool: per-wavefront edge working sets during the sweep, reduction scratch otherwise
+  // (never live at the same time; every use is bracketed by workgroup barriers)
+  constexpr int POOL = (4 * dompc::EL_SIZE > dompc::RED_MAX * 256) ? 4 * dompc::EL_SIZE : dompc::RED_MAX * 256;
+  __shared__ double pool[POOL];
   __shared__ double filt[2 * dompc::MAX_FILTER];
   __shared__ int flags[8];
   __shared__ int s_b;
-  __shared__ double edge_lds[4 * dompc::EL_SIZE];          // 256 threads = 4 wavefronts, one edge each
   __shared__ long long prof[8];
   if (threadIdx.x < 8) prof[threadIdx.x] = 0;
   __syncthreads();
-  dompc::Thr T{(int)threadIdx.x, (int)blockDim.x, red, filt, flags, edge_lds, prof, 64};
+  dompc::Thr T{(int)threadIdx.x, (int)blockDim.x, pool, filt, flags, pool, prof, 64};
   if (A.mode == 1) {
     if (blockIdx.x == 0) dompc::debug_newton(T, A);
     return;

@@ -23,6 +23,14 @@
 
 namespace dompc {
 
+// Phase functions.  (Measured on MI355X: keeping them out of line with __attribute__((noinline)) makes
+// the Thr/Prob descriptors live in scratch and doubles the time of the LDS loops, so they are inlined.)
+#ifndef DOMPC_HOST_EMU
+#define DOMPC_PHASE __device__ inline
+#else
+#define DOMPC_PHASE static inline
+#endif
+
 constexpr int NX = DOMPC_NX, NU = DOMPC_NU, NP = DOMPC_NP, NTVP = DOMPC_NTVP;
 constexpr int NE = DOMPC_NE, NS = DOMPC_NS;
 constexpr int DEG = DOMPC_DEG, NI = DOMPC_NI, M = DOMPC_M;
@@ -43,7 +51,7 @@ constexpr int GS_C = 64;             // lanes per edge group: one wavefront
 constexpr int GS_C = 1;
 #endif
 
-// per-edge interleaved workspace (index [field + i][edge]) -------------------------------------
+// per-edge forward-pass record (contiguous per edge; written/read cooperatively by one wavefront) --
 constexpr int EW_LU = 0;                     // NW x NW: G_w^-1 (row-major)
 constexpr int EW_PIV = EW_LU + NW * NW;
 constexpr int EW_W = EW_PIV + NW;            // NW x NA, row-major
@@ -89,13 +97,8 @@ constexpr int ND_P = 0;                      // NA x NA
 constexpr int ND_PV = ND_P + NA * NA;
 constexpr int ND_K = ND_PV + NA;             // NV x NA
 constexpr int ND_KV = ND_K + NV * NA;
-constexpr int ND_Q = ND_KV + NV;             // NYT x NYT
-constexpr int ND_QV = ND_Q + NYT * NYT;
-constexpr int ND_DXT = ND_QV + NYT;          // NA
-constexpr int ND_L = ND_DXT + NA;            // NV x NV
-constexpr int ND_QO = ND_L + NV * NV;        // NYT x NYT : node quadratic without the children's value functions
-constexpr int ND_QOV = ND_QO + NYT * NYT;
-constexpr int ND_SIZE = ND_QOV + NYT;
+constexpr int ND_DXT = ND_KV + NV;           // NA
+constexpr int ND_SIZE = ND_DXT + NA;
 
 struct WsLayout {
   int64_t x, zl, zu, lb, ub, dx, gf, rd, xt, dzl, dzu;
@@ -196,7 +199,7 @@ struct Prob {
   int e_pad;
   double sf;                                         // objective scaling
   double mu;
-  DOMPC_DEV double& EW(int e, int i) const { return ew[(int64_t)i * e_pad + e]; }
+  DOMPC_DEV double& EW(int e, int i) const { return ew[(int64_t)e * EW_SIZE + i]; }
   DOMPC_DEV double* ES(int e) const { return es + (int64_t)e * ES_SIZE; }
   DOMPC_DEV double* ND(int n) const { return nd + (int64_t)n * ND_SIZE; }
   DOMPC_DEV double* MO(int e) const { return mo + (int64_t)e * MO_SIZE; }
@@ -237,7 +240,7 @@ DOMPC_DEV inline double sigma_of(double x, double l, double u, double zl, double
 // ================================================================================================
 // Trial evaluation: constraint residuals + objective share of one edge at `xv` (no derivatives).
 // nlp_g / nlp_f of the reference for the rows/terms owned by edge e.
-DOMPC_DEV inline double eval_edge_f(const Prob& Q, int e, const double* xv, const double* sv, double* cv) {
+DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const double* sv, double* cv) {
   const KArgs& A = *Q.A;
   const int n = A.edge_parent[e], cn = A.edge_child[e], k = A.edge_level[e];
   const double* xn = xv + A.node_x_off[n];
@@ -326,18 +329,14 @@ DOMPC_DEV inline double node_rterm_f(const Prob& Q, int n, const double* xv) {
 constexpr int NC = NW + NA + 1;
 static_assert(NW <= 64, "collocation block larger than 64 unknowns per edge is not supported yet (pivot bitmask)");
 constexpr int EL_MX = 0;
-constexpr int EL_PT = EL_MX + NW * NC;
-constexpr int EL_LT = EL_PT + (NCOLL > 0 ? NCOLL : 1) * PT_STRIDE;   // lterm: val, g[NA], H[NA*NA]
-constexpr int EL_MT = EL_LT + 1 + NA + NA * NA;                        // mterm: val, g[NX], H[NX*NX]
-constexpr int EL_NL = EL_MT + 1 + NX + NX * NX;                        // nlcons: d[NE], Jd[NE*NA], H[NA*NA]
-constexpr int EL_T1 = EL_NL + NE + NE * NA + NA * NA;                  // Hww W  (NW x NA)
-static_assert(EL_T1 - EL_PT == MO_SIZE, "LDS copy of the model-output record");
+constexpr int EL_T1 = EL_MX + NW * NC;                                 // Hww W  (NW x NA)
 constexpr int EL_T0 = EL_T1 + NW * NA;                                 // Hww w0 (NW)
 constexpr int EL_RW = EL_T0 + NW;                                      // Newton-form gradient of w (NW)
 constexpr int EL_SG = EL_RW + NW;                                      // Sigma_w (NW)
 constexpr int EL_U1 = EL_SG + NW;                                      // Huw W (NU x NA), Huw w0 (NU)
 constexpr int EL_PV = EL_U1 + NU * NA + NU;                            // pivot rows (NW)
-constexpr int EL_SIZE = ((EL_PV + NW + 7) / 8) * 8;
+constexpr int RB_NEED = 2 * (NYT * NYT + NYT) + 4 * NA * NA + 5 * NA + NX * NA + NX + NV * NA + NV;
+constexpr int EL_SIZE = (((EL_PV + NW > RB_NEED ? EL_PV + NW : RB_NEED) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {
   for (int i = 0; i < NI; ++i)
@@ -350,7 +349,7 @@ DOMPC_DEV inline int point_of_slot(int sl) {
 // (edge, function instance) - NCOLL collocation points (f, J, lambda-weighted H), stage cost,
 // terminal cost (last stage), nonlinear constraints.  This is nlp_jac_g / nlp_hess_l / nlp_grad_f of
 // the reference, evaluated block-wise.
-DOMPC_DEV inline void eval_models(const Thr& T, const Prob& Q) {
+DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
   const KArgs& A = *Q.A;
   constexpr int NIT = (M == 0 ? 1 : NCOLL) + 3;
   for (int it = T.tid; it < A.n_edges * NIT; it += T.nt) {
@@ -384,7 +383,7 @@ DOMPC_DEV inline void eval_models(const Thr& T, const Prob& Q) {
   }
 }
 
-DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, int lane, int GS, double* Ld) {
+DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, int lane, int GS, double* Ld) {
   const KArgs& A = *Q.A;
   const bool act = e >= 0;
   const int ee = act ? e : 0;
@@ -402,15 +401,14 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
   const double* nu_e = Q.lam + row0 + NW;
   const double* yd = Q.lam + row0 + NW + NX;
   double* S_ = Q.ES(ee);
+  const double* mo = Q.MO(ee);
   int fail = 0;
   long long pc0 = prof_clock();
 #define DOMPC_PH(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
 
-  // ---- phase 1: zero Mx, copy the edge's model-output record (eval_models) into LDS
+  // ---- phase 1: zero Mx (the model-output record of eval_models is read from global memory / L2)
   if (act) {
     for (int i = lane; i < NW * NC; i += GS) Ld[EL_MX + i] = 0.0;
-    const double* mo = Q.MO(e);
-    for (int i = lane; i < MO_SIZE; i += GS) Ld[EL_PT + i] = mo[i];
   }
   T.gsync();
   DOMPC_PH(0)
@@ -418,7 +416,7 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
   if (M == 0) {
     // discrete model: x_c = f(x_n,u_n); rows f - x_c with multiplier nu_e; no collocation block
     if (act) {
-      const double* pt = Ld + EL_PT;
+      const double* pt = mo + MO_PT;
       for (int a = lane; a < NX; a += GS) {
         const double r = pt[a] - xc[a];
         Q.c[row0 + a] = r;
@@ -426,8 +424,8 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
       }
       for (int i = lane; i < NX * NA; i += GS) S_[ES_AB + i] = pt[NX + i];
       for (int i = lane; i < NA * NA; i += GS) {
-        double v = pt[NX + NX * NA + i] + om * Ld[EL_LT + 1 + NA + i];
-        if (NE > 0) v += Ld[EL_NL + NE + NE * NA + i];
+        double v = pt[NX + NX * NA + i] + om * mo[MO_LT + 1 + NA + i];
+        if (NE > 0) v += mo[MO_NL + NE + NE * NA + i];
         S_[ES_QT + i] = v;
         S_[ES_WTW + i] = 0.0;
       }
@@ -451,7 +449,7 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
         double* Mr = Ld + EL_MX + row * NC;
         if (jj < DEG) {
           const int j = jj + 1, sl = slot_of(i, j), p = i * DEG + jj;
-          const double* pt = Ld + EL_PT + p * PT_STRIDE;
+          const double* pt = mo + MO_PT + p * PT_STRIDE;
           double xp = DOMPC_C[0 * (DEG + 1) + j] * xi0[a];
           for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + j] * w[slot_of(i, r) * NX + a];
           const double res = pt[a] - xp;
@@ -503,73 +501,68 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
     T.gsync();
     DOMPC_PH(1)
     // ---- phase 4: in-place Gauss-Jordan inversion of [G_w | G_y | r_g], one matrix COLUMN per lane.
-    // Per step every lane reads column kk (the multipliers; same addresses for all lanes -> LDS
-    // broadcast), finds the pivot row redundantly (no cross-lane reduction, no row interchange: the
-    // pivot row of each column is remembered instead) and updates its own column with NW independent
-    // read-FMA-write chains.  In-place: column kk becomes the kk-th column of the inverse, so that
-    // finally  stored[p_k][c] = Ginv[k][p_c]  (p_k = pivot row of column k); the epilogue moves the
-    // entries to canonical positions.
+    // Per step every lane reads column kk (same addresses for all lanes -> LDS broadcast) and finds the
+    // pivot row redundantly with a packed (|value| high word, row) key - no cross-lane reduction; rows kk
+    // and pivot are interchanged; then each lane updates its own column: all loads, all FMAs, all stores
+    // (independent chains that pipeline in the LDS queue).  Column kk becomes the kk-th column of the
+    // inverse in place; the row interchanges are undone on the columns of the inverse afterwards.
     {
-      unsigned long long used = 0ull;          // rows already chosen as pivots (uniform)
+      static_assert(NW <= 64, "row index is packed into 6 bits of the pivot key");
       for (int kk = 0; kk < NW; ++kk) {
         double f[NW1];
-        int pr_ = 0;
-        double best = -1.0;
+        unsigned bestkey = 0u;
 #pragma unroll
         for (int r = 0; r < NW; ++r) {
           f[r] = act ? Ld[EL_MX + r * NC + kk] : 0.0;
-          const double v = fabs(f[r]);
-          if (!((used >> r) & 1ull) && v > best) { best = v; pr_ = r; }
+          unsigned key = (((unsigned)(__builtin_bit_cast(unsigned long long, f[r]) >> 32)) & 0x7fffffc0u) | (unsigned)r;
+          key = (r >= kk) ? key : 0u;
+          bestkey = key > bestkey ? key : bestkey;
         }
-        if (act && !(best > 1e-300)) fail = 1;
-        used |= (1ull << pr_);
-        const double pinv = (best > 1e-300) ? 1.0 / (act ? Ld[EL_MX + pr_ * NC + kk] : 1.0) : 1.0;
+        const int pv = (int)(bestkey & 63u);
+        if (act && (bestkey >> 6) == 0u) fail = 1;          // |pivot| < ~1e-300: singular collocation block
         if (act) {
-          if (lane == 0) Ld[EL_PV + kk] = (double)pr_;
+          if (lane == 0) Ld[EL_PV + kk] = (double)pv;
+          if (pv != kk)
+            for (int c = lane; c < NC; c += GS) {
+              const double t1 = Ld[EL_MX + kk * NC + c], t2 = Ld[EL_MX + pv * NC + c];
+              Ld[EL_MX + kk * NC + c] = t2;
+              Ld[EL_MX + pv * NC + c] = t1;
+            }
+        }
+        T.gsync();
+        if (act) {
+          if (pv != kk) {
+#pragma unroll
+            for (int r = 0; r < NW; ++r) f[r] = Ld[EL_MX + r * NC + kk];
+          }
+          const double piv = Ld[EL_MX + kk * NC + kk];
+          const double pinv = (fabs(piv) > 1e-300) ? 1.0 / piv : 1.0;
           for (int c = lane; c < NC; c += GS) {
-            // all loads first (independent, pipelined in the LDS queue), then the FMAs, then all stores
             double bcol[NW1];
 #pragma unroll
             for (int r = 0; r < NW; ++r) bcol[r] = Ld[EL_MX + r * NC + c];
-            double prow = pinv, pold = 0.0;
+            const double prow = (c == kk) ? pinv : Ld[EL_MX + kk * NC + c] * pinv;
+            const double keep = (c == kk) ? 0.0 : 1.0;
 #pragma unroll
-            for (int r = 0; r < NW; ++r) pold = (r == pr_) ? bcol[r] : pold;
-            if (c != kk) prow = pold * pinv;
-#pragma unroll
-            for (int r = 0; r < NW; ++r) {
-              const double base = (c == kk) ? 0.0 : bcol[r];
-              bcol[r] = (r == pr_) ? prow : base - f[r] * prow;
-            }
+            for (int r = 0; r < NW; ++r) bcol[r] = fma(-f[r], prow, bcol[r] * keep);
 #pragma unroll
             for (int r = 0; r < NW; ++r) Ld[EL_MX + r * NC + c] = bcol[r];
+            Ld[EL_MX + kk * NC + c] = prow;
           }
         }
         T.gsync();
       }
-      // epilogue: canonical order.  stored[r][c] -> row kof[r] (the column r was pivot of),
-      // column p_c for the inverse part (c < NW), unchanged for the right-hand sides.
-      constexpr int CPL = (NC + GS_C - 1) / GS_C;
-      double tmp[CPL * NW1];
+      // undo the row interchanges on the columns of the inverse (reverse order); lane r owns row r here
       if (act) {
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          const int c = lane + q * GS;
-#pragma unroll
-          for (int r = 0; r < NW; ++r) tmp[q * NW1 + r] = (c < NC) ? Ld[EL_MX + r * NC + c] : 0.0;
-        }
-      }
-      if (act)
-        for (int k2 = lane; k2 < NW; k2 += GS) Ld[EL_T0 + (int)Ld[EL_PV + k2]] = (double)k2;   // kof[row] = column it was pivot of
-      T.gsync();
-      if (act) {
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          const int c = lane + q * GS;
-          if (c >= NC) continue;
-          const int dst = (c < NW) ? (int)Ld[EL_PV + c] : c;
-#pragma unroll
-          for (int rr = 0; rr < NW; ++rr) Ld[EL_MX + (int)Ld[EL_T0 + rr] * NC + dst] = tmp[q * NW1 + rr];
-        }
+        for (int r = lane; r < NW; r += GS)
+          for (int kk = NW - 1; kk >= 0; --kk) {
+            const int pv = (int)Ld[EL_PV + kk];
+            if (pv != kk) {
+              const double t = Ld[EL_MX + r * NC + kk];
+              Ld[EL_MX + r * NC + kk] = Ld[EL_MX + r * NC + pv];
+              Ld[EL_MX + r * NC + pv] = t;
+            }
+          }
       }
       T.gsync();
     }
@@ -590,7 +583,7 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
         const int p = point_of_slot(sl);
         double t = Ld[EL_SG + row] * Ld[EL_MX + row * NC + NW + b];
         if (p >= 0) {
-          const double* Hp = Ld + EL_PT + p * PT_STRIDE + NX + NX * NA;
+          const double* Hp = mo + MO_PT + p * PT_STRIDE + NX + NX * NA;
           for (int a2 = 0; a2 < NX; ++a2) t += Hp[a * NA + a2] * Ld[EL_MX + (sl * NX + a2) * NC + NW + b];
         }
         if (b < NA) Ld[EL_T1 + row * NA + b] = t;
@@ -601,7 +594,7 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
         double t = 0.0;
         for (int p = 0; p < NCOLL; ++p) {
           const int sl = slot_of(p / DEG, p % DEG + 1);
-          const double* Hp = Ld + EL_PT + p * PT_STRIDE + NX + NX * NA;
+          const double* Hp = mo + MO_PT + p * PT_STRIDE + NX + NX * NA;
           for (int a = 0; a < NX; ++a) t += Hp[a * NA + NX + ub] * Ld[EL_MX + (sl * NX + a) * NC + NW + b];
         }
         Ld[EL_U1 + (b < NA ? ub * NA + b : NU * NA + ub)] = t;
@@ -612,8 +605,8 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
     if (act) {
       for (int it = lane; it < NA * NA; it += GS) {
         const int a1 = it / NA, b = it % NA;
-        double q = om * Ld[EL_LT + 1 + NA + it];
-        if (NE > 0) q += Ld[EL_NL + NE + NE * NA + it];
+        double q = om * mo[MO_LT + 1 + NA + it];
+        if (NE > 0) q += mo[MO_NL + NE + NE * NA + it];
         double ww = 0.0;
         for (int row = 0; row < NW; ++row) {
           const double wa = Ld[EL_MX + row * NC + NW + a1];
@@ -622,7 +615,7 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
         }
         if (a1 >= NX && b >= NX) {
           double h = 0.0;
-          for (int p = 0; p < NCOLL; ++p) h += Ld[EL_PT + p * PT_STRIDE + NX + NX * NA + a1 * NA + b];
+          for (int p = 0; p < NCOLL; ++p) h += mo[MO_PT + p * PT_STRIDE + NX + NX * NA + a1 * NA + b];
           q += h;
         }
         if (a1 >= NX) q += Ld[EL_U1 + (a1 - NX) * NA + b];
@@ -656,30 +649,30 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
         Q.EW(e, EW_RW + r) = Ld[EL_RW + r];
       }
       for (int it = lane; it < NCOLL * NA * NA; it += GS)
-        Q.EW(e, EW_HP + it) = Ld[EL_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + it % (NA * NA)];
+        Q.EW(e, EW_HP + it) = mo[MO_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + it % (NA * NA)];
     }
   }
   T.gsync();
   // ---- phase 7: stage cost / terminal cost / nl_cons shares (few values: lanes 0..)
   if (act) {
     for (int a = lane; a < NA; a += GS) {
-      double r = S_[ES_RY + a] + om * Ld[EL_LT + 1 + a];
+      double r = S_[ES_RY + a] + om * mo[MO_LT + 1 + a];
       if (NE > 0)
-        for (int i = 0; i < NE; ++i) r += Ld[EL_NL + NE + i * NA + a] * yd[i];
-      S_[ES_GFY + a] = om * Ld[EL_LT + 1 + a];
+        for (int i = 0; i < NE; ++i) r += mo[MO_NL + NE + i * NA + a] * yd[i];
+      S_[ES_GFY + a] = om * mo[MO_LT + 1 + a];
       S_[ES_RY + a] = r;
     }
     if (k == A.N - 1) {
-      for (int a = lane; a < NX; a += GS) S_[ES_MG + a] = om * Ld[EL_MT + 1 + a];
-      for (int a = lane; a < NX * NX; a += GS) S_[ES_MH + a] = om * Ld[EL_MT + 1 + NX + a];
+      for (int a = lane; a < NX; a += GS) S_[ES_MG + a] = om * mo[MO_MT + 1 + a];
+      for (int a = lane; a < NX * NX; a += GS) S_[ES_MH + a] = om * mo[MO_MT + 1 + NX + a];
     }
     if (lane == 0) {
-      double obj = om * Ld[EL_LT];
-      if (k == A.N - 1) obj += om * Ld[EL_MT];
+      double obj = om * mo[MO_LT];
+      if (k == A.N - 1) obj += om * mo[MO_MT];
       if (NE > 0) {
         const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
         for (int i = 0; i < NE; ++i) {
-          double d = Ld[EL_NL + i];
+          double d = mo[MO_NL + i];
           if (DOMPC_NL_SLACK[i] >= 0) d -= eps[DOMPC_NL_SLACK[i]];
           const int si = e * NE1 + i;
           const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
@@ -693,7 +686,7 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
       S_[ES_OBJ] = obj;
     }
     if (NE > 0)
-      for (int it = lane; it < NE * NA; it += GS) Q.EW(e, EW_JD + it) = Ld[EL_NL + NE + it];
+      for (int it = lane; it < NE * NA; it += GS) Q.EW(e, EW_JD + it) = mo[MO_NL + NE + it];
   }
   T.gsync();
   DOMPC_PH(3)
@@ -703,7 +696,7 @@ DOMPC_DEV inline int eval_edge_coop(const Thr& T, const Prob& Q, int e, double m
 
 // ================================================================================================
 // Gradient / dual-residual assembly for the variables owned by node n (x_n, u_n, eps_n).
-DOMPC_DEV inline void assemble_node(const Prob& Q, int n) {
+DOMPC_PHASE void assemble_node(const Prob& Q, int n) {
   const KArgs& A = *Q.A;
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const int xo = A.node_x_off[n];
@@ -773,16 +766,32 @@ DOMPC_DEV inline void assemble_node(const Prob& Q, int n) {
 // Children are summed at branching nodes (non-anticipativity = shared variables, _mpc.py:1212-1216).
 DOMPC_DEV inline int ycol(int yj) { return yj < NX ? yj : NA + (yj - NX); }
 
-DOMPC_DEV inline int riccati_backward(const Thr& T, const Prob& Q, double mu, double delta) {
+DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double delta) {
+  // One group of lanes (a wavefront) per tree node, the node's matrices staged in the group's LDS region:
+  //   RB_QO  own quadratic of the node over (x, u_prev, u, eps)       (NYT x NYT) + gradient
+  //   RB_QF  the same plus the children's value functions (coupling)  -> K = -Qvv^-1 Qvx
+  //   value function in closed-loop ("Joseph") form  P = Lc' QO Lc + sum_e Acl' P_c Acl,  Lc = [I;K],
+  //   Acl = Atilde Lc: the huge Sigma entries of active state bounds inside P_c meet closed-loop maps
+  //   that vanish in the constrained directions instead of being cancelled against each other
+  //   (Qxx - Qxv Qvv^-1 Qvx floors the KKT residual at ~Sigma_max*eps).
+  // Levels are processed leaves -> root with a workgroup barrier in between (children's P come from
+  // other groups through global memory).
   const KArgs& A = *Q.A;
+  constexpr int RB_QO = 0, RB_QOV = RB_QO + NYT * NYT, RB_QF = RB_QOV + NYT, RB_QFV = RB_QF + NYT * NYT;
+  constexpr int RB_PC = RB_QFV + NYT, RB_PCV = RB_PC + NA * NA, RB_AB = RB_PCV + NA, RB_CV = RB_AB + NX * NA;
+  constexpr int RB_TP = RB_CV + NX, RB_TV = RB_TP + NA * NA, RB_K = RB_TV + NA, RB_KV = RB_K + NV * NA;
+  constexpr int RB_ACL = RB_KV + NV, RB_CCL = RB_ACL + NA * NA, RB_PN = RB_CCL + NA, RB_PNV = RB_PN + NA * NA;
+  constexpr int RB_SIZE = RB_PNV + NA;
+  static_assert(RB_SIZE <= EL_SIZE, "node working set must fit the per-group LDS region");
+  const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
+  double* Ld = T.edge_lds + (int64_t)gid * EL_SIZE;
   if (T.tid == 0) T.flags[0] = 0;
   T.sync();
   for (int k = A.N; k >= 0; --k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
-    const int nn = n1 - n0;
     if (k == A.N) {
       // leaves: P = sf*omega*Hm + Sigma_x, p = sf*omega*gm - nu_in + barrier
-      for (int it = T.tid; it < nn * NA * (NA + 1); it += T.nt) {
+      for (int it = T.tid; it < (n1 - n0) * NA * (NA + 1); it += T.nt) {
         const int n = n0 + it / (NA * (NA + 1));
         const int r = it % (NA * (NA + 1));
         const int i = r / (NA + 1), j = r % (NA + 1);
@@ -807,265 +816,287 @@ DOMPC_DEV inline int riccati_backward(const Thr& T, const Prob& Q, double mu, do
       T.sync();
       continue;
     }
-    const int e0 = A.node_child_start[n0];
-    const int e1 = A.node_child_start[n1 - 1] + A.node_child_count[n1 - 1];
-    const int ne_ = e1 - e0;
-    // (a) per child edge: TP = P_c * Atilde (y columns), TV = P_c*ctilde + p_c
-    for (int it = T.tid; it < ne_ * NA * (NA + 1); it += T.nt) {
-      const int e = e0 + it / (NA * (NA + 1));
-      const int r = it % (NA * (NA + 1));
-      const int i = r / (NA + 1), yj = r % (NA + 1);
-      double* S_ = Q.ES(e);
-      const double* Pc = Q.ND(A.edge_child[e]) + ND_P;
-      if (yj < NA) {
-        double t = 0.0;
-        for (int a = 0; a < NX; ++a) t += Pc[i * NA + a] * S_[ES_AB + a * NA + yj];
-        if (yj >= NX) t += Pc[i * NA + NX + (yj - NX)];
-        S_[ES_TP + i * NA + yj] = t;
-      } else {
-        double t = Q.ND(A.edge_child[e])[ND_PV + i];
-        for (int a = 0; a < NX; ++a) t += Pc[i * NA + a] * S_[ES_CV + a];
-        S_[ES_TV + i] = t;
-      }
-    }
-    T.sync();
-    // (b) node quadratic Q (NYT x NYT) and q (NYT)
-    for (int it = T.tid; it < nn * NYT * (NYT + 1); it += T.nt) {
-      const int n = n0 + it / (NYT * (NYT + 1));
-      const int r = it % (NYT * (NYT + 1));
-      const int i = r / (NYT + 1), j = r % (NYT + 1);
+    for (int n = n0 + gid; n < n1; n += ng) {
       double* Nd = Q.ND(n);
       const int cs = A.node_child_start[n], cc = A.node_child_count[n];
       const int xo = A.node_x_off[n], uo = A.node_u_off[n];
       const int eo = NS > 0 ? A.node_eps_off[n] : -1;
+      const int ie = A.node_in_edge[n];
       const double rw = node_rweight(Q, n);
-      // classify index i (and j)
-      // 0..NX-1: x ; NX..NA-1: u_prev ; NA..NA+NU-1: u ; NA+NU.. : eps
-      const int yi = (i < NX) ? i : ((i >= NA && i < NA + NU) ? NX + (i - NA) : -1);   // y index or -1
-      if (j < NYT) {
-        const int yj2 = (j < NX) ? j : ((j >= NA && j < NA + NU) ? NX + (j - NA) : -1);
-        double v = 0.0, vc = 0.0;
-        if (i == j) {
-          if (i < NX) v += sigma_of(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], Q.zl[xo + i], Q.zu[xo + i]) + delta;
-          else if (i < NA) v += 2.0 * rw * DOMPC_RTERM[i - NX];
-          else if (i < NA + NU) {
-            const int g = uo + (i - NA);
-            v += 2.0 * rw * DOMPC_RTERM[i - NA] + sigma_of(Q.x[g], Q.lb[g], Q.ub[g], Q.zl[g], Q.zu[g]) + delta;
-          } else {
-            const int g = eo + (i - NA - NU);
-            v += sigma_of(Q.x[g], Q.lb[g], Q.ub[g], Q.zl[g], Q.zu[g]) + delta;
-          }
-        } else if (i >= NX && i < NA && j == i + NU) v -= 2.0 * rw * DOMPC_RTERM[i - NX];
-        else if (j >= NX && j < NA && i == j + NU) v -= 2.0 * rw * DOMPC_RTERM[j - NX];
-        for (int c = 0; c < cc; ++c) {
-          const int e = cs + c;
-          const double* S_ = Q.ES(e);
-          if (yi >= 0 && yj2 >= 0) {
-            v += S_[ES_QT + yi * NA + yj2] + delta * S_[ES_WTW + yi * NA + yj2];
-            double t = 0.0;
-            for (int a = 0; a < NX; ++a) t += S_[ES_AB + a * NA + yi] * S_[ES_TP + a * NA + yj2];
-            if (yi >= NX) t += S_[ES_TP + (NX + yi - NX) * NA + yj2];
-            vc += t;
-          }
-          if (NE > 0) {
-            for (int q = 0; q < NE; ++q) {
-              const double sg = S_[ES_SIGS + q] + delta;
-              double ji = 0.0, jj = 0.0;
-              if (yi >= 0) ji = Q.EW(e, EW_JD + q * NA + yi);
-              else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) ji = -1.0;
-              if (yj2 >= 0) jj = Q.EW(e, EW_JD + q * NA + yj2);
-              else if (j >= NA + NU && DOMPC_NL_SLACK[q] == j - NA - NU) jj = -1.0;
-              v += sg * ji * jj;
+      double utmp[NU];
+      const double* up = uprev_ptr(Q, n, Q.x, utmp);
+      // ---- own quadratic: bounds (Sigma), rterm, barrier gradients, slack penalty
+      for (int it = lane; it < NYT * (NYT + 1); it += GS) {
+        const int i = it / (NYT + 1), j = it % (NYT + 1);
+        double v = 0.0;
+        if (j < NYT) {
+          if (i == j) {
+            if (i < NX) v = sigma_of(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], Q.zl[xo + i], Q.zu[xo + i]) + delta;
+            else if (i < NA) v = 2.0 * rw * DOMPC_RTERM[i - NX];
+            else if (i < NA + NU) {
+              const int g = uo + (i - NA);
+              v = 2.0 * rw * DOMPC_RTERM[i - NA] + sigma_of(Q.x[g], Q.lb[g], Q.ub[g], Q.zl[g], Q.zu[g]) + delta;
+            } else {
+              const int g = eo + (i - NA - NU);
+              v = sigma_of(Q.x[g], Q.lb[g], Q.ub[g], Q.zl[g], Q.zu[g]) + delta;
             }
-          }
-        }
-        Nd[ND_Q + i * NYT + j] = v + vc;
-        Nd[ND_QO + i * NYT + j] = v;
-      } else {
-        double v = 0.0, vc = 0.0;
-        double tmp[NU];
-        if (i < NX) {
-          const int ie = A.node_in_edge[n];
-          v += (ie >= 0) ? -Q.lam[A.edge_row0[ie] + NW + i] : Q.lam[i];
-          v += bar_grad(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], mu);
-        } else if (i < NA) {
-          const double* up = uprev_ptr(Q, n, Q.x, tmp);
-          v -= 2.0 * rw * DOMPC_RTERM[i - NX] * (Q.x[uo + i - NX] - up[i - NX]);
-        } else if (i < NA + NU) {
-          const double* up = uprev_ptr(Q, n, Q.x, tmp);
-          const int g = uo + (i - NA);
-          v += 2.0 * rw * DOMPC_RTERM[i - NA] * (Q.x[g] - up[i - NA]) + bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu);
+          } else if (i >= NX && i < NA && j == i + NU) v = -2.0 * rw * DOMPC_RTERM[i - NX];
+          else if (j >= NX && j < NA && i == j + NU) v = -2.0 * rw * DOMPC_RTERM[j - NX];
+          Ld[RB_QO + i * NYT + j] = v;
+          Ld[RB_QF + i * NYT + j] = 0.0;
         } else {
-          const int q = i - NA - NU;
-          const int g = eo + q;
-          v += cc * Q.sf * DOMPC_EPS_PEN[q] + bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu);
-        }
-        for (int c = 0; c < cc; ++c) {
-          const int e = cs + c;
-          const double* S_ = Q.ES(e);
-          if (yi >= 0) {
-            v += S_[ES_RY + yi] + S_[ES_QV + yi] + delta * S_[ES_WTW0 + yi];
-            double t = 0.0;
-            for (int a = 0; a < NX; ++a) t += S_[ES_AB + a * NA + yi] * S_[ES_TV + a];
-            if (yi >= NX) t += S_[ES_TV + yi];
-            vc += t;
+          if (i < NX) {
+            v = (ie >= 0) ? -Q.lam[A.edge_row0[ie] + NW + i] : Q.lam[i];
+            v += bar_grad(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], mu);
+          } else if (i < NA) {
+            v = -2.0 * rw * DOMPC_RTERM[i - NX] * (Q.x[uo + i - NX] - up[i - NX]);
+          } else if (i < NA + NU) {
+            const int g = uo + (i - NA);
+            v = 2.0 * rw * DOMPC_RTERM[i - NA] * (Q.x[g] - up[i - NA]) + bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu);
+          } else {
+            const int q = i - NA - NU, g = eo + q;
+            v = cc * Q.sf * DOMPC_EPS_PEN[q] + bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu);
           }
-          if (NE > 0) {
-            const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
+          Ld[RB_QOV + i] = v;
+          Ld[RB_QFV + i] = 0.0;
+        }
+      }
+      T.gsync();
+      // ---- children, pass 1: condensed edge blocks into QO, coupling Atilde' P_c Atilde into QF
+      for (int c = 0; c < cc; ++c) {
+        const int e = cs + c;
+        const double* S_ = Q.ES(e);
+        const double* Nc = Q.ND(A.edge_child[e]);
+        for (int it = lane; it < NA * NA; it += GS) Ld[RB_PC + it] = Nc[ND_P + it];
+        for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Nc[ND_PV + it];
+        for (int it = lane; it < NX * NA; it += GS) Ld[RB_AB + it] = S_[ES_AB + it];
+        for (int it = lane; it < NX; it += GS) Ld[RB_CV + it] = S_[ES_CV + it];
+        for (int it = lane; it < NA * (NA + 1); it += GS) {
+          const int yi = it / (NA + 1), yj = it % (NA + 1);
+          const int i = ycol(yi);
+          if (yj < NA) Ld[RB_QO + i * NYT + ycol(yj)] += S_[ES_QT + yi * NA + yj] + delta * S_[ES_WTW + yi * NA + yj];
+          else Ld[RB_QOV + i] += S_[ES_RY + yi] + S_[ES_QV + yi] + delta * S_[ES_WTW0 + yi];
+        }
+        T.gsync();
+        if (NE > 0) {
+          const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
+          for (int it = lane; it < NYT * (NYT + 1); it += GS) {
+            const int i = it / (NYT + 1), j = it % (NYT + 1);
+            const int yi = (i < NX) ? i : ((i >= NA && i < NA + NU) ? NX + (i - NA) : -1);
+            double acc = 0.0;
             for (int q = 0; q < NE; ++q) {
               const double sg = S_[ES_SIGS + q] + delta;
               double ji = 0.0;
               if (yi >= 0) ji = Q.EW(e, EW_JD + q * NA + yi);
-              else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) { ji = -1.0; v -= yd[q]; }
-              v += ji * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
+              else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) ji = -1.0;
+              if (j < NYT) {
+                const int yj = (j < NX) ? j : ((j >= NA && j < NA + NU) ? NX + (j - NA) : -1);
+                double jj = 0.0;
+                if (yj >= 0) jj = Q.EW(e, EW_JD + q * NA + yj);
+                else if (j >= NA + NU && DOMPC_NL_SLACK[q] == j - NA - NU) jj = -1.0;
+                acc += sg * ji * jj;
+              } else {
+                if (yi < 0 && ji != 0.0) acc -= yd[q];
+                acc += ji * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
+              }
+            }
+            if (j < NYT) Ld[RB_QO + i * NYT + j] += acc;
+            else Ld[RB_QOV + i] += acc;
+          }
+          T.gsync();
+        }
+        // TP = P_c Atilde (y columns), TV = P_c ctilde + p_c
+        for (int it = lane; it < NA * (NA + 1); it += GS) {
+          const int i = it / (NA + 1), yj = it % (NA + 1);
+          if (yj < NA) {
+            double t = 0.0;
+#pragma unroll
+            for (int a = 0; a < NX; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_AB + a * NA + yj];
+            if (yj >= NX) t += Ld[RB_PC + i * NA + yj];
+            Ld[RB_TP + i * NA + yj] = t;
+          } else {
+            double t = Ld[RB_PCV + i];
+#pragma unroll
+            for (int a = 0; a < NX; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CV + a];
+            Ld[RB_TV + i] = t;
+          }
+        }
+        T.gsync();
+        for (int it = lane; it < NA * (NA + 1); it += GS) {
+          const int yi = it / (NA + 1), yj = it % (NA + 1);
+          const int i = ycol(yi);
+          if (yj < NA) {
+            double t = 0.0;
+#pragma unroll
+            for (int a = 0; a < NX; ++a) t += Ld[RB_AB + a * NA + yi] * Ld[RB_TP + a * NA + yj];
+            if (yi >= NX) t += Ld[RB_TP + yi * NA + yj];
+            Ld[RB_QF + i * NYT + ycol(yj)] += t;
+          } else {
+            double t = 0.0;
+#pragma unroll
+            for (int a = 0; a < NX; ++a) t += Ld[RB_AB + a * NA + yi] * Ld[RB_TV + a];
+            if (yi >= NX) t += Ld[RB_TV + yi];
+            Ld[RB_QFV + i] += t;
+          }
+        }
+        T.gsync();
+      }
+      // QF = QO + coupling
+      for (int it = lane; it < NYT * (NYT + 1); it += GS) {
+        const int i = it / (NYT + 1), j = it % (NYT + 1);
+        if (j < NYT) Ld[RB_QF + i * NYT + j] += Ld[RB_QO + i * NYT + j];
+        else Ld[RB_QFV + i] += Ld[RB_QOV + i];
+      }
+      T.gsync();
+      // ---- Cholesky of Qvv and K = -Qvv^-1 Qvx, kv = -Qvv^-1 qv  (one lane per column)
+      int bad = 0;
+      for (int j = lane; j < NA + 1; j += GS) {
+        double L[NV * NV];
+        for (int i = 0; i < NV; ++i)
+          for (int jj = 0; jj <= i; ++jj) {
+            double t = Ld[RB_QF + (NA + i) * NYT + NA + jj];
+            for (int q = 0; q < jj; ++q) t -= L[i * NV + q] * L[jj * NV + q];
+            if (i == jj) {
+              if (!(t > 0.0)) { bad = 1; t = 1.0; }
+              L[i * NV + i] = sqrt(t);
+            } else {
+              L[i * NV + jj] = t / L[jj * NV + jj];
             }
           }
+        double y[NV];
+        for (int i = 0; i < NV; ++i) {
+          double t = (j < NA) ? Ld[RB_QF + (NA + i) * NYT + j] : Ld[RB_QFV + NA + i];
+          for (int q = 0; q < i; ++q) t -= L[i * NV + q] * y[q];
+          y[i] = t / L[i * NV + i];
         }
-        Nd[ND_QV + i] = v + vc;
-        Nd[ND_QOV + i] = v;
+        for (int i = NV - 1; i >= 0; --i) {
+          double t = y[i];
+          for (int q = i + 1; q < NV; ++q) t -= L[q * NV + i] * y[q];
+          y[i] = t / L[i * NV + i];
+        }
+        for (int i = 0; i < NV; ++i) {
+          if (j < NA) { Ld[RB_K + i * NA + j] = -y[i]; Nd[ND_K + i * NA + j] = -y[i]; }
+          else { Ld[RB_KV + i] = -y[i]; Nd[ND_KV + i] = -y[i]; }
+        }
       }
-    }
-    T.sync();
-    // (c) Cholesky of Qvv (thread per node)
-    for (int it = T.tid; it < nn; it += T.nt) {
-      double* Nd = Q.ND(n0 + it);
-      double L[NV * NV];
-      int bad = 0;
-      for (int i = 0; i < NV; ++i)
-        for (int j = 0; j <= i; ++j) {
-          double t = Nd[ND_Q + (NA + i) * NYT + NA + j];
-          for (int q = 0; q < j; ++q) t -= L[i * NV + q] * L[j * NV + q];
-          if (i == j) {
-            if (!(t > 0.0)) { bad = 1; t = 1.0; }
-            L[i * NV + i] = sqrt(t);
+      if (bad) T.flags[0] = 1;
+      T.gsync();
+      // ---- PN = Lc' QO Lc ; pn = Lc'(QO l0 + qo),  l0 = [0; kv]
+      for (int it = lane; it < NA * (NA + 1); it += GS) {
+        const int i = it / (NA + 1), j = it % (NA + 1);
+        if (j < NA) {
+          double t = Ld[RB_QO + i * NYT + j];
+#pragma unroll
+          for (int q = 0; q < NV; ++q) {
+            t += Ld[RB_QO + i * NYT + NA + q] * Ld[RB_K + q * NA + j];
+            t += Ld[RB_K + q * NA + i] * Ld[RB_QO + (NA + q) * NYT + j];
+            double t2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < NV; ++w) t2 += Ld[RB_QO + (NA + q) * NYT + NA + w] * Ld[RB_K + w * NA + j];
+            t += Ld[RB_K + q * NA + i] * t2;
+          }
+          Ld[RB_PN + i * NA + j] = t;
+        } else {
+          double t = Ld[RB_QOV + i];
+#pragma unroll
+          for (int w = 0; w < NV; ++w) t += Ld[RB_QO + i * NYT + NA + w] * Ld[RB_KV + w];
+#pragma unroll
+          for (int q = 0; q < NV; ++q) {
+            double t2 = Ld[RB_QOV + NA + q];
+#pragma unroll
+            for (int w = 0; w < NV; ++w) t2 += Ld[RB_QO + (NA + q) * NYT + NA + w] * Ld[RB_KV + w];
+            t += Ld[RB_K + q * NA + i] * t2;
+          }
+          Ld[RB_PNV + i] = t;
+        }
+      }
+      T.gsync();
+      // ---- children, pass 2: PN += Acl' P_c Acl, pn += Acl'(P_c ccl + p_c)
+      for (int c = 0; c < cc; ++c) {
+        const int e = cs + c;
+        const double* S_ = Q.ES(e);
+        const double* Nc = Q.ND(A.edge_child[e]);
+        if (cc > 1) {     // (for a single child PC/AB/CV are still staged from pass 1)
+          for (int it = lane; it < NA * NA; it += GS) Ld[RB_PC + it] = Nc[ND_P + it];
+          for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Nc[ND_PV + it];
+          for (int it = lane; it < NX * NA; it += GS) Ld[RB_AB + it] = S_[ES_AB + it];
+          for (int it = lane; it < NX; it += GS) Ld[RB_CV + it] = S_[ES_CV + it];
+          T.gsync();
+        }
+        for (int it = lane; it < NA * (NA + 1); it += GS) {
+          const int i = it / (NA + 1), j = it % (NA + 1);
+          double t;
+          if (j < NA) {
+            if (i < NX) {
+              t = (j < NX) ? Ld[RB_AB + i * NA + j] : 0.0;
+#pragma unroll
+              for (int u = 0; u < NU; ++u) t += Ld[RB_AB + i * NA + NX + u] * Ld[RB_K + u * NA + j];
+            } else {
+              t = Ld[RB_K + (i - NX) * NA + j];
+            }
+            Ld[RB_ACL + i * NA + j] = t;
           } else {
-            L[i * NV + j] = t / L[j * NV + j];
+            if (i < NX) {
+              t = Ld[RB_CV + i];
+#pragma unroll
+              for (int u = 0; u < NU; ++u) t += Ld[RB_AB + i * NA + NX + u] * Ld[RB_KV + u];
+            } else {
+              t = Ld[RB_KV + i - NX];
+            }
+            Ld[RB_CCL + i] = t;
           }
         }
-      for (int i = 0; i < NV; ++i)
-        for (int j = 0; j <= i; ++j) Nd[ND_L + i * NV + j] = L[i * NV + j];
-      if (bad) T.flags[0] = 1;
+        T.gsync();
+        for (int it = lane; it < NA * (NA + 1); it += GS) {
+          const int i = it / (NA + 1), j = it % (NA + 1);
+          if (j < NA) {
+            double t = 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_ACL + a * NA + j];
+            Ld[RB_TP + i * NA + j] = t;
+          } else {
+            double t = Ld[RB_PCV + i];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CCL + a];
+            Ld[RB_TV + i] = t;
+          }
+        }
+        T.gsync();
+        for (int it = lane; it < NA * (NA + 1); it += GS) {
+          const int i = it / (NA + 1), j = it % (NA + 1);
+          if (j < NA) {
+            double t = 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) t += Ld[RB_ACL + a * NA + i] * Ld[RB_TP + a * NA + j];
+            Ld[RB_PN + i * NA + j] += t;
+          } else {
+            double t = 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) t += Ld[RB_ACL + a * NA + i] * Ld[RB_TV + a];
+            Ld[RB_PNV + i] += t;
+          }
+        }
+        T.gsync();
+      }
+      for (int it = lane; it < NA * NA; it += GS) Nd[ND_P + it] = Ld[RB_PN + it];
+      for (int it = lane; it < NA; it += GS) Nd[ND_PV + it] = Ld[RB_PNV + it];
+      T.gsync();
     }
     T.sync();
     if (T.flags[0]) return 1;
-    // (d) K = -Qvv^-1 Qvx, kv = -Qvv^-1 qv  (thread per (node, column))
-    for (int it = T.tid; it < nn * (NA + 1); it += T.nt) {
-      double* Nd = Q.ND(n0 + it / (NA + 1));
-      const int j = it % (NA + 1);
-      double y[NV];
-      for (int i = 0; i < NV; ++i) {
-        double t = (j < NA) ? Nd[ND_Q + (NA + i) * NYT + j] : Nd[ND_QV + NA + i];
-        for (int q = 0; q < i; ++q) t -= Nd[ND_L + i * NV + q] * y[q];
-        y[i] = t / Nd[ND_L + i * NV + i];
-      }
-      for (int i = NV - 1; i >= 0; --i) {
-        double t = y[i];
-        for (int q = i + 1; q < NV; ++q) t -= Nd[ND_L + q * NV + i] * y[q];
-        y[i] = t / Nd[ND_L + i * NV + i];
-      }
-      for (int i = 0; i < NV; ++i) {
-        if (j < NA) Nd[ND_K + i * NA + j] = -y[i];
-        else Nd[ND_KV + i] = -y[i];
-      }
-    }
-    T.sync();
-    // (e) value function in closed-loop ("Joseph") form.  P = Lc' Qown Lc + sum_e Acl' P_c Acl with
-    //     Lc = [I;K], Acl = Atilde*Lc:  the huge Sigma entries of active state bounds inside P_c are
-    //     multiplied by closed-loop maps that are ~0 in the constrained directions, instead of being
-    //     cancelled against each other as in Qxx - Qxv Qvv^-1 Qvx (which floors the KKT residual at
-    //     ~Sigma_max * eps).
-    // (e1) per child edge: Acl (NA x NA), ccl (NA)
-    for (int it = T.tid; it < ne_ * NA * (NA + 1); it += T.nt) {
-      const int e = e0 + it / (NA * (NA + 1));
-      const int r = it % (NA * (NA + 1));
-      const int i = r / (NA + 1), j = r % (NA + 1);
-      double* S_ = Q.ES(e);
-      const double* Nd = Q.ND(A.edge_parent[e]);
-      if (j < NA) {
-        double t;
-        if (i < NX) {
-          t = (j < NX) ? S_[ES_AB + i * NA + j] : 0.0;
-          for (int u = 0; u < NU; ++u) t += S_[ES_AB + i * NA + NX + u] * Nd[ND_K + u * NA + j];
-        } else {
-          t = Nd[ND_K + (i - NX) * NA + j];
-        }
-        S_[ES_ACL + i * NA + j] = t;
-      } else {
-        double t;
-        if (i < NX) {
-          t = S_[ES_CV + i];
-          for (int u = 0; u < NU; ++u) t += S_[ES_AB + i * NA + NX + u] * Nd[ND_KV + u];
-        } else {
-          t = Nd[ND_KV + i - NX];
-        }
-        S_[ES_CCL + i] = t;
-      }
-    }
-    T.sync();
-    // (e2) per child edge: TP = P_c Acl, TV = P_c ccl + p_c
-    for (int it = T.tid; it < ne_ * NA * (NA + 1); it += T.nt) {
-      const int e = e0 + it / (NA * (NA + 1));
-      const int r = it % (NA * (NA + 1));
-      const int i = r / (NA + 1), j = r % (NA + 1);
-      double* S_ = Q.ES(e);
-      const double* Nc = Q.ND(A.edge_child[e]);
-      if (j < NA) {
-        double t = 0.0;
-        for (int a = 0; a < NA; ++a) t += Nc[ND_P + i * NA + a] * S_[ES_ACL + a * NA + j];
-        S_[ES_TP + i * NA + j] = t;
-      } else {
-        double t = Nc[ND_PV + i];
-        for (int a = 0; a < NA; ++a) t += Nc[ND_P + i * NA + a] * S_[ES_CCL + a];
-        S_[ES_TV + i] = t;
-      }
-    }
-    T.sync();
-    // (e3) per node: P, p
-    for (int it = T.tid; it < nn * NA * (NA + 1); it += T.nt) {
-      const int n = n0 + it / (NA * (NA + 1));
-      double* Nd = Q.ND(n);
-      const int r = it % (NA * (NA + 1));
-      const int i = r / (NA + 1), j = r % (NA + 1);
-      const int cs = A.node_child_start[n], cc = A.node_child_count[n];
-      // column i of Lc = [e_i ; K[:,i]]
-      if (j < NA) {
-        double t = Nd[ND_QO + i * NYT + j];
-        for (int q = 0; q < NV; ++q) {
-          t += Nd[ND_QO + i * NYT + NA + q] * Nd[ND_K + q * NA + j];
-          t += Nd[ND_K + q * NA + i] * Nd[ND_QO + (NA + q) * NYT + j];
-          double t2 = 0.0;
-          for (int w = 0; w < NV; ++w) t2 += Nd[ND_QO + (NA + q) * NYT + NA + w] * Nd[ND_K + w * NA + j];
-          t += Nd[ND_K + q * NA + i] * t2;
-        }
-        for (int c = 0; c < cc; ++c) {
-          const double* S_ = Q.ES(cs + c);
-          for (int a = 0; a < NA; ++a) t += S_[ES_ACL + a * NA + i] * S_[ES_TP + a * NA + j];
-        }
-        Nd[ND_P + i * NA + j] = t;
-      } else {
-        // p = Lc' (Qown l0 + qown) + sum Acl' (P_c ccl + p_c),  l0 = [0; kv]
-        double t = Nd[ND_QOV + i];
-        for (int w = 0; w < NV; ++w) t += Nd[ND_QO + i * NYT + NA + w] * Nd[ND_KV + w];
-        for (int q = 0; q < NV; ++q) {
-          double t2 = Nd[ND_QOV + NA + q];
-          for (int w = 0; w < NV; ++w) t2 += Nd[ND_QO + (NA + q) * NYT + NA + w] * Nd[ND_KV + w];
-          t += Nd[ND_K + q * NA + i] * t2;
-        }
-        for (int c = 0; c < cc; ++c) {
-          const double* S_ = Q.ES(cs + c);
-          for (int a = 0; a < NA; ++a) t += S_[ES_ACL + a * NA + i] * S_[ES_TV + a];
-        }
-        Nd[ND_PV + i] = t;
-      }
-    }
-    T.sync();
   }
   return 0;
 }
 
 // Forward sweep: steps for node variables, then per edge the collocation steps and multipliers.
-DOMPC_DEV inline void riccati_forward(const Thr& T, const Prob& Q, double mu, double delta) {
+// One group of lanes per node (level by level), then one group per edge.
+DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double delta) {
   const KArgs& A = *Q.A;
+  const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
+  double* Ld = T.edge_lds + (int64_t)gid * EL_SIZE;
+  constexpr int RF_DX = 0, RF_DV = RF_DX + NA, RF_DY = RF_DV + NV, RF_DNU = RF_DY + NA, RF_DW = RF_DNU + NX,
+                RF_RHS = RF_DW + NW1;
+  static_assert(RF_RHS + NW1 <= EL_SIZE, "forward working set must fit the per-group LDS region");
   // root
   if (T.tid == 0) {
     double* Nd = Q.ND(0);
@@ -1076,104 +1107,106 @@ DOMPC_DEV inline void riccati_forward(const Thr& T, const Prob& Q, double mu, do
   T.sync();
   for (int k = 0; k < A.N; ++k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
-    for (int n = n0 + T.tid; n < n1; n += T.nt) {
-      double* Nd = Q.ND(n);
-      double dv[NV];
-      for (int i = 0; i < NV; ++i) {
+    for (int n = n0 + gid; n < n1; n += ng) {
+      const double* Nd = Q.ND(n);
+      for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Nd[ND_DXT + a];
+      T.gsync();
+      for (int i = lane; i < NV; i += GS) {
         double t = Nd[ND_KV + i];
-        for (int a = 0; a < NA; ++a) t += Nd[ND_K + i * NA + a] * Nd[ND_DXT + a];
-        dv[i] = t;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) t += Nd[ND_K + i * NA + a] * Ld[RF_DX + a];
+        Ld[RF_DV + i] = t;
+        if (i < NU) Q.dx[A.node_u_off[n] + i] = t;
+        else Q.dx[A.node_eps_off[n] + i - NU] = t;
       }
-      const int uo = A.node_u_off[n];
-      for (int i = 0; i < NU; ++i) Q.dx[uo + i] = dv[i];
-      if (NS > 0) for (int q = 0; q < NS; ++q) Q.dx[A.node_eps_off[n] + q] = dv[NU + q];
+      T.gsync();
       const int cs = A.node_child_start[n], cc = A.node_child_count[n];
-      for (int c = 0; c < cc; ++c) {
-        const int e = cs + c, cn = A.edge_child[e];
+      for (int it = lane; it < cc * NA; it += GS) {
+        const int e = cs + it / NA, a = it % NA, cn = A.edge_child[e];
         const double* S_ = Q.ES(e);
-        double* Nc = Q.ND(cn);
-        for (int a = 0; a < NX; ++a) {
-          double t = S_[ES_CV + a];
-          for (int b = 0; b < NX; ++b) t += S_[ES_AB + a * NA + b] * Nd[ND_DXT + b];
-          for (int b = 0; b < NU; ++b) t += S_[ES_AB + a * NA + NX + b] * dv[b];
-          Nc[ND_DXT + a] = t;
+        double t;
+        if (a < NX) {
+          t = S_[ES_CV + a];
+#pragma unroll
+          for (int b = 0; b < NX; ++b) t += S_[ES_AB + a * NA + b] * Ld[RF_DX + b];
+#pragma unroll
+          for (int b = 0; b < NU; ++b) t += S_[ES_AB + a * NA + NX + b] * Ld[RF_DV + b];
           Q.dx[A.node_x_off[cn] + a] = t;
+        } else {
+          t = Ld[RF_DV + a - NX];
         }
-        for (int b = 0; b < NU; ++b) Nc[ND_DXT + NX + b] = dv[b];
+        Q.ND(cn)[ND_DXT + a] = t;
       }
+      T.gsync();
     }
     T.sync();
   }
   // initial-condition multiplier step
-  if (T.tid == 0) {
+  for (int a = T.tid; a < NX; a += T.nt) {
     const double* Nd = Q.ND(0);
-    for (int a = 0; a < NX; ++a) {
-      double t = Nd[ND_PV + a];
-      for (int b = 0; b < NA; ++b) t += Nd[ND_P + a * NA + b] * Nd[ND_DXT + b];
-      Q.dlam[a] = -t;
-    }
+    double t = Nd[ND_PV + a];
+    for (int b = 0; b < NA; ++b) t += Nd[ND_P + a * NA + b] * Nd[ND_DXT + b];
+    Q.dlam[a] = -t;
   }
   // per edge: dw, d nu, d lambda, nl_cons steps
-  for (int e = T.tid; e < A.n_edges; e += T.nt) {
+  for (int e = gid; e < A.n_edges; e += ng) {
     const int n = A.edge_parent[e], cn = A.edge_child[e];
     const double* Nd = Q.ND(n);
     const double* Nc = Q.ND(cn);
     const int row0 = A.edge_row0[e];
-    double dy[NA];
-    for (int a = 0; a < NX; ++a) dy[a] = Nd[ND_DXT + a];
-    for (int b = 0; b < NU; ++b) dy[NX + b] = Q.dx[A.node_u_off[n] + b];
-    double dnu[NX];
-    for (int a = 0; a < NX; ++a) {
+    for (int a = lane; a < NA; a += GS) Ld[RF_DY + a] = (a < NX) ? Nd[ND_DXT + a] : Q.dx[A.node_u_off[n] + a - NX];
+    for (int a = lane; a < NX; a += GS) {
       double t = Nc[ND_PV + a];
+#pragma unroll
       for (int b = 0; b < NA; ++b) t += Nc[ND_P + a * NA + b] * Nc[ND_DXT + b];
-      dnu[a] = t;
+      Ld[RF_DNU + a] = t;
       Q.dlam[row0 + NW + a] = t;
     }
+    T.gsync();
     if (M > 0) {
       const int woff = A.edge_w_off[e];
-      double dw[NW1], rhs[NW1];
-      for (int r = 0; r < NW; ++r) {
+      for (int r = lane; r < NW; r += GS) {
         double t = Q.EW(e, EW_W0 + r);
-        for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_W + r * NA + b) * dy[b];
-        dw[r] = t;
+#pragma unroll
+        for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_W + r * NA + b) * Ld[RF_DY + b];
+        Ld[RF_DW + r] = t;
         Q.dx[woff + r] = t;
       }
-      // rhs = -(rw + (Hww+delta) dw + Hwu du + S' dnu)
-      for (int r = 0; r < NW; ++r) {
-        double t = Q.EW(e, EW_RW + r) + (Q.EW(e, EW_SIGW + r) + delta) * dw[r];
-        if (r >= (M - 1) * NX) t += dnu[r - (M - 1) * NX];
-        rhs[r] = t;
-      }
-      for (int i = 0; i < NI; ++i)
-        for (int j = 1; j <= DEG; ++j) {
-          const int sl = slot_of(i, j), pt = i * DEG + (j - 1);
-          for (int a = 0; a < NX; ++a) {
-            double t = 0.0;
-            for (int b = 0; b < NX; ++b) t += Q.EW(e, EW_HP + pt * NA * NA + a * NA + b) * dw[sl * NX + b];
-            for (int b = 0; b < NU; ++b) t += Q.EW(e, EW_HP + pt * NA * NA + a * NA + NX + b) * dy[NX + b];
-            rhs[sl * NX + a] += t;
-          }
+      T.gsync();
+      // rhs = -(rw + (Sigma_w+delta) dw + Hww dw + Hwu du + S' dnu)
+      for (int r = lane; r < NW; r += GS) {
+        double t = Q.EW(e, EW_RW + r) + (Q.EW(e, EW_SIGW + r) + delta) * Ld[RF_DW + r];
+        if (r >= (M - 1) * NX) t += Ld[RF_DNU + r - (M - 1) * NX];
+        const int sl = r / NX, a = r % NX;
+        const int p = point_of_slot(sl);
+        if (p >= 0) {
+#pragma unroll
+          for (int b = 0; b < NX; ++b) t += Q.EW(e, EW_HP + p * NA * NA + a * NA + b) * Ld[RF_DW + sl * NX + b];
+#pragma unroll
+          for (int b = 0; b < NU; ++b) t += Q.EW(e, EW_HP + p * NA * NA + a * NA + NX + b) * Ld[RF_DY + NX + b];
         }
-      for (int r = 0; r < NW; ++r) rhs[r] = -rhs[r];
-      // d lambda = G_w^-T rhs  (EW_LU holds G_w^-1)
-      for (int r = 0; r < NW; ++r) {
-        double t = 0.0;
-        for (int q = 0; q < NW; ++q) t += Q.EW(e, EW_LU + q * NW + r) * rhs[q];
-        dw[r] = t;
+        Ld[RF_RHS + r] = -t;
       }
-      for (int r = 0; r < NW; ++r) rhs[r] = dw[r];
-      for (int r = 0; r < NW; ++r) Q.dlam[row0 + r] = rhs[r];
+      T.gsync();
+      // d lambda = G_w^-T rhs  (EW_LU holds G_w^-1, row-major: lanes read consecutive addresses)
+      for (int r = lane; r < NW; r += GS) {
+        double t = 0.0;
+#pragma unroll 6
+        for (int q = 0; q < NW; ++q) t += Q.EW(e, EW_LU + q * NW + r) * Ld[RF_RHS + q];
+        Q.dlam[row0 + r] = t;
+      }
     }
     if (NE > 0) {
       const double* S_ = Q.ES(e);
-      for (int i = 0; i < NE; ++i) {
+      for (int i = lane; i < NE; i += GS) {
         double t = S_[ES_RDN + i];
-        for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_JD + i * NA + b) * dy[b];
+        for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_JD + i * NA + b) * Ld[RF_DY + b];
         if (DOMPC_NL_SLACK[i] >= 0) t -= Q.dx[A.node_eps_off[n] + DOMPC_NL_SLACK[i]];
         Q.ds[e * NE1 + i] = t;
         Q.dlam[row0 + NW + NX + i] = (S_[ES_SIGS + i] + delta) * t + S_[ES_RSN + i];
       }
     }
+    T.gsync();
   }
   // dummies (variables in no constraint / cost): independent scalar Newton steps
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
@@ -1229,7 +1262,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
 }
 
 // error measures (IPOPT eq. (5)/(6)) + objective + theta at the current iterate
-DOMPC_DEV inline Errs measure(const Thr& T, const Prob& Q, double mu_c) {
+DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, double mu_c) {
   const KArgs& A = *Q.A;
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // e_d, e_p, e_c, sum|y|, sum z, obj, theta
   for (int g = T.tid; g < A.n_opt_x; g += T.nt) {
