@@ -1,0 +1,61 @@
+"""Minimal `casadi` / `casadi.tools` / `do_mpc` stand-ins so that the reference's shipped
+`template_model.py` / `template_mpc.py` files run *un-edited* on this backend.
+
+The templates start with `from casadi import *`, `from casadi.tools import *`, `import do_mpc`
+(/root/reference/examples/industrial_poly/template_model.py:23-30).  CasADi is not installable in
+the build/bench images, and on the hot path we do not want its VM anyway (the model is lowered to
+gfx950 code), so `install()` registers small modules in `sys.modules` that expose exactly the names
+those files touch, backed by do_mpc_amd.sym / do_mpc_amd.model / do_mpc_amd.controller.
+With real CasADi installed do not call install(); use the ctypes stub of INTEGRATION.md instead.
+"""
+import sys
+import types
+
+from . import controller, model, structs, sym
+
+_CASADI_NAMES = [
+    "SX", "DM", "vertcat", "horzcat", "mtimes", "sum1", "sum2", "sumsqr", "dot", "exp", "log", "sqrt", "sin",
+    "cos", "tan", "tanh", "sinh", "cosh", "asin", "acos", "atan", "fabs", "fmin", "fmax", "jacobian",
+    "gradient", "hessian", "substitute", "Function",
+]
+
+
+def install(force: bool = False):
+    """Register the stand-in modules.  Returns the list of module names that were installed."""
+    installed = []
+    if force or "casadi" not in sys.modules:
+        cas = types.ModuleType("casadi")
+        cas.__doc__ = "do_mpc_amd stand-in for the subset of CasADi used by do-mpc model/controller templates"
+        for n in _CASADI_NAMES:
+            setattr(cas, n, getattr(sym, n))
+        cas.MX = sym.SX                      # both symbol flavours map onto the same scalar DAG
+        cas.inf = float("inf")
+        cas.pi = 3.141592653589793
+        cas.__all__ = _CASADI_NAMES + ["MX", "inf", "pi"]
+        tools = types.ModuleType("casadi.tools")
+        tools.entry = structs.entry
+        tools.__all__ = ["entry"]
+        cas.tools = tools
+        sys.modules["casadi"] = cas
+        sys.modules["casadi.tools"] = tools
+        installed += ["casadi", "casadi.tools"]
+    if force or "do_mpc" not in sys.modules:
+        dm = types.ModuleType("do_mpc")
+        dm.__doc__ = "do_mpc_amd stand-in exposing do_mpc.model.Model and do_mpc.controller.MPC"
+        m_model = types.ModuleType("do_mpc.model")
+        m_model.Model = model.Model
+        m_ctrl = types.ModuleType("do_mpc.controller")
+        m_ctrl.MPC = controller.MPC
+        m_ctrl.MPCSettings = controller.MPCSettings
+        dm.model, dm.controller = m_model, m_ctrl
+        dm.__version__ = "5.1.1+dompc_amd"
+        sys.modules["do_mpc"] = dm
+        sys.modules["do_mpc.model"] = m_model
+        sys.modules["do_mpc.controller"] = m_ctrl
+        installed += ["do_mpc", "do_mpc.model", "do_mpc.controller"]
+    return installed
+
+
+def uninstall(names):
+    for n in names:
+        sys.modules.pop(n, None)
