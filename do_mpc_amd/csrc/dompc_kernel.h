@@ -188,6 +188,49 @@ DOMPC_DEV void wg_reduce(const Thr& T, double (&v)[N_], const int (&op)[N_]) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small dense product for one lane group:  D (m x n, row-major, ldd) = beta*D + op(A) (m x k) * op(B) (k x n)
+// with A(i,l) = A[i*sai + l*sal], B(l,j) = B[l*sbl + j*sbj].  Every lane of the group must call it; the
+// caller separates it from producers/consumers of the operands with gsync().
+// Device: the FP64 matrix cores, v_mfma_f64_16x16x4_f64 on 16x16 tiles with zero padding (the stage blocks
+// are 13x13 / 10x13 / 13x30: one or two tiles) - operand fragment A[l&15][4kb+(l>>4)], B[4kb+(l>>4)][l&15],
+// result col = l&15, row = (l>>4) + 4*reg.  Host emulation: plain loops.
+DOMPC_DEV inline void gmm(int lane, int GS, int m, int n, int k, const double* A, int sai, int sal,
+                          const double* B, int sbl, int sbj, double beta, double* D, int ldd) {
+#ifndef DOMPC_HOST_EMU
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  (void)GS;
+  const int li = lane & 15, lk = lane >> 4;
+  for (int ti = 0; ti < m; ti += 16)
+    for (int tj = 0; tj < n; tj += 16) {
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      const int ai = ti + li, bj = tj + li;
+      for (int kb = 0; kb < k; kb += 4) {
+        const int kk = kb + lk;
+        const double a = (ai < m && kk < k) ? A[ai * sai + kk * sal] : 0.0;
+        const double b = (bj < n && kk < k) ? B[kk * sbl + bj * sbj] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+      const int col = tj + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti + lk + 4 * r;
+        if (row < m && col < n) {
+          double* d = D + row * ldd + col;
+          *d = (beta == 0.0) ? acc[r] : beta * (*d) + acc[r];
+        }
+      }
+    }
+#else
+  for (int it = lane; it < m * n; it += GS) {
+    const int i = it / n, j = it % n;
+    double t = 0.0;
+    for (int l = 0; l < k; ++l) t += A[i * sai + l * sal] * B[l * sbl + j * sbj];
+    D[i * ldd + j] = (beta == 0.0) ? t : beta * D[i * ldd + j] + t;
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-problem view
 struct Prob {
   const KArgs* A;
@@ -334,15 +377,16 @@ constexpr int EL_T0 = EL_T1 + NW * NA;                                 // Hww w0
 constexpr int EL_RW = EL_T0 + NW;                                      // Newton-form gradient of w (NW)
 constexpr int EL_SG = EL_RW + NW;                                      // Sigma_w (NW)
 constexpr int EL_U1 = EL_SG + NW;                                      // Huw W (NU x NA), Huw w0 (NU)
-constexpr int EL_PV = EL_U1 + NU * NA + NU;                            // pivot rows (NW)
+constexpr int EL_QT = EL_U1 + NU * NA + NU;                            // W'T1 (NA x NA), W'W (NA x NA)
+constexpr int EL_PV = EL_QT + 2 * NA * NA;                            // pivot rows (NW)
 constexpr int RB_NEED = 2 * (NYT * NYT + NYT) + 4 * NA * NA + 5 * NA + NX * NA + NX + NV * NA + NV;
 constexpr int EL_SIZE = (((EL_PV + NW > RB_NEED ? EL_PV + NW : RB_NEED) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {
-  for (int i = 0; i < NI; ++i)
-    for (int j = 1; j <= DEG; ++j)
-      if (slot_of(i, j) == sl) return i * DEG + (j - 1);
-  return -1;
+  // collocation point (i*DEG + j-1) stored in slot sl, or -1 for element-start states and xkf
+  if (sl < DEG) return sl;
+  const int s2 = sl - DEG, i = 1 + s2 / (DEG + 1), r = s2 % (DEG + 1);
+  return (r == 0 || i >= NI) ? -1 : i * DEG + r - 1;
 }
 
 // Thread-parallel evaluation of the lowered model functions at the current iterate: one thread per
@@ -508,14 +552,23 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
     // inverse in place; the row interchanges are undone on the columns of the inverse afterwards.
     {
       static_assert(NW <= 64, "row index is packed into 6 bits of the pivot key");
-      for (int kk = 0; kk < NW; ++kk) {
+      // Structure: rows/columns come in groups [collocation rows of element i | continuity rows of element i]
+      // (optimizer.py:943-983) and G_w is block lower-triangular in that grouping.  Pivots are searched
+      // inside the group of the current column only (the diagonal blocks are the nonsingular collocation
+      // Jacobians, resp. identities), which keeps the structure; the last NX columns (xkf: identity block,
+      // zero above) need no elimination step at all - their inverse columns are already in place.
+      constexpr int GJ_STEPS = NW - NX;
+      constexpr int EL_ROWS = (DEG + 1) * NX;
+      for (int kk = 0; kk < GJ_STEPS; ++kk) {
+        const int pos = kk % EL_ROWS;
+        const int grp_end = kk - pos + (pos < DEG * NX ? DEG * NX : EL_ROWS);
         double f[NW1];
         unsigned bestkey = 0u;
 #pragma unroll
         for (int r = 0; r < NW; ++r) {
           f[r] = act ? Ld[EL_MX + r * NC + kk] : 0.0;
           unsigned key = (((unsigned)(__builtin_bit_cast(unsigned long long, f[r]) >> 32)) & 0x7fffffc0u) | (unsigned)r;
-          key = (r >= kk) ? key : 0u;
+          key = (r >= kk && r < grp_end) ? key : 0u;
           bestkey = key > bestkey ? key : bestkey;
         }
         const int pv = (int)(bestkey & 63u);
@@ -555,7 +608,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
       // undo the row interchanges on the columns of the inverse (reverse order); lane r owns row r here
       if (act) {
         for (int r = lane; r < NW; r += GS)
-          for (int kk = NW - 1; kk >= 0; --kk) {
+          for (int kk = GJ_STEPS - 1; kk >= 0; --kk) {
             const int pv = (int)Ld[EL_PV + kk];
             if (pv != kk) {
               const double t = Ld[EL_MX + r * NC + kk];
@@ -575,19 +628,23 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
     }
     T.gsync();
     DOMPC_PH(2)
-    // ---- phase 5: T1 = Hww W, t0 = Hww w0, U1 = Huw W, u0 = Huw w0
+    // ---- phase 5: T1 = Hww W, t0 = Hww w0, U1 = Huw W, u0 = Huw w0   (Hww = blockdiag(Hxx_p) + Sigma_w)
     if (act) {
       for (int it = lane; it < NW * (NA + 1); it += GS) {
         const int row = it / (NA + 1), b = it % (NA + 1);
-        const int sl = row / NX, a = row % NX;
-        const int p = point_of_slot(sl);
         double t = Ld[EL_SG + row] * Ld[EL_MX + row * NC + NW + b];
-        if (p >= 0) {
-          const double* Hp = mo + MO_PT + p * PT_STRIDE + NX + NX * NA;
-          for (int a2 = 0; a2 < NX; ++a2) t += Hp[a * NA + a2] * Ld[EL_MX + (sl * NX + a2) * NC + NW + b];
+        if (b == NA) {            // the w0 column: small mat-vec on the vector units
+          const int sl = row / NX, a = row % NX;
+          const int p = point_of_slot(sl);
+          if (p >= 0) {
+            const double* Hp = mo + MO_PT + p * PT_STRIDE + NX + NX * NA;
+#pragma unroll
+            for (int a2 = 0; a2 < NX; ++a2) t += Hp[a * NA + a2] * Ld[EL_MX + (sl * NX + a2) * NC + NW + NA];
+          }
+          Ld[EL_T0 + row] = t;
+        } else {
+          Ld[EL_T1 + row * NA + b] = t;
         }
-        if (b < NA) Ld[EL_T1 + row * NA + b] = t;
-        else Ld[EL_T0 + row] = t;
       }
       for (int it = lane; it < NU * (NA + 1); it += GS) {
         const int ub = it / (NA + 1), b = it % (NA + 1);
@@ -595,24 +652,34 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
         for (int p = 0; p < NCOLL; ++p) {
           const int sl = slot_of(p / DEG, p % DEG + 1);
           const double* Hp = mo + MO_PT + p * PT_STRIDE + NX + NX * NA;
+#pragma unroll
           for (int a = 0; a < NX; ++a) t += Hp[a * NA + NX + ub] * Ld[EL_MX + (sl * NX + a) * NC + NW + b];
         }
         Ld[EL_U1 + (b < NA ? ub * NA + b : NU * NA + ub)] = t;
       }
     }
     T.gsync();
+    if (act) {
+      // T1[slot rows] += Hxx_p * W[slot rows]   (matrix cores)
+      for (int p = 0; p < NCOLL; ++p) {
+        const int sl = slot_of(p / DEG, p % DEG + 1);
+        gmm(lane, GS, NX, NA, NX, mo + MO_PT + p * PT_STRIDE + NX + NX * NA, NA, 1,
+            Ld + EL_MX + (sl * NX) * NC + NW, NC, 1, 1.0, Ld + EL_T1 + sl * NX * NA, NA);
+      }
+    }
+    T.gsync();
+    if (act) {
+      // W'T1 and W'W  (13x30 * 30x13 on the matrix cores)
+      gmm(lane, GS, NA, NA, NW, Ld + EL_MX + NW, 1, NC, Ld + EL_T1, NA, 1, 0.0, Ld + EL_QT, NA);
+      gmm(lane, GS, NA, NA, NW, Ld + EL_MX + NW, 1, NC, Ld + EL_MX + NW, NC, 1, 0.0, Ld + EL_QT + NA * NA, NA);
+    }
+    T.gsync();
     // ---- phase 6: condensed blocks to the shared per-edge record; data for the forward pass
     if (act) {
       for (int it = lane; it < NA * NA; it += GS) {
         const int a1 = it / NA, b = it % NA;
-        double q = om * mo[MO_LT + 1 + NA + it];
+        double q = om * mo[MO_LT + 1 + NA + it] + Ld[EL_QT + it];
         if (NE > 0) q += mo[MO_NL + NE + NE * NA + it];
-        double ww = 0.0;
-        for (int row = 0; row < NW; ++row) {
-          const double wa = Ld[EL_MX + row * NC + NW + a1];
-          q += wa * Ld[EL_T1 + row * NA + b];
-          ww += wa * Ld[EL_MX + row * NC + NW + b];
-        }
         if (a1 >= NX && b >= NX) {
           double h = 0.0;
           for (int p = 0; p < NCOLL; ++p) h += mo[MO_PT + p * PT_STRIDE + NX + NX * NA + a1 * NA + b];
@@ -621,7 +688,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
         if (a1 >= NX) q += Ld[EL_U1 + (a1 - NX) * NA + b];
         if (b >= NX) q += Ld[EL_U1 + (b - NX) * NA + a1];
         S_[ES_QT + it] = q;
-        S_[ES_WTW + it] = ww;
+        S_[ES_WTW + it] = Ld[EL_QT + NA * NA + it];
       }
       for (int a1 = lane; a1 < NA; a1 += GS) {
         double q = 0.0, ww = 0.0;
@@ -905,30 +972,28 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
           }
           T.gsync();
         }
-        // TP = P_c Atilde (y columns), TV = P_c ctilde + p_c
-        for (int it = lane; it < NA * (NA + 1); it += GS) {
-          const int i = it / (NA + 1), yj = it % (NA + 1);
-          if (yj < NA) {
-            double t = 0.0;
+        // TP = P_c Atilde (y columns) = P_c[:, :NX] [A|B] + P_c[:, NX:] on the u columns;  TV = P_c ctilde + p_c
+        gmm(lane, GS, NA, NA, NX, Ld + RB_PC, NA, 1, Ld + RB_AB, NA, 1, 0.0, Ld + RB_TP, NA);
+        for (int i = lane; i < NA; i += GS) {
+          double t = Ld[RB_PCV + i];
 #pragma unroll
-            for (int a = 0; a < NX; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_AB + a * NA + yj];
-            if (yj >= NX) t += Ld[RB_PC + i * NA + yj];
-            Ld[RB_TP + i * NA + yj] = t;
-          } else {
-            double t = Ld[RB_PCV + i];
-#pragma unroll
-            for (int a = 0; a < NX; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CV + a];
-            Ld[RB_TV + i] = t;
-          }
+          for (int a = 0; a < NX; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CV + a];
+          Ld[RB_TV + i] = t;
         }
+        T.gsync();
+        for (int it = lane; it < NA * NU; it += GS) {
+          const int i = it / NU, u = it % NU;
+          Ld[RB_TP + i * NA + NX + u] += Ld[RB_PC + i * NA + NX + u];
+        }
+        T.gsync();
+        // coupling Atilde' TP = [A|B]' TP[:NX, :] (+ TP rows of the u block) -> ACL used as scratch
+        gmm(lane, GS, NA, NA, NX, Ld + RB_AB, 1, NA, Ld + RB_TP, NA, 1, 0.0, Ld + RB_ACL, NA);
         T.gsync();
         for (int it = lane; it < NA * (NA + 1); it += GS) {
           const int yi = it / (NA + 1), yj = it % (NA + 1);
           const int i = ycol(yi);
           if (yj < NA) {
-            double t = 0.0;
-#pragma unroll
-            for (int a = 0; a < NX; ++a) t += Ld[RB_AB + a * NA + yi] * Ld[RB_TP + a * NA + yj];
+            double t = Ld[RB_ACL + yi * NA + yj];
             if (yi >= NX) t += Ld[RB_TP + yi * NA + yj];
             Ld[RB_QF + i * NYT + ycol(yj)] += t;
           } else {
@@ -1047,34 +1112,21 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
           }
         }
         T.gsync();
-        for (int it = lane; it < NA * (NA + 1); it += GS) {
-          const int i = it / (NA + 1), j = it % (NA + 1);
-          if (j < NA) {
-            double t = 0.0;
+        // T2 = P_c Acl ; tv2 = P_c ccl + p_c ; PN += Acl' T2 ; pn += Acl' tv2
+        gmm(lane, GS, NA, NA, NA, Ld + RB_PC, NA, 1, Ld + RB_ACL, NA, 1, 0.0, Ld + RB_TP, NA);
+        for (int i = lane; i < NA; i += GS) {
+          double t = Ld[RB_PCV + i];
 #pragma unroll
-            for (int a = 0; a < NA; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_ACL + a * NA + j];
-            Ld[RB_TP + i * NA + j] = t;
-          } else {
-            double t = Ld[RB_PCV + i];
-#pragma unroll
-            for (int a = 0; a < NA; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CCL + a];
-            Ld[RB_TV + i] = t;
-          }
+          for (int a = 0; a < NA; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CCL + a];
+          Ld[RB_TV + i] = t;
         }
         T.gsync();
-        for (int it = lane; it < NA * (NA + 1); it += GS) {
-          const int i = it / (NA + 1), j = it % (NA + 1);
-          if (j < NA) {
-            double t = 0.0;
+        gmm(lane, GS, NA, NA, NA, Ld + RB_ACL, 1, NA, Ld + RB_TP, NA, 1, 1.0, Ld + RB_PN, NA);
+        for (int i = lane; i < NA; i += GS) {
+          double t = 0.0;
 #pragma unroll
-            for (int a = 0; a < NA; ++a) t += Ld[RB_ACL + a * NA + i] * Ld[RB_TP + a * NA + j];
-            Ld[RB_PN + i * NA + j] += t;
-          } else {
-            double t = 0.0;
-#pragma unroll
-            for (int a = 0; a < NA; ++a) t += Ld[RB_ACL + a * NA + i] * Ld[RB_TV + a];
-            Ld[RB_PNV + i] += t;
-          }
+          for (int a = 0; a < NA; ++a) t += Ld[RB_ACL + a * NA + i] * Ld[RB_TV + a];
+          Ld[RB_PNV + i] += t;
         }
         T.gsync();
       }
@@ -1261,6 +1313,42 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   return T.flags[1];
 }
 
+// Barrier-parameter change at an unchanged iterate: only the barrier gradients move, linearly in mu.
+// Updates the mu-dependent pieces of the per-edge records (rw, the condensed gradient W'rw, the slack
+// residual) instead of repeating the whole derivative sweep.
+DOMPC_PHASE void refresh_mu(const Thr& T, const Prob& Q, double dmu) {
+  const KArgs& A = *Q.A;
+  const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
+  double* Ld = T.edge_lds + (int64_t)gid * EL_SIZE;
+  for (int e = gid; e < A.n_edges; e += ng) {
+    if (M > 0) {
+      const int woff = A.edge_w_off[e];
+      for (int r = lane; r < NW; r += GS) {
+        const int gi = woff + r;
+        const double b = bar_grad(Q.x[gi], Q.lb[gi], Q.ub[gi], 1.0);
+        Ld[r] = b;
+        Q.EW(e, EW_RW + r) += dmu * b;
+      }
+      T.gsync();
+      double* S_ = Q.ES(e);
+      for (int a = lane; a < NA; a += GS) {
+        double t = 0.0;
+        for (int r = 0; r < NW; ++r) t += Q.EW(e, EW_W + r * NA + a) * Ld[r];
+        S_[ES_QV + a] += dmu * t;
+      }
+      T.gsync();
+    }
+    if (NE > 0) {
+      double* S_ = Q.ES(e);
+      for (int i = lane; i < NE; i += GS) {
+        const int si = e * NE1 + i;
+        S_[ES_RSN + i] += dmu * bar_grad(Q.s[si], Q.sl[si], Q.su[si], 1.0);
+      }
+    }
+  }
+  T.sync();
+}
+
 // error measures (IPOPT eq. (5)/(6)) + objective + theta at the current iterate
 DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, double mu_c) {
   const KArgs& A = *Q.A;
@@ -1395,7 +1483,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (it >= O.max_iter) { status = 2; break; }
 
     // ---- barrier update (monotone Fiacco-McCormick)
-    bool mu_changed = false;
+    const double mu_before = mu;
     while (true) {
       c_t = prof_clock(); Errs Em = measure(T, Q, mu); c_meas += prof_clock() - c_t;
       const double Emu = fmax(Em.e_d / sd, fmax(Em.e_p, Em.e_c0 / sc));
@@ -1403,10 +1491,9 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         mu = fmax(mu_min, fmin(O.kappa_mu * mu, pow(mu, O.theta_mu)));
         tau = fmax(O.tau_min, 1.0 - mu);
         n_filt = 0;
-        mu_changed = true;
       } else break;
     }
-    if (mu_changed) { bad = sweep(T, Q, mu); ++n_sweeps; if (bad) { status = 3; break; } }
+    if (mu != mu_before) refresh_mu(T, Q, mu - mu_before);
 
     // ---- search direction with inertia correction (delta_w on all primal variables)
     double delta = 0.0;

@@ -170,6 +170,8 @@ def p_scenarios(case):
     """All parameter combinations, first keyword varies slowest, first value nominal
     (/root/reference/do_mpc/controller/_mpc.py:867, itertools.product)."""
     names = [str(s) for s in case["p"]]
+    if case.get("p_values") is not None:          # explicit scenario list (set_p_fun route, _mpc.py:760-818)
+        return np.asarray(case["p_values"], float).reshape(-1, len(names))
     unc = case["uncertainty"]
     if not names:
         return np.zeros((1, 0))

@@ -23,8 +23,11 @@ U_RTOL, X_RTOL, STEP_TOL = 1e-6, 1e-5, 1e-6
 _oracle_cache = {}
 
 
+PAIRED_P = [[950.0, 7.0], [950.0 * 1.30, 7.0 * 1.30], [950.0 * 0.70, 7.0 * 0.70]]   # industrial_poly "paired" scenarios
+
+
 def oracle_nlp(name, **over):
-    key = (name, tuple(sorted(over.items())))
+    key = (name, tuple(sorted((k, str(v)) for k, v in over.items())))
     if key not in _oracle_cache:
         _oracle_cache[key] = OracleNLP(ORACLE_CASES[name](**over))
     return _oracle_cache[key]
@@ -178,3 +181,23 @@ class HostArr:
     def __init__(self, a):
         self.a = np.ascontiguousarray(a, dtype=np.float64)
         self.ptr = self.a.ctypes.data
+
+
+def check_kkt_with_oracle_functions(mpc, nlp, x0):
+    """Size-independent check used where an oracle *solve* would take too long: the product's primal-dual
+    solution must satisfy the oracle's restated NLP - equality feasibility, dual feasibility
+    (stationarity with our multipliers), bounds and complementarity."""
+    x, p = mpc.opt_x_num.master, mpc.opt_p_num.master
+    assert np.allclose(p, nlp.opt_p(x0, np.zeros(nlp.nu)), rtol=0, atol=1e-12)
+    gv = nlp.g(x, p)
+    eq = nlp.lbg == nlp.ubg
+    assert np.max(np.abs(gv[eq])) < 1e-7
+    lam_g, lam_x = mpc.lam_g_num, mpc.lam_x_num
+    rd = nlp.grad(x, p) + nlp.jac(x, p).T @ lam_g + lam_x
+    assert np.max(np.abs(rd)) < 1e-5 * max(1.0, np.max(np.abs(lam_g)))
+    tol = 1e-7 * np.maximum(1.0, np.abs(x))
+    assert np.all(x >= nlp.lbx - tol) and np.all(x <= nlp.ubx + tol)
+    dist = np.minimum(np.where(np.isfinite(nlp.lbx), x - nlp.lbx, np.inf), np.where(np.isfinite(nlp.ubx), nlp.ubx - x, np.inf))
+    active = np.isfinite(dist)
+    assert np.max(np.abs(lam_x[active]) * np.maximum(dist[active], 0.0)) < 1e-6     # complementarity
+    assert np.all(lam_x[~active] == 0.0)

@@ -83,3 +83,32 @@ def test_infeasible_problem_reports_failure_not_exception():
     assert mpc.solver_stats["success"] is False
     assert mpc.solver_stats["return_status"] in ("Maximum_Iterations_Exceeded", "Error_In_Step_Computation",
                                                  "Invalid_Number_Detected")
+
+
+def test_industrial_poly_variant_b_tree_vs_oracle():
+    # BASELINE.json configs[3], second reading: 3 parameter combinations, n_robust=2 (9 leaves, 174 edges)
+    mpc = make_mpc("industrial_poly", n_robust=2, uncertainty="paired")
+    nlp = pc.oracle_nlp("industrial_poly", n_robust=2, p_values=pc.PAIRED_P)
+    assert (nlp.n_opt_x, nlp.n_g) == (mpc.structure.n_opt_x, mpc.structure.n_g) == (8100, 6970)
+    ex = CASES["industrial_poly"]
+    mpc.x0 = ex.X0
+    mpc.set_initial_guess()
+    u0 = mpc.make_step(ex.X0).ravel()
+    assert mpc.solver_stats["success"]
+    from oracle import ipm
+    r = ipm.solve(nlp, nlp.initial_guess(ex.X0), nlp.opt_p(ex.X0, np.zeros(3)))
+    assert r["stats"]["success"]
+    assert pc.relerr(u0, nlp.u0_of(r["x"])) < pc.U_RTOL
+    pc.check_kkt_with_oracle_functions(mpc, nlp, ex.X0)
+
+
+def test_deeper_tree_27_leaves_kkt_properties():
+    # n_robust=3: 27 leaves, 498 edges, 24 300 variables - checked through the oracle's NLP functions
+    mpc = make_mpc("industrial_poly", n_robust=3, uncertainty="paired")
+    nlp = pc.oracle_nlp("industrial_poly", n_robust=3, p_values=pc.PAIRED_P)
+    ex = CASES["industrial_poly"]
+    mpc.x0 = ex.X0
+    mpc.set_initial_guess()
+    mpc.make_step(ex.X0)
+    assert mpc.solver_stats["success"]
+    pc.check_kkt_with_oracle_functions(mpc, nlp, ex.X0)
