@@ -51,20 +51,42 @@ extern "C" __global__ void __launch_bounds__(256, 2) dompc_solve_kernel(dompc::K
   __shared__ long long prof[8];
   if (threadIdx.x < 8) prof[threadIdx.x] = 0;
   __syncthreads();
-  dompc::Thr T{(int)threadIdx.x, (int)blockDim.x, pool, filt, flags, pool, prof, 64};
+  // Thread context.  Normal mode: one workgroup per problem, problems pulled from a device-wide counter.
+  // Wide mode (small batches): K = A.wide workgroups per problem, static assignment problem = slot, all
+  // on one XCD when the dispatcher places block b on XCD b % 8 (affinity only - the barrier protocol does
+  // not depend on it): b = 8*q + r, workgroup-in-problem j = q % K, slot = (q / K) * 8 + r.
+  const bool wide = (A.mode == 0 && A.wide > 1);
+  const int K = wide ? A.wide : 1;
+  const int q = blockIdx.x / 8;
+  const int j = wide ? q % K : 0;
+  const int slot = wide ? (q / K) * 8 + (int)(blockIdx.x % 8) : (int)blockIdx.x;
+  if (wide && slot >= A.batch) return;
+  dompc::Thr T{j * (int)blockDim.x + (int)threadIdx.x, K * (int)blockDim.x, (dompc::ldsd*)pool, (dompc::ldsd*)filt,
+               wide ? A.wide_flags + slot * 8 : flags, (dompc::ldsd*)pool, prof, 64,
+               (int)threadIdx.x, (int)blockDim.x, j, K, wide ? A.wide_bar + slot * 16 : nullptr,
+               wide ? A.wide_partials + (int64_t)slot * 2 * K * dompc::RED_MAX : nullptr, 0u, 0u};
   if (A.mode == 1) {
     if (blockIdx.x == 0) dompc::debug_newton(T, A);
     return;
   }
-  // persistent workgroups: each pulls problems from a device-wide counter and owns one workspace slot
+  // (single call site of solve_problem: the compiler inlines the whole solver into the kernel; an
+  //  out-of-line copy keeps the context structs in scratch and is 2x slower)
+  bool first = true;
   while (true) {
-    if (threadIdx.x == 0) s_b = atomicAdd(A.work_counter, 1);
-    __syncthreads();
-    const int b = s_b;
-    __syncthreads();
-    if (b >= A.batch) break;
-    if (A.mode == 2) dompc::sweep_problem(T, A, b, blockIdx.x);
-    else dompc::solve_problem(T, A, b, blockIdx.x);
+    int b;
+    if (wide) {
+      if (!first) break;
+      b = slot;
+    } else {
+      if (threadIdx.x == 0) s_b = atomicAdd(A.work_counter, 1);
+      __syncthreads();
+      b = s_b;
+      __syncthreads();
+      if (b >= A.batch) break;
+    }
+    first = false;
+    if (A.mode == 2) dompc::sweep_problem(T, A, b, slot);
+    else dompc::solve_problem(T, A, b, slot);
   }
 }
 #else
@@ -78,7 +100,7 @@ extern "C" void dompc_hostemu_run(const dompc::KArgs* A) {
   static thread_local double filt[2 * dompc::MAX_FILTER];
   static thread_local int flags[8];
   static thread_local double edge_lds[dompc::EL_SIZE];
-  dompc::Thr T{0, 1, red, filt, flags, edge_lds, nullptr, 1};
+  dompc::Thr T{0, 1, red, filt, flags, edge_lds, nullptr, 1, 0, 1, 0, 1, nullptr, nullptr, 0u, 0u};
   if (A->mode == 1) { dompc::debug_newton(T, *A); return; }
   for (int b = 0; b < A->batch; ++b) {
     if (A->mode == 2) dompc::sweep_problem(T, *A, b, 0);

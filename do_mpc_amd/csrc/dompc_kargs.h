@@ -30,6 +30,12 @@ struct KArgs {
   // optional iteration trace of problem 0: 8 doubles per iteration (it, mu, E0, inf_pr, inf_du, alpha, delta_w, obj)
   double* trace;
   int32_t trace_cap, trace_pad;
+  // wide mode: `wide` workgroups cooperate on one problem (small batches); per-slot barrier counters
+  // (16 uints apart), reduction partials ([2][wide][12] doubles) and shared flags (8 ints)
+  int32_t wide, wide_pad;
+  uint32_t* wide_bar;
+  double* wide_partials;
+  int32_t* wide_flags;
   // sweep (mode 2)
   const double *sw_x, *sw_lam;
   double *sw_g, *sw_blocks;

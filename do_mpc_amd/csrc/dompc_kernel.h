@@ -127,16 +127,60 @@ DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad,
 }
 
 // ------------------------------------------------------------------------------------------------
-// workgroup context
+// LDS pointers carry their address space in the type.  With generic pointers the compiler may fall back to
+// FLAT instructions when address-space inference fails, and a flat access whose *base register* is
+// (legitimately) a few bytes below the LDS aperture - e.g. &Mx[row][slot*NX + a] with slot = -1 before a
+// positive immediate offset is added - faults, while the same ds_read/ds_write is fine.
+#ifndef DOMPC_HOST_EMU
+typedef __attribute__((address_space(3))) double ldsd;
+#else
+typedef double ldsd;
+#endif
+
+// execution context of the threads that work on one problem: one workgroup, or - "wide" mode, used for
+// small batches so that a single make_step can use many CUs - K workgroups that synchronise through a
+// device-scope barrier.  All loops over work items are written against (tid, nt), the index / count
+// among ALL threads of the problem; (ltid, lnt) are the coordinates inside the workgroup (LDS indexing).
 struct Thr {
   int tid, nt;
-  double* red;      // LDS: RED_MAX * nt doubles
-  double* filt;     // LDS: 2*MAX_FILTER doubles
-  int* flags;       // LDS: 8 ints
-  double* edge_lds; // LDS: (nt/gs) * EL_SIZE doubles (per-group edge working set)
+  ldsd* red;        // LDS: RED_MAX * lnt doubles
+  ldsd* filt;       // LDS: 2*MAX_FILTER doubles (every workgroup keeps an identical copy)
+  int* flags;       // 8 ints shared by all threads of the problem: LDS (one workgroup) or global (wide)
+  ldsd* edge_lds;   // LDS: (lnt/gs) * EL_SIZE doubles (per-group edge working set)
   long long* prof;  // optional sub-phase cycle counters (thread 0 only; may be null)
   int gs;           // lanes cooperating on one edge (64 = one wavefront on the device, 1 in the host emulation)
+  int ltid, lnt;    // thread index / count inside the workgroup
+  int wg, nwg;      // workgroup index / count of this problem
+  unsigned* bar;    // wide: global arrival counter of the problem slot (monotonic)
+  double* partials; // wide: global [2][nwg][RED_MAX] reduction partials
+  mutable unsigned gen, nred;
   DOMPC_DEV void sync() const {
+#ifndef DOMPC_HOST_EMU
+    __syncthreads();
+    if (nwg > 1) {
+      // device-scope barrier (MI355X_MICROARCH.md, inter-workgroup visibility): release fence + drained
+      // vmcnt before the arrival, relaxed polling, acquire fence after; every spin is bounded.
+      ++gen;
+      if (ltid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = gen * (unsigned)nwg;
+        long long spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > 40000000ll || __hip_atomic_load(flags + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(flags + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // abort: a peer is missing
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+    }
+#endif
+  }
+  DOMPC_DEV void lsync() const {        // workgroup-local barrier
 #ifndef DOMPC_HOST_EMU
     __syncthreads();
 #endif
@@ -156,7 +200,7 @@ struct Thr {
   }
 };
 
-// phase timer (shader clock on the device, 0 in the host emulation)
+
 DOMPC_DEV inline long long prof_clock() {
 #ifndef DOMPC_HOST_EMU
   return (long long)clock64();
@@ -172,19 +216,35 @@ template <int N_>
 DOMPC_DEV void wg_reduce(const Thr& T, double (&v)[N_], const int (&op)[N_]) {
   static_assert(N_ <= RED_MAX, "too many values");
   if (T.nt == 1) return;
-  for (int i = 0; i < N_; ++i) T.red[i * T.nt + T.tid] = v[i];
-  T.sync();
-  for (int s = T.nt >> 1; s > 0; s >>= 1) {
-    if (T.tid < s) {
+  for (int i = 0; i < N_; ++i) T.red[i * T.lnt + T.ltid] = v[i];
+  T.lsync();
+  for (int s = T.lnt >> 1; s > 0; s >>= 1) {
+    if (T.ltid < s) {
       for (int i = 0; i < N_; ++i) {
-        double a = T.red[i * T.nt + T.tid], b = T.red[i * T.nt + T.tid + s];
-        T.red[i * T.nt + T.tid] = op[i] == R_SUM ? a + b : (op[i] == R_MAX ? fmax(a, b) : fmin(a, b));
+        double a = T.red[i * T.lnt + T.ltid], b = T.red[i * T.lnt + T.ltid + s];
+        T.red[i * T.lnt + T.ltid] = op[i] == R_SUM ? a + b : (op[i] == R_MAX ? fmax(a, b) : fmin(a, b));
       }
     }
-    T.sync();
+    T.lsync();
   }
-  for (int i = 0; i < N_; ++i) v[i] = T.red[i * T.nt];
-  T.sync();
+  if (T.nwg > 1) {
+    // combine the workgroups' partials in a fixed order (bitwise identical on every workgroup)
+    double* buf = T.partials + (T.nred & 1u) * T.nwg * RED_MAX;
+    ++T.nred;
+    if (T.ltid < N_) buf[T.wg * RED_MAX + T.ltid] = T.red[T.ltid * T.lnt];
+    T.sync();
+    if (T.ltid < N_) {
+      double acc = buf[T.ltid];
+      for (int w = 1; w < T.nwg; ++w) {
+        const double b = buf[w * RED_MAX + T.ltid];
+        acc = op[T.ltid] == R_SUM ? acc + b : (op[T.ltid] == R_MAX ? fmax(acc, b) : fmin(acc, b));
+      }
+      T.red[T.ltid * T.lnt] = acc;
+    }
+    T.lsync();
+  }
+  for (int i = 0; i < N_; ++i) v[i] = T.red[i * T.lnt];
+  T.lsync();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,7 +487,7 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
   }
 }
 
-DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, int lane, int GS, double* Ld) {
+DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, int lane, int GS, ldsd* Ld) {
   const KArgs& A = *Q.A;
   const bool act = e >= 0;
   const int ee = act ? e : 0;
@@ -664,14 +724,14 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
       for (int p = 0; p < NCOLL; ++p) {
         const int sl = slot_of(p / DEG, p % DEG + 1);
         gmm(lane, GS, NX, NA, NX, mo + MO_PT + p * PT_STRIDE + NX + NX * NA, NA, 1,
-            Ld + EL_MX + (sl * NX) * NC + NW, NC, 1, 1.0, Ld + EL_T1 + sl * NX * NA, NA);
+            (double*)(Ld + EL_MX + (sl * NX) * NC + NW), NC, 1, 1.0, (double*)(Ld + EL_T1 + sl * NX * NA), NA);
       }
     }
     T.gsync();
     if (act) {
       // W'T1 and W'W  (13x30 * 30x13 on the matrix cores)
-      gmm(lane, GS, NA, NA, NW, Ld + EL_MX + NW, 1, NC, Ld + EL_T1, NA, 1, 0.0, Ld + EL_QT, NA);
-      gmm(lane, GS, NA, NA, NW, Ld + EL_MX + NW, 1, NC, Ld + EL_MX + NW, NC, 1, 0.0, Ld + EL_QT + NA * NA, NA);
+      gmm(lane, GS, NA, NA, NW, (double*)(Ld + EL_MX + NW), 1, NC, (double*)(Ld + EL_T1), NA, 1, 0.0, (double*)(Ld + EL_QT), NA);
+      gmm(lane, GS, NA, NA, NW, (double*)(Ld + EL_MX + NW), 1, NC, (double*)(Ld + EL_MX + NW), NC, 1, 0.0, (double*)(Ld + EL_QT + NA * NA), NA);
     }
     T.gsync();
     // ---- phase 6: condensed blocks to the shared per-edge record; data for the forward pass
@@ -851,7 +911,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
   constexpr int RB_SIZE = RB_PNV + NA;
   static_assert(RB_SIZE <= EL_SIZE, "node working set must fit the per-group LDS region");
   const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
-  double* Ld = T.edge_lds + (int64_t)gid * EL_SIZE;
+  ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   if (T.tid == 0) T.flags[0] = 0;
   T.sync();
   for (int k = A.N; k >= 0; --k) {
@@ -973,7 +1033,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
           T.gsync();
         }
         // TP = P_c Atilde (y columns) = P_c[:, :NX] [A|B] + P_c[:, NX:] on the u columns;  TV = P_c ctilde + p_c
-        gmm(lane, GS, NA, NA, NX, Ld + RB_PC, NA, 1, Ld + RB_AB, NA, 1, 0.0, Ld + RB_TP, NA);
+        gmm(lane, GS, NA, NA, NX, (double*)(Ld + RB_PC), NA, 1, (double*)(Ld + RB_AB), NA, 1, 0.0, (double*)(Ld + RB_TP), NA);
         for (int i = lane; i < NA; i += GS) {
           double t = Ld[RB_PCV + i];
 #pragma unroll
@@ -987,7 +1047,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
         }
         T.gsync();
         // coupling Atilde' TP = [A|B]' TP[:NX, :] (+ TP rows of the u block) -> ACL used as scratch
-        gmm(lane, GS, NA, NA, NX, Ld + RB_AB, 1, NA, Ld + RB_TP, NA, 1, 0.0, Ld + RB_ACL, NA);
+        gmm(lane, GS, NA, NA, NX, (double*)(Ld + RB_AB), 1, NA, (double*)(Ld + RB_TP), NA, 1, 0.0, (double*)(Ld + RB_ACL), NA);
         T.gsync();
         for (int it = lane; it < NA * (NA + 1); it += GS) {
           const int yi = it / (NA + 1), yj = it % (NA + 1);
@@ -1113,7 +1173,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
         }
         T.gsync();
         // T2 = P_c Acl ; tv2 = P_c ccl + p_c ; PN += Acl' T2 ; pn += Acl' tv2
-        gmm(lane, GS, NA, NA, NA, Ld + RB_PC, NA, 1, Ld + RB_ACL, NA, 1, 0.0, Ld + RB_TP, NA);
+        gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_PC), NA, 1, (double*)(Ld + RB_ACL), NA, 1, 0.0, (double*)(Ld + RB_TP), NA);
         for (int i = lane; i < NA; i += GS) {
           double t = Ld[RB_PCV + i];
 #pragma unroll
@@ -1121,7 +1181,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
           Ld[RB_TV + i] = t;
         }
         T.gsync();
-        gmm(lane, GS, NA, NA, NA, Ld + RB_ACL, 1, NA, Ld + RB_TP, NA, 1, 1.0, Ld + RB_PN, NA);
+        gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_ACL), 1, NA, (double*)(Ld + RB_TP), NA, 1, 1.0, (double*)(Ld + RB_PN), NA);
         for (int i = lane; i < NA; i += GS) {
           double t = 0.0;
 #pragma unroll
@@ -1145,7 +1205,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
 DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double delta) {
   const KArgs& A = *Q.A;
   const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
-  double* Ld = T.edge_lds + (int64_t)gid * EL_SIZE;
+  ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   constexpr int RF_DX = 0, RF_DV = RF_DX + NA, RF_DY = RF_DV + NV, RF_DNU = RF_DY + NA, RF_DW = RF_DNU + NX,
                 RF_RHS = RF_DW + NW1;
   static_assert(RF_RHS + NW1 <= EL_SIZE, "forward working set must fit the per-group LDS region");
@@ -1295,7 +1355,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   T.sync();
   {
     const int ng = T.nt / T.gs, gid = T.tid / T.gs, lane = T.tid % T.gs;
-    double* Ld = T.edge_lds + (int64_t)gid * EL_SIZE;
+    ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / T.gs) * EL_SIZE;
     const int rounds = (A.n_edges + ng - 1) / ng;
     for (int rd = 0; rd < rounds; ++rd) {
       const int e = rd * ng + gid;
@@ -1319,7 +1379,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
 DOMPC_PHASE void refresh_mu(const Thr& T, const Prob& Q, double dmu) {
   const KArgs& A = *Q.A;
   const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
-  double* Ld = T.edge_lds + (int64_t)gid * EL_SIZE;
+  ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   for (int e = gid; e < A.n_edges; e += ng) {
     if (M > 0) {
       const int woff = A.edge_w_off[e];
@@ -1470,6 +1530,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
 
   while (true) {
     if (bad) { status = 3; break; }
+    if (T.nwg > 1 && T.flags[7]) { status = 5; break; }       // a peer workgroup never arrived at a barrier
     const double sd = fmax(s_max, (E.sum_y + E.sum_z) / fmax(1.0, n_dual)) / s_max;
     const double sc = fmax(s_max, E.sum_z / fmax(1.0, n_bounds)) / s_max;
     E0 = fmax(E.e_d / sd, fmax(E.e_p, E.e_c0 / sc));
@@ -1627,13 +1688,13 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       ++n_ls_fail;
       n_filt = 0;
     } else if (!armijo_used) {
-      if (T.tid == 0) {
+      if (T.ltid == 0) {
         int q = n_filt < MAX_FILTER ? n_filt : MAX_FILTER - 1;
         T.filt[2 * q] = (1.0 - gamma_theta) * theta;
         T.filt[2 * q + 1] = phi - gamma_phi * theta;
       }
       if (n_filt < MAX_FILTER) ++n_filt;
-      T.sync();
+      T.lsync();
     }
     c_ls += prof_clock() - c_t;
     // ---- accept the trial point

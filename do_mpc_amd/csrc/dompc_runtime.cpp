@@ -292,6 +292,10 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   A.ws_stride = h->ws_stride;
   if (dev_alloc(h, (void**)&A.ws, sizeof(double) * (size_t)h->ws_stride * h->n_slots)) return fail(1);
   if (dev_alloc(h, (void**)&A.work_counter, 64)) return fail(1);
+  // wide mode (small batches): up to 64 slots x 32 workgroups
+  if (dev_alloc(h, (void**)&A.wide_bar, sizeof(uint32_t) * 16 * 64)) return fail(1);
+  if (dev_alloc(h, (void**)&A.wide_flags, sizeof(int32_t) * 8 * 64)) return fail(1);
+  if (dev_alloc(h, (void**)&A.wide_partials, sizeof(double) * 64 * 2 * 32 * 12)) return fail(1);
   for (int i = 0; i < 8; ++i)
     if (dev_alloc(h, (void**)&h->s_dbg[i], sizeof(double) * (size_t)(d.n_opt_x > d.n_g ? d.n_opt_x : d.n_g))) return fail(1);
   if (dev_alloc(h, (void**)&h->s_trace, sizeof(double) * 8 * h->trace_cap)) return fail(1);
@@ -320,7 +324,23 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.lbg = lbg; A.ubg = ubg; A.p = p;
   A.x_out = x; A.g_out = g; A.lam_x_out = lam_x; A.lam_g_out = lam_g; A.f_out = f; A.stats = stats;
   A.batch = B; A.mode = 0;
-  const int grid = B < h->n_slots ? B : h->n_slots;
+  int grid = B < h->n_slots ? B : h->n_slots;
+  A.wide = 1;
+#ifndef DOMPC_HOST_EMU
+  // small batches: several workgroups per problem so that one make_step can use many CUs
+  const char* wenv = getenv("DOMPC_WIDE");
+  // enough workgroups that every wavefront owns about two edges, fewer when the batch itself fills the chip
+  int K = wenv ? atoi(wenv) : (B <= 8 ? 32 : (B <= 32 ? 8 : (B <= 64 ? 4 : 1)));
+  if (!wenv && K > h->d.n_edges / 8) K = h->d.n_edges / 8 > 1 ? h->d.n_edges / 8 : 1;
+  if (K > 32) K = 32;
+  if (K > 1 && B <= 64 && B <= h->n_slots) {
+    A.wide = K;
+    grid = ((B + 7) / 8) * 8 * K;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(h, hipMemsetAsync(A.wide_bar, 0, sizeof(uint32_t) * 16 * 64, st));
+    HIPCHK(h, hipMemsetAsync(A.wide_flags, 0, sizeof(int32_t) * 8 * 64, st));
+  }
+#endif
   return launch(h, A, grid, stream);
 }
 
