@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DOMPC_BENCH_BATCH", "512")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DOMPC_BENCH_BATCH", "1024")),
                     help="problems per GPU per step")
     ap.add_argument("--variant", default="A", choices=["A", "B"],
                     help="A: shipped 9x1 tree (golden-pinned); B: 3 combinations, n_robust=2")

@@ -156,3 +156,35 @@ def test_infeasible_problem_reports_failure_not_exception():
     mpc.set_initial_guess()
     u0 = mpc.make_step(x0)
     assert u0.shape == (3, 1) and mpc.solver_stats["success"] is False
+
+
+def test_wide_mode_equals_single_workgroup_mode(monkeypatch):
+    """Small batches run K workgroups per problem synchronised by a device-scope barrier; the result must
+    agree with the one-workgroup-per-problem path (only the reduction grouping differs)."""
+    name = "industrial_poly"
+    ex = CASES[name]
+    res = {}
+    for K in ("1", "4", "32"):
+        monkeypatch.setenv("DOMPC_WIDE", K)
+        mpc = make_mpc(name)
+        mpc.x0 = ex.X0
+        mpc.set_initial_guess()
+        res[K] = (mpc.make_step(ex.X0).ravel(), mpc.solver_stats["iter_count"], mpc.opt_x_num.master.copy())
+        assert mpc.solver_stats["success"]
+    for K in ("4", "32"):
+        assert pc.relerr(res[K][0], res["1"][0]) < 1e-9
+        assert abs(res[K][1] - res["1"][1]) <= 1
+        used = np.ones(res[K][2].size, bool)
+        used[make_mpc(name).structure.tables["dummy_idx"]] = False
+        assert pc.relerr(res[K][2][used], res["1"][2][used]) < 1e-7
+    monkeypatch.delenv("DOMPC_WIDE")
+    # a small batch (wide, 8 workgroups per problem) against single solves
+    import bench
+    X0 = bench.synthetic_x0_batch(12)
+    mpc = make_mpc(name, max_batch=12)
+    r = mpc.make_step_batch(X0)
+    assert r["stats"]["success"].all()
+    m1 = make_mpc(name)
+    m1.x0 = X0[7]
+    m1.set_initial_guess()
+    assert pc.relerr(r["u0"][7], m1.make_step(X0[7]).ravel()) < 1e-9
