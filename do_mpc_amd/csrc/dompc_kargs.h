@@ -13,6 +13,7 @@ struct KArgs {
   const int32_t* dummy_idx;
   int32_t N, n_nodes, n_edges, n_dummy, n_opt_x, n_opt_p, n_g, e_pad;
   int32_t p_off_tvp, p_off_p, p_off_uprev;
+  int32_t chain_level;      // first stage from which every node has exactly one child of the same scenario index (= n_robust)
   // batch I/O (device pointers)
   const double *x0, *lbx, *ubx, *lbg, *ubg, *p;
   double *x_out, *g_out, *lam_x_out, *lam_g_out, *f_out;

@@ -53,11 +53,9 @@ constexpr int GS_C = 1;
 
 // per-edge forward-pass record (contiguous per edge; written/read cooperatively by one wavefront) --
 constexpr int EW_LU = 0;                     // NW x NW: G_w^-1 (row-major)
-constexpr int EW_PIV = EW_LU + NW * NW;
-constexpr int EW_W = EW_PIV + NW;            // NW x NA, row-major
+constexpr int EW_W = EW_LU + NW * NW;        // NW x NA, row-major
 constexpr int EW_W0 = EW_W + NW * NA;
-constexpr int EW_HP = EW_W0 + NW;            // NCOLL x NA x NA (lambda-weighted dyn Hessians)
-constexpr int EW_SIGW = EW_HP + NCOLL * NA * NA;
+constexpr int EW_SIGW = EW_W0 + NW;          // (the lambda-weighted Hessian blocks are read from the model-output record)
 constexpr int EW_RW = EW_SIGW + NW;
 constexpr int EW_JD = EW_RW + NW;            // NE x NA
 constexpr int EW_SIZE = EW_JD + NE * NA + 1;
@@ -190,12 +188,8 @@ struct Thr {
   // fence (keeps the compiler from reordering) is sufficient - no workgroup barrier.
   DOMPC_DEV void gsync() const {
 #ifndef DOMPC_HOST_EMU
-#ifdef DOMPC_GSYNC_BLOCK
-    __syncthreads();
-#else
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#endif
 #endif
   }
 };
@@ -439,7 +433,7 @@ constexpr int EL_SG = EL_RW + NW;                                      // Sigma_
 constexpr int EL_U1 = EL_SG + NW;                                      // Huw W (NU x NA), Huw w0 (NU)
 constexpr int EL_QT = EL_U1 + NU * NA + NU;                            // W'T1 (NA x NA), W'W (NA x NA)
 constexpr int EL_PV = EL_QT + 2 * NA * NA;                            // pivot rows (NW)
-constexpr int RB_NEED = 2 * (NYT * NYT + NYT) + 4 * NA * NA + 5 * NA + NX * NA + NX + NV * NA + NV;
+constexpr int RB_NEED = 2 * (NYT * NYT + NYT) + 5 * NA * NA + 6 * NA + NV * NA + NV;
 constexpr int EL_SIZE = (((EL_PV + NW > RB_NEED ? EL_PV + NW : RB_NEED) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {
@@ -513,6 +507,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
   // ---- phase 1: zero Mx (the model-output record of eval_models is read from global memory / L2)
   if (act) {
     for (int i = lane; i < NW * NC; i += GS) Ld[EL_MX + i] = 0.0;
+    for (int r = lane; r < NW; r += GS) Ld[EL_T0 + r] = lam_e[r];      // multipliers of the collocation rows (dual residual)
   }
   T.gsync();
   DOMPC_PH(0)
@@ -587,7 +582,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
     if (act) {
       for (int col = lane; col < NW; col += GS) {
         double t = 0.0;
-        for (int r = 0; r < NW; ++r) t += Ld[EL_MX + r * NC + col] * lam_e[r];
+#pragma unroll 6
+        for (int r = 0; r < NW; ++r) t += Ld[EL_MX + r * NC + col] * Ld[EL_T0 + r];
         if (col >= (M - 1) * NX) t += nu_e[col - (M - 1) * NX];
         const int gi = woff + col;
         const double xv = Q.x[gi], l = Q.lb[gi], u = Q.ub[gi];
@@ -598,7 +594,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
       }
       for (int b = lane; b < NA; b += GS) {
         double t = 0.0;
-        for (int r = 0; r < NW; ++r) t += Ld[EL_MX + r * NC + NW + b] * lam_e[r];
+#pragma unroll 6
+        for (int r = 0; r < NW; ++r) t += Ld[EL_MX + r * NC + NW + b] * Ld[EL_T0 + r];
         S_[ES_RY + b] = t;          // completed below
       }
     }
@@ -775,8 +772,6 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
         Q.EW(e, EW_SIGW + r) = Ld[EL_SG + r];
         Q.EW(e, EW_RW + r) = Ld[EL_RW + r];
       }
-      for (int it = lane; it < NCOLL * NA * NA; it += GS)
-        Q.EW(e, EW_HP + it) = mo[MO_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + it % (NA * NA)];
     }
   }
   T.gsync();
@@ -893,6 +888,287 @@ DOMPC_PHASE void assemble_node(const Prob& Q, int n) {
 // Children are summed at branching nodes (non-anticipativity = shared variables, _mpc.py:1212-1216).
 DOMPC_DEV inline int ycol(int yj) { return yj < NX ? yj : NA + (yj - NX); }
 
+// Riccati update of one tree node by one lane group (see riccati_backward).  Leaves P_n, p_n in the group's
+// LDS region (RB_PN) and in the node record; `child_staged`: the single child's P_c, p_c are already in
+// RB_PC (the group has just computed them while walking up its scenario chain).
+namespace rb {
+// LDS working set of one node update (offsets in doubles inside the group's region)
+constexpr int RB_QO = 0, RB_QOV = RB_QO + NYT * NYT;          // own quadratic (x, u_prev, u, eps) + gradient
+constexpr int RB_QF = RB_QOV + NYT, RB_QFV = RB_QF + NYT * NYT; // own + children's value functions
+constexpr int RB_PC = RB_QFV + NYT, RB_PCV = RB_PC + NA * NA;  // child P_c, p_c
+constexpr int RB_AT = RB_PCV + NA, RB_CT = RB_AT + NA * NA;    // Atilde over y=(x_n,u_n): [[A|B],[0|I]] (NA x NA), ctilde
+constexpr int RB_TP = RB_CT + NA, RB_TV = RB_TP + NA * NA;     // P_c Atilde / P_c Acl, and the vector twins
+constexpr int RB_K = RB_TV + NA, RB_KV = RB_K + NV * NA;
+constexpr int RB_ACL = RB_KV + NV, RB_CCL = RB_ACL + NA * NA;  // closed-loop map Atilde [I;K] (also: scratch for Atilde' TP)
+constexpr int RB_PN = RB_CCL + NA, RB_PNV = RB_PN + NA * NA;   // result P_n, p_n
+constexpr int RB_SIZE = RB_PNV + NA;
+}  // namespace rb
+
+// index of entry i of (x, u_prev, u, eps) inside y = (x_n, u_n), or -1
+DOMPC_DEV inline int yidx(int i) { return (i < NX) ? i : ((i >= NA && i < NA + NU) ? NX + (i - NA) : -1); }
+
+DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu, double delta, ldsd* Ld, int lane, int GS,
+                                  bool child_staged) {
+  using namespace rb;
+  const KArgs& A = *Q.A;
+  double* Nd = Q.ND(n);
+  const int cs = A.node_child_start[n], cc = A.node_child_count[n];
+  const int xo = A.node_x_off[n], uo = A.node_u_off[n];
+  const int eo = NS > 0 ? A.node_eps_off[n] : -1;
+  const int ie = A.node_in_edge[n];
+  const double rw = node_rweight(Q, n);
+  double utmp[NU];
+  const double* up = uprev_ptr(Q, n, Q.x, utmp);
+  long long pc0 = prof_clock();
+#define DOMPC_PN(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
+  // ---- pass A: own quadratic (bounds Sigma, rterm, barrier gradients, slack penalty) plus the condensed
+  //      blocks of all child edges; QF/QFV cleared.  All global loads are issued before anything is used
+  //      (the pass used to cost ~5 dependent global round trips = half of the node update).
+  constexpr int IPL = (NYT * NYT + GS_C - 1) / GS_C;
+  double qpre[IPL];
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int it = lane + q * GS;
+    const int itc = it < NYT * NYT ? it : 0;
+    const int yi = yidx(itc / NYT), yj = yidx(itc % NYT);
+    const bool valid = it < NYT * NYT && yi >= 0 && yj >= 0;
+    const int idx = valid ? yi * NA + yj : 0;
+    double v = 0.0;
+    for (int c = 0; c < cc; ++c) {
+      const double* S_ = Q.ES(cs + c);
+      double t = S_[ES_QT + idx];
+      if (delta != 0.0) t += delta * S_[ES_WTW + idx];
+      v += t;
+    }
+    qpre[q] = valid ? v : 0.0;
+  }
+  // per-variable terms (diagonal + gradient): lanes 0..NYT-1
+  for (int i = lane; i < NYT; i += GS) {
+    const int yi = yidx(i);
+    const bool is_up = (i >= NX && i < NA);
+    const int g = (i < NX) ? xo + i : (is_up ? uo + (i - NX) : (i < NA + NU ? uo + (i - NA) : eo + (i - NA - NU)));
+    const double xv = Q.x[g], lo = Q.lb[g], hi = Q.ub[g], zlo = Q.zl[g], zhi = Q.zu[g];
+    double dg, gv;
+    if (is_up) {
+      dg = 2.0 * rw * DOMPC_RTERM[i - NX];
+      gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - up[i - NX]);            // xv = u_n of the same input
+    } else {
+      dg = sigma_of(xv, lo, hi, zlo, zhi) + delta;
+      gv = bar_grad(xv, lo, hi, mu);
+      if (i < NX) gv += (ie >= 0) ? -Q.lam[A.edge_row0[ie] + NW + i] : Q.lam[i];
+      else if (i < NA + NU) {
+        dg += 2.0 * rw * DOMPC_RTERM[i - NA];
+        gv += 2.0 * rw * DOMPC_RTERM[i - NA] * (xv - up[i - NA]);
+      } else {
+        gv += cc * Q.sf * DOMPC_EPS_PEN[i - NA - NU];
+      }
+    }
+    for (int c = 0; c < cc; ++c) {
+      const int e = cs + c;
+      const double* S_ = Q.ES(e);
+      if (yi >= 0) gv += S_[ES_RY + yi] + S_[ES_QV + yi] + delta * S_[ES_WTW0 + yi];
+      if (NE > 0) {
+        const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
+        for (int q = 0; q < NE; ++q) {
+          const double sg = S_[ES_SIGS + q] + delta;
+          double ji = 0.0;
+          if (yi >= 0) ji = Q.EW(e, EW_JD + q * NA + yi);
+          else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) { ji = -1.0; gv -= yd[q]; }
+          gv += ji * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
+        }
+      }
+    }
+    Ld[RB_QOV + i] = gv;
+    Ld[RB_QFV + i] = 0.0;
+    Ld[RB_QF + i * NYT + i] = dg;      // diagonal parked in QF, merged below
+  }
+  T.gsync();
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int it = lane + q * GS;
+    if (it < NYT * NYT) {
+      const int i = it / NYT, j = it % NYT;
+      double v = qpre[q];
+      if (i == j) v += Ld[RB_QF + i * NYT + i];
+      else if (i >= NX && i < NA && j == i + NU) v -= 2.0 * rw * DOMPC_RTERM[i - NX];
+      else if (j >= NX && j < NA && i == j + NU) v -= 2.0 * rw * DOMPC_RTERM[j - NX];
+      if (NE > 0) {
+        const int yi = yidx(i), yj = yidx(j);
+        for (int c = 0; c < cc; ++c) {
+          const int e = cs + c;
+          const double* S_ = Q.ES(e);
+          for (int qq = 0; qq < NE; ++qq) {
+            const double sg = S_[ES_SIGS + qq] + delta;
+            double ji = 0.0, jj = 0.0;
+            if (yi >= 0) ji = Q.EW(e, EW_JD + qq * NA + yi);
+            else if (i >= NA + NU && DOMPC_NL_SLACK[qq] == i - NA - NU) ji = -1.0;
+            if (yj >= 0) jj = Q.EW(e, EW_JD + qq * NA + yj);
+            else if (j >= NA + NU && DOMPC_NL_SLACK[qq] == j - NA - NU) jj = -1.0;
+            v += sg * ji * jj;
+          }
+        }
+      }
+      Ld[RB_QO + it] = v;
+    }
+  }
+  T.gsync();
+  for (int it = lane; it < NYT * NYT; it += GS) Ld[RB_QF + it] = 0.0;
+  // stage Atilde (y columns) = [[A|B],[0|I]], ctilde = [c;0] and P_c, p_c of child c
+  auto stage_child = [&](int c, bool have_pc) {
+    const int e = cs + c;
+    const double* S_ = Q.ES(e);
+    const double* Nc = Q.ND(A.edge_child[e]);
+    for (int it = lane; it < NA * (NA + 1); it += GS) {
+      const int i = it / (NA + 1), j = it % (NA + 1);
+      if (j < NA) Ld[RB_AT + i * NA + j] = (i < NX) ? S_[ES_AB + i * NA + j] : ((j == i) ? 1.0 : 0.0);
+      else Ld[RB_CT + i] = (i < NX) ? S_[ES_CV + i] : 0.0;
+    }
+    if (!have_pc) {
+      for (int it = lane; it < NA * NA; it += GS) Ld[RB_PC + it] = Nc[ND_P + it];
+      for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Nc[ND_PV + it];
+    }
+  };
+  stage_child(0, child_staged && cc == 1);
+  T.gsync();
+  DOMPC_PN(4)
+  // ---- children, pass 1: coupling Atilde' P_c Atilde (and Atilde'(P_c ctilde + p_c)) summed into QF
+  for (int c = 0; c < cc; ++c) {
+    if (c > 0) { stage_child(c, false); T.gsync(); }
+    gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_PC), NA, 1, (double*)(Ld + RB_AT), NA, 1, 0.0, (double*)(Ld + RB_TP), NA);
+    for (int i = lane; i < NA; i += GS) {
+      double t = Ld[RB_PCV + i];
+#pragma unroll
+      for (int a = 0; a < NX; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CT + a];
+      Ld[RB_TV + i] = t;
+    }
+    T.gsync();
+    gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_AT), 1, NA, (double*)(Ld + RB_TP), NA, 1, 0.0, (double*)(Ld + RB_ACL), NA);
+    for (int i = lane; i < NA; i += GS) {
+      double t = 0.0;
+#pragma unroll
+      for (int a = 0; a < NA; ++a) t += Ld[RB_AT + a * NA + i] * Ld[RB_TV + a];
+      Ld[RB_CCL + i] = t;
+    }
+    T.gsync();
+    for (int it = lane; it < NA * (NA + 1); it += GS) {
+      const int yi = it / (NA + 1), yj = it % (NA + 1);
+      if (yj < NA) Ld[RB_QF + ycol(yi) * NYT + ycol(yj)] += Ld[RB_ACL + yi * NA + yj];
+      else Ld[RB_QFV + ycol(yi)] += Ld[RB_CCL + yi];
+    }
+    T.gsync();
+  }
+  DOMPC_PN(5)
+  // ---- Cholesky of Qvv (QF + QO) and K = -Qvv^-1 Qvx, kv = -Qvv^-1 qv  (one lane per column)
+  int bad = 0;
+  for (int j = lane; j < NA + 1; j += GS) {
+    double L[NV * NV];
+    for (int i = 0; i < NV; ++i)
+      for (int jj = 0; jj <= i; ++jj) {
+        double t = Ld[RB_QF + (NA + i) * NYT + NA + jj] + Ld[RB_QO + (NA + i) * NYT + NA + jj];
+        for (int q = 0; q < jj; ++q) t -= L[i * NV + q] * L[jj * NV + q];
+        if (i == jj) {
+          if (!(t > 0.0)) { bad = 1; t = 1.0; }
+          L[i * NV + i] = sqrt(t);
+        } else {
+          L[i * NV + jj] = t / L[jj * NV + jj];
+        }
+      }
+    double y[NV];
+    for (int i = 0; i < NV; ++i) {
+      double t = (j < NA) ? Ld[RB_QF + (NA + i) * NYT + j] + Ld[RB_QO + (NA + i) * NYT + j]
+                          : Ld[RB_QFV + NA + i] + Ld[RB_QOV + NA + i];
+      for (int q = 0; q < i; ++q) t -= L[i * NV + q] * y[q];
+      y[i] = t / L[i * NV + i];
+    }
+    for (int i = NV - 1; i >= 0; --i) {
+      double t = y[i];
+      for (int q = i + 1; q < NV; ++q) t -= L[q * NV + i] * y[q];
+      y[i] = t / L[i * NV + i];
+    }
+    for (int i = 0; i < NV; ++i) {
+      if (j < NA) { Ld[RB_K + i * NA + j] = -y[i]; Nd[ND_K + i * NA + j] = -y[i]; }
+      else { Ld[RB_KV + i] = -y[i]; Nd[ND_KV + i] = -y[i]; }
+    }
+  }
+  T.gsync();
+  DOMPC_PN(6)
+  // ---- children, pass 2 (closed-loop form):  PN = Lc' QO Lc + sum Acl' P_c Acl ; pn likewise.
+  //      Same pass: own part of PN and the closed-loop map of the staged (last) child.
+  auto closed_loop = [&]() {
+    for (int it = lane; it < NA * (NA + 1); it += GS) {
+      const int i = it / (NA + 1), j = it % (NA + 1);
+      double t;
+      if (j < NA) {
+        // Acl over the augmented state (x, u_prev): column j of [Atilde_x | 0] + Atilde_u K
+        t = (j < NX) ? Ld[RB_AT + i * NA + j] : 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) t += Ld[RB_AT + i * NA + NX + u] * Ld[RB_K + u * NA + j];
+        Ld[RB_ACL + i * NA + j] = t;
+      } else {
+        t = Ld[RB_CT + i];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) t += Ld[RB_AT + i * NA + NX + u] * Ld[RB_KV + u];
+        Ld[RB_CCL + i] = t;
+      }
+    }
+  };
+  for (int it = lane; it < NA * (NA + 1); it += GS) {
+    const int i = it / (NA + 1), j = it % (NA + 1);
+    if (j < NA) {
+      double t = Ld[RB_QO + i * NYT + j];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        t += Ld[RB_QO + i * NYT + NA + q] * Ld[RB_K + q * NA + j];
+        t += Ld[RB_K + q * NA + i] * Ld[RB_QO + (NA + q) * NYT + j];
+        double t2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NV; ++w) t2 += Ld[RB_QO + (NA + q) * NYT + NA + w] * Ld[RB_K + w * NA + j];
+        t += Ld[RB_K + q * NA + i] * t2;
+      }
+      Ld[RB_PN + i * NA + j] = t;
+    } else {
+      double t = Ld[RB_QOV + i];
+#pragma unroll
+      for (int w = 0; w < NV; ++w) t += Ld[RB_QO + i * NYT + NA + w] * Ld[RB_KV + w];
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        double t2 = Ld[RB_QOV + NA + q];
+#pragma unroll
+        for (int w = 0; w < NV; ++w) t2 += Ld[RB_QO + (NA + q) * NYT + NA + w] * Ld[RB_KV + w];
+        t += Ld[RB_K + q * NA + i] * t2;
+      }
+      Ld[RB_PNV + i] = t;
+    }
+  }
+  for (int c = cc - 1; c >= 0; --c) {
+    if (c != cc - 1) { stage_child(c, false); T.gsync(); }      // the last child of pass 1 is still staged
+    closed_loop();
+    T.gsync();
+    gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_PC), NA, 1, (double*)(Ld + RB_ACL), NA, 1, 0.0, (double*)(Ld + RB_TP), NA);
+    for (int i = lane; i < NA; i += GS) {
+      double t = Ld[RB_PCV + i];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CCL + a];
+      Ld[RB_TV + i] = t;
+    }
+    T.gsync();
+    gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_ACL), 1, NA, (double*)(Ld + RB_TP), NA, 1, 1.0, (double*)(Ld + RB_PN), NA);
+    for (int i = lane; i < NA; i += GS) {
+      double t = 0.0;
+#pragma unroll
+      for (int a = 0; a < NA; ++a) t += Ld[RB_ACL + a * NA + i] * Ld[RB_TV + a];
+      Ld[RB_PNV + i] += t;
+    }
+    T.gsync();
+  }
+  for (int it = lane; it < NA * NA; it += GS) Nd[ND_P + it] = Ld[RB_PN + it];
+  for (int it = lane; it < NA; it += GS) Nd[ND_PV + it] = Ld[RB_PNV + it];
+  T.gsync();
+  DOMPC_PN(7)
+#undef DOMPC_PN
+  return bad;
+}
+
 DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double delta) {
   // One group of lanes (a wavefront) per tree node, the node's matrices staged in the group's LDS region:
   //   RB_QO  own quadratic of the node over (x, u_prev, u, eps)       (NYT x NYT) + gradient
@@ -901,299 +1177,66 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
   //   Acl = Atilde Lc: the huge Sigma entries of active state bounds inside P_c meet closed-loop maps
   //   that vanish in the constrained directions instead of being cancelled against each other
   //   (Qxx - Qxv Qvv^-1 Qvx floors the KKT residual at ~Sigma_max*eps).
-  // Levels are processed leaves -> root with a workgroup barrier in between (children's P come from
-  // other groups through global memory).
+  // Below the robust horizon (stage >= chain_level) every node has one child of the same scenario index:
+  // a group walks its scenario chain from the leaf upwards without any barrier and keeps P_c in LDS.
+  // The branching part of the tree is processed level by level with a barrier in between.
+  using namespace rb;
   const KArgs& A = *Q.A;
-  constexpr int RB_QO = 0, RB_QOV = RB_QO + NYT * NYT, RB_QF = RB_QOV + NYT, RB_QFV = RB_QF + NYT * NYT;
-  constexpr int RB_PC = RB_QFV + NYT, RB_PCV = RB_PC + NA * NA, RB_AB = RB_PCV + NA, RB_CV = RB_AB + NX * NA;
-  constexpr int RB_TP = RB_CV + NX, RB_TV = RB_TP + NA * NA, RB_K = RB_TV + NA, RB_KV = RB_K + NV * NA;
-  constexpr int RB_ACL = RB_KV + NV, RB_CCL = RB_ACL + NA * NA, RB_PN = RB_CCL + NA, RB_PNV = RB_PN + NA * NA;
-  constexpr int RB_SIZE = RB_PNV + NA;
   static_assert(RB_SIZE <= EL_SIZE, "node working set must fit the per-group LDS region");
   const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   if (T.tid == 0) T.flags[0] = 0;
   T.sync();
-  for (int k = A.N; k >= 0; --k) {
-    const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
-    if (k == A.N) {
-      // leaves: P = sf*omega*Hm + Sigma_x, p = sf*omega*gm - nu_in + barrier
-      for (int it = T.tid; it < (n1 - n0) * NA * (NA + 1); it += T.nt) {
-        const int n = n0 + it / (NA * (NA + 1));
-        const int r = it % (NA * (NA + 1));
-        const int i = r / (NA + 1), j = r % (NA + 1);
-        double* Nd = Q.ND(n);
-        const int ie = A.node_in_edge[n];
-        const double* S_ = Q.ES(ie);
-        const int xo = A.node_x_off[n];
-        if (j < NA) {
-          double v = 0.0;
-          if (i < NX && j < NX) {
-            v = S_[ES_MH + i * NX + j];
-            if (i == j) v += sigma_of(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], Q.zl[xo + i], Q.zu[xo + i]) + delta;
-          }
-          Nd[ND_P + i * NA + j] = v;
-        } else {
-          double v = 0.0;
-          if (i < NX)
-            v = S_[ES_MG + i] - Q.lam[A.edge_row0[ie] + NW + i] + bar_grad(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], mu);
-          Nd[ND_PV + i] = v;
-        }
-      }
-      T.sync();
-      continue;
-    }
-    for (int n = n0 + gid; n < n1; n += ng) {
+  {
+    // leaves: P = sf*omega*Hm + Sigma_x, p = sf*omega*gm - nu_in + barrier
+    const int n0 = A.level_node_start[A.N], n1 = A.level_node_start[A.N + 1];
+    for (int it = T.tid; it < (n1 - n0) * NA * (NA + 1); it += T.nt) {
+      const int n = n0 + it / (NA * (NA + 1));
+      const int r = it % (NA * (NA + 1));
+      const int i = r / (NA + 1), j = r % (NA + 1);
       double* Nd = Q.ND(n);
-      const int cs = A.node_child_start[n], cc = A.node_child_count[n];
-      const int xo = A.node_x_off[n], uo = A.node_u_off[n];
-      const int eo = NS > 0 ? A.node_eps_off[n] : -1;
       const int ie = A.node_in_edge[n];
-      const double rw = node_rweight(Q, n);
-      double utmp[NU];
-      const double* up = uprev_ptr(Q, n, Q.x, utmp);
-      // ---- own quadratic: bounds (Sigma), rterm, barrier gradients, slack penalty
-      for (int it = lane; it < NYT * (NYT + 1); it += GS) {
-        const int i = it / (NYT + 1), j = it % (NYT + 1);
+      const double* S_ = Q.ES(ie);
+      const int xo = A.node_x_off[n];
+      if (j < NA) {
         double v = 0.0;
-        if (j < NYT) {
-          if (i == j) {
-            if (i < NX) v = sigma_of(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], Q.zl[xo + i], Q.zu[xo + i]) + delta;
-            else if (i < NA) v = 2.0 * rw * DOMPC_RTERM[i - NX];
-            else if (i < NA + NU) {
-              const int g = uo + (i - NA);
-              v = 2.0 * rw * DOMPC_RTERM[i - NA] + sigma_of(Q.x[g], Q.lb[g], Q.ub[g], Q.zl[g], Q.zu[g]) + delta;
-            } else {
-              const int g = eo + (i - NA - NU);
-              v = sigma_of(Q.x[g], Q.lb[g], Q.ub[g], Q.zl[g], Q.zu[g]) + delta;
-            }
-          } else if (i >= NX && i < NA && j == i + NU) v = -2.0 * rw * DOMPC_RTERM[i - NX];
-          else if (j >= NX && j < NA && i == j + NU) v = -2.0 * rw * DOMPC_RTERM[j - NX];
-          Ld[RB_QO + i * NYT + j] = v;
-          Ld[RB_QF + i * NYT + j] = 0.0;
-        } else {
-          if (i < NX) {
-            v = (ie >= 0) ? -Q.lam[A.edge_row0[ie] + NW + i] : Q.lam[i];
-            v += bar_grad(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], mu);
-          } else if (i < NA) {
-            v = -2.0 * rw * DOMPC_RTERM[i - NX] * (Q.x[uo + i - NX] - up[i - NX]);
-          } else if (i < NA + NU) {
-            const int g = uo + (i - NA);
-            v = 2.0 * rw * DOMPC_RTERM[i - NA] * (Q.x[g] - up[i - NA]) + bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu);
-          } else {
-            const int q = i - NA - NU, g = eo + q;
-            v = cc * Q.sf * DOMPC_EPS_PEN[q] + bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu);
-          }
-          Ld[RB_QOV + i] = v;
-          Ld[RB_QFV + i] = 0.0;
+        if (i < NX && j < NX) {
+          v = S_[ES_MH + i * NX + j];
+          if (i == j) v += sigma_of(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], Q.zl[xo + i], Q.zu[xo + i]) + delta;
         }
+        Nd[ND_P + i * NA + j] = v;
+      } else {
+        double v = 0.0;
+        if (i < NX)
+          v = S_[ES_MG + i] - Q.lam[A.edge_row0[ie] + NW + i] + bar_grad(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], mu);
+        Nd[ND_PV + i] = v;
       }
-      T.gsync();
-      // ---- children, pass 1: condensed edge blocks into QO, coupling Atilde' P_c Atilde into QF
-      for (int c = 0; c < cc; ++c) {
-        const int e = cs + c;
-        const double* S_ = Q.ES(e);
-        const double* Nc = Q.ND(A.edge_child[e]);
-        for (int it = lane; it < NA * NA; it += GS) Ld[RB_PC + it] = Nc[ND_P + it];
-        for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Nc[ND_PV + it];
-        for (int it = lane; it < NX * NA; it += GS) Ld[RB_AB + it] = S_[ES_AB + it];
-        for (int it = lane; it < NX; it += GS) Ld[RB_CV + it] = S_[ES_CV + it];
-        for (int it = lane; it < NA * (NA + 1); it += GS) {
-          const int yi = it / (NA + 1), yj = it % (NA + 1);
-          const int i = ycol(yi);
-          if (yj < NA) Ld[RB_QO + i * NYT + ycol(yj)] += S_[ES_QT + yi * NA + yj] + delta * S_[ES_WTW + yi * NA + yj];
-          else Ld[RB_QOV + i] += S_[ES_RY + yi] + S_[ES_QV + yi] + delta * S_[ES_WTW0 + yi];
-        }
-        T.gsync();
-        if (NE > 0) {
-          const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
-          for (int it = lane; it < NYT * (NYT + 1); it += GS) {
-            const int i = it / (NYT + 1), j = it % (NYT + 1);
-            const int yi = (i < NX) ? i : ((i >= NA && i < NA + NU) ? NX + (i - NA) : -1);
-            double acc = 0.0;
-            for (int q = 0; q < NE; ++q) {
-              const double sg = S_[ES_SIGS + q] + delta;
-              double ji = 0.0;
-              if (yi >= 0) ji = Q.EW(e, EW_JD + q * NA + yi);
-              else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) ji = -1.0;
-              if (j < NYT) {
-                const int yj = (j < NX) ? j : ((j >= NA && j < NA + NU) ? NX + (j - NA) : -1);
-                double jj = 0.0;
-                if (yj >= 0) jj = Q.EW(e, EW_JD + q * NA + yj);
-                else if (j >= NA + NU && DOMPC_NL_SLACK[q] == j - NA - NU) jj = -1.0;
-                acc += sg * ji * jj;
-              } else {
-                if (yi < 0 && ji != 0.0) acc -= yd[q];
-                acc += ji * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
-              }
-            }
-            if (j < NYT) Ld[RB_QO + i * NYT + j] += acc;
-            else Ld[RB_QOV + i] += acc;
-          }
-          T.gsync();
-        }
-        // TP = P_c Atilde (y columns) = P_c[:, :NX] [A|B] + P_c[:, NX:] on the u columns;  TV = P_c ctilde + p_c
-        gmm(lane, GS, NA, NA, NX, (double*)(Ld + RB_PC), NA, 1, (double*)(Ld + RB_AB), NA, 1, 0.0, (double*)(Ld + RB_TP), NA);
-        for (int i = lane; i < NA; i += GS) {
-          double t = Ld[RB_PCV + i];
-#pragma unroll
-          for (int a = 0; a < NX; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CV + a];
-          Ld[RB_TV + i] = t;
-        }
-        T.gsync();
-        for (int it = lane; it < NA * NU; it += GS) {
-          const int i = it / NU, u = it % NU;
-          Ld[RB_TP + i * NA + NX + u] += Ld[RB_PC + i * NA + NX + u];
-        }
-        T.gsync();
-        // coupling Atilde' TP = [A|B]' TP[:NX, :] (+ TP rows of the u block) -> ACL used as scratch
-        gmm(lane, GS, NA, NA, NX, (double*)(Ld + RB_AB), 1, NA, (double*)(Ld + RB_TP), NA, 1, 0.0, (double*)(Ld + RB_ACL), NA);
-        T.gsync();
-        for (int it = lane; it < NA * (NA + 1); it += GS) {
-          const int yi = it / (NA + 1), yj = it % (NA + 1);
-          const int i = ycol(yi);
-          if (yj < NA) {
-            double t = Ld[RB_ACL + yi * NA + yj];
-            if (yi >= NX) t += Ld[RB_TP + yi * NA + yj];
-            Ld[RB_QF + i * NYT + ycol(yj)] += t;
-          } else {
-            double t = 0.0;
-#pragma unroll
-            for (int a = 0; a < NX; ++a) t += Ld[RB_AB + a * NA + yi] * Ld[RB_TV + a];
-            if (yi >= NX) t += Ld[RB_TV + yi];
-            Ld[RB_QFV + i] += t;
-          }
-        }
-        T.gsync();
-      }
-      // QF = QO + coupling
-      for (int it = lane; it < NYT * (NYT + 1); it += GS) {
-        const int i = it / (NYT + 1), j = it % (NYT + 1);
-        if (j < NYT) Ld[RB_QF + i * NYT + j] += Ld[RB_QO + i * NYT + j];
-        else Ld[RB_QFV + i] += Ld[RB_QOV + i];
-      }
-      T.gsync();
-      // ---- Cholesky of Qvv and K = -Qvv^-1 Qvx, kv = -Qvv^-1 qv  (one lane per column)
-      int bad = 0;
-      for (int j = lane; j < NA + 1; j += GS) {
-        double L[NV * NV];
-        for (int i = 0; i < NV; ++i)
-          for (int jj = 0; jj <= i; ++jj) {
-            double t = Ld[RB_QF + (NA + i) * NYT + NA + jj];
-            for (int q = 0; q < jj; ++q) t -= L[i * NV + q] * L[jj * NV + q];
-            if (i == jj) {
-              if (!(t > 0.0)) { bad = 1; t = 1.0; }
-              L[i * NV + i] = sqrt(t);
-            } else {
-              L[i * NV + jj] = t / L[jj * NV + jj];
-            }
-          }
-        double y[NV];
-        for (int i = 0; i < NV; ++i) {
-          double t = (j < NA) ? Ld[RB_QF + (NA + i) * NYT + j] : Ld[RB_QFV + NA + i];
-          for (int q = 0; q < i; ++q) t -= L[i * NV + q] * y[q];
-          y[i] = t / L[i * NV + i];
-        }
-        for (int i = NV - 1; i >= 0; --i) {
-          double t = y[i];
-          for (int q = i + 1; q < NV; ++q) t -= L[q * NV + i] * y[q];
-          y[i] = t / L[i * NV + i];
-        }
-        for (int i = 0; i < NV; ++i) {
-          if (j < NA) { Ld[RB_K + i * NA + j] = -y[i]; Nd[ND_K + i * NA + j] = -y[i]; }
-          else { Ld[RB_KV + i] = -y[i]; Nd[ND_KV + i] = -y[i]; }
-        }
-      }
-      if (bad) T.flags[0] = 1;
-      T.gsync();
-      // ---- PN = Lc' QO Lc ; pn = Lc'(QO l0 + qo),  l0 = [0; kv]
-      for (int it = lane; it < NA * (NA + 1); it += GS) {
-        const int i = it / (NA + 1), j = it % (NA + 1);
-        if (j < NA) {
-          double t = Ld[RB_QO + i * NYT + j];
-#pragma unroll
-          for (int q = 0; q < NV; ++q) {
-            t += Ld[RB_QO + i * NYT + NA + q] * Ld[RB_K + q * NA + j];
-            t += Ld[RB_K + q * NA + i] * Ld[RB_QO + (NA + q) * NYT + j];
-            double t2 = 0.0;
-#pragma unroll
-            for (int w = 0; w < NV; ++w) t2 += Ld[RB_QO + (NA + q) * NYT + NA + w] * Ld[RB_K + w * NA + j];
-            t += Ld[RB_K + q * NA + i] * t2;
-          }
-          Ld[RB_PN + i * NA + j] = t;
-        } else {
-          double t = Ld[RB_QOV + i];
-#pragma unroll
-          for (int w = 0; w < NV; ++w) t += Ld[RB_QO + i * NYT + NA + w] * Ld[RB_KV + w];
-#pragma unroll
-          for (int q = 0; q < NV; ++q) {
-            double t2 = Ld[RB_QOV + NA + q];
-#pragma unroll
-            for (int w = 0; w < NV; ++w) t2 += Ld[RB_QO + (NA + q) * NYT + NA + w] * Ld[RB_KV + w];
-            t += Ld[RB_K + q * NA + i] * t2;
-          }
-          Ld[RB_PNV + i] = t;
-        }
-      }
-      T.gsync();
-      // ---- children, pass 2: PN += Acl' P_c Acl, pn += Acl'(P_c ccl + p_c)
-      for (int c = 0; c < cc; ++c) {
-        const int e = cs + c;
-        const double* S_ = Q.ES(e);
-        const double* Nc = Q.ND(A.edge_child[e]);
-        if (cc > 1) {     // (for a single child PC/AB/CV are still staged from pass 1)
-          for (int it = lane; it < NA * NA; it += GS) Ld[RB_PC + it] = Nc[ND_P + it];
-          for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Nc[ND_PV + it];
-          for (int it = lane; it < NX * NA; it += GS) Ld[RB_AB + it] = S_[ES_AB + it];
-          for (int it = lane; it < NX; it += GS) Ld[RB_CV + it] = S_[ES_CV + it];
-          T.gsync();
-        }
-        for (int it = lane; it < NA * (NA + 1); it += GS) {
-          const int i = it / (NA + 1), j = it % (NA + 1);
-          double t;
-          if (j < NA) {
-            if (i < NX) {
-              t = (j < NX) ? Ld[RB_AB + i * NA + j] : 0.0;
-#pragma unroll
-              for (int u = 0; u < NU; ++u) t += Ld[RB_AB + i * NA + NX + u] * Ld[RB_K + u * NA + j];
-            } else {
-              t = Ld[RB_K + (i - NX) * NA + j];
-            }
-            Ld[RB_ACL + i * NA + j] = t;
-          } else {
-            if (i < NX) {
-              t = Ld[RB_CV + i];
-#pragma unroll
-              for (int u = 0; u < NU; ++u) t += Ld[RB_AB + i * NA + NX + u] * Ld[RB_KV + u];
-            } else {
-              t = Ld[RB_KV + i - NX];
-            }
-            Ld[RB_CCL + i] = t;
-          }
-        }
-        T.gsync();
-        // T2 = P_c Acl ; tv2 = P_c ccl + p_c ; PN += Acl' T2 ; pn += Acl' tv2
-        gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_PC), NA, 1, (double*)(Ld + RB_ACL), NA, 1, 0.0, (double*)(Ld + RB_TP), NA);
-        for (int i = lane; i < NA; i += GS) {
-          double t = Ld[RB_PCV + i];
-#pragma unroll
-          for (int a = 0; a < NA; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CCL + a];
-          Ld[RB_TV + i] = t;
-        }
-        T.gsync();
-        gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_ACL), 1, NA, (double*)(Ld + RB_TP), NA, 1, 1.0, (double*)(Ld + RB_PN), NA);
-        for (int i = lane; i < NA; i += GS) {
-          double t = 0.0;
-#pragma unroll
-          for (int a = 0; a < NA; ++a) t += Ld[RB_ACL + a * NA + i] * Ld[RB_TV + a];
-          Ld[RB_PNV + i] += t;
-        }
-        T.gsync();
-      }
-      for (int it = lane; it < NA * NA; it += GS) Nd[ND_P + it] = Ld[RB_PN + it];
-      for (int it = lane; it < NA; it += GS) Nd[ND_PV + it] = Ld[RB_PNV + it];
-      T.gsync();
     }
+    T.sync();
+  }
+  const int cl = A.chain_level < A.N ? A.chain_level : A.N;
+  {
+    // scenario chains: stages N-1 ... chain_level, node (k, s) -> parent (k-1, s)
+    const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
+    for (int s_ = gid; s_ < S; s_ += ng) {
+      bool staged = false;
+      for (int k = A.N - 1; k >= cl; --k) {
+        if (staged) {            // P of the node just finished becomes P_c of its parent
+          for (int it = lane; it < NA * NA; it += GS) Ld[RB_PC + it] = Ld[RB_PN + it];
+          for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Ld[RB_PNV + it];
+          T.gsync();
+        }
+        if (riccati_node(T, Q, A.level_node_start[k] + s_, mu, delta, Ld, lane, GS, staged)) { T.flags[0] = 1; break; }
+        staged = true;
+      }
+    }
+    T.sync();
+    if (T.flags[0]) return 1;
+  }
+  for (int k = cl - 1; k >= 0; --k) {
+    const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
+    for (int n = n0 + gid; n < n1; n += ng)
+      if (riccati_node(T, Q, n, mu, delta, Ld, lane, GS, false)) T.flags[0] = 1;
     T.sync();
     if (T.flags[0]) return 1;
   }
@@ -1207,8 +1250,8 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   constexpr int RF_DX = 0, RF_DV = RF_DX + NA, RF_DY = RF_DV + NV, RF_DNU = RF_DY + NA, RF_DW = RF_DNU + NX,
-                RF_RHS = RF_DW + NW1;
-  static_assert(RF_RHS + NW1 <= EL_SIZE, "forward working set must fit the per-group LDS region");
+                RF_RHS = RF_DW + NW1, RF_DXN = RF_RHS + NW1;
+  static_assert(RF_DXN + NA <= EL_SIZE, "forward working set must fit the per-group LDS region");
   // root
   if (T.tid == 0) {
     double* Nd = Q.ND(0);
@@ -1217,40 +1260,57 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     for (int a = NX; a < NA; ++a) Nd[ND_DXT + a] = 0.0;
   }
   T.sync();
-  for (int k = 0; k < A.N; ++k) {
-    const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
-    for (int n = n0 + gid; n < n1; n += ng) {
-      const double* Nd = Q.ND(n);
+  // node steps: dv = K dx~ + kv, children dx~ = Atilde [dx~; dv] + c~.  Branching stages level by level with
+  // a barrier; below the robust horizon each group walks its scenario chain downwards with dx~ kept in LDS.
+  auto node_step = [&](int n, bool staged) {
+    const double* Nd = Q.ND(n);
+    if (!staged) {
       for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Nd[ND_DXT + a];
       T.gsync();
-      for (int i = lane; i < NV; i += GS) {
-        double t = Nd[ND_KV + i];
+    }
+    for (int i = lane; i < NV; i += GS) {
+      double t = Nd[ND_KV + i];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) t += Nd[ND_K + i * NA + a] * Ld[RF_DX + a];
-        Ld[RF_DV + i] = t;
-        if (i < NU) Q.dx[A.node_u_off[n] + i] = t;
-        else Q.dx[A.node_eps_off[n] + i - NU] = t;
+      for (int a = 0; a < NA; ++a) t += Nd[ND_K + i * NA + a] * Ld[RF_DX + a];
+      Ld[RF_DV + i] = t;
+      if (i < NU) Q.dx[A.node_u_off[n] + i] = t;
+      else Q.dx[A.node_eps_off[n] + i - NU] = t;
+    }
+    T.gsync();
+    const int cs = A.node_child_start[n], cc = A.node_child_count[n];
+    for (int it = lane; it < cc * NA; it += GS) {
+      const int e = cs + it / NA, a = it % NA, cn = A.edge_child[e];
+      const double* S_ = Q.ES(e);
+      double t;
+      if (a < NX) {
+        t = S_[ES_CV + a];
+#pragma unroll
+        for (int b = 0; b < NX; ++b) t += S_[ES_AB + a * NA + b] * Ld[RF_DX + b];
+#pragma unroll
+        for (int b = 0; b < NU; ++b) t += S_[ES_AB + a * NA + NX + b] * Ld[RF_DV + b];
+        Q.dx[A.node_x_off[cn] + a] = t;
+      } else {
+        t = Ld[RF_DV + a - NX];
       }
-      T.gsync();
-      const int cs = A.node_child_start[n], cc = A.node_child_count[n];
-      for (int it = lane; it < cc * NA; it += GS) {
-        const int e = cs + it / NA, a = it % NA, cn = A.edge_child[e];
-        const double* S_ = Q.ES(e);
-        double t;
-        if (a < NX) {
-          t = S_[ES_CV + a];
-#pragma unroll
-          for (int b = 0; b < NX; ++b) t += S_[ES_AB + a * NA + b] * Ld[RF_DX + b];
-#pragma unroll
-          for (int b = 0; b < NU; ++b) t += S_[ES_AB + a * NA + NX + b] * Ld[RF_DV + b];
-          Q.dx[A.node_x_off[cn] + a] = t;
-        } else {
-          t = Ld[RF_DV + a - NX];
-        }
-        Q.ND(cn)[ND_DXT + a] = t;
-      }
+      Q.ND(cn)[ND_DXT + a] = t;
+      if (cc == 1) Ld[RF_DXN + a] = t;
+    }
+    T.gsync();
+    if (cc == 1) {
+      for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Ld[RF_DXN + a];
       T.gsync();
     }
+  };
+  const int cl = A.chain_level < A.N ? A.chain_level : A.N;
+  for (int k = 0; k < cl; ++k) {
+    const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
+    for (int n = n0 + gid; n < n1; n += ng) node_step(n, false);
+    T.sync();
+  }
+  {
+    const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
+    for (int s_ = gid; s_ < S; s_ += ng)
+      for (int k = cl; k < A.N; ++k) node_step(A.level_node_start[k] + s_, k > cl);
     T.sync();
   }
   // initial-condition multiplier step
@@ -1260,12 +1320,32 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     for (int b = 0; b < NA; ++b) t += Nd[ND_P + a * NA + b] * Nd[ND_DXT + b];
     Q.dlam[a] = -t;
   }
-  // per edge: dw, d nu, d lambda, nl_cons steps
+  // per edge: dw, d nu, d lambda, nl_cons steps.  The per-edge record entries a lane needs (its rows of W, Hww,
+  // its column of G_w^-1) do not depend on the step, so they are loaded into registers up front: two global
+  // round trips per edge instead of one per dependent sub-step.
   for (int e = gid; e < A.n_edges; e += ng) {
     const int n = A.edge_parent[e], cn = A.edge_child[e];
     const double* Nd = Q.ND(n);
     const double* Nc = Q.ND(cn);
     const int row0 = A.edge_row0[e];
+    constexpr int RPL = (NW1 + GS_C - 1) / GS_C;          // rows (= columns of G_w^-1) per lane: 1 on the device
+    double wrow[RPL][NA + 1], hrow[RPL][NA], rw_r[RPL], sg_r[RPL];
+    if (M > 0) {
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) {
+        const int r = lane + q * GS;
+        const int rc = r < NW ? r : 0;
+        const int pt = point_of_slot(rc / NX);
+#pragma unroll
+        for (int b = 0; b < NA; ++b) wrow[q][b] = Q.EW(e, EW_W + rc * NA + b);
+        wrow[q][NA] = Q.EW(e, EW_W0 + rc);
+        rw_r[q] = Q.EW(e, EW_RW + rc);
+        sg_r[q] = Q.EW(e, EW_SIGW + rc);
+        const double* Hp = Q.MO(e) + MO_PT + (pt >= 0 ? pt : 0) * PT_STRIDE + NX + NX * NA;
+#pragma unroll
+        for (int b = 0; b < NA; ++b) hrow[q][b] = (pt >= 0) ? Hp[(rc % NX) * NA + b] : 0.0;
+      }
+    }
     for (int a = lane; a < NA; a += GS) Ld[RF_DY + a] = (a < NX) ? Nd[ND_DXT + a] : Q.dx[A.node_u_off[n] + a - NX];
     for (int a = lane; a < NX; a += GS) {
       double t = Nc[ND_PV + a];
@@ -1277,35 +1357,52 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     T.gsync();
     if (M > 0) {
       const int woff = A.edge_w_off[e];
-      for (int r = lane; r < NW; r += GS) {
-        double t = Q.EW(e, EW_W0 + r);
+      double inv_c[RPL][NW1];
 #pragma unroll
-        for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_W + r * NA + b) * Ld[RF_DY + b];
-        Ld[RF_DW + r] = t;
-        Q.dx[woff + r] = t;
+      for (int q = 0; q < RPL; ++q) {
+        const int r = lane + q * GS;
+        const int rc = r < NW ? r : 0;
+#pragma unroll
+        for (int k2 = 0; k2 < NW; ++k2) inv_c[q][k2] = Q.EW(e, EW_LU + k2 * NW + rc);     // column r of G_w^-1
+      }
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) {
+        const int r = lane + q * GS;
+        if (r < NW) {
+          double t = wrow[q][NA];
+#pragma unroll
+          for (int b = 0; b < NA; ++b) t += wrow[q][b] * Ld[RF_DY + b];
+          Ld[RF_DW + r] = t;
+          Q.dx[woff + r] = t;
+        }
       }
       T.gsync();
       // rhs = -(rw + (Sigma_w+delta) dw + Hww dw + Hwu du + S' dnu)
-      for (int r = lane; r < NW; r += GS) {
-        double t = Q.EW(e, EW_RW + r) + (Q.EW(e, EW_SIGW + r) + delta) * Ld[RF_DW + r];
-        if (r >= (M - 1) * NX) t += Ld[RF_DNU + r - (M - 1) * NX];
-        const int sl = r / NX, a = r % NX;
-        const int p = point_of_slot(sl);
-        if (p >= 0) {
 #pragma unroll
-          for (int b = 0; b < NX; ++b) t += Q.EW(e, EW_HP + p * NA * NA + a * NA + b) * Ld[RF_DW + sl * NX + b];
+      for (int q = 0; q < RPL; ++q) {
+        const int r = lane + q * GS;
+        if (r < NW) {
+          const int sl = r / NX;
+          double t = rw_r[q] + (sg_r[q] + delta) * Ld[RF_DW + r];
+          if (r >= (M - 1) * NX) t += Ld[RF_DNU + r - (M - 1) * NX];
 #pragma unroll
-          for (int b = 0; b < NU; ++b) t += Q.EW(e, EW_HP + p * NA * NA + a * NA + NX + b) * Ld[RF_DY + NX + b];
+          for (int b = 0; b < NX; ++b) t += hrow[q][b] * Ld[RF_DW + sl * NX + b];
+#pragma unroll
+          for (int b = 0; b < NU; ++b) t += hrow[q][NX + b] * Ld[RF_DY + NX + b];
+          Ld[RF_RHS + r] = -t;
         }
-        Ld[RF_RHS + r] = -t;
       }
       T.gsync();
-      // d lambda = G_w^-T rhs  (EW_LU holds G_w^-1, row-major: lanes read consecutive addresses)
-      for (int r = lane; r < NW; r += GS) {
-        double t = 0.0;
-#pragma unroll 6
-        for (int q = 0; q < NW; ++q) t += Q.EW(e, EW_LU + q * NW + r) * Ld[RF_RHS + q];
-        Q.dlam[row0 + r] = t;
+      // d lambda = G_w^-T rhs
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) {
+        const int r = lane + q * GS;
+        if (r < NW) {
+          double t = 0.0;
+#pragma unroll
+          for (int k2 = 0; k2 < NW; ++k2) t += inv_c[q][k2] * Ld[RF_RHS + k2];
+          Q.dlam[row0 + r] = t;
+        }
       }
     }
     if (NE > 0) {

@@ -287,6 +287,22 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   A.N = d.N; A.n_nodes = d.n_nodes; A.n_edges = d.n_edges; A.n_dummy = d.n_dummy;
   A.n_opt_x = d.n_opt_x; A.n_opt_p = d.n_opt_p; A.n_g = d.n_g; A.e_pad = h->e_pad;
   A.p_off_tvp = d.p_off_tvp; A.p_off_p = d.p_off_p; A.p_off_uprev = d.p_off_uprev;
+  {
+    // chain_level: first stage from which every node (k, s) has exactly one child, (k+1, s)
+    const int32_t* ls = desc->level_node_start;
+    const int S = ls[d.N + 1] - ls[d.N];
+    int cl = d.N;
+    for (int k = d.N - 1; k >= 0; --k) {
+      bool ok = (ls[k + 1] - ls[k]) == S;
+      for (int s = 0; ok && s < S; ++s) {
+        const int n = ls[k] + s;
+        ok = desc->node_child_count[n] == 1 && desc->edge_child[desc->node_child_start[n]] == ls[k + 1] + s;
+      }
+      if (!ok) break;
+      cl = k;
+    }
+    A.chain_level = cl;
+  }
   A.opt = d.opts;
   A.n_slots = h->n_slots;
   A.ws_stride = h->ws_stride;

@@ -30,7 +30,8 @@ def main():
         print(f"  {nm:12s} {v / 1e6:9.2f} Mcycles  {100 * v / tot:5.1f} %")
     print(f"  total        {tot / 1e6:9.2f} Mcycles (problem 0)")
     sub = mpc.S.trace(4096)[-2]
-    for nm, v in zip(("edge:model-eval", "edge:assemble+dual", "edge:gauss-jordan", "edge:condense+store"), sub[:4]):
+    for nm, v in zip(("edge:model-eval", "edge:assemble+dual", "edge:gauss-jordan", "edge:condense+store",
+                      "node:own+stage", "node:coupling", "node:cholesky+K", "node:closed-loop+store"), sub[:8]):
         print(f"    {nm:22s} {v / 1e6:9.2f} Mcycles")
 
 
