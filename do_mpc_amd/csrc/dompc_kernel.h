@@ -602,77 +602,95 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
     T.gsync();
     DOMPC_PH(1)
     // ---- phase 4: in-place Gauss-Jordan inversion of [G_w | G_y | r_g], one matrix COLUMN per lane.
-    // Per step every lane reads column kk (same addresses for all lanes -> LDS broadcast) and finds the
-    // pivot row redundantly with a packed (|value| high word, row) key - no cross-lane reduction; rows kk
-    // and pivot are interchanged; then each lane updates its own column: all loads, all FMAs, all stores
-    // (independent chains that pipeline in the LDS queue).  Column kk becomes the kk-th column of the
-    // inverse in place; the row interchanges are undone on the columns of the inverse afterwards.
+    // Per step every lane loads column kk (same addresses for all lanes -> LDS broadcast) and, in the same
+    // LDS round trip, its own column; the pivot row is found redundantly with a packed (|value| high word,
+    // row) key - no cross-lane reduction and no row interchange (the pivot row of each column is remembered
+    // and the rows are relabelled once at the end), so a step is ONE wavefront barrier and two LDS round
+    // trips.  Column kk becomes the kk-th column of the inverse in place.  (A register-resident variant -
+    // column per lane in VGPRs, v_readlane broadcast of column kk, scalar pivot search - was measured 25 %
+    // slower on MI355X: ~250 extra VALU/SALU instructions per step cost more than the LDS traffic they save.)
+    // Structure: rows/columns come in groups [collocation rows of element i | continuity rows of element i]
+    // (optimizer.py:943-983) and G_w is block lower-triangular in that grouping.  Pivots are searched inside
+    // the group of the current column only (the diagonal blocks are the nonsingular collocation Jacobians,
+    // resp. identities), which keeps the structure; the last NX columns (xkf: identity block, zero above)
+    // need no elimination step at all - their inverse columns are already in place.
     {
-      static_assert(NW <= 64, "row index is packed into 6 bits of the pivot key");
-      // Structure: rows/columns come in groups [collocation rows of element i | continuity rows of element i]
-      // (optimizer.py:943-983) and G_w is block lower-triangular in that grouping.  Pivots are searched
-      // inside the group of the current column only (the diagonal blocks are the nonsingular collocation
-      // Jacobians, resp. identities), which keeps the structure; the last NX columns (xkf: identity block,
-      // zero above) need no elimination step at all - their inverse columns are already in place.
+      static_assert(NW <= 64, "row index is packed into 6 bits of the pivot key / 64-bit used mask");
       constexpr int GJ_STEPS = NW - NX;
       constexpr int EL_ROWS = (DEG + 1) * NX;
+      constexpr int CPL = (NC + GS_C - 1) / GS_C;
+      unsigned long long used = 0ull;
       for (int kk = 0; kk < GJ_STEPS; ++kk) {
         const int pos = kk % EL_ROWS;
-        const int grp_end = kk - pos + (pos < DEG * NX ? DEG * NX : EL_ROWS);
-        double f[NW1];
+        const int grp0 = kk - pos + (pos < DEG * NX ? 0 : DEG * NX);
+        const int grp1 = kk - pos + (pos < DEG * NX ? DEG * NX : EL_ROWS);
+        double f[NW1], bcol[CPL][NW1];
         unsigned bestkey = 0u;
+        if (act) {
 #pragma unroll
-        for (int r = 0; r < NW; ++r) {
-          f[r] = act ? Ld[EL_MX + r * NC + kk] : 0.0;
-          unsigned key = (((unsigned)(__builtin_bit_cast(unsigned long long, f[r]) >> 32)) & 0x7fffffc0u) | (unsigned)r;
-          key = (r >= kk && r < grp_end) ? key : 0u;
-          bestkey = key > bestkey ? key : bestkey;
+          for (int r = 0; r < NW; ++r) f[r] = Ld[EL_MX + r * NC + kk];
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            const int c = lane + q * GS;
+            const int cc_ = c < NC ? c : 0;
+#pragma unroll
+            for (int r = 0; r < NW; ++r) bcol[q][r] = Ld[EL_MX + r * NC + cc_];
+          }
+#pragma unroll
+          for (int r = 0; r < NW; ++r) {
+            unsigned key = (((unsigned)(__builtin_bit_cast(unsigned long long, f[r]) >> 32)) & 0x7fffffc0u) | (unsigned)r;
+            key = (r >= grp0 && r < grp1 && !((used >> r) & 1ull)) ? key : 0u;
+            bestkey = key > bestkey ? key : bestkey;
+          }
         }
         const int pv = (int)(bestkey & 63u);
+        used |= (1ull << pv);
         if (act && (bestkey >> 6) == 0u) fail = 1;          // |pivot| < ~1e-300: singular collocation block
         if (act) {
           if (lane == 0) Ld[EL_PV + kk] = (double)pv;
-          if (pv != kk)
-            for (int c = lane; c < NC; c += GS) {
-              const double t1 = Ld[EL_MX + kk * NC + c], t2 = Ld[EL_MX + pv * NC + c];
-              Ld[EL_MX + kk * NC + c] = t2;
-              Ld[EL_MX + pv * NC + c] = t1;
-            }
-        }
-        T.gsync();
-        if (act) {
-          if (pv != kk) {
-#pragma unroll
-            for (int r = 0; r < NW; ++r) f[r] = Ld[EL_MX + r * NC + kk];
-          }
-          const double piv = Ld[EL_MX + kk * NC + kk];
+          const double piv = Ld[EL_MX + pv * NC + kk];
           const double pinv = (fabs(piv) > 1e-300) ? 1.0 / piv : 1.0;
-          for (int c = lane; c < NC; c += GS) {
-            double bcol[NW1];
 #pragma unroll
-            for (int r = 0; r < NW; ++r) bcol[r] = Ld[EL_MX + r * NC + c];
-            const double prow = (c == kk) ? pinv : Ld[EL_MX + kk * NC + c] * pinv;
-            const double keep = (c == kk) ? 0.0 : 1.0;
+          for (int q = 0; q < CPL; ++q) {
+            const int c = lane + q * GS;
+            if (c < NC) {
+              const double prow = (c == kk) ? pinv : Ld[EL_MX + pv * NC + c] * pinv;
+              const double keep = (c == kk) ? 0.0 : 1.0;
 #pragma unroll
-            for (int r = 0; r < NW; ++r) bcol[r] = fma(-f[r], prow, bcol[r] * keep);
-#pragma unroll
-            for (int r = 0; r < NW; ++r) Ld[EL_MX + r * NC + c] = bcol[r];
-            Ld[EL_MX + kk * NC + c] = prow;
+              for (int r = 0; r < NW; ++r) Ld[EL_MX + r * NC + c] = fma(-f[r], prow, bcol[q][r] * keep);
+              Ld[EL_MX + pv * NC + c] = prow;
+            }
           }
         }
         T.gsync();
       }
-      // undo the row interchanges on the columns of the inverse (reverse order); lane r owns row r here
+      // relabel: stored[p_k][c] = Ginv[k][p_c] for the inverse part, stored[p_k][c] = (Ginv B)[k][c] for the
+      // right-hand sides (p_k = pivot row of column k; identity for the skipped xkf columns)
+      double tmp[CPL][NW1];
       if (act) {
-        for (int r = lane; r < NW; r += GS)
-          for (int kk = GJ_STEPS - 1; kk >= 0; --kk) {
-            const int pv = (int)Ld[EL_PV + kk];
-            if (pv != kk) {
-              const double t = Ld[EL_MX + r * NC + kk];
-              Ld[EL_MX + r * NC + kk] = Ld[EL_MX + r * NC + pv];
-              Ld[EL_MX + r * NC + pv] = t;
-            }
+        for (int k2 = GJ_STEPS + lane; k2 < NW; k2 += GS) Ld[EL_PV + k2] = (double)k2;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          const int c = lane + q * GS;
+          const int cc_ = c < NC ? c : 0;
+#pragma unroll
+          for (int r = 0; r < NW; ++r) tmp[q][r] = Ld[EL_MX + r * NC + cc_];
+        }
+      }
+      T.gsync();
+      if (act)
+        for (int k2 = lane; k2 < NW; k2 += GS) Ld[EL_T0 + (int)Ld[EL_PV + k2]] = (double)k2;   // kof[row] = column it was the pivot of
+      T.gsync();
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          const int c = lane + q * GS;
+          if (c < NC) {
+            const int dst = (c < NW) ? (int)Ld[EL_PV + c] : c;
+#pragma unroll
+            for (int r = 0; r < NW; ++r) Ld[EL_MX + (int)Ld[EL_T0 + r] * NC + dst] = tmp[q][r];
           }
+        }
       }
       T.gsync();
     }
