@@ -431,8 +431,11 @@ constexpr int EL_T0 = EL_T1 + NW * NA;                                 // Hww w0
 constexpr int EL_RW = EL_T0 + NW;                                      // Newton-form gradient of w (NW)
 constexpr int EL_SG = EL_RW + NW;                                      // Sigma_w (NW)
 constexpr int EL_U1 = EL_SG + NW;                                      // Huw W (NU x NA), Huw w0 (NU)
-constexpr int EL_QT = EL_U1 + NU * NA + NU;                            // W'T1 (NA x NA), W'W (NA x NA)
-constexpr int EL_PV = EL_QT + 2 * NA * NA;                            // pivot rows (NW)
+constexpr int EL_HUU = EL_U1 + NU * NA + NU;                           // sum_p Huu_p (NU x NU)
+constexpr int EL_QT = EL_HUU + NU * NU;                                // W'T1 (NA x NA), W'W (NA x NA)
+constexpr int EL_HP = EL_QT;                                           // staged point Hessians H_p (NA x NA each): dead before QT is written
+constexpr int EL_NHP = (NI * DEG > 2 ? NI * DEG : 2);
+constexpr int EL_PV = EL_QT + EL_NHP * NA * NA;                        // pivot rows (NW)
 constexpr int RB_NEED = 2 * (NYT * NYT + NYT) + 5 * NA * NA + 6 * NA + NV * NA + NV;
 constexpr int EL_SIZE = (((EL_PV + NW > RB_NEED ? EL_PV + NW : RB_NEED) + 7) / 8) * 8;
 
@@ -481,7 +484,7 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
   }
 }
 
-DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, int lane, int GS, ldsd* Ld) {
+DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, double mu, int lane, int GS, ldsd* Ld) {
   const KArgs& A = *Q.A;
   const bool act = e >= 0;
   const int ee = act ? e : 0;
@@ -501,6 +504,12 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
   double* S_ = Q.ES(ee);
   const double* mo = Q.MO(ee);
   int fail = 0;
+#ifndef DOMPC_HOST_EMU
+  constexpr int PF_LINES = (MO_SIZE * 8 + 127) / 128, PF_N = (PF_LINES + 63) / 64;
+  unsigned pf_tok[PF_N];
+#pragma unroll
+  for (int q = 0; q < PF_N; ++q) pf_tok[q] = 0u;
+#endif
   long long pc0 = prof_clock();
 #define DOMPC_PH(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
 
@@ -537,8 +546,11 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
       }
     }
   } else {
-    // ---- phase 2: assemble Mx = [G_w | G_y | r_g] and the residual rows
+    // ---- phase 2: assemble Mx = [G_w | G_y | r_g] and the residual rows; the point Hessians needed by the
+    //      condensing phases are staged in LDS with the same batch of global loads
     if (act) {
+      for (int it = lane; it < NCOLL * NA * NA; it += GS)
+        Ld[EL_HP + it] = mo[MO_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + it % (NA * NA)];
       for (int it = lane; it < NI * (DEG + 1) * NX; it += GS) {
         const int i = it / ((DEG + 1) * NX);
         const int rr = it % ((DEG + 1) * NX);
@@ -704,6 +716,16 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
     T.gsync();
     DOMPC_PH(2)
     // ---- phase 5: T1 = Hww W, t0 = Hww w0, U1 = Huw W, u0 = Huw w0   (Hww = blockdiag(Hxx_p) + Sigma_w)
+    //      (stage-cost / nl_cons Hessian entries for phase 6 are requested now, consumed there)
+    constexpr int QPL = (NA * NA + GS_C - 1) / GS_C;
+    double qlt[QPL], qnl[QPL];
+#pragma unroll
+    for (int q = 0; q < QPL; ++q) {
+      const int it = lane + q * GS;
+      const int itc = it < NA * NA ? it : 0;
+      qlt[q] = act ? mo[MO_LT + 1 + NA + itc] : 0.0;
+      qnl[q] = (act && NE > 0) ? mo[MO_NL + NE + NE * NA + itc] : 0.0;
+    }
     if (act) {
       for (int it = lane; it < NW * (NA + 1); it += GS) {
         const int row = it / (NA + 1), b = it % (NA + 1);
@@ -712,7 +734,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
           const int sl = row / NX, a = row % NX;
           const int p = point_of_slot(sl);
           if (p >= 0) {
-            const double* Hp = mo + MO_PT + p * PT_STRIDE + NX + NX * NA;
+            const ldsd* Hp = Ld + EL_HP + p * NA * NA;
 #pragma unroll
             for (int a2 = 0; a2 < NX; ++a2) t += Hp[a * NA + a2] * Ld[EL_MX + (sl * NX + a2) * NC + NW + NA];
           }
@@ -726,11 +748,16 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
         double t = 0.0;
         for (int p = 0; p < NCOLL; ++p) {
           const int sl = slot_of(p / DEG, p % DEG + 1);
-          const double* Hp = mo + MO_PT + p * PT_STRIDE + NX + NX * NA;
+          const ldsd* Hp = Ld + EL_HP + p * NA * NA;
 #pragma unroll
           for (int a = 0; a < NX; ++a) t += Hp[a * NA + NX + ub] * Ld[EL_MX + (sl * NX + a) * NC + NW + b];
         }
         Ld[EL_U1 + (b < NA ? ub * NA + b : NU * NA + ub)] = t;
+      }
+      for (int it = lane; it < NU * NU; it += GS) {
+        double h = 0.0;
+        for (int p = 0; p < NCOLL; ++p) h += Ld[EL_HP + p * NA * NA + (NX + it / NU) * NA + NX + it % NU];
+        Ld[EL_HUU + it] = h;
       }
     }
     T.gsync();
@@ -738,7 +765,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
       // T1[slot rows] += Hxx_p * W[slot rows]   (matrix cores)
       for (int p = 0; p < NCOLL; ++p) {
         const int sl = slot_of(p / DEG, p % DEG + 1);
-        gmm(lane, GS, NX, NA, NX, mo + MO_PT + p * PT_STRIDE + NX + NX * NA, NA, 1,
+        gmm(lane, GS, NX, NA, NX, (double*)(Ld + EL_HP + p * NA * NA), NA, 1,
             (double*)(Ld + EL_MX + (sl * NX) * NC + NW), NC, 1, 1.0, (double*)(Ld + EL_T1 + sl * NX * NA), NA);
       }
     }
@@ -750,20 +777,31 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
     }
     T.gsync();
     // ---- phase 6: condensed blocks to the shared per-edge record; data for the forward pass
+#ifndef DOMPC_HOST_EMU
+    // touch the model-output record of the edge this wavefront handles next (one dword per 128-byte line):
+    // by the time its assembly starts the lines sit in L2 instead of HBM.  The values are consumed (never
+    // true) at the end of the function so that the loads stay where they are.
+#pragma unroll
+    for (int q = 0; q < PF_N; ++q) {
+      const int line = lane + 64 * q;
+      pf_tok[q] = (e_next >= 0 && line < PF_LINES)
+                      ? *((const volatile unsigned*)((const char*)Q.MO(e_next) + (int64_t)line * 128)) : 0u;
+    }
+#endif
     if (act) {
-      for (int it = lane; it < NA * NA; it += GS) {
-        const int a1 = it / NA, b = it % NA;
-        double q = om * mo[MO_LT + 1 + NA + it] + Ld[EL_QT + it];
-        if (NE > 0) q += mo[MO_NL + NE + NE * NA + it];
-        if (a1 >= NX && b >= NX) {
-          double h = 0.0;
-          for (int p = 0; p < NCOLL; ++p) h += mo[MO_PT + p * PT_STRIDE + NX + NX * NA + a1 * NA + b];
-          q += h;
+#pragma unroll
+      for (int qi = 0; qi < QPL; ++qi) {
+        const int it = lane + qi * GS;
+        if (it < NA * NA) {
+          const int a1 = it / NA, b = it % NA;
+          double q = om * qlt[qi] + Ld[EL_QT + it];
+          if (NE > 0) q += qnl[qi];
+          if (a1 >= NX && b >= NX) q += Ld[EL_HUU + (a1 - NX) * NU + (b - NX)];
+          if (a1 >= NX) q += Ld[EL_U1 + (a1 - NX) * NA + b];
+          if (b >= NX) q += Ld[EL_U1 + (b - NX) * NA + a1];
+          S_[ES_QT + it] = q;
+          S_[ES_WTW + it] = Ld[EL_QT + NA * NA + it];
         }
-        if (a1 >= NX) q += Ld[EL_U1 + (a1 - NX) * NA + b];
-        if (b >= NX) q += Ld[EL_U1 + (b - NX) * NA + a1];
-        S_[ES_QT + it] = q;
-        S_[ES_WTW + it] = Ld[EL_QT + NA * NA + it];
       }
       for (int a1 = lane; a1 < NA; a1 += GS) {
         double q = 0.0, ww = 0.0;
@@ -829,6 +867,14 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, double mu, in
       for (int it = lane; it < NE * NA; it += GS) Q.EW(e, EW_JD + it) = mo[MO_NL + NE + it];
   }
   T.gsync();
+#ifndef DOMPC_HOST_EMU
+  {
+    unsigned acc = 0u;
+#pragma unroll
+    for (int q = 0; q < PF_N; ++q) acc |= pf_tok[q] == 0x7ff8deadu ? 1u : 0u;
+    if (acc && mu < 0.0) fail = 1;
+  }
+#endif
   DOMPC_PH(3)
 #undef DOMPC_PH
   return fail;
@@ -906,9 +952,6 @@ DOMPC_PHASE void assemble_node(const Prob& Q, int n) {
 // Children are summed at branching nodes (non-anticipativity = shared variables, _mpc.py:1212-1216).
 DOMPC_DEV inline int ycol(int yj) { return yj < NX ? yj : NA + (yj - NX); }
 
-// Riccati update of one tree node by one lane group (see riccati_backward).  Leaves P_n, p_n in the group's
-// LDS region (RB_PN) and in the node record; `child_staged`: the single child's P_c, p_c are already in
-// RB_PC (the group has just computed them while walking up its scenario chain).
 namespace rb {
 // LDS working set of one node update (offsets in doubles inside the group's region)
 constexpr int RB_QO = 0, RB_QOV = RB_QO + NYT * NYT;          // own quadratic (x, u_prev, u, eps) + gradient
@@ -919,113 +962,222 @@ constexpr int RB_TP = RB_CT + NA, RB_TV = RB_TP + NA * NA;     // P_c Atilde / P
 constexpr int RB_K = RB_TV + NA, RB_KV = RB_K + NV * NA;
 constexpr int RB_ACL = RB_KV + NV, RB_CCL = RB_ACL + NA * NA;  // closed-loop map Atilde [I;K] (also: scratch for Atilde' TP)
 constexpr int RB_PN = RB_CCL + NA, RB_PNV = RB_PN + NA * NA;   // result P_n, p_n
-constexpr int RB_SIZE = RB_PNV + NA;
+constexpr int RB_NL = RB_PNV + NA;                             // staged nl_cons data of one child edge
+constexpr int RB_SIZE = RB_NL + NE * (NA + 4);
 }  // namespace rb
 
 // index of entry i of (x, u_prev, u, eps) inside y = (x_n, u_n), or -1
 DOMPC_DEV inline int yidx(int i) { return (i < NX) ? i : ((i >= NA && i < NA + NU) ? NX + (i - NA) : -1); }
 
+// Global operands of a node update that belong to the node itself and to its FIRST child edge, loaded into
+// registers ahead of time: while a group walks its scenario chain upwards, the loads of the parent are in
+// flight during the update of the child (the update used to spend ~40 % of its time waiting for exactly
+// these loads).  Raw values only - anything computed from them here would stall the issuing wavefront.
+constexpr int RN_IPL = (NYT * NYT + GS_C - 1) / GS_C;
+constexpr int RN_VPL = (NYT + GS_C - 1) / GS_C;
+constexpr int RN_NE1 = NE > 0 ? NE : 1;
+constexpr int RN_NLN = NE * (NA + 4);          // nl_cons data of a child edge: [JD (NE x NA) | SIGS | RDN | RSN | y_d]
+constexpr int RN_NLP = NE > 0 ? (RN_NLN + GS_C - 1) / GS_C : 1;
+constexpr int RN_ABN = NX * (NA + 1);          // [A | B | c] of a child edge
+constexpr int RN_ABP = (RN_ABN + GS_C - 1) / GS_C;
+struct NodePre {
+  double qt[RN_IPL], wtw[RN_IPL];
+  double pv[RN_VPL][10];                       // x, lb, ub, zl, zu, nu_in, u_prev, RY, QV, WTW0
+  double nl[RN_NLP];
+  double ab[RN_ABP];
+};
+
+DOMPC_DEV inline double node_nl_load(const Prob& Q, int e, int it) {
+  if (it < NE * NA) return Q.EW(e, EW_JD + it);
+  const int j = it - NE * NA, kind = j / RN_NE1, q = j % RN_NE1;
+  const double* S_ = Q.ES(e);
+  return kind == 0 ? S_[ES_SIGS + q] : kind == 1 ? S_[ES_RDN + q] : kind == 2 ? S_[ES_RSN + q]
+                   : Q.lam[Q.A->edge_row0[e] + NW + NX + q];
+}
+
+DOMPC_DEV inline void node_prefetch(const Prob& Q, int n, double delta, int lane, int GS, NodePre& R) {
+  const KArgs& A = *Q.A;
+  const int e = A.node_child_start[n];
+  const double* S_ = Q.ES(e);
+  const int xo = A.node_x_off[n], uo = A.node_u_off[n];
+  const int eo = NS > 0 ? A.node_eps_off[n] : -1;
+  const int ie = A.node_in_edge[n], pn = A.node_parent[n];
+  const bool wd = delta != 0.0;
+#pragma unroll
+  for (int q = 0; q < RN_IPL; ++q) {
+    const int it = lane + q * GS;
+    const int itc = it < NYT * NYT ? it : 0;
+    const int yi = yidx(itc / NYT), yj = yidx(itc % NYT);
+    const int idx = (yi >= 0 && yj >= 0) ? yi * NA + yj : 0;
+    R.qt[q] = S_[ES_QT + idx];
+    R.wtw[q] = wd ? S_[ES_WTW + idx] : 0.0;
+  }
+#pragma unroll
+  for (int v = 0; v < RN_VPL; ++v) {
+    const int i0 = lane + v * GS;
+    const int i = i0 < NYT ? i0 : 0;
+    const int yi = yidx(i);
+    const bool is_up = (i >= NX && i < NA);
+    const int g = (i < NX) ? xo + i : (is_up ? uo + (i - NX) : (i < NA + NU ? uo + (i - NA) : eo + (i - NA - NU)));
+    R.pv[v][0] = Q.x[g];
+    R.pv[v][1] = Q.lb[g];
+    R.pv[v][2] = Q.ub[g];
+    R.pv[v][3] = Q.zl[g];
+    R.pv[v][4] = Q.zu[g];
+    R.pv[v][5] = (i < NX) ? ((ie >= 0) ? Q.lam[A.edge_row0[ie] + NW + i] : Q.lam[i]) : 0.0;
+    const int iu = is_up ? i - NX : (i >= NA && i < NA + NU ? i - NA : 0);
+    const bool hu = i >= NX && i < NA + NU;
+    R.pv[v][6] = hu ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / DOMPC_SU[iu]) : 0.0;
+    R.pv[v][7] = yi >= 0 ? S_[ES_RY + yi] : 0.0;
+    R.pv[v][8] = yi >= 0 ? S_[ES_QV + yi] : 0.0;
+    R.pv[v][9] = (yi >= 0 && wd) ? S_[ES_WTW0 + yi] : 0.0;
+  }
+  if (NE > 0) {
+#pragma unroll
+    for (int q = 0; q < RN_NLP; ++q) {
+      const int it = lane + q * GS;
+      R.nl[q] = it < RN_NLN ? node_nl_load(Q, e, it) : 0.0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RN_ABP; ++q) {
+    const int it = lane + q * GS;
+    const int itc = it < RN_ABN ? it : 0;
+    const int i = itc / (NA + 1), j = itc % (NA + 1);
+    R.ab[q] = (j < NA) ? S_[ES_AB + i * NA + j] : S_[ES_CV + i];
+  }
+}
+
+// Riccati update of one tree node by one lane group (see riccati_backward).  Leaves P_n, p_n in the group's
+// LDS region (RB_PN) and in the node record; `child_staged`: the single child's P_c, p_c are already in
+// RB_PC (the group has just computed them while walking up its scenario chain).  R: node_prefetch(n).
 DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu, double delta, ldsd* Ld, int lane, int GS,
-                                  bool child_staged) {
+                                  bool child_staged, const NodePre& R) {
   using namespace rb;
   const KArgs& A = *Q.A;
   double* Nd = Q.ND(n);
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
-  const int xo = A.node_x_off[n], uo = A.node_u_off[n];
-  const int eo = NS > 0 ? A.node_eps_off[n] : -1;
-  const int ie = A.node_in_edge[n];
   const double rw = node_rweight(Q, n);
-  double utmp[NU];
-  const double* up = uprev_ptr(Q, n, Q.x, utmp);
   long long pc0 = prof_clock();
 #define DOMPC_PN(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
   // ---- pass A: own quadratic (bounds Sigma, rterm, barrier gradients, slack penalty) plus the condensed
-  //      blocks of all child edges; QF/QFV cleared.  All global loads are issued before anything is used
-  //      (the pass used to cost ~5 dependent global round trips = half of the node update).
-  constexpr int IPL = (NYT * NYT + GS_C - 1) / GS_C;
-  double qpre[IPL];
+  //      blocks of all child edges.  First child + own data come from the prefetched registers, further
+  //      children (branching nodes only) are added from global memory.
+  double qacc[RN_IPL];
 #pragma unroll
-  for (int q = 0; q < IPL; ++q) {
+  for (int q = 0; q < RN_IPL; ++q) {
     const int it = lane + q * GS;
     const int itc = it < NYT * NYT ? it : 0;
     const int yi = yidx(itc / NYT), yj = yidx(itc % NYT);
     const bool valid = it < NYT * NYT && yi >= 0 && yj >= 0;
     const int idx = valid ? yi * NA + yj : 0;
-    double v = 0.0;
-    for (int c = 0; c < cc; ++c) {
+    double v = R.qt[q] + delta * R.wtw[q];
+    for (int c = 1; c < cc; ++c) {
       const double* S_ = Q.ES(cs + c);
       double t = S_[ES_QT + idx];
       if (delta != 0.0) t += delta * S_[ES_WTW + idx];
       v += t;
     }
-    qpre[q] = valid ? v : 0.0;
+    qacc[q] = valid ? v : 0.0;
   }
   // per-variable terms (diagonal + gradient): lanes 0..NYT-1
-  for (int i = lane; i < NYT; i += GS) {
+  double gvv[RN_VPL], dgv[RN_VPL];
+#pragma unroll
+  for (int v = 0; v < RN_VPL; ++v) {
+    const int i0 = lane + v * GS;
+    const int i = i0 < NYT ? i0 : 0;
     const int yi = yidx(i);
     const bool is_up = (i >= NX && i < NA);
-    const int g = (i < NX) ? xo + i : (is_up ? uo + (i - NX) : (i < NA + NU ? uo + (i - NA) : eo + (i - NA - NU)));
-    const double xv = Q.x[g], lo = Q.lb[g], hi = Q.ub[g], zlo = Q.zl[g], zhi = Q.zu[g];
+    const double xv = R.pv[v][0], lo = R.pv[v][1], hi = R.pv[v][2], zlo = R.pv[v][3], zhi = R.pv[v][4];
+    const double upv = R.pv[v][6];
     double dg, gv;
     if (is_up) {
       dg = 2.0 * rw * DOMPC_RTERM[i - NX];
-      gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - up[i - NX]);            // xv = u_n of the same input
+      gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - upv);                    // xv = u_n of the same input
     } else {
       dg = sigma_of(xv, lo, hi, zlo, zhi) + delta;
       gv = bar_grad(xv, lo, hi, mu);
-      if (i < NX) gv += (ie >= 0) ? -Q.lam[A.edge_row0[ie] + NW + i] : Q.lam[i];
+      if (i < NX) gv += (A.node_in_edge[n] >= 0) ? -R.pv[v][5] : R.pv[v][5];
       else if (i < NA + NU) {
         dg += 2.0 * rw * DOMPC_RTERM[i - NA];
-        gv += 2.0 * rw * DOMPC_RTERM[i - NA] * (xv - up[i - NA]);
+        gv += 2.0 * rw * DOMPC_RTERM[i - NA] * (xv - upv);
       } else {
         gv += cc * Q.sf * DOMPC_EPS_PEN[i - NA - NU];
       }
     }
-    for (int c = 0; c < cc; ++c) {
-      const int e = cs + c;
-      const double* S_ = Q.ES(e);
-      if (yi >= 0) gv += S_[ES_RY + yi] + S_[ES_QV + yi] + delta * S_[ES_WTW0 + yi];
-      if (NE > 0) {
-        const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
-        for (int q = 0; q < NE; ++q) {
-          const double sg = S_[ES_SIGS + q] + delta;
-          double ji = 0.0;
-          if (yi >= 0) ji = Q.EW(e, EW_JD + q * NA + yi);
-          else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) { ji = -1.0; gv -= yd[q]; }
-          gv += ji * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
-        }
+    gv += R.pv[v][7] + R.pv[v][8] + delta * R.pv[v][9];
+    if (yi >= 0)
+      for (int c = 1; c < cc; ++c) {
+        const double* S_ = Q.ES(cs + c);
+        gv += S_[ES_RY + yi] + S_[ES_QV + yi] + delta * S_[ES_WTW0 + yi];
       }
+    gvv[v] = gv;
+    dgv[v] = dg;
+  }
+  if (NE > 0) {
+    constexpr int NL_JD = RB_NL, NL_SG = RB_NL + NE * NA, NL_RD = NL_SG + NE, NL_RS = NL_RD + NE, NL_YD = NL_RS + NE;
+    for (int c = 0; c < cc; ++c) {
+#pragma unroll
+      for (int q = 0; q < RN_NLP; ++q) {
+        const int it = lane + q * GS;
+        if (it < RN_NLN) Ld[RB_NL + it] = (c == 0) ? R.nl[q] : node_nl_load(Q, cs + c, it);
+      }
+      T.gsync();
+#pragma unroll
+      for (int v = 0; v < RN_VPL; ++v) {
+        const int i0 = lane + v * GS;
+        const int i = i0 < NYT ? i0 : 0;
+        const int yi = yidx(i);
+        double gv = gvv[v];
+        for (int q = 0; q < NE; ++q) {
+          const double sg = Ld[NL_SG + q] + delta;
+          double ji = 0.0;
+          if (yi >= 0) ji = Ld[NL_JD + q * NA + yi];
+          else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) { ji = -1.0; gv -= Ld[NL_YD + q]; }
+          gv += ji * (sg * Ld[NL_RD + q] + Ld[NL_RS + q]);
+        }
+        gvv[v] = gv;
+      }
+#pragma unroll
+      for (int q = 0; q < RN_IPL; ++q) {
+        const int it = lane + q * GS;
+        const int itc = it < NYT * NYT ? it : 0;
+        const int i = itc / NYT, j = itc % NYT;
+        const int yi = yidx(i), yj = yidx(j);
+        double v = qacc[q];
+        for (int qq = 0; qq < NE; ++qq) {
+          const double sg = Ld[NL_SG + qq] + delta;
+          double ji = 0.0, jj = 0.0;
+          if (yi >= 0) ji = Ld[NL_JD + qq * NA + yi];
+          else if (i >= NA + NU && DOMPC_NL_SLACK[qq] == i - NA - NU) ji = -1.0;
+          if (yj >= 0) jj = Ld[NL_JD + qq * NA + yj];
+          else if (j >= NA + NU && DOMPC_NL_SLACK[qq] == j - NA - NU) jj = -1.0;
+          v += sg * ji * jj;
+        }
+        qacc[q] = v;
+      }
+      T.gsync();
     }
-    Ld[RB_QOV + i] = gv;
-    Ld[RB_QFV + i] = 0.0;
-    Ld[RB_QF + i * NYT + i] = dg;      // diagonal parked in QF, merged below
+  }
+#pragma unroll
+  for (int v = 0; v < RN_VPL; ++v) {
+    const int i = lane + v * GS;
+    if (i < NYT) {
+      Ld[RB_QOV + i] = gvv[v];
+      Ld[RB_QFV + i] = 0.0;
+      Ld[RB_QF + i * NYT + i] = dgv[v];      // diagonal parked in QF, merged below
+    }
   }
   T.gsync();
 #pragma unroll
-  for (int q = 0; q < IPL; ++q) {
+  for (int q = 0; q < RN_IPL; ++q) {
     const int it = lane + q * GS;
     if (it < NYT * NYT) {
       const int i = it / NYT, j = it % NYT;
-      double v = qpre[q];
+      double v = qacc[q];
       if (i == j) v += Ld[RB_QF + i * NYT + i];
       else if (i >= NX && i < NA && j == i + NU) v -= 2.0 * rw * DOMPC_RTERM[i - NX];
       else if (j >= NX && j < NA && i == j + NU) v -= 2.0 * rw * DOMPC_RTERM[j - NX];
-      if (NE > 0) {
-        const int yi = yidx(i), yj = yidx(j);
-        for (int c = 0; c < cc; ++c) {
-          const int e = cs + c;
-          const double* S_ = Q.ES(e);
-          for (int qq = 0; qq < NE; ++qq) {
-            const double sg = S_[ES_SIGS + qq] + delta;
-            double ji = 0.0, jj = 0.0;
-            if (yi >= 0) ji = Q.EW(e, EW_JD + qq * NA + yi);
-            else if (i >= NA + NU && DOMPC_NL_SLACK[qq] == i - NA - NU) ji = -1.0;
-            if (yj >= 0) jj = Q.EW(e, EW_JD + qq * NA + yj);
-            else if (j >= NA + NU && DOMPC_NL_SLACK[qq] == j - NA - NU) jj = -1.0;
-            v += sg * ji * jj;
-          }
-        }
-      }
       Ld[RB_QO + it] = v;
     }
   }
@@ -1036,10 +1188,27 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
     const int e = cs + c;
     const double* S_ = Q.ES(e);
     const double* Nc = Q.ND(A.edge_child[e]);
-    for (int it = lane; it < NA * (NA + 1); it += GS) {
-      const int i = it / (NA + 1), j = it % (NA + 1);
-      if (j < NA) Ld[RB_AT + i * NA + j] = (i < NX) ? S_[ES_AB + i * NA + j] : ((j == i) ? 1.0 : 0.0);
-      else Ld[RB_CT + i] = (i < NX) ? S_[ES_CV + i] : 0.0;
+    if (c == 0) {
+#pragma unroll
+      for (int q = 0; q < RN_ABP; ++q) {
+        const int it = lane + q * GS;
+        if (it < RN_ABN) {
+          const int i = it / (NA + 1), j = it % (NA + 1);
+          if (j < NA) Ld[RB_AT + i * NA + j] = R.ab[q];
+          else Ld[RB_CT + i] = R.ab[q];
+        }
+      }
+      for (int it = lane; it < (NA - NX) * (NA + 1); it += GS) {
+        const int i = NX + it / (NA + 1), j = it % (NA + 1);
+        if (j < NA) Ld[RB_AT + i * NA + j] = (j == i) ? 1.0 : 0.0;
+        else Ld[RB_CT + i] = 0.0;
+      }
+    } else {
+      for (int it = lane; it < NA * (NA + 1); it += GS) {
+        const int i = it / (NA + 1), j = it % (NA + 1);
+        if (j < NA) Ld[RB_AT + i * NA + j] = (i < NX) ? S_[ES_AB + i * NA + j] : ((j == i) ? 1.0 : 0.0);
+        else Ld[RB_CT + i] = (i < NX) ? S_[ES_CV + i] : 0.0;
+      }
     }
     if (!have_pc) {
       for (int it = lane; it < NA * NA; it += GS) Ld[RB_PC + it] = Nc[ND_P + it];
@@ -1238,14 +1407,19 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
     const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
     for (int s_ = gid; s_ < S; s_ += ng) {
       bool staged = false;
+      NodePre R;
+      if (A.N - 1 >= cl) node_prefetch(Q, A.level_node_start[A.N - 1] + s_, delta, lane, GS, R);
       for (int k = A.N - 1; k >= cl; --k) {
+        NodePre Rn;              // the parent's operands: in flight while this node is updated
+        if (k > cl) node_prefetch(Q, A.level_node_start[k - 1] + s_, delta, lane, GS, Rn);
         if (staged) {            // P of the node just finished becomes P_c of its parent
           for (int it = lane; it < NA * NA; it += GS) Ld[RB_PC + it] = Ld[RB_PN + it];
           for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Ld[RB_PNV + it];
           T.gsync();
         }
-        if (riccati_node(T, Q, A.level_node_start[k] + s_, mu, delta, Ld, lane, GS, staged)) { T.flags[0] = 1; break; }
+        if (riccati_node(T, Q, A.level_node_start[k] + s_, mu, delta, Ld, lane, GS, staged, R)) { T.flags[0] = 1; break; }
         staged = true;
+        if (k > cl) R = Rn;
       }
     }
     T.sync();
@@ -1253,8 +1427,11 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
   }
   for (int k = cl - 1; k >= 0; --k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
-    for (int n = n0 + gid; n < n1; n += ng)
-      if (riccati_node(T, Q, n, mu, delta, Ld, lane, GS, false)) T.flags[0] = 1;
+    for (int n = n0 + gid; n < n1; n += ng) {
+      NodePre R;
+      node_prefetch(Q, n, delta, lane, GS, R);
+      if (riccati_node(T, Q, n, mu, delta, Ld, lane, GS, false, R)) T.flags[0] = 1;
+    }
     T.sync();
     if (T.flags[0]) return 1;
   }
@@ -1474,7 +1651,8 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     const int rounds = (A.n_edges + ng - 1) / ng;
     for (int rd = 0; rd < rounds; ++rd) {
       const int e = rd * ng + gid;
-      if (eval_edge_coop(T, Q, e < A.n_edges ? e : -1, mu, lane, T.gs, Ld)) T.flags[1] = 1;
+      const int en = e + ng;
+      if (eval_edge_coop(T, Q, e < A.n_edges ? e : -1, en < A.n_edges ? en : -1, mu, lane, T.gs, Ld)) T.flags[1] = 1;
     }
   }
   T.sync();

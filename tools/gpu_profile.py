@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of one solve (problem 0) from the kernel's own shader-clock counters."""
+import json
 import os
 import sys
 
@@ -14,8 +15,9 @@ from do_mpc_amd.examples import CASES  # noqa: E402
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "industrial_poly"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    kw = json.loads(sys.argv[3]) if len(sys.argv) > 3 else {}
     ex = CASES[name]
-    mpc = ex.build_mpc(ex.build_model(), max_batch=max(B, 1))
+    mpc = ex.build_mpc(ex.build_model(), max_batch=max(B, 1), **kw)
     X0 = bench.synthetic_x0_batch(B) if name == "industrial_poly" else np.tile(ex.X0, (B, 1))
     import time
     for rep in range(2):
