@@ -632,49 +632,169 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       constexpr int EL_ROWS = (DEG + 1) * NX;
       constexpr int CPL = (NC + GS_C - 1) / GS_C;
       unsigned long long used = 0ull;
-      for (int kk = 0; kk < GJ_STEPS; ++kk) {
-        const int pos = kk % EL_ROWS;
-        const int grp0 = kk - pos + (pos < DEG * NX ? 0 : DEG * NX);
-        const int grp1 = kk - pos + (pos < DEG * NX ? DEG * NX : EL_ROWS);
-        double f[NW1], bcol[CPL][NW1];
-        unsigned bestkey = 0u;
-        if (act) {
+      if constexpr (NI == 1) {
+        // Single finite element: G_w = [[G_cc, 0], [E, I]] with the continuity rows E = -[D_1 I ... D_DEG I]
+        // below the collocation block.  Only the R = DEG*NX collocation rows are eliminated (the continuity
+        // rows follow afterwards as D-weighted sums of the finished rows), and two pivot columns are
+        // processed per LDS pass: the second column is updated redundantly in registers, so each pass reads
+        // 3R and writes R+2 values per lane instead of 4R / 2R+2 (the phase is bound by LDS instruction
+        // issue, stores cost 3x a load).
+        constexpr int R = DEG * NX, RA = R > 0 ? R : 1;
+        auto keyof = [](double v, int r) -> unsigned {
+          return (((unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32)) & 0x7fffffc0u) | (unsigned)r;
+        };
+        int kk = 0;
+        for (; kk + 1 < R; kk += 2) {
+          double f0[RA], f1[RA], bcol[CPL][RA];
+          unsigned key0 = 0u, key1 = 0u;
+          if (act) {
 #pragma unroll
-          for (int r = 0; r < NW; ++r) f[r] = Ld[EL_MX + r * NC + kk];
+            for (int r = 0; r < R; ++r) { f0[r] = Ld[EL_MX + r * NC + kk]; f1[r] = Ld[EL_MX + r * NC + kk + 1]; }
 #pragma unroll
-          for (int q = 0; q < CPL; ++q) {
-            const int c = lane + q * GS;
-            const int cc_ = c < NC ? c : 0;
+            for (int q = 0; q < CPL; ++q) {
+              const int c = lane + q * GS;
+              const int cc_ = c < NC ? c : 0;
 #pragma unroll
-            for (int r = 0; r < NW; ++r) bcol[q][r] = Ld[EL_MX + r * NC + cc_];
-          }
+              for (int r = 0; r < R; ++r) bcol[q][r] = Ld[EL_MX + r * NC + cc_];
+            }
 #pragma unroll
-          for (int r = 0; r < NW; ++r) {
-            unsigned key = (((unsigned)(__builtin_bit_cast(unsigned long long, f[r]) >> 32)) & 0x7fffffc0u) | (unsigned)r;
-            key = (r >= grp0 && r < grp1 && !((used >> r) & 1ull)) ? key : 0u;
-            bestkey = key > bestkey ? key : bestkey;
-          }
-        }
-        const int pv = (int)(bestkey & 63u);
-        used |= (1ull << pv);
-        if (act && (bestkey >> 6) == 0u) fail = 1;          // |pivot| < ~1e-300: singular collocation block
-        if (act) {
-          if (lane == 0) Ld[EL_PV + kk] = (double)pv;
-          const double piv = Ld[EL_MX + pv * NC + kk];
-          const double pinv = (fabs(piv) > 1e-300) ? 1.0 / piv : 1.0;
-#pragma unroll
-          for (int q = 0; q < CPL; ++q) {
-            const int c = lane + q * GS;
-            if (c < NC) {
-              const double prow = (c == kk) ? pinv : Ld[EL_MX + pv * NC + c] * pinv;
-              const double keep = (c == kk) ? 0.0 : 1.0;
-#pragma unroll
-              for (int r = 0; r < NW; ++r) Ld[EL_MX + r * NC + c] = fma(-f[r], prow, bcol[q][r] * keep);
-              Ld[EL_MX + pv * NC + c] = prow;
+            for (int r = 0; r < R; ++r) {
+              unsigned key = keyof(f0[r], r);
+              key = !((used >> r) & 1ull) ? key : 0u;
+              key0 = key > key0 ? key : key0;
             }
           }
+          const int p0 = (int)(key0 & 63u);
+          used |= (1ull << p0);
+          if (act && (key0 >> 6) == 0u) fail = 1;
+          double pinv0 = 1.0, f1p0 = 0.0;
+          if (act) {
+            const double piv0 = Ld[EL_MX + p0 * NC + kk];
+            pinv0 = (fabs(piv0) > 1e-300) ? 1.0 / piv0 : 1.0;
+            f1p0 = Ld[EL_MX + p0 * NC + kk + 1] * pinv0;          // row p0 of column kk+1 after the first step
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              f1[r] = fma(-f0[r], f1p0, f1[r]);                   // column kk+1 after the first step (rows != p0)
+              unsigned key = keyof(f1[r], r);
+              key = !((used >> r) & 1ull) ? key : 0u;
+              key1 = key > key1 ? key : key1;
+            }
+          }
+          const int p1 = (int)(key1 & 63u);
+          used |= (1ull << p1);
+          if (act && (key1 >> 6) == 0u) fail = 1;
+          if (act) {
+            if (lane == 0) { Ld[EL_PV + kk] = (double)p0; Ld[EL_PV + kk + 1] = (double)p1; }
+            const double f0p1 = Ld[EL_MX + p1 * NC + kk];
+            const double piv1 = fma(-f0p1, f1p0, Ld[EL_MX + p1 * NC + kk + 1]);
+            const double pinv1 = (fabs(piv1) > 1e-300) ? 1.0 / piv1 : 1.0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const int c = lane + q * GS;
+              if (c < NC) {
+                const bool is0 = (c == kk), is1 = (c == kk + 1);
+                const double keep0 = is0 ? 0.0 : 1.0, keep1 = is1 ? 0.0 : 1.0;
+                const double prow0 = is0 ? pinv0 : Ld[EL_MX + p0 * NC + c] * pinv0;
+                const double bp1 = fma(-f0p1, prow0, Ld[EL_MX + p1 * NC + c] * keep0);   // row p1 after the first step
+                const double prow1 = is1 ? pinv1 : bp1 * pinv1;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                  const double t = fma(-f0[r], prow0, bcol[q][r] * keep0);
+                  Ld[EL_MX + r * NC + c] = fma(-f1[r], prow1, t * keep1);
+                }
+                Ld[EL_MX + p0 * NC + c] = fma(-f1p0, prow1, prow0 * keep1);
+                Ld[EL_MX + p1 * NC + c] = prow1;
+              }
+            }
+          }
+          T.gsync();
         }
-        T.gsync();
+        for (; kk < R; ++kk) {              // odd R: last column alone
+          double f[RA], bcol[CPL][RA];
+          unsigned bestkey = 0u;
+          if (act) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) f[r] = Ld[EL_MX + r * NC + kk];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const int c = lane + q * GS;
+              const int cc_ = c < NC ? c : 0;
+#pragma unroll
+              for (int r = 0; r < R; ++r) bcol[q][r] = Ld[EL_MX + r * NC + cc_];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              unsigned key = keyof(f[r], r);
+              key = !((used >> r) & 1ull) ? key : 0u;
+              bestkey = key > bestkey ? key : bestkey;
+            }
+          }
+          const int pv = (int)(bestkey & 63u);
+          used |= (1ull << pv);
+          if (act && (bestkey >> 6) == 0u) fail = 1;
+          if (act) {
+            if (lane == 0) Ld[EL_PV + kk] = (double)pv;
+            const double piv = Ld[EL_MX + pv * NC + kk];
+            const double pinv = (fabs(piv) > 1e-300) ? 1.0 / piv : 1.0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const int c = lane + q * GS;
+              if (c < NC) {
+                const double prow = (c == kk) ? pinv : Ld[EL_MX + pv * NC + c] * pinv;
+                const double keep = (c == kk) ? 0.0 : 1.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + c] = fma(-f[r], prow, bcol[q][r] * keep);
+                Ld[EL_MX + pv * NC + c] = prow;
+              }
+            }
+          }
+          T.gsync();
+        }
+      } else {
+        for (int kk = 0; kk < GJ_STEPS; ++kk) {
+          const int pos = kk % EL_ROWS;
+          const int grp0 = kk - pos + (pos < DEG * NX ? 0 : DEG * NX);
+          const int grp1 = kk - pos + (pos < DEG * NX ? DEG * NX : EL_ROWS);
+          double f[NW1], bcol[CPL][NW1];
+          unsigned bestkey = 0u;
+          if (act) {
+  #pragma unroll
+            for (int r = 0; r < NW; ++r) f[r] = Ld[EL_MX + r * NC + kk];
+  #pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const int c = lane + q * GS;
+              const int cc_ = c < NC ? c : 0;
+  #pragma unroll
+              for (int r = 0; r < NW; ++r) bcol[q][r] = Ld[EL_MX + r * NC + cc_];
+            }
+  #pragma unroll
+            for (int r = 0; r < NW; ++r) {
+              unsigned key = (((unsigned)(__builtin_bit_cast(unsigned long long, f[r]) >> 32)) & 0x7fffffc0u) | (unsigned)r;
+              key = (r >= grp0 && r < grp1 && !((used >> r) & 1ull)) ? key : 0u;
+              bestkey = key > bestkey ? key : bestkey;
+            }
+          }
+          const int pv = (int)(bestkey & 63u);
+          used |= (1ull << pv);
+          if (act && (bestkey >> 6) == 0u) fail = 1;          // |pivot| < ~1e-300: singular collocation block
+          if (act) {
+            if (lane == 0) Ld[EL_PV + kk] = (double)pv;
+            const double piv = Ld[EL_MX + pv * NC + kk];
+            const double pinv = (fabs(piv) > 1e-300) ? 1.0 / piv : 1.0;
+  #pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const int c = lane + q * GS;
+              if (c < NC) {
+                const double prow = (c == kk) ? pinv : Ld[EL_MX + pv * NC + c] * pinv;
+                const double keep = (c == kk) ? 0.0 : 1.0;
+  #pragma unroll
+                for (int r = 0; r < NW; ++r) Ld[EL_MX + r * NC + c] = fma(-f[r], prow, bcol[q][r] * keep);
+                Ld[EL_MX + pv * NC + c] = prow;
+              }
+            }
+          }
+          T.gsync();
+        }
       }
       // relabel: stored[p_k][c] = Ginv[k][p_c] for the inverse part, stored[p_k][c] = (Ginv B)[k][c] for the
       // right-hand sides (p_k = pivot row of column k; identity for the skipped xkf columns)
@@ -701,6 +821,23 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
             const int dst = (c < NW) ? (int)Ld[EL_PV + c] : c;
 #pragma unroll
             for (int r = 0; r < NW; ++r) Ld[EL_MX + (int)Ld[EL_T0 + r] * NC + dst] = tmp[q][r];
+          }
+        }
+      }
+      T.gsync();
+    }
+    if constexpr (NI == 1) {
+      // continuity rows: G_w^-1[R+a][c] = sum_r D_r * G_w^-1[(r-1)*NX + a][c]   (+ the assembled entry for the
+      // right-hand sides; the xkf columns keep their identity block)
+      constexpr int R = DEG * NX;
+      if (act) {
+        for (int it = lane; it < NX * NC; it += GS) {
+          const int a_ = it / NC, c = it % NC;
+          if (c < R || c >= NW) {
+            double t = (c >= NW) ? Ld[EL_MX + (R + a_) * NC + c] : 0.0;
+#pragma unroll
+            for (int r = 1; r <= DEG; ++r) t += DOMPC_D[r] * Ld[EL_MX + ((r - 1) * NX + a_) * NC + c];
+            Ld[EL_MX + (R + a_) * NC + c] = t;
           }
         }
       }
