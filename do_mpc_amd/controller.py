@@ -502,6 +502,11 @@ class MPC:
         every rank builds the same MPC, calls shard_tree(rank, world) once after setup() and then make_step(x0) with
         identical x0; the ranks meet in torch.distributed all-reduces (backend nccl = RCCL) during the solve."""
         assert self.flags["setup"] is True, "MPC was not setup yet. Please call MPC.setup()."
+        if not getattr(self.S, "shard_capable", False):
+            # the sharding-aware kernel is a second code object of the same model (build.py): swap the solver
+            ctor = dict(self.S._ctor)
+            self.S.close()
+            self.S = HipIpmSolver(ctor.pop("structure"), ctor.pop("header_text"), ctor.pop("model_hash"), shard=True, **ctor)
         return self.S.enable_sharding(rank, world, cut_level=cut_level, group=group, allreduce=allreduce)
 
     def solve(self) -> None:

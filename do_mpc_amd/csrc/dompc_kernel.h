@@ -44,6 +44,9 @@ constexpr int NE1 = NE > 0 ? NE : 1;
 constexpr int NS1 = NS > 0 ? NS : 1;
 constexpr int NW1 = NW > 0 ? NW : 1;
 constexpr int MAX_FILTER = 48;
+#ifndef DOMPC_SHARD
+#define DOMPC_SHARD 0
+#endif
 constexpr int RED_MAX = 12;          // values reduced per pass
 #ifndef DOMPC_HOST_EMU
 constexpr int GS_C = 64;             // lanes per edge group: one wavefront
@@ -139,6 +142,22 @@ typedef double ldsd;
 // small batches so that a single make_step can use many CUs - K workgroups that synchronise through a
 // device-scope barrier.  All loops over work items are written against (tid, nt), the index / count
 // among ALL threads of the problem; (ltid, lnt) are the coordinates inside the workgroup (LDS indexing).
+// exchange context of a sharded problem, copied out of the kernel arguments (by value: the argument block
+// itself must not escape into out-of-line code, or the compiler loses the address spaces of all its pointers)
+struct XCtx {
+  int on, rank, world;
+  double* xbuf;
+  volatile uint32_t *req, *ack, *cnt;
+  void (*cb)(void* ctx, double* buf, int32_t count);
+  void* ctx;
+};
+DOMPC_HD inline XCtx make_xctx(const KArgs& A) {
+  XCtx X;
+  X.on = A.x_mask != nullptr; X.rank = A.shard_rank; X.world = A.shard_world; X.xbuf = A.xbuf;
+  X.req = A.x_req; X.ack = A.x_ack; X.cnt = A.x_count; X.cb = A.x_callback; X.ctx = A.x_ctx;
+  return X;
+}
+
 struct Thr {
   int tid, nt;
   ldsd* red;        // LDS: RED_MAX * lnt doubles
@@ -152,7 +171,7 @@ struct Thr {
   unsigned* bar;    // wide: global arrival counter of the problem slot (monotonic)
   double* partials; // wide: global [2][nwg][RED_MAX] reduction partials
   mutable unsigned gen, nred;
-  const KArgs* KA;  // tree sharding: masks, exchange buffer and handshake words (KA->x_mask == nullptr: not sharded)
+  XCtx X;           // tree sharding: exchange buffer and handshake words (X.on == 0: not sharded)
   mutable unsigned xseq;
   DOMPC_DEV void sync() const {
 #ifndef DOMPC_HOST_EMU
@@ -194,25 +213,26 @@ struct Thr {
     __builtin_amdgcn_wave_barrier();
 #endif
   }
-  // Cross-rank exchange of a sharded problem: element-wise SUM over the ranks of KA->xbuf[0..n).  Called by
+  // Cross-rank exchange of a sharded problem: element-wise SUM over the ranks of X.xbuf[off..off+n).  Called by
   // ALL threads of the problem after they have written their part of the buffer.  Device: workgroup 0
   // publishes the request in pinned host memory and polls the acknowledge word while the host service loop
   // (dompc_runtime.cpp) runs the collective (RCCL all-reduce) on the buffer; bounded spin -> abort flag.
   DOMPC_DEV void xchg(int off, int n) const {
 #ifdef DOMPC_HOST_EMU
-    if (KA->x_callback) KA->x_callback(KA->x_ctx, KA->xbuf + off, n);
+    if (X.cb) X.cb(X.ctx, X.xbuf + off, n);
 #else
     sync();
     ++xseq;
     if (wg == 0 && ltid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      KA->x_count[0] = (unsigned)n;
-      KA->x_count[1] = (unsigned)off;
-      __hip_atomic_store((unsigned*)KA->x_req, xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      X.cnt[0] = (unsigned)n;
+      X.cnt[1] = (unsigned)off;
+      __hip_atomic_store((unsigned*)X.req, xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       long long spins = 0;
-      while (__hip_atomic_load((unsigned*)KA->x_ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != xseq) {
+      const bool dead = __hip_atomic_load(flags + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      while (!dead && __hip_atomic_load((unsigned*)X.ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != xseq) {
         __builtin_amdgcn_s_sleep(16);
-        if (++spins > 20000000ll) {                       // the host never answered: abort instead of hanging
+        if (++spins > 4000000ll) {                        // (seconds) the host never answered: abort instead of hanging
           __hip_atomic_store(flags + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
@@ -224,15 +244,19 @@ struct Thr {
   }
 };
 
-// ---- tree sharding: masks 0 = another rank's, 1 = mine, 2 = replicated (identical everywhere; counted once)
-DOMPC_DEV inline bool sh_on(const KArgs& A) { return A.x_mask != nullptr; }
-DOMPC_DEV inline int mk_x(const KArgs& A, int g) { return A.x_mask ? A.x_mask[g] : 1; }
-DOMPC_DEV inline int mk_g(const KArgs& A, int r) { return A.g_mask ? A.g_mask[r] : 1; }
-DOMPC_DEV inline int mk_e(const KArgs& A, int e) { return A.e_mask ? A.e_mask[e] : 1; }
-DOMPC_DEV inline int mk_n(const KArgs& A, int n) { return A.n_mask ? A.n_mask[n] : 1; }
+// ---- tree sharding: masks 0 = another rank's, 1 = mine, 2 = replicated (identical everywhere; counted once).
+// The support is compiled in only with -DDOMPC_SHARD=1 (a second code object per model, build.py): in the
+// plain build every helper folds to a constant and the batch path carries no mask loads and no extra registers
+// (measured: the mask-aware build is 9 % slower on the B=1024 batch).
+constexpr bool SHARD = DOMPC_SHARD != 0;
+DOMPC_DEV inline bool sh_on(const KArgs& A) { return SHARD && A.x_mask != nullptr; }
+DOMPC_DEV inline int mk_x(const KArgs& A, int g) { return (SHARD && A.x_mask) ? A.x_mask[g] : 1; }
+DOMPC_DEV inline int mk_g(const KArgs& A, int r) { return (SHARD && A.g_mask) ? A.g_mask[r] : 1; }
+DOMPC_DEV inline int mk_e(const KArgs& A, int e) { return (SHARD && A.e_mask) ? A.e_mask[e] : 1; }
+DOMPC_DEV inline int mk_n(const KArgs& A, int n) { return (SHARD && A.n_mask) ? A.n_mask[n] : 1; }
 // does an item with mask m enter a SUM on this rank?
-DOMPC_DEV inline bool sh_cnt(const KArgs& A, int m) { return m == 1 || (m == 2 && A.shard_rank == 0); }
-DOMPC_DEV inline int cut_of(const KArgs& A, int n) { return A.node_cut ? A.node_cut[n] : -1; }
+DOMPC_DEV inline bool sh_cnt(const KArgs& A, int m) { return !SHARD || m == 1 || (m == 2 && A.shard_rank == 0); }
+DOMPC_DEV inline int cut_of(const KArgs& A, int n) { return (SHARD && A.node_cut) ? A.node_cut[n] : -1; }
 
 
 DOMPC_DEV inline long long prof_clock() {
@@ -249,7 +273,7 @@ enum RedOp { R_SUM = 0, R_MAX = 1, R_MIN = 2 };
 template <int N_>
 DOMPC_DEV void wg_reduce(const Thr& T, double (&v)[N_], const int (&op)[N_]) {
   static_assert(N_ <= RED_MAX, "too many values");
-  if (T.nt == 1 && !(T.KA && T.KA->x_mask)) return;
+  if (T.nt == 1 && !(SHARD && T.X.on)) return;
   for (int i = 0; i < N_; ++i) T.red[i * T.lnt + T.ltid] = v[i];
   T.lsync();
   for (int s = T.lnt >> 1; s > 0; s >>= 1) {
@@ -277,12 +301,12 @@ DOMPC_DEV void wg_reduce(const Thr& T, double (&v)[N_], const int (&op)[N_]) {
     }
     T.lsync();
   }
-  if (T.KA && T.KA->x_mask) {
+  if (SHARD && T.X.on) {
     // combine the ranks: every rank deposits its values in its own row of a [world][RED_MAX] table (zeros
     // elsewhere), the SUM exchange turns that into an all-gather, and every rank folds the rows in rank order
     // with the requested operations -> bitwise identical results and control flow on all ranks
-    const int W = T.KA->shard_world, me = T.KA->shard_rank;
-    double* xb = T.KA->xbuf;
+    const int W = T.X.world, me = T.X.rank;
+    double* xb = T.X.xbuf;
     if (T.wg == 0)
       for (int i = T.ltid; i < W * RED_MAX; i += T.lnt) {
         const int w = i / RED_MAX, j = i % RED_MAX;
@@ -620,7 +644,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         const int jj = rr / NX, a = rr % NX;         // jj = 0..DEG-1: collocation row j=jj+1 ; jj = DEG: continuity row
         const double* xi0 = (i == 0) ? xn : w + slot_of(i, 0) * NX;
         const int row = i * (DEG + 1) * NX + jj * NX + a;
-        double* Mr = Ld + EL_MX + row * NC;
+        ldsd* Mr = Ld + EL_MX + row * NC;
         if (jj < DEG) {
           const int j = jj + 1, sl = slot_of(i, j), p = i * DEG + jj;
           const double* pt = mo + MO_PT + p * PT_STRIDE;
@@ -2351,7 +2375,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
 
   while (true) {
     if (bad) { status = 3; break; }
-    if (T.nwg > 1 && T.flags[7]) { status = 5; break; }       // a peer workgroup never arrived at a barrier
+    if ((T.nwg > 1 || sh_on(A)) && T.flags[7]) { status = 5; break; }       // a peer workgroup never arrived at a barrier
     const double sd = fmax(s_max, (E.sum_y + E.sum_z) / fmax(1.0, n_dual)) / s_max;
     const double sc = fmax(s_max, E.sum_z / fmax(1.0, n_bounds)) / s_max;
     E0 = fmax(E.e_d / sd, fmax(E.e_p, E.e_c0 / sc));

@@ -44,7 +44,7 @@ struct dompc_handle {
   int32_t cap_batch = 0;
   // tree sharding
   int64_t xlayout[4] = {0, 0, 0, 0};   // RED_MAX, ASM_N, CUT1, CUT2 of the code object
-  bool sharded = false;
+  bool sharded = false, shard_capable = false;
   dompc_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   uint32_t* x_words = nullptr;           // pinned host memory: [req, ack, count, off] (device build)
@@ -210,7 +210,15 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     return fail(1);
   }
   if (hipSetDevice(d.device) != hipSuccess) { h->error = "hipSetDevice failed"; return fail(1); }
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->error = "hipStreamCreate failed"; return fail(1); }
+  {
+    // Own stream, non-blocking and at the LOWEST priority: streams of different priorities never share a hardware
+    // queue, so the collective kernels of a sharded solve (RCCL, normal priority) are not queued behind the
+    // resident solver kernel that is waiting for them.
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (getenv("DOMPC_STREAM_NORMAL")) least = 0;      // debugging aid
+    if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) != hipSuccess) { h->error = "hipStreamCreate failed"; return fail(1); }
+  }
   if (!d.code_object_path) { h->error = "code_object_path is null"; return fail(1); }
   h->code_path = d.code_object_path;
   if (hipModuleLoad(&h->module, h->code_path.c_str()) != hipSuccess) {
@@ -228,7 +236,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   h->e_pad = ((d.n_edges + 15) / 16) * 16;
   // ---- model info from the code object
   int32_t in_h[5] = {d.n_opt_x, d.n_g, d.n_edges, h->e_pad, d.n_nodes};
-  int64_t info[16] = {0};
+  int64_t info[20] = {0};
   char hash[64] = {0};
 #ifndef DOMPC_HOST_EMU
   {
@@ -264,6 +272,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   h->ws_stride = info[9];
   h->sweep_block = info[10];
   for (int i = 0; i < 4; ++i) h->xlayout[i] = info[12 + i];
+  h->shard_capable = info[16] != 0;
   // ---- slots
   int max_batch = d.max_batch > 0 ? d.max_batch : 1;
   h->n_slots = d.n_slots > 0 ? d.n_slots : (max_batch < 512 ? max_batch : 512);
@@ -312,9 +321,15 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     A.chain_level = cl;
   }
   A.opt = d.opts;
+  if (const char* mi = getenv("DOMPC_MAX_ITER")) A.opt.max_iter = atoi(mi);      // debugging aid
   A.n_slots = h->n_slots;
   A.ws_stride = h->ws_stride;
   if (dev_alloc(h, (void**)&A.ws, sizeof(double) * (size_t)h->ws_stride * h->n_slots)) return fail(1);
+#ifndef DOMPC_HOST_EMU
+  if (const char* fill = getenv("DOMPC_WS_FILL")) {      // debugging aid: poison the workspace (uninitialised reads)
+    if (hipMemset(A.ws, atoi(fill), sizeof(double) * (size_t)h->ws_stride * h->n_slots) != hipSuccess) { h->error = "hipMemset failed"; return fail(1); }
+  }
+#endif
   if (dev_alloc(h, (void**)&A.work_counter, 64)) return fail(1);
   // wide mode (small batches): up to 64 slots x 32 workgroups
   if (dev_alloc(h, (void**)&A.wide_bar, sizeof(uint32_t) * 16 * 64)) return fail(1);
@@ -352,6 +367,7 @@ extern "C" int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* s) {
     return 0;
   }
   const dompc_problem_desc& d = h->d;
+  if (!h->shard_capable) { h->error = "this code object was built without tree-sharding support (-DDOMPC_SHARD=1)"; return 1; }
   if (s->world < 1 || s->rank < 0 || s->rank >= s->world || s->cut_level < 1 || s->n_cut < 1) { h->error = "invalid shard description"; return 1; }
   if (!s->x_mask || !s->g_mask || !s->edge_mask || !s->node_mask || !s->node_cut || !s->xbuf || !s->allreduce) { h->error = "null pointer in shard description"; return 1; }
 #ifndef DOMPC_HOST_EMU

@@ -134,12 +134,21 @@ class HipIpmSolver:
 
     def __init__(self, structure: ProblemStructure, header_text: str, model_hash: str,
                  nlpsol_opts: Optional[dict] = None, device: int = 0, max_batch: int = 1, n_slots: int = 0,
-                 block_threads: int = 0, _lib_path: Optional[str] = None, _code_object: Optional[str] = None):
+                 block_threads: int = 0, shard: bool = False, _lib_path: Optional[str] = None,
+                 _code_object: Optional[str] = None):
         self.structure = ps = structure
         self.model_hash = model_hash
+        self._ctor = dict(structure=structure, header_text=header_text, model_hash=model_hash, nlpsol_opts=nlpsol_opts,
+                          device=device, max_batch=max_batch, n_slots=n_slots, block_threads=block_threads)
+        self.shard_capable = bool(shard) or _code_object == ""
         if _lib_path is None:
+            try:                      # torch ships its own HIP runtime: it has to be the first one in the process
+                import torch          # noqa: F401
+                torch.cuda.is_available()
+            except ImportError:
+                pass
             _lib_path = build.runtime_library()
-            _code_object = build.model_code_object(header_text, model_hash)
+            _code_object = build.model_code_object(header_text, model_hash, shard=bool(shard))
         self._lib = _load(_lib_path)
         self._keep = []
         d = ProblemDesc()
@@ -225,6 +234,9 @@ class HipIpmSolver:
         on `group` (backend nccl = RCCL on the GPU, gloo in the CPU tests) unless `allreduce(view)` is given.
         Every rank must call the solver with identical inputs."""
         from .structure import shard_tables
+        if not self.shard_capable:
+            raise RuntimeError("this solver was built without tree-sharding support: construct it with shard=True "
+                               "(MPC.shard_tree does that)")
         t = shard_tables(self.structure, rank, world, cut_level)
         if t["cut_level"] < 1:
             raise ValueError("sharding needs a cut level >= 1 (a tree with n_robust >= 1)")
