@@ -2179,8 +2179,9 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     for (int rd = 0; rd < rounds; ++rd) {
       const int e = rd * ng + gid;
       const int en = e + ng;
-      if (e >= A.n_edges || !mk_e(A, e)) continue;      // (no workgroup barrier inside: groups are independent)
-      if (eval_edge_coop(T, Q, e, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld)) T.flags[1] = 1;
+      const bool mine = e < A.n_edges && mk_e(A, e);
+      if (sh_on(A) && !mine) continue;                  // sharded: another rank's edge (no workgroup barrier inside)
+      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld)) T.flags[1] = 1;
     }
   }
   T.sync();
@@ -2538,7 +2539,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         }
       }
       if (ok) { accepted = true; armijo_used = armijo_case; break; }
-      if (alpha * 0.5 < a_min) break;      // xt/st/ct stay at the last evaluated alpha
+      if (!(alpha * 0.5 >= a_min)) break;  // xt/st/ct stay at the last evaluated alpha (also leaves on a NaN step size)
       alpha *= 0.5;
     }
     if (!accepted) {

