@@ -68,18 +68,19 @@ def model_dir(model_hash: str) -> str:
     return d
 
 
-def model_code_object(header_text: str, model_hash: str, force: bool = False, opt: str = "-O3") -> str:
-    """Per-model gfx950 code object (hsaco) from the generated header + the kernel sources."""
+def model_code_object(header_text: str, model_hash: str, force: bool = False, opt: str = "-O3", shard: bool = False) -> str:
+    """Per-model gfx950 code object (hsaco) from the generated header + the kernel sources.
+    shard=True: the variant with tree-sharding support (ownership masks, cross-rank exchanges)."""
     d = model_dir(model_hash)
     hdr = os.path.join(d, "model_gen.h")
-    out = os.path.join(d, f"dompc_{ARCH}.hsaco")
+    out = os.path.join(d, f"dompc_{ARCH}{'_shard' if shard else ''}.hsaco")
     stamp = out + ".stamp"
-    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt
+    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt + ("S" if shard else "")
     if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
         return out
     with open(hdr, "w") as f:
         f.write(header_text)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco",
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}",
            f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC,
            os.path.join(CSRC, "dompc_device.hip"), "-o", out]
     _run(cmd, f"lowering model {model_hash} to {ARCH}")
@@ -101,7 +102,7 @@ def hostemu_library(header_text: str, model_hash: str, out_dir: str, force: bool
     with open(hdr, "w") as f:
         f.write(header_text)
     cxx = shutil.which("g++") or "g++"
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DDOMPC_HOST_EMU",
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DDOMPC_HOST_EMU", "-DDOMPC_SHARD=1",
            f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC,
            os.path.join(CSRC, "dompc_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "dompc_device.hip"),
            "-o", out, "-lm"]

@@ -28,6 +28,8 @@ DOMPC_HD inline void model_info(const int32_t* in, int64_t* out) {
   out[9] = L.total;
   out[10] = SWEEP_BLOCK;
   out[11] = (int64_t)sizeof(KArgs);
+  out[12] = RED_MAX; out[13] = ASM_N; out[14] = CUT1; out[15] = CUT2;      // exchange buffer layout (tree sharding)
+  out[16] = DOMPC_SHARD;                                                   // built with tree-sharding support?
 }
 }  // namespace dompc
 
@@ -49,7 +51,10 @@ extern "C" __global__ void __launch_bounds__(256, 2) dompc_solve_kernel(dompc::K
   __shared__ int flags[8];
   __shared__ int s_b;
   __shared__ long long prof[8];
-  if (threadIdx.x < 8) prof[threadIdx.x] = 0;
+  if (threadIdx.x < 8) { prof[threadIdx.x] = 0; flags[threadIdx.x] = 0; }
+  // defined LDS contents at kernel start (the pool of the previous kernel on this CU is still in there)
+  for (int i = threadIdx.x; i < POOL; i += blockDim.x) pool[i] = 0.0;
+  for (int i = threadIdx.x; i < 2 * dompc::MAX_FILTER; i += blockDim.x) filt[i] = 0.0;
   __syncthreads();
   // Thread context.  Normal mode: one workgroup per problem, problems pulled from a device-wide counter.
   // Wide mode (small batches): K = A.wide workgroups per problem, static assignment problem = slot, all
@@ -64,7 +69,7 @@ extern "C" __global__ void __launch_bounds__(256, 2) dompc_solve_kernel(dompc::K
   dompc::Thr T{j * (int)blockDim.x + (int)threadIdx.x, K * (int)blockDim.x, (dompc::ldsd*)pool, (dompc::ldsd*)filt,
                wide ? A.wide_flags + slot * 8 : flags, (dompc::ldsd*)pool, prof, 64,
                (int)threadIdx.x, (int)blockDim.x, j, K, wide ? A.wide_bar + slot * 16 : nullptr,
-               wide ? A.wide_partials + (int64_t)slot * 2 * K * dompc::RED_MAX : nullptr, 0u, 0u};
+               wide ? A.wide_partials + (int64_t)slot * 2 * K * dompc::RED_MAX : nullptr, 0u, 0u, dompc::make_xctx(A), 0u};
   if (A.mode == 1) {
     if (blockIdx.x == 0) dompc::debug_newton(T, A);
     return;
@@ -100,7 +105,7 @@ extern "C" void dompc_hostemu_run(const dompc::KArgs* A) {
   static thread_local double filt[2 * dompc::MAX_FILTER];
   static thread_local int flags[8];
   static thread_local double edge_lds[dompc::EL_SIZE];
-  dompc::Thr T{0, 1, red, filt, flags, edge_lds, nullptr, 1, 0, 1, 0, 1, nullptr, nullptr, 0u, 0u};
+  dompc::Thr T{0, 1, red, filt, flags, edge_lds, nullptr, 1, 0, 1, 0, 1, nullptr, nullptr, 0u, 0u, dompc::make_xctx(*A), 0u};
   if (A->mode == 1) { dompc::debug_newton(T, *A); return; }
   for (int b = 0; b < A->batch; ++b) {
     if (A->mode == 2) dompc::sweep_problem(T, *A, b, 0);

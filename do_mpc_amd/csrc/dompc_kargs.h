@@ -40,6 +40,21 @@ struct KArgs {
   // sweep (mode 2)
   const double *sw_x, *sw_lam;
   double *sw_g, *sw_blocks;
+  // tree sharding of ONE problem over ranks; masks null = not sharded.
+  // masks: 0 = another rank's, 1 = mine, 2 = replicated on every rank (counted once, by rank 0)
+  const int8_t *x_mask, *g_mask, *e_mask, *n_mask;
+  const int32_t* node_cut;   // index of a cut parent (a replicated node whose child edges are spread over the ranks), or -1
+  int32_t n_cut, cut_level, shard_rank, shard_world;
+  // exchange buffer (device memory, element-wise SUM over the ranks) and the handshake with the host service
+  // loop: the kernel publishes a request (sequence number, element count) in pinned host memory and polls the
+  // acknowledge word; the host runs the collective on the buffer in between.  Host emulation: direct callback.
+  double* xbuf;
+  int32_t xbuf_len, xpad;
+  volatile uint32_t* x_req;
+  volatile uint32_t* x_ack;
+  volatile uint32_t* x_count;
+  void (*x_callback)(void* ctx, double* buf, int32_t count);
+  void* x_ctx;
 };
 
 

@@ -44,6 +44,9 @@ constexpr int NE1 = NE > 0 ? NE : 1;
 constexpr int NS1 = NS > 0 ? NS : 1;
 constexpr int NW1 = NW > 0 ? NW : 1;
 constexpr int MAX_FILTER = 48;
+#ifndef DOMPC_SHARD
+#define DOMPC_SHARD 0
+#endif
 constexpr int RED_MAX = 12;          // values reduced per pass
 #ifndef DOMPC_HOST_EMU
 constexpr int GS_C = 64;             // lanes per edge group: one wavefront
@@ -139,6 +142,22 @@ typedef double ldsd;
 // small batches so that a single make_step can use many CUs - K workgroups that synchronise through a
 // device-scope barrier.  All loops over work items are written against (tid, nt), the index / count
 // among ALL threads of the problem; (ltid, lnt) are the coordinates inside the workgroup (LDS indexing).
+// exchange context of a sharded problem, copied out of the kernel arguments (by value: the argument block
+// itself must not escape into out-of-line code, or the compiler loses the address spaces of all its pointers)
+struct XCtx {
+  int on, rank, world;
+  double* xbuf;
+  volatile uint32_t *req, *ack, *cnt;
+  void (*cb)(void* ctx, double* buf, int32_t count);
+  void* ctx;
+};
+DOMPC_HD inline XCtx make_xctx(const KArgs& A) {
+  XCtx X;
+  X.on = A.x_mask != nullptr; X.rank = A.shard_rank; X.world = A.shard_world; X.xbuf = A.xbuf;
+  X.req = A.x_req; X.ack = A.x_ack; X.cnt = A.x_count; X.cb = A.x_callback; X.ctx = A.x_ctx;
+  return X;
+}
+
 struct Thr {
   int tid, nt;
   ldsd* red;        // LDS: RED_MAX * lnt doubles
@@ -152,6 +171,8 @@ struct Thr {
   unsigned* bar;    // wide: global arrival counter of the problem slot (monotonic)
   double* partials; // wide: global [2][nwg][RED_MAX] reduction partials
   mutable unsigned gen, nred;
+  XCtx X;           // tree sharding: exchange buffer and handshake words (X.on == 0: not sharded)
+  mutable unsigned xseq;
   DOMPC_DEV void sync() const {
 #ifndef DOMPC_HOST_EMU
     __syncthreads();
@@ -192,7 +213,50 @@ struct Thr {
     __builtin_amdgcn_wave_barrier();
 #endif
   }
+  // Cross-rank exchange of a sharded problem: element-wise SUM over the ranks of X.xbuf[off..off+n).  Called by
+  // ALL threads of the problem after they have written their part of the buffer.  Device: workgroup 0
+  // publishes the request in pinned host memory and polls the acknowledge word while the host service loop
+  // (dompc_runtime.cpp) runs the collective (RCCL all-reduce) on the buffer; bounded spin -> abort flag.
+  DOMPC_DEV void xchg(int off, int n) const {
+#ifdef DOMPC_HOST_EMU
+    if (X.cb) X.cb(X.ctx, X.xbuf + off, n);
+#else
+    sync();
+    ++xseq;
+    if (wg == 0 && ltid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      X.cnt[0] = (unsigned)n;
+      X.cnt[1] = (unsigned)off;
+      __hip_atomic_store((unsigned*)X.req, xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      long long spins = 0;
+      const bool dead = __hip_atomic_load(flags + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      while (!dead && __hip_atomic_load((unsigned*)X.ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != xseq) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > 4000000ll) {                        // (seconds) the host never answered: abort instead of hanging
+          __hip_atomic_store(flags + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    sync();
+#endif
+  }
 };
+
+// ---- tree sharding: masks 0 = another rank's, 1 = mine, 2 = replicated (identical everywhere; counted once).
+// The support is compiled in only with -DDOMPC_SHARD=1 (a second code object per model, build.py): in the
+// plain build every helper folds to a constant and the batch path carries no mask loads and no extra registers
+// (measured: the mask-aware build is 9 % slower on the B=1024 batch).
+constexpr bool SHARD = DOMPC_SHARD != 0;
+DOMPC_DEV inline bool sh_on(const KArgs& A) { return SHARD && A.x_mask != nullptr; }
+DOMPC_DEV inline int mk_x(const KArgs& A, int g) { return (SHARD && A.x_mask) ? A.x_mask[g] : 1; }
+DOMPC_DEV inline int mk_g(const KArgs& A, int r) { return (SHARD && A.g_mask) ? A.g_mask[r] : 1; }
+DOMPC_DEV inline int mk_e(const KArgs& A, int e) { return (SHARD && A.e_mask) ? A.e_mask[e] : 1; }
+DOMPC_DEV inline int mk_n(const KArgs& A, int n) { return (SHARD && A.n_mask) ? A.n_mask[n] : 1; }
+// does an item with mask m enter a SUM on this rank?
+DOMPC_DEV inline bool sh_cnt(const KArgs& A, int m) { return !SHARD || m == 1 || (m == 2 && A.shard_rank == 0); }
+DOMPC_DEV inline int cut_of(const KArgs& A, int n) { return (SHARD && A.node_cut) ? A.node_cut[n] : -1; }
 
 
 DOMPC_DEV inline long long prof_clock() {
@@ -209,7 +273,7 @@ enum RedOp { R_SUM = 0, R_MAX = 1, R_MIN = 2 };
 template <int N_>
 DOMPC_DEV void wg_reduce(const Thr& T, double (&v)[N_], const int (&op)[N_]) {
   static_assert(N_ <= RED_MAX, "too many values");
-  if (T.nt == 1) return;
+  if (T.nt == 1 && !(SHARD && T.X.on)) return;
   for (int i = 0; i < N_; ++i) T.red[i * T.lnt + T.ltid] = v[i];
   T.lsync();
   for (int s = T.lnt >> 1; s > 0; s >>= 1) {
@@ -234,6 +298,28 @@ DOMPC_DEV void wg_reduce(const Thr& T, double (&v)[N_], const int (&op)[N_]) {
         acc = op[T.ltid] == R_SUM ? acc + b : (op[T.ltid] == R_MAX ? fmax(acc, b) : fmin(acc, b));
       }
       T.red[T.ltid * T.lnt] = acc;
+    }
+    T.lsync();
+  }
+  if (SHARD && T.X.on) {
+    // combine the ranks: every rank deposits its values in its own row of a [world][RED_MAX] table (zeros
+    // elsewhere), the SUM exchange turns that into an all-gather, and every rank folds the rows in rank order
+    // with the requested operations -> bitwise identical results and control flow on all ranks
+    const int W = T.X.world, me = T.X.rank;
+    double* xb = T.X.xbuf;
+    if (T.wg == 0)
+      for (int i = T.ltid; i < W * RED_MAX; i += T.lnt) {
+        const int w = i / RED_MAX, j = i % RED_MAX;
+        xb[i] = (w == me && j < N_) ? T.red[j * T.lnt] : 0.0;
+      }
+    T.xchg(0, W * RED_MAX);
+    for (int i = T.ltid; i < N_; i += T.lnt) {
+      double acc = xb[i];
+      for (int w = 1; w < W; ++w) {
+        const double b = xb[w * RED_MAX + i];
+        acc = op[i] == R_SUM ? acc + b : (op[i] == R_MAX ? fmax(acc, b) : fmin(acc, b));
+      }
+      T.red[i * T.lnt] = acc;
     }
     T.lsync();
   }
@@ -455,6 +541,7 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
   constexpr int NIT = (M == 0 ? 1 : NCOLL) + 3;
   for (int it = T.tid; it < A.n_edges * NIT; it += T.nt) {
     const int e = it / NIT, j = it % NIT;
+    if (!mk_e(A, e)) continue;
     const int n = A.edge_parent[e], cn = A.edge_child[e], k = A.edge_level[e];
     const double* xn = Q.x + A.node_x_off[n];
     const double* un = Q.x + A.node_u_off[n];
@@ -557,7 +644,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         const int jj = rr / NX, a = rr % NX;         // jj = 0..DEG-1: collocation row j=jj+1 ; jj = DEG: continuity row
         const double* xi0 = (i == 0) ? xn : w + slot_of(i, 0) * NX;
         const int row = i * (DEG + 1) * NX + jj * NX + a;
-        double* Mr = Ld + EL_MX + row * NC;
+        ldsd* Mr = Ld + EL_MX + row * NC;
         if (jj < DEG) {
           const int j = jj + 1, sl = slot_of(i, j), p = i * DEG + jj;
           const double* pt = mo + MO_PT + p * PT_STRIDE;
@@ -1018,31 +1105,59 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
 }
 
 // ================================================================================================
-// Gradient / dual-residual assembly for the variables owned by node n (x_n, u_n, eps_n).
-DOMPC_PHASE void assemble_node(const Prob& Q, int n) {
+// Gradient / dual-residual assembly for the variables owned by node n (x_n, u_n, eps_n), in two parts so that
+// the child-dependent sums of a cut parent (tree sharding) can be exchanged between the ranks:
+//   assemble_children: sums over the child edges e with take(e):  [gx | rx | gu | ru | child rterm | r_eps]
+//   assemble_finish:   adds the node's own terms and writes gf / rd.
+constexpr int ASM_N = 2 * NX + 3 * NU + NS;
+// exchange buffer layout of a sharded problem (doubles):
+//   [reduction table W x RED_MAX | cut parents' assembly sums + W sweep flags | cut Riccati pass 1 | pass 2 + W flags]
+constexpr int CUT1 = 2 * (NYT * NYT + NYT);       // QO, QOV, QF, QFV
+constexpr int CUT2 = NA * NA + NA;                // closed-loop value-function share PN, PNV
+DOMPC_DEV inline int x_asm(const KArgs& A) { return A.shard_world * RED_MAX; }
+DOMPC_DEV inline int x_c1(const KArgs& A) { return x_asm(A) + A.n_cut * ASM_N + A.shard_world; }
+DOMPC_DEV inline int x_c2(const KArgs& A) { return x_c1(A) + A.n_cut * CUT1; }
+DOMPC_DEV inline int x_len(const KArgs& A) { return x_c2(A) + A.n_cut * CUT2 + A.shard_world; }
+DOMPC_DEV inline void assemble_children(const Prob& Q, int n, bool counted_only, double* out) {
   const KArgs& A = *Q.A;
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
-  const int xo = A.node_x_off[n];
-  double gx[NX], rx[NX];
-  for (int a = 0; a < NX; ++a) { gx[a] = 0.0; rx[a] = 0.0; }
+  const int uo = A.node_u_off[n];
+  for (int i = 0; i < ASM_N; ++i) out[i] = 0.0;
   for (int j = 0; j < cc; ++j) {
-    const double* S_ = Q.ES(cs + j);
-    for (int a = 0; a < NX; ++a) { gx[a] += S_[ES_GFY + a]; rx[a] += S_[ES_RY + a]; }
-  }
-  const int ie = A.node_in_edge[n];
-  if (ie >= 0) {
-    const double* nu_in = Q.lam + A.edge_row0[ie] + NW;
-    for (int a = 0; a < NX; ++a) rx[a] -= nu_in[a];
-    if (cc == 0) {
-      const double* S_ = Q.ES(ie);
-      for (int a = 0; a < NX; ++a) { gx[a] += S_[ES_MG + a]; rx[a] += S_[ES_MG + a]; }
+    const int e = cs + j;
+    if (counted_only && !sh_cnt(A, mk_e(A, e))) continue;
+    const double* S_ = Q.ES(e);
+    for (int a = 0; a < NX; ++a) { out[a] += S_[ES_GFY + a]; out[NX + a] += S_[ES_RY + a]; }
+    for (int i = 0; i < NU; ++i) { out[2 * NX + i] += S_[ES_GFY + NX + i]; out[2 * NX + NU + i] += S_[ES_RY + NX + i]; }
+    const int cn = A.edge_child[e];
+    if (A.node_u_off[cn] >= 0) {                   // the child's rterm w.r.t. its u_prev = u_n
+      const double rwc = node_rweight(Q, cn);
+      for (int i = 0; i < NU; ++i)
+        out[2 * NX + 2 * NU + i] -= 2.0 * rwc * DOMPC_RTERM[i] * (Q.x[A.node_u_off[cn] + i] - Q.x[uo + i]);
     }
-  } else {
-    for (int a = 0; a < NX; ++a) rx[a] += Q.lam[a];
+    if (NS > 0) {
+      const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
+      for (int q = 0; q < NS; ++q)
+        for (int i = 0; i < NE; ++i)
+          if (DOMPC_NL_SLACK[i] == q) out[2 * NX + 3 * NU + q] -= yd[i];
+    }
   }
+}
+DOMPC_DEV inline void assemble_finish(const Prob& Q, int n, const double* in) {
+  const KArgs& A = *Q.A;
+  const int cc = A.node_child_count[n];
+  const int xo = A.node_x_off[n];
+  const int ie = A.node_in_edge[n];
   for (int a = 0; a < NX; ++a) {
-    Q.gf[xo + a] = gx[a];
-    Q.rd[xo + a] = rx[a] - Q.zl[xo + a] + Q.zu[xo + a];
+    double gx = in[a], rx = in[NX + a];
+    if (ie >= 0) {
+      rx -= Q.lam[A.edge_row0[ie] + NW + a];
+      if (cc == 0) { const double mg = Q.ES(ie)[ES_MG + a]; gx += mg; rx += mg; }
+    } else {
+      rx += Q.lam[a];
+    }
+    Q.gf[xo + a] = gx;
+    Q.rd[xo + a] = rx - Q.zl[xo + a] + Q.zu[xo + a];
   }
   if (cc == 0) return;
   const int uo = A.node_u_off[n];
@@ -1050,37 +1165,23 @@ DOMPC_PHASE void assemble_node(const Prob& Q, int n) {
   const double* up = uprev_ptr(Q, n, Q.x, tmp);
   const double rw = node_rweight(Q, n);
   for (int i = 0; i < NU; ++i) {
-    double g = 0.0, r = 0.0;
-    for (int j = 0; j < cc; ++j) {
-      const double* S_ = Q.ES(cs + j);
-      g += S_[ES_GFY + NX + i];
-      r += S_[ES_RY + NX + i];
-    }
-    double rt = 2.0 * rw * DOMPC_RTERM[i] * (Q.x[uo + i] - up[i]);
-    for (int j = 0; j < cc; ++j) {                 // children's rterm w.r.t. their u_prev = u_n
-      const int cn = A.edge_child[cs + j];
-      if (A.node_u_off[cn] >= 0) {
-        const double rwc = node_rweight(Q, cn);
-        rt -= 2.0 * rwc * DOMPC_RTERM[i] * (Q.x[A.node_u_off[cn] + i] - Q.x[uo + i]);
-      }
-    }
-    Q.gf[uo + i] = g + rt;
-    Q.rd[uo + i] = r + rt - Q.zl[uo + i] + Q.zu[uo + i];
+    const double rt = 2.0 * rw * DOMPC_RTERM[i] * (Q.x[uo + i] - up[i]) + in[2 * NX + 2 * NU + i];
+    Q.gf[uo + i] = in[2 * NX + i] + rt;
+    Q.rd[uo + i] = in[2 * NX + NU + i] + rt - Q.zl[uo + i] + Q.zu[uo + i];
   }
   if (NS > 0) {
     const int eo = A.node_eps_off[n];
     for (int q = 0; q < NS; ++q) {
-      double g = cc * Q.sf * DOMPC_EPS_PEN[q];
-      double r = g;
-      for (int j = 0; j < cc; ++j) {
-        const double* yd = Q.lam + A.edge_row0[cs + j] + NW + NX;
-        for (int i = 0; i < NE; ++i)
-          if (DOMPC_NL_SLACK[i] == q) r -= yd[i];
-      }
+      const double g = cc * Q.sf * DOMPC_EPS_PEN[q];
       Q.gf[eo + q] = g;
-      Q.rd[eo + q] = r - Q.zl[eo + q] + Q.zu[eo + q];
+      Q.rd[eo + q] = g + in[2 * NX + 3 * NU + q] - Q.zl[eo + q] + Q.zu[eo + q];
     }
   }
+}
+DOMPC_PHASE void assemble_node(const Prob& Q, int n) {
+  double t[ASM_N];
+  assemble_children(Q, n, false, t);
+  assemble_finish(Q, n, t);
 }
 
 // ================================================================================================
@@ -1493,6 +1594,269 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
   return bad;
 }
 
+// Cut parent of a sharded tree (a replicated node whose child sub-trees live on different ranks): the node
+// update in three phases around two exchanges (SUM over the ranks of the per-node slots in KArgs::xbuf).
+//   phase 1: QO/QOV (own terms: rank 0 only; condensed blocks of the children this rank counts) and the
+//            coupling QF/QFV = sum Atilde' P_c Atilde of those children            -> slot in region x_c1
+//   phase 2: summed QO..QFV -> K, kv (identical on every rank); closed-loop shares sum Acl' P_c Acl
+//            of the counted children                                                -> slot in region x_c2
+//   phase 3: P_n = Lc' QO Lc + summed shares -> node record (identical on every rank)
+// Plain global loads (no register prefetch): at most a few dozen such nodes per factorisation.
+DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double mu, double delta, ldsd* Ld, int lane,
+                                      int GS, int phase) {
+  using namespace rb;
+  const KArgs& A = *Q.A;
+  double* Nd = Q.ND(n);
+  const int cs = A.node_child_start[n], cc = A.node_child_count[n];
+  const int ci = A.node_cut[n];
+  double* X1 = A.xbuf + x_c1(A) + ci * CUT1;
+  double* X2 = A.xbuf + x_c2(A) + ci * CUT2;
+  auto counted = [&](int c) { return sh_cnt(A, mk_e(A, cs + c)); };
+  auto stage_child = [&](int c) {
+    const int e = cs + c;
+    const double* S_ = Q.ES(e);
+    const double* Nc = Q.ND(A.edge_child[e]);
+    for (int it = lane; it < NA * (NA + 1); it += GS) {
+      const int i = it / (NA + 1), j = it % (NA + 1);
+      if (j < NA) Ld[RB_AT + i * NA + j] = (i < NX) ? S_[ES_AB + i * NA + j] : ((j == i) ? 1.0 : 0.0);
+      else Ld[RB_CT + i] = (i < NX) ? S_[ES_CV + i] : 0.0;
+    }
+    for (int it = lane; it < NA * NA; it += GS) Ld[RB_PC + it] = Nc[ND_P + it];
+    for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Nc[ND_PV + it];
+  };
+  if (phase == 1) {
+    const bool own = A.shard_rank == 0;
+    const double rw = node_rweight(Q, n);
+    const int xo = A.node_x_off[n], uo = A.node_u_off[n];
+    const int eo = NS > 0 ? A.node_eps_off[n] : -1;
+    const int ie = A.node_in_edge[n];
+    double utmp[NU];
+    const double* up = uprev_ptr(Q, n, Q.x, utmp);
+    for (int i = lane; i < NYT; i += GS) {
+      const int yi = yidx(i);
+      const bool is_up = (i >= NX && i < NA);
+      const int g = (i < NX) ? xo + i : (is_up ? uo + (i - NX) : (i < NA + NU ? uo + (i - NA) : eo + (i - NA - NU)));
+      double dg = 0.0, gv = 0.0;
+      if (own) {
+        const double xv = Q.x[g], lo = Q.lb[g], hi = Q.ub[g];
+        if (is_up) {
+          dg = 2.0 * rw * DOMPC_RTERM[i - NX];
+          gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - up[i - NX]);
+        } else {
+          dg = sigma_of(xv, lo, hi, Q.zl[g], Q.zu[g]) + delta;
+          gv = bar_grad(xv, lo, hi, mu);
+          if (i < NX) gv += (ie >= 0) ? -Q.lam[A.edge_row0[ie] + NW + i] : Q.lam[i];
+          else if (i < NA + NU) {
+            dg += 2.0 * rw * DOMPC_RTERM[i - NA];
+            gv += 2.0 * rw * DOMPC_RTERM[i - NA] * (xv - up[i - NA]);
+          } else {
+            gv += cc * Q.sf * DOMPC_EPS_PEN[i - NA - NU];
+          }
+        }
+      }
+      for (int c = 0; c < cc; ++c) {
+        if (!counted(c)) continue;
+        const int e = cs + c;
+        const double* S_ = Q.ES(e);
+        if (yi >= 0) gv += S_[ES_RY + yi] + S_[ES_QV + yi] + delta * S_[ES_WTW0 + yi];
+        if (NE > 0) {
+          const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
+          for (int q = 0; q < NE; ++q) {
+            const double sg = S_[ES_SIGS + q] + delta;
+            double ji = 0.0;
+            if (yi >= 0) ji = Q.EW(e, EW_JD + q * NA + yi);
+            else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) { ji = -1.0; gv -= yd[q]; }
+            gv += ji * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
+          }
+        }
+      }
+      Ld[RB_QOV + i] = gv;
+      Ld[RB_QFV + i] = 0.0;
+      Ld[RB_QF + i * NYT + i] = dg;      // diagonal parked in QF, merged below
+    }
+    T.gsync();
+    for (int it = lane; it < NYT * NYT; it += GS) {
+      const int i = it / NYT, j = it % NYT;
+      const int yi = yidx(i), yj = yidx(j);
+      double v = 0.0;
+      for (int c = 0; c < cc; ++c) {
+        if (!counted(c)) continue;
+        const int e = cs + c;
+        const double* S_ = Q.ES(e);
+        if (yi >= 0 && yj >= 0) {
+          v += S_[ES_QT + yi * NA + yj];
+          if (delta != 0.0) v += delta * S_[ES_WTW + yi * NA + yj];
+        }
+        if (NE > 0)
+          for (int qq = 0; qq < NE; ++qq) {
+            const double sg = S_[ES_SIGS + qq] + delta;
+            double ji = 0.0, jj = 0.0;
+            if (yi >= 0) ji = Q.EW(e, EW_JD + qq * NA + yi);
+            else if (i >= NA + NU && DOMPC_NL_SLACK[qq] == i - NA - NU) ji = -1.0;
+            if (yj >= 0) jj = Q.EW(e, EW_JD + qq * NA + yj);
+            else if (j >= NA + NU && DOMPC_NL_SLACK[qq] == j - NA - NU) jj = -1.0;
+            v += sg * ji * jj;
+          }
+      }
+      if (i == j) v += Ld[RB_QF + i * NYT + i];
+      else if (own && i >= NX && i < NA && j == i + NU) v -= 2.0 * rw * DOMPC_RTERM[i - NX];
+      else if (own && j >= NX && j < NA && i == j + NU) v -= 2.0 * rw * DOMPC_RTERM[j - NX];
+      Ld[RB_QO + it] = v;
+    }
+    T.gsync();
+    for (int it = lane; it < NYT * NYT; it += GS) Ld[RB_QF + it] = 0.0;
+    T.gsync();
+    for (int c = 0; c < cc; ++c) {
+      if (!counted(c)) continue;
+      stage_child(c);
+      T.gsync();
+      gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_PC), NA, 1, (double*)(Ld + RB_AT), NA, 1, 0.0, (double*)(Ld + RB_TP), NA);
+      for (int i = lane; i < NA; i += GS) {
+        double t = Ld[RB_PCV + i];
+        for (int a = 0; a < NX; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CT + a];
+        Ld[RB_TV + i] = t;
+      }
+      T.gsync();
+      gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_AT), 1, NA, (double*)(Ld + RB_TP), NA, 1, 0.0, (double*)(Ld + RB_ACL), NA);
+      for (int i = lane; i < NA; i += GS) {
+        double t = 0.0;
+        for (int a = 0; a < NA; ++a) t += Ld[RB_AT + a * NA + i] * Ld[RB_TV + a];
+        Ld[RB_CCL + i] = t;
+      }
+      T.gsync();
+      for (int it = lane; it < NA * (NA + 1); it += GS) {
+        const int yi = it / (NA + 1), yj = it % (NA + 1);
+        if (yj < NA) Ld[RB_QF + ycol(yi) * NYT + ycol(yj)] += Ld[RB_ACL + yi * NA + yj];
+        else Ld[RB_QFV + ycol(yi)] += Ld[RB_CCL + yi];
+      }
+      T.gsync();
+    }
+    for (int it = lane; it < NYT * NYT; it += GS) {
+      X1[it] = Ld[RB_QO + it];
+      X1[NYT * NYT + NYT + it] = Ld[RB_QF + it];
+    }
+    for (int i = lane; i < NYT; i += GS) {
+      X1[NYT * NYT + i] = Ld[RB_QOV + i];
+      X1[2 * NYT * NYT + NYT + i] = Ld[RB_QFV + i];
+    }
+    T.gsync();
+    return 0;
+  }
+  // phases 2 and 3 start from the summed quadratic
+  for (int it = lane; it < NYT * NYT; it += GS) {
+    Ld[RB_QO + it] = X1[it];
+    Ld[RB_QF + it] = X1[NYT * NYT + NYT + it];
+  }
+  for (int i = lane; i < NYT; i += GS) {
+    Ld[RB_QOV + i] = X1[NYT * NYT + i];
+    Ld[RB_QFV + i] = X1[2 * NYT * NYT + NYT + i];
+  }
+  T.gsync();
+  int bad = 0;
+  if (phase == 2) {
+    // Cholesky of Qvv (QF + QO) and K = -Qvv^-1 Qvx, kv = -Qvv^-1 qv  (one lane per column)
+    for (int j = lane; j < NA + 1; j += GS) {
+      double L[NV * NV];
+      for (int i = 0; i < NV; ++i)
+        for (int jj = 0; jj <= i; ++jj) {
+          double t = Ld[RB_QF + (NA + i) * NYT + NA + jj] + Ld[RB_QO + (NA + i) * NYT + NA + jj];
+          for (int q = 0; q < jj; ++q) t -= L[i * NV + q] * L[jj * NV + q];
+          if (i == jj) {
+            if (!(t > 0.0)) { bad = 1; t = 1.0; }
+            L[i * NV + i] = sqrt(t);
+          } else {
+            L[i * NV + jj] = t / L[jj * NV + jj];
+          }
+        }
+      double y[NV];
+      for (int i = 0; i < NV; ++i) {
+        double t = (j < NA) ? Ld[RB_QF + (NA + i) * NYT + j] + Ld[RB_QO + (NA + i) * NYT + j]
+                            : Ld[RB_QFV + NA + i] + Ld[RB_QOV + NA + i];
+        for (int q = 0; q < i; ++q) t -= L[i * NV + q] * y[q];
+        y[i] = t / L[i * NV + i];
+      }
+      for (int i = NV - 1; i >= 0; --i) {
+        double t = y[i];
+        for (int q = i + 1; q < NV; ++q) t -= L[q * NV + i] * y[q];
+        y[i] = t / L[i * NV + i];
+      }
+      for (int i = 0; i < NV; ++i) {
+        if (j < NA) { Ld[RB_K + i * NA + j] = -y[i]; Nd[ND_K + i * NA + j] = -y[i]; }
+        else { Ld[RB_KV + i] = -y[i]; Nd[ND_KV + i] = -y[i]; }
+      }
+    }
+    for (int it = lane; it < NA * NA; it += GS) Ld[RB_PN + it] = 0.0;
+    for (int it = lane; it < NA; it += GS) Ld[RB_PNV + it] = 0.0;
+    T.gsync();
+    for (int c = 0; c < cc; ++c) {
+      if (!counted(c)) continue;
+      stage_child(c);
+      T.gsync();
+      for (int it = lane; it < NA * (NA + 1); it += GS) {         // closed-loop map of this child
+        const int i = it / (NA + 1), j = it % (NA + 1);
+        double t;
+        if (j < NA) {
+          t = (j < NX) ? Ld[RB_AT + i * NA + j] : 0.0;
+          for (int u = 0; u < NU; ++u) t += Ld[RB_AT + i * NA + NX + u] * Ld[RB_K + u * NA + j];
+          Ld[RB_ACL + i * NA + j] = t;
+        } else {
+          t = Ld[RB_CT + i];
+          for (int u = 0; u < NU; ++u) t += Ld[RB_AT + i * NA + NX + u] * Ld[RB_KV + u];
+          Ld[RB_CCL + i] = t;
+        }
+      }
+      T.gsync();
+      gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_PC), NA, 1, (double*)(Ld + RB_ACL), NA, 1, 0.0, (double*)(Ld + RB_TP), NA);
+      for (int i = lane; i < NA; i += GS) {
+        double t = Ld[RB_PCV + i];
+        for (int a = 0; a < NA; ++a) t += Ld[RB_PC + i * NA + a] * Ld[RB_CCL + a];
+        Ld[RB_TV + i] = t;
+      }
+      T.gsync();
+      gmm(lane, GS, NA, NA, NA, (double*)(Ld + RB_ACL), 1, NA, (double*)(Ld + RB_TP), NA, 1, 1.0, (double*)(Ld + RB_PN), NA);
+      for (int i = lane; i < NA; i += GS) {
+        double t = 0.0;
+        for (int a = 0; a < NA; ++a) t += Ld[RB_ACL + a * NA + i] * Ld[RB_TV + a];
+        Ld[RB_PNV + i] += t;
+      }
+      T.gsync();
+    }
+    for (int it = lane; it < NA * NA; it += GS) X2[it] = Ld[RB_PN + it];
+    for (int it = lane; it < NA; it += GS) X2[NA * NA + it] = Ld[RB_PNV + it];
+    T.gsync();
+    return bad;
+  }
+  // phase 3: own congruence Lc' QO Lc with the stored gains, plus the summed closed-loop shares
+  for (int it = lane; it < NV * NA; it += GS) Ld[RB_K + it] = Nd[ND_K + it];
+  for (int it = lane; it < NV; it += GS) Ld[RB_KV + it] = Nd[ND_KV + it];
+  T.gsync();
+  for (int it = lane; it < NA * (NA + 1); it += GS) {
+    const int i = it / (NA + 1), j = it % (NA + 1);
+    if (j < NA) {
+      double t = Ld[RB_QO + i * NYT + j];
+      for (int q = 0; q < NV; ++q) {
+        t += Ld[RB_QO + i * NYT + NA + q] * Ld[RB_K + q * NA + j];
+        t += Ld[RB_K + q * NA + i] * Ld[RB_QO + (NA + q) * NYT + j];
+        double t2 = 0.0;
+        for (int w = 0; w < NV; ++w) t2 += Ld[RB_QO + (NA + q) * NYT + NA + w] * Ld[RB_K + w * NA + j];
+        t += Ld[RB_K + q * NA + i] * t2;
+      }
+      Nd[ND_P + i * NA + j] = t + X2[i * NA + j];
+    } else {
+      double t = Ld[RB_QOV + i];
+      for (int w = 0; w < NV; ++w) t += Ld[RB_QO + i * NYT + NA + w] * Ld[RB_KV + w];
+      for (int q = 0; q < NV; ++q) {
+        double t2 = Ld[RB_QOV + NA + q];
+        for (int w = 0; w < NV; ++w) t2 += Ld[RB_QO + (NA + q) * NYT + NA + w] * Ld[RB_KV + w];
+        t += Ld[RB_K + q * NA + i] * t2;
+      }
+      Nd[ND_PV + i] = t + X2[NA * NA + i];
+    }
+  }
+  T.gsync();
+  return 0;
+}
+
 DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double delta) {
   // One group of lanes (a wavefront) per tree node, the node's matrices staged in the group's LDS region:
   //   RB_QO  own quadratic of the node over (x, u_prev, u, eps)       (NYT x NYT) + gradient
@@ -1516,6 +1880,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
     const int n0 = A.level_node_start[A.N], n1 = A.level_node_start[A.N + 1];
     for (int it = T.tid; it < (n1 - n0) * NA * (NA + 1); it += T.nt) {
       const int n = n0 + it / (NA * (NA + 1));
+      if (!mk_n(A, n)) continue;
       const int r = it % (NA * (NA + 1));
       const int i = r / (NA + 1), j = r % (NA + 1);
       double* Nd = Q.ND(n);
@@ -1543,6 +1908,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
     // scenario chains: stages N-1 ... chain_level, node (k, s) -> parent (k-1, s)
     const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
     for (int s_ = gid; s_ < S; s_ += ng) {
+      if (!mk_n(A, A.level_node_start[A.N] + s_)) continue;      // another rank's sub-tree
       bool staged = false;
       NodePre R;
       if (A.N - 1 >= cl) node_prefetch(Q, A.level_node_start[A.N - 1] + s_, delta, lane, GS, R);
@@ -1560,17 +1926,35 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
       }
     }
     T.sync();
-    if (T.flags[0]) return 1;
+    if (T.flags[0] && !sh_on(A)) return 1;      // (sharded: the flag is only known to this rank until the cut exchange)
   }
   for (int k = cl - 1; k >= 0; --k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
+    if (sh_on(A) && k == A.cut_level - 1) {
+      // cut parents: their child sub-trees are spread over the ranks -> two exchanges (riccati_cut_node)
+      for (int n = n0 + gid; n < n1; n += ng) riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 1);
+      T.xchg(x_c1(A), A.n_cut * CUT1);
+      for (int n = n0 + gid; n < n1; n += ng)
+        if (riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 2)) T.flags[0] = 1;
+      T.sync();
+      double* fl = A.xbuf + x_c2(A) + A.n_cut * CUT2;          // failure flags of all ranks ride along
+      for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && T.flags[0]) ? 1.0 : 0.0;
+      T.xchg(x_c2(A), A.n_cut * CUT2 + A.shard_world);
+      for (int n = n0 + gid; n < n1; n += ng) riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 3);
+      int bad = 0;
+      for (int w = 0; w < A.shard_world; ++w) bad |= (fl[w] != 0.0);
+      T.sync();
+      if (bad) return 1;
+      continue;
+    }
     for (int n = n0 + gid; n < n1; n += ng) {
+      if (!mk_n(A, n)) continue;
       NodePre R;
       node_prefetch(Q, n, delta, lane, GS, R);
       if (riccati_node(T, Q, n, mu, delta, Ld, lane, GS, false, R)) T.flags[0] = 1;
     }
     T.sync();
-    if (T.flags[0]) return 1;
+    if (T.flags[0] && (!sh_on(A) || k < A.cut_level - 1)) return 1;
   }
   return 0;
 }
@@ -1612,6 +1996,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     const int cs = A.node_child_start[n], cc = A.node_child_count[n];
     for (int it = lane; it < cc * NA; it += GS) {
       const int e = cs + it / NA, a = it % NA, cn = A.edge_child[e];
+      if (!mk_e(A, e)) continue;                       // another rank's sub-tree
       const double* S_ = Q.ES(e);
       double t;
       if (a < NX) {
@@ -1636,13 +2021,16 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   const int cl = A.chain_level < A.N ? A.chain_level : A.N;
   for (int k = 0; k < cl; ++k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
-    for (int n = n0 + gid; n < n1; n += ng) node_step(n, false);
+    for (int n = n0 + gid; n < n1; n += ng)
+      if (mk_n(A, n)) node_step(n, false);
     T.sync();
   }
   {
     const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
-    for (int s_ = gid; s_ < S; s_ += ng)
+    for (int s_ = gid; s_ < S; s_ += ng) {
+      if (!mk_n(A, A.level_node_start[A.N] + s_)) continue;
       for (int k = cl; k < A.N; ++k) node_step(A.level_node_start[k] + s_, k > cl);
+    }
     T.sync();
   }
   // initial-condition multiplier step
@@ -1656,6 +2044,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   // its column of G_w^-1) do not depend on the step, so they are loaded into registers up front: two global
   // round trips per edge instead of one per dependent sub-step.
   for (int e = gid; e < A.n_edges; e += ng) {
+    if (!mk_e(A, e)) continue;
     const int n = A.edge_parent[e], cn = A.edge_child[e];
     const double* Nd = Q.ND(n);
     const double* Nc = Q.ND(cn);
@@ -1758,6 +2147,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   T.sync();
   // bound multiplier steps
   for (int g = T.tid; g < A.n_opt_x; g += T.nt) {
+    if (!mk_x(A, g)) continue;
     const double xv = Q.x[g], l = Q.lb[g], u = Q.ub[g];
     Q.dzl[g] = (l > -INFINITY) ? mu / (xv - l) - Q.zl[g] - Q.zl[g] / (xv - l) * Q.dx[g] : 0.0;
     Q.dzu[g] = (u < INFINITY) ? mu / (u - xv) - Q.zu[g] + Q.zu[g] / (u - xv) * Q.dx[g] : 0.0;
@@ -1789,17 +2179,36 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     for (int rd = 0; rd < rounds; ++rd) {
       const int e = rd * ng + gid;
       const int en = e + ng;
-      if (eval_edge_coop(T, Q, e < A.n_edges ? e : -1, en < A.n_edges ? en : -1, mu, lane, T.gs, Ld)) T.flags[1] = 1;
+      const bool mine = e < A.n_edges && mk_e(A, e);
+      if (sh_on(A) && !mine) continue;                  // sharded: another rank's edge (no workgroup barrier inside)
+      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld)) T.flags[1] = 1;
     }
   }
   T.sync();
-  for (int n = T.tid; n < A.n_nodes; n += T.nt) assemble_node(Q, n);
+  for (int n = T.tid; n < A.n_nodes; n += T.nt) {
+    if (!mk_n(A, n)) continue;
+    const int ci = cut_of(A, n);
+    if (ci >= 0) assemble_children(Q, n, true, A.xbuf + x_asm(A) + ci * ASM_N);   // completed after the exchange
+    else assemble_node(Q, n);
+  }
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
     const int g = A.dummy_idx[d];
     Q.gf[g] = 0.0;
     Q.rd[g] = -Q.zl[g] + Q.zu[g];
   }
   T.sync();
+  if (sh_on(A)) {
+    // cut parents: sum the child-dependent parts over the ranks; the failure flag rides along
+    double* fl = A.xbuf + x_asm(A) + A.n_cut * ASM_N;
+    for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && T.flags[1]) ? 1.0 : 0.0;
+    T.xchg(x_asm(A), A.n_cut * ASM_N + A.shard_world);
+    const int n0 = A.level_node_start[A.cut_level - 1];
+    for (int ci = T.tid; ci < A.n_cut; ci += T.nt) assemble_finish(Q, n0 + ci, A.xbuf + x_asm(A) + ci * ASM_N);
+    int bad = 0;
+    for (int w = 0; w < A.shard_world; ++w) bad |= (fl[w] != 0.0);
+    T.sync();
+    return bad;
+  }
   return T.flags[1];
 }
 
@@ -1811,6 +2220,7 @@ DOMPC_PHASE void refresh_mu(const Thr& T, const Prob& Q, double dmu) {
   const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   for (int e = gid; e < A.n_edges; e += ng) {
+    if (!mk_e(A, e)) continue;
     if (M > 0) {
       const int woff = A.edge_w_off[e];
       for (int r = lane; r < NW; r += GS) {
@@ -1844,6 +2254,7 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, double mu_c) {
   const KArgs& A = *Q.A;
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // e_d, e_p, e_c, sum|y|, sum z, obj, theta
   for (int g = T.tid; g < A.n_opt_x; g += T.nt) {
+    if (!sh_cnt(A, mk_x(A, g))) continue;
     v[0] = fmax(v[0], fabs(Q.rd[g]));
     const double l = Q.lb[g], u = Q.ub[g];
     if (l > -INFINITY) { v[2] = fmax(v[2], fabs((Q.x[g] - l) * Q.zl[g] - mu_c)); v[4] += Q.zl[g]; }
@@ -1851,6 +2262,7 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, double mu_c) {
   }
   for (int g = T.tid; g < A.n_edges * NE; g += T.nt) {
     const int e = g / NE1, i = g % NE1;
+    if (!sh_cnt(A, mk_e(A, e))) continue;
     const int si = e * NE1 + i;
     const double yd = Q.lam[A.edge_row0[e] + NW + NX + i];
     v[0] = fmax(v[0], fabs(-yd - Q.zsl[si] + Q.zsu[si]));
@@ -1859,12 +2271,15 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, double mu_c) {
     if (u < INFINITY) { v[2] = fmax(v[2], fabs((u - Q.s[si]) * Q.zsu[si] - mu_c)); v[4] += Q.zsu[si]; }
   }
   for (int r = T.tid; r < A.n_g; r += T.nt) {
+    if (!sh_cnt(A, mk_g(A, r))) continue;
     v[1] = fmax(v[1], fabs(Q.c[r]));
     v[3] += fabs(Q.lam[r]);
     v[6] += fabs(Q.c[r]);
   }
-  for (int e = T.tid; e < A.n_edges; e += T.nt) v[5] += Q.ES(e)[ES_OBJ];
-  for (int n = T.tid; n < A.n_nodes; n += T.nt) v[5] += node_rterm_f(Q, n, Q.x);
+  for (int e = T.tid; e < A.n_edges; e += T.nt)
+    if (sh_cnt(A, mk_e(A, e))) v[5] += Q.ES(e)[ES_OBJ];
+  for (int n = T.tid; n < A.n_nodes; n += T.nt)
+    if (sh_cnt(A, mk_n(A, n))) v[5] += node_rterm_f(Q, n, Q.x);
   const int ops[8] = {R_MAX, R_MAX, R_MAX, R_SUM, R_SUM, R_SUM, R_SUM, R_SUM};
   wg_reduce(T, v, ops);
   Errs E;
@@ -1895,7 +2310,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (hu) xv = fmin(xv, u - pu);
     Q.lb[g] = l; Q.ub[g] = u; Q.x[g] = xv;
     Q.zl[g] = hl ? 1.0 : 0.0; Q.zu[g] = hu ? 1.0 : 0.0;
-    cnt[0] += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
+    if (sh_cnt(A, mk_x(A, g))) cnt[0] += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
   }
   for (int r = T.tid; r < A.n_g; r += T.nt) Q.lam[r] = 0.0;
   T.sync();
@@ -1918,7 +2333,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         if (hu) sv = fmin(sv, u - pu);
         Q.s[si] = sv; Q.sl[si] = l; Q.su[si] = u;
         Q.zsl[si] = hl ? 1.0 : 0.0; Q.zsu[si] = hu ? 1.0 : 0.0;
-        cnt[1] += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
+        if (sh_cnt(A, mk_e(A, e))) cnt[1] += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
       }
     }
     T.sync();
@@ -1938,7 +2353,8 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   ++n_sweeps;
   if (O.obj_scaling) {
     double gm[1] = {0.0};
-    for (int g = T.tid; g < nX; g += T.nt) gm[0] = fmax(gm[0], fabs(Q.gf[g]));
+    for (int g = T.tid; g < nX; g += T.nt)
+      if (sh_cnt(A, mk_x(A, g))) gm[0] = fmax(gm[0], fabs(Q.gf[g]));
     const int ops[1] = {R_MAX};
     wg_reduce(T, gm, ops);
     if (gm[0] > O.nlp_scaling_max_gradient) {
@@ -1960,7 +2376,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
 
   while (true) {
     if (bad) { status = 3; break; }
-    if (T.nwg > 1 && T.flags[7]) { status = 5; break; }       // a peer workgroup never arrived at a barrier
+    if ((T.nwg > 1 || sh_on(A)) && T.flags[7]) { status = 5; break; }       // a peer workgroup never arrived at a barrier
     const double sd = fmax(s_max, (E.sum_y + E.sum_z) / fmax(1.0, n_dual)) / s_max;
     const double sc = fmax(s_max, E.sum_z / fmax(1.0, n_bounds)) / s_max;
     E0 = fmax(E.e_d / sd, fmax(E.e_p, E.e_c0 / sc));
@@ -2007,6 +2423,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     // ---- fraction to the boundary, directional derivative of the barrier function
     double r5[5] = {1.0, 1.0, 0.0, 0.0, 0.0};   // a_max, a_z, dphi, barrier-sum, (unused)
     for (int g = T.tid; g < nX; g += T.nt) {
+      if (!sh_cnt(A, mk_x(A, g))) continue;
       const double xv = Q.x[g], l = Q.lb[g], u = Q.ub[g], d = Q.dx[g];
       double gphi = Q.gf[g];
       if (l > -INFINITY) {
@@ -2024,6 +2441,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       r5[2] += gphi * d;
     }
     for (int g = T.tid; g < nSl; g += T.nt) {
+      if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
       const int si = (g / NE1) * NE1 + g % NE1;
       const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si], d = Q.ds[si];
       double gphi = 0.0;
@@ -2064,24 +2482,35 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     bool accepted = false, armijo_used = false;
     double th_t = 0.0, obj_t = 0.0;
     while (true) {
-      for (int g = T.tid; g < nX; g += T.nt) Q.xt[g] = Q.x[g] + alpha * Q.dx[g];
+      for (int g = T.tid; g < nX; g += T.nt)
+        if (mk_x(A, g)) Q.xt[g] = Q.x[g] + alpha * Q.dx[g];
       for (int g = T.tid; g < nSl; g += T.nt) {
+        if (!mk_e(A, g / NE1)) continue;
         const int si = (g / NE1) * NE1 + g % NE1;
         Q.st[si] = Q.s[si] + alpha * Q.ds[si];
       }
       T.sync();
       double r3[3] = {0.0, 0.0, 0.0};    // obj, theta, barrier
       for (int g = T.tid; g < NX; g += T.nt) Q.ct[g] = Q.xt[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
-      for (int e = T.tid; e < A.n_edges; e += T.nt) r3[0] += eval_edge_f(Q, e, Q.xt, Q.st, Q.ct);
-      for (int n = T.tid; n < A.n_nodes; n += T.nt) r3[0] += node_rterm_f(Q, n, Q.xt);
+      for (int e = T.tid; e < A.n_edges; e += T.nt) {
+        const int m = mk_e(A, e);
+        if (!m) continue;
+        const double fe = eval_edge_f(Q, e, Q.xt, Q.st, Q.ct);
+        if (sh_cnt(A, m)) r3[0] += fe;
+      }
+      for (int n = T.tid; n < A.n_nodes; n += T.nt)
+        if (sh_cnt(A, mk_n(A, n))) r3[0] += node_rterm_f(Q, n, Q.xt);
       T.sync();
-      for (int r = T.tid; r < A.n_g; r += T.nt) r3[1] += fabs(Q.ct[r]);
+      for (int r = T.tid; r < A.n_g; r += T.nt)
+        if (sh_cnt(A, mk_g(A, r))) r3[1] += fabs(Q.ct[r]);
       for (int g = T.tid; g < nX; g += T.nt) {
+        if (!sh_cnt(A, mk_x(A, g))) continue;
         const double l = Q.lb[g], u = Q.ub[g];
         if (l > -INFINITY) r3[2] -= log(Q.xt[g] - l);
         if (u < INFINITY) r3[2] -= log(u - Q.xt[g]);
       }
       for (int g = T.tid; g < nSl; g += T.nt) {
+        if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
         const int si = (g / NE1) * NE1 + g % NE1;
         if (Q.sl[si] > -INFINITY) r3[2] -= log(Q.st[si] - Q.sl[si]);
         if (Q.su[si] < INFINITY) r3[2] -= log(Q.su[si] - Q.st[si]);
@@ -2110,7 +2539,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         }
       }
       if (ok) { accepted = true; armijo_used = armijo_case; break; }
-      if (alpha * 0.5 < a_min) break;      // xt/st/ct stay at the last evaluated alpha
+      if (!(alpha * 0.5 >= a_min)) break;  // xt/st/ct stay at the last evaluated alpha (also leaves on a NaN step size)
       alpha *= 0.5;
     }
     if (!accepted) {
@@ -2130,6 +2559,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     // ---- accept the trial point
     const double ks = 1e10;
     for (int g = T.tid; g < nX; g += T.nt) {
+      if (!mk_x(A, g)) continue;
       const double xv = Q.xt[g];
       Q.x[g] = xv;
       const double l = Q.lb[g], u = Q.ub[g];
@@ -2145,6 +2575,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       }
     }
     for (int g = T.tid; g < nSl; g += T.nt) {
+      if (!mk_e(A, g / NE1)) continue;
       const int si = (g / NE1) * NE1 + g % NE1;
       const double sv = Q.st[si];
       Q.s[si] = sv;
@@ -2158,7 +2589,8 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         Q.zsu[si] = fmax(fmin(z, ks * mu / (u - sv)), mu / (ks * (u - sv)));
       }
     }
-    for (int r = T.tid; r < A.n_g; r += T.nt) Q.lam[r] += alpha * Q.dlam[r];
+    for (int r = T.tid; r < A.n_g; r += T.nt)
+      if (mk_g(A, r)) Q.lam[r] += alpha * Q.dlam[r];
     if (A.trace && b == 0 && T.tid == 0 && it < A.trace_cap) {
       double* tr = A.trace + 8 * it;
       tr[0] = it; tr[1] = mu; tr[2] = E0; tr[3] = E.e_p; tr[4] = E.e_d; tr[5] = accepted ? alpha : -alpha;
@@ -2174,15 +2606,17 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   // ---- outputs (unscaled multipliers, CasADi sign convention)
   if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = 0; tr[7] = 0; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; } }
   const double isf = 1.0 / Q.sf;
-  if (A.x_out) for (int g = T.tid; g < nX; g += T.nt) A.x_out[(int64_t)b * nX + g] = Q.x[g];
-  if (A.lam_x_out) for (int g = T.tid; g < nX; g += T.nt) A.lam_x_out[(int64_t)b * nX + g] = (Q.zu[g] - Q.zl[g]) * isf;
-  if (A.lam_g_out) for (int r = T.tid; r < A.n_g; r += T.nt) A.lam_g_out[(int64_t)b * A.n_g + r] = Q.lam[r] * isf;
+  // (sharded problem: every entry is written by exactly one rank, zeros elsewhere -> a SUM over the ranks is the full vector)
+  if (A.x_out) for (int g = T.tid; g < nX; g += T.nt) A.x_out[(int64_t)b * nX + g] = sh_cnt(A, mk_x(A, g)) ? Q.x[g] : 0.0;
+  if (A.lam_x_out) for (int g = T.tid; g < nX; g += T.nt) A.lam_x_out[(int64_t)b * nX + g] = sh_cnt(A, mk_x(A, g)) ? (Q.zu[g] - Q.zl[g]) * isf : 0.0;
+  if (A.lam_g_out) for (int r = T.tid; r < A.n_g; r += T.nt) A.lam_g_out[(int64_t)b * A.n_g + r] = sh_cnt(A, mk_g(A, r)) ? Q.lam[r] * isf : 0.0;
   if (A.g_out) {
     // g in the reference's convention: equality rows = residual (+rhs 0), nl rows = d(x)
-    for (int r = T.tid; r < A.n_g; r += T.nt) A.g_out[(int64_t)b * A.n_g + r] = Q.c[r];
+    for (int r = T.tid; r < A.n_g; r += T.nt) A.g_out[(int64_t)b * A.n_g + r] = sh_cnt(A, mk_g(A, r)) ? Q.c[r] : 0.0;
     T.sync();
     for (int g = T.tid; g < nSl; g += T.nt) {
       const int e = g / NE1, i = g % NE1;
+      if (!sh_cnt(A, mk_e(A, e))) continue;
       const int row = A.edge_row0[e] + NW + NX + i;
       A.g_out[(int64_t)b * A.n_g + row] = Q.c[row] + Q.s[e * NE1 + i];
     }

@@ -42,10 +42,17 @@ struct dompc_handle {
   double* s_trace = nullptr;
   int32_t trace_cap = 4096;
   int32_t cap_batch = 0;
+  // tree sharding
+  int64_t xlayout[4] = {0, 0, 0, 0};   // RED_MAX, ASM_N, CUT1, CUT2 of the code object
+  bool sharded = false, shard_capable = false;
+  dompc_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+  uint32_t* x_words = nullptr;           // pinned host memory: [req, ack, count, off] (device build)
 #ifndef DOMPC_HOST_EMU
   hipModule_t module = nullptr;
   hipFunction_t fn_solve = nullptr, fn_info = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t shard_stream = nullptr;    // lowest priority: never shares a hardware queue with the collective's kernels
 #endif
 };
 
@@ -137,6 +144,8 @@ extern "C" void dompc_destroy(dompc_handle* h) {
   for (void* p : h->dev_allocs) hipFree(p);
   if (h->module) hipModuleUnload(h->module);
   if (h->stream) hipStreamDestroy(h->stream);
+  if (h->x_words) hipHostFree(h->x_words);
+  if (h->shard_stream) hipStreamDestroy(h->shard_stream);
 #else
   for (void* p : h->dev_allocs) free(p);
 #endif
@@ -167,7 +176,7 @@ static int ensure_staging(dompc_handle* h, int B) {
 
 static void* own_stream(dompc_handle* h) {
 #ifndef DOMPC_HOST_EMU
-  return (void*)h->stream;
+  return (void*)((h->sharded && h->shard_stream) ? h->shard_stream : h->stream);
 #else
   (void)h;
   return nullptr;
@@ -221,7 +230,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   h->e_pad = ((d.n_edges + 15) / 16) * 16;
   // ---- model info from the code object
   int32_t in_h[5] = {d.n_opt_x, d.n_g, d.n_edges, h->e_pad, d.n_nodes};
-  int64_t info[12] = {0};
+  int64_t info[20] = {0};
   char hash[64] = {0};
 #ifndef DOMPC_HOST_EMU
   {
@@ -256,6 +265,8 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   }
   h->ws_stride = info[9];
   h->sweep_block = info[10];
+  for (int i = 0; i < 4; ++i) h->xlayout[i] = info[12 + i];
+  h->shard_capable = info[16] != 0;
   // ---- slots
   int max_batch = d.max_batch > 0 ? d.max_batch : 1;
   h->n_slots = d.n_slots > 0 ? d.n_slots : (max_batch < 512 ? max_batch : 512);
@@ -304,9 +315,15 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     A.chain_level = cl;
   }
   A.opt = d.opts;
+  if (const char* mi = getenv("DOMPC_MAX_ITER")) A.opt.max_iter = atoi(mi);      // debugging aid
   A.n_slots = h->n_slots;
   A.ws_stride = h->ws_stride;
   if (dev_alloc(h, (void**)&A.ws, sizeof(double) * (size_t)h->ws_stride * h->n_slots)) return fail(1);
+#ifndef DOMPC_HOST_EMU
+  if (const char* fill = getenv("DOMPC_WS_FILL")) {      // debugging aid: poison the workspace (uninitialised reads)
+    if (hipMemset(A.ws, atoi(fill), sizeof(double) * (size_t)h->ws_stride * h->n_slots) != hipSuccess) { h->error = "hipMemset failed"; return fail(1); }
+  }
+#endif
   if (dev_alloc(h, (void**)&A.work_counter, 64)) return fail(1);
   // wide mode (small batches): up to 64 slots x 32 workgroups
   if (dev_alloc(h, (void**)&A.wide_bar, sizeof(uint32_t) * 16 * 64)) return fail(1);
@@ -327,6 +344,94 @@ extern "C" int64_t dompc_workspace_bytes(const dompc_handle* h) { return h ? (in
 extern "C" int32_t dompc_num_slots(const dompc_handle* h) { return h ? h->n_slots : 0; }
 extern "C" int64_t dompc_sweep_block_doubles(const dompc_handle* h) { return h ? h->sweep_block : 0; }
 
+extern "C" int64_t dompc_exchange_doubles(const dompc_handle* h, int32_t world, int32_t n_cut) {
+  if (!h || world < 1 || n_cut < 0) return 0;
+  const int64_t* L = h->xlayout;
+  return (int64_t)world * L[0] + (int64_t)n_cut * (L[1] + L[2] + L[3]) + 2 * (int64_t)world;
+}
+
+extern "C" int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* s) {
+  if (!h) return 1;
+  dompc::KArgs& A = h->base;
+  if (!s) {
+    A.x_mask = A.g_mask = A.e_mask = A.n_mask = nullptr; A.node_cut = nullptr;
+    A.n_cut = 0; A.cut_level = 0; A.shard_rank = 0; A.shard_world = 1; A.xbuf = nullptr; A.xbuf_len = 0;
+    A.x_callback = nullptr; A.x_ctx = nullptr;
+    h->sharded = false;
+    return 0;
+  }
+  const dompc_problem_desc& d = h->d;
+  if (!h->shard_capable) { h->error = "this code object was built without tree-sharding support (-DDOMPC_SHARD=1)"; return 1; }
+  if (s->world < 1 || s->rank < 0 || s->rank >= s->world || s->cut_level < 1 || s->n_cut < 1) { h->error = "invalid shard description"; return 1; }
+  if (!s->x_mask || !s->g_mask || !s->edge_mask || !s->node_mask || !s->node_cut || !s->xbuf || !s->allreduce) { h->error = "null pointer in shard description"; return 1; }
+#ifndef DOMPC_HOST_EMU
+  HIPCHK(h, hipSetDevice(d.device));
+#endif
+  int rc = 0;
+  rc |= upload(h, &A.x_mask, s->x_mask, d.n_opt_x);
+  rc |= upload(h, &A.g_mask, s->g_mask, d.n_g);
+  rc |= upload(h, &A.e_mask, s->edge_mask, d.n_edges);
+  rc |= upload(h, &A.n_mask, s->node_mask, d.n_nodes);
+  rc |= upload(h, &A.node_cut, s->node_cut, d.n_nodes);
+  if (rc) return 1;
+  A.n_cut = s->n_cut; A.cut_level = s->cut_level; A.shard_rank = s->rank; A.shard_world = s->world;
+  A.xbuf = s->xbuf; A.xbuf_len = (int32_t)dompc_exchange_doubles(h, s->world, s->n_cut);
+  h->allreduce = s->allreduce; h->allreduce_ctx = s->ctx;
+#ifndef DOMPC_HOST_EMU
+  if (!h->x_words) {
+    HIPCHK(h, hipHostMalloc((void**)&h->x_words, 64, hipHostMallocMapped));
+    memset(h->x_words, 0, 64);
+  }
+  if (!h->shard_stream) {
+    // The resident solver kernel of a sharded solve waits for collectives (RCCL kernels on the caller's streams).
+    // Streams of different priorities never share a hardware queue, so it runs on its own lowest-priority stream
+    // and the collective is never queued behind the kernel that is waiting for it.
+    int least = 0, greatest = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(h, hipStreamCreateWithPriority(&h->shard_stream, hipStreamNonBlocking, least));
+  }
+  void* dw = nullptr;
+  HIPCHK(h, hipHostGetDevicePointer(&dw, h->x_words, 0));
+  A.x_req = (volatile uint32_t*)dw; A.x_ack = (volatile uint32_t*)dw + 1; A.x_count = (volatile uint32_t*)dw + 2;
+  A.x_callback = nullptr; A.x_ctx = nullptr;
+#else
+  A.x_callback = s->allreduce; A.x_ctx = s->ctx;
+#endif
+  if (dev_sync(h)) return 1;
+  h->sharded = true;
+  return 0;
+}
+
+#ifndef DOMPC_HOST_EMU
+// Host side of the exchange handshake (Thr::xchg): serve the kernel's requests until it has finished.
+static int serve_exchanges(dompc_handle* h, hipStream_t st) {
+  hipEvent_t done;
+  HIPCHK(h, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  HIPCHK(h, hipEventRecord(done, st));
+  volatile uint32_t* w = h->x_words;
+  uint32_t served = 0;
+  int rc = 0;
+  while (true) {
+    const uint32_t r = w[0];
+    if (r != served) {
+      __sync_synchronize();
+      const uint32_t count = w[2], off = w[3];
+      if ((int64_t)off + count > h->base.xbuf_len) { h->error = "exchange request outside the buffer"; rc = 1; w[1] = r; served = r; continue; }
+      h->allreduce(h->allreduce_ctx, h->base.xbuf + off, (int32_t)count);
+      served = r;
+      __sync_synchronize();
+      w[1] = r;
+    } else {
+      const hipError_t q = hipEventQuery(done);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) { h->error = std::string("sharded solve: ") + hipGetErrorString(q); rc = 1; break; }
+    }
+  }
+  hipEventDestroy(done);
+  return rc;
+}
+#endif
+
 extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double* x0, const double* lbx, const double* ubx,
                                         const double* lbg, const double* ubg, const double* p, double* x, double* g,
                                         double* lam_x, double* lam_g, double* f, dompc_stats* stats, void* stream) {
@@ -342,6 +447,13 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   A.batch = B; A.mode = 0;
   int grid = B < h->n_slots ? B : h->n_slots;
   A.wide = 1;
+  if (h->sharded) {
+    if (B != 1) { h->error = "a sharded handle solves one problem per call"; return 1; }
+#ifndef DOMPC_HOST_EMU
+    if (!stream) { h->error = "sharded solve needs a non-blocking stream (not the default stream)"; return 1; }
+    h->x_words[0] = h->x_words[1] = h->x_words[2] = h->x_words[3] = 0;
+#endif
+  }
 #ifndef DOMPC_HOST_EMU
   // small batches: several workgroups per problem so that one make_step can use many CUs
   const char* wenv = getenv("DOMPC_WIDE");
@@ -357,7 +469,11 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
     HIPCHK(h, hipMemsetAsync(A.wide_flags, 0, sizeof(int32_t) * 8 * 64, st));
   }
 #endif
-  return launch(h, A, grid, stream);
+  if (launch(h, A, grid, stream)) return 1;
+#ifndef DOMPC_HOST_EMU
+  if (h->sharded) return serve_exchanges(h, (hipStream_t)stream);
+#endif
+  return 0;
 }
 
 extern "C" int dompc_solve_batch(dompc_handle* h, int32_t B, const double* x0, const double* lbx, const double* ubx,
@@ -380,6 +496,7 @@ extern "C" int dompc_solve_batch(dompc_handle* h, int32_t B, const double* x0, c
   rc |= h2d(h, h->s_lbg, lbg, sizeof(double) * d.n_g);
   rc |= h2d(h, h->s_ubg, ubg, sizeof(double) * d.n_g);
   if (rc) return 1;
+  if (h->sharded && dev_sync(h)) return 1;      // the sharded solve runs on its own stream: inputs must have landed
   if (dompc_solve_batch_device(h, B, h->s_x0, h->s_lbx, h->s_ubx, h->s_lbg, h->s_ubg, h->s_p, h->s_x, h->s_g, h->s_lamx,
                                h->s_lamg, h->s_f, h->s_stats, own_stream(h)))
     return 1;

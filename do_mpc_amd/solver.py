@@ -49,6 +49,16 @@ class Stats(C.Structure):
                [(n, C.c_double) for n in ("mu", "obj", "inf_pr", "inf_du", "inf_compl", "obj_scaling", "t_wall_total")]
 
 
+_ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int32)
+
+
+class ShardDesc(C.Structure):
+    """dompc_shard_desc (include/dompc_ipm.h)"""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("cut_level", C.c_int32), ("n_cut", C.c_int32),
+                ("x_mask", C.c_void_p), ("g_mask", C.c_void_p), ("edge_mask", C.c_void_p), ("node_mask", C.c_void_p),
+                ("node_cut", C.c_void_p), ("xbuf", C.c_void_p), ("allreduce", _ALLREDUCE_FN), ("ctx", C.c_void_p)]
+
+
 STATS_DTYPE = np.dtype([("success", "i4"), ("status", "i4"), ("iter_count", "i4"), ("n_reg", "i4"),
                         ("n_ls_fail", "i4"), ("n_sweeps", "i4"), ("n_trials", "i4"), ("reserved", "i4"), ("mu", "f8"), ("obj", "f8"), ("inf_pr", "f8"),
                         ("inf_du", "f8"), ("inf_compl", "f8"), ("obj_scaling", "f8"), ("t_wall_total", "f8")])
@@ -97,6 +107,10 @@ def _load(lib_path: str) -> C.CDLL:
     lib.dompc_workspace_bytes.restype = C.c_int64
     lib.dompc_num_slots.argtypes = [vp]
     lib.dompc_num_slots.restype = C.c_int32
+    lib.dompc_exchange_doubles.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.dompc_exchange_doubles.restype = C.c_int64
+    lib.dompc_set_sharding.argtypes = [vp, C.POINTER(ShardDesc)]
+    lib.dompc_set_sharding.restype = C.c_int
     return lib
 
 
@@ -120,12 +134,23 @@ class HipIpmSolver:
 
     def __init__(self, structure: ProblemStructure, header_text: str, model_hash: str,
                  nlpsol_opts: Optional[dict] = None, device: int = 0, max_batch: int = 1, n_slots: int = 0,
-                 block_threads: int = 0, _lib_path: Optional[str] = None, _code_object: Optional[str] = None):
+                 block_threads: int = 0, shard: bool = False, _lib_path: Optional[str] = None,
+                 _code_object: Optional[str] = None):
         self.structure = ps = structure
         self.model_hash = model_hash
+        self._ctor = dict(structure=structure, header_text=header_text, model_hash=model_hash, nlpsol_opts=nlpsol_opts,
+                          device=device, max_batch=max_batch, n_slots=n_slots, block_threads=block_threads)
+        self.shard_capable = bool(shard) or _code_object == ""
         if _lib_path is None:
+            import os
+            if not os.environ.get("DOMPC_NO_TORCH_FIRST"):
+                try:                      # torch ships its own HIP runtime: it has to be the first one in the process
+                    import torch          # noqa: F401
+                    torch.cuda.is_available()
+                except ImportError:
+                    pass
             _lib_path = build.runtime_library()
-            _code_object = build.model_code_object(header_text, model_hash)
+            _code_object = build.model_code_object(header_text, model_hash, shard=bool(shard))
         self._lib = _load(_lib_path)
         self._keep = []
         d = ProblemDesc()
@@ -163,6 +188,9 @@ class HipIpmSolver:
             raise RuntimeError("dompc_create failed: " + (self._lib.dompc_last_error(None) or b"?").decode())
         self._h = h
         self._stats: Dict = {}
+        self._device = device
+        self._host_emulation = _code_object == ""
+        self._shard = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -193,7 +221,75 @@ class HipIpmSolver:
         self._check(self._lib.dompc_solve(self._h, _ptr(x0), _ptr(lbx), _ptr(ubx), _ptr(lbg), _ptr(ubg), _ptr(p),
                                           None, None, _ptr(x), _ptr(g), _ptr(lam_x), _ptr(lam_g), _ptr(f), _ptr(st)))
         self._stats = self._stats_dict(st[0])
+        if self._shard is not None:
+            # every entry was written by exactly one rank (zeros elsewhere): the sum is the full vector
+            x, g, lam_x, lam_g = (self._sum_over_ranks(a) for a in (x, g, lam_x, lam_g))
         return {"x": x, "f": float(f[0]), "g": g, "lam_x": lam_x, "lam_g": lam_g, "lam_p": np.zeros(ps.n_opt_p)}
+
+    # ------------------------------------------------------------------ tree sharding over ranks
+    def enable_sharding(self, rank: int, world: int, cut_level: Optional[int] = None, group=None, allreduce=None) -> dict:
+        """Shard the scenario tree of this handle's problem over `world` ranks (one process per GPU).
+
+        The sub-trees below the cut go to the ranks in contiguous blocks, the stages above are replicated; during a
+        solve the kernel asks the host for element-wise SUMs over a small exchange buffer (cut-edge contributions
+        of the Riccati recursion, scalar reductions of the IPM).  The collective is `torch.distributed.all_reduce`
+        on `group` (backend nccl = RCCL on the GPU, gloo in the CPU tests) unless `allreduce(view)` is given.
+        Every rank must call the solver with identical inputs."""
+        from .structure import shard_tables
+        if not self.shard_capable:
+            raise RuntimeError("this solver was built without tree-sharding support: construct it with shard=True "
+                               "(MPC.shard_tree does that)")
+        t = shard_tables(self.structure, rank, world, cut_level)
+        if t["cut_level"] < 1:
+            raise ValueError("sharding needs a cut level >= 1 (a tree with n_robust >= 1)")
+        n = int(self._lib.dompc_exchange_doubles(self._h, world, t["n_cut"]))
+        import torch
+        if self._host_emulation:
+            xbuf = torch.zeros(n, dtype=torch.float64)
+            stream = None
+        else:
+            xbuf = torch.zeros(n, dtype=torch.float64, device=torch.device("cuda", self._device))
+            stream = torch.cuda.Stream(device=self._device)          # never the default stream: the solver kernel is resident
+        base = xbuf.data_ptr()
+
+        def reduce_view(view):
+            if allreduce is not None:
+                allreduce(view)
+                return
+            import torch.distributed as dist
+            if stream is None:
+                dist.all_reduce(view, group=group)
+            else:
+                with torch.cuda.stream(stream):
+                    dist.all_reduce(view, group=group)
+                stream.synchronize()
+
+        def callback(_ctx, buf, count):
+            off = (int(buf) - base) // 8
+            reduce_view(xbuf[off:off + int(count)])
+
+        cb = _ALLREDUCE_FN(callback)
+        arrays = {k: np.ascontiguousarray(t[k]) for k in ("x_mask", "g_mask", "edge_mask", "node_mask", "node_cut")}
+        d = ShardDesc(rank=rank, world=world, cut_level=t["cut_level"], n_cut=t["n_cut"], xbuf=base, allreduce=cb, ctx=None,
+                      **{k: v.ctypes.data for k, v in arrays.items()})
+        self._check(self._lib.dompc_set_sharding(self._h, C.byref(d)))
+        self._shard = {"tables": t, "xbuf": xbuf, "callback": cb, "reduce": reduce_view, "stream": stream, "arrays": arrays}
+        reduce_view(xbuf[:1])                                          # communicator warm-up outside the solve
+        return t
+
+    def disable_sharding(self):
+        self._check(self._lib.dompc_set_sharding(self._h, None))
+        self._shard = None
+
+    def _sum_over_ranks(self, a: np.ndarray) -> np.ndarray:
+        import torch
+        if self._host_emulation:
+            v = torch.from_numpy(np.ascontiguousarray(a))
+            self._shard["reduce"](v)
+            return v.numpy()
+        v = torch.from_numpy(np.ascontiguousarray(a)).to(self._shard["xbuf"].device)
+        self._shard["reduce"](v)
+        return v.cpu().numpy()
 
     def _stats_dict(self, s) -> dict:
         status = self._lib.dompc_status_string(int(s["status"])).decode()

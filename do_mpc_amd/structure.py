@@ -245,3 +245,66 @@ def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust,
         "parent_scenario": parent_scenario, "branch_offset": branch_offset, "child_scenario": child_scenario,
     }
     return ps
+
+
+def shard_tables(ps: ProblemStructure, rank: int = 0, world: int = 1, cut_level: int = None) -> dict:
+    """Ownership tables for sharding the scenario tree of ONE problem over `world` ranks.
+
+    The tree is cut above level `cut_level` (default: the first level with at least `world` nodes, at most
+    n_robust): the sub-trees rooted at the level-`cut_level` nodes go to the ranks in contiguous blocks (siblings
+    stay together), everything above is replicated on every rank.  An edge and its collocation unknowns belong to
+    its child node, so the only quantities that cross ranks are (a) the condensed contributions of the cut edges
+    to their parents (`cut parents`, level cut_level-1) in the Riccati recursion and (b) scalar reductions.
+
+    masks: 0 = another rank's, 1 = mine, 2 = replicated (identical on every rank; counted once, by rank 0).
+    cut_level 0 means "no cut" (everything mine)."""
+    T = ps.tables
+    n_scen = ps.scenario_tree["n_scenarios"]
+    N = ps.N
+    n_nodes, n_edges = ps.n_nodes, ps.n_edges
+    if cut_level is None:
+        cut_level = 0
+        if world > 1:
+            cut_level = next((k for k in range(1, ps.n_robust + 1) if n_scen[k] >= world), ps.n_robust)
+            if cut_level == 0:
+                raise ValueError("a tree without branching (n_robust = 0) cannot be sharded")
+    if not (0 <= cut_level <= max(ps.n_robust, 0)):
+        raise ValueError(f"cut_level {cut_level} outside 0..n_robust={ps.n_robust}")
+    if world > 1 and cut_level == 0:
+        raise ValueError("world > 1 needs a cut level >= 1")
+    c = cut_level
+    node_mask = np.ones(n_nodes, np.int8)
+    node_cut = -np.ones(n_nodes, np.int32)
+    n_cut = 0
+    if c > 0:
+        n_roots = n_scen[c]
+        for n in range(n_nodes):
+            k = int(T["node_level"][n])
+            s = n - int(T["level_node_start"][k])
+            if k < c:
+                node_mask[n] = 2
+                if k == c - 1:
+                    node_cut[n] = s
+            else:
+                anc = s // (n_scen[k] // n_roots)
+                node_mask[n] = 1 if (anc * world) // n_roots == rank else 0
+        n_cut = n_scen[c - 1]
+    edge_mask = node_mask[T["edge_child"]].astype(np.int8) if n_edges else np.zeros(0, np.int8)
+    x_mask = np.full(ps.n_opt_x, 2 if c > 0 else 1, np.int8)
+    nx, nu, ns, M = ps.nx, ps.nu, ps.ns, ps.M
+    for n in range(n_nodes):
+        m = node_mask[n]
+        x_mask[T["node_x_off"][n]:T["node_x_off"][n] + nx] = m
+        if T["node_u_off"][n] >= 0:
+            x_mask[T["node_u_off"][n]:T["node_u_off"][n] + nu] = m
+        if T["node_eps_off"][n] >= 0:
+            x_mask[T["node_eps_off"][n]:T["node_eps_off"][n] + ns] = m
+    rpe = ps.rows_per_edge
+    g_mask = np.full(ps.n_g, 2 if c > 0 else 1, np.int8)
+    for e in range(n_edges):
+        w = int(T["edge_w_off"][e])
+        x_mask[w:w + M * nx] = edge_mask[e]
+        r0 = int(T["edge_row0"][e])
+        g_mask[r0:r0 + rpe] = edge_mask[e]
+    return dict(cut_level=c, n_cut=int(n_cut), rank=int(rank), world=int(world), node_mask=node_mask, edge_mask=edge_mask,
+                node_cut=node_cut, x_mask=x_mask, g_mask=g_mask)

@@ -168,6 +168,35 @@ int dompc_debug_get_trace(dompc_handle* h, double* out, int32_t max_rows);
 int64_t dompc_workspace_bytes(const dompc_handle* h);
 int32_t dompc_num_slots(const dompc_handle* h);
 
+/* ---- tree sharding of ONE problem over several ranks / GPUs --------------------
+ * Replaces nothing in the reference (IPOPT/MUMPS is single-process); it is the multi-GPU path the
+ * north star asks for: the sub-trees below `cut_level` of the scenario tree built by
+ * do_mpc/optimizer.py:998-1048 (_setup_scenario_tree) go to the ranks in contiguous blocks, the stages
+ * above are replicated, and the ranks exchange (a) the condensed contributions of the cut edges to
+ * their parent nodes in the Riccati recursion and (b) the scalar reductions of the IPM (norms, step
+ * sizes, filter quantities) - all as element-wise SUMs over a small exchange buffer.
+ * The collective itself is supplied by the caller (RCCL all-reduce through torch.distributed in
+ * do_mpc_amd/solver.py): `allreduce(ctx, buf, count)` must return when buf[0..count) holds the sum
+ * over all ranks.  While a sharded solve runs the library serves the kernel's exchange requests from
+ * the calling thread, so dompc_solve* returns only when the solve is finished.
+ * Masks (host arrays, copied): 0 = another rank's, 1 = mine, 2 = replicated on every rank. */
+typedef void (*dompc_allreduce_fn)(void* ctx, double* buf, int32_t count);
+typedef struct dompc_shard_desc {
+  int32_t rank, world, cut_level, n_cut;
+  const int8_t* x_mask;      /* n_opt_x */
+  const int8_t* g_mask;      /* n_g */
+  const int8_t* edge_mask;   /* n_edges */
+  const int8_t* node_mask;   /* n_nodes */
+  const int32_t* node_cut;   /* n_nodes: index of a cut parent among the cut parents, else -1 */
+  double* xbuf;              /* exchange buffer, dompc_exchange_doubles() doubles, DEVICE memory owned by the caller */
+  dompc_allreduce_fn allreduce;
+  void* ctx;
+} dompc_shard_desc;
+/* doubles the exchange buffer needs for (world, n_cut) */
+int64_t dompc_exchange_doubles(const dompc_handle* h, int32_t world, int32_t n_cut);
+/* desc == NULL switches sharding off again */
+int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* desc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+"""Tree sharding of ONE problem over several ranks: the sub-trees below the cut of the
+scenario tree go to the ranks, the stages above are replicated, and the ranks exchange cut-edge
+contributions of the Riccati recursion plus the scalar reductions of the IPM as element-wise SUMs.
+
+CPU coverage of the multi-rank path: the kernel text runs in the host emulation (tests/hostemu.py),
+the collective is torch.distributed all_reduce on a gloo group with world_size 2 and 3.  The sharded
+solves must reproduce the single-rank solve of the same problem."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import hostemu
+from do_mpc_amd.examples import CASES
+from do_mpc_amd.structure import build_structure, shard_tables
+
+PAIRED = {"n_robust": 2, "uncertainty": "paired"}
+
+
+def test_masks_partition_variables_rows_and_edges():
+    ps = build_structure(nx=10, nu=3, nz=0, np_=2, ntvp=0, ne=1, ns=1, deg=2, ni=1, N=20, n_comb=3, n_robust=3, discrete=False)
+    for world in (2, 4, 8):
+        own_x = np.zeros(ps.n_opt_x, int)
+        own_g = np.zeros(ps.n_g, int)
+        own_e = np.zeros(ps.n_edges, int)
+        for r in range(world):
+            t = shard_tables(ps, r, world)
+            own_x += t["x_mask"] == 1
+            own_g += t["g_mask"] == 1
+            own_e += t["edge_mask"] == 1
+            rep = (t["x_mask"] == 2, t["g_mask"] == 2, t["edge_mask"] == 2)
+            assert t["n_cut"] == ps.scenario_tree["n_scenarios"][t["cut_level"] - 1]
+            assert ps.scenario_tree["n_scenarios"][t["cut_level"]] >= world
+            # a cut parent is replicated and all its children are sub-tree roots
+            for n in np.where(t["node_cut"] >= 0)[0]:
+                assert t["node_mask"][n] == 2
+                cs, cc = ps.tables["node_child_start"][n], ps.tables["node_child_count"][n]
+                assert all(t["node_mask"][ps.tables["edge_child"][cs + j]] in (0, 1) for j in range(cc))
+        assert np.all(own_x + rep[0] == 1) and np.all(own_g + rep[1] == 1) and np.all(own_e + rep[2] == 1)
+
+
+def _solve(name, kw, shard=None):
+    ex = CASES[name]
+    with hostemu.patched():
+        mpc = ex.build_mpc(ex.build_model(), **kw)
+        mpc.x0 = ex.X0
+        mpc.set_initial_guess()
+        info = mpc.shard_tree(**shard) if shard else None
+        u0 = mpc.make_step(ex.X0).ravel().copy()
+        return (u0, mpc.opt_x_num.master.copy(), np.array(mpc.lam_g_num).copy(), dict(mpc.solver_stats), info,
+                mpc.structure.tables["dummy_idx"])
+
+
+@pytest.mark.parametrize("name,kw,cut", [("CSTR", {}, 1), ("industrial_poly", PAIRED, 1), ("industrial_poly", PAIRED, 2)])
+def test_forced_cut_on_one_rank_is_the_unsharded_solve(name, kw, cut):
+    """world = 1 with a cut: every exchange is the identity, the cut-parent code path must give the same iterates."""
+    u_ref, x_ref, lg_ref, st_ref, _, dummy = _solve(name, kw)
+    calls = []
+    u, x, lg, st, info, _ = _solve(name, kw, dict(rank=0, world=1, cut_level=cut, allreduce=lambda v: calls.append(v.numel())))
+    assert info["cut_level"] == cut and len(calls) > st["iter_count"]
+    assert st["success"] and st["iter_count"] == st_ref["iter_count"]
+    keep = np.ones(x.size, bool)
+    keep[dummy] = False                                    # variables in no row / cost term: not determined
+    assert np.allclose(u, u_ref, rtol=1e-10, atol=0)
+    assert np.allclose(x[keep], x_ref[keep], rtol=1e-8, atol=1e-10)
+    assert np.allclose(lg, lg_ref, rtol=1e-7, atol=1e-8)          # (several cut parents: the sums are formed in another order)
+
+
+def _worker(rank, world, port, name, kw, cut, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        u, x, lg, st, info, dummy = _solve(name, kw, dict(rank=rank, world=world, cut_level=cut))
+        q.put((rank, u, x, lg, st["iter_count"], st["success"], int((info["edge_mask"] == 1).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,kw,world,cut", [("CSTR", {}, 2, None), ("industrial_poly", PAIRED, 2, None),
+                                               ("industrial_poly", PAIRED, 3, 2)])
+def test_gloo_ranks_reproduce_the_single_rank_solve(name, kw, world, cut):
+    u_ref, x_ref, lg_ref, st_ref, _, dummy = _solve(name, kw)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, kw, cut, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    keep = np.ones(x_ref.size, bool)
+    keep[dummy] = False
+    assert sum(r[6] for r in res) > 0 and all(r[6] > 0 for r in res)          # every rank owns edges
+    for rank, u, x, lg, iters, ok, _ in res:
+        assert ok and abs(iters - st_ref["iter_count"]) <= 2
+        assert np.allclose(u, u_ref, rtol=1e-7, atol=0), (rank, u, u_ref)
+        assert np.allclose(x[keep], x_ref[keep], rtol=1e-6, atol=1e-8)
+        assert np.allclose(lg, lg_ref, rtol=1e-5, atol=1e-7)
+    # all ranks hold the same combined solution
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2][keep], res[0][2][keep])
