@@ -10,6 +10,11 @@ kernel with every input already resident in HBM.  value = B * steps * n_gpus / t
 Multi-GPU: the x0 batch shards across ranks with no data-path collective (weak scaling:
 B problems per GPU); the only collectives are the timing barrier and the max-over-ranks reduce.
 
+`--variant tree`: ONE industrial_poly problem with a 3^n_robust-leaf scenario tree (default n_robust=5: the
+243-leaf tree of BASELINE.json configs[4]) whose sub-trees are sharded over the ranks (strong scaling): the ranks
+exchange cut-edge contributions of the Riccati recursion and the scalar reductions of the IPM through RCCL
+all-reduces (torch.distributed, backend nccl) - SURVEY.md 8(e).  value = MPC steps/s of that single problem.
+
 Extra fields: `roofline` for the dominant kernel (dompc_solve_kernel; HBM-bound model:
 algorithmic bytes of the derivative sweeps it executed / its HIP-event duration) and
 `cpu_baseline` (the CPU oracle, a port of the reference algorithm, timed on a bounded sample).
@@ -89,8 +94,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DOMPC_BENCH_BATCH", "1024")),
                     help="problems per GPU per step")
-    ap.add_argument("--variant", default="A", choices=["A", "B"],
-                    help="A: shipped 9x1 tree (golden-pinned); B: 3 combinations, n_robust=2")
+    ap.add_argument("--variant", default="A", choices=["A", "B", "tree"],
+                    help="A: shipped 9x1 tree (golden-pinned); B: 3 combinations, n_robust=2; "
+                         "tree: one 3^n_robust-leaf problem sharded over the ranks (strong scaling)")
+    ap.add_argument("--n-robust", type=int, default=5, help="--variant tree: depth of the branching part (3^n leaves)")
+    ap.add_argument("--cut-level", type=int, default=0, help="--variant tree: level whose nodes are the sub-tree roots (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,6 +117,8 @@ def main():
 
     from do_mpc_amd.examples import industrial_poly as ex
     from do_mpc_amd.solver import STATS_DTYPE
+    if args.variant == "tree":
+        return bench_tree(args, ex, rank, world, local_rank, dist)
     kw = {} if args.variant == "A" else {"n_robust": 2, "uncertainty": "paired"}
     B = args.batch
     mpc = ex.build_mpc(ex.build_model(), gpu_index=local_rank, max_batch=B, **kw)
@@ -204,6 +214,63 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_tree(args, ex, rank, world, local_rank, dist):
+    """Strong scaling of ONE problem: the scenario tree sharded over the ranks."""
+    import torch
+    if dist is None and world == 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    mpc = ex.build_mpc(ex.build_model(), gpu_index=local_rank, n_robust=args.n_robust, uncertainty="paired")
+    ps = mpc.structure
+    n_scen = ps.scenario_tree["n_scenarios"]
+    # cut where there are at least 3 sub-trees per rank (balance: 27 sub-trees over 8 ranks = 4/3 per rank)
+    cut = args.cut_level or next((k for k in range(1, ps.n_robust + 1) if n_scen[k] >= 3 * world), ps.n_robust)
+    info = mpc.shard_tree(rank, world, cut_level=cut)
+    t_step = []
+    iters = []
+    ok = True
+    for k in range(args.warmup + args.steps):
+        mpc.x0 = ex.X0
+        mpc.u0 = np.zeros(ps.nu)
+        mpc._t0 = mpc._t0 * 0
+        mpc.set_initial_guess()                     # every step is a cold start of the same problem
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        u0 = mpc.make_step(ex.X0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        if k >= args.warmup:
+            t_step.append(dt)
+            iters.append(mpc.solver_stats["iter_count"])
+            ok = ok and bool(mpc.solver_stats["success"])
+    t = torch.tensor([sum(t_step)], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        sweep_b = sweep_bytes_per_problem(ps)
+        n_sweeps = float(np.mean(iters)) + 1.0
+        achieved = n_sweeps * sweep_b * args.steps / dt / 1e9
+        print(json.dumps({
+            "metric": "MPC steps/sec (make_step wall-time), industrial_poly robust multi-stage", "value": args.steps / dt,
+            "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"industrial_poly robust multi-stage NMPC, ONE problem, {ps.S}-leaf scenario tree "
+                                   f"(3 combos x n_robust={args.n_robust}, N=20, Radau deg 2), tree sharded over the ranks",
+                       "n_opt_x": ps.n_opt_x, "n_g": ps.n_g, "edges": ps.n_edges, "cut_level": info["cut_level"],
+                       "cut_parents": info["n_cut"], "start": "cold", "parallelism": f"scenario sub-trees x{world}, RCCL all-reduce"},
+            "solve": {"converged": bool(ok), "iters_mean": float(np.mean(iters)), "u0": [float(v) for v in np.ravel(u0)]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None, "kernel": "dompc_solve_kernel",
+                         "kernel_ms": dt / args.steps * 1e3, "sweep_bytes_per_problem": sweep_b,
+                         "note": "host wall time of make_step (includes the exchange handshakes), not a kernel-only time"},
+            "cpu_baseline": None}), flush=True)
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":
