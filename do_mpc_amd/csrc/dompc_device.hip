@@ -9,6 +9,7 @@
 #define DOMPC_DEV __device__
 #define DOMPC_HD __host__ __device__
 #else
+#include <stdlib.h>
 #define DOMPC_FN static inline
 #define DOMPC_CONST static const
 #define DOMPC_DEV
@@ -105,6 +106,12 @@ extern "C" void dompc_hostemu_run(const dompc::KArgs* A) {
   static thread_local double filt[2 * dompc::MAX_FILTER];
   static thread_local int flags[8];
   static thread_local double edge_lds[dompc::EL_SIZE];
+  if (const char* poison = getenv("DOMPC_EMU_POISON")) {     // test aid: undefined "LDS" contents (read-before-write hunts)
+    const double v = atof(poison);
+    for (int i = 0; i < dompc::EL_SIZE; ++i) edge_lds[i] = v;
+    for (int i = 0; i < dompc::RED_MAX; ++i) red[i] = v;
+    for (int i = 0; i < 2 * dompc::MAX_FILTER; ++i) filt[i] = v;
+  }
   dompc::Thr T{0, 1, red, filt, flags, edge_lds, nullptr, 1, 0, 1, 0, 1, nullptr, nullptr, 0u, 0u, dompc::make_xctx(*A), 0u};
   if (A->mode == 1) { dompc::debug_newton(T, *A); return; }
   for (int b = 0; b < A->batch; ++b) {
