@@ -55,7 +55,7 @@ def runtime_library(force: bool = False) -> str:
     if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
         return out
     cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
-           os.path.join(CSRC, "dompc_runtime.cpp"), "-o", out]
+           os.path.join(CSRC, "dompc_runtime.cpp"), "-o", out, "-ldl"]
     _run(cmd, "building libdompc_ipm.so")
     with open(stamp, "w") as f:
         f.write(dig)

@@ -497,7 +497,7 @@ class MPC:
         self.opt_x_num["_z"] = self._z0.master / self._z_scaling.master
         self.flags["set_initial_guess"] = True
 
-    def shard_tree(self, rank: int, world: int, cut_level=None, group=None, allreduce=None) -> dict:
+    def shard_tree(self, rank: int, world: int, cut_level=None, group=None, allreduce=None, native_rccl: bool = True) -> dict:
         """Shard the scenario tree of this controller's NLP over `world` ranks (one process per GPU):
         every rank builds the same MPC, calls shard_tree(rank, world) once after setup() and then make_step(x0) with
         identical x0; the ranks meet in torch.distributed all-reduces (backend nccl = RCCL) during the solve."""
@@ -507,7 +507,8 @@ class MPC:
             ctor = dict(self.S._ctor)
             self.S.close()
             self.S = HipIpmSolver(ctor.pop("structure"), ctor.pop("header_text"), ctor.pop("model_hash"), shard=True, **ctor)
-        return self.S.enable_sharding(rank, world, cut_level=cut_level, group=group, allreduce=allreduce)
+        return self.S.enable_sharding(rank, world, cut_level=cut_level, group=group, allreduce=allreduce,
+                                      native_rccl=native_rccl)
 
     def solve(self) -> None:
         """Optimizer.solve (optimizer.py:731-787) on the HIP solver."""

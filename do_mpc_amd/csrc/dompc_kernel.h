@@ -1515,6 +1515,9 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
       else { Ld[RB_KV + i] = -y[i]; Nd[ND_KV + i] = -y[i]; }
     }
   }
+#ifndef DOMPC_HOST_EMU
+  bad = __ballot(bad) != 0ull;          // wave-uniform verdict: the callers branch on it (all lanes stay together)
+#endif
   T.gsync();
   DOMPC_PN(6)
   // ---- children, pass 2 (closed-loop form):  PN = Lc' QO Lc + sum Acl' P_c Acl ; pn likewise.

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,18 @@ struct dompc_handle {
   dompc_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   uint32_t* x_words = nullptr;           // pinned host memory: [req, ack, count, off] (device build)
+#ifndef DOMPC_HOST_EMU
+  // native RCCL collective (dlopen'ed): communicator of the sharded problem and its stream
+  struct RcclUid { char internal[128]; };
+  void* rccl_lib = nullptr;
+  int (*nccl_get_unique_id)(RcclUid*) = nullptr;
+  int (*nccl_comm_init_rank)(void**, int, RcclUid, int) = nullptr;
+  int (*nccl_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*nccl_comm_destroy)(void*) = nullptr;
+  const char* (*nccl_error_string)(int) = nullptr;
+  void* rccl_comm = nullptr;
+  hipStream_t rccl_stream = nullptr;
+#endif
 #ifndef DOMPC_HOST_EMU
   hipModule_t module = nullptr;
   hipFunction_t fn_solve = nullptr, fn_info = nullptr;
@@ -146,6 +159,8 @@ extern "C" void dompc_destroy(dompc_handle* h) {
   if (h->stream) hipStreamDestroy(h->stream);
   if (h->x_words) hipHostFree(h->x_words);
   if (h->shard_stream) hipStreamDestroy(h->shard_stream);
+  if (h->rccl_comm && h->nccl_comm_destroy) h->nccl_comm_destroy(h->rccl_comm);
+  if (h->rccl_stream) hipStreamDestroy(h->rccl_stream);
 #else
   for (void* p : h->dev_allocs) free(p);
 #endif
@@ -350,6 +365,60 @@ extern "C" int64_t dompc_exchange_doubles(const dompc_handle* h, int32_t world, 
   return (int64_t)world * L[0] + (int64_t)n_cut * (L[1] + L[2] + L[3]) + 2 * (int64_t)world;
 }
 
+#ifndef DOMPC_HOST_EMU
+static int rccl_open(dompc_handle* h, const char* path) {
+  if (h->rccl_lib) return 0;
+  h->rccl_lib = dlopen(path && *path ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h->rccl_lib) { h->error = std::string("dlopen(librccl) failed: ") + dlerror(); return 1; }
+  h->nccl_get_unique_id = (int (*)(dompc_handle::RcclUid*))dlsym(h->rccl_lib, "ncclGetUniqueId");
+  h->nccl_comm_init_rank = (int (*)(void**, int, dompc_handle::RcclUid, int))dlsym(h->rccl_lib, "ncclCommInitRank");
+  h->nccl_all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h->rccl_lib, "ncclAllReduce");
+  h->nccl_comm_destroy = (int (*)(void*))dlsym(h->rccl_lib, "ncclCommDestroy");
+  h->nccl_error_string = (const char* (*)(int))dlsym(h->rccl_lib, "ncclGetErrorString");
+  if (!h->nccl_get_unique_id || !h->nccl_comm_init_rank || !h->nccl_all_reduce || !h->nccl_comm_destroy) {
+    h->error = "librccl does not export the expected nccl* entry points"; return 1;
+  }
+  return 0;
+}
+#define NCCLCHK(h, expr)                                                                                       \
+  do {                                                                                                         \
+    const int _r = (expr);                                                                                     \
+    if (_r != 0) {                                                                                             \
+      (h)->error = std::string(#expr) + ": " + ((h)->nccl_error_string ? (h)->nccl_error_string(_r) : "rccl error"); \
+      return 1;                                                                                                \
+    }                                                                                                          \
+  } while (0)
+#endif
+
+extern "C" int dompc_rccl_unique_id(dompc_handle* h, const char* librccl_path, uint8_t id[128]) {
+  if (!h || !id) return 1;
+#ifndef DOMPC_HOST_EMU
+  if (rccl_open(h, librccl_path)) return 1;
+  dompc_handle::RcclUid u;
+  NCCLCHK(h, h->nccl_get_unique_id(&u));
+  memcpy(id, u.internal, 128);
+  return 0;
+#else
+  (void)librccl_path; h->error = "no RCCL in the host emulation"; return 1;
+#endif
+}
+
+extern "C" int dompc_rccl_init(dompc_handle* h, const char* librccl_path, const uint8_t id[128], int32_t rank, int32_t world) {
+  if (!h || !id) return 1;
+#ifndef DOMPC_HOST_EMU
+  if (rccl_open(h, librccl_path)) return 1;
+  HIPCHK(h, hipSetDevice(h->d.device));
+  if (h->rccl_comm) { h->nccl_comm_destroy(h->rccl_comm); h->rccl_comm = nullptr; }
+  dompc_handle::RcclUid u;
+  memcpy(u.internal, id, 128);
+  NCCLCHK(h, h->nccl_comm_init_rank(&h->rccl_comm, world, u, rank));
+  if (!h->rccl_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->rccl_stream, hipStreamNonBlocking));
+  return 0;
+#else
+  (void)librccl_path; (void)rank; (void)world; h->error = "no RCCL in the host emulation"; return 1;
+#endif
+}
+
 extern "C" int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* s) {
   if (!h) return 1;
   dompc::KArgs& A = h->base;
@@ -363,7 +432,12 @@ extern "C" int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* s) {
   const dompc_problem_desc& d = h->d;
   if (!h->shard_capable) { h->error = "this code object was built without tree-sharding support (-DDOMPC_SHARD=1)"; return 1; }
   if (s->world < 1 || s->rank < 0 || s->rank >= s->world || s->cut_level < 1 || s->n_cut < 1) { h->error = "invalid shard description"; return 1; }
-  if (!s->x_mask || !s->g_mask || !s->edge_mask || !s->node_mask || !s->node_cut || !s->xbuf || !s->allreduce) { h->error = "null pointer in shard description"; return 1; }
+  if (!s->x_mask || !s->g_mask || !s->edge_mask || !s->node_mask || !s->node_cut || !s->xbuf) { h->error = "null pointer in shard description"; return 1; }
+#ifndef DOMPC_HOST_EMU
+  if (!s->allreduce && !h->rccl_comm) { h->error = "no collective: pass allreduce or call dompc_rccl_init first"; return 1; }
+#else
+  if (!s->allreduce) { h->error = "the host emulation needs an allreduce callback"; return 1; }
+#endif
 #ifndef DOMPC_HOST_EMU
   HIPCHK(h, hipSetDevice(d.device));
 #endif
@@ -417,7 +491,13 @@ static int serve_exchanges(dompc_handle* h, hipStream_t st) {
       __sync_synchronize();
       const uint32_t count = w[2], off = w[3];
       if ((int64_t)off + count > h->base.xbuf_len) { h->error = "exchange request outside the buffer"; rc = 1; w[1] = r; served = r; continue; }
-      h->allreduce(h->allreduce_ctx, h->base.xbuf + off, (int32_t)count);
+      if (h->allreduce) {
+        h->allreduce(h->allreduce_ctx, h->base.xbuf + off, (int32_t)count);
+      } else {                                   // native RCCL: in-place sum of doubles (ncclFloat64 = 8, ncclSum = 0)
+        double* buf = h->base.xbuf + off;
+        const int e1 = h->nccl_all_reduce(buf, buf, (size_t)count, 8, 0, h->rccl_comm, h->rccl_stream);
+        if (e1 != 0 || hipStreamSynchronize(h->rccl_stream) != hipSuccess) { h->error = "ncclAllReduce failed in the exchange loop"; rc = 1; }
+      }
       served = r;
       __sync_synchronize();
       w[1] = r;

@@ -111,6 +111,10 @@ def _load(lib_path: str) -> C.CDLL:
     lib.dompc_exchange_doubles.restype = C.c_int64
     lib.dompc_set_sharding.argtypes = [vp, C.POINTER(ShardDesc)]
     lib.dompc_set_sharding.restype = C.c_int
+    lib.dompc_rccl_unique_id.argtypes = [vp, C.c_char_p, vp]
+    lib.dompc_rccl_unique_id.restype = C.c_int
+    lib.dompc_rccl_init.argtypes = [vp, C.c_char_p, vp, C.c_int32, C.c_int32]
+    lib.dompc_rccl_init.restype = C.c_int
     return lib
 
 
@@ -227,14 +231,16 @@ class HipIpmSolver:
         return {"x": x, "f": float(f[0]), "g": g, "lam_x": lam_x, "lam_g": lam_g, "lam_p": np.zeros(ps.n_opt_p)}
 
     # ------------------------------------------------------------------ tree sharding over ranks
-    def enable_sharding(self, rank: int, world: int, cut_level: Optional[int] = None, group=None, allreduce=None) -> dict:
+    def enable_sharding(self, rank: int, world: int, cut_level: Optional[int] = None, group=None, allreduce=None,
+                        native_rccl: bool = True) -> dict:
         """Shard the scenario tree of this handle's problem over `world` ranks (one process per GPU).
 
         The sub-trees below the cut go to the ranks in contiguous blocks, the stages above are replicated; during a
         solve the kernel asks the host for element-wise SUMs over a small exchange buffer (cut-edge contributions
-        of the Riccati recursion, scalar reductions of the IPM).  The collective is `torch.distributed.all_reduce`
-        on `group` (backend nccl = RCCL on the GPU, gloo in the CPU tests) unless `allreduce(view)` is given.
-        Every rank must call the solver with identical inputs."""
+        of the Riccati recursion, scalar reductions of the IPM).  On the GPU the runtime joins its own RCCL
+        communicator (unique id broadcast over `group`) and calls ncclAllReduce itself from the service loop
+        (`native_rccl`); otherwise the collective is `torch.distributed.all_reduce` on `group` (nccl, or gloo in the
+        CPU tests) or the callable `allreduce(view)`.  Every rank must call the solver with identical inputs."""
         from .structure import shard_tables
         if not self.shard_capable:
             raise RuntimeError("this solver was built without tree-sharding support: construct it with shard=True "
@@ -268,13 +274,31 @@ class HipIpmSolver:
             off = (int(buf) - base) // 8
             reduce_view(xbuf[off:off + int(count)])
 
-        cb = _ALLREDUCE_FN(callback)
+        native = bool(native_rccl) and allreduce is None and not self._host_emulation
+        if native:
+            import os
+            import torch.distributed as dist
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                raw = (C.c_uint8 * 128)()
+                self._check(self._lib.dompc_rccl_unique_id(self._h, path, raw))
+                uid = torch.tensor(list(raw), dtype=torch.uint8)
+            if world > 1:
+                uid = uid.to(xbuf.device)
+                dist.broadcast(uid, src=0, group=group)
+                uid = uid.cpu()
+            raw = (C.c_uint8 * 128)(*uid.tolist())
+            self._check(self._lib.dompc_rccl_init(self._h, path, raw, rank, world))
+        cb = _ALLREDUCE_FN() if native else _ALLREDUCE_FN(callback)
         arrays = {k: np.ascontiguousarray(t[k]) for k in ("x_mask", "g_mask", "edge_mask", "node_mask", "node_cut")}
         d = ShardDesc(rank=rank, world=world, cut_level=t["cut_level"], n_cut=t["n_cut"], xbuf=base, allreduce=cb, ctx=None,
                       **{k: v.ctypes.data for k, v in arrays.items()})
         self._check(self._lib.dompc_set_sharding(self._h, C.byref(d)))
-        self._shard = {"tables": t, "xbuf": xbuf, "callback": cb, "reduce": reduce_view, "stream": stream, "arrays": arrays}
-        reduce_view(xbuf[:1])                                          # communicator warm-up outside the solve
+        self._shard = {"tables": t, "xbuf": xbuf, "callback": cb, "reduce": reduce_view, "stream": stream, "arrays": arrays,
+                       "native_rccl": native}
+        if not native or world > 1:
+            reduce_view(xbuf[:1])                                      # communicator warm-up outside the solve
         return t
 
     def disable_sharding(self):
@@ -283,6 +307,8 @@ class HipIpmSolver:
 
     def _sum_over_ranks(self, a: np.ndarray) -> np.ndarray:
         import torch
+        if self._shard["tables"]["world"] == 1:
+            return a
         if self._host_emulation:
             v = torch.from_numpy(np.ascontiguousarray(a))
             self._shard["reduce"](v)

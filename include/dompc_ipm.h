@@ -192,6 +192,14 @@ typedef struct dompc_shard_desc {
   dompc_allreduce_fn allreduce;
   void* ctx;
 } dompc_shard_desc;
+/* Native collective: with allreduce == NULL in dompc_shard_desc the runtime calls RCCL itself
+ * (ncclAllReduce, double, sum, on its own communicator and stream) from the service loop - no Python in the
+ * exchange path.  The library is opened with dlopen (pass the path of the librccl already loaded in the process,
+ * e.g. torch/lib/librccl.so, so that one copy is used).  Rank 0 creates the 128-byte unique id, the caller
+ * distributes it (any transport), every rank joins with dompc_rccl_init before dompc_set_sharding. */
+int dompc_rccl_unique_id(dompc_handle* h, const char* librccl_path, uint8_t id[128]);
+int dompc_rccl_init(dompc_handle* h, const char* librccl_path, const uint8_t id[128], int32_t rank, int32_t world);
+
 /* doubles the exchange buffer needs for (world, n_cut) */
 int64_t dompc_exchange_doubles(const dompc_handle* h, int32_t world, int32_t n_cut);
 /* desc == NULL switches sharding off again */

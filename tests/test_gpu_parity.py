@@ -193,11 +193,13 @@ def test_wide_mode_equals_single_workgroup_mode(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,kw,cut", [("CSTR", {}, 1), ("industrial_poly", {"n_robust": 2, "uncertainty": "paired"}, 2)])
-def test_tree_sharded_solve_on_one_gpu_matches_the_plain_solve(name, kw, cut):
+@pytest.mark.parametrize("name,kw,cut,native", [("CSTR", {}, 1, False), ("CSTR", {}, 1, True),
+                                                ("industrial_poly", {"n_robust": 2, "uncertainty": "paired"}, 2, True)])
+def test_tree_sharded_solve_on_one_gpu_matches_the_plain_solve(name, kw, cut, native):
     """the tree-sharding kernel variant with a cut and world = 1.  Every exchange goes through the
-    device<->host handshake (pinned request/acknowledge words, host service loop) and a torch.distributed
-    all_reduce on an nccl (= RCCL) group of size 1; the result must be the plain single-GPU solve."""
+    device<->host handshake (pinned request/acknowledge words, host service loop) and an RCCL all-reduce on a
+    communicator of size 1 - called natively by the runtime (ncclAllReduce) or through torch.distributed (nccl
+    group); the result must be the plain single-GPU solve."""
     import torch.distributed as dist
     from do_mpc_amd.examples import CASES
     ex = CASES[name]
@@ -207,12 +209,12 @@ def test_tree_sharded_solve_on_one_gpu_matches_the_plain_solve(name, kw, cut):
         mpc.x0 = ex.X0
         mpc.set_initial_guess()
         if shard:
-            mpc.shard_tree(0, 1, cut_level=cut)
+            mpc.shard_tree(0, 1, cut_level=cut, native_rccl=native)
         u0 = mpc.make_step(ex.X0).ravel().copy()
         return u0, mpc.opt_x_num.master.copy(), dict(mpc.solver_stats), mpc.structure.tables["dummy_idx"]
 
     u_ref, x_ref, st_ref, dummy = solve(False)
-    created = not dist.is_initialized()
+    created = not native and not dist.is_initialized()
     if created:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")

@@ -42,12 +42,16 @@ def main():
     print(f"cut, identity  : u0={u} it={st['iter_count']} {st['return_status']} {dt * 1e3:.1f} ms / warm {dt2 * 1e3:.1f} ms, "
           f"{len(calls)} exchanges, max|dx|={np.abs(x - x_ref)[keep].max():.2e}", flush=True)
     assert st["success"] and np.allclose(u, u_ref, rtol=1e-8)
+    u, x, st, dt, dt2, _ = solve(name, kw, dict(rank=0, world=1, cut_level=cut))            # native RCCL (default)
+    print(f"cut, native RCCL: u0={u} it={st['iter_count']} {st['return_status']} {dt * 1e3:.1f} ms / warm {dt2 * 1e3:.1f} ms, "
+          f"max|dx|={np.abs(x - x_ref)[keep].max():.2e}", flush=True)
+    assert st["success"] and np.allclose(u, u_ref, rtol=1e-8)
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1)
-    u, x, st, dt, dt2, _ = solve(name, kw, dict(rank=0, world=1, cut_level=cut))
-    print(f"cut, RCCL ws=1 : u0={u} it={st['iter_count']} {st['return_status']} {dt * 1e3:.1f} ms / warm {dt2 * 1e3:.1f} ms, "
+    u, x, st, dt, dt2, _ = solve(name, kw, dict(rank=0, world=1, cut_level=cut, native_rccl=False))
+    print(f"cut, torch nccl: u0={u} it={st['iter_count']} {st['return_status']} {dt * 1e3:.1f} ms / warm {dt2 * 1e3:.1f} ms, "
           f"max|dx|={np.abs(x - x_ref)[keep].max():.2e}", flush=True)
     assert st["success"] and np.allclose(u, u_ref, rtol=1e-8)
     dist.destroy_process_group()
