@@ -54,7 +54,7 @@ extern "C" __global__ void __launch_bounds__(256, 2) dompc_solve_kernel(dompc::K
   __shared__ long long prof[8];
   if (threadIdx.x < 8) { prof[threadIdx.x] = 0; flags[threadIdx.x] = 0; }
   // defined LDS contents at kernel start (the pool of the previous kernel on this CU is still in there)
-  for (int i = threadIdx.x; i < POOL; i += blockDim.x) pool[i] = 0.0;
+  for (int i = threadIdx.x; i < POOL; i += blockDim.x) pool[i] = (i >= A.lds_fill_lo && i < A.lds_fill_hi) ? A.lds_fill : 0.0;
   for (int i = threadIdx.x; i < 2 * dompc::MAX_FILTER; i += blockDim.x) filt[i] = 0.0;
   __syncthreads();
   // Thread context.  Normal mode: one workgroup per problem, problems pulled from a device-wide counter.

@@ -55,6 +55,9 @@ struct KArgs {
   volatile uint32_t* x_count;
   void (*x_callback)(void* ctx, double* buf, int32_t count);
   void* x_ctx;
+  // debugging aid: value the LDS pool is filled with when the kernel starts (0 in production), words [lo, hi)
+  double lds_fill;
+  int32_t lds_fill_lo, lds_fill_hi;
 };
 
 

@@ -331,6 +331,11 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   }
   A.opt = d.opts;
   if (const char* mi = getenv("DOMPC_MAX_ITER")) A.opt.max_iter = atoi(mi);      // debugging aid
+  if (const char* lf = getenv("DOMPC_LDS_FILL")) {                                 // debugging aid: "value[,lo,hi]"
+    double v = 0.0; int lo = 0, hi = 1 << 30;
+    sscanf(lf, "%lf,%d,%d", &v, &lo, &hi);
+    A.lds_fill = v; A.lds_fill_lo = lo; A.lds_fill_hi = hi;
+  }
   A.n_slots = h->n_slots;
   A.ws_stride = h->ws_stride;
   if (dev_alloc(h, (void**)&A.ws, sizeof(double) * (size_t)h->ws_stride * h->n_slots)) return fail(1);
