@@ -29,12 +29,17 @@ for p in ("p1", "p2", "p3", "p4"):
     for k, v in agg.items():
         print(f"{p} {k:28s} {v:.6g}")
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+    rf, wf = 2.0, 1.0      # profiles/pmc_calibration.json (tools/pmc_calib/run.sh): 8 B/lane f64 traffic on gfx950
+    cal = os.path.join(os.path.dirname(os.path.dirname(out)), "profiles", "pmc_calibration.json")
+    if os.path.exists(cal):
+        c = json.load(open(cal)); rf, wf = round(c["read_factor"], 3), round(c["write_factor"], 3)
     summ = {"batch": batch, "variant": "A", "launches": 1, "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"],
-            "hbm_bytes_per_launch": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0,
+            "read_factor": rf, "write_factor": wf,
+            "hbm_bytes_per_launch_raw": (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0,
+            "hbm_bytes_per_launch": (tot["FETCH_SIZE"] * rf + tot["WRITE_SIZE"] * wf) * 1024.0,
             "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_run.sh: bench.py --steps 1 --warmup 0 "
-                    "--batch N), summed over the dispatch rows of dompc_solve_kernel; counter units are KB. The x2 gfx950 correction "
-                    "of MI355X_MICROARCH.md is calibrated for 16 B/lane streaming reads; this kernel moves 8 B/lane (f64), which is "
-                    "uncalibrated, so the raw counters are reported."}
+                    "--batch N), summed over the dispatch rows of dompc_solve_kernel; counter units are KB. Corrected with the factors calibrated for "
+                    "8 B/lane coalesced f64 traffic (tools/pmc_calib/): FETCH_SIZE x2.0, WRITE_SIZE x1.0 on gfx950."}
     json.dump(summ, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
     print(json.dumps(summ)[:200])
 PY
