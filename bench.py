@@ -69,7 +69,7 @@ def sweep_bytes_per_problem(ps) -> int:
     return 8 * (reads + writes) * ps.n_edges
 
 
-def cpu_baseline(sample: int = 2) -> dict:
+def cpu_baseline(sample: int = 4) -> dict:
     """Oracle (numpy/scipy restatement of NLP + IPOPT algorithm) on the same workload, bounded sample."""
     from oracle import ipm
     from oracle.models import CASES
