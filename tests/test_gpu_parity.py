@@ -229,3 +229,12 @@ def test_tree_sharded_solve_on_one_gpu_matches_the_plain_solve(name, kw, cut, na
     assert st["success"] and abs(st["iter_count"] - st_ref["iter_count"]) <= 1
     assert np.allclose(u, u_ref, rtol=1e-8, atol=0)
     assert pc.relerr(x[keep], x_ref[keep]) < 1e-6          # (several cut parents: sums are formed in another order)
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly"])
+def test_closed_loop_reproduces_the_reference_trajectory(name):
+    """The reference's closed-loop tests (testing/test_*.py) on the HIP path: make_step -> plant (tests/plant.py)
+    for 5 steps against the golden inputs and states."""
+    from test_closed_loop import CL_RTOL, run_closed_loop
+    wu, wx = run_closed_loop(make_mpc, name)
+    assert wu < CL_RTOL and wx < CL_RTOL
