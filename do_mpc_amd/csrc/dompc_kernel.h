@@ -1117,7 +1117,6 @@ constexpr int CUT2 = NA * NA + NA;                // closed-loop value-function 
 DOMPC_DEV inline int x_asm(const KArgs& A) { return A.shard_world * RED_MAX; }
 DOMPC_DEV inline int x_c1(const KArgs& A) { return x_asm(A) + A.n_cut * ASM_N + A.shard_world; }
 DOMPC_DEV inline int x_c2(const KArgs& A) { return x_c1(A) + A.n_cut * CUT1; }
-DOMPC_DEV inline int x_len(const KArgs& A) { return x_c2(A) + A.n_cut * CUT2 + A.shard_world; }
 DOMPC_DEV inline void assemble_children(const Prob& Q, int n, bool counted_only, double* out) {
   const KArgs& A = *Q.A;
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];

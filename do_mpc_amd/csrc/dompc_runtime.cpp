@@ -446,6 +446,7 @@ extern "C" int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* s) {
 #ifndef DOMPC_HOST_EMU
   HIPCHK(h, hipSetDevice(d.device));
 #endif
+  if (s->xbuf_doubles < dompc_exchange_doubles(h, s->world, s->n_cut)) { h->error = "exchange buffer too small (dompc_exchange_doubles)"; return 1; }
   int rc = 0;
   rc |= upload(h, &A.x_mask, s->x_mask, d.n_opt_x);
   rc |= upload(h, &A.g_mask, s->g_mask, d.n_g);

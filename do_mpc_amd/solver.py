@@ -56,7 +56,8 @@ class ShardDesc(C.Structure):
     """dompc_shard_desc (include/dompc_ipm.h)"""
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("cut_level", C.c_int32), ("n_cut", C.c_int32),
                 ("x_mask", C.c_void_p), ("g_mask", C.c_void_p), ("edge_mask", C.c_void_p), ("node_mask", C.c_void_p),
-                ("node_cut", C.c_void_p), ("xbuf", C.c_void_p), ("allreduce", _ALLREDUCE_FN), ("ctx", C.c_void_p)]
+                ("node_cut", C.c_void_p), ("xbuf", C.c_void_p), ("xbuf_doubles", C.c_int64), ("allreduce", _ALLREDUCE_FN),
+                ("ctx", C.c_void_p)]
 
 
 STATS_DTYPE = np.dtype([("success", "i4"), ("status", "i4"), ("iter_count", "i4"), ("n_reg", "i4"),
@@ -292,7 +293,7 @@ class HipIpmSolver:
             self._check(self._lib.dompc_rccl_init(self._h, path, raw, rank, world))
         cb = _ALLREDUCE_FN() if native else _ALLREDUCE_FN(callback)
         arrays = {k: np.ascontiguousarray(t[k]) for k in ("x_mask", "g_mask", "edge_mask", "node_mask", "node_cut")}
-        d = ShardDesc(rank=rank, world=world, cut_level=t["cut_level"], n_cut=t["n_cut"], xbuf=base, allreduce=cb, ctx=None,
+        d = ShardDesc(rank=rank, world=world, cut_level=t["cut_level"], n_cut=t["n_cut"], xbuf=base, xbuf_doubles=n, allreduce=cb, ctx=None,
                       **{k: v.ctypes.data for k, v in arrays.items()})
         self._check(self._lib.dompc_set_sharding(self._h, C.byref(d)))
         self._shard = {"tables": t, "xbuf": xbuf, "callback": cb, "reduce": reduce_view, "stream": stream, "arrays": arrays,

@@ -188,7 +188,8 @@ typedef struct dompc_shard_desc {
   const int8_t* edge_mask;   /* n_edges */
   const int8_t* node_mask;   /* n_nodes */
   const int32_t* node_cut;   /* n_nodes: index of a cut parent among the cut parents, else -1 */
-  double* xbuf;              /* exchange buffer, dompc_exchange_doubles() doubles, DEVICE memory owned by the caller */
+  double* xbuf;              /* exchange buffer, DEVICE memory owned by the caller */
+  int64_t xbuf_doubles;      /* its length; must be >= dompc_exchange_doubles(h, world, n_cut) */
   dompc_allreduce_fn allreduce;
   void* ctx;
 } dompc_shard_desc;
