@@ -55,8 +55,12 @@ constexpr int GS_C = 1;
 #endif
 
 // per-edge forward-pass record (contiguous per edge; written/read cooperatively by one wavefront) --
-constexpr int EW_LU = 0;                     // NW x NW: G_w^-1 (row-major)
-constexpr int EW_W = EW_LU + NW * NW;        // NW x NA, row-major
+// stored part of G_w^-1 (row-major LU_N x LU_N).  Single finite element: G_w^-1 = [[Gi, 0], [-E Gi, I]] with the
+// continuity rows E = -[D_1 I ... D_DEG I], so only Gi = G_cc^-1 (collocation block) is kept - 400 instead of
+// 900 doubles per industrial_poly edge written by every sweep and read by every forward pass.
+constexpr int LU_N = (NI == 1 && DEG > 0) ? DEG * NX : NW;
+constexpr int EW_LU = 0;
+constexpr int EW_W = EW_LU + LU_N * LU_N;    // NW x NA, row-major
 constexpr int EW_W0 = EW_W + NW * NA;
 constexpr int EW_SIGW = EW_W0 + NW;          // (the lambda-weighted Hessian blocks are read from the model-output record)
 constexpr int EW_RW = EW_SIGW + NW;
@@ -1045,7 +1049,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         else S_[ES_CV + a] = v + (w[(M - 1) * NX + a] - xc[a]);
       }
       // forward-pass data (interleaved per-edge workspace)
-      for (int it = lane; it < NW * NW; it += GS) Q.EW(e, EW_LU + it) = Ld[EL_MX + (it / NW) * NC + it % NW];
+      for (int it = lane; it < LU_N * LU_N; it += GS) Q.EW(e, EW_LU + it) = Ld[EL_MX + (it / LU_N) * NC + it % LU_N];
       for (int it = lane; it < NW * NA; it += GS) Q.EW(e, EW_W + it) = Ld[EL_MX + (it / NA) * NC + NW + it % NA];
       for (int r = lane; r < NW; r += GS) {
         Q.EW(e, EW_W0 + r) = Ld[EL_MX + r * NC + NW + NA];
@@ -2080,13 +2084,14 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     T.gsync();
     if (M > 0) {
       const int woff = A.edge_w_off[e];
-      double inv_c[RPL][NW1];
+      constexpr int LU1 = LU_N > 0 ? LU_N : 1;
+      double inv_c[RPL][LU1];
 #pragma unroll
       for (int q = 0; q < RPL; ++q) {
         const int r = lane + q * GS;
-        const int rc = r < NW ? r : 0;
+        const int rc = r < LU_N ? r : 0;
 #pragma unroll
-        for (int k2 = 0; k2 < NW; ++k2) inv_c[q][k2] = Q.EW(e, EW_LU + k2 * NW + rc);     // column r of G_w^-1
+        for (int k2 = 0; k2 < LU_N; ++k2) inv_c[q][k2] = Q.EW(e, EW_LU + k2 * LU_N + rc);   // column r of the stored block
       }
 #pragma unroll
       for (int q = 0; q < RPL; ++q) {
@@ -2122,8 +2127,17 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         const int r = lane + q * GS;
         if (r < NW) {
           double t = 0.0;
+          if (LU_N == NW) {
 #pragma unroll
-          for (int k2 = 0; k2 < NW; ++k2) t += inv_c[q][k2] * Ld[RF_RHS + k2];
+            for (int k2 = 0; k2 < LU_N; ++k2) t += inv_c[q][k2] * Ld[RF_RHS + k2];
+          } else if (r < LU_N) {
+            // G_w^-T = [[Gi', -Gi'E'], [0, I]]: the continuity part of the right-hand side folds into the collocation part
+#pragma unroll
+            for (int k2 = 0; k2 < LU_N; ++k2)
+              t += inv_c[q][k2] * (Ld[RF_RHS + k2] + DOMPC_D[k2 / NX + 1] * Ld[RF_RHS + LU_N + k2 % NX]);
+          } else {
+            t = Ld[RF_RHS + r];
+          }
           Q.dlam[row0 + r] = t;
         }
       }
