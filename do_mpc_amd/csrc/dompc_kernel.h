@@ -2330,6 +2330,17 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   }
   for (int r = T.tid; r < A.n_g; r += T.nt) Q.lam[r] = 0.0;
   T.sync();
+  // Variables that appear in no constraint and no cost term (unused scenario slots of the reference's opt_x struct,
+  // SURVEY.md App. A.7) are not determined by the NLP: with a one-sided bound the barrier alone drives them to
+  // +-1e160 over a few warm-started solves.  They are taken out of the problem: no bounds, no multipliers, value
+  // = the caller's x0 entry projected onto its box.
+  for (int d = T.tid; d < A.n_dummy; d += T.nt) {
+    const int g = A.dummy_idx[d];
+    if (sh_cnt(A, mk_x(A, g))) cnt[0] -= (Q.lb[g] > -INFINITY ? 1.0 : 0.0) + (Q.ub[g] < INFINITY ? 1.0 : 0.0);
+    Q.x[g] = fmin(fmax(x0[g], A.lbx[g]), A.ubx[g]);           // the caller's value, projected onto its box
+    Q.lb[g] = -INFINITY; Q.ub[g] = INFINITY; Q.zl[g] = 0.0; Q.zu[g] = 0.0;
+  }
+  T.sync();
   // slacks of the nl_cons rows: s = d(x) pushed into [lbg,ubg]
   if (NE > 0) {
     for (int e = T.tid; e < A.n_edges; e += T.nt) {
