@@ -90,12 +90,15 @@ constexpr int ES_SIZE = ES_OBJ + 1;
 
 // per-edge model-output record (global): results of the lowered model functions at the current iterate,
 // written by the thread-parallel evaluation phase and copied into LDS by the edge groups
-constexpr int PT_STRIDE = NX + NX * NA + NA * NA;           // f, J, H of one collocation point
+// symmetric blocks of the model-output record are packed (upper triangle, row by row) by the generated code
+constexpr int NA_T = NA * (NA + 1) / 2, NX_T = NX * (NX + 1) / 2;
+DOMPC_HD constexpr int symi(int i, int j, int n) { return i <= j ? i * n - i * (i - 1) / 2 + j - i : j * n - j * (j - 1) / 2 + i - j; }
+constexpr int PT_STRIDE = NX + NX * NA + NA_T;              // f, J, H (packed) of one collocation point
 constexpr int MO_PT = 0;
 constexpr int MO_LT = MO_PT + (NI * DEG > 0 ? NI * DEG : 1) * PT_STRIDE;   // lterm: val, g[NA], H[NA*NA]
-constexpr int MO_MT = MO_LT + 1 + NA + NA * NA;                              // mterm: val, g[NX], H[NX*NX]
-constexpr int MO_NL = MO_MT + 1 + NX + NX * NX;                              // nlcons: d[NE], Jd[NE*NA], H[NA*NA]
-constexpr int MO_SIZE = MO_NL + NE + NE * NA + NA * NA;
+constexpr int MO_MT = MO_LT + 1 + NA + NA_T;                                 // mterm: val, g[NX], H (packed)
+constexpr int MO_NL = MO_MT + 1 + NX + NX_T;                                 // nlcons: d[NE], Jd[NE*NA], H (packed)
+constexpr int MO_SIZE = MO_NL + NE + NE * NA + NA_T;
 
 // per node -------------------------------------------------------------------------------------
 constexpr int ND_P = 0;                      // NA x NA
@@ -623,8 +626,9 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
       for (int i = lane; i < NX * NA; i += GS) S_[ES_AB + i] = pt[NX + i];
       for (int i = lane; i < NA * NA; i += GS) {
-        double v = pt[NX + NX * NA + i] + om * mo[MO_LT + 1 + NA + i];
-        if (NE > 0) v += mo[MO_NL + NE + NE * NA + i];
+        const int ip = symi(i / NA, i % NA, NA);
+        double v = pt[NX + NX * NA + ip] + om * mo[MO_LT + 1 + NA + ip];
+        if (NE > 0) v += mo[MO_NL + NE + NE * NA + ip];
         S_[ES_QT + i] = v;
         S_[ES_WTW + i] = 0.0;
       }
@@ -641,7 +645,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     //      condensing phases are staged in LDS with the same batch of global loads
     if (act) {
       for (int it = lane; it < NCOLL * NA * NA; it += GS)
-        Ld[EL_HP + it] = mo[MO_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + it % (NA * NA)];
+        Ld[EL_HP + it] = mo[MO_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + symi((it % (NA * NA)) / NA, it % NA, NA)];
       for (int it = lane; it < NI * (DEG + 1) * NX; it += GS) {
         const int i = it / ((DEG + 1) * NX);
         const int rr = it % ((DEG + 1) * NX);
@@ -951,8 +955,9 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     for (int q = 0; q < QPL; ++q) {
       const int it = lane + q * GS;
       const int itc = it < NA * NA ? it : 0;
-      qlt[q] = act ? mo[MO_LT + 1 + NA + itc] : 0.0;
-      qnl[q] = (act && NE > 0) ? mo[MO_NL + NE + NE * NA + itc] : 0.0;
+      const int ip = symi(itc / NA, itc % NA, NA);
+      qlt[q] = act ? mo[MO_LT + 1 + NA + ip] : 0.0;
+      qnl[q] = (act && NE > 0) ? mo[MO_NL + NE + NE * NA + ip] : 0.0;
     }
     if (act) {
       for (int it = lane; it < NW * (NA + 1); it += GS) {
@@ -1070,7 +1075,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     }
     if (k == A.N - 1) {
       for (int a = lane; a < NX; a += GS) S_[ES_MG + a] = om * mo[MO_MT + 1 + a];
-      for (int a = lane; a < NX * NX; a += GS) S_[ES_MH + a] = om * mo[MO_MT + 1 + NX + a];
+      for (int a = lane; a < NX * NX; a += GS) S_[ES_MH + a] = om * mo[MO_MT + 1 + NX + symi(a / NX, a % NX, NX)];
     }
     if (lane == 0) {
       double obj = om * mo[MO_LT];
@@ -2070,7 +2075,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         sg_r[q] = Q.EW(e, EW_SIGW + rc);
         const double* Hp = Q.MO(e) + MO_PT + (pt >= 0 ? pt : 0) * PT_STRIDE + NX + NX * NA;
 #pragma unroll
-        for (int b = 0; b < NA; ++b) hrow[q][b] = (pt >= 0) ? Hp[(rc % NX) * NA + b] : 0.0;
+        for (int b = 0; b < NA; ++b) hrow[q][b] = (pt >= 0) ? Hp[symi(rc % NX, b, NA)] : 0.0;
       }
     }
     for (int a = lane; a < NA; a += GS) Ld[RF_DY + a] = (a < NX) ? Nd[ND_DXT + a] : Q.dx[A.node_u_off[n] + a - NX];

@@ -94,11 +94,12 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         return f"DOMPC_FN {sig} {{\n{body}\n}}\n"
 
     def hess_outs(H, n, name="H"):
+        """symmetric matrix, packed upper triangle row by row (index i*n - i*(i-1)/2 + j - i for i <= j;
+        symi() in csrc/dompc_kernel.h) - the device writes and re-reads n(n+1)/2 instead of n*n doubles"""
         outs = []
         for i in range(n):
-            for j in range(n):
-                node = H[i][j] if i <= j else H[j][i]
-                outs.append((f"{name}[{i * n + j}]", node))
+            for j in range(i, n):
+                outs.append((f"{name}[{i * n - i * (i - 1) // 2 + j - i}]", H[i][j]))
         return outs
 
     parts: List[str] = []
