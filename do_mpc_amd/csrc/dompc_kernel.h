@@ -65,16 +65,14 @@ constexpr int EW_W0 = EW_W + NW * NA;
 constexpr int EW_SIGW = EW_W0 + NW;          // (the lambda-weighted Hessian blocks are read from the model-output record)
 constexpr int EW_RW = EW_SIGW + NW;
 constexpr int EW_JD = EW_RW + NW;            // NE x NA
-constexpr int EW_SIZE = EW_JD + NE * NA + 1;
+constexpr int EW_SIZE = ((EW_JD + NE * NA + 1 + 7) / 8) * 8;      // records start on 64-byte boundaries
 
 // per-edge shared (contiguous per edge) --------------------------------------------------------
 constexpr int ES_AB = 0;                     // NX x NA
 constexpr int ES_CV = ES_AB + NX * NA;
 constexpr int ES_QT = ES_CV + NX;            // NA x NA
 constexpr int ES_QV = ES_QT + NA * NA;
-constexpr int ES_WTW = ES_QV + NA;
-constexpr int ES_WTW0 = ES_WTW + NA * NA;
-constexpr int ES_RY = ES_WTW0 + NA;          // G_y' lam + sf*omega*grad l + Jd' yd      (NA)
+constexpr int ES_RY = ES_QV + NA;          // G_y' lam + sf*omega*grad l + Jd' yd      (NA)
 constexpr int ES_GFY = ES_RY + NA;           // sf*omega*grad l                            (NA)
 constexpr int ES_MG = ES_GFY + NA;           // sf*omega*grad m (last edges)               (NX)
 constexpr int ES_MH = ES_MG + NX;            // sf*omega*hess m                            (NX x NX)
@@ -86,7 +84,7 @@ constexpr int ES_TV = ES_TP + NA * NA;       // NA : P_c*ctilde + p_c
 constexpr int ES_ACL = ES_TV + NA;          // NA x NA : Atilde * [I;K] (closed-loop map)
 constexpr int ES_CCL = ES_ACL + NA * NA;     // NA : Atilde*[0;kv] + ctilde
 constexpr int ES_OBJ = ES_CCL + NA;
-constexpr int ES_SIZE = ES_OBJ + 1;
+constexpr int ES_SIZE = ((ES_OBJ + 1 + 7) / 8) * 8;
 
 // per-edge model-output record (global): results of the lowered model functions at the current iterate,
 // written by the thread-parallel evaluation phase and copied into LDS by the edge groups
@@ -98,7 +96,7 @@ constexpr int MO_PT = 0;
 constexpr int MO_LT = MO_PT + (NI * DEG > 0 ? NI * DEG : 1) * PT_STRIDE;   // lterm: val, g[NA], H[NA*NA]
 constexpr int MO_MT = MO_LT + 1 + NA + NA_T;                                 // mterm: val, g[NX], H (packed)
 constexpr int MO_NL = MO_MT + 1 + NX + NX_T;                                 // nlcons: d[NE], Jd[NE*NA], H (packed)
-constexpr int MO_SIZE = MO_NL + NE + NE * NA + NA_T;
+constexpr int MO_SIZE = ((MO_NL + NE + NE * NA + NA_T + 7) / 8) * 8;
 
 // per node -------------------------------------------------------------------------------------
 constexpr int ND_P = 0;                      // NA x NA
@@ -106,7 +104,7 @@ constexpr int ND_PV = ND_P + NA * NA;
 constexpr int ND_K = ND_PV + NA;             // NV x NA
 constexpr int ND_KV = ND_K + NV * NA;
 constexpr int ND_DXT = ND_KV + NV;           // NA
-constexpr int ND_SIZE = ND_DXT + NA;
+constexpr int ND_SIZE = ((ND_DXT + NA + 7) / 8) * 8;
 
 struct WsLayout {
   int64_t x, zl, zu, lb, ub, dx, gf, rd, xt, dzl, dzu;
@@ -630,14 +628,12 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         double v = pt[NX + NX * NA + ip] + om * mo[MO_LT + 1 + NA + ip];
         if (NE > 0) v += mo[MO_NL + NE + NE * NA + ip];
         S_[ES_QT + i] = v;
-        S_[ES_WTW + i] = 0.0;
       }
       for (int b = lane; b < NA; b += GS) {
         double t = 0.0;
         for (int a = 0; a < NX; ++a) t += pt[NX + a * NA + b] * nu_e[a];
         S_[ES_RY + b] = t;          // completed below
         S_[ES_QV + b] = 0.0;
-        S_[ES_WTW0 + b] = 0.0;
       }
     }
   } else {
@@ -1006,7 +1002,6 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     if (act) {
       // W'T1 and W'W  (13x30 * 30x13 on the matrix cores)
       gmm(lane, GS, NA, NA, NW, (double*)(Ld + EL_MX + NW), 1, NC, (double*)(Ld + EL_T1), NA, 1, 0.0, (double*)(Ld + EL_QT), NA);
-      gmm(lane, GS, NA, NA, NW, (double*)(Ld + EL_MX + NW), 1, NC, (double*)(Ld + EL_MX + NW), NC, 1, 0.0, (double*)(Ld + EL_QT + NA * NA), NA);
     }
     T.gsync();
     // ---- phase 6: condensed blocks to the shared per-edge record; data for the forward pass
@@ -1033,19 +1028,13 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           if (a1 >= NX) q += Ld[EL_U1 + (a1 - NX) * NA + b];
           if (b >= NX) q += Ld[EL_U1 + (b - NX) * NA + a1];
           S_[ES_QT + it] = q;
-          S_[ES_WTW + it] = Ld[EL_QT + NA * NA + it];
         }
       }
       for (int a1 = lane; a1 < NA; a1 += GS) {
-        double q = 0.0, ww = 0.0;
-        for (int row = 0; row < NW; ++row) {
-          const double wa = Ld[EL_MX + row * NC + NW + a1];
-          q += wa * (Ld[EL_RW + row] + Ld[EL_T0 + row]);
-          ww += wa * Ld[EL_MX + row * NC + NW + NA];
-        }
+        double q = 0.0;
+        for (int row = 0; row < NW; ++row) q += Ld[EL_MX + row * NC + NW + a1] * (Ld[EL_RW + row] + Ld[EL_T0 + row]);
         if (a1 >= NX) q += Ld[EL_U1 + NU * NA + a1 - NX];
         S_[ES_QV + a1] = q;
-        S_[ES_WTW0 + a1] = ww;
       }
       for (int it = lane; it < NX * (NA + 1); it += GS) {
         const int a = it / (NA + 1), b = it % (NA + 1);
@@ -1226,6 +1215,19 @@ constexpr int RN_NLN = NE * (NA + 4);          // nl_cons data of a child edge: 
 constexpr int RN_NLP = NE > 0 ? (RN_NLN + GS_C - 1) / GS_C : 1;
 constexpr int RN_ABN = NX * (NA + 1);          // [A | B | c] of a child edge
 constexpr int RN_ABP = (RN_ABN + GS_C - 1) / GS_C;
+// W'W and W'w0 of an edge enter only under inertia correction (Q(delta) = Q + delta W'W, a handful of iterations per
+// solve at most): they are formed on demand from the stored W instead of being written by every sweep.
+DOMPC_DEV inline double wtw_entry(const Prob& Q, int e, int yi, int yj) {
+  double t = 0.0;
+  for (int r = 0; r < NW; ++r) t += Q.EW(e, EW_W + r * NA + yi) * Q.EW(e, EW_W + r * NA + yj);
+  return t;
+}
+DOMPC_DEV inline double wtw0_entry(const Prob& Q, int e, int yi) {
+  double t = 0.0;
+  for (int r = 0; r < NW; ++r) t += Q.EW(e, EW_W + r * NA + yi) * Q.EW(e, EW_W0 + r);
+  return t;
+}
+
 struct NodePre {
   double qt[RN_IPL], wtw[RN_IPL];
   double pv[RN_VPL][10];                       // x, lb, ub, zl, zu, nu_in, u_prev, RY, QV, WTW0
@@ -1256,7 +1258,7 @@ DOMPC_DEV inline void node_prefetch(const Prob& Q, int n, double delta, int lane
     const int yi = yidx(itc / NYT), yj = yidx(itc % NYT);
     const int idx = (yi >= 0 && yj >= 0) ? yi * NA + yj : 0;
     R.qt[q] = S_[ES_QT + idx];
-    R.wtw[q] = wd ? S_[ES_WTW + idx] : 0.0;
+    R.wtw[q] = (wd && yi >= 0 && yj >= 0) ? wtw_entry(Q, e, yi, yj) : 0.0;
   }
 #pragma unroll
   for (int v = 0; v < RN_VPL; ++v) {
@@ -1276,7 +1278,7 @@ DOMPC_DEV inline void node_prefetch(const Prob& Q, int n, double delta, int lane
     R.pv[v][6] = hu ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / DOMPC_SU[iu]) : 0.0;
     R.pv[v][7] = yi >= 0 ? S_[ES_RY + yi] : 0.0;
     R.pv[v][8] = yi >= 0 ? S_[ES_QV + yi] : 0.0;
-    R.pv[v][9] = (yi >= 0 && wd) ? S_[ES_WTW0 + yi] : 0.0;
+    R.pv[v][9] = (yi >= 0 && wd) ? wtw0_entry(Q, e, yi) : 0.0;
   }
   if (NE > 0) {
 #pragma unroll
@@ -1321,7 +1323,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
     for (int c = 1; c < cc; ++c) {
       const double* S_ = Q.ES(cs + c);
       double t = S_[ES_QT + idx];
-      if (delta != 0.0) t += delta * S_[ES_WTW + idx];
+      if (delta != 0.0 && valid) t += delta * wtw_entry(Q, cs + c, yi, yj);
       v += t;
     }
     qacc[q] = valid ? v : 0.0;
@@ -1355,7 +1357,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
     if (yi >= 0)
       for (int c = 1; c < cc; ++c) {
         const double* S_ = Q.ES(cs + c);
-        gv += S_[ES_RY + yi] + S_[ES_QV + yi] + delta * S_[ES_WTW0 + yi];
+        gv += S_[ES_RY + yi] + S_[ES_QV + yi] + (delta != 0.0 ? delta * wtw0_entry(Q, cs + c, yi) : 0.0);
       }
     gvv[v] = gv;
     dgv[v] = dg;
@@ -1669,7 +1671,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
         if (!counted(c)) continue;
         const int e = cs + c;
         const double* S_ = Q.ES(e);
-        if (yi >= 0) gv += S_[ES_RY + yi] + S_[ES_QV + yi] + delta * S_[ES_WTW0 + yi];
+        if (yi >= 0) gv += S_[ES_RY + yi] + S_[ES_QV + yi] + (delta != 0.0 ? delta * wtw0_entry(Q, e, yi) : 0.0);
         if (NE > 0) {
           const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
           for (int q = 0; q < NE; ++q) {
@@ -1696,7 +1698,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
         const double* S_ = Q.ES(e);
         if (yi >= 0 && yj >= 0) {
           v += S_[ES_QT + yi * NA + yj];
-          if (delta != 0.0) v += delta * S_[ES_WTW + yi * NA + yj];
+          if (delta != 0.0) v += delta * wtw_entry(Q, e, yi, yj);
         }
         if (NE > 0)
           for (int qq = 0; qq < NE; ++qq) {

@@ -96,9 +96,10 @@ def check_against_oracle_solve(make_mpc, name, x0_scale=1.0, **over):
     return mpc
 
 
-def check_newton_step(make_mpc, name, oracle_iters=6):
+def check_newton_step(make_mpc, name, oracle_iters=6, delta=0.0):
     """One Newton direction of the structured solve (condensing + tree Riccati) against a general sparse
-    LU of the same KKT system, at an interior iterate produced by the oracle."""
+    LU of the same KKT system, at an interior iterate produced by the oracle.  delta > 0: the inertia-correction
+    path (delta_w on every primal variable, IPOPT's first diagonal block W + Sigma + delta I)."""
     ex = CASES[name]
     mpc = make_mpc(name)
     nlp = oracle_nlp(name)
@@ -113,7 +114,7 @@ def check_newton_step(make_mpc, name, oracle_iters=6):
     dl, du = np.where(hl, x - lb, 1.0), np.where(hu, ub - x, 1.0)
     assert dl.min() > 0 and du.min() > 0
     zl, zu = np.where(hl, mu / dl, 0.0), np.where(hu, mu / du, 0.0)
-    dx, dlam, rd, c = mpc.S.debug_newton_step(x, lam, zl, zu, lb, ub, nlp.lbg, nlp.ubg, p, mu, 0.0)
+    dx, dlam, rd, c = mpc.S.debug_newton_step(x, lam, zl, zu, lb, ub, nlp.lbg, nlp.ubg, p, mu, delta)
     W, A, gf, cv = nlp.hess(x, p, 1.0, lam), nlp.jac(x, p), nlp.grad(x, p), nlp.g(x, p) - nlp.lbg
     assert np.max(np.abs(c - cv)) < 1e-10 * max(1.0, np.max(np.abs(cv)))
     assert np.max(np.abs(rd - (gf + A.T @ lam - zl + zu))) < 1e-9 * max(1.0, np.max(np.abs(rd)))
@@ -122,7 +123,7 @@ def check_newton_step(make_mpc, name, oracle_iters=6):
     dummy = np.asarray(mpc.structure.tables["dummy_idx"])
     pin = np.zeros(x.size)
     pin[dummy] = (sig[dummy] == 0)
-    K = sps.bmat([[W + sps.diags(sig + pin), A.T], [A, None]], format="csc")
+    K = sps.bmat([[W + sps.diags(sig + pin + delta), A.T], [A, None]], format="csc")
     rhs = -np.concatenate([rx, cv])
     lu = spla.splu(K)
     sol = lu.solve(rhs)

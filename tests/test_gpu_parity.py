@@ -46,6 +46,12 @@ def test_newton_direction_matches_sparse_kkt_solve(name):
     pc.check_newton_step(make_mpc, name)
 
 
+@pytest.mark.parametrize("name", ["batch_reactor", "industrial_poly"])
+def test_newton_direction_with_inertia_correction(name):
+    """delta_w > 0: W'W and W'w0 of every edge are formed on demand from the stored W"""
+    pc.check_newton_step(make_mpc, name, delta=0.05)
+
+
 @pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly"])
 def test_sweep_blocks_match_oracle_jacobian(name):
     mpc = make_mpc(name, max_batch=8)
