@@ -362,20 +362,39 @@ class MPC:
         eps_entries = [Entry(sl["slack_name"], sl["shape"]) for sl in self.slack_vars_list]
         self._eps_layout = Layout(eps_entries)
         self.n_eps = self._eps_layout.size
-        for c in self.nl_cons_list:
-            if c["expr"].numel() != 1:
-                raise NotImplementedError("structured HIP backend: vector-valued nl_cons; add one constraint per row")
-        self._nl_cons_ub = np.array([float(np.asarray(c["ub"]).reshape(-1)[0]) for c in self.nl_cons_list])
-        self._nl_cons_lb = -np.inf * np.ones(len(self.nl_cons_list))
+        # a vector-valued expression contributes one row per element (rows and slack elements in the reference's
+        # order: vertcat of the expressions, `_eps` entries with the expression's shape, optimizer.py:560-585)
         slack_names = [sl["slack_name"] for sl in self.slack_vars_list]
-        self._nl_slack_index = [slack_names.index(c["expr_name"]) if c["expr_name"] in slack_names else -1
-                                for c in self.nl_cons_list]
+        slack_off = np.concatenate([[0], np.cumsum([int(np.prod(sl["shape"])) for sl in self.slack_vars_list])]).astype(int)
+        self._nl_rows, ub_rows, self._nl_slack_index = [], [], []
+        for c in self.nl_cons_list:
+            nodes = c["expr"].nodes()
+            ub = np.broadcast_to(np.asarray(c["ub"], dtype=float).reshape(-1), (len(nodes),)) if np.size(c["ub"]) in (1, len(nodes)) \
+                else None
+            assert ub is not None, "ub of nl_cons '{}' does not match the shape of the expression".format(c["expr_name"])
+            si = slack_names.index(c["expr_name"]) if c["expr_name"] in slack_names else -1
+            for i, nd in enumerate(nodes):
+                self._nl_rows.append(nd)
+                ub_rows.append(float(ub[i]))
+                self._nl_slack_index.append(int(slack_off[si]) + i if si >= 0 else -1)
+        self._nl_cons_ub = np.array(ub_rows)
+        self._nl_cons_lb = -np.inf * np.ones(len(self._nl_rows))
+
+        def per_element(key):
+            out = []
+            for sl in self.slack_vars_list:
+                n = int(np.prod(sl["shape"]))
+                v = np.asarray(sl[key], dtype=float).reshape(-1)
+                assert v.size in (1, n), "{} of slack '{}' does not match its shape".format(key, sl["slack_name"])
+                out.extend(np.broadcast_to(v, (n,)) if v.size == 1 else v)
+            return np.array(out, dtype=float)
+
         self._eps_lb = np.zeros(self.n_eps)
-        self._eps_ub = np.array([float(sl["ub"]) for sl in self.slack_vars_list]) if self.n_eps else np.zeros(0)
-        self._eps_pen = np.array([float(sl["penalty"]) for sl in self.slack_vars_list]) if self.n_eps else np.zeros(0)
+        self._eps_ub = per_element("ub") if self.n_eps else np.zeros(0)
+        self._eps_pen = per_element("penalty") if self.n_eps else np.zeros(0)
 
         discrete = m.model_type == "discrete"
-        ps = build_structure(nx=m.n_x, nu=m.n_u, nz=m.n_z, np_=m.n_p, ntvp=m.n_tvp, ne=len(self.nl_cons_list),
+        ps = build_structure(nx=m.n_x, nu=m.n_u, nz=m.n_z, np_=m.n_p, ntvp=m.n_tvp, ne=len(self._nl_rows),
                              ns=self.n_eps, deg=s.collocation_deg, ni=s.collocation_ni, N=s.n_horizon,
                              n_comb=self.n_combinations, n_robust=s.n_robust, discrete=discrete,
                              open_loop=bool(s.open_loop), single_slack=bool(s.nl_cons_single_slack))
@@ -465,7 +484,7 @@ class MPC:
             rhs = sym.substitute(m._rhs, m._w.cat, sym.SX.zeros(m.n_w, 1)).nodes()     # _w = 0 in the MPC (_mpc.py:1166)
         else:
             rhs = m._rhs.nodes()
-        nl_exprs = [c["expr"].nodes()[0] for c in self.nl_cons_list]
+        nl_exprs = list(self._nl_rows)
         return lowering.lower_model(
             nx=m.n_x, nu=m.n_u, np_=m.n_p, ntvp=m.n_tvp,
             x_sym=m._x.cat.nodes(), u_sym=m._u.cat.nodes(), tvp_sym=m._tvp.cat.nodes(), p_sym=m._p.cat.nodes(),

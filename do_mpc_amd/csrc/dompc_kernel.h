@@ -527,7 +527,7 @@ constexpr int EL_QT = EL_HUU + NU * NU;                                // W'T1 (
 constexpr int EL_HP = EL_QT;                                           // staged point Hessians H_p (NA x NA each): dead before QT is written
 constexpr int EL_NHP = (NI * DEG > 2 ? NI * DEG : 2);
 constexpr int EL_PV = EL_QT + EL_NHP * NA * NA;                        // pivot rows (NW)
-constexpr int RB_NEED = 2 * (NYT * NYT + NYT) + 5 * NA * NA + 6 * NA + NV * NA + NV;
+constexpr int RB_NEED = 2 * (NYT * NYT + NYT) + 5 * NA * NA + 6 * NA + NV * NA + NV + NE * (NA + 4);   // = rb::RB_SIZE (asserted there)
 constexpr int EL_SIZE = (((EL_PV + NW > RB_NEED ? EL_PV + NW : RB_NEED) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {

@@ -70,3 +70,49 @@ def test_repeated_solves_on_one_handle_are_reproducible():
         out.append((mpc.make_step(ex.X0).ravel().copy(), mpc.opt_x_num.master.copy(), mpc.solver_stats["iter_count"]))
     for u, x, it in out[1:]:
         assert np.array_equal(u, out[0][0]) and np.array_equal(x, out[0][1]) and it == out[0][2]
+
+
+def _cstr_with_constraints(vector: bool):
+    """CSTR with two soft constraints (T_R <= 137 and C_b <= 0.9), posed as one 2x1 expression or as two scalars."""
+    from do_mpc_amd import sym
+    from do_mpc_amd.controller import MPC
+    ex = CASES["CSTR"]
+    model = ex.build_model()
+    with hostemu.patched():
+        mpc = MPC(model)
+        st = mpc.settings
+        st.n_horizon, st.n_robust, st.t_step = 6, 1, 0.005
+        st.collocation_deg, st.collocation_ni = 2, 1
+        st.supress_ipopt_output()
+        for k, v in (("T_R", 100), ("T_K", 100)):
+            mpc.scaling["_x", k] = v
+        mpc.scaling["_u", "Q_dot"] = 2000
+        mpc.scaling["_u", "F"] = 100
+        track = (model.x["C_b"] - 0.6) ** 2
+        mpc.set_objective(mterm=track, lterm=track)
+        mpc.set_rterm(F=0.1, Q_dot=1e-3)
+        mpc.bounds["lower", "_u", "F"] = 5
+        mpc.bounds["lower", "_u", "Q_dot"] = -8500
+        mpc.bounds["upper", "_u", "F"] = 100
+        mpc.bounds["upper", "_u", "Q_dot"] = 0.0
+        if vector:
+            mpc.set_nl_cons("both", sym.vertcat(model.x["T_R"], model.x["C_b"]), ub=np.array([137.0, 0.9]), soft_constraint=True,
+                            penalty_term_cons=np.array([1e2, 3e2]), maximum_violation=np.array([5.0, 0.2]))
+        else:
+            mpc.set_nl_cons("tr", model.x["T_R"], ub=137.0, soft_constraint=True, penalty_term_cons=1e2, maximum_violation=5.0)
+            mpc.set_nl_cons("cb", model.x["C_b"], ub=0.9, soft_constraint=True, penalty_term_cons=3e2, maximum_violation=0.2)
+        mpc.set_uncertainty_values(alpha=np.array([1.0, 1.05, 0.95]), beta=np.array([1.0, 1.1, 0.9]))
+        mpc.setup()
+    mpc.x0 = ex.X0
+    mpc.set_initial_guess()
+    u0 = mpc.make_step(ex.X0).ravel()
+    return u0, mpc.opt_x_num.master.copy(), np.array(mpc.lam_g_num), dict(mpc.solver_stats), mpc.structure
+
+
+def test_vector_valued_nl_cons_equals_one_constraint_per_row():
+    """optimizer.py:483-585: a vector expression contributes one row and one slack element per entry."""
+    uv, xv, lv, sv, psv = _cstr_with_constraints(True)
+    us, xs, ls, ss, pss = _cstr_with_constraints(False)
+    assert (psv.ne, psv.ns) == (pss.ne, pss.ns) == (2, 2) and psv.n_opt_x == pss.n_opt_x and psv.n_g == pss.n_g
+    assert sv["success"] and ss["success"] and sv["iter_count"] == ss["iter_count"]
+    assert np.array_equal(uv, us) and np.array_equal(xv, xs) and np.array_equal(lv, ls)
