@@ -110,3 +110,35 @@ def test_gloo_ranks_reproduce_the_single_rank_solve(name, kw, world, cut):
     # all ranks hold the same combined solution
     for r in res[1:]:
         assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2][keep], res[0][2][keep])
+
+
+def test_shard_description_is_validated():
+    """dompc_set_sharding refuses inconsistent descriptions instead of running with them (C ABI error path)."""
+    import ctypes as C
+    from do_mpc_amd.solver import ShardDesc, _ALLREDUCE_FN
+    ex = CASES["CSTR"]
+    with hostemu.patched():
+        mpc = ex.build_mpc(ex.build_model())
+    S = mpc.S
+    t = shard_tables(mpc.structure, 0, 2)
+    n = int(S._lib.dompc_exchange_doubles(S._h, 2, t["n_cut"]))
+    assert n == 2 * 12 + t["n_cut"] * (S._lib.dompc_exchange_doubles(S._h, 1, 1) - 12 - 2) + 2 * 2   # [W x RED_MAX | per cut parent | 2W flags]
+    buf = np.zeros(n)
+    keep = {k: np.ascontiguousarray(t[k]) for k in ("x_mask", "g_mask", "edge_mask", "node_mask", "node_cut")}
+    cb = _ALLREDUCE_FN(lambda ctx, b, c: None)
+
+    def desc(**over):
+        kw = dict(rank=0, world=2, cut_level=t["cut_level"], n_cut=t["n_cut"], xbuf=buf.ctypes.data, xbuf_doubles=n, allreduce=cb,
+                  ctx=None, **{k: v.ctypes.data for k, v in keep.items()})
+        kw.update(over)
+        return ShardDesc(**kw)
+
+    assert S._lib.dompc_set_sharding(S._h, C.byref(desc())) == 0
+    assert S._lib.dompc_set_sharding(S._h, None) == 0                              # off again
+    for bad in (dict(rank=2), dict(world=0), dict(cut_level=0), dict(n_cut=0), dict(xbuf_doubles=n - 1), dict(x_mask=None),
+                dict(xbuf=None)):
+        assert S._lib.dompc_set_sharding(S._h, C.byref(desc(**bad))) != 0, bad
+        assert S._lib.dompc_last_error(S._h)
+    # host emulation has no RCCL: the native collective is refused with a message
+    raw = (C.c_uint8 * 128)()
+    assert S._lib.dompc_rccl_unique_id(S._h, b"", raw) != 0 and b"RCCL" in S._lib.dompc_last_error(S._h)
