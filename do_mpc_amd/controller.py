@@ -549,15 +549,19 @@ class MPC:
         U = opt_x_unscaled.master[ps.off_u:ps.off_eps].reshape(N, ps.S, ps.nu)
         TV = opt_p.master[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
         Pm = opt_p.master[ps.p_off_p:ps.p_off_uprev].reshape(ps.n_comb, ps.np_)
-        n_scen, n_br = ps.scenario_tree["n_scenarios"], ps.scenario_tree["n_branches"]
-        boff = ps.scenario_tree["branch_offset"]
-        src_s = np.zeros((N, ps.S), int)
-        pidx = np.zeros((N, ps.S), int)
-        for k in range(N):
-            for s_ in range(ps.S):
-                s = min(s_, n_scen[k] - 1)
-                src_s[k, s_] = s
-                pidx[k, s_] = n_br[k] - 1 + boff[k][s]
+        cache = getattr(self, "_aux_index_cache", None)
+        if cache is None:                     # index tables depend on the tree only: built once
+            n_scen, n_br = ps.scenario_tree["n_scenarios"], ps.scenario_tree["n_branches"]
+            boff = ps.scenario_tree["branch_offset"]
+            src_s = np.zeros((N, ps.S), int)
+            pidx = np.zeros((N, ps.S), int)
+            for k in range(N):
+                for s_ in range(ps.S):
+                    s = min(s_, n_scen[k] - 1)
+                    src_s[k, s_] = s
+                    pidx[k, s_] = n_br[k] - 1 + boff[k][s]
+            cache = self._aux_index_cache = (src_s, pidx)
+        src_s, pidx = cache
         kk = np.repeat(np.arange(N), ps.S)
         Xf = X[kk, src_s.reshape(-1)].T
         Uf = U[kk, src_s.reshape(-1)].T
