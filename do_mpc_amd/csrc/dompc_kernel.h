@@ -1886,6 +1886,12 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
   static_assert(RB_SIZE <= EL_SIZE, "node working set must fit the per-group LDS region");
   const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
+  // The failure flag is read by every thread after a barrier and reset here by thread 0.  When the caller repeats the
+  // factorisation (inertia correction) a fast wavefront could reset it before a slow one had read the verdict of the
+  // previous pass - the wavefronts then disagree about "failed" and the workgroup falls apart (garbage steps or a
+  // barrier that never completes; seen as a timing-dependent failure of a 37-problem batch).  Hence the barrier
+  // BEFORE the reset: every thread is past its last read of the previous pass.
+  T.sync();
   if (T.tid == 0) T.flags[0] = 0;
   T.sync();
   {
@@ -2190,6 +2196,7 @@ struct Errs { double e_d, e_p, e_c0, sum_y, sum_z, obj, theta; };
 // derivative sweep at the current iterate: per-edge evaluation/condensing, node assembly, dummies
 DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   const KArgs& A = *Q.A;
+  T.sync();                                  // (every thread has read the previous sweep's verdict, see riccati_backward)
   if (T.tid == 0) T.flags[1] = 0;
   T.sync();
   for (int g = T.tid; g < NX; g += T.nt) Q.c[g] = Q.x[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
