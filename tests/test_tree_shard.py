@@ -142,3 +142,34 @@ def test_shard_description_is_validated():
     # host emulation has no RCCL: the native collective is refused with a message
     raw = (C.c_uint8 * 128)()
     assert S._lib.dompc_rccl_unique_id(S._h, b"", raw) != 0 and b"RCCL" in S._lib.dompc_last_error(S._h)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_trees_and_worlds_partition(seed):
+    """ownership is a partition for arbitrary (n_comb, n_robust, N, world, cut_level): every variable / row / edge is
+    owned by exactly one rank or replicated on all, sub-trees are contiguous, cut parents sit right above the cut"""
+    rng = np.random.default_rng(seed)
+    n_comb = int(rng.integers(2, 5))
+    n_robust = int(rng.integers(1, 4))
+    N = int(n_robust + rng.integers(0, 4))
+    ps = build_structure(nx=int(rng.integers(1, 4)), nu=int(rng.integers(1, 3)), nz=0, np_=1, ntvp=0, ne=int(rng.integers(0, 2)),
+                         ns=0, deg=2, ni=int(rng.integers(1, 3)), N=N, n_comb=n_comb, n_robust=n_robust, discrete=False)
+    n_scen = ps.scenario_tree["n_scenarios"]
+    cut = int(rng.integers(1, n_robust + 1))
+    world = int(rng.integers(1, n_scen[cut] + 1))
+    own = [np.zeros(n, int) for n in (ps.n_opt_x, ps.n_g, ps.n_edges, ps.n_nodes)]
+    for r in range(world):
+        t = shard_tables(ps, r, world, cut_level=cut)
+        for acc, key in zip(own, ("x_mask", "g_mask", "edge_mask", "node_mask")):
+            acc += t[key] == 1
+        reps = [t[key] == 2 for key in ("x_mask", "g_mask", "edge_mask", "node_mask")]
+        mine = np.where(t["node_mask"][ps.tables["level_node_start"][cut]:ps.tables["level_node_start"][cut + 1]] == 1)[0]
+        assert mine.size == 0 or np.array_equal(mine, np.arange(mine[0], mine[-1] + 1))      # contiguous block of sub-tree roots
+        lv = ps.tables["node_level"]
+        assert np.all((t["node_cut"] >= 0) == (lv == cut - 1)) and np.all(t["node_mask"][lv < cut] == 2)
+        # an owned node's whole sub-tree is owned: parent of an owned node below the cut is owned too
+        par = ps.tables["node_parent"]
+        below = np.where(lv > cut)[0]
+        assert np.array_equal(t["node_mask"][below], t["node_mask"][par[below]])
+    for acc, rep in zip(own, reps):
+        assert np.all(acc + rep == 1)
