@@ -5,10 +5,13 @@ the gpurun snapshot).  hipcc cross-compiles for gfx950 without a GPU.
 """
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import hashlib
 import os
 import shutil
 import subprocess
+import tempfile
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -36,6 +39,46 @@ def _run(cmd, what):
     return r.stdout
 
 
+@contextlib.contextmanager
+def _locked(directory: str):
+    """Exclusive lock on a build directory: several rank processes lower the same MPC at the same time
+    (MPC.shard_tree, torchrun) and must not compile into the same paths concurrently."""
+    os.makedirs(directory, exist_ok=True)
+    fd = os.open(os.path.join(directory, ".lock"), os.O_CREAT | os.O_RDWR, 0o644)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
+
+
+def _write_atomic(path: str, text: str) -> None:
+    """temp file in the same directory + rename: a reader never sees a truncated file"""
+    fd, tmp = tempfile.mkstemp(dir=os.path.dirname(path), prefix=os.path.basename(path) + ".", suffix=".tmp")
+    with os.fdopen(fd, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def _fresh(out: str, stamp: str, dig: str) -> bool:
+    try:
+        return os.path.exists(out) and open(stamp).read() == dig
+    except OSError:
+        return False
+
+
+def _compile_to(cmd_without_out, out: str, what: str) -> None:
+    """run the compiler into a temporary name next to `out`, then rename into place"""
+    tmp = f"{out}.{os.getpid()}.tmp"
+    try:
+        _run(cmd_without_out + ["-o", tmp], what)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def _sources_digest() -> str:
     h = hashlib.sha256()
     for fn in ("dompc_kernel.h", "dompc_kargs.h", "dompc_device.hip", "dompc_runtime.cpp"):
@@ -52,13 +95,15 @@ def runtime_library(force: bool = False) -> str:
     out = os.path.join(BUILD, "libdompc_ipm.so")
     stamp = out + ".stamp"
     dig = _sources_digest()
-    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
+    if not force and _fresh(out, stamp, dig):
         return out
-    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
-           os.path.join(CSRC, "dompc_runtime.cpp"), "-o", out, "-ldl"]
-    _run(cmd, "building libdompc_ipm.so")
-    with open(stamp, "w") as f:
-        f.write(dig)
+    with _locked(BUILD):
+        if not force and _fresh(out, stamp, dig):       # another process built it while we waited
+            return out
+        cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+               os.path.join(CSRC, "dompc_runtime.cpp"), "-ldl"]
+        _compile_to(cmd, out, "building libdompc_ipm.so")
+        _write_atomic(stamp, dig)
     return out
 
 
@@ -76,16 +121,17 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
     out = os.path.join(d, f"dompc_{ARCH}{'_shard' if shard else ''}.hsaco")
     stamp = out + ".stamp"
     dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt + ("S" if shard else "")
-    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
+    if not force and _fresh(out, stamp, dig):
         return out
-    with open(hdr, "w") as f:
-        f.write(header_text)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}",
-           f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC,
-           os.path.join(CSRC, "dompc_device.hip"), "-o", out]
-    _run(cmd, f"lowering model {model_hash} to {ARCH}")
-    with open(stamp, "w") as f:
-        f.write(dig)
+    with _locked(d):
+        if not force and _fresh(out, stamp, dig):       # another rank built it while we waited for the lock
+            return out
+        if not (os.path.exists(hdr) and open(hdr).read() == header_text):
+            _write_atomic(hdr, header_text)
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}",
+               f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC, os.path.join(CSRC, "dompc_device.hip")]
+        _compile_to(cmd, out, f"lowering model {model_hash} to {ARCH}")
+        _write_atomic(stamp, dig)
     return out
 
 
@@ -97,16 +143,17 @@ def hostemu_library(header_text: str, model_hash: str, out_dir: str, force: bool
     out = os.path.join(out_dir, f"libdompc_hostemu_{model_hash}.so")
     stamp = out + ".stamp"
     dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12]
-    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
+    if not force and _fresh(out, stamp, dig):
         return out
-    with open(hdr, "w") as f:
-        f.write(header_text)
-    cxx = shutil.which("g++") or "g++"
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DDOMPC_HOST_EMU", "-DDOMPC_SHARD=1",
-           f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC,
-           os.path.join(CSRC, "dompc_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "dompc_device.hip"),
-           "-o", out, "-lm"]
-    _run(cmd, "building host emulation")
-    with open(stamp, "w") as f:
-        f.write(dig)
+    with _locked(out_dir):                                # (world_size-2 gloo tests build from two processes)
+        if not force and _fresh(out, stamp, dig):
+            return out
+        if not (os.path.exists(hdr) and open(hdr).read() == header_text):
+            _write_atomic(hdr, header_text)
+        cxx = shutil.which("g++") or "g++"
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DDOMPC_HOST_EMU", "-DDOMPC_SHARD=1",
+               f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC,
+               os.path.join(CSRC, "dompc_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "dompc_device.hip"), "-lm"]
+        _compile_to(cmd, out, "building host emulation")
+        _write_atomic(stamp, dig)
     return out

@@ -51,6 +51,7 @@ class MPCSettings:
     nlpsol_opts: Dict = field(default_factory=dict)
     gpu_index: int = 0          # extension: which HIP device owns this controller
     max_batch: int = 1          # extension: capacity for make_step_batch
+    block_threads: int = 0      # extension: threads per problem in batch mode (64/128/256; 0 = choose from max_batch)
 
     def check_for_mandatory_settings(self):
         if self.n_horizon is None:
@@ -502,7 +503,8 @@ class MPC:
         self.model_hash = self.generated_header.rsplit('DOMPC_MODEL_HASH "', 1)[1].split('"')[0]
         factory = _solver_factory or HipIpmSolver
         self.S = factory(self.structure, self.generated_header, self.model_hash, nlpsol_opts=self.settings.nlpsol_opts,
-                         device=self.settings.gpu_index, max_batch=self.settings.max_batch)
+                         device=self.settings.gpu_index, max_batch=self.settings.max_batch,
+                         block_threads=self.settings.block_threads)
         meta = {k: v for k, v in asdict(self.settings).items()}
         meta["structure_scenario"] = self.scenario_tree["structure_scenario"]
         self.data.set_meta(**meta)

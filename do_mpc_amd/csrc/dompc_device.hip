@@ -31,6 +31,7 @@ DOMPC_HD inline void model_info(const int32_t* in, int64_t* out) {
   out[11] = (int64_t)sizeof(KArgs);
   out[12] = RED_MAX; out[13] = ASM_N; out[14] = CUT1; out[15] = CUT2;      // exchange buffer layout (tree sharding)
   out[16] = DOMPC_SHARD;                                                   // built with tree-sharding support?
+  out[17] = EL_SIZE;                                                       // LDS doubles per wavefront (edge / node working set)
 }
 }  // namespace dompc
 
@@ -44,10 +45,11 @@ extern "C" __global__ void dompc_model_info_kernel(const int32_t* in, int64_t* o
 }
 
 extern "C" __global__ void __launch_bounds__(256, 2) dompc_solve_kernel(dompc::KArgs A) {
-  // one LDS pool: per-wavefront edge working sets during the sweep, reduction scratch otherwise
+  // one LDS pool (dynamic: the runtime sizes it for the number of wavefronts per workgroup it launches):
+  // per-wavefront edge working sets during the sweep, reduction scratch otherwise
   // (never live at the same time; every use is bracketed by workgroup barriers)
-  constexpr int POOL = (4 * dompc::EL_SIZE > dompc::RED_MAX * 256) ? 4 * dompc::EL_SIZE : dompc::RED_MAX * 256;
-  __shared__ double pool[POOL];
+  extern __shared__ double pool[];
+  const int POOL = A.pool_doubles;
   __shared__ double filt[2 * dompc::MAX_FILTER];
   __shared__ int flags[8];
   __shared__ int s_b;

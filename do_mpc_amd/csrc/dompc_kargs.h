@@ -33,7 +33,8 @@ struct KArgs {
   int32_t trace_cap, trace_pad;
   // wide mode: `wide` workgroups cooperate on one problem (small batches); per-slot barrier counters
   // (16 uints apart), reduction partials ([2][wide][12] doubles) and shared flags (8 ints)
-  int32_t wide, wide_pad;
+  int32_t wide;
+  int32_t pool_doubles;      // doubles in the dynamic LDS pool of a workgroup: max(waves * EL_SIZE, RED_MAX * threads)
   uint32_t* wide_bar;
   double* wide_partials;
   int32_t* wide_flags;
@@ -55,6 +56,9 @@ struct KArgs {
   volatile uint32_t* x_count;
   void (*x_callback)(void* ctx, double* buf, int32_t count);
   void* x_ctx;
+  // stop request (watchdog / dompc_abort): a word in pinned host memory, read once per IPM iteration by thread 0 of the
+  // problem and handed to the other threads through flags[6]; unfinished problems return status 6
+  const int32_t* abort_flag;
   // debugging aid: value the LDS pool is filled with when the kernel starts (0 in production), words [lo, hi)
   double lds_fill;
   int32_t lds_fill_lo, lds_fill_hi;

@@ -178,12 +178,31 @@ struct Thr {
   mutable unsigned gen, nred;
   XCtx X;           // tree sharding: exchange buffer and handshake words (X.on == 0: not sharded)
   mutable unsigned xseq;
+  // flags: LDS words in a one-workgroup problem; global words shared by the K workgroups of a wide problem - those are
+  // read and written with agent-scope atomics (a plain load could be served from this CU's L1).
+  DOMPC_DEV void fset(int i, int v) const {
+#ifndef DOMPC_HOST_EMU
+    if (nwg > 1) { __hip_atomic_store(flags + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+#endif
+    flags[i] = v;
+  }
+  DOMPC_DEV int fget(int i) const {
+#ifndef DOMPC_HOST_EMU
+    if (nwg > 1) return __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    return flags[i];
+  }
   DOMPC_DEV void sync() const {
 #ifndef DOMPC_HOST_EMU
-    __syncthreads();
     if (nwg > 1) {
-      // device-scope barrier (MI355X_MICROARCH.md, inter-workgroup visibility): release fence + drained
-      // vmcnt before the arrival, relaxed polling, acquire fence after; every spin is bounded.
+      // device-scope barrier (MI355X_MICROARCH.md, inter-workgroup visibility).  Release side: EVERY wavefront drains
+      // its own outstanding global stores (a workgroup-scope barrier does not wait for vmcnt outside tgsplit mode, so
+      // without this a peer wavefront's stores could still be in flight when wavefront 0 signals the arrival); after the
+      // workgroup barrier lane 0 writes the XCD's L2 back (agent-scope release), drains, and arrives on the monotonic
+      // counter.  Acquire side: relaxed polling (bounded), ONE agent-scope acquire (invalidates this CU's L1, which all
+      // wavefronts of the workgroup share), workgroup barrier, then plain loads.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       ++gen;
       if (ltid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -200,6 +219,8 @@ struct Thr {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
+      __syncthreads();
+    } else {
       __syncthreads();
     }
 #endif
@@ -269,6 +290,15 @@ DOMPC_DEV inline long long prof_clock() {
   return (long long)clock64();
 #else
   return 0;
+#endif
+}
+
+// stop request of the host (watchdog of the blocking entry points, dompc_abort): system-scope load of the pinned word
+DOMPC_DEV inline int abort_requested(const KArgs& A) {
+#ifndef DOMPC_HOST_EMU
+  return A.abort_flag ? __hip_atomic_load(A.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+#else
+  return A.abort_flag ? *(const volatile int32_t*)A.abort_flag : 0;
 #endif
 }
 
@@ -1892,7 +1922,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
   // barrier that never completes; seen as a timing-dependent failure of a 37-problem batch).  Hence the barrier
   // BEFORE the reset: every thread is past its last read of the previous pass.
   T.sync();
-  if (T.tid == 0) T.flags[0] = 0;
+  if (T.tid == 0) T.fset(0, 0);
   T.sync();
   {
     // leaves: P = sf*omega*Hm + Sigma_x, p = sf*omega*gm - nu_in + barrier
@@ -1939,13 +1969,13 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
           for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Ld[RB_PNV + it];
           T.gsync();
         }
-        if (riccati_node(T, Q, A.level_node_start[k] + s_, mu, delta, Ld, lane, GS, staged, R)) { T.flags[0] = 1; break; }
+        if (riccati_node(T, Q, A.level_node_start[k] + s_, mu, delta, Ld, lane, GS, staged, R)) { T.fset(0, 1); break; }
         staged = true;
         if (k > cl) R = Rn;
       }
     }
     T.sync();
-    if (T.flags[0] && !sh_on(A)) return 1;      // (sharded: the flag is only known to this rank until the cut exchange)
+    if (T.fget(0) && !sh_on(A)) return 1;      // (sharded: the flag is only known to this rank until the cut exchange)
   }
   for (int k = cl - 1; k >= 0; --k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
@@ -1954,10 +1984,10 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
       for (int n = n0 + gid; n < n1; n += ng) riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 1);
       T.xchg(x_c1(A), A.n_cut * CUT1);
       for (int n = n0 + gid; n < n1; n += ng)
-        if (riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 2)) T.flags[0] = 1;
+        if (riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 2)) T.fset(0, 1);
       T.sync();
       double* fl = A.xbuf + x_c2(A) + A.n_cut * CUT2;          // failure flags of all ranks ride along
-      for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && T.flags[0]) ? 1.0 : 0.0;
+      for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && T.fget(0)) ? 1.0 : 0.0;
       T.xchg(x_c2(A), A.n_cut * CUT2 + A.shard_world);
       for (int n = n0 + gid; n < n1; n += ng) riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 3);
       int bad = 0;
@@ -1970,10 +2000,10 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
       if (!mk_n(A, n)) continue;
       NodePre R;
       node_prefetch(Q, n, delta, lane, GS, R);
-      if (riccati_node(T, Q, n, mu, delta, Ld, lane, GS, false, R)) T.flags[0] = 1;
+      if (riccati_node(T, Q, n, mu, delta, Ld, lane, GS, false, R)) T.fset(0, 1);
     }
     T.sync();
-    if (T.flags[0] && (!sh_on(A) || k < A.cut_level - 1)) return 1;
+    if (T.fget(0) && (!sh_on(A) || k < A.cut_level - 1)) return 1;
   }
   return 0;
 }
@@ -2197,7 +2227,7 @@ struct Errs { double e_d, e_p, e_c0, sum_y, sum_z, obj, theta; };
 DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   const KArgs& A = *Q.A;
   T.sync();                                  // (every thread has read the previous sweep's verdict, see riccati_backward)
-  if (T.tid == 0) T.flags[1] = 0;
+  if (T.tid == 0) T.fset(1, 0);
   T.sync();
   for (int g = T.tid; g < NX; g += T.nt) Q.c[g] = Q.x[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
   eval_models(T, Q);
@@ -2211,7 +2241,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
       const int en = e + ng;
       const bool mine = e < A.n_edges && mk_e(A, e);
       if (sh_on(A) && !mine) continue;                  // sharded: another rank's edge (no workgroup barrier inside)
-      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld)) T.flags[1] = 1;
+      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld)) T.fset(1, 1);
     }
   }
   T.sync();
@@ -2230,7 +2260,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   if (sh_on(A)) {
     // cut parents: sum the child-dependent parts over the ranks; the failure flag rides along
     double* fl = A.xbuf + x_asm(A) + A.n_cut * ASM_N;
-    for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && T.flags[1]) ? 1.0 : 0.0;
+    for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && T.fget(1)) ? 1.0 : 0.0;
     T.xchg(x_asm(A), A.n_cut * ASM_N + A.shard_world);
     const int n0 = A.level_node_start[A.cut_level - 1];
     for (int ci = T.tid; ci < A.n_cut; ci += T.nt) assemble_finish(Q, n0 + ci, A.xbuf + x_asm(A) + ci * ASM_N);
@@ -2239,7 +2269,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     T.sync();
     return bad;
   }
-  return T.flags[1];
+  return T.fget(1);
 }
 
 // Barrier-parameter change at an unchanged iterate: only the barrier gradients move, linearly in mu.
@@ -2390,6 +2420,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   double mu = O.mu_init;
   Q.sf = 1.0;
   long long c_sweep = 0, c_bwd = 0, c_fwd = 0, c_ls = 0, c_meas = 0, c_t = 0; const long long c_start = prof_clock();
+  if (T.tid == 0) T.fset(6, abort_requested(A));      // (read by everybody at the top of the loop, barriers in between)
   int bad = sweep(T, Q, mu);
   ++n_sweeps;
   if (O.obj_scaling) {
@@ -2417,7 +2448,8 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
 
   while (true) {
     if (bad) { status = 3; break; }
-    if ((T.nwg > 1 || sh_on(A)) && T.flags[7]) { status = 5; break; }       // a peer workgroup never arrived at a barrier
+    if (T.fget(6)) { status = 6; break; }                                    // the host asked the kernel to stop
+    if ((T.nwg > 1 || sh_on(A)) && T.fget(7)) { status = 5; break; }       // a peer workgroup never arrived at a barrier
     const double sd = fmax(s_max, (E.sum_y + E.sum_z) / fmax(1.0, n_dual)) / s_max;
     const double sc = fmax(s_max, E.sum_z / fmax(1.0, n_bounds)) / s_max;
     E0 = fmax(E.e_d / sd, fmax(E.e_p, E.e_c0 / sc));
@@ -2637,6 +2669,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       tr[0] = it; tr[1] = mu; tr[2] = E0; tr[3] = E.e_p; tr[4] = E.e_d; tr[5] = accepted ? alpha : -alpha;
       tr[6] = delta; tr[7] = E.obj / Q.sf;
     }
+    if (T.tid == 0) T.fset(6, abort_requested(A));
     T.sync();
     ++it;
     c_t = prof_clock(); bad = sweep(T, Q, mu); c_sweep += prof_clock() - c_t;

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dompc_kargs.h"
@@ -32,7 +33,7 @@ struct dompc_handle {
   std::string error;
   std::string code_path;
   int32_t e_pad = 0, n_slots = 0, block = 256;
-  int64_t ws_stride = 0, sweep_block = 0;
+  int64_t ws_stride = 0, sweep_block = 0, el_size = 0;
   dompc::KArgs base;       // tables + workspace filled in, I/O pointers zero
   std::vector<void*> dev_allocs;
   // staging for host-pointer calls
@@ -49,6 +50,8 @@ struct dompc_handle {
   dompc_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
   uint32_t* x_words = nullptr;           // pinned host memory: [req, ack, count, off] (device build)
+  int32_t* abort_word = nullptr;         // pinned host memory (device build) / plain word: stop request read by the kernel
+  double watchdog_s = 600.0;
 #ifndef DOMPC_HOST_EMU
   // native RCCL collective (dlopen'ed): communicator of the sharded problem and its stream
   struct RcclUid { char internal[128]; };
@@ -86,6 +89,11 @@ static int dev_alloc(dompc_handle* h, void** p, size_t bytes) {
   h->dev_allocs.push_back(*p);
   return 0;
 }
+static void dev_release(dompc_handle* h, void* p) {
+  if (!p) return;
+  for (size_t i = 0; i < h->dev_allocs.size(); ++i)
+    if (h->dev_allocs[i] == p) { h->dev_allocs.erase(h->dev_allocs.begin() + i); hipFree(p); return; }
+}
 static int h2d(dompc_handle* h, void* dst, const void* src, size_t bytes) {
   if (!bytes) return 0;
   HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
@@ -100,6 +108,26 @@ static int dev_sync(dompc_handle* h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
+// Wait for `st` with the watchdog: after watchdog_s the stop request is raised (the kernel leaves its IPM loops with
+// status 6); if the stream still has not drained after a grace period the call fails instead of blocking forever.
+static int dev_sync_watchdog(dompc_handle* h, hipStream_t st) {
+  const auto t0 = std::chrono::steady_clock::now();
+  bool raised = false;
+  while (true) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) { h->error = std::string("hipStreamQuery: ") + hipGetErrorString(q); return 1; }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!raised && dt > h->watchdog_s) { __atomic_store_n(h->abort_word, 1, __ATOMIC_RELEASE); raised = true; }
+    if (raised && dt > h->watchdog_s + 30.0) {
+      h->error = "watchdog: the solver kernel did not finish and did not react to the stop request";
+      return 1;
+    }
+    if (dt > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(dt > 0.2 ? 500 : 20));
+  }
+  if (raised) __atomic_store_n(h->abort_word, 0, __ATOMIC_RELEASE);
+  return 0;
+}
 static int dev_zero(dompc_handle* h, void* p, size_t bytes, hipStream_t s) {
   HIPCHK(h, hipMemsetAsync(p, 0, bytes, s));
   return 0;
@@ -112,10 +140,21 @@ static int dev_alloc(dompc_handle* h, void** p, size_t bytes) {
   h->dev_allocs.push_back(*p);
   return 0;
 }
+static void dev_release(dompc_handle* h, void* p) {
+  if (!p) return;
+  for (size_t i = 0; i < h->dev_allocs.size(); ++i)
+    if (h->dev_allocs[i] == p) { h->dev_allocs.erase(h->dev_allocs.begin() + i); free(p); return; }
+}
 static int h2d(dompc_handle*, void* dst, const void* src, size_t bytes) { if (bytes) memcpy(dst, src, bytes); return 0; }
 static int d2h(dompc_handle*, void* dst, const void* src, size_t bytes) { if (bytes) memcpy(dst, src, bytes); return 0; }
 static int dev_sync(dompc_handle*) { return 0; }
 #endif
+
+extern "C" int dompc_abort(dompc_handle* h, int32_t stop) {
+  if (!h || !h->abort_word) return 1;
+  __atomic_store_n(h->abort_word, stop ? 1 : 0, __ATOMIC_RELEASE);
+  return 0;
+}
 
 template <typename Tp>
 static int upload(dompc_handle* h, const Tp** dst, const Tp* src, size_t n) {
@@ -144,6 +183,7 @@ extern "C" const char* dompc_status_string(int32_t s) {
     case 2: return "Maximum_Iterations_Exceeded";
     case 3: return "Error_In_Step_Computation";
     case 4: return "Invalid_Number_Detected";
+    case 6: return "User_Requested_Stop";
     default: return "Internal_Error";
   }
 }
@@ -158,11 +198,13 @@ extern "C" void dompc_destroy(dompc_handle* h) {
   if (h->module) hipModuleUnload(h->module);
   if (h->stream) hipStreamDestroy(h->stream);
   if (h->x_words) hipHostFree(h->x_words);
+  if (h->abort_word) hipHostFree(h->abort_word);
   if (h->shard_stream) hipStreamDestroy(h->shard_stream);
   if (h->rccl_comm && h->nccl_comm_destroy) h->nccl_comm_destroy(h->rccl_comm);
   if (h->rccl_stream) hipStreamDestroy(h->rccl_stream);
 #else
   for (void* p : h->dev_allocs) free(p);
+  free(h->abort_word);
 #endif
   delete h;
 }
@@ -170,7 +212,11 @@ extern "C" void dompc_destroy(dompc_handle* h) {
 static int ensure_staging(dompc_handle* h, int B) {
   if (B <= h->cap_batch) return 0;
   const dompc_problem_desc& d = h->d;
-  // (re)allocate; old buffers stay in dev_allocs and are released at destroy
+  // (re)allocate for the larger batch; the superseded per-batch buffers are released now
+  if (dev_sync(h)) return 1;
+  for (void* old : {(void*)h->s_x0, (void*)h->s_p, (void*)h->s_x, (void*)h->s_g, (void*)h->s_lamx, (void*)h->s_lamg,
+                    (void*)h->s_f, (void*)h->s_stats})
+    dev_release(h, old);
   if (dev_alloc(h, (void**)&h->s_x0, sizeof(double) * (size_t)B * d.n_opt_x)) return 1;
   if (dev_alloc(h, (void**)&h->s_p, sizeof(double) * (size_t)B * d.n_opt_p)) return 1;
   if (dev_alloc(h, (void**)&h->s_x, sizeof(double) * (size_t)B * d.n_opt_x)) return 1;
@@ -189,6 +235,14 @@ static int ensure_staging(dompc_handle* h, int B) {
   return 0;
 }
 
+static void* main_stream(dompc_handle* h) {      // the stream of the staging copies
+#ifndef DOMPC_HOST_EMU
+  return (void*)h->stream;
+#else
+  (void)h;
+  return nullptr;
+#endif
+}
 static void* own_stream(dompc_handle* h) {
 #ifndef DOMPC_HOST_EMU
   return (void*)((h->sharded && h->shard_stream) ? h->shard_stream : h->stream);
@@ -198,15 +252,18 @@ static void* own_stream(dompc_handle* h) {
 #endif
 }
 
-static int launch(dompc_handle* h, dompc::KArgs& A, int grid, void* stream_v) {
+// `block` threads per workgroup (a multiple of 64): the LDS pool is sized for block/64 wavefronts
+static int launch(dompc_handle* h, dompc::KArgs& A, int grid, int block, void* stream_v) {
 #ifndef DOMPC_HOST_EMU
   hipStream_t st = (hipStream_t)stream_v;          // nullptr = HIP default stream
   if (dev_zero(h, A.work_counter, sizeof(int32_t), st)) return 1;
+  const int64_t per_wave = (int64_t)(block / 64) * h->el_size, red = h->xlayout[0] * (int64_t)block;
+  A.pool_doubles = (int32_t)(per_wave > red ? per_wave : red);
   size_t sz = sizeof(A);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIPCHK(h, hipModuleLaunchKernel(h->fn_solve, grid, 1, 1, h->block, 1, 1, 0, st, nullptr, cfg));
+  HIPCHK(h, hipModuleLaunchKernel(h->fn_solve, grid, 1, 1, block, 1, 1, (unsigned)(A.pool_doubles * sizeof(double)), st, nullptr, cfg));
 #else
-  (void)grid; (void)stream_v;
+  (void)grid; (void)block; (void)stream_v;
   dompc_hostemu_run(&A);
 #endif
   return 0;
@@ -220,6 +277,8 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   const dompc_problem_desc& d = h->d;
   if (d.n_edges <= 0 || d.n_nodes <= 0 || d.n_opt_x <= 0) { h->error = "empty problem description"; return fail(1); }
   h->block = d.block_threads > 0 ? d.block_threads : 256;
+  if (const char* be = getenv("DOMPC_BLOCK")) h->block = atoi(be);                // tuning aid: threads per problem (64/128/256)
+  if (h->block != 64 && h->block != 128 && h->block != 256) { h->error = "block_threads must be 64, 128 or 256"; return fail(1); }
 #ifndef DOMPC_HOST_EMU
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -228,6 +287,8 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   }
   if (hipSetDevice(d.device) != hipSuccess) { h->error = "hipSetDevice failed"; return fail(1); }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->error = "hipStreamCreate failed"; return fail(1); }
+  if (hipHostMalloc((void**)&h->abort_word, 64, hipHostMallocMapped) != hipSuccess) { h->error = "hipHostMalloc failed"; return fail(1); }
+  *h->abort_word = 0;
   if (!d.code_object_path) { h->error = "code_object_path is null"; return fail(1); }
   h->code_path = d.code_object_path;
   if (hipModuleLoad(&h->module, h->code_path.c_str()) != hipSuccess) {
@@ -241,7 +302,9 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   }
 #else
   h->block = 1;
+  h->abort_word = (int32_t*)calloc(16, sizeof(int32_t));
 #endif
+  if (const char* wd = getenv("DOMPC_WATCHDOG_S")) h->watchdog_s = atof(wd);
   h->e_pad = ((d.n_edges + 15) / 16) * 16;
   // ---- model info from the code object
   int32_t in_h[5] = {d.n_opt_x, d.n_g, d.n_edges, h->e_pad, d.n_nodes};
@@ -282,9 +345,12 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   h->sweep_block = info[10];
   for (int i = 0; i < 4; ++i) h->xlayout[i] = info[12 + i];
   h->shard_capable = info[16] != 0;
-  // ---- slots
+  h->el_size = info[17];
+  // ---- slots: one per resident workgroup (2 wavefronts per SIMD = 8 per CU, 256 CUs)
   int max_batch = d.max_batch > 0 ? d.max_batch : 1;
-  h->n_slots = d.n_slots > 0 ? d.n_slots : (max_batch < 512 ? max_batch : 512);
+  const int resident = 512 * (256 / h->block);
+  h->n_slots = d.n_slots > 0 ? d.n_slots : (max_batch < resident ? max_batch : resident);
+  if (const char* se = getenv("DOMPC_SLOTS")) h->n_slots = atoi(se);
 #ifdef DOMPC_HOST_EMU
   h->n_slots = 1;
 #endif
@@ -338,6 +404,15 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   }
   A.n_slots = h->n_slots;
   A.ws_stride = h->ws_stride;
+#ifndef DOMPC_HOST_EMU
+  {
+    void* dw = nullptr;
+    if (hipHostGetDevicePointer(&dw, h->abort_word, 0) != hipSuccess) { h->error = "hipHostGetDevicePointer failed"; return fail(1); }
+    A.abort_flag = (const int32_t*)dw;
+  }
+#else
+  A.abort_flag = h->abort_word;
+#endif
   if (dev_alloc(h, (void**)&A.ws, sizeof(double) * (size_t)h->ws_stride * h->n_slots)) return fail(1);
 #ifndef DOMPC_HOST_EMU
   if (const char* fill = getenv("DOMPC_WS_FILL")) {      // debugging aid: poison the workspace (uninitialised reads)
@@ -491,7 +566,15 @@ static int serve_exchanges(dompc_handle* h, hipStream_t st) {
   volatile uint32_t* w = h->x_words;
   uint32_t served = 0;
   int rc = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool raised = false;
+  unsigned polls = 0;
   while (true) {
+    if ((++polls & 0xfffu) == 0) {               // watchdog (see dev_sync_watchdog)
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (!raised && dt > h->watchdog_s) { __atomic_store_n(h->abort_word, 1, __ATOMIC_RELEASE); raised = true; }
+      if (raised && dt > h->watchdog_s + 30.0) { h->error = "watchdog: the sharded solve did not finish"; rc = 1; break; }
+    }
     const uint32_t r = w[0];
     if (r != served) {
       __sync_synchronize();
@@ -514,6 +597,7 @@ static int serve_exchanges(dompc_handle* h, hipStream_t st) {
     }
   }
   hipEventDestroy(done);
+  if (raised) __atomic_store_n(h->abort_word, 0, __ATOMIC_RELEASE);
   return rc;
 }
 #endif
@@ -555,7 +639,7 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
     HIPCHK(h, hipMemsetAsync(A.wide_flags, 0, sizeof(int32_t) * 8 * 64, st));
   }
 #endif
-  if (launch(h, A, grid, stream)) return 1;
+  if (launch(h, A, grid, (A.wide > 1 || h->sharded) ? 256 : h->block, stream)) return 1;
 #ifndef DOMPC_HOST_EMU
   if (h->sharded) return serve_exchanges(h, (hipStream_t)stream);
 #endif
@@ -586,6 +670,10 @@ extern "C" int dompc_solve_batch(dompc_handle* h, int32_t B, const double* x0, c
   if (dompc_solve_batch_device(h, B, h->s_x0, h->s_lbx, h->s_ubx, h->s_lbg, h->s_ubg, h->s_p, h->s_x, h->s_g, h->s_lamx,
                                h->s_lamg, h->s_f, h->s_stats, own_stream(h)))
     return 1;
+#ifndef DOMPC_HOST_EMU
+  // wait here (bounded by the watchdog) before the result copies are queued behind the kernel
+  if (!h->sharded && dev_sync_watchdog(h, h->stream)) return 1;
+#endif
   if (x) rc |= d2h(h, x, h->s_x, sizeof(double) * (size_t)B * d.n_opt_x);
   if (g) rc |= d2h(h, g, h->s_g, sizeof(double) * (size_t)B * d.n_g);
   if (lam_x) rc |= d2h(h, lam_x, h->s_lamx, sizeof(double) * (size_t)B * d.n_opt_x);
@@ -618,7 +706,7 @@ extern "C" int dompc_sweep_batch_device(dompc_handle* h, int32_t B, const double
   A.p = p; A.sw_x = x; A.sw_lam = lam; A.sw_g = g; A.sw_blocks = blocks;
   A.batch = B; A.mode = 2;
   const int grid = B < h->n_slots ? B : h->n_slots;
-  return launch(h, A, grid, stream);
+  return launch(h, A, grid, h->block, stream);
 }
 
 extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const double* lam_g, const double* zl,
@@ -630,6 +718,7 @@ extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const d
   HIPCHK(h, hipSetDevice(h->d.device));
 #endif
   const dompc_problem_desc& d = h->d;
+  if (h->sharded) { h->error = "dompc_debug_newton_step is not available on a sharded handle (call dompc_set_sharding(h, NULL) first)"; return 1; }
   if (ensure_staging(h, 1)) return 1;
   int rc = 0;
   rc |= h2d(h, h->s_x0, x, sizeof(double) * d.n_opt_x);
@@ -648,7 +737,7 @@ extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const d
   A.dbg_dx = h->s_dbg[3]; A.dbg_dlam = h->s_dbg[4]; A.dbg_rd = h->s_dbg[5]; A.dbg_c = h->s_dbg[6];
   A.dbg_mu = mu; A.dbg_delta = delta_w;
   A.batch = 1; A.mode = 1;
-  if (launch(h, A, 1, own_stream(h))) return 1;
+  if (launch(h, A, 1, 256, main_stream(h))) return 1;
   if (dx) rc |= d2h(h, dx, h->s_dbg[3], sizeof(double) * d.n_opt_x);
   if (dlam) rc |= d2h(h, dlam, h->s_dbg[4], sizeof(double) * d.n_g);
   if (rd) rc |= d2h(h, rd, h->s_dbg[5], sizeof(double) * d.n_opt_x);

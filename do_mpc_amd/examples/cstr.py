@@ -40,7 +40,9 @@ def build_model(symvar_type="SX"):
     return mdl
 
 
-def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_deg=2, **overrides):
+def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_deg=2, track_sign=1.0, **overrides):
+    """track_sign=-1 turns the tracking cost into a concave one (C_b is pushed AWAY from 0.6, bounded only by the
+    box): a non-convex test problem whose reduced Hessian needs inertia correction in most iterations."""
     mpc = MPC(model)
     st = mpc.settings
     st.n_horizon, st.n_robust, st.open_loop = n_horizon, n_robust, 0
@@ -56,7 +58,7 @@ def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_
     mpc.scaling["_x", "T_K"] = 100
     mpc.scaling["_u", "Q_dot"] = 2000
     mpc.scaling["_u", "F"] = 100
-    track = (model.x["C_b"] - 0.6) ** 2
+    track = track_sign * (model.x["C_b"] - 0.6) ** 2
     mpc.set_objective(mterm=track, lterm=track)
     mpc.set_rterm(F=0.1, Q_dot=1e-3)
     for k, v in dict(C_a=0.1, C_b=0.1, T_R=50, T_K=50).items():

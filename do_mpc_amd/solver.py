@@ -104,6 +104,8 @@ def _load(lib_path: str) -> C.CDLL:
     lib.dompc_debug_newton_step.restype = C.c_int
     lib.dompc_debug_get_trace.argtypes = [vp, vp, C.c_int32]
     lib.dompc_debug_get_trace.restype = C.c_int
+    lib.dompc_abort.argtypes = [vp, C.c_int32]
+    lib.dompc_abort.restype = C.c_int
     lib.dompc_workspace_bytes.argtypes = [vp]
     lib.dompc_workspace_bytes.restype = C.c_int64
     lib.dompc_num_slots.argtypes = [vp]
@@ -329,6 +331,11 @@ class HipIpmSolver:
 
     def stats(self) -> dict:
         return dict(self._stats)
+
+    def abort(self, stop: bool = True):
+        """Stop request (dompc_abort): solves in flight leave their IPM loop with return_status
+        'User_Requested_Stop'; `abort(False)` re-arms the handle.  May be called from another thread."""
+        self._check(self._lib.dompc_abort(self._h, 1 if stop else 0))
 
     # ------------------------------------------------------------------ batch (host buffers)
     def solve_batch(self, X0, lbx, ubx, lbg, ubg, P):

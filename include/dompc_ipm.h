@@ -99,7 +99,8 @@ typedef struct dompc_problem_desc {
 typedef struct dompc_stats {
   int32_t success;          /* 1 = converged to tol (or acceptable level)                                  */
   int32_t status;           /* 0 Solve_Succeeded, 1 Solved_To_Acceptable_Level, 2 Maximum_Iterations_Exceeded,
-                               3 Error_In_Step_Computation, 4 Invalid_Number_Detected                      */
+                               3 Error_In_Step_Computation, 4 Invalid_Number_Detected, 5 Internal_Error (a peer
+                               workgroup / rank never arrived), 6 User_Requested_Stop (dompc_abort / watchdog)  */
   int32_t iter_count;
   int32_t n_reg;            /* iterations that needed Hessian regularisation                               */
   int32_t n_ls_fail;        /* line searches that hit alpha_min (no restoration phase)                     */
@@ -164,6 +165,13 @@ int dompc_debug_newton_step(dompc_handle* h,
 /* Iteration trace of problem 0 of the last solve: rows of 8 doubles (it, mu, E0, inf_pr, inf_du,
  * +-alpha (negative: line search failed), delta_w, obj). */
 int dompc_debug_get_trace(dompc_handle* h, double* out, int32_t max_rows);
+
+/* Stop request: running and queued solves of this handle leave their IPM loop at the next iteration and report
+ * status 6 (User_Requested_Stop, success = 0); may be called from another thread while a solve is in flight.
+ * stop = 0 re-arms the handle.  The blocking entry points (dompc_solve, dompc_solve_batch, the service loop of a
+ * sharded solve) raise it themselves when the device has not finished within the watchdog time (environment
+ * variable DOMPC_WATCHDOG_S, default 600 s) and return an error if the kernel does not react. */
+int dompc_abort(dompc_handle* h, int32_t stop);
 
 int64_t dompc_workspace_bytes(const dompc_handle* h);
 int32_t dompc_num_slots(const dompc_handle* h);

@@ -13,7 +13,7 @@ from do_mpc_amd.solver import HipIpmSolver
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_hostemu")
 
 
-def factory(structure, header, model_hash, nlpsol_opts=None, device=0, max_batch=1, **kw):
+def factory(structure, header, model_hash, nlpsol_opts=None, device=0, max_batch=1, block_threads=0, **kw):
     lib = build.hostemu_library(header, model_hash, OUT)
     return HipIpmSolver(structure, header, model_hash, nlpsol_opts=nlpsol_opts, device=device, max_batch=max_batch,
                         _lib_path=lib, _code_object="")

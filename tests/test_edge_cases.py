@@ -116,3 +116,22 @@ def test_vector_valued_nl_cons_equals_one_constraint_per_row():
     assert (psv.ne, psv.ns) == (pss.ne, pss.ns) == (2, 2) and psv.n_opt_x == pss.n_opt_x and psv.n_g == pss.n_g
     assert sv["success"] and ss["success"] and sv["iter_count"] == ss["iter_count"]
     assert np.array_equal(uv, us) and np.array_equal(xv, xs) and np.array_equal(lv, ls)
+
+
+def test_stop_request_returns_user_requested_stop():
+    """dompc_abort: a raised stop request makes a solve leave its IPM loop at the first check with status 6
+    (IPOPT's User_Requested_Stop); lowering it re-arms the handle."""
+    ex = CASES["batch_reactor"]
+    mpc = make("batch_reactor")
+    mpc.x0 = ex.X0
+    mpc.set_initial_guess()
+    mpc.S.abort(True)
+    mpc.make_step(ex.X0)
+    assert mpc.solver_stats["return_status"] == "User_Requested_Stop" and mpc.solver_stats["success"] is False
+    assert mpc.solver_stats["iter_count"] == 0
+    mpc.S.abort(False)
+    mpc.u0 = np.zeros(1)
+    mpc._t0 = mpc._t0 * 0
+    mpc.set_initial_guess()
+    mpc.make_step(ex.X0)
+    assert mpc.solver_stats["success"], mpc.solver_stats
