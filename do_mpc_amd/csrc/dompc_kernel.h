@@ -606,6 +606,20 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
   }
 }
 
+// value of `v` in lane `src` (wave-uniform, here a compile-time constant) for every lane: two v_readlane_b32, the
+// result lives in SGPRs.  Host emulation (one lane): the value itself.
+DOMPC_DEV inline double lane_bcast(double v, int src) {
+#ifndef DOMPC_HOST_EMU
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+#else
+  (void)src;
+  return v;
+#endif
+}
+
 DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, double mu, int lane, int GS, ldsd* Ld) {
   const KArgs& A = *Q.A;
   const bool act = e >= 0;
@@ -734,14 +748,132 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     }
     T.gsync();
     DOMPC_PH(1)
-    // ---- phase 4: in-place Gauss-Jordan inversion of [G_w | G_y | r_g], one matrix COLUMN per lane.
+    // ---- phase 4: [G_w | G_y | r_g] -> G_w^-1, W = -G_w^-1 G_y, w0 = -G_w^-1 r_g
+    if constexpr (NI == 1) {
+      // Single finite element: G_w = [[G_cc, 0], [E, I]] with the continuity rows E = -[D_1 I ... D_DEG I] below the
+      // R x R collocation block, so only G_cc is eliminated (the continuity rows of W, w0 follow as D-weighted sums).
+      // Register-resident Gauss-Jordan on the extended matrix [G_cc | G_y r | I], one COLUMN per lane (R + NA + 1 + R
+      // lanes: 54 for industrial_poly): per step the pivot column is broadcast with v_readlane (it ends up in SGPRs
+      // and feeds the FMAs as a scalar operand) - no LDS traffic and no barrier inside the elimination.
+      // Pivoting: the natural order is tried first (the diagonal of G_cc = h J - C (x) I carries the collocation
+      // coefficients C_jj) under a threshold test |a_kk| >= GJ_U max_{r >= k} |a_rk| evaluated by the lane that owns
+      // column k; if any test fails, the wavefront repeats the elimination from the untouched LDS copy with partial
+      // pivoting and explicit row interchanges (rare; measured: never on the BASELINE workloads).
+      // (The LDS variant - column per lane re-read and re-written every step, packed pivot keys - spent two thirds of
+      // its ~600 instructions per pair of steps on the redundant pivot search; this one issues ~85 per step.)
+      constexpr int R = DEG * NX, RA = R > 0 ? R : 1;
+      constexpr int NRHS = NA + 1;
+      constexpr int NCX = 2 * R + NRHS;                      // extended columns: G_cc | G_y r | I
+      constexpr int CPX = (NCX + GS_C - 1) / GS_C;
+      constexpr double GJ_U = 0.01;
+      double bc[CPX][RA];
+      auto load_cols = [&]() {
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) {
+          const int cx = lane + q * GS;
+          const int src = cx < R ? cx : (cx < R + NRHS ? NW + (cx - R) : 0);
+          const bool unit = cx >= R + NRHS;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const double v = Ld[EL_MX + r * NC + src];
+            bc[q][r] = unit ? ((cx - (R + NRHS) == r) ? 1.0 : 0.0) : v;
+          }
+        }
+      };
+      auto eliminate = [&](bool pivoting) -> int {           // returns 1: threshold test failed / singular block
+        int badl = 0;
+#pragma unroll
+        for (int kk = 0; kk < R; ++kk) {
+          const int qk = kk / GS_C, lk = kk % GS_C;          // column kk lives in slot qk of lane lk
+          if (pivoting) {
+            int pr = kk;
+            double best = fabs(bc[qk][kk]);
+#pragma unroll
+            for (int r = kk + 1; r < R; ++r) {
+              const double a = fabs(bc[qk][r]);
+              if (a > best) { best = a; pr = r; }
+            }
+            if (lane == lk && !(best > 1e-300)) badl = 1;
+#ifndef DOMPC_HOST_EMU
+            pr = __builtin_amdgcn_readlane(pr, lk);
+#endif
+#pragma unroll
+            for (int q = 0; q < CPX; ++q) {                  // rows kk <-> pr (the appended identity is permuted along)
+              const double t = bc[q][kk];
+              double nk = t;
+#pragma unroll
+              for (int r = kk + 1; r < R; ++r) {
+                const bool hit = (r == pr);
+                nk = hit ? bc[q][r] : nk;
+                bc[q][r] = hit ? t : bc[q][r];
+              }
+              bc[q][kk] = nk;
+            }
+          } else {
+            double m = 0.0;
+#pragma unroll
+            for (int r = kk + 1; r < R; ++r) m = fmax(m, fabs(bc[qk][r]));
+            const double akk = fabs(bc[qk][kk]);
+            if (lane == lk && !(akk >= GJ_U * m && akk > 1e-300)) badl = 1;
+          }
+          double f[RA];
+#pragma unroll
+          for (int r = 0; r < R; ++r) f[r] = lane_bcast(bc[qk][r], lk);
+          const double pinv = 1.0 / ((fabs(f[kk]) > 1e-300) ? f[kk] : 1.0);
+#pragma unroll
+          for (int q = 0; q < CPX; ++q) {
+            const double prow = bc[q][kk] * pinv;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              if (r != kk) bc[q][r] = fma(-f[r], prow, bc[q][r]);
+            bc[q][kk] = prow;
+          }
+        }
+#ifndef DOMPC_HOST_EMU
+        return __ballot(badl) != 0ull;
+#else
+        return badl;
+#endif
+      };
+      if (act) {
+        load_cols();
+        if (eliminate(false)) {
+          load_cols();
+          if (eliminate(true)) fail = 1;
+        }
+      }
+      T.gsync();                                             // (every lane has read its columns: Mx may be overwritten)
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) {
+          const int cx = lane + q * GS;
+          if (cx >= R && cx < R + NRHS) {
+            // right-hand sides: W = -G_w^-1 G_y, w0 = -G_w^-1 r_g; continuity row a = assembled entry + sum_r D_r row((r-1)NX+a)
+            const int col = NW + (cx - R);
+#pragma unroll
+            for (int a_ = 0; a_ < NX; ++a_) {
+              double t = Ld[EL_MX + (R + a_) * NC + col];
+#pragma unroll
+              for (int r = 1; r <= DEG; ++r) t += DOMPC_D[r] * bc[q][(r - 1) * NX + a_];
+              Ld[EL_MX + (R + a_) * NC + col] = -t;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + col] = -bc[q][r];
+          } else if (cx >= R + NRHS && cx < NCX) {
+            const int col = cx - (R + NRHS);                 // column `col` of G_cc^-1 (kept for the multiplier recovery)
+#pragma unroll
+            for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + col] = bc[q][r];
+          }
+        }
+      }
+      T.gsync();
+    } else {
+    // in-place Gauss-Jordan inversion of [G_w | G_y | r_g] in LDS, one matrix COLUMN per lane.
     // Per step every lane loads column kk (same addresses for all lanes -> LDS broadcast) and, in the same
     // LDS round trip, its own column; the pivot row is found redundantly with a packed (|value| high word,
     // row) key - no cross-lane reduction and no row interchange (the pivot row of each column is remembered
     // and the rows are relabelled once at the end), so a step is ONE wavefront barrier and two LDS round
-    // trips.  Column kk becomes the kk-th column of the inverse in place.  (A register-resident variant -
-    // column per lane in VGPRs, v_readlane broadcast of column kk, scalar pivot search - was measured 25 %
-    // slower on MI355X: ~250 extra VALU/SALU instructions per step cost more than the LDS traffic they save.)
+    // trips.  Column kk becomes the kk-th column of the inverse in place.
     // Structure: rows/columns come in groups [collocation rows of element i | continuity rows of element i]
     // (optimizer.py:943-983) and G_w is block lower-triangular in that grouping.  Pivots are searched inside
     // the group of the current column only (the diagonal blocks are the nonsingular collocation Jacobians,
@@ -753,125 +885,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       constexpr int EL_ROWS = (DEG + 1) * NX;
       constexpr int CPL = (NC + GS_C - 1) / GS_C;
       unsigned long long used = 0ull;
-      if constexpr (NI == 1) {
-        // Single finite element: G_w = [[G_cc, 0], [E, I]] with the continuity rows E = -[D_1 I ... D_DEG I]
-        // below the collocation block.  Only the R = DEG*NX collocation rows are eliminated (the continuity
-        // rows follow afterwards as D-weighted sums of the finished rows), and two pivot columns are
-        // processed per LDS pass: the second column is updated redundantly in registers, so each pass reads
-        // 3R and writes R+2 values per lane instead of 4R / 2R+2 (the phase is bound by LDS instruction
-        // issue, stores cost 3x a load).
-        constexpr int R = DEG * NX, RA = R > 0 ? R : 1;
-        auto keyof = [](double v, int r) -> unsigned {
-          return (((unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32)) & 0x7fffffc0u) | (unsigned)r;
-        };
-        int kk = 0;
-        for (; kk + 1 < R; kk += 2) {
-          double f0[RA], f1[RA], bcol[CPL][RA];
-          unsigned key0 = 0u, key1 = 0u;
-          if (act) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) { f0[r] = Ld[EL_MX + r * NC + kk]; f1[r] = Ld[EL_MX + r * NC + kk + 1]; }
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-              const int c = lane + q * GS;
-              const int cc_ = c < NC ? c : 0;
-#pragma unroll
-              for (int r = 0; r < R; ++r) bcol[q][r] = Ld[EL_MX + r * NC + cc_];
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              unsigned key = keyof(f0[r], r);
-              key = !((used >> r) & 1ull) ? key : 0u;
-              key0 = key > key0 ? key : key0;
-            }
-          }
-          const int p0 = (int)(key0 & 63u);
-          used |= (1ull << p0);
-          if (act && (key0 >> 6) == 0u) fail = 1;
-          double pinv0 = 1.0, f1p0 = 0.0;
-          if (act) {
-            const double piv0 = Ld[EL_MX + p0 * NC + kk];
-            pinv0 = (fabs(piv0) > 1e-300) ? 1.0 / piv0 : 1.0;
-            f1p0 = Ld[EL_MX + p0 * NC + kk + 1] * pinv0;          // row p0 of column kk+1 after the first step
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              f1[r] = fma(-f0[r], f1p0, f1[r]);                   // column kk+1 after the first step (rows != p0)
-              unsigned key = keyof(f1[r], r);
-              key = !((used >> r) & 1ull) ? key : 0u;
-              key1 = key > key1 ? key : key1;
-            }
-          }
-          const int p1 = (int)(key1 & 63u);
-          used |= (1ull << p1);
-          if (act && (key1 >> 6) == 0u) fail = 1;
-          if (act) {
-            if (lane == 0) { Ld[EL_PV + kk] = (double)p0; Ld[EL_PV + kk + 1] = (double)p1; }
-            const double f0p1 = Ld[EL_MX + p1 * NC + kk];
-            const double piv1 = fma(-f0p1, f1p0, Ld[EL_MX + p1 * NC + kk + 1]);
-            const double pinv1 = (fabs(piv1) > 1e-300) ? 1.0 / piv1 : 1.0;
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-              const int c = lane + q * GS;
-              if (c < NC) {
-                const bool is0 = (c == kk), is1 = (c == kk + 1);
-                const double keep0 = is0 ? 0.0 : 1.0, keep1 = is1 ? 0.0 : 1.0;
-                const double prow0 = is0 ? pinv0 : Ld[EL_MX + p0 * NC + c] * pinv0;
-                const double bp1 = fma(-f0p1, prow0, Ld[EL_MX + p1 * NC + c] * keep0);   // row p1 after the first step
-                const double prow1 = is1 ? pinv1 : bp1 * pinv1;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                  const double t = fma(-f0[r], prow0, bcol[q][r] * keep0);
-                  Ld[EL_MX + r * NC + c] = fma(-f1[r], prow1, t * keep1);
-                }
-                Ld[EL_MX + p0 * NC + c] = fma(-f1p0, prow1, prow0 * keep1);
-                Ld[EL_MX + p1 * NC + c] = prow1;
-              }
-            }
-          }
-          T.gsync();
-        }
-        for (; kk < R; ++kk) {              // odd R: last column alone
-          double f[RA], bcol[CPL][RA];
-          unsigned bestkey = 0u;
-          if (act) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) f[r] = Ld[EL_MX + r * NC + kk];
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-              const int c = lane + q * GS;
-              const int cc_ = c < NC ? c : 0;
-#pragma unroll
-              for (int r = 0; r < R; ++r) bcol[q][r] = Ld[EL_MX + r * NC + cc_];
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-              unsigned key = keyof(f[r], r);
-              key = !((used >> r) & 1ull) ? key : 0u;
-              bestkey = key > bestkey ? key : bestkey;
-            }
-          }
-          const int pv = (int)(bestkey & 63u);
-          used |= (1ull << pv);
-          if (act && (bestkey >> 6) == 0u) fail = 1;
-          if (act) {
-            if (lane == 0) Ld[EL_PV + kk] = (double)pv;
-            const double piv = Ld[EL_MX + pv * NC + kk];
-            const double pinv = (fabs(piv) > 1e-300) ? 1.0 / piv : 1.0;
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-              const int c = lane + q * GS;
-              if (c < NC) {
-                const double prow = (c == kk) ? pinv : Ld[EL_MX + pv * NC + c] * pinv;
-                const double keep = (c == kk) ? 0.0 : 1.0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + c] = fma(-f[r], prow, bcol[q][r] * keep);
-                Ld[EL_MX + pv * NC + c] = prow;
-              }
-            }
-          }
-          T.gsync();
-        }
-      } else {
+      {
         for (int kk = 0; kk < GJ_STEPS; ++kk) {
           const int pos = kk % EL_ROWS;
           const int grp0 = kk - pos + (pos < DEG * NX ? 0 : DEG * NX);
@@ -947,23 +961,6 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
       T.gsync();
     }
-    if constexpr (NI == 1) {
-      // continuity rows: G_w^-1[R+a][c] = sum_r D_r * G_w^-1[(r-1)*NX + a][c]   (+ the assembled entry for the
-      // right-hand sides; the xkf columns keep their identity block)
-      constexpr int R = DEG * NX;
-      if (act) {
-        for (int it = lane; it < NX * NC; it += GS) {
-          const int a_ = it / NC, c = it % NC;
-          if (c < R || c >= NW) {
-            double t = (c >= NW) ? Ld[EL_MX + (R + a_) * NC + c] : 0.0;
-#pragma unroll
-            for (int r = 1; r <= DEG; ++r) t += DOMPC_D[r] * Ld[EL_MX + ((r - 1) * NX + a_) * NC + c];
-            Ld[EL_MX + (R + a_) * NC + c] = t;
-          }
-        }
-      }
-      T.gsync();
-    }
     // now: Mx[:, :NW] = G_w^-1 ; Mx[:, NW:NW+NA] = G_w^-1 G_y = -W ; Mx[:, NW+NA] = G_w^-1 r_g = -w0
     if (act) {
       for (int it = lane; it < NW * (NA + 1); it += GS) {
@@ -972,6 +969,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
     }
     T.gsync();
+    }
     DOMPC_PH(2)
     // ---- phase 5: T1 = Hww W, t0 = Hww w0, U1 = Huw W, u0 = Huw w0   (Hww = blockdiag(Hxx_p) + Sigma_w)
     //      (stage-cost / nl_cons Hessian entries for phase 6 are requested now, consumed there)
