@@ -81,7 +81,7 @@ def _compile_to(cmd_without_out, out: str, what: str) -> None:
 
 def _sources_digest() -> str:
     h = hashlib.sha256()
-    for fn in ("dompc_kernel.h", "dompc_kargs.h", "dompc_device.hip", "dompc_runtime.cpp"):
+    for fn in ("dompc_kernel.h", "dompc_riccati16.h", "dompc_kargs.h", "dompc_device.hip", "dompc_runtime.cpp"):
         with open(os.path.join(CSRC, fn), "rb") as f:
             h.update(f.read())
     with open(os.path.join(INCLUDE, "dompc_ipm.h"), "rb") as f:

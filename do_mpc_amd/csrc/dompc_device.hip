@@ -45,34 +45,20 @@ extern "C" __global__ void dompc_model_info_kernel(const int32_t* in, int64_t* o
 }
 
 extern "C" __global__ void __launch_bounds__(256, 2) dompc_solve_kernel(dompc::KArgs A) {
-  // one LDS pool (dynamic: the runtime sizes it for the number of wavefronts per workgroup it launches):
-  // per-wavefront edge working sets during the sweep, reduction scratch otherwise
-  // (never live at the same time; every use is bracketed by workgroup barriers)
-  extern __shared__ double pool[];
+  using namespace dompc;
   const int POOL = A.pool_doubles;
-  __shared__ double filt[2 * dompc::MAX_FILTER];
-  __shared__ int flags[8];
-  __shared__ int s_b;
-  __shared__ long long prof[8];
-  if (threadIdx.x < 8) { prof[threadIdx.x] = 0; flags[threadIdx.x] = 0; }
+  if (threadIdx.x < 8) { lds_prof[threadIdx.x] = 0; lds_flags[threadIdx.x] = 0; }
   // defined LDS contents at kernel start (the pool of the previous kernel on this CU is still in there)
-  for (int i = threadIdx.x; i < POOL; i += blockDim.x) pool[i] = (i >= A.lds_fill_lo && i < A.lds_fill_hi) ? A.lds_fill : 0.0;
-  for (int i = threadIdx.x; i < 2 * dompc::MAX_FILTER; i += blockDim.x) filt[i] = 0.0;
+  for (int i = threadIdx.x; i < POOL; i += blockDim.x) lds_pool[i] = (i >= A.lds_fill_lo && i < A.lds_fill_hi) ? A.lds_fill : 0.0;
+  for (int i = threadIdx.x; i < 2 * MAX_FILTER; i += blockDim.x) lds_filt[i] = 0.0;
   __syncthreads();
-  // Thread context.  Normal mode: one workgroup per problem, problems pulled from a device-wide counter.
-  // Wide mode (small batches): K = A.wide workgroups per problem, static assignment problem = slot, all
-  // on one XCD when the dispatcher places block b on XCD b % 8 (affinity only - the barrier protocol does
-  // not depend on it): b = 8*q + r, workgroup-in-problem j = q % K, slot = (q / K) * 8 + r.
+  // Thread context (make_thr).  Normal mode: one workgroup per problem, problems pulled from a device-wide counter.
+  // Wide mode (small batches): K = A.wide workgroups per problem, static assignment problem = slot.
   const bool wide = (A.mode == 0 && A.wide > 1);
-  const int K = wide ? A.wide : 1;
-  const int q = blockIdx.x / 8;
-  const int j = wide ? q % K : 0;
-  const int slot = wide ? (q / K) * 8 + (int)(blockIdx.x % 8) : (int)blockIdx.x;
+  const int slot = slot_of_block(A);
   if (wide && slot >= A.batch) return;
-  dompc::Thr T{j * (int)blockDim.x + (int)threadIdx.x, K * (int)blockDim.x, (dompc::ldsd*)pool, (dompc::ldsd*)filt,
-               wide ? A.wide_flags + slot * 8 : flags, (dompc::ldsd*)pool, prof, 64,
-               (int)threadIdx.x, (int)blockDim.x, j, K, wide ? A.wide_bar + slot * 16 : nullptr,
-               wide ? A.wide_partials + (int64_t)slot * 2 * K * dompc::RED_MAX : nullptr, 0u, 0u, dompc::make_xctx(A), 0u};
+  Thr T = make_thr(A);
+  T.kp = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
   if (A.mode == 1) {
     if (blockIdx.x == 0) dompc::debug_newton(T, A);
     return;
@@ -86,9 +72,9 @@ extern "C" __global__ void __launch_bounds__(256, 2) dompc_solve_kernel(dompc::K
       if (!first) break;
       b = slot;
     } else {
-      if (threadIdx.x == 0) s_b = atomicAdd(A.work_counter, 1);
+      if (threadIdx.x == 0) lds_b = atomicAdd(A.work_counter, 1);
       __syncthreads();
-      b = s_b;
+      b = lds_b;
       __syncthreads();
       if (b >= A.batch) break;
     }
@@ -114,7 +100,7 @@ extern "C" void dompc_hostemu_run(const dompc::KArgs* A) {
     for (int i = 0; i < dompc::RED_MAX; ++i) red[i] = v;
     for (int i = 0; i < 2 * dompc::MAX_FILTER; ++i) filt[i] = v;
   }
-  dompc::Thr T{0, 1, red, filt, flags, edge_lds, nullptr, 1, 0, 1, 0, 1, nullptr, nullptr, 0u, 0u, dompc::make_xctx(*A), 0u};
+  dompc::Thr T{0, 1, red, filt, flags, edge_lds, nullptr, 1, 0, 1, 0, 1, nullptr, nullptr, 0u, 0u, dompc::make_xctx(*A), 0u, nullptr};
   if (A->mode == 1) { dompc::debug_newton(T, *A); return; }
   for (int b = 0; b < A->batch; ++b) {
     if (A->mode == 2) dompc::sweep_problem(T, *A, b, 0);

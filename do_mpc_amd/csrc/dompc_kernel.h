@@ -178,6 +178,7 @@ struct Thr {
   mutable unsigned gen, nred;
   XCtx X;           // tree sharding: exchange buffer and handshake words (X.on == 0: not sharded)
   mutable unsigned xseq;
+  const void* kp;   // device: the kernel's argument block in the kernarg segment (handed to the outlined phases)
   // flags: LDS words in a one-workgroup problem; global words shared by the K workgroups of a wide problem - those are
   // read and written with agent-scope atomics (a plain load could be served from this CU's L1).
   DOMPC_DEV void fset(int i, int v) const {
@@ -269,6 +270,54 @@ struct Thr {
 #endif
   }
 };
+
+#ifndef DOMPC_HOST_EMU
+// LDS of a workgroup (file scope: the outlined phase functions below rebuild their thread context from it).
+// One pool (dynamic: the runtime sizes it for the wavefronts per workgroup it launches): per-wavefront edge / node working
+// sets during sweeps and Riccati passes, reduction scratch otherwise (never live at the same time; every use is
+// bracketed by workgroup barriers).
+extern __shared__ double lds_pool[];
+__shared__ double lds_filt[2 * MAX_FILTER];
+__shared__ int lds_flags[8];
+__shared__ int lds_b;
+__shared__ long long lds_prof[8];
+
+// slot of the calling workgroup: normal mode one workgroup per problem slot; wide mode (small batches) K = A.wide
+// workgroups per problem, all on one XCD when the dispatcher places block b on XCD b % 8 (affinity only - the barrier
+// protocol does not depend on it): b = 8*q + r, workgroup-in-problem j = q % K, slot = (q / K) * 8 + r.
+__device__ inline int slot_of_block(const KArgs& A) {
+  const bool wide = (A.mode == 0 && A.wide > 1);
+  const int q = blockIdx.x / 8;
+  return wide ? (q / A.wide) * 8 + (int)(blockIdx.x % 8) : (int)blockIdx.x;
+}
+__device__ inline Thr make_thr(const KArgs& A) {
+  const bool wide = (A.mode == 0 && A.wide > 1);
+  const int K = wide ? A.wide : 1;
+  const int q = blockIdx.x / 8;
+  const int j = wide ? q % K : 0;
+  const int slot = slot_of_block(A);
+  return Thr{j * (int)blockDim.x + (int)threadIdx.x, K * (int)blockDim.x, (ldsd*)lds_pool, (ldsd*)lds_filt,
+             wide ? A.wide_flags + slot * 8 : lds_flags, (ldsd*)lds_pool, lds_prof, 64,
+             (int)threadIdx.x, (int)blockDim.x, j, K, wide ? A.wide_bar + slot * 16 : nullptr,
+             wide ? A.wide_partials + (int64_t)slot * 2 * K * RED_MAX : nullptr, 0u, 0u, make_xctx(A), 0u, nullptr};
+}
+// wave-uniform copies of values that reach an outlined function in vector registers
+__device__ inline int ufl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline unsigned ufl(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline double ufl(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = ufl((unsigned)u), hi = ufl((unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+// The kernel's argument block, read through the kernarg-segment pointer the kernel obtained and passed down (the
+// pointer builtin itself is only valid inside the kernel function): made uniform -> scalar loads.
+typedef const __attribute__((address_space(4))) KArgs* KArgsCP;
+__device__ inline KArgs kernel_args(const void* kp) {
+  const unsigned long long u = (unsigned long long)kp;
+  const unsigned lo = ufl((unsigned)u), hi = ufl((unsigned)(u >> 32));
+  return *(KArgsCP)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+#endif
 
 // ---- tree sharding: masks 0 = another rank's, 1 = mine, 2 = replicated (identical everywhere; counted once).
 // The support is compiled in only with -DDOMPC_SHARD=1 (a second code object per model, build.py): in the
@@ -1898,7 +1947,17 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
   return 0;
 }
 
+}  // namespace dompc
+#include "dompc_riccati16.h"
+namespace dompc {
+
 DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double delta) {
+#ifndef DOMPC_HOST_EMU
+  // register-resident matrix-core recursion (dompc_riccati16.h) unless the model is too large for one tile or the
+  // caller asked for the generic LDS-staged path (option dompc.generic_riccati: A/B checks)
+  if constexpr (r16::ENABLED)
+    if (!(Q.A->opt.reserved & 1)) return r16::backward(T, Q, mu, delta);
+#endif
   // One group of lanes (a wavefront) per tree node, the node's matrices staged in the group's LDS region:
   //   RB_QO  own quadratic of the node over (x, u_prev, u, eps)       (NYT x NYT) + gradient
   //   RB_QF  the same plus the children's value functions (coupling)  -> K = -Qvv^-1 Qvx
@@ -2346,6 +2405,69 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, double mu_c) {
 }
 
 // ================================================================================================
+// Outlined phases.  Inlined into one kernel, the phases share one register allocation: values that live across the
+// whole IPM loop get spilled around the register-hungry phases and are reloaded from scratch at every use inside
+// the hot loops of the others (measured: adding the matrix-core Riccati pass made the SWEEP 45 % slower).  As
+// separate functions each phase has the whole register file; its context is rebuilt inside from uniform sources
+// (kernel arguments from the kernarg segment, block / thread indices, v_readfirstlane of the few scalar arguments), so
+// nothing is passed through memory.  Host emulation: plain calls.
+struct PhaseRet { unsigned gen, nred, xseq; int rc; };
+#ifndef DOMPC_HOST_EMU
+#define DOMPC_PHASE_PROLOGUE                                                        \
+  const KArgs A = kernel_args(kp);                                                  \
+  Thr T = make_thr(A);                                                              \
+  T.kp = kp;                                                                        \
+  T.gen = ufl(gen); T.nred = ufl(nred); T.xseq = ufl(xseq);                         \
+  Prob Q = make_prob(A, ufl(slot), A.p + (int64_t)ufl(b) * A.n_opt_p);              \
+  Q.sf = ufl(sf);
+__device__ __attribute__((noinline)) PhaseRet phase_sweep(const void* kp, int b, int slot, double sf, double mu, unsigned gen, unsigned nred, unsigned xseq) {
+  DOMPC_PHASE_PROLOGUE
+  const int rc = sweep(T, Q, ufl(mu));
+  return PhaseRet{T.gen, T.nred, T.xseq, rc};
+}
+__device__ __attribute__((noinline)) PhaseRet phase_backward(const void* kp, int b, int slot, double sf, double mu, double delta, unsigned gen, unsigned nred, unsigned xseq) {
+  DOMPC_PHASE_PROLOGUE
+  const int rc = riccati_backward(T, Q, ufl(mu), ufl(delta));
+  return PhaseRet{T.gen, T.nred, T.xseq, rc};
+}
+__device__ __attribute__((noinline)) PhaseRet phase_forward(const void* kp, int b, int slot, double sf, double mu, double delta, unsigned gen, unsigned nred, unsigned xseq) {
+  DOMPC_PHASE_PROLOGUE
+  riccati_forward(T, Q, ufl(mu), ufl(delta));
+  return PhaseRet{T.gen, T.nred, T.xseq, 0};
+}
+#undef DOMPC_PHASE_PROLOGUE
+#define DOMPC_PHASE_CALL(fn, ...)                                                   \
+  const PhaseRet r_ = fn(T.kp, b, slot, Q.sf, __VA_ARGS__, T.gen, T.nred, T.xseq);        \
+  T.gen = ufl(r_.gen); T.nred = ufl(r_.nred); T.xseq = ufl(r_.xseq);
+#endif
+DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu) {
+#ifndef DOMPC_HOST_EMU
+  DOMPC_PHASE_CALL(phase_sweep, mu)
+  return ufl(r_.rc);
+#else
+  (void)b; (void)slot;
+  return sweep(T, Q, mu);
+#endif
+}
+DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta) {
+#ifndef DOMPC_HOST_EMU
+  DOMPC_PHASE_CALL(phase_backward, mu, delta)
+  return ufl(r_.rc);
+#else
+  (void)b; (void)slot;
+  return riccati_backward(T, Q, mu, delta);
+#endif
+}
+DOMPC_DEV inline void run_forward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta) {
+#ifndef DOMPC_HOST_EMU
+  DOMPC_PHASE_CALL(phase_forward, mu, delta)
+#else
+  (void)b; (void)slot;
+  riccati_forward(T, Q, mu, delta);
+#endif
+}
+
+// ================================================================================================
 DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slot) {
   const dompc_options& O = A.opt;
   Prob Q = make_prob(A, slot, A.p + (int64_t)b * A.n_opt_p);
@@ -2419,7 +2541,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   Q.sf = 1.0;
   long long c_sweep = 0, c_bwd = 0, c_fwd = 0, c_ls = 0, c_meas = 0, c_t = 0; const long long c_start = prof_clock();
   if (T.tid == 0) T.fset(6, abort_requested(A));      // (read by everybody at the top of the loop, barriers in between)
-  int bad = sweep(T, Q, mu);
+  int bad = run_sweep(T, Q, b, slot, mu);
   ++n_sweeps;
   if (O.obj_scaling) {
     double gm[1] = {0.0};
@@ -2429,7 +2551,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     wg_reduce(T, gm, ops);
     if (gm[0] > O.nlp_scaling_max_gradient) {
       Q.sf = fmax(O.nlp_scaling_max_gradient / gm[0], 1e-8);
-      bad = sweep(T, Q, mu);
+      bad = run_sweep(T, Q, b, slot, mu);
       ++n_sweeps;
     }
   }
@@ -2477,7 +2599,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     double delta = 0.0;
     bool first_try = true, dir_ok = true;
     while (true) {
-      c_t = prof_clock(); const int fail = riccati_backward(T, Q, mu, delta); c_bwd += prof_clock() - c_t;
+      c_t = prof_clock(); const int fail = run_backward(T, Q, b, slot, mu, delta); c_bwd += prof_clock() - c_t;
       if (!fail) break;
       if (delta == 0.0) {
         delta = (delta_last == 0.0) ? O.delta_w_0 : fmax(O.delta_w_min, O.kappa_w_minus * delta_last);
@@ -2489,7 +2611,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     }
     if (!dir_ok) { status = 3; break; }
     if (delta > 0.0) { delta_last = delta; ++n_reg; }
-    c_t = prof_clock(); riccati_forward(T, Q, mu, delta); c_fwd += prof_clock() - c_t;
+    c_t = prof_clock(); run_forward(T, Q, b, slot, mu, delta); c_fwd += prof_clock() - c_t;
 
     // ---- fraction to the boundary, directional derivative of the barrier function
     double r5[5] = {1.0, 1.0, 0.0, 0.0, 0.0};   // a_max, a_z, dphi, barrier-sum, (unused)
@@ -2670,7 +2792,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (T.tid == 0) T.fset(6, abort_requested(A));
     T.sync();
     ++it;
-    c_t = prof_clock(); bad = sweep(T, Q, mu); c_sweep += prof_clock() - c_t;
+    c_t = prof_clock(); bad = run_sweep(T, Q, b, slot, mu); c_sweep += prof_clock() - c_t;
     ++n_sweeps;
     c_t = prof_clock(); E = measure(T, Q, 0.0); c_meas += prof_clock() - c_t;
   }
@@ -2740,9 +2862,9 @@ DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A) {
     T.sync();
   }
   Q.sf = 1.0;
-  sweep(T, Q, A.dbg_mu);
-  const int fail = riccati_backward(T, Q, A.dbg_mu, A.dbg_delta);
-  riccati_forward(T, Q, A.dbg_mu, A.dbg_delta);
+  run_sweep(T, Q, 0, 0, A.dbg_mu);
+  const int fail = run_backward(T, Q, 0, 0, A.dbg_mu, A.dbg_delta);
+  run_forward(T, Q, 0, 0, A.dbg_mu, A.dbg_delta);
   for (int g = T.tid; g < nX; g += T.nt) {
     A.dbg_dx[g] = fail ? NAN : Q.dx[g];
     A.dbg_rd[g] = Q.rd[g];
@@ -2770,7 +2892,7 @@ DOMPC_DEV inline void sweep_problem(const Thr& T, const KArgs& A, int b, int slo
   }
   T.sync();
   Q.sf = 1.0;
-  sweep(T, Q, 0.0);
+  run_sweep(T, Q, b, slot, 0.0);
   double* gout = A.sw_g + (int64_t)b * A.n_g;
   for (int r = T.tid; r < A.n_g; r += T.nt) gout[r] = Q.c[r];
   double* bl = A.sw_blocks + (int64_t)b * A.n_edges * SWEEP_BLOCK;

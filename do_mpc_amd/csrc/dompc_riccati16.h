@@ -1,0 +1,334 @@
+// dompc_riccati16.h - tree Riccati recursion on the FP64 matrix cores with register-resident tiles (gfx950 only).
+//
+// The node quadratic of the reference NLP lives over z = (x, u_prev, u [, eps]) - 16 entries for industrial_poly - and
+// every matrix of the backward recursion (P_c, F = [[A|0|B],[0|0|I]], Q, the gains) fits ONE 16x16 tile of
+// v_mfma_f64_16x16x4_f64.  A tile is kept in the ACCUMULATOR layout of that instruction,
+//     lane l holds  M[(l >> 4) + 4 r][l & 15],  r = 0..3        (4 doubles per lane),
+// and the operand layouts of the instruction make such a tile directly usable
+//     * as the B operand of k-block r  (B[4r + (l>>4)][l&15]  = element r of the lane), and
+//     * as the A operand of k-block r  for the TRANSPOSED matrix (A[l&15][4r + (l>>4)] = M'[..]),
+// so  tmul(X, Y) = X' Y  is four back-to-back MFMAs on registers: products chain without LDS, barriers or data
+// movement (P_c is symmetric, F' P_c F = tmul(F, tmul(P_c, F)), L' Q L = tmul(L, tmul(Q, L)), ...).
+// Vectors travel as column 0 of a second tile through the same products.
+// This replaces the generic LDS-staged riccati_node() (dompc_kernel.h; still used by the host emulation, by models
+// with more than 16 node variables or nl_cons rows, and by the tree-sharding build) - the algebra is the same:
+//     Q_tot = Q_own + sum_c F_c' P_c F_c ,  K = -Q_vv^-1 Q_vx ,
+//     P = Lc' Q_own Lc + sum_c Acl_c' P_c Acl_c   (closed-loop "Joseph" form, Lc = [I;K], Acl = F Lc).
+#pragma once
+
+namespace dompc {
+namespace r16 {
+
+constexpr bool ENABLED = (NYT <= 16) && (NE == 0) && (NS == 0) && !SHARD;
+
+#ifndef DOMPC_HOST_EMU
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int KB_A = (NA + 3) / 4, KB_Y = (NYT + 3) / 4;
+
+template <int KB>
+__device__ inline d4 tmul(const d4& At, const d4& B) {      // At' * B over the first 4*KB rows of both
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(At[kb], B[kb], acc, 0, 0, 0);
+  return acc;
+}
+__device__ inline double rl(double v, int src) { return lane_bcast(v, src); }
+
+// index of z-entry i inside y = (x_n, u_n) of the condensed edge blocks, or -1 (u_prev, eps)
+__device__ inline int yz(int i) { return (i < NX) ? i : ((i >= NA && i < NA + NU) ? NX + (i - NA) : -1); }
+
+// column-layout vector (lane l holds v[l & 15]) -> column 0 of a tile
+__device__ inline d4 col_to_tile0(double vc, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+  d4 t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double s = __shfl(vc, g + 4 * r);
+    t[r] = (j == 0) ? s : 0.0;
+  }
+  return t;
+}
+
+struct Val { d4 P, p0; };      // value function of a node: P (tile), p (column 0 of a tile)
+
+// F tile, c column and rank-update operand of edge e
+__device__ inline void load_edge(const Prob& Q, int e, int lane, d4& F, d4& f0, double& fu) {
+  const int g = lane >> 4, j = lane & 15;
+  const double* S_ = Q.ES(e);
+  const int yj = yz(j);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = g + 4 * r;
+    double fv = 0.0;
+    if (i < NX) { if (yj >= 0 && j < NYT) fv = S_[ES_AB + i * NA + yj]; }
+    else if (i < NA) fv = (j == NA + (i - NX)) ? 1.0 : 0.0;
+    F[r] = fv;
+    f0[r] = (j == 0 && i < NX) ? S_[ES_CV + i] : 0.0;
+  }
+  double v = 0.0;
+  if (g < NU) { if (j < NX) v = S_[ES_AB + j * NA + NX + g]; else if (j < NA) v = (g == j - NX) ? 1.0 : 0.0; }
+  fu = v;
+}
+
+// condensed Hessian block of edge e scattered into the z x z tile (+ delta W'W under inertia correction)
+__device__ inline d4 load_qt(const Prob& Q, int e, double delta, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+  const double* S_ = Q.ES(e);
+  const int yj = yz(j);
+  d4 t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = g + 4 * r;
+    const int yi = yz(i);
+    const bool valid = i < NYT && j < NYT && yi >= 0 && yj >= 0;
+    double v = valid ? S_[ES_QT + yi * NA + yj] : 0.0;
+    if (delta != 0.0 && valid) v += delta * wtw_entry(Q, e, yi, yj);
+    t[r] = v;
+  }
+  return t;
+}
+
+__device__ inline Val load_val(const Prob& Q, int n, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+  const double* Nd = Q.ND(n);
+  Val V;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = g + 4 * r;
+    V.P[r] = (i < NA && j < NA) ? Nd[ND_P + i * NA + j] : 0.0;
+    V.p0[r] = (i < NA && j == 0) ? Nd[ND_PV + i] : 0.0;
+  }
+  return V;
+}
+__device__ inline void store_val(const Prob& Q, int n, const Val& V, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+  double* Nd = Q.ND(n);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = g + 4 * r;
+    if (i < NA && j < NA) Nd[ND_P + i * NA + j] = V.P[r];
+    if (i < NA && j == 0) Nd[ND_PV + i] = V.p0[r];
+  }
+}
+
+// leaf: P = sf*omega*Hm + Sigma_x + delta, p = sf*omega*gm - nu_in + barrier gradient   (x part only)
+__device__ inline Val leaf(const Prob& Q, int n, double mu, double delta, int lane) {
+  const KArgs& A = *Q.A;
+  const int g = lane >> 4, j = lane & 15;
+  const int ie = A.node_in_edge[n];
+  const double* S_ = Q.ES(ie);
+  const int xo = A.node_x_off[n];
+  const int jj = j < NX ? j : 0;
+  const double xv = Q.x[xo + jj], lo = Q.lb[xo + jj], hi = Q.ub[xo + jj];
+  const double dg = sigma_of(xv, lo, hi, Q.zl[xo + jj], Q.zu[xo + jj]) + delta;
+  const double gv = (j < NX) ? S_[ES_MG + jj] - Q.lam[A.edge_row0[ie] + NW + jj] + bar_grad(xv, lo, hi, mu) : 0.0;
+  Val V;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = g + 4 * r;
+    double v = (i < NX && j < NX) ? S_[ES_MH + i * NX + j] : 0.0;
+    if (i == j && j < NX) v += dg;
+    V.P[r] = v;
+  }
+  V.p0 = col_to_tile0(gv, lane);
+  return V;
+}
+
+// One node update.  `first`: value function of the first child when it is already in registers (chain walk), else
+// null and every child's value function is read from its node record.  Returns 1 if Q_vv is not positive definite.
+__device__ inline int node(const Prob& Q, int n, double mu, double delta, int lane, const Val* first, Val& out) {
+  const KArgs& A = *Q.A;
+  const int g = lane >> 4, j = lane & 15;
+  const int cs = A.node_child_start[n], cc = A.node_child_count[n];
+  const double rw = node_rweight(Q, n);
+  // ---- own quadratic: per-variable terms in column layout (lane: z-entry j)
+  double dg = 0.0, gv = 0.0;
+  {
+    const int xo = A.node_x_off[n], uo = A.node_u_off[n];
+    const int ie = A.node_in_edge[n], pn = A.node_parent[n];
+    const bool is_up = (j >= NX && j < NA);
+    const int jj = j < NYT ? j : 0;
+    const int gi = (jj < NX) ? xo + jj : (is_up ? uo + (jj - NX) : uo + (jj - NA));
+    const double xv = Q.x[gi], lo = Q.lb[gi], hi = Q.ub[gi], zlo = Q.zl[gi], zhi = Q.zu[gi];
+    const int iu = is_up ? jj - NX : (jj >= NA ? jj - NA : 0);
+    const double upv = (jj >= NX) ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / DOMPC_SU[iu]) : 0.0;
+    if (is_up) {
+      dg = 2.0 * rw * DOMPC_RTERM[iu];
+      gv = -2.0 * rw * DOMPC_RTERM[iu] * (xv - upv);
+    } else {
+      dg = sigma_of(xv, lo, hi, zlo, zhi) + delta;
+      gv = bar_grad(xv, lo, hi, mu);
+      if (jj < NX) {
+        const double nu = (ie >= 0) ? Q.lam[A.edge_row0[ie] + NW + jj] : Q.lam[jj];
+        gv += (ie >= 0) ? -nu : nu;
+      } else {
+        dg += 2.0 * rw * DOMPC_RTERM[iu];
+        gv += 2.0 * rw * DOMPC_RTERM[iu] * (xv - upv);
+      }
+    }
+    const int yjj = yz(jj);
+    if (yjj >= 0)
+      for (int c = 0; c < cc; ++c) {
+        const double* S_ = Q.ES(cs + c);
+        gv += S_[ES_RY + yjj] + S_[ES_QV + yjj] + (delta != 0.0 ? delta * wtw0_entry(Q, cs + c, yjj) : 0.0);
+      }
+    if (j >= NYT) { dg = 0.0; gv = 0.0; }
+  }
+  d4 QO = load_qt(Q, cs, delta, lane);
+  for (int c = 1; c < cc; ++c) QO += load_qt(Q, cs + c, delta, lane);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = g + 4 * r;
+    if (i == j) QO[r] += dg;
+    else if ((i >= NX && i < NA && j == i + NU) || (j >= NX && j < NA && i == j + NU))
+      QO[r] -= 2.0 * rw * DOMPC_RTERM[(i < j ? i : j) - NX];
+  }
+  const d4 qo0 = col_to_tile0(gv, lane);
+  // ---- children, pass 1: Q_tot = Q_own + sum F' P_c F ,  q_tot = q_own + sum F'(P_c f + p_c)
+  d4 QT = QO, qt0 = qo0;
+  d4 F, f0;
+  double fu;
+  Val Vc;
+  for (int c = 0; c < cc; ++c) {
+    load_edge(Q, cs + c, lane, F, f0, fu);
+    Vc = (c == 0 && first) ? *first : load_val(Q, A.edge_child[cs + c], lane);
+    const d4 Tm = tmul<KB_A>(Vc.P, F);
+    const d4 tv = tmul<KB_A>(Vc.P, f0) + Vc.p0;
+    QT += tmul<KB_A>(F, Tm);
+    qt0 += tmul<KB_A>(F, tv);
+  }
+  // ---- Cholesky of Q_vv (uniform arithmetic on values read with v_readlane), gains for this lane's column
+  double L[NV * NV], kv[NV], Kj[NV];
+  int bad = 0;
+  {
+    double qvv[NV * NV], qv[NV], qx[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = NA + u;
+#pragma unroll
+      for (int w = 0; w <= u; ++w) qvv[u * NV + w] = rl(QT[i / 4], 16 * (i % 4) + NA + w);
+      qv[u] = rl(qt0[i / 4], 16 * (i % 4));
+      qx[u] = __shfl(QT[i / 4], 16 * (i % 4) + j);
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+      for (int w = 0; w <= u; ++w) {
+        double t = qvv[u * NV + w];
+#pragma unroll
+        for (int q = 0; q < w; ++q) t -= L[u * NV + q] * L[w * NV + q];
+        if (u == w) {
+          if (!(t > 0.0)) { bad = 1; t = 1.0; }
+          L[u * NV + u] = sqrt(t);
+        } else {
+          L[u * NV + w] = t / L[w * NV + w];
+        }
+      }
+    auto solve = [&](double* y) {        // y <- Q_vv^-1 y
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        double t = y[u];
+#pragma unroll
+        for (int q = 0; q < u; ++q) t -= L[u * NV + q] * y[q];
+        y[u] = t / L[u * NV + u];
+      }
+#pragma unroll
+      for (int u = NV - 1; u >= 0; --u) {
+        double t = y[u];
+#pragma unroll
+        for (int q = u + 1; q < NV; ++q) t -= L[q * NV + u] * y[q];
+        y[u] = t / L[u * NV + u];
+      }
+    };
+    solve(qv);
+    solve(qx);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) { kv[u] = -qv[u]; Kj[u] = (j < NA) ? -qx[u] : 0.0; }
+  }
+  double* Nd = Q.ND(n);
+  if (g == 0 && j < NA)
+#pragma unroll
+    for (int u = 0; u < NV; ++u) Nd[ND_K + u * NA + j] = Kj[u];
+  if (lane == 0)
+#pragma unroll
+    for (int u = 0; u < NV; ++u) Nd[ND_KV + u] = kv[u];
+  // ---- Lc = [I;K], l0 = (0;kv) as tiles; operands of the rank-NV updates
+  d4 Lc, l0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = g + 4 * r;
+    double v = (k < NA) ? ((k == j) ? 1.0 : 0.0) : 0.0, w0 = 0.0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+      if (k == NA + u) { v = Kj[u]; w0 = kv[u]; }
+    Lc[r] = v;
+    l0[r] = (j == 0) ? w0 : 0.0;
+  }
+  double bK = 0.0, bkv = 0.0;
+#pragma unroll
+  for (int u = 0; u < NV; ++u)
+    if (g == u) { bK = Kj[u]; bkv = (j == 0) ? kv[u] : 0.0; }
+  // ---- own part of the value function: Lc' Q_own Lc, Lc'(q_own + Q_own l0)
+  {
+    const d4 U = tmul<KB_Y>(QO, Lc);
+    const d4 u0 = tmul<KB_Y>(QO, l0) + qo0;
+    out.P = tmul<KB_Y>(Lc, U);
+    out.p0 = tmul<KB_Y>(Lc, u0);
+  }
+  // ---- children, pass 2: closed-loop maps Acl = F Lc, ccl = F l0 + f ; P += Acl' P_c Acl
+  for (int c = cc - 1; c >= 0; --c) {
+    if (c != cc - 1) {                       // (the last child of pass 1 is still in registers)
+      load_edge(Q, cs + c, lane, F, f0, fu);
+      Vc = (c == 0 && first) ? *first : load_val(Q, A.edge_child[cs + c], lane);
+    }
+    d4 Fy;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Fy[r] = (j < NA) ? F[r] : 0.0;
+    const d4 Acl = __builtin_amdgcn_mfma_f64_16x16x4f64(fu, bK, Fy, 0, 0, 0);
+    const d4 ccl = __builtin_amdgcn_mfma_f64_16x16x4f64(fu, bkv, f0, 0, 0, 0);
+    const d4 T2 = tmul<KB_A>(Vc.P, Acl);
+    const d4 tv2 = tmul<KB_A>(Vc.P, ccl) + Vc.p0;
+    out.P += tmul<KB_A>(Acl, T2);
+    out.p0 += tmul<KB_A>(Acl, tv2);
+  }
+  store_val(Q, n, out, lane);
+  return bad;
+}
+
+// Backward recursion of one problem (all wavefronts of the problem take part; same protocol as riccati_backward).
+__device__ inline int backward(const Thr& T, const Prob& Q, double mu, double delta) {
+  const KArgs& A = *Q.A;
+  const int ng = T.nt / 64, gid = T.tid / 64, lane = T.tid % 64;
+  T.sync();
+  if (T.tid == 0) T.fset(0, 0);
+  T.sync();
+  const int cl = A.chain_level < A.N ? A.chain_level : A.N;
+  {
+    const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
+    for (int s_ = gid; s_ < S; s_ += ng) {
+      Val V = leaf(Q, A.level_node_start[A.N] + s_, mu, delta, lane);
+      store_val(Q, A.level_node_start[A.N] + s_, V, lane);
+      for (int k = A.N - 1; k >= cl; --k) {
+        Val Vn;
+        if (node(Q, A.level_node_start[k] + s_, mu, delta, lane, &V, Vn)) { T.fset(0, 1); break; }
+        V = Vn;
+      }
+    }
+    T.sync();
+    if (T.fget(0)) return 1;
+  }
+  for (int k = cl - 1; k >= 0; --k) {
+    const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
+    for (int n = n0 + gid; n < n1; n += ng) {
+      Val Vn;
+      if (node(Q, n, mu, delta, lane, nullptr, Vn)) T.fset(0, 1);
+    }
+    T.sync();
+    if (T.fget(0)) return 1;
+  }
+  return 0;
+}
+#endif  // !DOMPC_HOST_EMU
+
+}  // namespace r16
+}  // namespace dompc
