@@ -606,8 +606,9 @@ constexpr int EL_QT = EL_HUU + NU * NU;                                // W'T1 (
 constexpr int EL_HP = EL_QT;                                           // staged point Hessians H_p (NA x NA each): dead before QT is written
 constexpr int EL_NHP = (NI * DEG > 2 ? NI * DEG : 2);
 constexpr int EL_PV = EL_QT + EL_NHP * NA * NA;                        // pivot rows (NW)
+constexpr int EL_RY = EL_PV + NW;                                      // G_y' lambda (NA), completed in phase 7
 constexpr int RB_NEED = 2 * (NYT * NYT + NYT) + 5 * NA * NA + 6 * NA + NV * NA + NV + NE * (NA + 4);   // = rb::RB_SIZE (asserted there)
-constexpr int EL_SIZE = (((EL_PV + NW > RB_NEED ? EL_PV + NW : RB_NEED) + 7) / 8) * 8;
+constexpr int EL_SIZE = (((EL_RY + NA > RB_NEED ? EL_RY + NA : RB_NEED) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {
   // collocation point (i*DEG + j-1) stored in slot sl, or -1 for element-start states and xkf
@@ -700,7 +701,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
 
   // ---- phase 1: zero Mx (the model-output record of eval_models is read from global memory / L2)
   if (act) {
-    for (int i = lane; i < NW * NC; i += GS) Ld[EL_MX + i] = 0.0;
+    if (NI != 1)
+      for (int i = lane; i < NW * NC; i += GS) Ld[EL_MX + i] = 0.0;
     for (int r = lane; r < NW; r += GS) Ld[EL_T0 + r] = lam_e[r];      // multipliers of the collocation rows (dual residual)
   }
   T.gsync();
@@ -725,11 +727,239 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       for (int b = lane; b < NA; b += GS) {
         double t = 0.0;
         for (int a = 0; a < NX; ++a) t += pt[NX + a * NA + b] * nu_e[a];
-        S_[ES_RY + b] = t;          // completed below
+        Ld[EL_RY + b] = t;          // completed in phase 7
         S_[ES_QV + b] = 0.0;
       }
     }
   } else {
+    if constexpr (NI == 1) {
+      // ---- phases 2-4, single finite element: [G_cc | G_y r | I] is assembled, used for the dual residual and
+      // eliminated in REGISTERS, one extended column per lane - the LDS matrix of the general path does not exist
+      // here (only W, w0 and G_cc^-1 are written to it afterwards for the condensing phases).
+      // Single finite element: G_w = [[G_cc, 0], [E, I]] with the continuity rows E = -[D_1 I ... D_DEG I] below the
+      // R x R collocation block, so only G_cc is eliminated (the continuity rows of W, w0 follow as D-weighted sums).
+      // Register-resident Gauss-Jordan on the extended matrix [G_cc | G_y r | I], one COLUMN per lane (R + NA + 1 + R
+      // lanes: 54 for industrial_poly): per step the pivot column is broadcast with v_readlane (it ends up in SGPRs
+      // and feeds the FMAs as a scalar operand) - no LDS traffic and no barrier inside the elimination.
+      // Pivoting: the natural order is tried first (the diagonal of G_cc = h J - C (x) I carries the collocation
+      // coefficients C_jj) under a threshold test |a_kk| >= GJ_U max_{r >= k} |a_rk| evaluated by the lane that owns
+      // column k; if any test fails, the wavefront repeats the elimination from the untouched LDS copy with partial
+      // pivoting and explicit row interchanges (rare; measured: never on the BASELINE workloads).
+      // (The LDS variant - column per lane re-read and re-written every step, packed pivot keys - spent two thirds of
+      // its ~600 instructions per pair of steps on the redundant pivot search; this one issues ~85 per step.)
+      constexpr int R = DEG * NX, RA = R > 0 ? R : 1;
+      constexpr int NRHS = NA + 1;
+      constexpr int NCX = 2 * R + NRHS;                      // extended columns: G_cc | G_y r | I
+      constexpr int CPX = (NCX + GS_C - 1) / GS_C;
+      constexpr double GJ_U = 0.01;
+      double bc[CPX][RA];
+      // column cx of the collocation rows (row r = (jj, a): point j = jj + 1, state a), straight from the model-output
+      // record (optimizer.py:951-963):  G_cc (slot sl, state b): [sl == jj] J_jj[a][b] - [a == b] C[sl+1][j];
+      // G_y: x_n columns -[a == yb] C[0][j], u_n columns J_jj[a][yb];  r: the residuals (staged in LDS by the lanes
+      // that computed them);  I.  One unconditional load per entry (clamped address) + selects: no divergent branches.
+      auto load_cols = [&]() {
+        // (all global loads first, in one batch: loads issued between dependent selects / branches are waited for one
+        //  by one - the first version of this loop spent 40 serialized memory round trips per edge that way)
+        double jv[CPX][RA], cd[CPX][DEG > 0 ? DEG : 1];
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) {
+          const int cx = lane + q * GS;
+          const bool isG = cx < R, isY = cx >= R && cx < R + NA;
+          const int jcol = isG ? cx % NX : (isY ? cx - R : 0);           // column of the point Jacobian this lane reads
+          const int sl1 = isG ? cx / NX + 1 : 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) jv[q][r] = mo[MO_PT + (r / NX) * PT_STRIDE + NX + (r % NX) * NA + jcol];
+#pragma unroll
+          for (int jj = 0; jj < DEG; ++jj) cd[q][jj] = DOMPC_C[sl1 * (DEG + 1) + (jj + 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) {
+          const int cx = lane + q * GS;
+          const bool isG = cx < R, isY = cx >= R && cx < R + NA, isR = cx == R + NA;
+          const int sl = isG ? cx / NX : -1, b = isG ? cx % NX : -1, yb = isY ? cx - R : -1;
+          const int unit_row = cx - (R + NRHS);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int jj = r / NX, a = r % NX;
+            const bool useJ = isG ? (sl == jj) : (isY && yb >= NX);
+            double v = useJ ? jv[q][r] : 0.0;
+            v -= (a == b) ? cd[q][jj] : 0.0;
+            v -= (a == yb) ? DOMPC_C[0 * (DEG + 1) + (jj + 1)] : 0.0;
+            v = (unit_row == r) ? 1.0 : v;
+            bc[q][r] = v;
+          }
+          if (isR) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) bc[q][r] = Ld[EL_T1 + r];
+          }
+        }
+      };
+      auto eliminate = [&](bool pivoting) -> int {           // returns 1: threshold test failed / singular block
+        int badl = 0;
+#pragma unroll
+        for (int kk = 0; kk < R; ++kk) {
+          const int qk = kk / GS_C, lk = kk % GS_C;          // column kk lives in slot qk of lane lk
+          if (pivoting) {
+            int pr = kk;
+            double best = fabs(bc[qk][kk]);
+#pragma unroll
+            for (int r = kk + 1; r < R; ++r) {
+              const double a = fabs(bc[qk][r]);
+              if (a > best) { best = a; pr = r; }
+            }
+            if (lane == lk && !(best > 1e-300)) badl = 1;
+#ifndef DOMPC_HOST_EMU
+            pr = __builtin_amdgcn_readlane(pr, lk);
+#endif
+#pragma unroll
+            for (int q = 0; q < CPX; ++q) {                  // rows kk <-> pr (the appended identity is permuted along)
+              const double t = bc[q][kk];
+              double nk = t;
+#pragma unroll
+              for (int r = kk + 1; r < R; ++r) {
+                const bool hit = (r == pr);
+                nk = hit ? bc[q][r] : nk;
+                bc[q][r] = hit ? t : bc[q][r];
+              }
+              bc[q][kk] = nk;
+            }
+          } else {
+            double m = 0.0;
+#pragma unroll
+            for (int r = kk + 1; r < R; ++r) m = fmax(m, fabs(bc[qk][r]));
+            const double akk = fabs(bc[qk][kk]);
+            if (lane == lk && !(akk >= GJ_U * m && akk > 1e-300)) badl = 1;
+          }
+          double f[RA];
+#pragma unroll
+          for (int r = 0; r < R; ++r) f[r] = lane_bcast(bc[qk][r], lk);
+          const double pinv = 1.0 / ((fabs(f[kk]) > 1e-300) ? f[kk] : 1.0);
+#pragma unroll
+          for (int q = 0; q < CPX; ++q) {
+            const double prow = bc[q][kk] * pinv;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              if (r != kk) bc[q][r] = fma(-f[r], prow, bc[q][r]);
+            bc[q][kk] = prow;
+          }
+        }
+#ifndef DOMPC_HOST_EMU
+        return __ballot(badl) != 0ull;
+#else
+        return badl;
+#endif
+      };
+      // residual rows (collocation, continuity, end point): computed by one lane each, written to g and staged in LDS
+      // for the lane that owns the right-hand-side column; the point Hessians of the condensing phases are staged
+      // with the same batch of global loads
+      if (act) {
+        for (int it = lane; it < NCOLL * NA * NA; it += GS)
+          Ld[EL_HP + it] = mo[MO_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + symi((it % (NA * NA)) / NA, it % NA, NA)];
+        for (int it = lane; it < NW; it += GS) {
+          const int jj = it / NX, a = it % NX;
+          double res;
+          if (jj < DEG) {
+            const int j = jj + 1;
+            double xp = DOMPC_C[0 * (DEG + 1) + j] * xn[a];
+#pragma unroll
+            for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + j] * w[(r - 1) * NX + a];
+            res = mo[MO_PT + jj * PT_STRIDE + a] - xp;
+          } else {
+            double xf = DOMPC_D[0] * xn[a];
+#pragma unroll
+            for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * w[(r - 1) * NX + a];
+            res = w[(M - 1) * NX + a] - xf;
+          }
+          Q.c[row0 + it] = res;
+          Ld[EL_T1 + it] = res;
+        }
+        for (int a = lane; a < NX; a += GS) Q.c[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
+      }
+      T.gsync();
+      if (act) {
+        // per-variable data of the collocation unknowns (this lane's column, plus the end-point columns on the first
+        // NX lanes): requested together with the column loads
+        double vx[CPX][5], ex[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) {
+          const int cx = lane + q * GS;
+          const int gi = woff + (cx < R ? cx : 0);
+          vx[q][0] = Q.x[gi]; vx[q][1] = Q.lb[gi]; vx[q][2] = Q.ub[gi]; vx[q][3] = Q.zl[gi]; vx[q][4] = Q.zu[gi];
+        }
+        double nu_a = 0.0;
+        if (GS > 1) {
+          const int gi = woff + R + (lane < NX ? lane : 0);
+          ex[0] = Q.x[gi]; ex[1] = Q.lb[gi]; ex[2] = Q.ub[gi]; ex[3] = Q.zl[gi]; ex[4] = Q.zu[gi];
+          nu_a = nu_e[lane < NX ? lane : 0];
+        }
+        load_cols();
+        // dual-residual pieces: column c of G_w / G_y times the multipliers of the edge's rows (continuity rows:
+        // -D_{sl+1} on the diagonal of the G_cc columns, -D_0 for the x_n columns, +1 for the end-point columns)
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) {
+          const int cx = lane + q * GS;
+          double t = 0.0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) t += bc[q][r] * Ld[EL_T0 + r];
+          if (cx < R) {
+            t -= DOMPC_D[cx / NX + 1] * Ld[EL_T0 + R + cx % NX];
+            const int gi = woff + cx;
+            const double xv = vx[q][0], l = vx[q][1], u = vx[q][2], zl_ = vx[q][3], zu_ = vx[q][4];
+            Q.gf[gi] = 0.0;
+            Q.rd[gi] = t - zl_ + zu_;
+            Ld[EL_RW + cx] = t + bar_grad(xv, l, u, mu);
+            Ld[EL_SG + cx] = sigma_of(xv, l, u, zl_, zu_);
+          } else if (cx < R + NA) {
+            const int yb = cx - R;
+            if (yb < NX) t -= DOMPC_D[0] * Ld[EL_T0 + R + yb];
+            Ld[EL_RY + yb] = t;          // completed in phase 7
+          }
+        }
+        for (int a = lane; a < NX; a += GS) {               // end-point (xkf) columns
+          const int col = R + a, gi = woff + col;
+          const double t = Ld[EL_T0 + R + a] + (GS > 1 ? nu_a : nu_e[a]);
+          double xv, l, u, zl_, zu_;
+          if (GS > 1) { xv = ex[0]; l = ex[1]; u = ex[2]; zl_ = ex[3]; zu_ = ex[4]; }
+          else { xv = Q.x[gi]; l = Q.lb[gi]; u = Q.ub[gi]; zl_ = Q.zl[gi]; zu_ = Q.zu[gi]; }
+          Q.gf[gi] = 0.0;
+          Q.rd[gi] = t - zl_ + zu_;
+          Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu);
+          Ld[EL_SG + col] = sigma_of(xv, l, u, zl_, zu_);
+        }
+      }
+      DOMPC_PH(1)
+      if (act) {
+        if (eliminate(false)) {
+          load_cols();
+          if (eliminate(true)) fail = 1;
+        }
+      }
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) {
+          const int cx = lane + q * GS;
+          if (cx >= R && cx < R + NRHS) {
+            // right-hand sides: W = -G_w^-1 G_y, w0 = -G_w^-1 r_g; continuity row a = assembled entry + sum_r D_r row((r-1)NX+a)
+            const int col = NW + (cx - R);
+#pragma unroll
+            for (int a_ = 0; a_ < NX; ++a_) {
+              const int yb = cx - R;                       // assembled entry of the continuity row: -D_0 / the residual
+              double t = (yb == NA) ? Ld[EL_T1 + R + a_] : ((yb == a_) ? -DOMPC_D[0] : 0.0);
+#pragma unroll
+              for (int r = 1; r <= DEG; ++r) t += DOMPC_D[r] * bc[q][(r - 1) * NX + a_];
+              Ld[EL_MX + (R + a_) * NC + col] = -t;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + col] = -bc[q][r];
+          } else if (cx >= R + NRHS && cx < NCX) {
+            const int col = cx - (R + NRHS);                 // column `col` of G_cc^-1 (kept for the multiplier recovery)
+#pragma unroll
+            for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + col] = bc[q][r];
+          }
+        }
+      }
+      T.gsync();
+    } else {
     // ---- phase 2: assemble Mx = [G_w | G_y | r_g] and the residual rows; the point Hessians needed by the
     //      condensing phases are staged in LDS with the same batch of global loads
     if (act) {
@@ -792,131 +1022,11 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         double t = 0.0;
 #pragma unroll 6
         for (int r = 0; r < NW; ++r) t += Ld[EL_MX + r * NC + NW + b] * Ld[EL_T0 + r];
-        S_[ES_RY + b] = t;          // completed below
+        Ld[EL_RY + b] = t;          // completed in phase 7
       }
     }
     T.gsync();
     DOMPC_PH(1)
-    // ---- phase 4: [G_w | G_y | r_g] -> G_w^-1, W = -G_w^-1 G_y, w0 = -G_w^-1 r_g
-    if constexpr (NI == 1) {
-      // Single finite element: G_w = [[G_cc, 0], [E, I]] with the continuity rows E = -[D_1 I ... D_DEG I] below the
-      // R x R collocation block, so only G_cc is eliminated (the continuity rows of W, w0 follow as D-weighted sums).
-      // Register-resident Gauss-Jordan on the extended matrix [G_cc | G_y r | I], one COLUMN per lane (R + NA + 1 + R
-      // lanes: 54 for industrial_poly): per step the pivot column is broadcast with v_readlane (it ends up in SGPRs
-      // and feeds the FMAs as a scalar operand) - no LDS traffic and no barrier inside the elimination.
-      // Pivoting: the natural order is tried first (the diagonal of G_cc = h J - C (x) I carries the collocation
-      // coefficients C_jj) under a threshold test |a_kk| >= GJ_U max_{r >= k} |a_rk| evaluated by the lane that owns
-      // column k; if any test fails, the wavefront repeats the elimination from the untouched LDS copy with partial
-      // pivoting and explicit row interchanges (rare; measured: never on the BASELINE workloads).
-      // (The LDS variant - column per lane re-read and re-written every step, packed pivot keys - spent two thirds of
-      // its ~600 instructions per pair of steps on the redundant pivot search; this one issues ~85 per step.)
-      constexpr int R = DEG * NX, RA = R > 0 ? R : 1;
-      constexpr int NRHS = NA + 1;
-      constexpr int NCX = 2 * R + NRHS;                      // extended columns: G_cc | G_y r | I
-      constexpr int CPX = (NCX + GS_C - 1) / GS_C;
-      constexpr double GJ_U = 0.01;
-      double bc[CPX][RA];
-      auto load_cols = [&]() {
-#pragma unroll
-        for (int q = 0; q < CPX; ++q) {
-          const int cx = lane + q * GS;
-          const int src = cx < R ? cx : (cx < R + NRHS ? NW + (cx - R) : 0);
-          const bool unit = cx >= R + NRHS;
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const double v = Ld[EL_MX + r * NC + src];
-            bc[q][r] = unit ? ((cx - (R + NRHS) == r) ? 1.0 : 0.0) : v;
-          }
-        }
-      };
-      auto eliminate = [&](bool pivoting) -> int {           // returns 1: threshold test failed / singular block
-        int badl = 0;
-#pragma unroll
-        for (int kk = 0; kk < R; ++kk) {
-          const int qk = kk / GS_C, lk = kk % GS_C;          // column kk lives in slot qk of lane lk
-          if (pivoting) {
-            int pr = kk;
-            double best = fabs(bc[qk][kk]);
-#pragma unroll
-            for (int r = kk + 1; r < R; ++r) {
-              const double a = fabs(bc[qk][r]);
-              if (a > best) { best = a; pr = r; }
-            }
-            if (lane == lk && !(best > 1e-300)) badl = 1;
-#ifndef DOMPC_HOST_EMU
-            pr = __builtin_amdgcn_readlane(pr, lk);
-#endif
-#pragma unroll
-            for (int q = 0; q < CPX; ++q) {                  // rows kk <-> pr (the appended identity is permuted along)
-              const double t = bc[q][kk];
-              double nk = t;
-#pragma unroll
-              for (int r = kk + 1; r < R; ++r) {
-                const bool hit = (r == pr);
-                nk = hit ? bc[q][r] : nk;
-                bc[q][r] = hit ? t : bc[q][r];
-              }
-              bc[q][kk] = nk;
-            }
-          } else {
-            double m = 0.0;
-#pragma unroll
-            for (int r = kk + 1; r < R; ++r) m = fmax(m, fabs(bc[qk][r]));
-            const double akk = fabs(bc[qk][kk]);
-            if (lane == lk && !(akk >= GJ_U * m && akk > 1e-300)) badl = 1;
-          }
-          double f[RA];
-#pragma unroll
-          for (int r = 0; r < R; ++r) f[r] = lane_bcast(bc[qk][r], lk);
-          const double pinv = 1.0 / ((fabs(f[kk]) > 1e-300) ? f[kk] : 1.0);
-#pragma unroll
-          for (int q = 0; q < CPX; ++q) {
-            const double prow = bc[q][kk] * pinv;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-              if (r != kk) bc[q][r] = fma(-f[r], prow, bc[q][r]);
-            bc[q][kk] = prow;
-          }
-        }
-#ifndef DOMPC_HOST_EMU
-        return __ballot(badl) != 0ull;
-#else
-        return badl;
-#endif
-      };
-      if (act) {
-        load_cols();
-        if (eliminate(false)) {
-          load_cols();
-          if (eliminate(true)) fail = 1;
-        }
-      }
-      T.gsync();                                             // (every lane has read its columns: Mx may be overwritten)
-      if (act) {
-#pragma unroll
-        for (int q = 0; q < CPX; ++q) {
-          const int cx = lane + q * GS;
-          if (cx >= R && cx < R + NRHS) {
-            // right-hand sides: W = -G_w^-1 G_y, w0 = -G_w^-1 r_g; continuity row a = assembled entry + sum_r D_r row((r-1)NX+a)
-            const int col = NW + (cx - R);
-#pragma unroll
-            for (int a_ = 0; a_ < NX; ++a_) {
-              double t = Ld[EL_MX + (R + a_) * NC + col];
-#pragma unroll
-              for (int r = 1; r <= DEG; ++r) t += DOMPC_D[r] * bc[q][(r - 1) * NX + a_];
-              Ld[EL_MX + (R + a_) * NC + col] = -t;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + col] = -bc[q][r];
-          } else if (cx >= R + NRHS && cx < NCX) {
-            const int col = cx - (R + NRHS);                 // column `col` of G_cc^-1 (kept for the multiplier recovery)
-#pragma unroll
-            for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + col] = bc[q][r];
-          }
-        }
-      }
-      T.gsync();
-    } else {
     // in-place Gauss-Jordan inversion of [G_w | G_y | r_g] in LDS, one matrix COLUMN per lane.
     // Per step every lane loads column kk (same addresses for all lanes -> LDS broadcast) and, in the same
     // LDS round trip, its own column; the pivot row is found redundantly with a packed (|value| high word,
@@ -1133,7 +1243,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   // ---- phase 7: stage cost / terminal cost / nl_cons shares (few values: lanes 0..)
   if (act) {
     for (int a = lane; a < NA; a += GS) {
-      double r = S_[ES_RY + a] + om * mo[MO_LT + 1 + a];
+      double r = Ld[EL_RY + a] + om * mo[MO_LT + 1 + a];
       if (NE > 0)
         for (int i = 0; i < NE; ++i) r += mo[MO_NL + NE + i * NA + a] * yd[i];
       S_[ES_GFY + a] = om * mo[MO_LT + 1 + a];
