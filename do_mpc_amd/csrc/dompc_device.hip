@@ -16,6 +16,11 @@
 #define DOMPC_HD
 #endif
 
+// resident wavefronts per SIMD the register allocation is sized for (2: 256 VGPRs, 3: 168, 4: 128)
+#ifndef DOMPC_LB
+#define DOMPC_LB 2
+#endif
+
 #include DOMPC_MODEL_HEADER
 #include "dompc_kernel.h"
 
@@ -44,7 +49,7 @@ extern "C" __global__ void dompc_model_info_kernel(const int32_t* in, int64_t* o
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256, 2) dompc_solve_kernel(dompc::KArgs A) {
+extern "C" __global__ void __launch_bounds__(256, DOMPC_LB) dompc_solve_kernel(dompc::KArgs A) {
   using namespace dompc;
   const int POOL = A.pool_doubles;
   if (threadIdx.x < 8) { lds_prof[threadIdx.x] = 0; lds_flags[threadIdx.x] = 0; }

@@ -595,8 +595,11 @@ DOMPC_DEV inline double node_rterm_f(const Prob& Q, int n, const double* xv) {
 // barrier T.sync() is safe; groups with e < 0 only take part in the barriers.
 constexpr int NC = NW + NA + 1;
 static_assert(NW <= 64, "collocation block larger than 64 unknowns per edge is not supported yet (pivot bitmask)");
+// (single finite element: the matrix is assembled and eliminated in registers, LDS only holds W | w0 afterwards)
+constexpr int MX_LD = (NI == 1) ? NA + 1 : NC;                         // leading dimension of the LDS matrix
+constexpr int MX_W = (NI == 1) ? 0 : NW;                               // column offset of [W | w0] inside it
 constexpr int EL_MX = 0;
-constexpr int EL_T1 = EL_MX + NW * NC;                                 // Hww W  (NW x NA)
+constexpr int EL_T1 = EL_MX + NW * MX_LD;                              // Hww W  (NW x NA)
 constexpr int EL_T0 = EL_T1 + NW * NA;                                 // Hww w0 (NW)
 constexpr int EL_RW = EL_T0 + NW;                                      // Newton-form gradient of w (NW)
 constexpr int EL_SG = EL_RW + NW;                                      // Sigma_w (NW)
@@ -607,7 +610,13 @@ constexpr int EL_HP = EL_QT;                                           // staged
 constexpr int EL_NHP = (NI * DEG > 2 ? NI * DEG : 2);
 constexpr int EL_PV = EL_QT + EL_NHP * NA * NA;                        // pivot rows (NW)
 constexpr int EL_RY = EL_PV + NW;                                      // G_y' lambda (NA), completed in phase 7
-constexpr int RB_NEED = 2 * (NYT * NYT + NYT) + 5 * NA * NA + 6 * NA + NV * NA + NV + NE * (NA + 4);   // = rb::RB_SIZE (asserted there)
+constexpr bool R16_ENABLED = (NYT <= 16) && (NE == 0) && (NS == 0) && (DOMPC_SHARD == 0);   // dompc_riccati16.h (device)
+#ifndef DOMPC_HOST_EMU
+constexpr bool RB_IN_LDS = !R16_ENABLED;
+#else
+constexpr bool RB_IN_LDS = true;
+#endif
+constexpr int RB_NEED = RB_IN_LDS ? 2 * (NYT * NYT + NYT) + 5 * NA * NA + 6 * NA + NV * NA + NV + NE * (NA + 4) : 0;   // = rb::RB_SIZE (asserted there)
 constexpr int EL_SIZE = (((EL_RY + NA > RB_NEED ? EL_RY + NA : RB_NEED) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {
@@ -940,21 +949,21 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           const int cx = lane + q * GS;
           if (cx >= R && cx < R + NRHS) {
             // right-hand sides: W = -G_w^-1 G_y, w0 = -G_w^-1 r_g; continuity row a = assembled entry + sum_r D_r row((r-1)NX+a)
-            const int col = NW + (cx - R);
+            const int col = MX_W + (cx - R);
 #pragma unroll
             for (int a_ = 0; a_ < NX; ++a_) {
               const int yb = cx - R;                       // assembled entry of the continuity row: -D_0 / the residual
               double t = (yb == NA) ? Ld[EL_T1 + R + a_] : ((yb == a_) ? -DOMPC_D[0] : 0.0);
 #pragma unroll
               for (int r = 1; r <= DEG; ++r) t += DOMPC_D[r] * bc[q][(r - 1) * NX + a_];
-              Ld[EL_MX + (R + a_) * NC + col] = -t;
+              Ld[EL_MX + (R + a_) * MX_LD + col] = -t;
             }
 #pragma unroll
-            for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + col] = -bc[q][r];
+            for (int r = 0; r < R; ++r) Ld[EL_MX + r * MX_LD + col] = -bc[q][r];
           } else if (cx >= R + NRHS && cx < NCX) {
             const int col = cx - (R + NRHS);                 // column `col` of G_cc^-1 (kept for the multiplier recovery)
 #pragma unroll
-            for (int r = 0; r < R; ++r) Ld[EL_MX + r * NC + col] = bc[q][r];
+            for (int r = 0; r < R; ++r) Q.EW(e, EW_LU + r * LU_N + col) = bc[q][r];
           }
         }
       }
@@ -1145,14 +1154,14 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     if (act) {
       for (int it = lane; it < NW * (NA + 1); it += GS) {
         const int row = it / (NA + 1), b = it % (NA + 1);
-        double t = Ld[EL_SG + row] * Ld[EL_MX + row * NC + NW + b];
+        double t = Ld[EL_SG + row] * Ld[EL_MX + row * MX_LD + MX_W + b];
         if (b == NA) {            // the w0 column: small mat-vec on the vector units
           const int sl = row / NX, a = row % NX;
           const int p = point_of_slot(sl);
           if (p >= 0) {
             const ldsd* Hp = Ld + EL_HP + p * NA * NA;
 #pragma unroll
-            for (int a2 = 0; a2 < NX; ++a2) t += Hp[a * NA + a2] * Ld[EL_MX + (sl * NX + a2) * NC + NW + NA];
+            for (int a2 = 0; a2 < NX; ++a2) t += Hp[a * NA + a2] * Ld[EL_MX + (sl * NX + a2) * MX_LD + MX_W + NA];
           }
           Ld[EL_T0 + row] = t;
         } else {
@@ -1166,7 +1175,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           const int sl = slot_of(p / DEG, p % DEG + 1);
           const ldsd* Hp = Ld + EL_HP + p * NA * NA;
 #pragma unroll
-          for (int a = 0; a < NX; ++a) t += Hp[a * NA + NX + ub] * Ld[EL_MX + (sl * NX + a) * NC + NW + b];
+          for (int a = 0; a < NX; ++a) t += Hp[a * NA + NX + ub] * Ld[EL_MX + (sl * NX + a) * MX_LD + MX_W + b];
         }
         Ld[EL_U1 + (b < NA ? ub * NA + b : NU * NA + ub)] = t;
       }
@@ -1182,13 +1191,13 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       for (int p = 0; p < NCOLL; ++p) {
         const int sl = slot_of(p / DEG, p % DEG + 1);
         gmm(lane, GS, NX, NA, NX, (double*)(Ld + EL_HP + p * NA * NA), NA, 1,
-            (double*)(Ld + EL_MX + (sl * NX) * NC + NW), NC, 1, 1.0, (double*)(Ld + EL_T1 + sl * NX * NA), NA);
+            (double*)(Ld + EL_MX + (sl * NX) * MX_LD + MX_W), MX_LD, 1, 1.0, (double*)(Ld + EL_T1 + sl * NX * NA), NA);
       }
     }
     T.gsync();
     if (act) {
       // W'T1 and W'W  (13x30 * 30x13 on the matrix cores)
-      gmm(lane, GS, NA, NA, NW, (double*)(Ld + EL_MX + NW), 1, NC, (double*)(Ld + EL_T1), NA, 1, 0.0, (double*)(Ld + EL_QT), NA);
+      gmm(lane, GS, NA, NA, NW, (double*)(Ld + EL_MX + MX_W), 1, MX_LD, (double*)(Ld + EL_T1), NA, 1, 0.0, (double*)(Ld + EL_QT), NA);
     }
     T.gsync();
     // ---- phase 6: condensed blocks to the shared per-edge record; data for the forward pass
@@ -1219,21 +1228,22 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
       for (int a1 = lane; a1 < NA; a1 += GS) {
         double q = 0.0;
-        for (int row = 0; row < NW; ++row) q += Ld[EL_MX + row * NC + NW + a1] * (Ld[EL_RW + row] + Ld[EL_T0 + row]);
+        for (int row = 0; row < NW; ++row) q += Ld[EL_MX + row * MX_LD + MX_W + a1] * (Ld[EL_RW + row] + Ld[EL_T0 + row]);
         if (a1 >= NX) q += Ld[EL_U1 + NU * NA + a1 - NX];
         S_[ES_QV + a1] = q;
       }
       for (int it = lane; it < NX * (NA + 1); it += GS) {
         const int a = it / (NA + 1), b = it % (NA + 1);
-        const double v = Ld[EL_MX + ((M - 1) * NX + a) * NC + NW + b];
+        const double v = Ld[EL_MX + ((M - 1) * NX + a) * MX_LD + MX_W + b];
         if (b < NA) S_[ES_AB + a * NA + b] = v;
         else S_[ES_CV + a] = v + (w[(M - 1) * NX + a] - xc[a]);
       }
       // forward-pass data (interleaved per-edge workspace)
-      for (int it = lane; it < LU_N * LU_N; it += GS) Q.EW(e, EW_LU + it) = Ld[EL_MX + (it / LU_N) * NC + it % LU_N];
-      for (int it = lane; it < NW * NA; it += GS) Q.EW(e, EW_W + it) = Ld[EL_MX + (it / NA) * NC + NW + it % NA];
+      if (NI != 1)       // (single element: G_cc^-1 went to the record straight from the registers)
+        for (int it = lane; it < LU_N * LU_N; it += GS) Q.EW(e, EW_LU + it) = Ld[EL_MX + (it / LU_N) * NC + it % LU_N];
+      for (int it = lane; it < NW * NA; it += GS) Q.EW(e, EW_W + it) = Ld[EL_MX + (it / NA) * MX_LD + MX_W + it % NA];
       for (int r = lane; r < NW; r += GS) {
-        Q.EW(e, EW_W0 + r) = Ld[EL_MX + r * NC + NW + NA];
+        Q.EW(e, EW_W0 + r) = Ld[EL_MX + r * MX_LD + MX_W + NA];
         Q.EW(e, EW_SIGW + r) = Ld[EL_SG + r];
         Q.EW(e, EW_RW + r) = Ld[EL_RW + r];
       }
@@ -2063,10 +2073,9 @@ namespace dompc {
 
 DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double delta) {
 #ifndef DOMPC_HOST_EMU
-  // register-resident matrix-core recursion (dompc_riccati16.h) unless the model is too large for one tile or the
-  // caller asked for the generic LDS-staged path (option dompc.generic_riccati: A/B checks)
-  if constexpr (r16::ENABLED)
-    if (!(Q.A->opt.reserved & 1)) return r16::backward(T, Q, mu, delta);
+  // register-resident matrix-core recursion (dompc_riccati16.h) unless the model is too large for one tile; the generic
+  // LDS-staged path below then is dead code on the device and its working set is not part of the LDS pool
+  if constexpr (R16_ENABLED) return r16::backward(T, Q, mu, delta);
 #endif
   // One group of lanes (a wavefront) per tree node, the node's matrices staged in the group's LDS region:
   //   RB_QO  own quadratic of the node over (x, u_prev, u, eps)       (NYT x NYT) + gradient
@@ -2080,7 +2089,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
   // The branching part of the tree is processed level by level with a barrier in between.
   using namespace rb;
   const KArgs& A = *Q.A;
-  static_assert(RB_SIZE <= EL_SIZE, "node working set must fit the per-group LDS region");
+  static_assert(!RB_IN_LDS || RB_SIZE <= EL_SIZE, "node working set must fit the per-group LDS region");
   const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   // The failure flag is read by every thread after a barrier and reset here by thread 0.  When the caller repeats the
@@ -2399,6 +2408,10 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   for (int g = T.tid; g < NX; g += T.nt) Q.c[g] = Q.x[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
   eval_models(T, Q);
   T.sync();
+  for (int rep = 0; rep < A.trace_pad; ++rep) {      // measurement aid (DOMPC_EXTRA_TRAFFIC): extra read+write passes over the model-output records
+    for (int i = T.tid; i < A.n_edges * MO_SIZE; i += T.nt) { volatile double* p_ = Q.mo + i; *p_ = *p_; }
+    T.sync();
+  }
   {
     const int ng = T.nt / T.gs, gid = T.tid / T.gs, lane = T.tid % T.gs;
     ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / T.gs) * EL_SIZE;

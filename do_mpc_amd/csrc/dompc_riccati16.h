@@ -19,7 +19,7 @@
 namespace dompc {
 namespace r16 {
 
-constexpr bool ENABLED = (NYT <= 16) && (NE == 0) && (NS == 0) && !SHARD;
+constexpr bool ENABLED = R16_ENABLED;      // (NYT <= 16, no nl_cons rows, not the tree-sharding build)
 
 #ifndef DOMPC_HOST_EMU
 typedef double d4 __attribute__((ext_vector_type(4)));

@@ -32,7 +32,7 @@ struct dompc_handle {
   dompc_problem_desc d;
   std::string error;
   std::string code_path;
-  int32_t e_pad = 0, n_slots = 0, block = 256;
+  int32_t e_pad = 0, n_slots = 0, block = 256, occupancy = 0;
   int64_t ws_stride = 0, sweep_block = 0, el_size = 0;
   dompc::KArgs base;       // tables + workspace filled in, I/O pointers zero
   std::vector<void*> dev_allocs;
@@ -346,9 +346,21 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   for (int i = 0; i < 4; ++i) h->xlayout[i] = info[12 + i];
   h->shard_capable = info[16] != 0;
   h->el_size = info[17];
-  // ---- slots: one per resident workgroup (2 wavefronts per SIMD = 8 per CU, 256 CUs)
+  // ---- slots: one per workgroup the device can keep resident (occupancy of the solver kernel at this block size
+  //      and LDS pool, times the number of CUs); more problems than slots are pulled from a work counter
   int max_batch = d.max_batch > 0 ? d.max_batch : 1;
-  const int resident = 512 * (256 / h->block);
+  int resident = 512 * (256 / h->block);
+#ifndef DOMPC_HOST_EMU
+  {
+    const int64_t per_wave = (int64_t)(h->block / 64) * h->el_size, red = h->xlayout[0] * (int64_t)h->block;
+    const size_t lds = sizeof(double) * (size_t)(per_wave > red ? per_wave : red);
+    int occ = 0, cus = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->fn_solve, h->block, lds) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d.device) == hipSuccess && occ > 0 && cus > 0)
+      resident = occ * cus;
+    h->occupancy = occ;
+  }
+#endif
   h->n_slots = d.n_slots > 0 ? d.n_slots : (max_batch < resident ? max_batch : resident);
   if (const char* se = getenv("DOMPC_SLOTS")) h->n_slots = atoi(se);
 #ifdef DOMPC_HOST_EMU
@@ -428,6 +440,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     if (dev_alloc(h, (void**)&h->s_dbg[i], sizeof(double) * (size_t)(d.n_opt_x > d.n_g ? d.n_opt_x : d.n_g))) return fail(1);
   if (dev_alloc(h, (void**)&h->s_trace, sizeof(double) * 8 * h->trace_cap)) return fail(1);
   A.trace = h->s_trace; A.trace_cap = h->trace_cap;
+  if (const char* xt = getenv("DOMPC_EXTRA_TRAFFIC")) A.trace_pad = atoi(xt);    // measurement aid, see sweep()
   if (dev_sync(h)) return fail(1);
   // the description's table pointers are not valid after return
   h->d.level_node_start = nullptr;

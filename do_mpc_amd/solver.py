@@ -186,8 +186,6 @@ class HipIpmSolver:
                 setattr(d.opts, f, type(getattr(d.opts, f))(v))
             elif k == "dompc.obj_scaling":
                 d.opts.obj_scaling = int(v)
-            elif k == "dompc.generic_riccati":     # A/B aid: LDS-staged node update instead of the matrix-core tiles
-                d.opts.reserved = (d.opts.reserved & ~1) | (1 if v else 0)
             else:
                 self.ignored_options.append(k)     # print levels, linear solver, ... : no meaning here
         self.options = d.opts
