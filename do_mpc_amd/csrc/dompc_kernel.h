@@ -2380,24 +2380,11 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     Q.dx[g] = sg > 0.0 ? -bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu) / sg : 0.0;
   }
   T.sync();
-  // bound multiplier steps
-  for (int g = T.tid; g < A.n_opt_x; g += T.nt) {
-    if (!mk_x(A, g)) continue;
-    const double xv = Q.x[g], l = Q.lb[g], u = Q.ub[g];
-    Q.dzl[g] = (l > -INFINITY) ? mu / (xv - l) - Q.zl[g] - Q.zl[g] / (xv - l) * Q.dx[g] : 0.0;
-    Q.dzu[g] = (u < INFINITY) ? mu / (u - xv) - Q.zu[g] + Q.zu[g] / (u - xv) * Q.dx[g] : 0.0;
-  }
-  for (int g = T.tid; g < A.n_edges * NE; g += T.nt) {
-    const int si = (g / NE1) * NE1 + g % NE1;
-    const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
-    Q.dzsl[si] = (l > -INFINITY) ? mu / (sv - l) - Q.zsl[si] - Q.zsl[si] / (sv - l) * Q.ds[si] : 0.0;
-    Q.dzsu[si] = (u < INFINITY) ? mu / (u - sv) - Q.zsu[si] + Q.zsu[si] / (u - sv) * Q.ds[si] : 0.0;
-  }
+  // (the bound multiplier steps dz are functions of (x, bound, z, dx, mu): formed where they are used - dz_lo / dz_up)
   T.sync();
 }
 
 // ================================================================================================
-struct Errs { double e_d, e_p, e_c0, sum_y, sum_z, obj, theta; };
 
 // derivative sweep at the current iterate: per-edge evaluation/condensing, node assembly, dummies
 DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
@@ -2489,16 +2476,60 @@ DOMPC_PHASE void refresh_mu(const Thr& T, const Prob& Q, double dmu) {
   T.sync();
 }
 
-// error measures (IPOPT eq. (5)/(6)) + objective + theta at the current iterate
-DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, double mu_c) {
+// bound multiplier steps of the primal-dual system:  dz_L = mu/(x-l) - z_L - z_L/(x-l) dx ,  dz_U = mu/(u-x) - z_U + z_U/(u-x) dx
+DOMPC_DEV inline double dz_lo(double x, double l, double z, double d, double mu) { return mu / (x - l) - z - z / (x - l) * d; }
+DOMPC_DEV inline double dz_up(double x, double u, double z, double d, double mu) { return mu / (u - x) - z + z / (u - x) * d; }
+
+// Complementarity statistics of the bounded variables: extremes of the products s = (x-l) z_L, (u-x) z_U and the
+// sum of the multipliers.  max_i |s_i - mu| = max(s_max - mu, mu - s_min) gives the complementarity error for ANY
+// barrier parameter without another pass over the variables (the barrier-update test needs it at several mu).
+struct Comp { double smax, smin, sum_z; };      // thread-local partials or reduced values
+DOMPC_DEV inline void comp_add(Comp& C, double s, double z) { C.smax = fmax(C.smax, s); C.smin = fmin(C.smin, s); C.sum_z += z; }
+DOMPC_DEV inline double comp_err(const Comp& C, double mu) { return C.smax >= C.smin ? fmax(C.smax - mu, mu - C.smin) : 0.0; }
+
+// Strided loop over [0, n) by the threads of the problem, four elements per thread and trip: LOAD(u, g) pulls the
+// operands of element g into slot u (all loads of a trip are issued before anything is computed from them - a plain
+// grid-stride loop keeps ONE dependent load -> compute -> store chain per thread in flight and spends its time
+// waiting for HBM), BODY(u, g) consumes slot u.
+#define DOMPC_FOR4(n, LOAD, BODY)                                              \
+  for (int g0_ = T.tid; g0_ < (n); g0_ += 4 * T.nt) {                          \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                         \
+      const int g_ = g0_ + u_ * T.nt;                                          \
+      const int gc_ = g_ < (n) ? g_ : g0_;                                     \
+      LOAD(u_, gc_)                                                            \
+    }                                                                          \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                         \
+      const int g_ = g0_ + u_ * T.nt;                                          \
+      if (g_ < (n)) { BODY(u_, g_) }                                           \
+    }                                                                          \
+  }
+
+// error measures (IPOPT eq. (5)/(6)) + objective + theta at the current iterate.  `pre`: thread-local complementarity
+// partials already accumulated by the caller (the accept pass has the updated x, z in registers), or null.
+struct Errs { double e_d, e_p, sum_y, obj, theta; Comp C; };
+DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, const Comp* pre) {
   const KArgs& A = *Q.A;
-  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // e_d, e_p, e_c, sum|y|, sum z, obj, theta
-  for (int g = T.tid; g < A.n_opt_x; g += T.nt) {
-    if (!sh_cnt(A, mk_x(A, g))) continue;
-    v[0] = fmax(v[0], fabs(Q.rd[g]));
-    const double l = Q.lb[g], u = Q.ub[g];
-    if (l > -INFINITY) { v[2] = fmax(v[2], fabs((Q.x[g] - l) * Q.zl[g] - mu_c)); v[4] += Q.zl[g]; }
-    if (u < INFINITY) { v[2] = fmax(v[2], fabs((u - Q.x[g]) * Q.zu[g] - mu_c)); v[4] += Q.zu[g]; }
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // e_d, e_p, sum|y|, obj, theta, smax, -smin, sum z
+  Comp C = pre ? *pre : Comp{-INFINITY, INFINITY, 0.0};
+  if (pre) {
+    double rd_[4];
+#define L_(u, g) rd_[u] = Q.rd[g];
+#define B_(u, g) if (sh_cnt(A, mk_x(A, g))) v[0] = fmax(v[0], fabs(rd_[u]));
+    DOMPC_FOR4(A.n_opt_x, L_, B_)
+#undef L_
+#undef B_
+  } else {
+    double rd_[4], x_[4], l_[4], u2_[4], zl_[4], zu_[4];
+#define L_(u, g) rd_[u] = Q.rd[g]; x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
+#define B_(u, g)                                                                   \
+    if (sh_cnt(A, mk_x(A, g))) {                                                   \
+      v[0] = fmax(v[0], fabs(rd_[u]));                                             \
+      if (l_[u] > -INFINITY) comp_add(C, (x_[u] - l_[u]) * zl_[u], zl_[u]);        \
+      if (u2_[u] < INFINITY) comp_add(C, (u2_[u] - x_[u]) * zu_[u], zu_[u]);       \
+    }
+    DOMPC_FOR4(A.n_opt_x, L_, B_)
+#undef L_
+#undef B_
   }
   for (int g = T.tid; g < A.n_edges * NE; g += T.nt) {
     const int e = g / NE1, i = g % NE1;
@@ -2506,24 +2537,30 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, double mu_c) {
     const int si = e * NE1 + i;
     const double yd = Q.lam[A.edge_row0[e] + NW + NX + i];
     v[0] = fmax(v[0], fabs(-yd - Q.zsl[si] + Q.zsu[si]));
-    const double l = Q.sl[si], u = Q.su[si];
-    if (l > -INFINITY) { v[2] = fmax(v[2], fabs((Q.s[si] - l) * Q.zsl[si] - mu_c)); v[4] += Q.zsl[si]; }
-    if (u < INFINITY) { v[2] = fmax(v[2], fabs((u - Q.s[si]) * Q.zsu[si] - mu_c)); v[4] += Q.zsu[si]; }
+    if (!pre) {
+      const double l = Q.sl[si], u = Q.su[si];
+      if (l > -INFINITY) comp_add(C, (Q.s[si] - l) * Q.zsl[si], Q.zsl[si]);
+      if (u < INFINITY) comp_add(C, (u - Q.s[si]) * Q.zsu[si], Q.zsu[si]);
+    }
   }
-  for (int r = T.tid; r < A.n_g; r += T.nt) {
-    if (!sh_cnt(A, mk_g(A, r))) continue;
-    v[1] = fmax(v[1], fabs(Q.c[r]));
-    v[3] += fabs(Q.lam[r]);
-    v[6] += fabs(Q.c[r]);
+  {
+    double c_[4], y_[4];
+#define L_(u, g) c_[u] = Q.c[g]; y_[u] = Q.lam[g];
+#define B_(u, g) if (sh_cnt(A, mk_g(A, g))) { v[1] = fmax(v[1], fabs(c_[u])); v[2] += fabs(y_[u]); v[4] += fabs(c_[u]); }
+    DOMPC_FOR4(A.n_g, L_, B_)
+#undef L_
+#undef B_
   }
   for (int e = T.tid; e < A.n_edges; e += T.nt)
-    if (sh_cnt(A, mk_e(A, e))) v[5] += Q.ES(e)[ES_OBJ];
+    if (sh_cnt(A, mk_e(A, e))) v[3] += Q.ES(e)[ES_OBJ];
   for (int n = T.tid; n < A.n_nodes; n += T.nt)
-    if (sh_cnt(A, mk_n(A, n))) v[5] += node_rterm_f(Q, n, Q.x);
-  const int ops[8] = {R_MAX, R_MAX, R_MAX, R_SUM, R_SUM, R_SUM, R_SUM, R_SUM};
+    if (sh_cnt(A, mk_n(A, n))) v[3] += node_rterm_f(Q, n, Q.x);
+  v[5] = C.smax; v[6] = -C.smin; v[7] = C.sum_z;
+  const int ops[8] = {R_MAX, R_MAX, R_SUM, R_SUM, R_SUM, R_MAX, R_MAX, R_SUM};
   wg_reduce(T, v, ops);
   Errs E;
-  E.e_d = v[0]; E.e_p = v[1]; E.e_c0 = v[2]; E.sum_y = v[3]; E.sum_z = v[4]; E.obj = v[5]; E.theta = v[6];
+  E.e_d = v[0]; E.e_p = v[1]; E.sum_y = v[2]; E.obj = v[3]; E.theta = v[4];
+  E.C.smax = v[5]; E.C.smin = -v[6]; E.C.sum_z = v[7];
   return E;
 }
 
@@ -2680,7 +2717,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   }
   const double mu_min = fmin(O.tol, O.compl_inf_tol * Q.sf) / (O.kappa_eps + 1.0);
   double tau = fmax(O.tau_min, 1.0 - mu);
-  Errs E = measure(T, Q, 0.0);
+  Errs E = measure(T, Q, nullptr);
   const double theta0 = E.theta;
   const double theta_max = 1e4 * fmax(1.0, theta0), theta_min = 1e-4 * fmax(1.0, theta0);
   int n_filt = 0;
@@ -2693,11 +2730,12 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (bad) { status = 3; break; }
     if (T.fget(6)) { status = 6; break; }                                    // the host asked the kernel to stop
     if ((T.nwg > 1 || sh_on(A)) && T.fget(7)) { status = 5; break; }       // a peer workgroup never arrived at a barrier
-    const double sd = fmax(s_max, (E.sum_y + E.sum_z) / fmax(1.0, n_dual)) / s_max;
-    const double sc = fmax(s_max, E.sum_z / fmax(1.0, n_bounds)) / s_max;
-    E0 = fmax(E.e_d / sd, fmax(E.e_p, E.e_c0 / sc));
+    const double sd = fmax(s_max, (E.sum_y + E.C.sum_z) / fmax(1.0, n_dual)) / s_max;
+    const double sc = fmax(s_max, E.C.sum_z / fmax(1.0, n_bounds)) / s_max;
+    const double e_c0 = comp_err(E.C, 0.0);
+    E0 = fmax(E.e_d / sd, fmax(E.e_p, e_c0 / sc));
     if (!(E0 == E0) || !(E.obj == E.obj)) { status = 4; break; }
-    if (E0 <= O.tol && E.e_d <= O.dual_inf_tol && E.e_p <= O.constr_viol_tol && E.e_c0 <= O.compl_inf_tol) {
+    if (E0 <= O.tol && E.e_d <= O.dual_inf_tol && E.e_p <= O.constr_viol_tol && e_c0 <= O.compl_inf_tol) {
       status = 0; break;
     }
     if (E0 <= O.acceptable_tol) {
@@ -2707,9 +2745,8 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
 
     // ---- barrier update (monotone Fiacco-McCormick)
     const double mu_before = mu;
-    while (true) {
-      c_t = prof_clock(); Errs Em = measure(T, Q, mu); c_meas += prof_clock() - c_t;
-      const double Emu = fmax(Em.e_d / sd, fmax(Em.e_p, Em.e_c0 / sc));
+    while (true) {       // (the iterate does not move in here: only the complementarity error depends on mu - comp_err)
+      const double Emu = fmax(E.e_d / sd, fmax(E.e_p, comp_err(E.C, mu) / sc));
       if (Emu <= O.kappa_eps * mu && mu > mu_min) {
         mu = fmax(mu_min, fmin(O.kappa_mu * mu, pow(mu, O.theta_mu)));
         tau = fmax(O.tau_min, 1.0 - mu);
@@ -2738,23 +2775,32 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
 
     // ---- fraction to the boundary, directional derivative of the barrier function
     double r5[5] = {1.0, 1.0, 0.0, 0.0, 0.0};   // a_max, a_z, dphi, barrier-sum, (unused)
-    for (int g = T.tid; g < nX; g += T.nt) {
-      if (!sh_cnt(A, mk_x(A, g))) continue;
-      const double xv = Q.x[g], l = Q.lb[g], u = Q.ub[g], d = Q.dx[g];
-      double gphi = Q.gf[g];
-      if (l > -INFINITY) {
-        if (d < 0.0) r5[0] = fmin(r5[0], -tau * (xv - l) / d);
-        if (Q.dzl[g] < 0.0) r5[1] = fmin(r5[1], -tau * Q.zl[g] / Q.dzl[g]);
-        gphi -= mu / (xv - l);
-        r5[3] -= log(xv - l);
+    {
+      double x_[4], l_[4], u2_[4], d_[4], gf_[4], zl_[4], zu_[4];
+#define L_(u, g) x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; d_[u] = Q.dx[g]; gf_[u] = Q.gf[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
+#define B_(u, g)                                                                               \
+      if (sh_cnt(A, mk_x(A, g))) {                                                             \
+        const double xv = x_[u], l = l_[u], ub_ = u2_[u], d = d_[u];                           \
+        double gphi = gf_[u];                                                                  \
+        if (l > -INFINITY) {                                                                   \
+          if (d < 0.0) r5[0] = fmin(r5[0], -tau * (xv - l) / d);                               \
+          const double dz = dz_lo(xv, l, zl_[u], d, mu);                                       \
+          if (dz < 0.0) r5[1] = fmin(r5[1], -tau * zl_[u] / dz);                               \
+          gphi -= mu / (xv - l);                                                               \
+          r5[3] -= log(xv - l);                                                                \
+        }                                                                                      \
+        if (ub_ < INFINITY) {                                                                  \
+          if (d > 0.0) r5[0] = fmin(r5[0], tau * (ub_ - xv) / d);                              \
+          const double dz = dz_up(xv, ub_, zu_[u], d, mu);                                     \
+          if (dz < 0.0) r5[1] = fmin(r5[1], -tau * zu_[u] / dz);                               \
+          gphi += mu / (ub_ - xv);                                                             \
+          r5[3] -= log(ub_ - xv);                                                              \
+        }                                                                                      \
+        r5[2] += gphi * d;                                                                     \
       }
-      if (u < INFINITY) {
-        if (d > 0.0) r5[0] = fmin(r5[0], tau * (u - xv) / d);
-        if (Q.dzu[g] < 0.0) r5[1] = fmin(r5[1], -tau * Q.zu[g] / Q.dzu[g]);
-        gphi += mu / (u - xv);
-        r5[3] -= log(u - xv);
-      }
-      r5[2] += gphi * d;
+      DOMPC_FOR4(nX, L_, B_)
+#undef L_
+#undef B_
     }
     for (int g = T.tid; g < nSl; g += T.nt) {
       if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
@@ -2763,13 +2809,15 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       double gphi = 0.0;
       if (l > -INFINITY) {
         if (d < 0.0) r5[0] = fmin(r5[0], -tau * (sv - l) / d);
-        if (Q.dzsl[si] < 0.0) r5[1] = fmin(r5[1], -tau * Q.zsl[si] / Q.dzsl[si]);
+        const double dz = dz_lo(sv, l, Q.zsl[si], d, mu);
+        if (dz < 0.0) r5[1] = fmin(r5[1], -tau * Q.zsl[si] / dz);
         gphi -= mu / (sv - l);
         r5[3] -= log(sv - l);
       }
       if (u < INFINITY) {
         if (d > 0.0) r5[0] = fmin(r5[0], tau * (u - sv) / d);
-        if (Q.dzsu[si] < 0.0) r5[1] = fmin(r5[1], -tau * Q.zsu[si] / Q.dzsu[si]);
+        const double dz = dz_up(sv, u, Q.zsu[si], d, mu);
+        if (dz < 0.0) r5[1] = fmin(r5[1], -tau * Q.zsu[si] / dz);
         gphi += mu / (u - sv);
         r5[3] -= log(u - sv);
       }
@@ -2798,15 +2846,29 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     bool accepted = false, armijo_used = false;
     double th_t = 0.0, obj_t = 0.0;
     while (true) {
-      for (int g = T.tid; g < nX; g += T.nt)
-        if (mk_x(A, g)) Q.xt[g] = Q.x[g] + alpha * Q.dx[g];
+      double r3[3] = {0.0, 0.0, 0.0};    // obj, theta, barrier
+      {                                  // trial point and its barrier terms in one pass
+        double x_[4], d_[4], l_[4], u2_[4];
+#define L_(u, g) x_[u] = Q.x[g]; d_[u] = Q.dx[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g];
+#define B_(u, g)                                                                               \
+        if (mk_x(A, g)) {                                                                      \
+          const double xt_ = x_[u] + alpha * d_[u];                                            \
+          Q.xt[g] = xt_;                                                                       \
+          if (sh_cnt(A, mk_x(A, g))) {                                                         \
+            if (l_[u] > -INFINITY) r3[2] -= log(xt_ - l_[u]);                                  \
+            if (u2_[u] < INFINITY) r3[2] -= log(u2_[u] - xt_);                                 \
+          }                                                                                    \
+        }
+        DOMPC_FOR4(nX, L_, B_)
+#undef L_
+#undef B_
+      }
       for (int g = T.tid; g < nSl; g += T.nt) {
         if (!mk_e(A, g / NE1)) continue;
         const int si = (g / NE1) * NE1 + g % NE1;
         Q.st[si] = Q.s[si] + alpha * Q.ds[si];
       }
       T.sync();
-      double r3[3] = {0.0, 0.0, 0.0};    // obj, theta, barrier
       for (int g = T.tid; g < NX; g += T.nt) Q.ct[g] = Q.xt[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
       for (int e = T.tid; e < A.n_edges; e += T.nt) {
         const int m = mk_e(A, e);
@@ -2817,13 +2879,13 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       for (int n = T.tid; n < A.n_nodes; n += T.nt)
         if (sh_cnt(A, mk_n(A, n))) r3[0] += node_rterm_f(Q, n, Q.xt);
       T.sync();
-      for (int r = T.tid; r < A.n_g; r += T.nt)
-        if (sh_cnt(A, mk_g(A, r))) r3[1] += fabs(Q.ct[r]);
-      for (int g = T.tid; g < nX; g += T.nt) {
-        if (!sh_cnt(A, mk_x(A, g))) continue;
-        const double l = Q.lb[g], u = Q.ub[g];
-        if (l > -INFINITY) r3[2] -= log(Q.xt[g] - l);
-        if (u < INFINITY) r3[2] -= log(u - Q.xt[g]);
+      {
+        double c_[4];
+#define L_(u, g) c_[u] = Q.ct[g];
+#define B_(u, g) if (sh_cnt(A, mk_g(A, g))) r3[1] += fabs(c_[u]);
+        DOMPC_FOR4(A.n_g, L_, B_)
+#undef L_
+#undef B_
       }
       for (int g = T.tid; g < nSl; g += T.nt) {
         if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
@@ -2874,39 +2936,62 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     c_ls += prof_clock() - c_t;
     // ---- accept the trial point
     const double ks = 1e10;
-    for (int g = T.tid; g < nX; g += T.nt) {
-      if (!mk_x(A, g)) continue;
-      const double xv = Q.xt[g];
-      Q.x[g] = xv;
-      const double l = Q.lb[g], u = Q.ub[g];
-      if (l > -INFINITY) {
-        double z = Q.zl[g] + a_z * Q.dzl[g];
-        const double d = xv - l;
-        Q.zl[g] = fmax(fmin(z, ks * mu / d), mu / (ks * d));
+    Comp Cp{-INFINITY, INFINITY, 0.0};       // complementarity statistics of the new iterate (consumed by measure() after the sweep)
+    {
+      double xt_[4], x_[4], d_[4], l_[4], u2_[4], zl_[4], zu_[4];
+#define L_(u, g) xt_[u] = Q.xt[g]; x_[u] = Q.x[g]; d_[u] = Q.dx[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
+#define B_(u, g)                                                                               \
+      if (mk_x(A, g)) {                                                                        \
+        const double xv = xt_[u], l = l_[u], ub_ = u2_[u];                                     \
+        const bool cnt_ = sh_cnt(A, mk_x(A, g));                                               \
+        Q.x[g] = xv;                                                                           \
+        if (l > -INFINITY) {                                                                   \
+          const double z = zl_[u] + a_z * dz_lo(x_[u], l, zl_[u], d_[u], mu);                  \
+          const double dd = xv - l;                                                            \
+          const double zn = fmax(fmin(z, ks * mu / dd), mu / (ks * dd));                       \
+          Q.zl[g] = zn;                                                                        \
+          if (cnt_) comp_add(Cp, dd * zn, zn);                                                 \
+        }                                                                                      \
+        if (ub_ < INFINITY) {                                                                  \
+          const double z = zu_[u] + a_z * dz_up(x_[u], ub_, zu_[u], d_[u], mu);                \
+          const double dd = ub_ - xv;                                                          \
+          const double zn = fmax(fmin(z, ks * mu / dd), mu / (ks * dd));                       \
+          Q.zu[g] = zn;                                                                        \
+          if (cnt_) comp_add(Cp, dd * zn, zn);                                                 \
+        }                                                                                      \
       }
-      if (u < INFINITY) {
-        double z = Q.zu[g] + a_z * Q.dzu[g];
-        const double d = u - xv;
-        Q.zu[g] = fmax(fmin(z, ks * mu / d), mu / (ks * d));
-      }
+      DOMPC_FOR4(nX, L_, B_)
+#undef L_
+#undef B_
     }
     for (int g = T.tid; g < nSl; g += T.nt) {
       if (!mk_e(A, g / NE1)) continue;
       const int si = (g / NE1) * NE1 + g % NE1;
-      const double sv = Q.st[si];
+      const double sv = Q.st[si], so = Q.s[si], dsv = Q.ds[si];
+      const bool cnt_ = sh_cnt(A, mk_e(A, g / NE1));
       Q.s[si] = sv;
       const double l = Q.sl[si], u = Q.su[si];
       if (l > -INFINITY) {
-        double z = Q.zsl[si] + a_z * Q.dzsl[si];
-        Q.zsl[si] = fmax(fmin(z, ks * mu / (sv - l)), mu / (ks * (sv - l)));
+        const double z = Q.zsl[si] + a_z * dz_lo(so, l, Q.zsl[si], dsv, mu);
+        const double zn = fmax(fmin(z, ks * mu / (sv - l)), mu / (ks * (sv - l)));
+        Q.zsl[si] = zn;
+        if (cnt_) comp_add(Cp, (sv - l) * zn, zn);
       }
       if (u < INFINITY) {
-        double z = Q.zsu[si] + a_z * Q.dzsu[si];
-        Q.zsu[si] = fmax(fmin(z, ks * mu / (u - sv)), mu / (ks * (u - sv)));
+        const double z = Q.zsu[si] + a_z * dz_up(so, u, Q.zsu[si], dsv, mu);
+        const double zn = fmax(fmin(z, ks * mu / (u - sv)), mu / (ks * (u - sv)));
+        Q.zsu[si] = zn;
+        if (cnt_) comp_add(Cp, (u - sv) * zn, zn);
       }
     }
-    for (int r = T.tid; r < A.n_g; r += T.nt)
-      if (mk_g(A, r)) Q.lam[r] += alpha * Q.dlam[r];
+    {
+      double y_[4], dy_[4];
+#define L_(u, g) y_[u] = Q.lam[g]; dy_[u] = Q.dlam[g];
+#define B_(u, g) if (mk_g(A, g)) Q.lam[g] = y_[u] + alpha * dy_[u];
+      DOMPC_FOR4(A.n_g, L_, B_)
+#undef L_
+#undef B_
+    }
     if (A.trace && b == 0 && T.tid == 0 && it < A.trace_cap) {
       double* tr = A.trace + 8 * it;
       tr[0] = it; tr[1] = mu; tr[2] = E0; tr[3] = E.e_p; tr[4] = E.e_d; tr[5] = accepted ? alpha : -alpha;
@@ -2917,7 +3002,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     ++it;
     c_t = prof_clock(); bad = run_sweep(T, Q, b, slot, mu); c_sweep += prof_clock() - c_t;
     ++n_sweeps;
-    c_t = prof_clock(); E = measure(T, Q, 0.0); c_meas += prof_clock() - c_t;
+    c_t = prof_clock(); E = measure(T, Q, &Cp); c_meas += prof_clock() - c_t;
   }
 
   // ---- outputs (unscaled multipliers, CasADi sign convention)
@@ -2944,7 +3029,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       dompc_stats& S = A.stats[b];
       S.success = (status == 0 || status == 1) ? 1 : 0;
       S.status = status; S.iter_count = it; S.n_reg = n_reg; S.n_ls_fail = n_ls_fail; S.n_sweeps = n_sweeps; S.n_trials = n_trials; S.reserved = 0;
-      S.mu = mu; S.obj = E.obj * isf; S.inf_pr = E.e_p; S.inf_du = E.e_d; S.inf_compl = E.e_c0;
+      S.mu = mu; S.obj = E.obj * isf; S.inf_pr = E.e_p; S.inf_du = E.e_d; S.inf_compl = comp_err(E.C, 0.0);
       S.obj_scaling = Q.sf; S.t_wall_total = 0.0;
     }
   }
