@@ -128,6 +128,7 @@ DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad,
   L.es = take((int64_t)ES_SIZE * n_edges);
   L.nd = take((int64_t)ND_SIZE * n_nodes);
   L.mo = take((int64_t)MO_SIZE * n_edges);
+  o += 128;                       // slack: block-granular staging reads of the last records may run past their end
   L.total = o;
   return L;
 }
@@ -617,7 +618,12 @@ constexpr bool RB_IN_LDS = !R16_ENABLED;
 constexpr bool RB_IN_LDS = true;
 #endif
 constexpr int RB_NEED = RB_IN_LDS ? 2 * (NYT * NYT + NYT) + 5 * NA * NA + 6 * NA + NV * NA + NV + NE * (NA + 4) : 0;   // = rb::RB_SIZE (asserted there)
-constexpr int EL_SIZE = (((EL_RY + NA > RB_NEED ? EL_RY + NA : RB_NEED) + 7) / 8) * 8;
+// forward pass: step vectors + staged operands of a chain-node step (riccati_forward); matrix-core Riccati: two staging buffers
+constexpr int RF_NEED = 3 * NA + NV + NX + 2 * NW1 + (NV * NA + NV) + 2 * (NX * NA + NX);
+constexpr int R16_STAGE = ((NX * NA + NX + NA * NA + 3 * NA + 127) / 128) * 128;      // staged head of an edge record (dompc_riccati16.h)
+constexpr int R16_NEED = R16_ENABLED ? 2 * R16_STAGE : 0;
+constexpr int el_max(int a, int b) { return a > b ? a : b; }
+constexpr int EL_SIZE = ((el_max(el_max(EL_RY + NA, RB_NEED), el_max(RF_NEED, R16_NEED)) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {
   // collocation point (i*DEG + j-1) stored in slot sl, or -1 for element-start states and xkf
@@ -2190,9 +2196,13 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   const KArgs& A = *Q.A;
   const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
+  // operands of a chain-node step, staged in LDS: own gains [K | kv], the child edge's [A B | c], the first NX rows of
+  // the child's value function [P_c | p_c]
+  constexpr int FW_K = NV * NA + NV, FW_AB = NX * NA + NX, FW_N = FW_K + 2 * FW_AB;
+  constexpr int FW_PL = (FW_N + GS_C - 1) / GS_C;
   constexpr int RF_DX = 0, RF_DV = RF_DX + NA, RF_DY = RF_DV + NV, RF_DNU = RF_DY + NA, RF_DW = RF_DNU + NX,
-                RF_RHS = RF_DW + NW1, RF_DXN = RF_RHS + NW1;
-  static_assert(RF_DXN + NA <= EL_SIZE, "forward working set must fit the per-group LDS region");
+                RF_RHS = RF_DW + NW1, RF_DXN = RF_RHS + NW1, RF_IN = RF_DXN + NA;
+  static_assert(RF_IN + FW_N <= EL_SIZE, "forward working set must fit the per-group LDS region");
   // root
   if (T.tid == 0) {
     double* Nd = Q.ND(0);
@@ -2203,12 +2213,10 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   T.sync();
   // node steps: dv = K dx~ + kv, children dx~ = Atilde [dx~; dv] + c~.  Branching stages level by level with
   // a barrier; below the robust horizon each group walks its scenario chain downwards with dx~ kept in LDS.
-  auto node_step = [&](int n, bool staged) {
+  auto node_step = [&](int n) {                         // generic (any number of children; operands from global memory)
     const double* Nd = Q.ND(n);
-    if (!staged) {
-      for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Nd[ND_DXT + a];
-      T.gsync();
-    }
+    for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Nd[ND_DXT + a];
+    T.gsync();
     for (int i = lane; i < NV; i += GS) {
       double t = Nd[ND_KV + i];
 #pragma unroll
@@ -2235,26 +2243,96 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         t = Ld[RF_DV + a - NX];
       }
       Q.ND(cn)[ND_DXT + a] = t;
-      if (cc == 1) Ld[RF_DXN + a] = t;
     }
     T.gsync();
-    if (cc == 1) {
-      for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Ld[RF_DXN + a];
-      T.gsync();
+  };
+  // chain node (one child): operands requested one node ahead (load_step), staged through LDS; also forms the
+  // multiplier step of the child's incoming continuity rows  d nu = P_c dx~_c + p_c  (x rows)
+  auto load_step = [&](int n, double (&v)[FW_PL]) {
+    const int e = A.node_child_start[n];
+    const double *Nd = Q.ND(n), *S_ = Q.ES(e), *Nc = Q.ND(A.edge_child[e]);
+#pragma unroll
+    for (int q = 0; q < FW_PL; ++q) {
+      const int i = lane + q * GS;
+      double x = 0.0;
+      if (i < NV * NA) x = Nd[ND_K + i];
+      else if (i < FW_K) x = Nd[ND_KV + i - NV * NA];
+      else if (i < FW_K + NX * NA) x = S_[ES_AB + i - FW_K];
+      else if (i < FW_K + FW_AB) x = S_[ES_CV + i - FW_K - NX * NA];
+      else if (i < FW_K + FW_AB + NX * NA) x = Nc[ND_P + i - FW_K - FW_AB];
+      else if (i < FW_N) x = Nc[ND_PV + i - FW_K - FW_AB - NX * NA];
+      v[q] = x;
     }
+  };
+  auto chain_step = [&](int n, const double (&v)[FW_PL]) {      // dx~ of node n is in Ld[RF_DX]
+    const int e = A.node_child_start[n], cn = A.edge_child[e];
+#pragma unroll
+    for (int q = 0; q < FW_PL; ++q) {
+      const int i = lane + q * GS;
+      if (i < FW_N) Ld[RF_IN + i] = v[q];
+    }
+    T.gsync();
+    const ldsd *K_ = Ld + RF_IN, *KV_ = K_ + NV * NA, *AB_ = Ld + RF_IN + FW_K, *CV_ = AB_ + NX * NA,
+               *PC_ = Ld + RF_IN + FW_K + FW_AB, *PV_ = PC_ + NX * NA;
+    for (int i = lane; i < NV; i += GS) {
+      double t = KV_[i];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) t += K_[i * NA + a] * Ld[RF_DX + a];
+      Ld[RF_DV + i] = t;
+      if (i < NU) Q.dx[A.node_u_off[n] + i] = t;
+      else Q.dx[A.node_eps_off[n] + i - NU] = t;
+    }
+    T.gsync();
+    for (int a = lane; a < NA; a += GS) {
+      double t;
+      if (a < NX) {
+        t = CV_[a];
+#pragma unroll
+        for (int b = 0; b < NX; ++b) t += AB_[a * NA + b] * Ld[RF_DX + b];
+#pragma unroll
+        for (int b = 0; b < NU; ++b) t += AB_[a * NA + NX + b] * Ld[RF_DV + b];
+        Q.dx[A.node_x_off[cn] + a] = t;
+      } else {
+        t = Ld[RF_DV + a - NX];
+      }
+      Q.ND(cn)[ND_DXT + a] = t;
+      Ld[RF_DXN + a] = t;
+    }
+    T.gsync();
+    for (int a = lane; a < NX; a += GS) {
+      double t = PV_[a];
+#pragma unroll
+      for (int b = 0; b < NA; ++b) t += PC_[a * NA + b] * Ld[RF_DXN + b];
+      Q.dlam[A.edge_row0[e] + NW + a] = t;
+    }
+    for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Ld[RF_DXN + a];
+    T.gsync();
   };
   const int cl = A.chain_level < A.N ? A.chain_level : A.N;
   for (int k = 0; k < cl; ++k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
     for (int n = n0 + gid; n < n1; n += ng)
-      if (mk_n(A, n)) node_step(n, false);
+      if (mk_n(A, n)) node_step(n);
     T.sync();
   }
   {
     const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
     for (int s_ = gid; s_ < S; s_ += ng) {
       if (!mk_n(A, A.level_node_start[A.N] + s_)) continue;
-      for (int k = cl; k < A.N; ++k) node_step(A.level_node_start[k] + s_, k > cl);
+      if (cl >= A.N) continue;
+      double vin[FW_PL];
+      load_step(A.level_node_start[cl] + s_, vin);
+      for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Q.ND(A.level_node_start[cl] + s_)[ND_DXT + a];
+      T.gsync();
+      for (int k = cl; k < A.N; ++k) {
+        double vnx[FW_PL];
+        if (k + 1 < A.N) load_step(A.level_node_start[k + 1] + s_, vnx);
+        chain_step(A.level_node_start[k] + s_, vin);
+        if (k + 1 < A.N) {
+#pragma unroll
+          for (int q = 0; q < FW_PL; ++q) vin[q] = vnx[q];
+        }
+      }
     }
     T.sync();
   }
@@ -2265,17 +2343,18 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     for (int b = 0; b < NA; ++b) t += Nd[ND_P + a * NA + b] * Nd[ND_DXT + b];
     Q.dlam[a] = -t;
   }
-  // per edge: dw, d nu, d lambda, nl_cons steps.  The per-edge record entries a lane needs (its rows of W, Hww,
-  // its column of G_w^-1) do not depend on the step, so they are loaded into registers up front: two global
-  // round trips per edge instead of one per dependent sub-step.
+  // per edge: dw, d nu, d lambda, nl_cons steps.  Everything a lane needs from the per-edge record (its rows of W, Hww,
+  // its column of the stored inverse block) and from the node steps is loaded in ONE batch at the top of the edge.
   for (int e = gid; e < A.n_edges; e += ng) {
     if (!mk_e(A, e)) continue;
     const int n = A.edge_parent[e], cn = A.edge_child[e];
     const double* Nd = Q.ND(n);
     const double* Nc = Q.ND(cn);
     const int row0 = A.edge_row0[e];
+    const bool chain_edge = A.edge_level[e] >= cl;          // its d nu was formed by the chain walk
     constexpr int RPL = (NW1 + GS_C - 1) / GS_C;          // rows (= columns of G_w^-1) per lane: 1 on the device
-    double wrow[RPL][NA + 1], hrow[RPL][NA], rw_r[RPL], sg_r[RPL];
+    constexpr int LU1 = LU_N > 0 ? LU_N : 1;
+    double wrow[RPL][NA + 1], hrow[RPL][NA], rw_r[RPL], sg_r[RPL], inv_c[RPL][LU1];
     if (M > 0) {
 #pragma unroll
       for (int q = 0; q < RPL; ++q) {
@@ -2289,29 +2368,40 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         sg_r[q] = Q.EW(e, EW_SIGW + rc);
         const double* Hp = Q.MO(e) + MO_PT + (pt >= 0 ? pt : 0) * PT_STRIDE + NX + NX * NA;
 #pragma unroll
-        for (int b = 0; b < NA; ++b) hrow[q][b] = (pt >= 0) ? Hp[symi(rc % NX, b, NA)] : 0.0;
+        for (int b = 0; b < NA; ++b) hrow[q][b] = Hp[symi(rc % NX, b, NA)];
+        const int rl = r < LU_N ? r : 0;
+#pragma unroll
+        for (int k2 = 0; k2 < LU_N; ++k2) inv_c[q][k2] = Q.EW(e, EW_LU + k2 * LU_N + rl);   // column r of the stored block
+        if (pt < 0) {
+#pragma unroll
+          for (int b = 0; b < NA; ++b) hrow[q][b] = 0.0;
+        }
       }
     }
-    for (int a = lane; a < NA; a += GS) Ld[RF_DY + a] = (a < NX) ? Nd[ND_DXT + a] : Q.dx[A.node_u_off[n] + a - NX];
-    for (int a = lane; a < NX; a += GS) {
-      double t = Nc[ND_PV + a];
-#pragma unroll
-      for (int b = 0; b < NA; ++b) t += Nc[ND_P + a * NA + b] * Nc[ND_DXT + b];
-      Ld[RF_DNU + a] = t;
-      Q.dlam[row0 + NW + a] = t;
+    {
+      const int a0 = lane < NA ? lane : 0;
+      const double dy0 = (a0 < NX) ? Nd[ND_DXT + a0] : Q.dx[A.node_u_off[n] + a0 - NX];
+      const double dnu0 = Q.dlam[row0 + NW + (lane < NX ? lane : 0)];
+      if (GS > 1) {
+        if (lane < NA) Ld[RF_DY + lane] = dy0;
+        if (chain_edge && lane < NX) Ld[RF_DNU + lane] = dnu0;
+      } else {
+        for (int a = 0; a < NA; ++a) Ld[RF_DY + a] = (a < NX) ? Nd[ND_DXT + a] : Q.dx[A.node_u_off[n] + a - NX];
+        if (chain_edge)
+          for (int a = 0; a < NX; ++a) Ld[RF_DNU + a] = Q.dlam[row0 + NW + a];
+      }
     }
+    if (!chain_edge)
+      for (int a = lane; a < NX; a += GS) {
+        double t = Nc[ND_PV + a];
+#pragma unroll
+        for (int b = 0; b < NA; ++b) t += Nc[ND_P + a * NA + b] * Nc[ND_DXT + b];
+        Ld[RF_DNU + a] = t;
+        Q.dlam[row0 + NW + a] = t;
+      }
     T.gsync();
     if (M > 0) {
       const int woff = A.edge_w_off[e];
-      constexpr int LU1 = LU_N > 0 ? LU_N : 1;
-      double inv_c[RPL][LU1];
-#pragma unroll
-      for (int q = 0; q < RPL; ++q) {
-        const int r = lane + q * GS;
-        const int rc = r < LU_N ? r : 0;
-#pragma unroll
-        for (int k2 = 0; k2 < LU_N; ++k2) inv_c[q][k2] = Q.EW(e, EW_LU + k2 * LU_N + rc);   // column r of the stored block
-      }
 #pragma unroll
       for (int q = 0; q < RPL; ++q) {
         const int r = lane + q * GS;

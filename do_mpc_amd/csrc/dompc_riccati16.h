@@ -134,47 +134,114 @@ __device__ inline Val leaf(const Prob& Q, int n, double mu, double delta, int la
   return V;
 }
 
+// Operands of one node update that come from global memory, requested ONE NODE AHEAD while a wavefront walks its
+// scenario chain (they arrive during the ~50 matrix-core instructions of the child's update instead of costing a
+// memory round trip at the start of every node):
+//   * the node's own variable data (column layout: lane l, z-entry l & 15) - NodeIn, 7 registers;
+//   * the head of the first child edge's record [A B | c | Q~ | q~ | r_y] (ES_STAGE doubles, contiguous) - copied
+//     asynchronously into the wavefront's LDS region by the LDS-DMA path (global_load_lds_dwordx4: no staging
+//     registers), two buffers alternating between consecutive nodes.
+constexpr int ES_STAGE = R16_STAGE;                 // doubles: whole 64 lanes x 16 B pieces covering [0, ES_RY + NA)
+static_assert(ES_RY + NA <= ES_STAGE && ES_QV + NA <= ES_STAGE && ES_QT + NA * NA <= ES_STAGE && ES_CV + NX <= ES_STAGE,
+              "the staged head of the edge record must contain A, B, c, Q~, q~, r_y");
+// (a piece may run past the end of a short record into the following records of the same workspace slot - never used;
+//  ws_layout() keeps 128 doubles of slack behind the last array)
+static_assert(!R16_ENABLED || 2 * ES_STAGE <= EL_SIZE, "two staging buffers must fit the wavefront's LDS region");
+struct NodeIn { double xv, lo, hi, zlo, zhi, nu, upv; };
+__device__ inline void stage_edge(const Prob& Q, int e, int lane, ldsd* dst) {
+  const double* S_ = Q.ES(e);
+#pragma unroll
+  for (int q = 0; q < ES_STAGE / 128; ++q)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(S_ + 128 * q + 2 * lane),
+                                     (__attribute__((address_space(3))) void*)(dst + 128 * q), 16, 0, 0);
+}
+__device__ inline void staged_ready() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ inline void load_node(const Prob& Q, int n, int lane, NodeIn& R) {
+  const KArgs& A = *Q.A;
+  const int j = lane & 15;
+  const int xo = A.node_x_off[n], uo = A.node_u_off[n];
+  const int ie = A.node_in_edge[n], pn = A.node_parent[n];
+  const bool is_up = (j >= NX && j < NA);
+  const int jj = j < NYT ? j : 0;
+  const int gi = (jj < NX) ? xo + jj : (is_up ? uo + (jj - NX) : uo + (jj - NA));
+  R.xv = Q.x[gi]; R.lo = Q.lb[gi]; R.hi = Q.ub[gi]; R.zlo = Q.zl[gi]; R.zhi = Q.zu[gi];
+  const int iu = is_up ? jj - NX : (jj >= NA ? jj - NA : 0);
+  R.upv = (jj >= NX) ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / DOMPC_SU[iu]) : 0.0;
+  R.nu = (jj < NX) ? ((ie >= 0) ? Q.lam[A.edge_row0[ie] + NW + jj] : Q.lam[jj]) : 0.0;
+}
+// tiles of the staged first child edge (LDS reads)
+__device__ inline void staged_tiles(const ldsd* Ls, int lane, d4& qt, d4& F, d4& f0, double& fu, double& ry, double& qv) {
+  const int g = lane >> 4, j = lane & 15;
+  const int yj = yz(j);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = g + 4 * r;
+    const int yi = yz(i);
+    const bool valid = i < NYT && j < NYT && yi >= 0 && yj >= 0;
+    const double q_ = Ls[ES_QT + (valid ? yi * NA + yj : 0)];
+    qt[r] = valid ? q_ : 0.0;
+    const double ab = Ls[ES_AB + ((i < NX && yj >= 0) ? i * NA + yj : 0)];
+    double fv = (i < NX && yj >= 0 && j < NYT) ? ab : 0.0;
+    if (i >= NX && i < NA) fv = (j == NA + (i - NX)) ? 1.0 : 0.0;
+    F[r] = fv;
+    const double cv = Ls[ES_CV + (i < NX ? i : 0)];
+    f0[r] = (j == 0 && i < NX) ? cv : 0.0;
+  }
+  {
+    const double ab = Ls[ES_AB + ((j < NX && g < NU) ? j * NA + NX + g : 0)];
+    double v = (g < NU && j < NX) ? ab : 0.0;
+    if (g < NU && j >= NX && j < NA) v = (g == j - NX) ? 1.0 : 0.0;
+    fu = v;
+  }
+  const int yjj = (j < NYT) ? yj : -1;
+  ry = (yjj >= 0) ? Ls[ES_RY + (yjj >= 0 ? yjj : 0)] : 0.0;
+  qv = (yjj >= 0) ? Ls[ES_QV + (yjj >= 0 ? yjj : 0)] : 0.0;
+}
+
 // One node update.  `first`: value function of the first child when it is already in registers (chain walk), else
 // null and every child's value function is read from its node record.  Returns 1 if Q_vv is not positive definite.
-__device__ inline int node(const Prob& Q, int n, double mu, double delta, int lane, const Val* first, Val& out) {
+__device__ inline int node(const Prob& Q, int n, double mu, double delta, int lane, const NodeIn& R, const ldsd* Ls, const Val* first, Val& out) {
   const KArgs& A = *Q.A;
   const int g = lane >> 4, j = lane & 15;
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
+  d4 qt_s, F, f0;
+  double fu, ry_s, qv_s;
+  staged_tiles(Ls, lane, qt_s, F, f0, fu, ry_s, qv_s);
   // ---- own quadratic: per-variable terms in column layout (lane: z-entry j)
   double dg = 0.0, gv = 0.0;
   {
-    const int xo = A.node_x_off[n], uo = A.node_u_off[n];
-    const int ie = A.node_in_edge[n], pn = A.node_parent[n];
+    const int ie = A.node_in_edge[n];
     const bool is_up = (j >= NX && j < NA);
     const int jj = j < NYT ? j : 0;
-    const int gi = (jj < NX) ? xo + jj : (is_up ? uo + (jj - NX) : uo + (jj - NA));
-    const double xv = Q.x[gi], lo = Q.lb[gi], hi = Q.ub[gi], zlo = Q.zl[gi], zhi = Q.zu[gi];
     const int iu = is_up ? jj - NX : (jj >= NA ? jj - NA : 0);
-    const double upv = (jj >= NX) ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / DOMPC_SU[iu]) : 0.0;
+    const double xv = R.xv, lo = R.lo, hi = R.hi, upv = R.upv;
     if (is_up) {
       dg = 2.0 * rw * DOMPC_RTERM[iu];
       gv = -2.0 * rw * DOMPC_RTERM[iu] * (xv - upv);
     } else {
-      dg = sigma_of(xv, lo, hi, zlo, zhi) + delta;
+      dg = sigma_of(xv, lo, hi, R.zlo, R.zhi) + delta;
       gv = bar_grad(xv, lo, hi, mu);
       if (jj < NX) {
-        const double nu = (ie >= 0) ? Q.lam[A.edge_row0[ie] + NW + jj] : Q.lam[jj];
-        gv += (ie >= 0) ? -nu : nu;
+        gv += (ie >= 0) ? -R.nu : R.nu;
       } else {
         dg += 2.0 * rw * DOMPC_RTERM[iu];
         gv += 2.0 * rw * DOMPC_RTERM[iu] * (xv - upv);
       }
     }
     const int yjj = yz(jj);
-    if (yjj >= 0)
-      for (int c = 0; c < cc; ++c) {
+    gv += ry_s + qv_s;
+    if (yjj >= 0) {
+      if (delta != 0.0) gv += delta * wtw0_entry(Q, cs, yjj);
+      for (int c = 1; c < cc; ++c) {
         const double* S_ = Q.ES(cs + c);
         gv += S_[ES_RY + yjj] + S_[ES_QV + yjj] + (delta != 0.0 ? delta * wtw0_entry(Q, cs + c, yjj) : 0.0);
       }
+    }
     if (j >= NYT) { dg = 0.0; gv = 0.0; }
   }
-  d4 QO = load_qt(Q, cs, delta, lane);
+  d4 QO = qt_s;
+  if (delta != 0.0) QO = load_qt(Q, cs, delta, lane);
   for (int c = 1; c < cc; ++c) QO += load_qt(Q, cs + c, delta, lane);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -186,11 +253,9 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   const d4 qo0 = col_to_tile0(gv, lane);
   // ---- children, pass 1: Q_tot = Q_own + sum F' P_c F ,  q_tot = q_own + sum F'(P_c f + p_c)
   d4 QT = QO, qt0 = qo0;
-  d4 F, f0;
-  double fu;
   Val Vc;
   for (int c = 0; c < cc; ++c) {
-    load_edge(Q, cs + c, lane, F, f0, fu);
+    if (c > 0) load_edge(Q, cs + c, lane, F, f0, fu);
     Vc = (c == 0 && first) ? *first : load_val(Q, A.edge_child[cs + c], lane);
     const d4 Tm = tmul<KB_A>(Vc.P, F);
     const d4 tv = tmul<KB_A>(Vc.P, f0) + Vc.p0;
@@ -299,6 +364,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
 __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double delta) {
   const KArgs& A = *Q.A;
   const int ng = T.nt / 64, gid = T.tid / 64, lane = T.tid % 64;
+  ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / 64) * EL_SIZE;      // this wavefront's LDS region: two staging buffers
   T.sync();
   if (T.tid == 0) T.fset(0, 0);
   T.sync();
@@ -306,12 +372,28 @@ __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double de
   {
     const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
     for (int s_ = gid; s_ < S; s_ += ng) {
+      NodeIn in;
+      int buf = 0;
+      if (A.N - 1 >= cl) {
+        const int n1 = A.level_node_start[A.N - 1] + s_;
+        load_node(Q, n1, lane, in);
+        stage_edge(Q, A.node_child_start[n1], lane, Ld);
+      }
       Val V = leaf(Q, A.level_node_start[A.N] + s_, mu, delta, lane);
       store_val(Q, A.level_node_start[A.N] + s_, V, lane);
       for (int k = A.N - 1; k >= cl; --k) {
+        staged_ready();            // the staged record of THIS node has landed
+        NodeIn nx;                 // the parent's operands: in flight while this node is updated
+        if (k > cl) {
+          const int np = A.level_node_start[k - 1] + s_;
+          load_node(Q, np, lane, nx);
+          stage_edge(Q, A.node_child_start[np], lane, Ld + (buf ^ 1) * ES_STAGE);
+        }
         Val Vn;
-        if (node(Q, A.level_node_start[k] + s_, mu, delta, lane, &V, Vn)) { T.fset(0, 1); break; }
+        if (node(Q, A.level_node_start[k] + s_, mu, delta, lane, in, Ld + buf * ES_STAGE, &V, Vn)) { T.fset(0, 1); break; }
         V = Vn;
+        if (k > cl) in = nx;
+        buf ^= 1;
       }
     }
     T.sync();
@@ -320,8 +402,12 @@ __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double de
   for (int k = cl - 1; k >= 0; --k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
     for (int n = n0 + gid; n < n1; n += ng) {
+      NodeIn in;
+      load_node(Q, n, lane, in);
+      stage_edge(Q, A.node_child_start[n], lane, Ld);
+      staged_ready();
       Val Vn;
-      if (node(Q, n, mu, delta, lane, nullptr, Vn)) T.fset(0, 1);
+      if (node(Q, n, mu, delta, lane, in, Ld, nullptr, Vn)) T.fset(0, 1);
     }
     T.sync();
     if (T.fget(0)) return 1;

@@ -106,7 +106,9 @@ def test_gloo_ranks_reproduce_the_single_rank_solve(name, kw, world, cut):
         assert ok and abs(iters - st_ref["iter_count"]) <= 2
         assert np.allclose(u, u_ref, rtol=1e-7, atol=0), (rank, u, u_ref)
         assert np.allclose(x[keep], x_ref[keep], rtol=1e-6, atol=1e-8)
-        assert np.allclose(lg, lg_ref, rtol=1e-5, atol=1e-7)
+        # (the ranks may stop one iteration earlier or later than the single-rank run - both points satisfy the 1e-8
+        #  tolerances; the multipliers of the two acceptable points differ by a few 1e-5)
+        assert np.max(np.abs(lg - lg_ref) / np.maximum(1.0, np.abs(lg_ref))) < 2e-4
     # all ranks hold the same combined solution
     for r in res[1:]:
         assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2][keep], res[0][2][keep])
