@@ -671,6 +671,23 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
   }
 }
 
+#ifndef DOMPC_HOST_EMU
+// 16x16 FP64 tiles in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane l holds M[(l >> 4) + 4 r][l & 15], r = 0..3):
+// such a tile is directly the B operand of k-block r and, as A operand, the TRANSPOSED matrix, so
+// tile_mul(X, Y) = X' Y is KB back-to-back MFMAs on registers (see dompc_riccati16.h).
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <int KB>
+__device__ inline d4 tile_mul(const d4& At, const d4& B) {      // At' * B over the first 4*KB rows of both
+  d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(At[kb], B[kb], acc, 0, 0, 0);
+  return acc;
+}
+constexpr bool TILE_CONDENSE = (NI == 1) && (DEG >= 1) && (NA <= 16);
+#else
+constexpr bool TILE_CONDENSE = false;
+#endif
+
 // value of `v` in lane `src` (wave-uniform, here a compile-time constant) for every lane: two v_readlane_b32, the
 // result lives in SGPRs.  Host emulation (one lane): the value itself.
 DOMPC_DEV inline double lane_bcast(double v, int src) {
@@ -1145,7 +1162,73 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     T.gsync();
     }
     DOMPC_PH(2)
-    // ---- phase 5: T1 = Hww W, t0 = Hww w0, U1 = Huw W, u0 = Huw w0   (Hww = blockdiag(Hxx_p) + Sigma_w)
+    // ---- phase 5 (device, single finite element, <= 16 stage variables): condensing on the matrix cores with
+    //      register-resident tiles.  Per collocation point p the stage variables are (x_p; u) = Z_p y + z0_p with
+    //      Z_p = [W_p; E_u], z0_p = (w0_p; 0), so
+    //          Q~ = omega H_l + H_nl + sum_p Z_p'(H_p + Sigma_p) Z_p + W_k' Sigma_k W_k          (k: end-point slot)
+    //          q~ = sum_p Z_p'((H_p + Sigma_p) z0_p + rw_p) + W_k'(Sigma_k w0_k + rw_k)
+    //      - 38 MFMAs instead of the LDS-staged products of the generic path below (H_ww W, H_uw W, W'T1, ...).
+    if constexpr (TILE_CONDENSE) {
+#ifndef DOMPC_HOST_EMU
+      if (act) {
+        constexpr int KB_A = (NA + 3) / 4, KB_X = (NX + 3) / 4;
+        const int g = lane >> 4, j = lane & 15;
+        auto Wm = [&](int row, int col) -> double { return Ld[EL_MX + row * MX_LD + MX_W + col]; };
+        d4 QTt, qv0 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                  // stage-cost and nl_cons Hessians (packed in the model-output record)
+          const int i = g + 4 * r;
+          const bool in = i < NA && j < NA;
+          const int ip = in ? symi(i, j, NA) : 0;
+          double v = om * mo[MO_LT + 1 + NA + ip];
+          if (NE > 0) v += mo[MO_NL + NE + NE * NA + ip];
+          QTt[r] = in ? v : 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < NCOLL; ++p) {              // (NI == 1: point p lives in slot p)
+          d4 Z, z0, H, rwv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = g + 4 * r;
+            const int row = p * NX + (i < NX ? i : 0);
+            const double wv = Wm(row, j < NA ? j : 0), w0v = Wm(row, NA);
+            const double hv = Ld[EL_HP + p * NA * NA + (i < NA ? i : 0) * NA + (j < NA ? j : 0)];
+            const double sg = Ld[EL_SG + row], rw = Ld[EL_RW + row];
+            Z[r] = (i < NX) ? (j < NA ? wv : 0.0) : ((i < NA && j == i) ? 1.0 : 0.0);
+            z0[r] = (j == 0 && i < NX) ? w0v : 0.0;
+            H[r] = (i < NA && j < NA) ? hv + ((i == j && i < NX) ? sg : 0.0) : 0.0;
+            rwv[r] = (j == 0 && i < NX) ? rw : 0.0;
+          }
+          const d4 HZ = tile_mul<KB_A>(H, Z);
+          const d4 hz0 = tile_mul<KB_A>(H, z0) + rwv;
+          QTt += tile_mul<KB_A>(Z, HZ);
+          qv0 += tile_mul<KB_A>(Z, hz0);
+        }
+        {
+          d4 Wk, SWk, sv0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = g + 4 * r;
+            const int row = (M - 1) * NX + (i < NX ? i : 0);
+            const double wv = Wm(row, j < NA ? j : 0), w0v = Wm(row, NA);
+            const double sg = Ld[EL_SG + row], rw = Ld[EL_RW + row];
+            Wk[r] = (i < NX && j < NA) ? wv : 0.0;
+            SWk[r] = (i < NX && j < NA) ? sg * wv : 0.0;
+            sv0[r] = (j == 0 && i < NX) ? sg * w0v + rw : 0.0;
+          }
+          QTt += tile_mul<KB_X>(Wk, SWk);
+          qv0 += tile_mul<KB_X>(Wk, sv0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = g + 4 * r;
+          if (i < NA && j < NA) S_[ES_QT + i * NA + j] = QTt[r];
+          if (i < NA && j == 0) S_[ES_QV + i] = qv0[r];
+        }
+      }
+#endif
+    } else {
+    // ---- phase 5 (generic): T1 = Hww W, t0 = Hww w0, U1 = Huw W, u0 = Huw w0   (Hww = blockdiag(Hxx_p) + Sigma_w)
     //      (stage-cost / nl_cons Hessian entries for phase 6 are requested now, consumed there)
     constexpr int QPL = (NA * NA + GS_C - 1) / GS_C;
     double qlt[QPL], qnl[QPL];
@@ -1206,18 +1289,6 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       gmm(lane, GS, NA, NA, NW, (double*)(Ld + EL_MX + MX_W), 1, MX_LD, (double*)(Ld + EL_T1), NA, 1, 0.0, (double*)(Ld + EL_QT), NA);
     }
     T.gsync();
-    // ---- phase 6: condensed blocks to the shared per-edge record; data for the forward pass
-#ifndef DOMPC_HOST_EMU
-    // touch the model-output record of the edge this wavefront handles next (one dword per 128-byte line):
-    // by the time its assembly starts the lines sit in L2 instead of HBM.  The values are consumed (never
-    // true) at the end of the function so that the loads stay where they are.
-#pragma unroll
-    for (int q = 0; q < PF_N; ++q) {
-      const int line = lane + 64 * q;
-      pf_tok[q] = (e_next >= 0 && line < PF_LINES)
-                      ? *((const volatile unsigned*)((const char*)Q.MO(e_next) + (int64_t)line * 128)) : 0u;
-    }
-#endif
     if (act) {
 #pragma unroll
       for (int qi = 0; qi < QPL; ++qi) {
@@ -1238,6 +1309,21 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         if (a1 >= NX) q += Ld[EL_U1 + NU * NA + a1 - NX];
         S_[ES_QV + a1] = q;
       }
+    }
+    }
+    // ---- phase 6: condensed blocks to the shared per-edge record; data for the forward pass
+#ifndef DOMPC_HOST_EMU
+    // touch the model-output record of the edge this wavefront handles next (one dword per 128-byte line):
+    // by the time its assembly starts the lines sit in L2 instead of HBM.  The values are consumed (never
+    // true) at the end of the function so that the loads stay where they are.
+#pragma unroll
+    for (int q = 0; q < PF_N; ++q) {
+      const int line = lane + 64 * q;
+      pf_tok[q] = (e_next >= 0 && line < PF_LINES)
+                      ? *((const volatile unsigned*)((const char*)Q.MO(e_next) + (int64_t)line * 128)) : 0u;
+    }
+#endif
+    if (act) {
       for (int it = lane; it < NX * (NA + 1); it += GS) {
         const int a = it / (NA + 1), b = it % (NA + 1);
         const double v = Ld[EL_MX + ((M - 1) * NX + a) * MX_LD + MX_W + b];

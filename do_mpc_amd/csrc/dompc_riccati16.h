@@ -22,16 +22,9 @@ namespace r16 {
 constexpr bool ENABLED = R16_ENABLED;      // (NYT <= 16, no nl_cons rows, not the tree-sharding build)
 
 #ifndef DOMPC_HOST_EMU
-typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int KB_A = (NA + 3) / 4, KB_Y = (NYT + 3) / 4;
-
 template <int KB>
-__device__ inline d4 tmul(const d4& At, const d4& B) {      // At' * B over the first 4*KB rows of both
-  d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(At[kb], B[kb], acc, 0, 0, 0);
-  return acc;
-}
+__device__ inline d4 tmul(const d4& At, const d4& B) { return tile_mul<KB>(At, B); }      // At' * B (dompc_kernel.h)
 __device__ inline double rl(double v, int src) { return lane_bcast(v, src); }
 
 // index of z-entry i inside y = (x_n, u_n) of the condensed edge blocks, or -1 (u_prev, eps)
