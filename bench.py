@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("DOMPC_BENCH_BATCH", "1024")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("DOMPC_BENCH_BATCH", "4096")),
                     help="problems per GPU per step")
     ap.add_argument("--variant", default="A", choices=["A", "B", "tree"],
                     help="A: shipped 9x1 tree (golden-pinned); B: 3 combinations, n_robust=2; "
@@ -197,7 +197,8 @@ def main():
                                    f"({'9 combos x n_robust=1' if args.variant == 'A' else '3 combos x n_robust=2'}, "
                                    f"9 scenarios, N=20, Radau deg 2)",
                        "batch_per_gpu": B, "n_opt_x": ps.n_opt_x, "n_g": ps.n_g, "edges": ps.n_edges,
-                       "start": "cold (set_initial_guess semantics)", "parallelism": f"x0-batch shards x{world}"},
+                       "start": "cold (set_initial_guess semantics)", "parallelism": f"x0-batch shards x{world}",
+                       "problem_slots": S.num_slots},
             "solve": {"converged": n_ok, "of": B, "iters_mean": float(stats["iter_count"].mean()),
                       "iters_max": int(stats["iter_count"].max()),
                       "sweeps_per_solve": float(stats["n_sweeps"].mean()), "trials_per_solve": float(stats["n_trials"].mean()),

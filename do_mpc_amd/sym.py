@@ -810,6 +810,7 @@ asin = _unary_fn("asin")
 acos = _unary_fn("acos")
 atan = _unary_fn("atan")
 fabs = _unary_fn("fabs")
+sign = _unary_fn("sign")
 
 
 def fmin(a, b):
@@ -864,6 +865,14 @@ _NP_BINARY = dict(_C_BINARY, pow="np.power({a},{b})", fmin="np.minimum({a},{b})"
                   fmax="np.maximum({a},{b})", atan2="np.arctan2({a},{b})")
 
 
+def _npfloat(v: float) -> str:
+    if math.isinf(v):
+        return "np.inf" if v > 0 else "(-np.inf)"
+    if math.isnan(v):
+        return "np.nan"
+    return repr(float(v))
+
+
 def _cfloat(v: float) -> str:
     if math.isinf(v):
         return "INFINITY" if v > 0 else "(-INFINITY)"
@@ -876,13 +885,15 @@ def _cfloat(v: float) -> str:
 
 
 def emit_c(outputs: Sequence[Tuple[str, Node]], inputs: Dict[int, str],
-           indent: str = "  ", skip_zero: bool = False, accumulate: bool = False) -> str:
+           indent: str = "  ", skip_zero: bool = False, accumulate: bool = False, numpy: bool = False) -> str:
     """Straight-line C for `outputs` = [(lvalue, node)].
 
     `inputs` maps symbol idx -> C rvalue (e.g. "x[3]").  Every interior node that is
     used more than once, or is a transcendental, gets a named temporary; single-use
     arithmetic is inlined so the compiler sees FMA-able trees.
     """
+    unary_tab, binary_tab = (_NP_UNARY, _NP_BINARY) if numpy else (_C_UNARY, _C_BINARY)
+    decl, end = ("", "") if numpy else ("const double ", ";")
     nodes = topo([n for _, n in outputs])
     uses: Dict[int, int] = {}
     for n in nodes:
@@ -900,7 +911,8 @@ def emit_c(outputs: Sequence[Tuple[str, Node]], inputs: Dict[int, str],
 
     for n in nodes:
         if n.op == "const":
-            name[n.idx] = _cfloat(n.val) if n.val >= 0 else f"({_cfloat(n.val)})"
+            lit = _npfloat(n.val) if numpy else _cfloat(n.val)
+            name[n.idx] = lit if n.val >= 0 else f"({lit})"
             continue
         if n.op == "sym":
             if n.idx not in inputs:
@@ -908,21 +920,21 @@ def emit_c(outputs: Sequence[Tuple[str, Node]], inputs: Dict[int, str],
             name[n.idx] = inputs[n.idx]
             continue
         if n.b is None:
-            ex = _C_UNARY[n.op].format(a=ref(n.a))
+            ex = unary_tab[n.op].format(a=ref(n.a))
         else:
-            ex = _C_BINARY[n.op].format(a=ref(n.a), b=ref(n.b))
+            ex = binary_tab[n.op].format(a=ref(n.a), b=ref(n.b))
         inline = uses.get(n.idx, 0) <= 1 and n.op in ("add", "sub", "mul", "neg", "div") and len(ex) < 200
         if inline:
             name[n.idx] = f"({ex})"
         else:
             tn = f"t{tcount}"
             tcount += 1
-            lines.append(f"{indent}const double {tn} = {ex};")
+            lines.append(f"{indent}{decl}{tn} = {ex}{end}")
             name[n.idx] = tn
     for lv, n in outputs:
         if skip_zero and _is(n, 0.0):
             continue
-        lines.append(f"{indent}{lv} {'+=' if accumulate else '='} {ref(n)};")
+        lines.append(f"{indent}{lv} {'+=' if accumulate else '='} {ref(n)}{end}")
     return "\n".join(lines)
 
 
@@ -962,23 +974,13 @@ class Function:
         for k, o in enumerate(self.outputs):
             for e, d in enumerate(o.data):
                 outs.append((f"r{k}[{e}]", d))
-        body = emit_c(outs, binds, indent="    ")
-        # translate the C-ish text to Python
-        py = []
-        for ln in body.split("\n"):
-            ln = ln.replace("const double ", "").rstrip(";")
-            py.append(ln)
+        # numpy source straight from the operator tables (_NP_UNARY / _NP_BINARY): every operator of the DAG has an
+        # array-valued counterpart there (arcsin/arccos/arctan, np.sign, ...), nothing is translated from C text
+        body = emit_c(outs, binds, indent="    ", numpy=True)
         src = "def _f(" + ",".join(f"a{k}" for k in range(len(self.inputs))) + "," + \
               ",".join(f"r{k}" for k in range(len(self.outputs))) + "):\n"
-        src += "\n".join(py) if py and py[0].strip() else "    pass"
+        src += body if body.strip() else "    pass"
         src += "\n"
-        for cfun, npfun in (("sqrt(", "np.sqrt("), ("exp(", "np.exp("), ("log(", "np.log("),
-                            ("sin(", "np.sin("), ("cos(", "np.cos("), ("tan(", "np.tan("),
-                            ("tanh(", "np.tanh("), ("fabs(", "np.abs("), ("sinh(", "np.sinh("),
-                            ("cosh(", "np.cosh("), ("pow(", "np.power("), ("fmin(", "np.minimum("),
-                            ("fmax(", "np.maximum("), ("atan2(", "np.arctan2(")):
-            src = _replace_call(src, cfun, npfun)
-        src = src.replace("INFINITY", "np.inf").replace("NAN", "np.nan")
         ns = {"np": np}
         exec(compile(src, f"<sym:{self.name}>", "exec"), ns)
         self._np = ns["_f"]
@@ -1023,18 +1025,3 @@ class Function:
         outs = self.eval(*num)
         res = [DM(o.reshape(s.shape, order="F")) for o, s in zip(outs, self.outputs)]
         return res[0] if len(res) == 1 else res
-
-
-def _replace_call(src: str, cfun: str, npfun: str) -> str:
-    """Replace bare C math calls by numpy ones without touching e.g. 'np.exp(' twice."""
-    out = []
-    i = 0
-    L = len(cfun)
-    while i < len(src):
-        if src.startswith(cfun, i) and (i == 0 or not (src[i - 1].isalnum() or src[i - 1] in "._")):
-            out.append(npfun)
-            i += L
-        else:
-            out.append(src[i])
-            i += 1
-    return "".join(out)

@@ -91,8 +91,8 @@ typedef struct dompc_problem_desc {
   const char*    model_hash;            /* must equal the hash embedded in the code object                  */
   int32_t device;                       /* HIP device ordinal                                              */
   int32_t max_batch;                    /* largest batch that will be passed to *_batch calls               */
-  int32_t n_slots;                      /* concurrent problem slots (workgroups); 0 = choose                */
-  int32_t block_threads;                /* threads per workgroup; 0 = default (256)                         */
+  int32_t n_slots;                      /* concurrent problem slots (workgroups); 0 = what the device keeps resident */
+  int32_t block_threads;                /* threads per problem in batch mode: 64, 128 or 256; 0 = choose from max_batch */
   dompc_options opts;
 } dompc_problem_desc;
 

@@ -79,3 +79,24 @@ def test_power_indexing_layout_matches_canonical_order():
     st["_u", 1] = 9.0
     assert st.master[-1] == 9.0
     assert float(st["_x", 1, 0, "v", 1]) == 6.0
+
+
+def test_numpy_evaluation_covers_every_operator_with_batched_inputs():
+    """Function.eval is generated from the operator tables (no C-text translation): inverse trigonometric functions,
+    sign and the derivative of fabs must evaluate on arrays (these ran into NameError / TypeError before)."""
+    from do_mpc_amd import sym
+    x = sym.SX.sym("x", 3)
+    f = sym.Function("f", [x], [sym.vertcat(sym.asin(x[0]), sym.acos(x[1]), sym.atan(x[2]), sym.sign(x[0] - 0.5),
+                                            sym.fabs(x[1] - 0.45), sym.fmax(x[0], x[1]), sym.fmin(x[0], x[2]))])
+    X = np.array([[0.1, 0.6, -0.3], [0.2, 0.3, 0.4], [1.0, -2.0, 3.0]])       # (numel, batch)
+    out = f.eval(X)[0]
+    ref = np.vstack([np.arcsin(X[0]), np.arccos(X[1]), np.arctan(X[2]), np.sign(X[0] - 0.5), np.abs(X[1] - 0.45),
+                     np.maximum(X[0], X[1]), np.minimum(X[0], X[2])])
+    assert out.shape == ref.shape and np.allclose(out, ref, rtol=0, atol=1e-15)
+    g = sym.Function("g", [x], [sym.jacobian(sym.fabs(x[0] - 0.3) * x[1] + sym.atan(x[2]), x)])       # d|x|/dx = sign(x)
+    J = g.eval(X)[0]
+    assert J.shape == (3, 3)
+    assert np.allclose(J[0], np.sign(X[0] - 0.3) * X[1]) and np.allclose(J[1], np.abs(X[0] - 0.3))
+    assert np.allclose(J[2], 1.0 / (1.0 + X[2] ** 2))
+    # single-point call path
+    assert np.allclose(np.asarray(f(np.array([0.1, 0.2, 1.0])).arr).ravel(), ref[:, 0])
