@@ -27,12 +27,15 @@ extern "C" void dompc_hostemu_run(const dompc::KArgs* A);
 #endif
 
 static thread_local std::string g_create_error;
+static const int BATCH_ONE_WAVE = 4096;     // batch size from which a problem gets one wavefront instead of four (see dompc_create)
 
 struct dompc_handle {
   dompc_problem_desc d;
   std::string error;
   std::string code_path;
   int32_t e_pad = 0, n_slots = 0, block = 256, occupancy = 0;
+  bool block_auto = true;          // threads per problem chosen per call from the batch size
+  int32_t slots64 = 0, slots256 = 0;   // resident workgroups at 64 / 256 threads
   int64_t ws_stride = 0, sweep_block = 0, el_size = 0;
   dompc::KArgs base;       // tables + workspace filled in, I/O pointers zero
   std::vector<void*> dev_allocs;
@@ -280,8 +283,10 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   // wavefronts in the tree recursion) once the batch fills every resident wavefront at least twice, else four
   // wavefronts per problem (measured on MI355X, industrial_poly: B = 1024: 256 threads 1832 vs 64 threads 1152
   // steps/s; B = 4096: 3093 vs 3221)
-  h->block = d.block_threads > 0 ? d.block_threads : (d.max_batch >= 4096 ? 64 : 256);
-  if (const char* be = getenv("DOMPC_BLOCK")) h->block = atoi(be);                // tuning aid: threads per problem (64/128/256)
+  // The choice is made per call from the batch size unless the description fixes it (block_auto).
+  h->block = d.block_threads > 0 ? d.block_threads : 256;
+  h->block_auto = d.block_threads <= 0;
+  if (const char* be = getenv("DOMPC_BLOCK")) { h->block = atoi(be); h->block_auto = false; }   // tuning aid (64/128/256)
   if (h->block != 64 && h->block != 128 && h->block != 256) { h->error = "block_threads must be 64, 128 or 256"; return fail(1); }
 #ifndef DOMPC_HOST_EMU
   int ndev = 0;
@@ -353,19 +358,26 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   // ---- slots: one per workgroup the device can keep resident (occupancy of the solver kernel at this block size
   //      and LDS pool, times the number of CUs); more problems than slots are pulled from a work counter
   int max_batch = d.max_batch > 0 ? d.max_batch : 1;
-  int resident = 512 * (256 / h->block);
+  auto resident_at = [&](int block) -> int {
+    int resident = 512 * (256 / block);
 #ifndef DOMPC_HOST_EMU
-  {
-    const int64_t per_wave = (int64_t)(h->block / 64) * h->el_size, red = h->xlayout[0] * (int64_t)h->block;
+    const int64_t per_wave = (int64_t)(block / 64) * h->el_size, red = h->xlayout[0] * (int64_t)block;
     const size_t lds = sizeof(double) * (size_t)(per_wave > red ? per_wave : red);
     int occ = 0, cus = 0;
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->fn_solve, h->block, lds) == hipSuccess &&
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, h->fn_solve, block, lds) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d.device) == hipSuccess && occ > 0 && cus > 0)
       resident = occ * cus;
     h->occupancy = occ;
-  }
 #endif
-  h->n_slots = d.n_slots > 0 ? d.n_slots : (max_batch < resident ? max_batch : resident);
+    return resident;
+  };
+  h->slots64 = resident_at(64);
+  h->slots256 = resident_at(256);
+  {
+    // batches of >= BATCH_ONE_WAVE problems run one wavefront per problem and need that many more slots
+    const int resident = h->block_auto ? (max_batch >= BATCH_ONE_WAVE ? h->slots64 : h->slots256) : resident_at(h->block);
+    h->n_slots = d.n_slots > 0 ? d.n_slots : (max_batch < resident ? max_batch : resident);
+  }
   if (const char* se = getenv("DOMPC_SLOTS")) h->n_slots = atoi(se);
 #ifdef DOMPC_HOST_EMU
   h->n_slots = 1;
@@ -632,7 +644,9 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.lbg = lbg; A.ubg = ubg; A.p = p;
   A.x_out = x; A.g_out = g; A.lam_x_out = lam_x; A.lam_g_out = lam_g; A.f_out = f; A.stats = stats;
   A.batch = B; A.mode = 0;
-  int grid = B < h->n_slots ? B : h->n_slots;
+  const int block = h->block_auto ? (B >= BATCH_ONE_WAVE ? 64 : 256) : h->block;
+  const int cap = (h->block_auto && block == 256 && h->slots256 < h->n_slots) ? h->slots256 : h->n_slots;   // resident workgroups at this block size
+  int grid = B < cap ? B : cap;
   A.wide = 1;
   if (h->sharded) {
     if (B != 1) { h->error = "a sharded handle solves one problem per call"; return 1; }
@@ -656,7 +670,7 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
     HIPCHK(h, hipMemsetAsync(A.wide_flags, 0, sizeof(int32_t) * 8 * 64, st));
   }
 #endif
-  if (launch(h, A, grid, (A.wide > 1 || h->sharded) ? 256 : h->block, stream)) return 1;
+  if (launch(h, A, grid, (A.wide > 1 || h->sharded) ? 256 : block, stream)) return 1;
 #ifndef DOMPC_HOST_EMU
   if (h->sharded) return serve_exchanges(h, (hipStream_t)stream);
 #endif

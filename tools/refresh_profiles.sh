@@ -1,9 +1,13 @@
+# Re-creates the measured artefacts of a round in one GPU call (every step bounded by its own timeout):
+#   bash tools/refresh_profiles.sh r02      -> gpurun_out/r02/...   (copy what should be judged into profiles/)
+R=${1:-r02}
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r01b
-python bench.py --steps 3 --warmup 1 > gpurun_out/r01b/bench.json 2> gpurun_out/r01b/bench.err
-cut -c1-300 gpurun_out/r01b/bench.json
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r01b/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r01b/stats.log 2>&1)
-ls -t gpurun_out/r01b/stats/*/*kernel_stats.csv | head -1 | xargs cat | head -5
-(python tools/gpu_profile.py industrial_poly 1024; python tools/gpu_profile.py industrial_poly 1; python tools/gpu_check.py 2>&1 | tail -12) > gpurun_out/r01b/phase.txt 2>&1
-bash tools/pmc_run.sh > gpurun_out/r01b/pmc.log 2>&1
-tail -3 gpurun_out/r01b/pmc.log
+O=gpurun_out/$R
+mkdir -p $O
+timeout 300 python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
+cut -c1-400 $O/bench.json
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/stats.log 2>&1)
+ls -t $O/stats/*/*kernel_stats.csv | head -1 | xargs cat | head -5
+(timeout 200 python tools/gpu_profile.py industrial_poly 4096; timeout 100 python tools/gpu_profile.py industrial_poly 1024; timeout 100 python tools/gpu_profile.py industrial_poly 1; timeout 200 python tools/gpu_check.py 2>&1 | tail -12) > $O/phase.txt 2>&1
+DOMPC_PMC_BATCH=4096 DOMPC_PMC_DIR=$R/pmc DOMPC_PMC_TIMEOUT=120 timeout 700 bash tools/pmc_run2.sh > $O/pmc.log 2>&1
+tail -32 $O/pmc.log
