@@ -2747,6 +2747,22 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, const Comp* pre) {
 // separate functions each phase has the whole register file; its context is rebuilt inside from uniform sources
 // (kernel arguments from the kernarg segment, block / thread indices, v_readfirstlane of the few scalar arguments), so
 // nothing is passed through memory.  Host emulation: plain calls.
+// function-only evaluation of the trial point (line search): this thread's share of the objective; the constraint
+// values of its edges go to Q.ct.  Straight-line model code with its own register allocation (inlined into the
+// driver it was the main source of the driver's scratch traffic).
+DOMPC_DEV inline double trial_edges(const Thr& T, const Prob& Q) {
+  const KArgs& A = *Q.A;
+  double f = 0.0;
+  for (int e = T.tid; e < A.n_edges; e += T.nt) {
+    const int m = mk_e(A, e);
+    if (!m) continue;
+    const double fe = eval_edge_f(Q, e, Q.xt, Q.st, Q.ct);
+    if (sh_cnt(A, m)) f += fe;
+  }
+  for (int n = T.tid; n < A.n_nodes; n += T.nt)
+    if (sh_cnt(A, mk_n(A, n))) f += node_rterm_f(Q, n, Q.xt);
+  return f;
+}
 struct PhaseRet { unsigned gen, nred, xseq; int rc; };
 #ifndef DOMPC_HOST_EMU
 #define DOMPC_PHASE_PROLOGUE                                                        \
@@ -2771,6 +2787,11 @@ __device__ __attribute__((noinline)) PhaseRet phase_forward(const void* kp, int 
   riccati_forward(T, Q, ufl(mu), ufl(delta));
   return PhaseRet{T.gen, T.nred, T.xseq, 0};
 }
+__device__ __attribute__((noinline)) double phase_trial(const void* kp, int b, int slot, double sf) {
+  const unsigned gen = 0u, nred = 0u, xseq = 0u;
+  DOMPC_PHASE_PROLOGUE
+  return trial_edges(T, Q);
+}
 #undef DOMPC_PHASE_PROLOGUE
 #define DOMPC_PHASE_CALL(fn, ...)                                                   \
   const PhaseRet r_ = fn(T.kp, b, slot, Q.sf, __VA_ARGS__, T.gen, T.nred, T.xseq);        \
@@ -2792,6 +2813,14 @@ DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, 
 #else
   (void)b; (void)slot;
   return riccati_backward(T, Q, mu, delta);
+#endif
+}
+DOMPC_DEV inline double run_trial(const Thr& T, const Prob& Q, int b, int slot) {
+#ifndef DOMPC_HOST_EMU
+  return phase_trial(T.kp, b, slot, Q.sf);
+#else
+  (void)b; (void)slot;
+  return trial_edges(T, Q);
 #endif
 }
 DOMPC_DEV inline void run_forward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta) {
@@ -2896,6 +2925,30 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   Errs E = measure(T, Q, nullptr);
   const double theta0 = E.theta;
   const double theta_max = 1e4 * fmax(1.0, theta0), theta_min = 1e-4 * fmax(1.0, theta0);
+  // barrier sum -sum log(x - l) - sum log(u - x) of the starting point; afterwards it is carried over from the line search
+  double bar_sum;
+  {
+    double bs[1] = {0.0};
+    double x_[4], l_[4], u2_[4];
+#define L_(u, g) x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g];
+#define B_(u, g)                                                       \
+    if (sh_cnt(A, mk_x(A, g))) {                                       \
+      if (l_[u] > -INFINITY) bs[0] -= log(x_[u] - l_[u]);              \
+      if (u2_[u] < INFINITY) bs[0] -= log(u2_[u] - x_[u]);             \
+    }
+    DOMPC_FOR4(nX, L_, B_)
+#undef L_
+#undef B_
+    for (int g = T.tid; g < nSl; g += T.nt) {
+      if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
+      const int si = (g / NE1) * NE1 + g % NE1;
+      if (Q.sl[si] > -INFINITY) bs[0] -= log(Q.s[si] - Q.sl[si]);
+      if (Q.su[si] < INFINITY) bs[0] -= log(Q.su[si] - Q.s[si]);
+    }
+    const int ops[1] = {R_SUM};
+    wg_reduce(T, bs, ops);
+    bar_sum = bs[0];
+  }
   int n_filt = 0;
   double delta_last = 0.0;
   int acc_count = 0;
@@ -2950,7 +3003,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     c_t = prof_clock(); run_forward(T, Q, b, slot, mu, delta); c_fwd += prof_clock() - c_t;
 
     // ---- fraction to the boundary, directional derivative of the barrier function
-    double r5[5] = {1.0, 1.0, 0.0, 0.0, 0.0};   // a_max, a_z, dphi, barrier-sum, (unused)
+    double r5[5] = {1.0, 1.0, 0.0, 0.0, 0.0};   // a_max, a_z, dphi, (unused), (unused)
     {
       double x_[4], l_[4], u2_[4], d_[4], gf_[4], zl_[4], zu_[4];
 #define L_(u, g) x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; d_[u] = Q.dx[g]; gf_[u] = Q.gf[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
@@ -2963,14 +3016,12 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
           const double dz = dz_lo(xv, l, zl_[u], d, mu);                                       \
           if (dz < 0.0) r5[1] = fmin(r5[1], -tau * zl_[u] / dz);                               \
           gphi -= mu / (xv - l);                                                               \
-          r5[3] -= log(xv - l);                                                                \
         }                                                                                      \
         if (ub_ < INFINITY) {                                                                  \
           if (d > 0.0) r5[0] = fmin(r5[0], tau * (ub_ - xv) / d);                              \
           const double dz = dz_up(xv, ub_, zu_[u], d, mu);                                     \
           if (dz < 0.0) r5[1] = fmin(r5[1], -tau * zu_[u] / dz);                               \
           gphi += mu / (ub_ - xv);                                                             \
-          r5[3] -= log(ub_ - xv);                                                              \
         }                                                                                      \
         r5[2] += gphi * d;                                                                     \
       }
@@ -2988,14 +3039,12 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         const double dz = dz_lo(sv, l, Q.zsl[si], d, mu);
         if (dz < 0.0) r5[1] = fmin(r5[1], -tau * Q.zsl[si] / dz);
         gphi -= mu / (sv - l);
-        r5[3] -= log(sv - l);
       }
       if (u < INFINITY) {
         if (d > 0.0) r5[0] = fmin(r5[0], tau * (u - sv) / d);
         const double dz = dz_up(sv, u, Q.zsu[si], d, mu);
         if (dz < 0.0) r5[1] = fmin(r5[1], -tau * Q.zsu[si] / dz);
         gphi += mu / (u - sv);
-        r5[3] -= log(u - sv);
       }
       r5[2] += gphi * d;
     }
@@ -3005,7 +3054,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     }
     const double a_max = r5[0], a_z = r5[1], dphi = r5[2];
     const double theta = E.theta;
-    const double phi = E.obj + mu * r5[3];
+    const double phi = E.obj + mu * bar_sum;       // (the barrier sum of the current point was formed when it was a trial point)
 
     c_t = prof_clock();
     // ---- filter line search (no second-order correction, no restoration phase)
@@ -3020,7 +3069,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     a_min = fmax(a_min, 1e-14);
     double alpha = a_max;
     bool accepted = false, armijo_used = false;
-    double th_t = 0.0, obj_t = 0.0;
+    double th_t = 0.0, obj_t = 0.0, bar_t = bar_sum;
     while (true) {
       double r3[3] = {0.0, 0.0, 0.0};    // obj, theta, barrier
       {                                  // trial point and its barrier terms in one pass
@@ -3046,14 +3095,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       }
       T.sync();
       for (int g = T.tid; g < NX; g += T.nt) Q.ct[g] = Q.xt[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
-      for (int e = T.tid; e < A.n_edges; e += T.nt) {
-        const int m = mk_e(A, e);
-        if (!m) continue;
-        const double fe = eval_edge_f(Q, e, Q.xt, Q.st, Q.ct);
-        if (sh_cnt(A, m)) r3[0] += fe;
-      }
-      for (int n = T.tid; n < A.n_nodes; n += T.nt)
-        if (sh_cnt(A, mk_n(A, n))) r3[0] += node_rterm_f(Q, n, Q.xt);
+      r3[0] += run_trial(T, Q, b, slot);
       T.sync();
       {
         double c_[4];
@@ -3074,7 +3116,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         wg_reduce(T, r3, ops);
       }
       ++n_trials;
-      obj_t = r3[0]; th_t = r3[1];
+      obj_t = r3[0]; th_t = r3[1]; bar_t = r3[2];
       const double ph_t = obj_t + mu * r3[2];
       bool ok = (ph_t == ph_t) && (th_t == th_t) && fabs(ph_t) < INFINITY && th_t <= theta_max;
       if (ok) {
@@ -3109,6 +3151,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       if (n_filt < MAX_FILTER) ++n_filt;
       T.lsync();
     }
+    bar_sum = bar_t;                  // xt of the last evaluated trial becomes the iterate
     c_ls += prof_clock() - c_t;
     // ---- accept the trial point
     const double ks = 1e10;
