@@ -735,7 +735,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   if (act) {
     if (NI != 1)
       for (int i = lane; i < NW * NC; i += GS) Ld[EL_MX + i] = 0.0;
-    for (int r = lane; r < NW; r += GS) Ld[EL_T0 + r] = lam_e[r];      // multipliers of the collocation rows (dual residual)
+    if (NI != 1 || M == 0)      // (single element: staged below, behind the other loads of the edge)
+      for (int r = lane; r < NW; r += GS) Ld[EL_T0 + r] = lam_e[r];      // multipliers of the collocation rows (dual residual)
   }
   T.gsync();
   DOMPC_PH(0)
@@ -789,10 +790,11 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       // record (optimizer.py:951-963):  G_cc (slot sl, state b): [sl == jj] J_jj[a][b] - [a == b] C[sl+1][j];
       // G_y: x_n columns -[a == yb] C[0][j], u_n columns J_jj[a][yb];  r: the residuals (staged in LDS by the lanes
       // that computed them);  I.  One unconditional load per entry (clamped address) + selects: no divergent branches.
-      auto load_cols = [&]() {
-        // (all global loads first, in one batch: loads issued between dependent selects / branches are waited for one
-        //  by one - the first version of this loop spent 40 serialized memory round trips per edge that way)
-        double jv[CPX][RA], cd[CPX][DEG > 0 ? DEG : 1];
+      // (all global loads first, in one batch - fetch_cols(), called before anything of this edge is computed: loads
+      //  issued between dependent selects / branches are waited for one by one; the first version of this assembly
+      //  spent 40 serialized memory round trips per edge that way)
+      double jv[CPX][RA], cd[CPX][DEG > 0 ? DEG : 1];
+      auto fetch_cols = [&]() {
 #pragma unroll
         for (int q = 0; q < CPX; ++q) {
           const int cx = lane + q * GS;
@@ -804,6 +806,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
 #pragma unroll
           for (int jj = 0; jj < DEG; ++jj) cd[q][jj] = DOMPC_C[sl1 * (DEG + 1) + (jj + 1)];
         }
+      };
+      auto build_cols = [&]() {
 #pragma unroll
         for (int q = 0; q < CPX; ++q) {
           const int cx = lane + q * GS;
@@ -881,6 +885,25 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         return badl;
 #endif
       };
+      // per-variable data of the collocation unknowns (this lane's column, plus the end-point columns on the first
+      // NX lanes) and the Jacobian columns: requested up front, together with the loads of the residual rows
+      double vx[CPX][5], ex[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      double nu_a = 0.0;
+      if (act) {
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) {
+          const int cx = lane + q * GS;
+          const int gi = woff + (cx < R ? cx : 0);
+          vx[q][0] = Q.x[gi]; vx[q][1] = Q.lb[gi]; vx[q][2] = Q.ub[gi]; vx[q][3] = Q.zl[gi]; vx[q][4] = Q.zu[gi];
+        }
+        if (GS > 1) {
+          const int gi = woff + R + (lane < NX ? lane : 0);
+          ex[0] = Q.x[gi]; ex[1] = Q.lb[gi]; ex[2] = Q.ub[gi]; ex[3] = Q.zl[gi]; ex[4] = Q.zu[gi];
+          nu_a = nu_e[lane < NX ? lane : 0];
+        }
+        fetch_cols();
+        for (int r = lane; r < NW; r += GS) Ld[EL_T0 + r] = lam_e[r];      // multipliers of the edge's rows (dual residual)
+      }
       // residual rows (collocation, continuity, end point): computed by one lane each, written to g and staged in LDS
       // for the lane that owns the right-hand-side column; the point Hessians of the condensing phases are staged
       // with the same batch of global loads
@@ -909,22 +932,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
       T.gsync();
       if (act) {
-        // per-variable data of the collocation unknowns (this lane's column, plus the end-point columns on the first
-        // NX lanes): requested together with the column loads
-        double vx[CPX][5], ex[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < CPX; ++q) {
-          const int cx = lane + q * GS;
-          const int gi = woff + (cx < R ? cx : 0);
-          vx[q][0] = Q.x[gi]; vx[q][1] = Q.lb[gi]; vx[q][2] = Q.ub[gi]; vx[q][3] = Q.zl[gi]; vx[q][4] = Q.zu[gi];
-        }
-        double nu_a = 0.0;
-        if (GS > 1) {
-          const int gi = woff + R + (lane < NX ? lane : 0);
-          ex[0] = Q.x[gi]; ex[1] = Q.lb[gi]; ex[2] = Q.ub[gi]; ex[3] = Q.zl[gi]; ex[4] = Q.zu[gi];
-          nu_a = nu_e[lane < NX ? lane : 0];
-        }
-        load_cols();
+        build_cols();
         // dual-residual pieces: column c of G_w / G_y times the multipliers of the edge's rows (continuity rows:
         // -D_{sl+1} on the diagonal of the G_cc columns, -D_0 for the x_n columns, +1 for the end-point columns)
 #pragma unroll
@@ -962,7 +970,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       DOMPC_PH(1)
       if (act) {
         if (eliminate(false)) {
-          load_cols();
+          fetch_cols();
+          build_cols();
           if (eliminate(true)) fail = 1;
         }
       }
