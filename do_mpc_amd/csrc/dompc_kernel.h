@@ -702,6 +702,19 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #endif
 }
 
+// reciprocal of a normal, non-zero double: v_rcp_f64 + two Newton steps (5 instructions instead of the ~12 of the IEEE
+// division sequence; the result is within an ulp or two, no denormal / infinity handling - the callers exclude those)
+DOMPC_DEV inline double fast_rcp(double x) {
+#ifndef DOMPC_HOST_EMU
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
 DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, double mu, int lane, int GS, ldsd* Ld) {
   const KArgs& A = *Q.A;
   const bool act = e >= 0;
@@ -869,7 +882,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           double f[RA];
 #pragma unroll
           for (int r = 0; r < R; ++r) f[r] = lane_bcast(bc[qk][r], lk);
-          const double pinv = 1.0 / ((fabs(f[kk]) > 1e-300) ? f[kk] : 1.0);
+          const double pinv = fast_rcp((fabs(f[kk]) > 1e-300) ? f[kk] : 1.0);
 #pragma unroll
           for (int q = 0; q < CPX; ++q) {
             const double prow = bc[q][kk] * pinv;
@@ -2913,7 +2926,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   // ---- objective scaling from the gradient at the (pushed) starting point
   double mu = O.mu_init;
   Q.sf = 1.0;
-  long long c_sweep = 0, c_bwd = 0, c_fwd = 0, c_ls = 0, c_meas = 0, c_t = 0; const long long c_start = prof_clock();
+  long long c_sweep = 0, c_bwd = 0, c_fwd = 0, c_ls = 0, c_meas = 0, c_ftb = 0, c_acc = 0, c_t = 0; const long long c_start = prof_clock();
   if (T.tid == 0) T.fset(6, abort_requested(A));      // (read by everybody at the top of the loop, barriers in between)
   int bad = run_sweep(T, Q, b, slot, mu);
   ++n_sweeps;
@@ -3012,6 +3025,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     c_t = prof_clock(); run_forward(T, Q, b, slot, mu, delta); c_fwd += prof_clock() - c_t;
 
     // ---- fraction to the boundary, directional derivative of the barrier function
+    c_t = prof_clock();
     double r5[5] = {1.0, 1.0, 0.0, 0.0, 0.0};   // a_max, a_z, dphi, (unused), (unused)
     {
       double x_[4], l_[4], u2_[4], d_[4], gf_[4], zl_[4], zu_[4];
@@ -3062,6 +3076,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       wg_reduce(T, r5, ops);
     }
     const double a_max = r5[0], a_z = r5[1], dphi = r5[2];
+    c_ftb += prof_clock() - c_t;
     const double theta = E.theta;
     const double phi = E.obj + mu * bar_sum;       // (the barrier sum of the current point was formed when it was a trial point)
 
@@ -3163,6 +3178,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     bar_sum = bar_t;                  // xt of the last evaluated trial becomes the iterate
     c_ls += prof_clock() - c_t;
     // ---- accept the trial point
+    c_t = prof_clock();
     const double ks = 1e10;
     Comp Cp{-INFINITY, INFINITY, 0.0};       // complementarity statistics of the new iterate (consumed by measure() after the sweep)
     {
@@ -3227,6 +3243,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     }
     if (T.tid == 0) T.fset(6, abort_requested(A));
     T.sync();
+    c_acc += prof_clock() - c_t;
     ++it;
     c_t = prof_clock(); bad = run_sweep(T, Q, b, slot, mu); c_sweep += prof_clock() - c_t;
     ++n_sweeps;
@@ -3234,7 +3251,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   }
 
   // ---- outputs (unscaled multipliers, CasADi sign convention)
-  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = 0; tr[7] = 0; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; } }
+  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = (double)c_ftb; tr[7] = (double)c_acc; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; } }
   const double isf = 1.0 / Q.sf;
   // (sharded problem: every entry is written by exactly one rank, zeros elsewhere -> a SUM over the ranks is the full vector)
   if (A.x_out) for (int g = T.tid; g < nX; g += T.nt) A.x_out[(int64_t)b * nX + g] = sh_cnt(A, mk_x(A, g)) ? Q.x[g] : 0.0;

@@ -30,6 +30,8 @@ def main():
     print(f"{name} B={B}: wall {dt * 1e3:.1f} ms, iters {st['iter_count'][0]}, sweeps {st['n_sweeps'][0]}, trials {st['n_trials'][0]}")
     for nm, v in zip(("sweep", "riccati_bwd", "riccati_fwd", "linesearch", "measure"), tr[:5]):
         print(f"  {nm:12s} {v / 1e6:9.2f} Mcycles  {100 * v / tot:5.1f} %")
+    for nm, v in zip(("step rules", "accept"), tr[6:8]):
+        print(f"  {nm:12s} {v / 1e6:9.2f} Mcycles  {100 * v / tot:5.1f} %")
     print(f"  total        {tot / 1e6:9.2f} Mcycles (problem 0)")
     sub = mpc.S.trace(4096)[-2]
     for nm, v in zip(("edge:model-eval", "edge:assemble+dual", "edge:gauss-jordan", "edge:condense+store",
