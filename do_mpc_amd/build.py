@@ -81,7 +81,8 @@ def _compile_to(cmd_without_out, out: str, what: str) -> None:
 
 def _sources_digest() -> str:
     h = hashlib.sha256()
-    for fn in ("dompc_kernel.h", "dompc_riccati16.h", "dompc_kargs.h", "dompc_device.hip", "dompc_runtime.cpp"):
+    for fn in ("dompc_kernel.h", "dompc_riccati16.h", "dompc_kargs.h", "dompc_device.hip", "dompc_runtime.cpp",
+               "dompc_plant.hip", "dompc_plant_args.h", "dompc_plant_runtime.cpp"):
         with open(os.path.join(CSRC, fn), "rb") as f:
             h.update(f.read())
     with open(os.path.join(INCLUDE, "dompc_ipm.h"), "rb") as f:
@@ -101,7 +102,7 @@ def runtime_library(force: bool = False) -> str:
         if not force and _fresh(out, stamp, dig):       # another process built it while we waited
             return out
         cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
-               os.path.join(CSRC, "dompc_runtime.cpp"), "-ldl"]
+               os.path.join(CSRC, "dompc_runtime.cpp"), os.path.join(CSRC, "dompc_plant_runtime.cpp"), "-ldl"]
         _compile_to(cmd, out, "building libdompc_ipm.so")
         _write_atomic(stamp, dig)
     return out
@@ -156,5 +157,48 @@ def hostemu_library(header_text: str, model_hash: str, out_dir: str, force: bool
                f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC,
                os.path.join(CSRC, "dompc_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "dompc_device.hip"), "-lm"]
         _compile_to(cmd, out, "building host emulation")
+        _write_atomic(stamp, dig)
+    return out
+
+
+def plant_code_object(header_text: str, model_hash: str, force: bool = False) -> str:
+    """gfx950 code object of the batched plant integrator (csrc/dompc_plant.hip) for one lowered plant model."""
+    d = model_dir("plant_" + model_hash)
+    hdr = os.path.join(d, "plant_gen.h")
+    out = os.path.join(d, f"dompc_plant_{ARCH}.hsaco")
+    stamp = out + ".stamp"
+    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12]
+    if not force and _fresh(out, stamp, dig):
+        return out
+    with _locked(d):
+        if not force and _fresh(out, stamp, dig):
+            return out
+        if not (os.path.exists(hdr) and open(hdr).read() == header_text):
+            _write_atomic(hdr, header_text)
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "--genco", f"-DDOMPC_PLANT_HEADER=\"{hdr}\"", "-I", CSRC,
+               os.path.join(CSRC, "dompc_plant.hip")]
+        _compile_to(cmd, out, f"lowering plant {model_hash} to {ARCH}")
+        _write_atomic(stamp, dig)
+    return out
+
+
+def plant_hostemu_library(header_text: str, model_hash: str, out_dir: str, force: bool = False) -> str:
+    """TEST-ONLY: plant integrator compiled for the host (g++); lives in tests/_hostemu, never loaded by the product."""
+    os.makedirs(out_dir, exist_ok=True)
+    hdr = os.path.join(out_dir, f"plant_gen_{model_hash}.h")
+    out = os.path.join(out_dir, f"libdompc_plant_hostemu_{model_hash}.so")
+    stamp = out + ".stamp"
+    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12]
+    if not force and _fresh(out, stamp, dig):
+        return out
+    with _locked(out_dir):
+        if not force and _fresh(out, stamp, dig):
+            return out
+        if not (os.path.exists(hdr) and open(hdr).read() == header_text):
+            _write_atomic(hdr, header_text)
+        cxx = shutil.which("g++") or "g++"
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DDOMPC_HOST_EMU", f"-DDOMPC_PLANT_HEADER=\"{hdr}\"", "-I", CSRC,
+               os.path.join(CSRC, "dompc_plant_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "dompc_plant.hip"), "-lm"]
+        _compile_to(cmd, out, "building plant host emulation")
         _write_atomic(stamp, dig)
     return out

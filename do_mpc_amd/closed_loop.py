@@ -1,0 +1,75 @@
+"""Batched closed loop with the whole x0 batch resident in HBM.
+
+The reference closes the loop one sample at a time on the host - `u0 = mpc.make_step(x0)`, `y = simulator.make_step(u0)`,
+`x0 = estimator.make_step(y)` (/root/reference/examples/industrial_poly/main.py:105-108) - and fans batches of such loops
+out over processes (`do_mpc.sampling.Sampler`, /root/reference/do_mpc/sampling/_sampler.py:198-228).  Here B loops
+advance together: one `dompc_solve_batch_device` launch (structured IPM, B problems) and one
+`dompc_plant_step_batch_device` launch (plant integrator, B samples) per control step on the same stream; states,
+inputs, parameters and the warm-start solution stay in device memory (torch tensors are only the allocator).
+State feedback (`StateFeedback.make_step` returns y, estimator/_base.py:63-72), measurement = state.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .solver import STATS_DTYPE
+
+
+class BatchClosedLoop:
+    def __init__(self, mpc, simulator, X0, device: int = 0):
+        import torch
+        self.torch = torch
+        self.mpc, self.sim = mpc, simulator
+        ps = self.ps = mpc.structure
+        m = simulator.model
+        assert m.n_x == ps.nx and m.n_u == ps.nu, "controller and plant must share states and inputs"
+        assert m.n_y == m.n_x, "state feedback: the plant's measurement must be its state"
+        X0 = np.asarray(X0, dtype=float).reshape(-1, ps.nx)
+        self.B = B = X0.shape[0]
+        dev = self.dev = torch.device("cuda", device)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)      # noqa: E731
+        t0 = float(mpc._t0[0])
+        P = np.tile(mpc.opt_p_num.master, (B, 1))
+        P[:, :ps.nx] = X0
+        P[:, ps.p_off_tvp:ps.p_off_p] = mpc.tvp_fun(t0).master
+        P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(t0).master
+        P[:, ps.p_off_uprev:] = 0.0
+        Xi = np.zeros((B, ps.n_opt_x))
+        Xi[:, :ps.off_u].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
+        self.P, self.guess = t(P), t(Xi)                      # opt_p per sample; initial guess = set_initial_guess semantics
+        self.X = t(X0)                                        # plant states
+        self.lbx, self.ubx = t(mpc._lb_opt_x.master), t(mpc._ub_opt_x.master)
+        self.lbg, self.ubg = t(mpc._nlp_cons_lb), t(mpc._nlp_cons_ub)
+        self.sol = torch.empty((B, ps.n_opt_x), dtype=torch.float64, device=dev)
+        self.f = torch.empty(B, dtype=torch.float64, device=dev)
+        self.stats = torch.zeros(B * STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        self.U = torch.empty((B, ps.nu), dtype=torch.float64, device=dev)
+        self.Xn = torch.empty_like(self.X)
+        self.pstat = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.xs, self.us = t(mpc._x_scaling.master), t(mpc._u_scaling.master)
+        ts = float(simulator._t0[0])
+        self.p_plant = t(simulator.p_fun(ts).master if m.n_p else np.zeros(1))
+        self.tvp_plant = t(simulator.tvp_fun(ts).master if m.n_tvp else np.zeros(1))
+        self.k = 0
+
+    def step(self) -> dict:
+        """one control step of all B loops; returns the solver statistics (numpy record array) and the plant status"""
+        torch, ps, S = self.torch, self.ps, self.mpc.S
+        stream = torch.cuda.current_stream()
+        S.solve_batch_device(self.B, self.guess.data_ptr(), self.lbx.data_ptr(), self.ubx.data_ptr(), self.lbg.data_ptr(),
+                             self.ubg.data_ptr(), self.P.data_ptr(), self.sol.data_ptr(), 0, 0, 0, self.f.data_ptr(),
+                             self.stats.data_ptr(), stream=stream.cuda_stream)
+        iu = ps.iu(0, 0)
+        torch.mul(self.sol[:, iu:iu + ps.nu], self.us, out=self.U)                      # u0 in physical units
+        self.sim.step_batch_device(self.B, self.X.data_ptr(), self.U.data_ptr(), self.tvp_plant.data_ptr(),
+                                   self.p_plant.data_ptr(), self.Xn.data_ptr(), 0, self.pstat.data_ptr(),
+                                   shared_mask=2 | 4 | 8 | 16, stream=stream.cuda_stream)
+        # next problem: x0 <- plant state, u_prev <- applied input, initial guess <- previous solution (optimizer.py:754-768)
+        self.X, self.Xn = self.Xn, self.X
+        self.P[:, :ps.nx] = self.X
+        self.P[:, ps.p_off_uprev:] = self.U
+        self.guess.copy_(self.sol)
+        self.k += 1
+        torch.cuda.synchronize()
+        st = np.frombuffer(self.stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
+        return {"stats": st, "plant_status": (self.pstat.cpu().numpy() & 0xFF), "u0": self.U.cpu().numpy(), "x": self.X.cpu().numpy()}

@@ -169,3 +169,32 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     text = "\n".join(hdr) + "\n" + "\n".join(parts)
     digest = hashlib.sha256(text.encode()).hexdigest()[:16]
     return text + f"\n#define DOMPC_MODEL_HASH \"{digest}\"\n"
+
+
+def lower_plant(*, x_sym, u_sym, tvp_sym, p_sym, w_sym, v_sym, rhs, meas, discrete, name="plant") -> str:
+    """Header for the batched plant integrator (csrc/dompc_plant.hip): the model's right-hand side and measurement
+    function in PHYSICAL units, as the reference's Simulator integrates them
+    (/root/reference/do_mpc/simulator.py:363-416: `_rhs_fun(x, u, z, tvp, p, w)`, `_meas_fun` at :822)."""
+    groups = [("x", x_sym), ("u", u_sym), ("tvp", tvp_sym), ("p", p_sym), ("w", w_sym), ("v", v_sym)]
+    binds: Dict[int, str] = {}
+    for cname, syms in groups:
+        for i, s in enumerate(syms):
+            binds[s.idx] = f"{cname}[{i}]"
+    for what, nodes in (("rhs", rhs), ("meas", meas)):
+        free = [s for s in sym.free_symbols(list(nodes)) if s.idx not in binds]
+        if free:
+            raise Exception(f"{what} depends on symbols outside (_x,_u,_tvp,_p,_w,_v): {free}")
+    sig = "const double* x, const double* u, const double* tvp, const double* p"
+    parts = []
+    body = sym.emit_c([(f"f[{i}]", e) for i, e in enumerate(rhs)], binds, indent="  ")
+    parts.append(f"DOMPC_FN void plant_rhs({sig}, const double* w, double* f) {{\n{body}\n}}\n")
+    body = sym.emit_c([(f"y[{i}]", e) for i, e in enumerate(meas)], binds, indent="  ")
+    parts.append(f"DOMPC_FN void plant_meas({sig}, const double* v, double* y) {{\n{body}\n}}\n")
+    hdr = ["// GENERATED by do_mpc_amd/lowering.py:lower_plant - do not edit.", "#pragma once", "#include <math.h>",
+           f"#define PLANT_MODEL_NAME \"{name}\"",
+           f"#define PLANT_NX {len(x_sym)}", f"#define PLANT_NU {len(u_sym)}", f"#define PLANT_NP {len(p_sym)}",
+           f"#define PLANT_NTVP {len(tvp_sym)}", f"#define PLANT_NW {len(w_sym)}", f"#define PLANT_NV {len(v_sym)}",
+           f"#define PLANT_NY {len(meas)}", f"#define PLANT_DISCRETE {1 if discrete else 0}", ""]
+    text = "\n".join(hdr) + "\n" + "\n".join(parts)
+    digest = hashlib.sha256(text.encode()).hexdigest()[:16]
+    return text + f"\n#define PLANT_MODEL_HASH \"{digest}\"\n"

@@ -214,6 +214,38 @@ int64_t dompc_exchange_doubles(const dompc_handle* h, int32_t world, int32_t n_c
 /* desc == NULL switches sharding off again */
 int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* desc);
 
+/* ---- batched plant integration ---------------------------------------------------------
+ * Replaces the integrator object of do_mpc.simulator.Simulator (do_mpc/simulator.py:381-416:
+ * casadi.integrator('simulator', 'cvodes', dae, t0, t_step, {abstol, reltol}); discrete models: the `simulator`
+ * Function of simulator.py:363-378) and its call in Simulator.make_step (simulator.py:757-850): x, u, tvp, p, w in,
+ * x_next and y = meas(x_next, u, tvp, p) + v out, in physical units - for B samples at once, one GPU thread per sample,
+ * so that an x0 batch stays resident in HBM between the controller's make_step calls.  The model's right-hand side and
+ * measurement function come from a per-model gfx950 code object (do_mpc_amd/lowering.py:lower_plant).
+ * Explicit Dormand-Prince 5(4) with per-sample step-size control (local error at 1/100 of abstol / reltol);
+ * algebraic states are not supported.  status[b]: bit 0 = step limit reached or NaN right-hand side (x_next is the
+ * state reached so far), steps taken = status[b] >> 8.
+ * shared_mask: bit 0/1/2/3/4 set = u/tvp/p/w/v is ONE row shared by all samples instead of [B][n]. */
+typedef struct dompc_plant dompc_plant;
+typedef struct dompc_plant_desc {
+  int32_t nx, nu, np, ntvp, nw, nv, ny;
+  int32_t discrete;                  /* 1: x_next = rhs(x, u, tvp, p, w) (no integration)                     */
+  const char* code_object_path;      /* gfx950 code object built from the lowered plant                       */
+  const char* model_hash;            /* must equal the hash embedded in the code object (NULL = no check)      */
+  int32_t device;
+  int32_t max_steps;                 /* per sample and call; 0 = 200000                                        */
+  double t_step, reltol, abstol;     /* settings.t_step / reltol / abstol of the reference's SimulatorSettings */
+} dompc_plant_desc;
+int  dompc_plant_create(const dompc_plant_desc* desc, dompc_plant** out);
+void dompc_plant_destroy(dompc_plant* h);
+const char* dompc_plant_last_error(const dompc_plant* h);     /* h may be NULL: error of the last failed create */
+/* host buffers; w, v, y, status may be NULL */
+int dompc_plant_step_batch(dompc_plant* h, int32_t B, const double* x, const double* u, const double* tvp, const double* p,
+                           const double* w, const double* v, int32_t shared_mask, double* x_next, double* y, int32_t* status);
+/* DEVICE buffers, asynchronous on `stream` (hipStream_t as void*) */
+int dompc_plant_step_batch_device(dompc_plant* h, int32_t B, const double* x, const double* u, const double* tvp,
+                                  const double* p, const double* w, const double* v, int32_t shared_mask, double* x_next,
+                                  double* y, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

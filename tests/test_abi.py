@@ -25,6 +25,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/dompc_ipm.h but not exported"
 
 
+def test_product_simulator_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from do_mpc_amd.examples import oscillating_masses as ex
+    from do_mpc_amd.simulator import Simulator
+    sim = Simulator(ex.build_model())
+    sim.set_param(t_step=0.5)
+    with pytest.raises(RuntimeError, match="HIP|GPU|hip"):
+        sim.setup()
+
+
 def test_stats_struct_layout_matches_header():
     from do_mpc_amd.solver import STATS_DTYPE, Stats
     assert ctypes.sizeof(Stats) == STATS_DTYPE.itemsize == 8 * 4 + 7 * 8

@@ -14,7 +14,8 @@ from do_mpc_amd.examples import CASES
 CL_RTOL = 2e-6
 
 
-def run_closed_loop(make_mpc, name, steps=5):
+def run_closed_loop(make_mpc, name, steps=5, make_plant=None):
+    """make_plant(name, model, t_step) -> callable (x, u) -> x_next; default: tests/plant.py (scipy Radau)"""
     ex = CASES[name]
     mpc = make_mpc(name)
     g = pc.golden(name)
@@ -24,6 +25,7 @@ def run_closed_loop(make_mpc, name, steps=5):
     mpc.x0 = x
     mpc.set_initial_guess()
     t_step = float(mpc.settings.t_step)
+    step = make_plant(name, mpc.model, t_step) if make_plant else (lambda x_, u_: plant.plant_step(mpc.model, x_, u_, p, t_step))
     worst_u = worst_x = 0.0
     for k in range(steps):
         assert pc.relerr(x, Xs[k]) < CL_RTOL, (name, k, x, Xs[k])
@@ -31,7 +33,7 @@ def run_closed_loop(make_mpc, name, steps=5):
         assert mpc.solver_stats["success"], (name, k, mpc.solver_stats)
         worst_u = max(worst_u, pc.relerr(u0, U[k]))
         assert worst_u < CL_RTOL, (name, k, u0, U[k])
-        x = plant.plant_step(mpc.model, x, u0, p, t_step)
+        x = step(x, u0)
         if k + 1 < len(Xs):
             worst_x = max(worst_x, pc.relerr(x, Xs[k + 1]))
     return worst_u, worst_x

@@ -1,0 +1,59 @@
+"""Plant integrator and batched closed loop on the MI355X (HIP path through the C ABI dompc_plant_*)."""
+import numpy as np
+import pytest
+
+import parity_common as pc
+import simulator_common as sc
+from do_mpc_amd.examples import CASES
+from test_closed_loop import CL_RTOL, run_closed_loop
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly"])
+def test_make_step_matches_scipy_radau(name):
+    sc.check_against_scipy(name, hostemu=False)
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "CSTR", "industrial_poly"])
+def test_batch_semantics(name):
+    sc.check_batch(name, hostemu=False, B=257)
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly"])
+def test_closed_loop_with_gpu_controller_and_gpu_plant_reproduces_the_reference_trajectory(name):
+    def make_mpc(n):
+        ex = CASES[n]
+        return ex.build_mpc(ex.build_model())
+    wu, wx = run_closed_loop(make_mpc, name, make_plant=sc.closed_loop_plant(hostemu=False))
+    assert wu < CL_RTOL and wx < CL_RTOL
+
+
+def test_device_resident_batched_closed_loop_equals_the_per_sample_loops():
+    """B closed loops advanced together with states, inputs and warm starts resident in HBM (do_mpc_amd/closed_loop.py)
+    against the same loops run one sample at a time through MPC.make_step / Simulator.make_step."""
+    import bench
+    from do_mpc_amd.closed_loop import BatchClosedLoop
+    name, B, steps = "industrial_poly", 6, 3
+    ex = CASES[name]
+    X0 = bench.synthetic_x0_batch(B)
+    mpc = ex.build_mpc(ex.build_model(), max_batch=B)
+    sim = sc.make_simulator(name, hostemu=False)
+    loop = BatchClosedLoop(mpc, sim, X0)
+    traj_u, traj_x = [], []
+    for k in range(steps):
+        r = loop.step()
+        assert r["stats"]["success"].all() and (r["plant_status"] == 0).all()
+        traj_u.append(r["u0"].copy()), traj_x.append(r["x"].copy())
+    for b in (0, B - 1):
+        m1 = ex.build_mpc(ex.build_model())
+        s1 = sc.make_simulator(name, hostemu=False)
+        x = X0[b].copy()
+        m1.x0 = x
+        m1.set_initial_guess()
+        s1.x0 = x
+        for k in range(steps):
+            u = m1.make_step(x)
+            x = s1.make_step(u).ravel()
+            assert pc.relerr(u.ravel(), traj_u[k][b]) < 1e-7, (b, k)
+            assert pc.relerr(x, traj_x[k][b]) < 1e-8, (b, k)
