@@ -94,9 +94,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DOMPC_BENCH_BATCH", "4096")),
                     help="problems per GPU per step")
-    ap.add_argument("--variant", default="A", choices=["A", "B", "tree"],
+    ap.add_argument("--variant", default="A", choices=["A", "B", "tree", "closed_loop"],
                     help="A: shipped 9x1 tree (golden-pinned); B: 3 combinations, n_robust=2; "
-                         "tree: one 3^n_robust-leaf problem sharded over the ranks (strong scaling)")
+                         "tree: one 3^n_robust-leaf problem sharded over the ranks (strong scaling); "
+                         "closed_loop: B closed loops (controller + GPU plant) resident in HBM, warm-started steps")
     ap.add_argument("--n-robust", type=int, default=5, help="--variant tree: depth of the branching part (3^n leaves)")
     ap.add_argument("--cut-level", type=int, default=0, help="--variant tree: level whose nodes are the sub-tree roots (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,6 +120,8 @@ def main():
     from do_mpc_amd.solver import STATS_DTYPE
     if args.variant == "tree":
         return bench_tree(args, ex, rank, world, local_rank, dist)
+    if args.variant == "closed_loop":
+        return bench_closed_loop(args, ex, rank, world, local_rank, dist)
     kw = {} if args.variant == "A" else {"n_robust": 2, "uncertainty": "paired"}
     B = args.batch
     mpc = ex.build_mpc(ex.build_model(), gpu_index=local_rank, max_batch=B, **kw)
@@ -213,6 +216,65 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_closed_loop(args, ex, rank, world, local_rank, dist):
+    """B closed loops per GPU: every step = one batched make_step (warm-started from the previous
+    solution, like Optimizer.solve) + one batched plant step (do_mpc_amd/simulator.py), everything resident in HBM.
+    The warm-up steps include the cold first solve; value = loop steps/s."""
+    import torch
+    from do_mpc_amd.closed_loop import BatchClosedLoop
+    from do_mpc_amd.simulator import Simulator
+    B = args.batch
+    model = ex.build_model()
+    mpc = ex.build_mpc(model, gpu_index=local_rank, max_batch=B)
+    sim = Simulator(model)
+    sim.set_param(t_step=float(mpc.settings.t_step), abstol=1e-10, reltol=1e-10, gpu_index=local_rank)
+    pt = sim.get_p_template()
+    pt["delH_R"], pt["k_0"] = 950.0, 7.0            # true plant parameters of examples/industrial_poly/template_simulator.py
+    sim.set_p_fun(lambda t: pt)
+    sim.setup()
+    lo, hi = shard(B * world, rank, world)
+    loop = BatchClosedLoop(mpc, sim, synthetic_x0_batch(B * world)[lo:hi], device=local_rank)
+    iters, ok = [], True
+    for _ in range(max(args.warmup, 1)):
+        loop.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = loop.step()
+        iters.append(float(r["stats"]["iter_count"].mean()))
+        ok = ok and bool(r["stats"]["success"].all()) and bool((r["plant_status"] == 0).all())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ps = mpc.structure
+        sweep_b = sweep_bytes_per_problem(ps)
+        achieved = (float(np.mean(iters)) + 1.0) * sweep_b * B * args.steps / dt / 1e9
+        print(json.dumps({
+            "metric": "MPC steps/sec (make_step wall-time), industrial_poly robust multi-stage", "value": B * world * args.steps / dt,
+            "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "industrial_poly robust multi-stage NMPC, variant A, CLOSED LOOP: warm-started make_step + "
+                                   "GPU plant step per loop step, batch resident in HBM", "batch_per_gpu": B,
+                       "n_opt_x": ps.n_opt_x, "n_g": ps.n_g, "edges": ps.n_edges, "start": "warm (previous solution)",
+                       "parallelism": f"x0-batch shards x{world}"},
+            "solve": {"converged": bool(ok), "iters_mean": float(np.mean(iters))},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "dompc_solve_kernel", "kernel_ms": dt / args.steps * 1e3,
+                         "sweep_bytes_per_problem": sweep_b,
+                         "note": "wall time of a loop step (solver kernel + plant kernel + host bookkeeping), not a kernel-only time"},
+            "cpu_baseline": None}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
