@@ -11,13 +11,32 @@ With real CasADi installed do not call install(); use the ctypes stub of INTEGRA
 import sys
 import types
 
-from . import controller, model, structs, sym
+from . import controller, model, simulator, structs, sym
 
 _CASADI_NAMES = [
     "SX", "DM", "vertcat", "horzcat", "mtimes", "sum1", "sum2", "sumsqr", "dot", "exp", "log", "sqrt", "sin",
     "cos", "tan", "tanh", "sinh", "cosh", "asin", "acos", "atan", "fabs", "fmin", "fmax", "jacobian",
     "gradient", "hessian", "substitute", "Function",
 ]
+
+
+class StateFeedback:
+    """`do_mpc.estimator.StateFeedback` (/root/reference/do_mpc/estimator/_base.py:55-72): passes the measurement
+    through as the state estimate - what every closed loop of the shipped examples uses between simulator and controller."""
+
+    def __init__(self, model):
+        self.model = model
+        self._x0 = model._x(0.0)
+
+    x0 = property(lambda self: self._x0, lambda self, v: self._x0.master.__setitem__(slice(None), _flat(v)))
+
+    def make_step(self, y0):
+        return y0
+
+
+def _flat(v):
+    import numpy as np
+    return np.asarray(v.master if hasattr(v, "master") else v, dtype=float).reshape(-1)
 
 
 def install(force: bool = False):
@@ -47,12 +66,18 @@ def install(force: bool = False):
         m_ctrl = types.ModuleType("do_mpc.controller")
         m_ctrl.MPC = controller.MPC
         m_ctrl.MPCSettings = controller.MPCSettings
-        dm.model, dm.controller = m_model, m_ctrl
+        m_sim = types.ModuleType("do_mpc.simulator")
+        m_sim.Simulator = simulator.Simulator
+        m_est = types.ModuleType("do_mpc.estimator")
+        m_est.StateFeedback = StateFeedback
+        dm.model, dm.controller, dm.simulator, dm.estimator = m_model, m_ctrl, m_sim, m_est
         dm.__version__ = "5.1.1+dompc_amd"
         sys.modules["do_mpc"] = dm
         sys.modules["do_mpc.model"] = m_model
         sys.modules["do_mpc.controller"] = m_ctrl
-        installed += ["do_mpc", "do_mpc.model", "do_mpc.controller"]
+        sys.modules["do_mpc.simulator"] = m_sim
+        sys.modules["do_mpc.estimator"] = m_est
+        installed += ["do_mpc", "do_mpc.model", "do_mpc.controller", "do_mpc.simulator", "do_mpc.estimator"]
     return installed
 
 

@@ -78,3 +78,44 @@ def test_unedited_industrial_poly_template_reproduces_golden_first_step(compat):
     mpc.set_initial_guess()
     u0 = mpc.make_step(g["mpc._x"][0]).ravel()
     assert np.max(np.abs(u0 - g["mpc._u"][0]) / np.maximum(1, np.abs(g["mpc._u"][0]))) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["CSTR", "industrial_poly"])
+def test_unedited_template_simulator_closes_the_loop_like_main_py(name, compat):
+    """template_model.py + template_mpc.py + template_simulator.py of the reference, un-edited, in the loop of
+    examples/*/main.py:105-108 (mpc.make_step -> simulator.make_step -> estimator.make_step) - controller and plant on the
+    host emulation of the kernels here - against the golden trajectory of the reference's own test."""
+    import simulator_common as sc
+    from do_mpc_amd import build
+    import do_mpc                                  # the stand-in registered by the fixture
+    d = os.path.join(REF, DIRS[name])
+    tm = _load(os.path.join(d, "template_model.py"), f"ref_{name}_tm3")
+    tc = _load(os.path.join(d, "template_mpc.py"), f"ref_{name}_tc3")
+    tsim = _load(os.path.join(d, "template_simulator.py"), f"ref_{name}_ts3")
+    model = tm.template_model()
+    orig_setup = do_mpc.simulator.Simulator.setup
+
+    def setup_on_hostemu(self):                    # (no GPU here: the plant kernel's host emulation; same entry point)
+        hdr = self._lower()
+        h = hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0]
+        orig_setup(self, _lib_path=build.plant_hostemu_library(hdr, h, sc.OUT), _code_object="")
+    do_mpc.simulator.Simulator.setup = setup_on_hostemu
+    try:
+        with hostemu.patched():
+            mpc = tc.template_mpc(model, silence_solver=True)
+        simulator = tsim.template_simulator(model)
+    finally:
+        do_mpc.simulator.Simulator.setup = orig_setup
+    estimator = do_mpc.estimator.StateFeedback(model)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
+    x0 = g["mpc._x"][0].reshape(-1, 1)
+    mpc.x0 = x0
+    simulator.x0 = x0
+    estimator.x0 = x0
+    mpc.set_initial_guess()
+    for k in range(3):
+        u0 = mpc.make_step(x0)
+        y_next = simulator.make_step(u0)
+        x0 = estimator.make_step(y_next)
+        assert np.max(np.abs(u0.ravel() - g["mpc._u"][k]) / np.maximum(1, np.abs(g["mpc._u"][k]))) < 2e-6
+        assert np.max(np.abs(x0.ravel() - g["mpc._x"][k + 1]) / np.maximum(1, np.abs(g["mpc._x"][k + 1]))) < 2e-6
