@@ -2678,6 +2678,21 @@ DOMPC_PHASE void refresh_mu(const Thr& T, const Prob& Q, double dmu) {
 DOMPC_DEV inline double dz_lo(double x, double l, double z, double d, double mu) { return mu / (x - l) - z - z / (x - l) * d; }
 DOMPC_DEV inline double dz_up(double x, double u, double z, double d, double mu) { return mu / (u - x) - z + z / (u - x) * d; }
 
+// Sum of logarithms of many positive numbers with ONE log(): the mantissas are multiplied, the exponents added
+// (frexp: two instructions on the device) - sum log a_i = log(prod frac_i) + (sum exp_i) ln 2.  A non-positive or NaN
+// term makes the sum NaN, as log() would (a trial point outside its bounds must fail the line search).
+// The barrier terms of the line search cost ~100 instructions per variable and bound with log().
+struct LogAcc { double m; int e; int bad; };
+DOMPC_DEV inline void logacc_add(LogAcc& L, double a) {
+  if (!(a > 0.0) || !(a < INFINITY)) L.bad = 1;
+  int ea = 0;
+  const double fa = frexp(a, &ea);
+  L.m *= fa;
+  L.e += ea;
+  if (L.m < 0x1p-500) { int em = 0; L.m = frexp(L.m, &em); L.e += em; }
+}
+DOMPC_DEV inline double logacc_value(const LogAcc& L) { return L.bad ? NAN : log(L.m) + (double)L.e * 0.6931471805599453; }
+
 // Complementarity statistics of the bounded variables: extremes of the products s = (x-l) z_L, (u-x) z_U and the
 // sum of the multipliers.  max_i |s_i - mu| = max(s_max - mu, mu - s_min) gives the complementarity error for ANY
 // barrier parameter without another pass over the variables (the barrier-update test needs it at several mu).
@@ -2951,12 +2966,13 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   double bar_sum;
   {
     double bs[1] = {0.0};
+    LogAcc La{1.0, 0, 0};
     double x_[4], l_[4], u2_[4];
 #define L_(u, g) x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g];
 #define B_(u, g)                                                       \
     if (sh_cnt(A, mk_x(A, g))) {                                       \
-      if (l_[u] > -INFINITY) bs[0] -= log(x_[u] - l_[u]);              \
-      if (u2_[u] < INFINITY) bs[0] -= log(u2_[u] - x_[u]);             \
+      if (l_[u] > -INFINITY) logacc_add(La, x_[u] - l_[u]);            \
+      if (u2_[u] < INFINITY) logacc_add(La, u2_[u] - x_[u]);           \
     }
     DOMPC_FOR4(nX, L_, B_)
 #undef L_
@@ -2964,9 +2980,10 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     for (int g = T.tid; g < nSl; g += T.nt) {
       if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
       const int si = (g / NE1) * NE1 + g % NE1;
-      if (Q.sl[si] > -INFINITY) bs[0] -= log(Q.s[si] - Q.sl[si]);
-      if (Q.su[si] < INFINITY) bs[0] -= log(Q.su[si] - Q.s[si]);
+      if (Q.sl[si] > -INFINITY) logacc_add(La, Q.s[si] - Q.sl[si]);
+      if (Q.su[si] < INFINITY) logacc_add(La, Q.su[si] - Q.s[si]);
     }
+    bs[0] = -logacc_value(La);
     const int ops[1] = {R_SUM};
     wg_reduce(T, bs, ops);
     bar_sum = bs[0];
@@ -3096,6 +3113,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     double th_t = 0.0, obj_t = 0.0, bar_t = bar_sum;
     while (true) {
       double r3[3] = {0.0, 0.0, 0.0};    // obj, theta, barrier
+      LogAcc La{1.0, 0, 0};
       {                                  // trial point and its barrier terms in one pass
         double x_[4], d_[4], l_[4], u2_[4];
 #define L_(u, g) x_[u] = Q.x[g]; d_[u] = Q.dx[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g];
@@ -3104,8 +3122,8 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
           const double xt_ = x_[u] + alpha * d_[u];                                            \
           Q.xt[g] = xt_;                                                                       \
           if (sh_cnt(A, mk_x(A, g))) {                                                         \
-            if (l_[u] > -INFINITY) r3[2] -= log(xt_ - l_[u]);                                  \
-            if (u2_[u] < INFINITY) r3[2] -= log(u2_[u] - xt_);                                 \
+            if (l_[u] > -INFINITY) logacc_add(La, xt_ - l_[u]);                                \
+            if (u2_[u] < INFINITY) logacc_add(La, u2_[u] - xt_);                               \
           }                                                                                    \
         }
         DOMPC_FOR4(nX, L_, B_)
@@ -3132,9 +3150,10 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       for (int g = T.tid; g < nSl; g += T.nt) {
         if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
         const int si = (g / NE1) * NE1 + g % NE1;
-        if (Q.sl[si] > -INFINITY) r3[2] -= log(Q.st[si] - Q.sl[si]);
-        if (Q.su[si] < INFINITY) r3[2] -= log(Q.su[si] - Q.st[si]);
+        if (Q.sl[si] > -INFINITY) logacc_add(La, Q.st[si] - Q.sl[si]);
+        if (Q.su[si] < INFINITY) logacc_add(La, Q.su[si] - Q.st[si]);
       }
+      r3[2] = -logacc_value(La);
       {
         const int ops[3] = {R_SUM, R_SUM, R_SUM};
         wg_reduce(T, r3, ops);
