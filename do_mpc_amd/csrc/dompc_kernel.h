@@ -3043,7 +3043,9 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
 
     // ---- fraction to the boundary, directional derivative of the barrier function
     c_t = prof_clock();
-    double r5[5] = {1.0, 1.0, 0.0, 0.0, 0.0};   // a_max, a_z, dphi, (unused), (unused)
+    // largest ratios (-dx)/(x - l), dx/(u - x) and (-dz)/z over the bounded variables: the fraction-to-the-boundary steps
+    // are tau / ratio (one division at the end instead of one per bound), and the directional derivative of the barrier function
+    double r5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // ratio_x, ratio_z, dphi, (unused), (unused)
     {
       double x_[4], l_[4], u2_[4], d_[4], gf_[4], zl_[4], zu_[4];
 #define L_(u, g) x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; d_[u] = Q.dx[g]; gf_[u] = Q.gf[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
@@ -3052,16 +3054,16 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         const double xv = x_[u], l = l_[u], ub_ = u2_[u], d = d_[u];                           \
         double gphi = gf_[u];                                                                  \
         if (l > -INFINITY) {                                                                   \
-          if (d < 0.0) r5[0] = fmin(r5[0], -tau * (xv - l) / d);                               \
-          const double dz = dz_lo(xv, l, zl_[u], d, mu);                                       \
-          if (dz < 0.0) r5[1] = fmin(r5[1], -tau * zl_[u] / dz);                               \
-          gphi -= mu / (xv - l);                                                               \
+          const double r = fast_rcp(xv - l);                                                   \
+          r5[0] = fmax(r5[0], -d * r);                              /* step to the bound */    \
+          r5[1] = fmax(r5[1], 1.0 + r * d - mu * r * fast_rcp(zl_[u]));      /* -dz / z */     \
+          gphi -= mu * r;                                                                      \
         }                                                                                      \
         if (ub_ < INFINITY) {                                                                  \
-          if (d > 0.0) r5[0] = fmin(r5[0], tau * (ub_ - xv) / d);                              \
-          const double dz = dz_up(xv, ub_, zu_[u], d, mu);                                     \
-          if (dz < 0.0) r5[1] = fmin(r5[1], -tau * zu_[u] / dz);                               \
-          gphi += mu / (ub_ - xv);                                                             \
+          const double r = fast_rcp(ub_ - xv);                                                 \
+          r5[0] = fmax(r5[0], d * r);                                                          \
+          r5[1] = fmax(r5[1], 1.0 - r * d - mu * r * fast_rcp(zu_[u]));                        \
+          gphi += mu * r;                                                                      \
         }                                                                                      \
         r5[2] += gphi * d;                                                                     \
       }
@@ -3075,24 +3077,24 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si], d = Q.ds[si];
       double gphi = 0.0;
       if (l > -INFINITY) {
-        if (d < 0.0) r5[0] = fmin(r5[0], -tau * (sv - l) / d);
-        const double dz = dz_lo(sv, l, Q.zsl[si], d, mu);
-        if (dz < 0.0) r5[1] = fmin(r5[1], -tau * Q.zsl[si] / dz);
-        gphi -= mu / (sv - l);
+        const double r = fast_rcp(sv - l);
+        r5[0] = fmax(r5[0], -d * r);
+        r5[1] = fmax(r5[1], 1.0 + r * d - mu * r * fast_rcp(Q.zsl[si]));
+        gphi -= mu * r;
       }
       if (u < INFINITY) {
-        if (d > 0.0) r5[0] = fmin(r5[0], tau * (u - sv) / d);
-        const double dz = dz_up(sv, u, Q.zsu[si], d, mu);
-        if (dz < 0.0) r5[1] = fmin(r5[1], -tau * Q.zsu[si] / dz);
-        gphi += mu / (u - sv);
+        const double r = fast_rcp(u - sv);
+        r5[0] = fmax(r5[0], d * r);
+        r5[1] = fmax(r5[1], 1.0 - r * d - mu * r * fast_rcp(Q.zsu[si]));
+        gphi += mu * r;
       }
       r5[2] += gphi * d;
     }
     {
-      const int ops[5] = {R_MIN, R_MIN, R_SUM, R_SUM, R_SUM};
+      const int ops[5] = {R_MAX, R_MAX, R_SUM, R_SUM, R_SUM};
       wg_reduce(T, r5, ops);
     }
-    const double a_max = r5[0], a_z = r5[1], dphi = r5[2];
+    const double a_max = (r5[0] > tau) ? tau / r5[0] : 1.0, a_z = (r5[1] > tau) ? tau / r5[1] : 1.0, dphi = r5[2];
     c_ftb += prof_clock() - c_t;
     const double theta = E.theta;
     const double phi = E.obj + mu * bar_sum;       // (the barrier sum of the current point was formed when it was a trial point)
@@ -3209,16 +3211,18 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         const bool cnt_ = sh_cnt(A, mk_x(A, g));                                               \
         Q.x[g] = xv;                                                                           \
         if (l > -INFINITY) {                                                                   \
-          const double z = zl_[u] + a_z * dz_lo(x_[u], l, zl_[u], d_[u], mu);                  \
-          const double dd = xv - l;                                                            \
-          const double zn = fmax(fmin(z, ks * mu / dd), mu / (ks * dd));                       \
+          const double ro = fast_rcp(x_[u] - l);                     /* dz_lo with 1/(x - l) */  \
+          const double z = zl_[u] + a_z * (mu * ro - zl_[u] - zl_[u] * ro * d_[u]);            \
+          const double dd = xv - l, mr = mu * fast_rcp(dd);                                    \
+          const double zn = fmax(fmin(z, ks * mr), mr * (1.0 / ks));                           \
           Q.zl[g] = zn;                                                                        \
           if (cnt_) comp_add(Cp, dd * zn, zn);                                                 \
         }                                                                                      \
         if (ub_ < INFINITY) {                                                                  \
-          const double z = zu_[u] + a_z * dz_up(x_[u], ub_, zu_[u], d_[u], mu);                \
-          const double dd = ub_ - xv;                                                          \
-          const double zn = fmax(fmin(z, ks * mu / dd), mu / (ks * dd));                       \
+          const double ro = fast_rcp(ub_ - x_[u]);                                             \
+          const double z = zu_[u] + a_z * (mu * ro - zu_[u] + zu_[u] * ro * d_[u]);            \
+          const double dd = ub_ - xv, mr = mu * fast_rcp(dd);                                  \
+          const double zn = fmax(fmin(z, ks * mr), mr * (1.0 / ks));                           \
           Q.zu[g] = zn;                                                                        \
           if (cnt_) comp_add(Cp, dd * zn, zn);                                                 \
         }                                                                                      \
