@@ -492,16 +492,29 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
 DOMPC_DEV constexpr int slot_of(int i, int r) { return i == 0 ? r - 1 : DEG + (i - 1) * (DEG + 1) + r; }
 DOMPC_DEV constexpr int next_slot(int i) { return (i + 1 < NI) ? slot_of(i + 1, 0) : M - 1; }
 
+// reciprocal of a normal, non-zero double: v_rcp_f64 + two Newton steps (5 instructions instead of the ~12 of the IEEE
+// division sequence; the result is within an ulp or two, no denormal / infinity handling - the callers exclude those)
+DOMPC_DEV inline double fast_rcp(double x) {
+#ifndef DOMPC_HOST_EMU
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
 DOMPC_DEV inline double bar_grad(double x, double l, double u, double mu) {
   double g = 0.0;
-  if (l > -INFINITY) g -= mu / (x - l);
-  if (u < INFINITY) g += mu / (u - x);
+  if (l > -INFINITY) g -= mu * fast_rcp(x - l);
+  if (u < INFINITY) g += mu * fast_rcp(u - x);
   return g;
 }
 DOMPC_DEV inline double sigma_of(double x, double l, double u, double zl, double zu) {
   double sg = 0.0;
-  if (l > -INFINITY) sg += zl / (x - l);
-  if (u < INFINITY) sg += zu / (u - x);
+  if (l > -INFINITY) sg += zl * fast_rcp(x - l);
+  if (u < INFINITY) sg += zu * fast_rcp(u - x);
   return sg;
 }
 
@@ -699,19 +712,6 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #else
   (void)src;
   return v;
-#endif
-}
-
-// reciprocal of a normal, non-zero double: v_rcp_f64 + two Newton steps (5 instructions instead of the ~12 of the IEEE
-// division sequence; the result is within an ulp or two, no denormal / infinity handling - the callers exclude those)
-DOMPC_DEV inline double fast_rcp(double x) {
-#ifndef DOMPC_HOST_EMU
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-#else
-  return 1.0 / x;
 #endif
 }
 

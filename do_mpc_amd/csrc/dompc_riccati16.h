@@ -198,6 +198,8 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   const int g = lane >> 4, j = lane & 15;
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
+  long long pc0 = prof_clock();
+#define R16_PN(i) if (threadIdx.x == 0) { const long long pc1 = prof_clock(); lds_prof[i] += pc1 - pc0; pc0 = pc1; }
   d4 qt_s, F, f0;
   double fu, ry_s, qv_s;
   staged_tiles(Ls, lane, qt_s, F, f0, fu, ry_s, qv_s);
@@ -244,6 +246,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       QO[r] -= 2.0 * rw * DOMPC_RTERM[(i < j ? i : j) - NX];
   }
   const d4 qo0 = col_to_tile0(gv, lane);
+  R16_PN(4)
   // ---- children, pass 1: Q_tot = Q_own + sum F' P_c F ,  q_tot = q_own + sum F'(P_c f + p_c)
   d4 QT = QO, qt0 = qo0;
   Val Vc;
@@ -255,6 +258,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     QT += tmul<KB_A>(F, Tm);
     qt0 += tmul<KB_A>(F, tv);
   }
+  R16_PN(5)
   // ---- Cholesky of Q_vv (uniform arithmetic on values read with v_readlane), gains for this lane's column
   double L[NV * NV], kv[NV], Kj[NV];
   int bad = 0;
@@ -268,6 +272,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       qv[u] = rl(qt0[i / 4], 16 * (i % 4));
       qx[u] = __shfl(QT[i / 4], 16 * (i % 4) + j);
     }
+    double Li[NV];                       // reciprocals of the Cholesky diagonal: every division below is a multiplication
 #pragma unroll
     for (int u = 0; u < NV; ++u)
 #pragma unroll
@@ -278,8 +283,9 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
         if (u == w) {
           if (!(t > 0.0)) { bad = 1; t = 1.0; }
           L[u * NV + u] = sqrt(t);
+          Li[u] = fast_rcp(L[u * NV + u]);
         } else {
-          L[u * NV + w] = t / L[w * NV + w];
+          L[u * NV + w] = t * Li[w];
         }
       }
     auto solve = [&](double* y) {        // y <- Q_vv^-1 y
@@ -288,14 +294,14 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
         double t = y[u];
 #pragma unroll
         for (int q = 0; q < u; ++q) t -= L[u * NV + q] * y[q];
-        y[u] = t / L[u * NV + u];
+        y[u] = t * Li[u];
       }
 #pragma unroll
       for (int u = NV - 1; u >= 0; --u) {
         double t = y[u];
 #pragma unroll
         for (int q = u + 1; q < NV; ++q) t -= L[q * NV + u] * y[q];
-        y[u] = t / L[u * NV + u];
+        y[u] = t * Li[u];
       }
     };
     solve(qv);
@@ -303,13 +309,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
 #pragma unroll
     for (int u = 0; u < NV; ++u) { kv[u] = -qv[u]; Kj[u] = (j < NA) ? -qx[u] : 0.0; }
   }
-  double* Nd = Q.ND(n);
-  if (g == 0 && j < NA)
-#pragma unroll
-    for (int u = 0; u < NV; ++u) Nd[ND_K + u * NA + j] = Kj[u];
-  if (lane == 0)
-#pragma unroll
-    for (int u = 0; u < NV; ++u) Nd[ND_KV + u] = kv[u];
+  R16_PN(6)
   // ---- Lc = [I;K], l0 = (0;kv) as tiles; operands of the rank-NV updates
   d4 Lc, l0;
 #pragma unroll
@@ -349,7 +349,21 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     out.P += tmul<KB_A>(Acl, T2);
     out.p0 += tmul<KB_A>(Acl, tv2);
   }
+  // All global stores of the node at its very end, behind one wait for the operands that were requested for the NEXT
+  // node (LDS-DMA copy, register prefetch): on gfx9 stores count in vmcnt like loads, so a wait for data issued after
+  // a store also waits for the store's ~2 us round trip - waiting first and storing afterwards keeps the stores of
+  // this node in flight during the whole update of the next one.
+  staged_ready();
+  double* Nd = Q.ND(n);
+  if (g == 0 && j < NA)
+#pragma unroll
+    for (int u = 0; u < NV; ++u) Nd[ND_K + u * NA + j] = Kj[u];
+  if (lane == 0)
+#pragma unroll
+    for (int u = 0; u < NV; ++u) Nd[ND_KV + u] = kv[u];
   store_val(Q, n, out, lane);
+  R16_PN(7)
+#undef R16_PN
   return bad;
 }
 
@@ -374,8 +388,8 @@ __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double de
       }
       Val V = leaf(Q, A.level_node_start[A.N] + s_, mu, delta, lane);
       store_val(Q, A.level_node_start[A.N] + s_, V, lane);
+      staged_ready();              // the staged record of the first node has landed (later ones: waited for inside node())
       for (int k = A.N - 1; k >= cl; --k) {
-        staged_ready();            // the staged record of THIS node has landed
         NodeIn nx;                 // the parent's operands: in flight while this node is updated
         if (k > cl) {
           const int np = A.level_node_start[k - 1] + s_;
