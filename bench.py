@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--n-robust", type=int, default=5, help="--variant tree: depth of the branching part (3^n leaves)")
     ap.add_argument("--cut-level", type=int, default=0, help="--variant tree: level whose nodes are the sub-tree roots (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-soc", type=int, default=None,
+                    help="measurement aid: ipopt.max_soc (default: IPOPT's 4; 0 switches the second-order correction off)")
     args = ap.parse_args()
 
     import torch
@@ -123,6 +125,8 @@ def main():
     if args.variant == "closed_loop":
         return bench_closed_loop(args, ex, rank, world, local_rank, dist)
     kw = {} if args.variant == "A" else {"n_robust": 2, "uncertainty": "paired"}
+    if args.max_soc is not None:
+        kw["nlpsol_opts"] = {"ipopt.max_soc": args.max_soc}
     B = args.batch
     mpc = ex.build_mpc(ex.build_model(), gpu_index=local_rank, max_batch=B, **kw)
     ps = mpc.structure

@@ -15,7 +15,7 @@ from . import controller, model, simulator, structs, sym
 
 _CASADI_NAMES = [
     "SX", "DM", "vertcat", "horzcat", "mtimes", "sum1", "sum2", "sumsqr", "dot", "exp", "log", "sqrt", "sin",
-    "cos", "tan", "tanh", "sinh", "cosh", "asin", "acos", "atan", "fabs", "fmin", "fmax", "jacobian",
+    "cos", "tan", "tanh", "sinh", "cosh", "asin", "acos", "atan", "atan2", "sign", "fabs", "fmin", "fmax", "jacobian",
     "gradient", "hessian", "substitute", "Function",
 ]
 

@@ -107,9 +107,9 @@ constexpr int ND_DXT = ND_KV + NV;           // NA
 constexpr int ND_SIZE = ((ND_DXT + NA + 7) / 8) * 8;
 
 struct WsLayout {
-  int64_t x, zl, zu, lb, ub, dx, gf, rd, xt, dzl, dzu;
-  int64_t lam, dlam, c, ct;
-  int64_t s, zsl, zsu, sl, su, ds, st, dzsl, dzsu;
+  int64_t x, zl, zu, lb, ub, dx, gf, rd, xt, dx_sv;
+  int64_t lam, dlam, c, ct, dlam_sv;
+  int64_t s, zsl, zsu, sl, su, ds, st, ds_sv;
   int64_t ew, es, nd, mo, total;
 };
 
@@ -119,11 +119,11 @@ DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad,
   auto take = [&](int64_t n) { int64_t r = o; o += (n + 7) & ~int64_t(7); return r; };
   L.x = take(n_opt_x); L.zl = take(n_opt_x); L.zu = take(n_opt_x); L.lb = take(n_opt_x); L.ub = take(n_opt_x);
   L.dx = take(n_opt_x); L.gf = take(n_opt_x); L.rd = take(n_opt_x); L.xt = take(n_opt_x);
-  L.dzl = take(n_opt_x); L.dzu = take(n_opt_x);
-  L.lam = take(n_g); L.dlam = take(n_g); L.c = take(n_g); L.ct = take(n_g);
+  L.dx_sv = take(n_opt_x);         // (dx_sv / dlam_sv / ds_sv: the Newton direction while a second-order correction is tried)
+  L.lam = take(n_g); L.dlam = take(n_g); L.c = take(n_g); L.ct = take(n_g); L.dlam_sv = take(n_g);
   int64_t nsl = (int64_t)n_edges * NE1;
   L.s = take(nsl); L.zsl = take(nsl); L.zsu = take(nsl); L.sl = take(nsl); L.su = take(nsl);
-  L.ds = take(nsl); L.st = take(nsl); L.dzsl = take(nsl); L.dzsu = take(nsl);
+  L.ds = take(nsl); L.st = take(nsl); L.ds_sv = take(nsl);
   L.ew = take((int64_t)EW_SIZE * e_pad);
   L.es = take((int64_t)ES_SIZE * n_edges);
   L.nd = take((int64_t)ND_SIZE * n_nodes);
@@ -460,13 +460,14 @@ DOMPC_DEV inline void gmm(int lane, int GS, int m, int n, int k, const double* A
 struct Prob {
   const KArgs* A;
   const double* P;                                   // opt_p of this problem
-  double *x, *zl, *zu, *lb, *ub, *dx, *gf, *rd, *xt, *dzl, *dzu;
-  double *lam, *dlam, *c, *ct;
-  double *s, *zsl, *zsu, *sl, *su, *ds, *st, *dzsl, *dzsu;
+  double *x, *zl, *zu, *lb, *ub, *dx, *gf, *rd, *xt, *dx_sv;
+  double *lam, *dlam, *c, *ct, *dlam_sv;
+  double *s, *zsl, *zsu, *sl, *su, *ds, *st, *ds_sv;
   double *ew, *es, *nd, *mo;
   int e_pad;
   double sf;                                         // objective scaling
   double mu;
+  int soc;                                           // second-order correction solve: the constraint residual c is an INPUT of the sweep
   DOMPC_DEV double& EW(int e, int i) const { return ew[(int64_t)e * EW_SIZE + i]; }
   DOMPC_DEV double* ES(int e) const { return es + (int64_t)e * ES_SIZE; }
   DOMPC_DEV double* ND(int n) const { return nd + (int64_t)n * ND_SIZE; }
@@ -479,12 +480,12 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   Prob p;
   p.A = &A; p.P = P;
   p.x = w + L.x; p.zl = w + L.zl; p.zu = w + L.zu; p.lb = w + L.lb; p.ub = w + L.ub; p.dx = w + L.dx;
-  p.gf = w + L.gf; p.rd = w + L.rd; p.xt = w + L.xt; p.dzl = w + L.dzl; p.dzu = w + L.dzu;
-  p.lam = w + L.lam; p.dlam = w + L.dlam; p.c = w + L.c; p.ct = w + L.ct;
+  p.gf = w + L.gf; p.rd = w + L.rd; p.xt = w + L.xt; p.dx_sv = w + L.dx_sv;
+  p.lam = w + L.lam; p.dlam = w + L.dlam; p.c = w + L.c; p.ct = w + L.ct; p.dlam_sv = w + L.dlam_sv;
   p.s = w + L.s; p.zsl = w + L.zsl; p.zsu = w + L.zsu; p.sl = w + L.sl; p.su = w + L.su;
-  p.ds = w + L.ds; p.st = w + L.st; p.dzsl = w + L.dzsl; p.dzsu = w + L.dzsu;
+  p.ds = w + L.ds; p.st = w + L.st; p.ds_sv = w + L.ds_sv;
   p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo;
-  p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0;
+  p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0;
   return p;
 }
 
@@ -759,8 +760,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     if (act) {
       const double* pt = mo + MO_PT;
       for (int a = lane; a < NX; a += GS) {
-        const double r = pt[a] - xc[a];
-        Q.c[row0 + a] = r;
+        const double r = Q.soc ? Q.c[row0 + a] : pt[a] - xc[a];
+        if (!Q.soc) Q.c[row0 + a] = r;
         S_[ES_CV + a] = r;
       }
       for (int i = lane; i < NX * NA; i += GS) S_[ES_AB + i] = pt[NX + i];
@@ -938,10 +939,12 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
             for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * w[(r - 1) * NX + a];
             res = w[(M - 1) * NX + a] - xf;
           }
-          Q.c[row0 + it] = res;
+          if (Q.soc) res = Q.c[row0 + it];           // (second-order correction: corrected residual instead of c(x))
+          else Q.c[row0 + it] = res;
           Ld[EL_T1 + it] = res;
         }
-        for (int a = lane; a < NX; a += GS) Q.c[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
+        if (!Q.soc)
+          for (int a = lane; a < NX; a += GS) Q.c[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
       }
       T.gsync();
       if (act) {
@@ -1031,8 +1034,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           const double* pt = mo + MO_PT + p * PT_STRIDE;
           double xp = DOMPC_C[0 * (DEG + 1) + j] * xi0[a];
           for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + j] * w[slot_of(i, r) * NX + a];
-          const double res = pt[a] - xp;
-          Q.c[row0 + row] = res;
+          const double res = Q.soc ? Q.c[row0 + row] : pt[a] - xp;
+          if (!Q.soc) Q.c[row0 + row] = res;
           Mr[NW + NA] = res;
           for (int b = 0; b < NX; ++b) Mr[sl * NX + b] += pt[NX + a * NA + b];
           for (int b = 0; b < NU; ++b) Mr[NW + NX + b] = pt[NX + a * NA + NX + b];
@@ -1045,8 +1048,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           const int ns_ = next_slot(i);
           double xf = DOMPC_D[0] * xi0[a];
           for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * w[slot_of(i, r) * NX + a];
-          const double res = w[ns_ * NX + a] - xf;
-          Q.c[row0 + row] = res;
+          const double res = Q.soc ? Q.c[row0 + row] : w[ns_ * NX + a] - xf;
+          if (!Q.soc) Q.c[row0 + row] = res;
           Mr[NW + NA] = res;
           Mr[ns_ * NX + a] += 1.0;
           for (int r = 0; r <= DEG; ++r) {
@@ -1055,7 +1058,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           }
         }
       }
-      for (int a = lane; a < NX; a += GS) Q.c[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
+      if (!Q.soc)
+        for (int a = lane; a < NX; a += GS) Q.c[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
     }
     T.gsync();
     // ---- phase 3: dual-residual pieces that need G_w / G_y (before they are overwritten)
@@ -1350,7 +1354,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         const int a = it / (NA + 1), b = it % (NA + 1);
         const double v = Ld[EL_MX + ((M - 1) * NX + a) * MX_LD + MX_W + b];
         if (b < NA) S_[ES_AB + a * NA + b] = v;
-        else S_[ES_CV + a] = v + (w[(M - 1) * NX + a] - xc[a]);
+        else S_[ES_CV + a] = v + (Q.soc ? Q.c[row0 + NW + a] : w[(M - 1) * NX + a] - xc[a]);
       }
       // forward-pass data (interleaved per-edge workspace)
       if (NI != 1)       // (single element: G_cc^-1 went to the record straight from the registers)
@@ -1387,8 +1391,9 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           if (DOMPC_NL_SLACK[i] >= 0) d -= eps[DOMPC_NL_SLACK[i]];
           const int si = e * NE1 + i;
           const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
-          Q.c[row0 + NW + NX + i] = d - sv;
-          S_[ES_RDN + i] = d - sv;
+          const double rdn = Q.soc ? Q.c[row0 + NW + NX + i] : d - sv;
+          if (!Q.soc) Q.c[row0 + NW + NX + i] = rdn;
+          S_[ES_RDN + i] = rdn;
           S_[ES_SIGS + i] = sigma_of(sv, l, u, Q.zsl[si], Q.zsu[si]);
           S_[ES_RSN + i] = -yd[i] + bar_grad(sv, l, u, mu);
         }
@@ -2590,7 +2595,8 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   T.sync();                                  // (every thread has read the previous sweep's verdict, see riccati_backward)
   if (T.tid == 0) T.fset(1, 0);
   T.sync();
-  for (int g = T.tid; g < NX; g += T.nt) Q.c[g] = Q.x[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
+  if (!Q.soc)
+    for (int g = T.tid; g < NX; g += T.nt) Q.c[g] = Q.x[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
   eval_models(T, Q);
   T.sync();
   for (int rep = 0; rep < A.trace_pad; ++rep) {      // measurement aid (DOMPC_EXTRA_TRAFFIC): extra read+write passes over the model-output records
@@ -2800,7 +2806,180 @@ DOMPC_DEV inline double trial_edges(const Thr& T, const Prob& Q) {
     if (sh_cnt(A, mk_n(A, n))) f += node_rterm_f(Q, n, Q.xt);
   return f;
 }
+// ---- the thread-parallel passes of the line search (outlined on the device like the phases above: inlined into the
+//      driver, their register arrays and the second call sites of the second-order correction cost the hot loops of
+//      the driver 3 % in spills)
+// largest ratios (-dx)/(x - l), dx/(u - x) and (-dz)/z over the bounded variables: the fraction-to-the-boundary steps are
+// tau / ratio (one division at the end instead of one per bound), and the directional derivative of the barrier function
+DOMPC_DEV inline void step_rules_pass(const Thr& T, const Prob& Q, double mu, double (&r5)[5]) {   // ratio_x, ratio_z, dphi of Q.dx / Q.ds
+  const KArgs& A = *Q.A;
+  const int nX = A.n_opt_x, nSl = A.n_edges * NE;
+  for (int i = 0; i < 5; ++i) r5[i] = 0.0;
+  {
+    double x_[4], l_[4], u2_[4], d_[4], gf_[4], zl_[4], zu_[4];
+#define L_(u, g) x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; d_[u] = Q.dx[g]; gf_[u] = Q.gf[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
+#define B_(u, g)                                                                               \
+    if (sh_cnt(A, mk_x(A, g))) {                                                           \
+      const double xv = x_[u], l = l_[u], ub_ = u2_[u], d = d_[u];                         \
+      double gphi = gf_[u];                                                                \
+      if (l > -INFINITY) {                                                                 \
+        const double r = fast_rcp(xv - l);                                                 \
+        r5[0] = fmax(r5[0], -d * r);                            /* step to the bound */    \
+        r5[1] = fmax(r5[1], 1.0 + r * d - mu * r * fast_rcp(zl_[u]));    /* -dz / z */     \
+        gphi -= mu * r;                                                                    \
+      }                                                                                    \
+      if (ub_ < INFINITY) {                                                                \
+        const double r = fast_rcp(ub_ - xv);                                               \
+        r5[0] = fmax(r5[0], d * r);                                                        \
+        r5[1] = fmax(r5[1], 1.0 - r * d - mu * r * fast_rcp(zu_[u]));                      \
+        gphi += mu * r;                                                                    \
+      }                                                                                    \
+      r5[2] += gphi * d;                                                                   \
+    }
+    DOMPC_FOR4(nX, L_, B_)
+#undef L_
+#undef B_
+  }
+  for (int g = T.tid; g < nSl; g += T.nt) {
+    if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
+    const int si = (g / NE1) * NE1 + g % NE1;
+    const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si], d = Q.ds[si];
+    double gphi = 0.0;
+    if (l > -INFINITY) {
+      const double r = fast_rcp(sv - l);
+      r5[0] = fmax(r5[0], -d * r);
+      r5[1] = fmax(r5[1], 1.0 + r * d - mu * r * fast_rcp(Q.zsl[si]));
+      gphi -= mu * r;
+    }
+    if (u < INFINITY) {
+      const double r = fast_rcp(u - sv);
+      r5[0] = fmax(r5[0], d * r);
+      r5[1] = fmax(r5[1], 1.0 - r * d - mu * r * fast_rcp(Q.zsu[si]));
+      gphi += mu * r;
+    }
+    r5[2] += gphi * d;
+  }
+  const int ops[5] = {R_MAX, R_MAX, R_SUM, R_SUM, R_SUM};
+  wg_reduce(T, r5, ops);
+}
+// objective, constraint violation and barrier sum of the trial point x + al * dx (left in Q.xt / Q.st, constraint values in Q.ct)
+DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, double& obj_o, double& th_o, double& bar_o) {
+  const KArgs& A = *Q.A;
+  const int nX = A.n_opt_x, nSl = A.n_edges * NE;
+  double r3[3] = {0.0, 0.0, 0.0};    // obj, theta, barrier
+  LogAcc La{1.0, 0, 0};
+  {                                  // trial point and its barrier terms in one pass
+    double x_[4], d_[4], l_[4], u2_[4];
+#define L_(u, g) x_[u] = Q.x[g]; d_[u] = Q.dx[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g];
+#define B_(u, g)                                                                               \
+    if (mk_x(A, g)) {                                                                      \
+      const double xt_ = x_[u] + al * d_[u];                                               \
+      Q.xt[g] = xt_;                                                                       \
+      if (sh_cnt(A, mk_x(A, g))) {                                                         \
+        if (l_[u] > -INFINITY) logacc_add(La, xt_ - l_[u]);                                \
+        if (u2_[u] < INFINITY) logacc_add(La, u2_[u] - xt_);                               \
+      }                                                                                    \
+    }
+    DOMPC_FOR4(nX, L_, B_)
+#undef L_
+#undef B_
+  }
+  for (int g = T.tid; g < nSl; g += T.nt) {
+    if (!mk_e(A, g / NE1)) continue;
+    const int si = (g / NE1) * NE1 + g % NE1;
+    Q.st[si] = Q.s[si] + al * Q.ds[si];
+  }
+  T.sync();
+  for (int g = T.tid; g < NX; g += T.nt) Q.ct[g] = Q.xt[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
+  r3[0] += trial_edges(T, Q);
+  T.sync();
+  {
+    double c_[4];
+#define L_(u, g) c_[u] = Q.ct[g];
+#define B_(u, g) if (sh_cnt(A, mk_g(A, g))) r3[1] += fabs(c_[u]);
+    DOMPC_FOR4(A.n_g, L_, B_)
+#undef L_
+#undef B_
+  }
+  for (int g = T.tid; g < nSl; g += T.nt) {
+    if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
+    const int si = (g / NE1) * NE1 + g % NE1;
+    if (Q.sl[si] > -INFINITY) logacc_add(La, Q.st[si] - Q.sl[si]);
+    if (Q.su[si] < INFINITY) logacc_add(La, Q.su[si] - Q.st[si]);
+  }
+  r3[2] = -logacc_value(La);
+  const int ops[3] = {R_SUM, R_SUM, R_SUM};
+  wg_reduce(T, r3, ops);
+  obj_o = r3[0]; th_o = r3[1]; bar_o = r3[2];
+}
+// the trial point becomes the iterate: x, s, bound multipliers (step a_z, safeguarded) and constraint multipliers (step alpha);
+// returns this thread's complementarity statistics of the new iterate (consumed by measure() after the sweep)
+DOMPC_DEV inline Comp accept_pass(const Thr& T, const Prob& Q, double alpha, double a_z, double mu) {
+  const KArgs& A = *Q.A;
+  const int nX = A.n_opt_x, nSl = A.n_edges * NE;
+  const double ks = 1e10;
+  Comp Cp{-INFINITY, INFINITY, 0.0};       // complementarity statistics of the new iterate (consumed by measure() after the sweep)
+  {
+    double xt_[4], x_[4], d_[4], l_[4], u2_[4], zl_[4], zu_[4];
+#define L_(u, g) xt_[u] = Q.xt[g]; x_[u] = Q.x[g]; d_[u] = Q.dx[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
+#define B_(u, g)                                                                               \
+    if (mk_x(A, g)) {                                                                        \
+      const double xv = xt_[u], l = l_[u], ub_ = u2_[u];                                     \
+      const bool cnt_ = sh_cnt(A, mk_x(A, g));                                               \
+      Q.x[g] = xv;                                                                           \
+      if (l > -INFINITY) {                                                                   \
+        const double ro = fast_rcp(x_[u] - l);                     /* dz_lo with 1/(x - l) */  \
+        const double z = zl_[u] + a_z * (mu * ro - zl_[u] - zl_[u] * ro * d_[u]);            \
+        const double dd = xv - l, mr = mu * fast_rcp(dd);                                    \
+        const double zn = fmax(fmin(z, ks * mr), mr * (1.0 / ks));                           \
+        Q.zl[g] = zn;                                                                        \
+        if (cnt_) comp_add(Cp, dd * zn, zn);                                                 \
+      }                                                                                      \
+      if (ub_ < INFINITY) {                                                                  \
+        const double ro = fast_rcp(ub_ - x_[u]);                                             \
+        const double z = zu_[u] + a_z * (mu * ro - zu_[u] + zu_[u] * ro * d_[u]);            \
+        const double dd = ub_ - xv, mr = mu * fast_rcp(dd);                                  \
+        const double zn = fmax(fmin(z, ks * mr), mr * (1.0 / ks));                           \
+        Q.zu[g] = zn;                                                                        \
+        if (cnt_) comp_add(Cp, dd * zn, zn);                                                 \
+      }                                                                                      \
+    }
+    DOMPC_FOR4(nX, L_, B_)
+#undef L_
+#undef B_
+  }
+  for (int g = T.tid; g < nSl; g += T.nt) {
+    if (!mk_e(A, g / NE1)) continue;
+    const int si = (g / NE1) * NE1 + g % NE1;
+    const double sv = Q.st[si], so = Q.s[si], dsv = Q.ds[si];
+    const bool cnt_ = sh_cnt(A, mk_e(A, g / NE1));
+    Q.s[si] = sv;
+    const double l = Q.sl[si], u = Q.su[si];
+    if (l > -INFINITY) {
+      const double z = Q.zsl[si] + a_z * dz_lo(so, l, Q.zsl[si], dsv, mu);
+      const double zn = fmax(fmin(z, ks * mu / (sv - l)), mu / (ks * (sv - l)));
+      Q.zsl[si] = zn;
+      if (cnt_) comp_add(Cp, (sv - l) * zn, zn);
+    }
+    if (u < INFINITY) {
+      const double z = Q.zsu[si] + a_z * dz_up(so, u, Q.zsu[si], dsv, mu);
+      const double zn = fmax(fmin(z, ks * mu / (u - sv)), mu / (ks * (u - sv)));
+      Q.zsu[si] = zn;
+      if (cnt_) comp_add(Cp, (u - sv) * zn, zn);
+    }
+  }
+  {
+    double y_[4], dy_[4];
+#define L_(u, g) y_[u] = Q.lam[g]; dy_[u] = Q.dlam[g];
+#define B_(u, g) if (mk_g(A, g)) Q.lam[g] = y_[u] + alpha * dy_[u];
+    DOMPC_FOR4(A.n_g, L_, B_)
+#undef L_
+#undef B_
+  }
+  return Cp;
+}
 struct PhaseRet { unsigned gen, nred, xseq; int rc; };
+struct PhaseRet3 { unsigned gen, nred, xseq; double v0, v1, v2; };
 #ifndef DOMPC_HOST_EMU
 #define DOMPC_PHASE_PROLOGUE                                                        \
   const KArgs A = kernel_args(kp);                                                  \
@@ -2809,8 +2988,9 @@ struct PhaseRet { unsigned gen, nred, xseq; int rc; };
   T.gen = ufl(gen); T.nred = ufl(nred); T.xseq = ufl(xseq);                         \
   Prob Q = make_prob(A, ufl(slot), A.p + (int64_t)ufl(b) * A.n_opt_p);              \
   Q.sf = ufl(sf);
-__device__ __attribute__((noinline)) PhaseRet phase_sweep(const void* kp, int b, int slot, double sf, double mu, unsigned gen, unsigned nred, unsigned xseq) {
+__device__ __attribute__((noinline)) PhaseRet phase_sweep(const void* kp, int b, int slot, double sf, double mu, int soc, unsigned gen, unsigned nred, unsigned xseq) {
   DOMPC_PHASE_PROLOGUE
+  Q.soc = ufl(soc);
   const int rc = sweep(T, Q, ufl(mu));
   return PhaseRet{T.gen, T.nred, T.xseq, rc};
 }
@@ -2824,23 +3004,38 @@ __device__ __attribute__((noinline)) PhaseRet phase_forward(const void* kp, int 
   riccati_forward(T, Q, ufl(mu), ufl(delta));
   return PhaseRet{T.gen, T.nred, T.xseq, 0};
 }
-__device__ __attribute__((noinline)) double phase_trial(const void* kp, int b, int slot, double sf) {
-  const unsigned gen = 0u, nred = 0u, xseq = 0u;
+__device__ __attribute__((noinline)) PhaseRet3 phase_step_rules(const void* kp, int b, int slot, double sf, double mu, unsigned gen, unsigned nred, unsigned xseq) {
   DOMPC_PHASE_PROLOGUE
-  return trial_edges(T, Q);
+  double r5[5];
+  step_rules_pass(T, Q, ufl(mu), r5);
+  return PhaseRet3{T.gen, T.nred, T.xseq, r5[0], r5[1], r5[2]};
+}
+__device__ __attribute__((noinline)) PhaseRet3 phase_eval_trial(const void* kp, int b, int slot, double sf, double al, unsigned gen, unsigned nred, unsigned xseq) {
+  DOMPC_PHASE_PROLOGUE
+  double o = 0.0, th = 0.0, br = 0.0;
+  eval_trial_pass(T, Q, ufl(al), o, th, br);
+  return PhaseRet3{T.gen, T.nred, T.xseq, o, th, br};
+}
+__device__ __attribute__((noinline)) PhaseRet3 phase_accept(const void* kp, int b, int slot, double sf, double alpha, double a_z, double mu, unsigned gen, unsigned nred, unsigned xseq) {
+  DOMPC_PHASE_PROLOGUE
+  const Comp C = accept_pass(T, Q, ufl(alpha), ufl(a_z), ufl(mu));
+  return PhaseRet3{T.gen, T.nred, T.xseq, C.smax, C.smin, C.sum_z};
 }
 #undef DOMPC_PHASE_PROLOGUE
 #define DOMPC_PHASE_CALL(fn, ...)                                                   \
-  const PhaseRet r_ = fn(T.kp, b, slot, Q.sf, __VA_ARGS__, T.gen, T.nred, T.xseq);        \
+  const auto r_ = fn(T.kp, b, slot, Q.sf, __VA_ARGS__, T.gen, T.nred, T.xseq);            \
   T.gen = ufl(r_.gen); T.nred = ufl(r_.nred); T.xseq = ufl(r_.xseq);
 #endif
-DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu) {
+DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu, int soc = 0) {
 #ifndef DOMPC_HOST_EMU
-  DOMPC_PHASE_CALL(phase_sweep, mu)
+  DOMPC_PHASE_CALL(phase_sweep, mu, soc)
   return ufl(r_.rc);
 #else
   (void)b; (void)slot;
-  return sweep(T, Q, mu);
+  Q.soc = soc;
+  const int rc = sweep(T, Q, mu);
+  Q.soc = 0;
+  return rc;
 #endif
 }
 DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta) {
@@ -2852,12 +3047,31 @@ DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, 
   return riccati_backward(T, Q, mu, delta);
 #endif
 }
-DOMPC_DEV inline double run_trial(const Thr& T, const Prob& Q, int b, int slot) {
+DOMPC_DEV inline void run_step_rules(const Thr& T, const Prob& Q, int b, int slot, double mu, double (&r5)[5]) {
 #ifndef DOMPC_HOST_EMU
-  return phase_trial(T.kp, b, slot, Q.sf);
+  DOMPC_PHASE_CALL(phase_step_rules, mu)
+  r5[0] = ufl(r_.v0); r5[1] = ufl(r_.v1); r5[2] = ufl(r_.v2); r5[3] = 0.0; r5[4] = 0.0;
 #else
   (void)b; (void)slot;
-  return trial_edges(T, Q);
+  step_rules_pass(T, Q, mu, r5);
+#endif
+}
+DOMPC_DEV inline void run_eval_trial(const Thr& T, const Prob& Q, int b, int slot, double al, double& obj_o, double& th_o, double& bar_o) {
+#ifndef DOMPC_HOST_EMU
+  DOMPC_PHASE_CALL(phase_eval_trial, al)
+  obj_o = ufl(r_.v0); th_o = ufl(r_.v1); bar_o = ufl(r_.v2);
+#else
+  (void)b; (void)slot;
+  eval_trial_pass(T, Q, al, obj_o, th_o, bar_o);
+#endif
+}
+DOMPC_DEV inline Comp run_accept(const Thr& T, const Prob& Q, int b, int slot, double alpha, double a_z, double mu) {
+#ifndef DOMPC_HOST_EMU
+  DOMPC_PHASE_CALL(phase_accept, alpha, a_z, mu)
+  return Comp{r_.v0, r_.v1, r_.v2};
+#else
+  (void)b; (void)slot;
+  return accept_pass(T, Q, alpha, a_z, mu);
 #endif
 }
 DOMPC_DEV inline void run_forward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta) {
@@ -2875,7 +3089,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   Prob Q = make_prob(A, slot, A.p + (int64_t)b * A.n_opt_p);
   const double* x0 = A.x0 + (int64_t)b * A.n_opt_x;
   const int nX = A.n_opt_x, nSl = A.n_edges * NE;
-  int status = 2, it = 0, n_reg = 0, n_ls_fail = 0, n_sweeps = 0, n_trials = 0;
+  int status = 2, it = 0, n_reg = 0, n_ls_fail = 0, n_sweeps = 0, n_trials = 0, n_soc = 0;
 
   // ---- bounds (relaxed, bound_relax_factor), starting point pushed inside, z = 1
   double cnt[2] = {0.0, 0.0};
@@ -3045,63 +3259,19 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     c_t = prof_clock();
     // largest ratios (-dx)/(x - l), dx/(u - x) and (-dz)/z over the bounded variables: the fraction-to-the-boundary steps
     // are tau / ratio (one division at the end instead of one per bound), and the directional derivative of the barrier function
-    double r5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // ratio_x, ratio_z, dphi, (unused), (unused)
-    {
-      double x_[4], l_[4], u2_[4], d_[4], gf_[4], zl_[4], zu_[4];
-#define L_(u, g) x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; d_[u] = Q.dx[g]; gf_[u] = Q.gf[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
-#define B_(u, g)                                                                               \
-      if (sh_cnt(A, mk_x(A, g))) {                                                             \
-        const double xv = x_[u], l = l_[u], ub_ = u2_[u], d = d_[u];                           \
-        double gphi = gf_[u];                                                                  \
-        if (l > -INFINITY) {                                                                   \
-          const double r = fast_rcp(xv - l);                                                   \
-          r5[0] = fmax(r5[0], -d * r);                              /* step to the bound */    \
-          r5[1] = fmax(r5[1], 1.0 + r * d - mu * r * fast_rcp(zl_[u]));      /* -dz / z */     \
-          gphi -= mu * r;                                                                      \
-        }                                                                                      \
-        if (ub_ < INFINITY) {                                                                  \
-          const double r = fast_rcp(ub_ - xv);                                                 \
-          r5[0] = fmax(r5[0], d * r);                                                          \
-          r5[1] = fmax(r5[1], 1.0 - r * d - mu * r * fast_rcp(zu_[u]));                        \
-          gphi += mu * r;                                                                      \
-        }                                                                                      \
-        r5[2] += gphi * d;                                                                     \
-      }
-      DOMPC_FOR4(nX, L_, B_)
-#undef L_
-#undef B_
-    }
-    for (int g = T.tid; g < nSl; g += T.nt) {
-      if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
-      const int si = (g / NE1) * NE1 + g % NE1;
-      const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si], d = Q.ds[si];
-      double gphi = 0.0;
-      if (l > -INFINITY) {
-        const double r = fast_rcp(sv - l);
-        r5[0] = fmax(r5[0], -d * r);
-        r5[1] = fmax(r5[1], 1.0 + r * d - mu * r * fast_rcp(Q.zsl[si]));
-        gphi -= mu * r;
-      }
-      if (u < INFINITY) {
-        const double r = fast_rcp(u - sv);
-        r5[0] = fmax(r5[0], d * r);
-        r5[1] = fmax(r5[1], 1.0 - r * d - mu * r * fast_rcp(Q.zsu[si]));
-        gphi += mu * r;
-      }
-      r5[2] += gphi * d;
-    }
-    {
-      const int ops[5] = {R_MAX, R_MAX, R_SUM, R_SUM, R_SUM};
-      wg_reduce(T, r5, ops);
-    }
-    const double a_max = (r5[0] > tau) ? tau / r5[0] : 1.0, a_z = (r5[1] > tau) ? tau / r5[1] : 1.0, dphi = r5[2];
+    auto step_rules = [&](double (&r5)[5]) { run_step_rules(T, Q, b, slot, mu, r5); };
+    double r5[5];
+    step_rules(r5);
+    const double a_max = (r5[0] > tau) ? tau / r5[0] : 1.0, dphi = r5[2];
+    double a_z = (r5[1] > tau) ? tau / r5[1] : 1.0;
     c_ftb += prof_clock() - c_t;
     const double theta = E.theta;
     const double phi = E.obj + mu * bar_sum;       // (the barrier sum of the current point was formed when it was a trial point)
 
     c_t = prof_clock();
-    // ---- filter line search (no second-order correction, no restoration phase)
+    // ---- filter line search with second-order correction (no restoration phase)
     const double gamma_theta = 1e-5, gamma_phi = 1e-8, eta_phi = 1e-8, s_theta = 1.1, s_phi = 2.3, gamma_alpha = 0.05;
+    const double kappa_soc = 0.99;
     double a_min;
     if (dphi < 0.0 && theta <= theta_min)
       a_min = (theta > 0.0) ? gamma_alpha * fmin(gamma_theta, fmin(gamma_phi * theta / (-dphi),
@@ -3110,79 +3280,101 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     else if (dphi < 0.0) a_min = gamma_alpha * fmin(gamma_theta, gamma_phi * theta / (-dphi));
     else a_min = gamma_alpha * gamma_theta;
     a_min = fmax(a_min, 1e-14);
-    double alpha = a_max;
-    bool accepted = false, armijo_used = false;
-    double th_t = 0.0, obj_t = 0.0, bar_t = bar_sum;
-    while (true) {
-      double r3[3] = {0.0, 0.0, 0.0};    // obj, theta, barrier
-      LogAcc La{1.0, 0, 0};
-      {                                  // trial point and its barrier terms in one pass
-        double x_[4], d_[4], l_[4], u2_[4];
-#define L_(u, g) x_[u] = Q.x[g]; d_[u] = Q.dx[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g];
-#define B_(u, g)                                                                               \
-        if (mk_x(A, g)) {                                                                      \
-          const double xt_ = x_[u] + alpha * d_[u];                                            \
-          Q.xt[g] = xt_;                                                                       \
-          if (sh_cnt(A, mk_x(A, g))) {                                                         \
-            if (l_[u] > -INFINITY) logacc_add(La, xt_ - l_[u]);                                \
-            if (u2_[u] < INFINITY) logacc_add(La, u2_[u] - xt_);                               \
-          }                                                                                    \
-        }
-        DOMPC_FOR4(nX, L_, B_)
-#undef L_
-#undef B_
-      }
-      for (int g = T.tid; g < nSl; g += T.nt) {
-        if (!mk_e(A, g / NE1)) continue;
-        const int si = (g / NE1) * NE1 + g % NE1;
-        Q.st[si] = Q.s[si] + alpha * Q.ds[si];
-      }
-      T.sync();
-      for (int g = T.tid; g < NX; g += T.nt) Q.ct[g] = Q.xt[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
-      r3[0] += run_trial(T, Q, b, slot);
-      T.sync();
-      {
-        double c_[4];
-#define L_(u, g) c_[u] = Q.ct[g];
-#define B_(u, g) if (sh_cnt(A, mk_g(A, g))) r3[1] += fabs(c_[u]);
-        DOMPC_FOR4(A.n_g, L_, B_)
-#undef L_
-#undef B_
-      }
-      for (int g = T.tid; g < nSl; g += T.nt) {
-        if (!sh_cnt(A, mk_e(A, g / NE1))) continue;
-        const int si = (g / NE1) * NE1 + g % NE1;
-        if (Q.sl[si] > -INFINITY) logacc_add(La, Q.st[si] - Q.sl[si]);
-        if (Q.su[si] < INFINITY) logacc_add(La, Q.su[si] - Q.st[si]);
-      }
-      r3[2] = -logacc_value(La);
-      {
-        const int ops[3] = {R_SUM, R_SUM, R_SUM};
-        wg_reduce(T, r3, ops);
-      }
+    // objective, constraint violation and barrier sum of the trial point x + al * dx (left in Q.xt / Q.st, constraint values in Q.ct)
+    auto eval_trial = [&](double al, double& obj_o, double& th_o, double& bar_o) {
+      run_eval_trial(T, Q, b, slot, al, obj_o, th_o, bar_o);
       ++n_trials;
-      obj_t = r3[0]; th_t = r3[1]; bar_t = r3[2];
-      const double ph_t = obj_t + mu * r3[2];
-      bool ok = (ph_t == ph_t) && (th_t == th_t) && fabs(ph_t) < INFINITY && th_t <= theta_max;
+    };
+    // filter / sufficient-decrease tests of a trial point reached with step size al (IPOPT eqs. (18)-(20))
+    auto acceptable = [&](double th_, double ph_, double al, bool& armijo_case) -> bool {
+      armijo_case = false;
+      bool ok = (ph_ == ph_) && (th_ == th_) && fabs(ph_) < INFINITY && th_ <= theta_max;
       if (ok) {
         for (int q = 0; q < n_filt; ++q)
-          if (th_t >= T.filt[2 * q] && ph_t >= T.filt[2 * q + 1]) { ok = false; break; }
+          if (th_ >= T.filt[2 * q] && ph_ >= T.filt[2 * q + 1]) { ok = false; break; }
       }
-      bool armijo_case = false;
       if (ok) {
-        const bool switching = dphi < 0.0 && alpha * pow(-dphi, s_phi) > pow(theta, s_theta);
+        const bool switching = dphi < 0.0 && al * pow(-dphi, s_phi) > pow(theta, s_theta);
         const double eps_m = 10.0 * 2.220446049250313e-16 * fabs(phi);
         if (theta <= theta_min && switching) {
           armijo_case = true;
-          ok = (ph_t - phi - eps_m <= eta_phi * alpha * dphi);
+          ok = (ph_ - phi - eps_m <= eta_phi * al * dphi);
         } else {
-          ok = (th_t <= (1.0 - gamma_theta) * theta) || (ph_t - phi - eps_m <= -gamma_phi * theta);
+          ok = (th_ <= (1.0 - gamma_theta) * theta) || (ph_ - phi - eps_m <= -gamma_phi * theta);
         }
       }
-      if (ok) { accepted = true; armijo_used = armijo_case; break; }
+      return ok;
+    };
+    // corrected constraint residual of the second-order correction: c <- al * c + c(trial point)   (IPOPT eq. (27))
+    auto soc_residual = [&](double al) {
+      double c_[4], ct_[4];
+#define L_(u, g) c_[u] = Q.c[g]; ct_[u] = Q.ct[g];
+#define B_(u, g) if (mk_g(A, g)) Q.c[g] = al * c_[u] + ct_[u];
+      DOMPC_FOR4(A.n_g, L_, B_)
+#undef L_
+#undef B_
+      T.sync();
+    };
+    // the Newton direction is set aside while corrected directions are tried (nothing else of the regular solve is needed
+    // again: the per-edge records and Q.c are rebuilt by the sweep of the next iterate)
+    auto keep_direction = [&](bool restore) {
+      for (int g = T.tid; g < nX; g += T.nt) { if (restore) Q.dx[g] = Q.dx_sv[g]; else Q.dx_sv[g] = Q.dx[g]; }
+      for (int g = T.tid; g < A.n_g; g += T.nt) { if (restore) Q.dlam[g] = Q.dlam_sv[g]; else Q.dlam_sv[g] = Q.dlam[g]; }
+      for (int g = T.tid; g < nSl; g += T.nt) { if (restore) Q.ds[g] = Q.ds_sv[g]; else Q.ds_sv[g] = Q.ds[g]; }
+      T.sync();
+    };
+    double alpha = a_max;
+    bool accepted = false, armijo_used = false, stale = false;
+    double th_t = 0.0, obj_t = 0.0, bar_t = bar_sum;
+    int n_ls = 0;
+    while (true) {
+      eval_trial(alpha, obj_t, th_t, bar_t);
+      stale = false;
+      bool armijo_case = false;
+      if (acceptable(th_t, obj_t + mu * bar_t, alpha, armijo_case)) { accepted = true; armijo_used = armijo_case; break; }
+      if (n_ls == 0 && O.max_soc > 0 && th_t >= theta) {
+        // Second-order correction (IPOPT section 2.4): the full step was rejected and did not reduce the constraint violation.
+        // Solve the SAME linear system again with the corrected residual c_soc = alpha c(x) + c(x + alpha d): the sweep is repeated
+        // with the residual as an input (all matrices come out identical; only the vector parts of the records change),
+        // followed by the two Riccati passes.  Accepted: the corrected direction replaces the Newton direction (step size,
+        // multiplier steps and all).  Not accepted: the Newton direction comes back from its copy.  First trial of an
+        // iteration only; on the industrial_poly benchmark 1.2 corrections per cold solve (57 iterations).
+        double th_old = theta;
+        keep_direction(false);
+        soc_residual(alpha);
+        bool soc_ok = false;
+        for (int k = 0; k < O.max_soc; ++k) {
+          ++n_soc; ++n_sweeps;
+          if (run_sweep(T, Q, b, slot, mu, 1)) break;
+          if (run_backward(T, Q, b, slot, mu, delta)) break;
+          run_forward(T, Q, b, slot, mu, delta);
+          double q5[5];
+          step_rules(q5);
+          const double a_s = (q5[0] > tau) ? tau / q5[0] : 1.0;
+          double obj_s = 0.0, th_s = 0.0, bar_s = 0.0;
+          eval_trial(a_s, obj_s, th_s, bar_s);
+          bool arm_s = false;
+          if (acceptable(th_s, obj_s + mu * bar_s, a_s, arm_s)) {
+            accepted = true; armijo_used = arm_s; soc_ok = true;
+            alpha = a_s;
+            a_z = (q5[1] > tau) ? tau / q5[1] : 1.0;
+            obj_t = obj_s; th_t = th_s; bar_t = bar_s;
+            break;
+          }
+          if (!(th_s <= kappa_soc * th_old)) break;
+          th_old = th_s;
+          soc_residual(a_s);
+        }
+        if (soc_ok) break;
+        keep_direction(true);                             // back to the Newton direction of this iterate
+        stale = true;                                     // (Q.xt / Q.st / Q.ct hold the last corrected trial point)
+      }
       if (!(alpha * 0.5 >= a_min)) break;  // xt/st/ct stay at the last evaluated alpha (also leaves on a NaN step size)
       alpha *= 0.5;
+      ++n_ls;
     }
+    if (bad) { status = 3; break; }
+    if (!accepted && stale) eval_trial(alpha, obj_t, th_t, bar_t);
     if (!accepted) {
       // no restoration phase: take the smallest trial step and reset the filter
       ++n_ls_fail;
@@ -3200,65 +3392,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     c_ls += prof_clock() - c_t;
     // ---- accept the trial point
     c_t = prof_clock();
-    const double ks = 1e10;
-    Comp Cp{-INFINITY, INFINITY, 0.0};       // complementarity statistics of the new iterate (consumed by measure() after the sweep)
-    {
-      double xt_[4], x_[4], d_[4], l_[4], u2_[4], zl_[4], zu_[4];
-#define L_(u, g) xt_[u] = Q.xt[g]; x_[u] = Q.x[g]; d_[u] = Q.dx[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
-#define B_(u, g)                                                                               \
-      if (mk_x(A, g)) {                                                                        \
-        const double xv = xt_[u], l = l_[u], ub_ = u2_[u];                                     \
-        const bool cnt_ = sh_cnt(A, mk_x(A, g));                                               \
-        Q.x[g] = xv;                                                                           \
-        if (l > -INFINITY) {                                                                   \
-          const double ro = fast_rcp(x_[u] - l);                     /* dz_lo with 1/(x - l) */  \
-          const double z = zl_[u] + a_z * (mu * ro - zl_[u] - zl_[u] * ro * d_[u]);            \
-          const double dd = xv - l, mr = mu * fast_rcp(dd);                                    \
-          const double zn = fmax(fmin(z, ks * mr), mr * (1.0 / ks));                           \
-          Q.zl[g] = zn;                                                                        \
-          if (cnt_) comp_add(Cp, dd * zn, zn);                                                 \
-        }                                                                                      \
-        if (ub_ < INFINITY) {                                                                  \
-          const double ro = fast_rcp(ub_ - x_[u]);                                             \
-          const double z = zu_[u] + a_z * (mu * ro - zu_[u] + zu_[u] * ro * d_[u]);            \
-          const double dd = ub_ - xv, mr = mu * fast_rcp(dd);                                  \
-          const double zn = fmax(fmin(z, ks * mr), mr * (1.0 / ks));                           \
-          Q.zu[g] = zn;                                                                        \
-          if (cnt_) comp_add(Cp, dd * zn, zn);                                                 \
-        }                                                                                      \
-      }
-      DOMPC_FOR4(nX, L_, B_)
-#undef L_
-#undef B_
-    }
-    for (int g = T.tid; g < nSl; g += T.nt) {
-      if (!mk_e(A, g / NE1)) continue;
-      const int si = (g / NE1) * NE1 + g % NE1;
-      const double sv = Q.st[si], so = Q.s[si], dsv = Q.ds[si];
-      const bool cnt_ = sh_cnt(A, mk_e(A, g / NE1));
-      Q.s[si] = sv;
-      const double l = Q.sl[si], u = Q.su[si];
-      if (l > -INFINITY) {
-        const double z = Q.zsl[si] + a_z * dz_lo(so, l, Q.zsl[si], dsv, mu);
-        const double zn = fmax(fmin(z, ks * mu / (sv - l)), mu / (ks * (sv - l)));
-        Q.zsl[si] = zn;
-        if (cnt_) comp_add(Cp, (sv - l) * zn, zn);
-      }
-      if (u < INFINITY) {
-        const double z = Q.zsu[si] + a_z * dz_up(so, u, Q.zsu[si], dsv, mu);
-        const double zn = fmax(fmin(z, ks * mu / (u - sv)), mu / (ks * (u - sv)));
-        Q.zsu[si] = zn;
-        if (cnt_) comp_add(Cp, (u - sv) * zn, zn);
-      }
-    }
-    {
-      double y_[4], dy_[4];
-#define L_(u, g) y_[u] = Q.lam[g]; dy_[u] = Q.dlam[g];
-#define B_(u, g) if (mk_g(A, g)) Q.lam[g] = y_[u] + alpha * dy_[u];
-      DOMPC_FOR4(A.n_g, L_, B_)
-#undef L_
-#undef B_
-    }
+    const Comp Cp = run_accept(T, Q, b, slot, alpha, a_z, mu);
     if (A.trace && b == 0 && T.tid == 0 && it < A.trace_cap) {
       double* tr = A.trace + 8 * it;
       tr[0] = it; tr[1] = mu; tr[2] = E0; tr[3] = E.e_p; tr[4] = E.e_d; tr[5] = accepted ? alpha : -alpha;
@@ -3296,7 +3430,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (A.stats) {
       dompc_stats& S = A.stats[b];
       S.success = (status == 0 || status == 1) ? 1 : 0;
-      S.status = status; S.iter_count = it; S.n_reg = n_reg; S.n_ls_fail = n_ls_fail; S.n_sweeps = n_sweeps; S.n_trials = n_trials; S.reserved = 0;
+      S.status = status; S.iter_count = it; S.n_reg = n_reg; S.n_ls_fail = n_ls_fail; S.n_sweeps = n_sweeps; S.n_trials = n_trials; S.n_soc = n_soc;
       S.mu = mu; S.obj = E.obj * isf; S.inf_pr = E.e_p; S.inf_du = E.e_d; S.inf_compl = comp_err(E.C, 0.0);
       S.obj_scaling = Q.sf; S.t_wall_total = 0.0;
     }

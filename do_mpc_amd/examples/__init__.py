@@ -1,11 +1,14 @@
-"""The four BASELINE workloads, restated on do_mpc_amd's Model/MPC surface.
+"""The four BASELINE workloads and three more of the reference's shipped NMPC examples (bicycle models, kite),
+restated on do_mpc_amd's Model/MPC surface.
 
 Each module has `build_model()` and `build_mpc(model, **settings_overrides)` plus `X0`, the
 example's initial state.  Equations/settings follow the reference examples (cited per file);
 the un-edited reference templates themselves run through do_mpc_amd.casadi_compat in
 tests/test_reference_templates.py when /root/reference is present.
 """
-from . import batch_reactor, cstr, industrial_poly, oscillating_masses  # noqa: F401
+from . import batch_reactor, bicycle, cstr, industrial_poly, kite, oscillating_masses  # noqa: F401
 
 CASES = {"industrial_poly": industrial_poly, "CSTR": cstr, "batch_reactor": batch_reactor,
-         "oscillating_masses": oscillating_masses}
+         "oscillating_masses": oscillating_masses, "kinematic_bicycle": bicycle.kinematic,
+         "dynamic_bicycle": bicycle.dynamic, "kite": kite}
+BASELINE_CASES = ("industrial_poly", "CSTR", "batch_reactor", "oscillating_masses")

@@ -28,7 +28,7 @@ class Options(C.Structure):
         "tol", "dual_inf_tol", "constr_viol_tol", "compl_inf_tol", "acceptable_tol", "mu_init", "kappa_mu",
         "theta_mu", "kappa_eps", "tau_min", "bound_push", "bound_frac", "bound_relax_factor",
         "nlp_scaling_max_gradient", "delta_w_0", "delta_w_min", "delta_w_max", "kappa_w_minus", "kappa_w_plus",
-        "kappa_w_plus_bar")] + [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "obj_scaling", "reserved")]
+        "kappa_w_plus_bar")] + [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "obj_scaling", "max_soc")]
 
 
 class ProblemDesc(C.Structure):
@@ -45,7 +45,7 @@ class ProblemDesc(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("success", "status", "iter_count", "n_reg", "n_ls_fail", "n_sweeps", "n_trials", "reserved")] + \
+    _fields_ = [(n, C.c_int32) for n in ("success", "status", "iter_count", "n_reg", "n_ls_fail", "n_sweeps", "n_trials", "n_soc")] + \
                [(n, C.c_double) for n in ("mu", "obj", "inf_pr", "inf_du", "inf_compl", "obj_scaling", "t_wall_total")]
 
 
@@ -61,7 +61,7 @@ class ShardDesc(C.Structure):
 
 
 STATS_DTYPE = np.dtype([("success", "i4"), ("status", "i4"), ("iter_count", "i4"), ("n_reg", "i4"),
-                        ("n_ls_fail", "i4"), ("n_sweeps", "i4"), ("n_trials", "i4"), ("reserved", "i4"), ("mu", "f8"), ("obj", "f8"), ("inf_pr", "f8"),
+                        ("n_ls_fail", "i4"), ("n_sweeps", "i4"), ("n_trials", "i4"), ("n_soc", "i4"), ("mu", "f8"), ("obj", "f8"), ("inf_pr", "f8"),
                         ("inf_du", "f8"), ("inf_compl", "f8"), ("obj_scaling", "f8"), ("t_wall_total", "f8")])
 assert STATS_DTYPE.itemsize == C.sizeof(Stats)
 
@@ -75,7 +75,7 @@ _IPOPT_OPTS = {
     "ipopt.nlp_scaling_max_gradient": "nlp_scaling_max_gradient", "ipopt.max_iter": "max_iter",
     "ipopt.acceptable_iter": "acceptable_iter",
     "ipopt.first_hessian_perturbation": "delta_w_0", "ipopt.min_hessian_perturbation": "delta_w_min",
-    "ipopt.max_hessian_perturbation": "delta_w_max",
+    "ipopt.max_hessian_perturbation": "delta_w_max", "ipopt.max_soc": "max_soc",
 }
 
 
@@ -324,7 +324,7 @@ class HipIpmSolver:
         status = self._lib.dompc_status_string(int(s["status"])).decode()
         return {"success": bool(s["success"]), "return_status": status, "iter_count": int(s["iter_count"]),
                 "t_wall_total": float(s["t_wall_total"]), "t_proc_total": float(s["t_wall_total"]),
-                "n_reg": int(s["n_reg"]), "n_ls_fail": int(s["n_ls_fail"]), "n_sweeps": int(s["n_sweeps"]), "n_trials": int(s["n_trials"]),
+                "n_reg": int(s["n_reg"]), "n_ls_fail": int(s["n_ls_fail"]), "n_sweeps": int(s["n_sweeps"]), "n_trials": int(s["n_trials"]), "n_soc": int(s["n_soc"]),
                 "mu": float(s["mu"]), "obj": float(s["obj"]), "inf_pr": float(s["inf_pr"]),
                 "inf_du": float(s["inf_du"]), "obj_scaling": float(s["obj_scaling"]),
                 "unified_return_status": "SOLVER_RET_SUCCESS" if s["success"] else "SOLVER_RET_UNKNOWN"}

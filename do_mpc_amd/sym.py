@@ -821,6 +821,10 @@ def fmax(a, b):
     return _sx(a)._ew(b, lambda x, y: binary("fmax", x, y))
 
 
+def atan2(a, b):
+    return _sx(a)._ew(b, lambda x, y: binary("atan2", x, y))
+
+
 def jacobian(expr, wrt) -> SX:
     expr, wrt = _sx(expr), _sx(wrt)
     J = forward_jacobian(expr.data, wrt.data)

@@ -58,7 +58,7 @@ typedef struct dompc_options {
   int32_t max_iter;          /* ipopt.max_iter                 3000  */
   int32_t acceptable_iter;   /* ipopt.acceptable_iter          15    */
   int32_t obj_scaling;       /* gradient-based objective scaling on/off (1) */
-  int32_t reserved;
+  int32_t max_soc;           /* ipopt.max_soc: second-order correction attempts per iteration   4 (0 = off) */
 } dompc_options;
 
 /* Description of one multi-stage problem class (fixed at MPC.setup()). All pointers are host
@@ -106,7 +106,7 @@ typedef struct dompc_stats {
   int32_t n_ls_fail;        /* line searches that hit alpha_min (no restoration phase)                     */
   int32_t n_sweeps;         /* derivative sweeps executed (model evaluation + condensing of every edge)        */
   int32_t n_trials;         /* function-only trial sweeps of the line search                                 */
-  int32_t reserved;
+  int32_t n_soc;            /* second-order correction solves (each one more sweep + Riccati pass)            */
   double  mu;
   double  obj;              /* unscaled objective                                                          */
   double  inf_pr, inf_du, inf_compl; /* scaled errors at exit                                                  */

@@ -15,10 +15,12 @@ stage structure - so it is an independent check of the product's Riccati path.
 Parity is pinned on the reference's golden vectors (tests/golden/*.npz), see
 tests/test_oracle_golden.py.
 
-Deviations from IPOPT (documented, none changes the limit point):
-  * inertia is not available from scipy's LU: the inertia-correction loop uses the
+Deviations from IPOPT (documented, none changes the limit point of a convex problem):
+  * inertia is not available from scipy's sparse LU: by default the inertia-correction loop uses the
     curvature test d'(W+Sigma+delta I)d >= kappa |d|^2 (IPOPT option neg_curv_test)
-    instead of counting negative pivots;
+    instead of counting negative pivots.  opts["inertia"] = "ldl" counts them (dense Bunch-Kaufman
+    LDL' of the augmented matrix, scipy.linalg.ldl: n positive / m negative eigenvalues required, as
+    IPOPT does with MUMPS) - O(n^3), for the small non-convex cases of the test-suite;
   * no restoration phase: if the backtracking line search hits alpha_min the last
     trial step is taken and the filter is reset (counted in stats['n_ls_fail']).
 """
@@ -38,13 +40,33 @@ DEFAULTS = dict(
     theta_max_fact=1e4, theta_min_fact=1e-4, gamma_alpha=0.05, max_soc=4, kappa_soc=0.99,
     delta_w_min=1e-20, delta_w_0=1e-4, delta_w_max=1e40, kappa_w_minus=1.0 / 3.0,
     kappa_w_plus=8.0, kappa_w_plus_bar=100.0, delta_c_bar=1e-8, kappa_c=0.25,
-    ls_mult_init=True,
+    ls_mult_init=True, inertia="curvature",
     nlp_scaling_max_gradient=100.0, nlp_scaling_min_value=1e-8, obj_scaling=True, con_scaling=True,
 )
 
 
 class Result(dict):
     pass
+
+
+def _n_negative(K):
+    """Number of negative eigenvalues of the symmetric matrix K (Sylvester: those of the block-diagonal factor of its
+    Bunch-Kaufman LDL' factorisation); -1 if a pivot block is exactly singular (MUMPS, as IPOPT runs it, does not
+    declare small pivots singular either)."""
+    import scipy.linalg as sla
+    _, d, _ = sla.ldl(K.toarray(), lower=True)
+    n, neg, i = d.shape[0], 0, 0
+    while i < n:
+        if i + 1 < n and d[i + 1, i] != 0.0:
+            ev = np.linalg.eigvalsh(d[i:i + 2, i:i + 2])
+            i += 2
+        else:
+            ev = d[i:i + 1, i]
+            i += 1
+        if np.any(ev == 0.0):
+            return -1
+        neg += int(np.sum(ev < 0))
+    return neg
 
 
 def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, lbg=None, ubg=None, trace=None):
@@ -253,7 +275,10 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
                 ok = False
                 if delta_c == 0.0:
                     delta_c = o["delta_c_bar"] * mu ** o["kappa_c"]
-            if ok:
+            if ok and o["inertia"] == "ldl":
+                if _n_negative(K) == m:
+                    break
+            elif ok:
                 dv = sol[:nv]
                 curv = dv @ (Hreg @ dv)
                 if curv >= 1e-11 * (dv @ dv) or (dv @ dv) == 0.0:
@@ -340,11 +365,16 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
                     ph_s = barrier(f_s, v_s) if np.isfinite(f_s) else np.inf
                     ok_s, arm_s = acceptable(th_s, ph_s, a_s) if np.isfinite(ph_s) and np.isfinite(th_s) else (False, False)
                     if ok_s:
+                        # the corrected direction replaces the Newton direction in every component (IPOPT:
+                        # IpBacktrackingLineSearch uses actual_delta = delta_soc for the primal AND the dual step)
                         accepted, armijo = True, arm_s
                         v_t, f_t, g_t, c_t, th_t, ph_t = v_s, f_s, g_s, c_s, th_s, ph_s
                         dy = sol_s[nv:]
                         alpha_y = a_s
                         used_dv = dv_s
+                        dzl = np.where(has_l, mu / dl - zl - zl / dl * dv_s, 0.0)
+                        dzu = np.where(has_u, mu / du - zu + zu / du * dv_s, 0.0)
+                        a_z = min(ftb(zl[has_l], dzl[has_l]), ftb(zu[has_u], dzu[has_u]))
                         break
                     if th_s > o["kappa_soc"] * th_old:
                         break

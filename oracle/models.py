@@ -162,8 +162,93 @@ def case_oscillating_masses(**over):
     return d
 
 
+def case_kinematic_bicycle(**over):
+    """/root/reference/examples/kinematic_bicycle_model/template_model.py:34-75, template_mpc.py:34-95, main.py:57-62."""
+    x = sp.symbols("X_p Y_p Psi V")
+    u = sp.symbols("Delta Acc")
+    X_p, Y_p, Psi, V = x
+    Delta, Acc = u
+    lf, lr = 0.3, 0.3
+    Beta = sp.atan((lr / (lr + lf)) * sp.tan(Delta))
+    rhs = [V * sp.cos(Psi + Beta), V * sp.sin(Psi + Beta), (V / lr) * sp.sin(Beta), Acc]
+    mterm = (Y_p - 2) ** 2 + (X_p - 3) ** 2 + (Psi - 0) ** 2
+    d = _base(name="kinematic_bicycle", x=x, u=u, p=(), rhs=rhs, lterm=sp.Integer(0), mterm=mterm,
+              rterm=np.array([1.0, 1e-3]), n_horizon=10, n_robust=0, t_step=0.05,
+              x_lb=np.array([-50.0, -50.0, -np.pi / 2, -5.0]), x_ub=np.array([50.0, 50.0, np.pi / 2, 5.0]),
+              u_lb=np.array([-5.0, -5.0]), u_ub=np.array([5.0, 5.0]),
+              x_scaling=np.ones(4), u_scaling=np.ones(2), x0=np.array([0.0, 0.0, 0.0, 0.1]), aux={})
+    d.update(over)
+    return d
+
+
+def case_dynamic_bicycle(**over):
+    """/root/reference/examples/dynamic_bicycle_model/template_model.py:34-104, template_mpc.py:34-100, main.py:57-64."""
+    x = sp.symbols("X_p Y_p Psi V_x V_y W")
+    u = sp.symbols("Delta d")
+    X_p, Y_p, Psi, V_x, V_y, W = x
+    Delta, dd = u
+    m, I_z, lf, lr = 5.692, 0.204, 0.178, 0.147
+    D_f, D_r, C_f, C_r, B_f, B_r = 134.585, 159.919, 0.085, 0.133, 9.242, 17.716
+    c_m1, c_m2, c_m3, c_m4 = 20, 6.92 * 1e-7, 3.99, 0.67
+    alpha_f = -sp.atan2(W * lf + V_y, V_x) + Delta
+    alpha_r = sp.atan2((W * lr - V_y), V_x)
+    F_f_y = D_f * sp.sin(C_f * sp.atan(B_f * alpha_f))
+    F_r_y = D_r * sp.sin(C_r * sp.atan(B_r * alpha_r))
+    F_x = (c_m1 - c_m2 * V_x) * dd - c_m4 * V_x ** 2 - c_m3
+    rhs = [V_x * sp.cos(Psi) - V_y * sp.sin(Psi),
+           V_x * sp.sin(Psi) + V_y * sp.cos(Psi),
+           W,
+           (1 / m) * (F_x - F_f_y * sp.sin(Delta) + m * V_y * W),
+           (1 / m) * (F_r_y + F_f_y * sp.cos(Delta) - m * V_x * W),
+           (1 / I_z) * (F_f_y * lf * sp.cos(Delta) - lf * F_x * sp.sin(Delta) - lr * F_r_y)]
+    cost = (Y_p - 1) ** 2
+    d = _base(name="dynamic_bicycle", x=x, u=u, p=(), rhs=rhs, lterm=cost, mterm=cost,
+              rterm=np.array([1e-3, 1e-3]), n_horizon=10, n_robust=0, t_step=0.1,
+              x_lb=np.array([-50000.0, -2.0, -0.78, 0.1, -1.0, -0.2]), x_ub=np.array([50000.0, 2.0, 0.78, 5.0, 1.0, 0.2]),
+              u_lb=np.array([-2.0, 0.0]), u_ub=np.array([2.0, 1.0]),
+              x_scaling=np.ones(6), u_scaling=np.ones(2), x0=np.array([0.0, 0.0, 0.0, 0.1, 0.0, 0.0]),
+              aux={"Vel": sp.sqrt(V_x ** 2 + V_y ** 2)})
+    d.update(over)
+    return d
+
+
+KITE = dict(w_ref=10.0, E_0=6.0, h_min=100.0)       # main.py:46-48 draws these at random; fixed here
+
+
+def case_kite(**over):
+    """/root/reference/examples/kite/template_model.py:34-98, template_mpc.py:34-103, main.py:44-72 (tethered kite, economic
+    NMPC with a soft height constraint; w_ref, E_0, h_min and x0 are random draws in main.py, fixed values here)."""
+    x = sp.symbols("theta phi psi")
+    u = (sp.Symbol("u_tilde"),)
+    p = sp.symbols("E_0 v_0")
+    theta, phi, psi = x
+    u_tilde = u[0]
+    E_0, v_0 = p
+    L_tether, A, rho, beta, c_tilde = 400.0, 300.0, 1.0, 0.0, 0.028
+    E = E_0 - c_tilde * u_tilde ** 2
+    v_a = v_0 * E * sp.cos(theta)
+    P_D = (rho * v_0 ** 2) / 2.0
+    T_F = (P_D * A * sp.cos(theta) ** 2 * (E + 1.0) * sp.sqrt(E ** 2 + 1.0)) * (
+        sp.cos(theta) * np.cos(beta) + sp.sin(theta) * np.sin(beta) * sp.sin(phi))
+    height = L_tether * sp.sin(theta) * sp.cos(phi)
+    dphi = -v_a / (L_tether * sp.sin(theta)) * sp.sin(psi)
+    rhs = [v_a / L_tether * (sp.cos(psi) - sp.tan(theta) / E), dphi, v_a / L_tether * u_tilde + dphi * sp.cos(theta)]
+    w = KITE["w_ref"]
+    d = _base(name="kite", x=x, u=u, p=p, rhs=rhs, lterm=-T_F / 1e4, mterm=sp.Integer(0),
+              rterm=np.array([0.5]), n_horizon=80, n_robust=0, t_step=0.15,
+              x_lb=np.array([0.0, -0.5 * np.pi, -np.pi]), x_ub=np.array([0.5 * np.pi, 0.5 * np.pi, np.pi]),
+              u_lb=np.array([-10.0]), u_ub=np.array([10.0]),
+              x_scaling=np.ones(3), u_scaling=np.ones(1),
+              nl_cons=[dict(name="height_kite", expr=-height, ub=-KITE["h_min"], soft=True, penalty=1e3, max_violation=10.0)],
+              uncertainty=dict(E_0=[KITE["E_0"]], v_0=[w, w * 0.8, w * 1.2]),
+              x0=np.array([0.5, 0.3, 0.2]), aux={"E_0": E_0, "v_0": v_0, "T_F": T_F, "height_kite": height})
+    d.update(over)
+    return d
+
+
 CASES = {"industrial_poly": case_industrial_poly, "CSTR": case_CSTR,
-         "batch_reactor": case_batch_reactor, "oscillating_masses": case_oscillating_masses}
+         "batch_reactor": case_batch_reactor, "oscillating_masses": case_oscillating_masses,
+         "kinematic_bicycle": case_kinematic_bicycle, "dynamic_bicycle": case_dynamic_bicycle, "kite": case_kite}
 
 
 def p_scenarios(case):

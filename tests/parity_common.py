@@ -22,6 +22,16 @@ U_RTOL, X_RTOL, STEP_TOL = 1e-6, 1e-5, 1e-6
 
 _oracle_cache = {}
 
+# Non-convex problems of the reference's example set (trigonometric vehicle / kite models; the four BASELINE cases never
+# need an inertia correction on their test trajectories).  Which local solution an interior-point method reaches depends
+# on every algorithmic detail, so these cases pin the details that the BASELINE cases cannot: the inertia correction
+# (the oracle counts negative eigenvalues exactly with inertia="ldl", as IPOPT does through MUMPS; the product detects a
+# wrong inertia through the Cholesky factors of the Riccati recursion) and the second-order correction of the line search
+# (kinematic bicycle: without it the solve ends in a different local minimum, u0 = 0.697 instead of 0.805).
+# kite: horizon 20 instead of the example's 80 - at 80 both solvers run into line-search failures that IPOPT would hand
+# to its restoration phase (not restated on either side), and the iterates part ways.
+NONCONVEX_CASES = [("kinematic_bicycle", {}), ("dynamic_bicycle", {}), ("kite", {"n_horizon": 20})]
+
 
 PAIRED_P = [[950.0, 7.0], [950.0 * 1.30, 7.0 * 1.30], [950.0 * 0.70, 7.0 * 0.70]]   # industrial_poly "paired" scenarios
 
@@ -70,8 +80,9 @@ def check_golden_replay(make_mpc, name, steps):
     return mpc
 
 
-def check_against_oracle_solve(make_mpc, name, x0_scale=1.0, **over):
-    """Cold solve from the documented initial guess; compare with the oracle's solve of the same NLP."""
+def check_against_oracle_solve(make_mpc, name, x0_scale=1.0, oracle_opts=None, **over):
+    """Cold solve from the documented initial guess; compare with the oracle's solve of the same NLP.
+    `oracle_opts`: options of oracle.ipm.solve (non-convex cases: inertia="ldl", see NONCONVEX_CASES)."""
     ex = CASES[name]
     mpc = make_mpc(name, **over)
     o_over = {k: v for k, v in over.items() if k in ("n_horizon", "n_robust", "collocation_deg", "collocation_ni")}
@@ -82,9 +93,13 @@ def check_against_oracle_solve(make_mpc, name, x0_scale=1.0, **over):
     mpc.set_initial_guess()
     u0 = mpc.make_step(x0).ravel()
     assert mpc.solver_stats["success"], mpc.solver_stats
-    r = ipm.solve(nlp, nlp.initial_guess(x0), nlp.opt_p(x0, np.zeros(nlp.nu)))
+    r = ipm.solve(nlp, nlp.initial_guess(x0), nlp.opt_p(x0, np.zeros(nlp.nu)), opts=oracle_opts)
     assert r["stats"]["success"]
     assert relerr(u0, nlp.u0_of(r["x"])) < U_RTOL, (u0, nlp.u0_of(r["x"]))
+    if oracle_opts:      # non-convex case: same local solution, not merely the same first input
+        used = np.ones(nlp.n_opt_x, bool)
+        used[mpc.structure.tables["dummy_idx"]] = False
+        assert relerr(mpc.opt_x_num.master[used], r["x"][used]) < X_RTOL
     # solution is a KKT point of the oracle's NLP: feasibility and stationarity with OUR multipliers
     x = mpc.opt_x_num.master
     p = mpc.opt_p_num.master

@@ -58,6 +58,14 @@ def test_sweep_blocks_match_oracle_jacobian(name):
     pc.check_sweep_blocks(mpc, name, DevArr, _from_dev)
 
 
+@pytest.mark.parametrize("name,over", pc.NONCONVEX_CASES)
+def test_nonconvex_examples_reach_the_oracles_local_solution(name, over):
+    """Second-order correction + inertia correction: same local minimum as the IPOPT-default oracle with exact inertia."""
+    mpc = pc.check_against_oracle_solve(make_mpc, name, oracle_opts=dict(inertia="ldl"), **over)
+    if name == "kinematic_bicycle":
+        assert mpc.solver_stats["n_soc"] >= 1
+
+
 def test_baseline_config_cstr_nominal_deg3_vs_oracle():
     pc.check_against_oracle_solve(make_mpc, "CSTR", n_robust=0, collocation_deg=3)
 

@@ -37,6 +37,30 @@ def test_sweep_blocks_match_oracle_jacobian(name):
     pc.check_sweep_blocks(mpc, name, pc.HostArr, lambda d: d.a)
 
 
+@pytest.mark.parametrize("name,over", pc.NONCONVEX_CASES)
+def test_nonconvex_examples_reach_the_oracles_local_solution(name, over):
+    """Second-order correction + inertia correction: same local minimum as the IPOPT-default oracle with exact inertia."""
+    mpc = pc.check_against_oracle_solve(make_mpc, name, oracle_opts=dict(inertia="ldl"), **over)
+    if name == "kinematic_bicycle":
+        assert mpc.solver_stats["n_soc"] >= 1          # (the case that needs the correction)
+
+
+def test_second_order_correction_can_be_switched_off():
+    """ipopt.max_soc = 0 reproduces the oracle without the correction (another local minimum of the kinematic bicycle)."""
+    from oracle import ipm
+    mpc = make_mpc("kinematic_bicycle", nlpsol_opts={"ipopt.max_soc": 0})
+    ex = CASES["kinematic_bicycle"]
+    mpc.x0 = ex.X0
+    mpc.set_initial_guess()
+    u0 = mpc.make_step(ex.X0).ravel()
+    assert mpc.solver_stats["success"] and mpc.solver_stats["n_soc"] == 0
+    nlp = pc.oracle_nlp("kinematic_bicycle")
+    r = ipm.solve(nlp, nlp.initial_guess(ex.X0), nlp.opt_p(ex.X0, np.zeros(nlp.nu)), opts=dict(inertia="ldl", max_soc=0))
+    assert pc.relerr(u0, nlp.u0_of(r["x"])) < pc.U_RTOL
+    r4 = ipm.solve(nlp, nlp.initial_guess(ex.X0), nlp.opt_p(ex.X0, np.zeros(nlp.nu)), opts=dict(inertia="ldl"))
+    assert pc.relerr(u0, nlp.u0_of(r4["x"])) > 1e-2    # (the two local minima are far apart)
+
+
 def test_baseline_config_cstr_nominal_deg3_vs_oracle():
     # BASELINE.json configs[1]: CSTR nominal NMPC, N=20, collocation deg 3 (no fixture -> oracle)
     pc.check_against_oracle_solve(make_mpc, "CSTR", n_robust=0, collocation_deg=3)

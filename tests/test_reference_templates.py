@@ -19,7 +19,9 @@ REF = "/root/reference/examples"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not available")
 
 DIRS = {"industrial_poly": "industrial_poly", "CSTR": "CSTR", "batch_reactor": "batch_reactor",
-        "oscillating_masses": "oscillating_masses_discrete"}
+        "oscillating_masses": "oscillating_masses_discrete", "kinematic_bicycle": "kinematic_bicycle_model",
+        "dynamic_bicycle": "dynamic_bicycle_model", "kite": "kite"}
+MPC_ARGS = {"kite": (10.0, 6.0)}           # template_mpc(model, w_ref, E_0, h_min=100): main.py draws them at random
 
 
 def _load(path, name):
@@ -43,7 +45,7 @@ def test_unedited_templates_lower_to_the_same_model(name, compat):
     tc = _load(os.path.join(d, "template_mpc.py"), f"ref_{name}_template_mpc")
     with hostemu.patched():
         ref_model = tm.template_model()
-        ref_mpc = tc.template_mpc(ref_model, silence_solver=True)
+        ref_mpc = tc.template_mpc(ref_model, *MPC_ARGS.get(name, ()), silence_solver=True)
         ours = CASES[name].build_mpc(CASES[name].build_model())
     assert ref_mpc.structure.n_opt_x == ours.structure.n_opt_x
     assert ref_mpc.structure.n_g == ours.structure.n_g
@@ -55,7 +57,7 @@ def test_unedited_templates_lower_to_the_same_model(name, compat):
     rng = np.random.default_rng(0)
     m1, m2 = ref_model, ours.model
     for _ in range(5):
-        x = ours._x0.master * 0 + CASES[name].X0 * (1 + 0.01 * rng.standard_normal(m1.n_x))
+        x = ours._x0.master * 0 + CASES[name].X0 * (1 + 0.01 * rng.standard_normal(m1.n_x)) + 0.01 * rng.standard_normal(m1.n_x)
         u = 0.5 * (ours._u_lb.master + ours._u_ub.master) * (1 + 0.01 * rng.standard_normal(m1.n_u))
         p = ours.p_fun(0.0).master[:m1.n_p]
         z = np.zeros(0)
