@@ -122,7 +122,8 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
     out = os.path.join(d, f"dompc_{ARCH}{'_shard' if shard else ''}.hsaco")
     stamp = out + ".stamp"
     lb = os.environ.get("DOMPC_LB", "2")          # tuning aid: wavefronts per SIMD the kernel is compiled for
-    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt + ("S" if shard else "") + "lb" + lb
+    prof = os.environ.get("DOMPC_PROFILE", "0")    # measurement aid: sub-phase cycle counters compiled in (tools/gpu_profile.py)
+    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt + ("S" if shard else "") + "lb" + lb + "p" + prof
     if not force and _fresh(out, stamp, dig):
         return out
     with _locked(d):
@@ -130,7 +131,7 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
             return out
         if not (os.path.exists(hdr) and open(hdr).read() == header_text):
             _write_atomic(hdr, header_text)
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_LB={lb}",
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_LB={lb}", f"-DDOMPC_PROFILE={prof}",
                f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC, os.path.join(CSRC, "dompc_device.hip")]
         _compile_to(cmd, out, f"lowering model {model_hash} to {ARCH}")
         _write_atomic(stamp, dig)

@@ -4,6 +4,7 @@
 // = one host thread); see dompc_kernel.h.
 #ifndef DOMPC_HOST_EMU
 #include <hip/hip_runtime.h>
+#define DOMPC_CONSTANT_TABLES 1          // structure tables of KArgs: constant address space (dompc_kargs.h)
 #define DOMPC_FN __device__ static inline
 #define DOMPC_CONST __device__ static const
 #define DOMPC_DEV __device__
@@ -52,7 +53,8 @@ extern "C" __global__ void dompc_model_info_kernel(const int32_t* in, int64_t* o
 extern "C" __global__ void __launch_bounds__(256, DOMPC_LB) dompc_solve_kernel(dompc::KArgs A) {
   using namespace dompc;
   const int POOL = A.pool_doubles;
-  if (threadIdx.x < 8) { lds_prof[threadIdx.x] = 0; lds_flags[threadIdx.x] = 0; }
+  if (threadIdx.x < 16) lds_prof[threadIdx.x] = 0;
+  if (threadIdx.x < 8) lds_flags[threadIdx.x] = 0;
   // defined LDS contents at kernel start (the pool of the previous kernel on this CU is still in there)
   for (int i = threadIdx.x; i < POOL; i += blockDim.x) lds_pool[i] = (i >= A.lds_fill_lo && i < A.lds_fill_hi) ? A.lds_fill : 0.0;
   for (int i = threadIdx.x; i < 2 * MAX_FILTER; i += blockDim.x) lds_filt[i] = 0.0;

@@ -5,12 +5,23 @@
 #include "../../include/dompc_ipm.h"
 
 namespace dompc {
+// Structure tables of the problem class: written once by dompc_create(), never by a kernel.  In device code they are
+// pointers into the CONSTANT address space, which is what lets the compiler read them with scalar loads (s_load through
+// the scalar cache, result in SGPRs) wherever the index is wave-uniform - with plain global pointers every look-up is a
+// vector load and every address derived from it a 64-bit VGPR pair.  Same 64-bit pointers on the host side.
+#if defined(DOMPC_CONSTANT_TABLES)      // (defined by dompc_device.hip; the host runtime sees ordinary pointers)
+typedef const __attribute__((address_space(4))) int32_t* itab_t;
+typedef const __attribute__((address_space(4))) double* dtab_t;
+#else
+typedef const int32_t* itab_t;
+typedef const double* dtab_t;
+#endif
 struct KArgs {
-  const int32_t *level_node_start, *node_level, *node_x_off, *node_u_off, *node_eps_off;
-  const int32_t *node_child_start, *node_child_count, *node_parent, *node_in_edge;
-  const int32_t *edge_parent, *edge_child, *edge_pidx, *edge_w_off, *edge_row0, *edge_level;
-  const double* edge_omega;
-  const int32_t* dummy_idx;
+  itab_t level_node_start, node_level, node_x_off, node_u_off, node_eps_off;
+  itab_t node_child_start, node_child_count, node_parent, node_in_edge;
+  itab_t edge_parent, edge_child, edge_pidx, edge_w_off, edge_row0, edge_level;
+  dtab_t edge_omega;
+  itab_t dummy_idx;
   int32_t N, n_nodes, n_edges, n_dummy, n_opt_x, n_opt_p, n_g, e_pad;
   int32_t p_off_tvp, p_off_p, p_off_uprev;
   int32_t chain_level;      // first stage from which every node has exactly one child of the same scenario index (= n_robust)

@@ -281,7 +281,10 @@ extern __shared__ double lds_pool[];
 __shared__ double lds_filt[2 * MAX_FILTER];
 __shared__ int lds_flags[8];
 __shared__ int lds_b;
-__shared__ long long lds_prof[8];
+#ifndef DOMPC_PROFILE
+#define DOMPC_PROFILE 0             // 1: sub-phase shader-clock counters of the edge sweep / node update (tools/gpu_profile.py)
+#endif
+__shared__ long long lds_prof[16];
 
 // slot of the calling workgroup: normal mode one workgroup per problem slot; wide mode (small batches) K = A.wide
 // workgroups per problem, all on one XCD when the dispatcher places block b on XCD b % 8 (affinity only - the barrier
@@ -493,6 +496,27 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
 DOMPC_DEV constexpr int slot_of(int i, int r) { return i == 0 ? r - 1 : DEG + (i - 1) * (DEG + 1) + r; }
 DOMPC_DEV constexpr int next_slot(int i) { return (i + 1 < NI) ? slot_of(i + 1, 0) : M - 1; }
 
+// Index of the lane group (= wavefront on the device) a thread belongs to, as a wave-uniform value: everything derived
+// from it - the edge / node number, the table look-ups, the record pointers - then lives in SGPRs (scalar loads, SGPR
+// base + 32-bit lane offset addressing) instead of one 64-bit VGPR address pair and one vector load per look-up.
+DOMPC_DEV inline int group_index(int tid, int gs) {
+#ifndef DOMPC_HOST_EMU
+  return __builtin_amdgcn_readfirstlane(tid / gs);
+#else
+  return tid / gs;
+#endif
+}
+
+// base[idx] with the BYTE offset formed in 32-bit arithmetic: wave-uniform base (SGPR pair) + zero-extended 32-bit lane
+// offset is an addressing mode of the global loads; an index that is scaled after its extension to 64 bits is not.
+DOMPC_DEV inline double ldoff(const double* base, unsigned idx) {
+#ifndef DOMPC_HOST_EMU
+  return *(const double*)((const char*)base + (idx << 3));
+#else
+  return base[idx];
+#endif
+}
+
 // reciprocal of a normal, non-zero double: v_rcp_f64 + two Newton steps (5 instructions instead of the ~12 of the IEEE
 // division sequence; the result is within an ulp or two, no denormal / infinity handling - the callers exclude those)
 DOMPC_DEV inline double fast_rcp(double x) {
@@ -637,7 +661,16 @@ constexpr int RF_NEED = 3 * NA + NV + NX + 2 * NW1 + (NV * NA + NV) + 2 * (NX * 
 constexpr int R16_STAGE = ((NX * NA + NX + NA * NA + 3 * NA + 127) / 128) * 128;      // staged head of an edge record (dompc_riccati16.h)
 constexpr int R16_NEED = R16_ENABLED ? 2 * R16_STAGE : 0;
 constexpr int el_max(int a, int b) { return a > b ? a : b; }
-constexpr int EL_SIZE = ((el_max(el_max(EL_RY + NA, RB_NEED), el_max(RF_NEED, R16_NEED)) + 7) / 8) * 8;
+// single finite element, device: the model-output record of the edge is copied into LDS by the LDS-DMA path one edge
+// ahead (eval_edge_coop), 64 lanes x 16 B per instruction
+#ifndef DOMPC_HOST_EMU
+constexpr bool MO_LDS = (NI == 1) && (M > 0);
+#else
+constexpr bool MO_LDS = false;
+#endif
+constexpr int EL_MOS = ((EL_RY + NA + 1) / 2) * 2;                        // (16-byte aligned)
+constexpr int MO_STAGE = MO_LDS ? ((MO_SIZE + 127) / 128) * 128 : 0;
+constexpr int EL_SIZE = ((el_max(el_max(EL_MOS + MO_STAGE, RB_NEED), el_max(RF_NEED, R16_NEED)) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {
   // collocation point (i*DEG + j-1) stored in slot sl, or -1 for element-start states and xkf
@@ -716,7 +749,22 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #endif
 }
 
-DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, double mu, int lane, int GS, ldsd* Ld) {
+#ifndef DOMPC_HOST_EMU
+// request the copy of the model-output record of edge e into the wavefront's staging area (LDS-DMA: global_load_lds_dwordx4,
+// 64 lanes x 16 B per instruction, no staging registers; completion is awaited with s_waitcnt vmcnt).  The last piece may run
+// past the end of the record into the next one / the slack behind the array (ws_layout) - never used.
+__device__ inline void stage_mo(const Prob& Q, int e, int lane, ldsd* Ld) {
+  const double* src = Q.MO(e);
+#pragma unroll
+  for (int q = 0; q < MO_STAGE / 128; ++q)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 128 * q + 2 * lane),
+                                     (__attribute__((address_space(3))) void*)(Ld + EL_MOS + 128 * q), 16, 0, 0);
+}
+#endif
+
+// `staged_e` (device, single finite element): the edge whose model-output record is in (or on its way into) the staging area
+// of this wavefront; the function requests the record of `e_next` as soon as it has read the last entry of its own.
+DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, double mu, int lane, int GS, ldsd* Ld, int& staged_e) {
   const KArgs& A = *Q.A;
   const bool act = e >= 0;
   const int ee = act ? e : 0;
@@ -736,14 +784,39 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   double* S_ = Q.ES(ee);
   const double* mo = Q.MO(ee);
   int fail = 0;
+  // operands requested with the first batch of loads of the edge (fetch_rest(), single finite element)
+  constexpr bool PF = (NI == 1 && M > 0);
+  constexpr int RPL = PF ? (NW + GS_C - 1) / GS_C : 1;
+  constexpr int APL = PF ? (NA + GS_C - 1) / GS_C : 1, MHL = PF ? (NX * NX + GS_C - 1) / GS_C : 1;
+  double pf_xn[RPL], pf_w[RPL][DEG > 0 ? DEG : 1], pf_wend[RPL], pf_xc[RPL], pf_lam[RPL], pf_c[RPL], pf_cend[RPL];
+  double pf_ltg[APL], pf_mg[RPL], pf_mh[MHL], pf_lt0 = 0.0, pf_mt0 = 0.0;
+  const bool last_stage = (k == A.N - 1);
+  (void)pf_xn; (void)pf_w; (void)pf_wend; (void)pf_xc; (void)pf_lam; (void)pf_c; (void)pf_cend;
+  (void)pf_ltg; (void)pf_mg; (void)pf_mh; (void)pf_lt0; (void)pf_mt0; (void)last_stage;
+  // the model-output record of this edge: staged in LDS (device, single finite element - requested by the previous edge
+  // of this wavefront / the prologue of the sweep, see stage_mo) or read from global memory
+#ifndef DOMPC_HOST_EMU
+  const ldsd* mol = Ld + EL_MOS;
+#define MOV(i) (MO_LDS ? (double)mol[(i)] : mo[(i)])
+#else
+#define MOV(i) mo[(i)]
+#endif
 #ifndef DOMPC_HOST_EMU
   constexpr int PF_LINES = (MO_SIZE * 8 + 127) / 128, PF_N = (PF_LINES + 63) / 64;
   unsigned pf_tok[PF_N];
 #pragma unroll
   for (int q = 0; q < PF_N; ++q) pf_tok[q] = 0u;
 #endif
+#ifndef DOMPC_HOST_EMU
+  if (MO_LDS && act && staged_e != e) { stage_mo(Q, e, lane, Ld); staged_e = e; }
+#endif
+  (void)staged_e;
   long long pc0 = prof_clock();
+#if DOMPC_PROFILE
 #define DOMPC_PH(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
+#else
+#define DOMPC_PH(i)
+#endif
 
   // ---- phase 1: zero Mx (the model-output record of eval_models is read from global memory / L2)
   if (act) {
@@ -811,14 +884,14 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       auto fetch_cols = [&]() {
 #pragma unroll
         for (int q = 0; q < CPX; ++q) {
-          const int cx = lane + q * GS;
-          const bool isG = cx < R, isY = cx >= R && cx < R + NA;
-          const int jcol = isG ? cx % NX : (isY ? cx - R : 0);           // column of the point Jacobian this lane reads
-          const int sl1 = isG ? cx / NX + 1 : 0;
+          const unsigned cx = (unsigned)lane + (unsigned)q * (unsigned)GS;
+          const bool isG = cx < (unsigned)R, isY = cx >= (unsigned)R && cx < (unsigned)(R + NA);
+          const unsigned jcol = isG ? cx % (unsigned)NX : (isY ? cx - (unsigned)R : 0u);   // column of the point Jacobian this lane reads
+          const unsigned sl1 = isG ? cx / (unsigned)NX + 1u : 0u;
 #pragma unroll
-          for (int r = 0; r < R; ++r) jv[q][r] = mo[MO_PT + (r / NX) * PT_STRIDE + NX + (r % NX) * NA + jcol];
+          for (int r = 0; r < R; ++r) jv[q][r] = MOV((unsigned)(MO_PT + (r / NX) * PT_STRIDE + NX + (r % NX) * NA) + jcol);
 #pragma unroll
-          for (int jj = 0; jj < DEG; ++jj) cd[q][jj] = DOMPC_C[sl1 * (DEG + 1) + (jj + 1)];
+          for (int jj = 0; jj < DEG; ++jj) cd[q][jj] = DOMPC_C[sl1 * (unsigned)(DEG + 1) + (unsigned)(jj + 1)];
         }
       };
       auto build_cols = [&]() {
@@ -899,6 +972,30 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         return badl;
 #endif
       };
+      // Operands of the residual rows that live outside the model-output record (iterate, multipliers; second-order
+      // correction: the corrected residual), requested in one batch with the per-variable data below.  A load issued
+      // between stores, or one load -> LDS store pair per loop trip, costs a full memory round trip each (stores count in
+      // vmcnt on gfx9): the point-Hessian staging loop and the residual rows were 24 % of the sweep that way, the cost
+      // loads behind the record stores another 10 %.
+      // (indices are formed in UNSIGNED arithmetic from the lane number, byte offsets in 32 bits - ldoff(): uniform base
+      //  pointer + zero-extended lane offset is an addressing mode of the global loads, a sign-extended index is not)
+      const unsigned ul = (unsigned)lane, ugs = (unsigned)GS;
+      const double* c_e = Q.c + row0;
+      auto fetch_rest = [&]() {
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+          const unsigned it = ul + (unsigned)q * ugs, itc = it < (unsigned)NW ? it : 0u;
+          const unsigned a = itc % (unsigned)NX;
+          pf_xn[q] = ldoff(xn, a);
+#pragma unroll
+          for (int r = 1; r <= DEG; ++r) pf_w[q][r - 1] = ldoff(w, (unsigned)((r - 1) * NX) + a);
+          pf_wend[q] = ldoff(w, (unsigned)((M - 1) * NX) + a);
+          pf_xc[q] = ldoff(xc, a);
+          pf_lam[q] = ldoff(lam_e, itc);
+          pf_c[q] = Q.soc ? ldoff(c_e, itc) : 0.0;
+          pf_cend[q] = Q.soc ? ldoff(c_e, (unsigned)NW + a) : 0.0;
+        }
+      };
       // per-variable data of the collocation unknowns (this lane's column, plus the end-point columns on the first
       // NX lanes) and the Jacobian columns: requested up front, together with the loads of the residual rows
       double vx[CPX][5], ex[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -906,49 +1003,66 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       if (act) {
 #pragma unroll
         for (int q = 0; q < CPX; ++q) {
-          const int cx = lane + q * GS;
-          const int gi = woff + (cx < R ? cx : 0);
-          vx[q][0] = Q.x[gi]; vx[q][1] = Q.lb[gi]; vx[q][2] = Q.ub[gi]; vx[q][3] = Q.zl[gi]; vx[q][4] = Q.zu[gi];
+          const unsigned cx = ul + (unsigned)q * ugs;
+          const unsigned gi = cx < (unsigned)R ? cx : 0u;
+          vx[q][0] = ldoff(Q.x + woff, gi); vx[q][1] = ldoff(Q.lb + woff, gi); vx[q][2] = ldoff(Q.ub + woff, gi);
+          vx[q][3] = ldoff(Q.zl + woff, gi); vx[q][4] = ldoff(Q.zu + woff, gi);
         }
         if (GS > 1) {
-          const int gi = woff + R + (lane < NX ? lane : 0);
-          ex[0] = Q.x[gi]; ex[1] = Q.lb[gi]; ex[2] = Q.ub[gi]; ex[3] = Q.zl[gi]; ex[4] = Q.zu[gi];
-          nu_a = nu_e[lane < NX ? lane : 0];
+          const unsigned gi = (unsigned)R + (ul < (unsigned)NX ? ul : 0u);
+          ex[0] = ldoff(Q.x + woff, gi); ex[1] = ldoff(Q.lb + woff, gi); ex[2] = ldoff(Q.ub + woff, gi);
+          ex[3] = ldoff(Q.zl + woff, gi); ex[4] = ldoff(Q.zu + woff, gi);
+          nu_a = ldoff(nu_e, ul < (unsigned)NX ? ul : 0u);
         }
+        fetch_rest();
+#ifndef DOMPC_HOST_EMU
+        if (MO_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staged record (and everything above) has landed
+#endif
         fetch_cols();
-        for (int r = lane; r < NW; r += GS) Ld[EL_T0 + r] = lam_e[r];      // multipliers of the edge's rows (dual residual)
       }
+      DOMPC_PH(4)
       // residual rows (collocation, continuity, end point): computed by one lane each, written to g and staged in LDS
-      // for the lane that owns the right-hand-side column; the point Hessians of the condensing phases are staged
-      // with the same batch of global loads
+      // for the lane that owns the right-hand-side column; the point Hessians of the condensing phases are staged in LDS;
+      // all operands were requested by fetch_rest()
       if (act) {
-        for (int it = lane; it < NCOLL * NA * NA; it += GS)
-          Ld[EL_HP + it] = mo[MO_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + symi((it % (NA * NA)) / NA, it % NA, NA)];
-        for (int it = lane; it < NW; it += GS) {
-          const int jj = it / NX, a = it % NX;
-          double res;
-          if (jj < DEG) {
-            const int j = jj + 1;
-            double xp = DOMPC_C[0 * (DEG + 1) + j] * xn[a];
+        if constexpr (!TILE_CONDENSE)           // (the matrix-core condensing reads the point Hessians from the record itself)
+          for (int it = lane; it < NCOLL * NA * NA; it += GS)
+            Ld[EL_HP + it] = MOV(MO_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + symi((it % (NA * NA)) / NA, it % NA, NA));
 #pragma unroll
-            for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + j] * w[(r - 1) * NX + a];
-            res = mo[MO_PT + jj * PT_STRIDE + a] - xp;
-          } else {
-            double xf = DOMPC_D[0] * xn[a];
+        for (int q = 0; q < RPL; ++q) {
+          const int it = lane + q * GS;
+          if (it < NW) {
+            const int jj = it / NX;
+            double res;
+            if (jj < DEG) {
+              const int j = jj + 1;
+              double xp = DOMPC_C[0 * (DEG + 1) + j] * pf_xn[q];
 #pragma unroll
-            for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * w[(r - 1) * NX + a];
-            res = w[(M - 1) * NX + a] - xf;
+              for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + j] * pf_w[q][r - 1];
+              res = MOV(MO_PT + jj * PT_STRIDE + it % NX) - xp;
+            } else {
+              double xf = DOMPC_D[0] * pf_xn[q];
+#pragma unroll
+              for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * pf_w[q][r - 1];
+              res = pf_wend[q] - xf;
+            }
+            if (Q.soc) res = pf_c[q];                  // (second-order correction: corrected residual instead of c(x))
+            else Q.c[row0 + it] = res;
+            Ld[EL_T1 + it] = res;
+            Ld[EL_T0 + it] = pf_lam[q];                // multipliers of the edge's rows (dual residual)
           }
-          if (Q.soc) res = Q.c[row0 + it];           // (second-order correction: corrected residual instead of c(x))
-          else Q.c[row0 + it] = res;
-          Ld[EL_T1 + it] = res;
+          if (it < NX) {                               // end-point rows (it = a: jj = 0, same w_end / x_c entry)
+            const double ce = Q.soc ? pf_cend[q] : pf_wend[q] - pf_xc[q];
+            if (!Q.soc) Q.c[row0 + NW + it] = ce;
+            Ld[EL_PV + it] = ce;                       // (read back by the record stores: c~ of the edge; the pivot-row slots are free here)
+          }
         }
-        if (!Q.soc)
-          for (int a = lane; a < NX; a += GS) Q.c[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
       }
+      DOMPC_PH(5)
       T.gsync();
       if (act) {
         build_cols();
+        DOMPC_PH(6)
         // dual-residual pieces: column c of G_w / G_y times the multipliers of the edge's rows (continuity rows:
         // -D_{sl+1} on the diagonal of the G_cc columns, -D_0 for the x_n columns, +1 for the end-point columns)
 #pragma unroll
@@ -1206,8 +1320,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           const int i = g + 4 * r;
           const bool in = i < NA && j < NA;
           const int ip = in ? symi(i, j, NA) : 0;
-          double v = om * mo[MO_LT + 1 + NA + ip];
-          if (NE > 0) v += mo[MO_NL + NE + NE * NA + ip];
+          double v = om * MOV(MO_LT + 1 + NA + ip);
+          if (NE > 0) v += MOV(MO_NL + NE + NE * NA + ip);
           QTt[r] = in ? v : 0.0;
         }
 #pragma unroll
@@ -1218,7 +1332,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
             const int i = g + 4 * r;
             const int row = p * NX + (i < NX ? i : 0);
             const double wv = Wm(row, j < NA ? j : 0), w0v = Wm(row, NA);
-            const double hv = Ld[EL_HP + p * NA * NA + (i < NA ? i : 0) * NA + (j < NA ? j : 0)];
+            const double hv = MOV(MO_PT + p * PT_STRIDE + NX + NX * NA + symi(i < NA ? i : 0, j < NA ? j : 0, NA));
             const double sg = Ld[EL_SG + row], rw = Ld[EL_RW + row];
             Z[r] = (i < NX) ? (j < NA ? wv : 0.0) : ((i < NA && j == i) ? 1.0 : 0.0);
             z0[r] = (j == 0 && i < NX) ? w0v : 0.0;
@@ -1253,6 +1367,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         }
       }
 #endif
+      DOMPC_PH(7)
     } else {
     // ---- phase 5 (generic): T1 = Hww W, t0 = Hww w0, U1 = Huw W, u0 = Huw w0   (Hww = blockdiag(Hxx_p) + Sigma_w)
     //      (stage-cost / nl_cons Hessian entries for phase 6 are requested now, consumed there)
@@ -1263,8 +1378,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       const int it = lane + q * GS;
       const int itc = it < NA * NA ? it : 0;
       const int ip = symi(itc / NA, itc % NA, NA);
-      qlt[q] = act ? mo[MO_LT + 1 + NA + ip] : 0.0;
-      qnl[q] = (act && NE > 0) ? mo[MO_NL + NE + NE * NA + ip] : 0.0;
+      qlt[q] = act ? MOV(MO_LT + 1 + NA + ip) : 0.0;
+      qnl[q] = (act && NE > 0) ? MOV(MO_NL + NE + NE * NA + ip) : 0.0;
     }
     if (act) {
       for (int it = lane; it < NW * (NA + 1); it += GS) {
@@ -1338,15 +1453,46 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     }
     }
     // ---- phase 6: condensed blocks to the shared per-edge record; data for the forward pass
-#ifndef DOMPC_HOST_EMU
-    // touch the model-output record of the edge this wavefront handles next (one dword per 128-byte line):
-    // by the time its assembly starts the lines sit in L2 instead of HBM.  The values are consumed (never
-    // true) at the end of the function so that the loads stay where they are.
+    if constexpr (PF) {
+      // the cost pieces of the record that phases 6-7 still need, taken out before the staging area is handed to the next edge
+      if (act) {
 #pragma unroll
-    for (int q = 0; q < PF_N; ++q) {
-      const int line = lane + 64 * q;
-      pf_tok[q] = (e_next >= 0 && line < PF_LINES)
-                      ? *((const volatile unsigned*)((const char*)Q.MO(e_next) + (int64_t)line * 128)) : 0u;
+        for (int q = 0; q < APL; ++q) {
+          const int a = lane + q * GS;
+          pf_ltg[q] = MOV(MO_LT + 1 + (a < NA ? a : 0));
+        }
+        pf_lt0 = MOV(MO_LT);
+        if (last_stage) {
+#pragma unroll
+          for (int q = 0; q < RPL; ++q) {
+            const int a = lane + q * GS;
+            pf_mg[q] = MOV(MO_MT + 1 + (a < NX ? a : 0));
+          }
+#pragma unroll
+          for (int q = 0; q < MHL; ++q) {
+            const int a = lane + q * GS, ac = a < NX * NX ? a : 0;
+            pf_mh[q] = MOV(MO_MT + 1 + NX + symi(ac / NX, ac % NX, NX));
+          }
+          pf_mt0 = MOV(MO_MT);
+        }
+      }
+    }
+#ifndef DOMPC_HOST_EMU
+    if constexpr (MO_LDS && NE == 0) {
+      // the record of the edge this wavefront handles next: on its way into LDS while the stores of this edge drain
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (every read of the current record has returned)
+      if (e_next >= 0) { stage_mo(Q, e_next, lane, Ld); staged_e = e_next; }
+    }
+    // (other device variants) touch the model-output record of the edge this wavefront handles next (one dword per
+    // 128-byte line): by the time its assembly starts the lines sit in L2 instead of HBM.  The values are consumed (never
+    // true) at the end of the function so that the loads stay where they are.
+    if constexpr (!MO_LDS) {
+#pragma unroll
+      for (int q = 0; q < PF_N; ++q) {
+        const int line = lane + 64 * q;
+        pf_tok[q] = (e_next >= 0 && line < PF_LINES)
+                        ? *((const volatile unsigned*)((const char*)Q.MO(e_next) + (int64_t)line * 128)) : 0u;
+      }
     }
 #endif
     if (act) {
@@ -1354,6 +1500,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         const int a = it / (NA + 1), b = it % (NA + 1);
         const double v = Ld[EL_MX + ((M - 1) * NX + a) * MX_LD + MX_W + b];
         if (b < NA) S_[ES_AB + a * NA + b] = v;
+        else if (PF) S_[ES_CV + a] = v + Ld[EL_PV + a];
         else S_[ES_CV + a] = v + (Q.soc ? Q.c[row0 + NW + a] : w[(M - 1) * NX + a] - xc[a]);
       }
       // forward-pass data (interleaved per-edge workspace)
@@ -1370,6 +1517,31 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   T.gsync();
   // ---- phase 7: stage cost / terminal cost / nl_cons shares (few values: lanes 0..)
   if (act) {
+    if constexpr (PF) {                    // (operands in registers since the first load batch of the edge)
+#pragma unroll
+      for (int q = 0; q < APL; ++q) {
+        const int a = lane + q * GS;
+        if (a < NA) {
+          double r = Ld[EL_RY + a] + om * pf_ltg[q];
+          if (NE > 0)
+            for (int i = 0; i < NE; ++i) r += MOV(MO_NL + NE + i * NA + a) * yd[i];
+          S_[ES_GFY + a] = om * pf_ltg[q];
+          S_[ES_RY + a] = r;
+        }
+      }
+      if (last_stage) {
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+          const int a = lane + q * GS;
+          if (a < NX) S_[ES_MG + a] = om * pf_mg[q];
+        }
+#pragma unroll
+        for (int q = 0; q < MHL; ++q) {
+          const int a = lane + q * GS;
+          if (a < NX * NX) S_[ES_MH + a] = om * pf_mh[q];
+        }
+      }
+    } else {
     for (int a = lane; a < NA; a += GS) {
       double r = Ld[EL_RY + a] + om * mo[MO_LT + 1 + a];
       if (NE > 0)
@@ -1381,13 +1553,14 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       for (int a = lane; a < NX; a += GS) S_[ES_MG + a] = om * mo[MO_MT + 1 + a];
       for (int a = lane; a < NX * NX; a += GS) S_[ES_MH + a] = om * mo[MO_MT + 1 + NX + symi(a / NX, a % NX, NX)];
     }
+    }
     if (lane == 0) {
-      double obj = om * mo[MO_LT];
-      if (k == A.N - 1) obj += om * mo[MO_MT];
+      double obj = PF ? om * pf_lt0 : om * mo[MO_LT];
+      if (k == A.N - 1) obj += PF ? om * pf_mt0 : om * mo[MO_MT];
       if (NE > 0) {
         const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
         for (int i = 0; i < NE; ++i) {
-          double d = mo[MO_NL + i];
+          double d = MOV(MO_NL + i);
           if (DOMPC_NL_SLACK[i] >= 0) d -= eps[DOMPC_NL_SLACK[i]];
           const int si = e * NE1 + i;
           const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
@@ -1402,7 +1575,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       S_[ES_OBJ] = obj;
     }
     if (NE > 0)
-      for (int it = lane; it < NE * NA; it += GS) Q.EW(e, EW_JD + it) = mo[MO_NL + NE + it];
+      for (int it = lane; it < NE * NA; it += GS) Q.EW(e, EW_JD + it) = MOV(MO_NL + NE + it);
   }
   T.gsync();
 #ifndef DOMPC_HOST_EMU
@@ -1413,8 +1586,15 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     if (acc && mu < 0.0) fail = 1;
   }
 #endif
+#ifndef DOMPC_HOST_EMU
+  if constexpr (MO_LDS && NE > 0) {          // (nl_cons rows: the record is read until the end of the edge)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (e_next >= 0) { stage_mo(Q, e_next, lane, Ld); staged_e = e_next; }
+  }
+#endif
   DOMPC_PH(3)
 #undef DOMPC_PH
+#undef MOV
   return fail;
 }
 
@@ -1623,7 +1803,11 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
   long long pc0 = prof_clock();
+#if DOMPC_PROFILE
 #define DOMPC_PN(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
+#else
+#define DOMPC_PN(i)
+#endif
   // ---- pass A: own quadratic (bounds Sigma, rterm, barrier gradients, slack penalty) plus the condensed
   //      blocks of all child edges.  First child + own data come from the prefetched registers, further
   //      children (branching nodes only) are added from global memory.
@@ -1781,7 +1965,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
   };
   stage_child(0, child_staged && cc == 1);
   T.gsync();
-  DOMPC_PN(4)
+  DOMPC_PN(8)
   // ---- children, pass 1: coupling Atilde' P_c Atilde (and Atilde'(P_c ctilde + p_c)) summed into QF
   for (int c = 0; c < cc; ++c) {
     if (c > 0) { stage_child(c, false); T.gsync(); }
@@ -1808,7 +1992,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
     }
     T.gsync();
   }
-  DOMPC_PN(5)
+  DOMPC_PN(9)
   // ---- Cholesky of Qvv (QF + QO) and K = -Qvv^-1 Qvx, kv = -Qvv^-1 qv  (one lane per column)
   int bad = 0;
   for (int j = lane; j < NA + 1; j += GS) {
@@ -1845,7 +2029,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
   bad = __ballot(bad) != 0ull;          // wave-uniform verdict: the callers branch on it (all lanes stay together)
 #endif
   T.gsync();
-  DOMPC_PN(6)
+  DOMPC_PN(10)
   // ---- children, pass 2 (closed-loop form):  PN = Lc' QO Lc + sum Acl' P_c Acl ; pn likewise.
   //      Same pass: own part of PN and the closed-loop map of the staged (last) child.
   auto closed_loop = [&]() {
@@ -1918,7 +2102,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
   for (int it = lane; it < NA * NA; it += GS) Nd[ND_P + it] = Ld[RB_PN + it];
   for (int it = lane; it < NA; it += GS) Nd[ND_PV + it] = Ld[RB_PNV + it];
   T.gsync();
-  DOMPC_PN(7)
+  DOMPC_PN(11)
 #undef DOMPC_PN
   return bad;
 }
@@ -2209,7 +2393,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
   using namespace rb;
   const KArgs& A = *Q.A;
   static_assert(!RB_IN_LDS || RB_SIZE <= EL_SIZE, "node working set must fit the per-group LDS region");
-  const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
+  const int GS = T.gs, ng = T.nt / GS, gid = group_index(T.tid, GS), lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   // The failure flag is read by every thread after a barrier and reset here by thread 0.  When the caller repeats the
   // factorisation (inertia correction) a fast wavefront could reset it before a slow one had read the verdict of the
@@ -2307,7 +2491,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
 // One group of lanes per node (level by level), then one group per edge.
 DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double delta) {
   const KArgs& A = *Q.A;
-  const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
+  const int GS = T.gs, ng = T.nt / GS, gid = group_index(T.tid, GS), lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   // operands of a chain-node step, staged in LDS: own gains [K | kv], the child edge's [A B | c], the first NX rows of
   // the child's value function [P_c | p_c]
@@ -2604,15 +2788,16 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     T.sync();
   }
   {
-    const int ng = T.nt / T.gs, gid = T.tid / T.gs, lane = T.tid % T.gs;
+    const int ng = T.nt / T.gs, gid = group_index(T.tid, T.gs), lane = T.tid % T.gs;
     ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / T.gs) * EL_SIZE;
     const int rounds = (A.n_edges + ng - 1) / ng;
+    int staged_e = -1;
     for (int rd = 0; rd < rounds; ++rd) {
       const int e = rd * ng + gid;
       const int en = e + ng;
       const bool mine = e < A.n_edges && mk_e(A, e);
       if (sh_on(A) && !mine) continue;                  // sharded: another rank's edge (no workgroup barrier inside)
-      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld)) T.fset(1, 1);
+      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld, staged_e)) T.fset(1, 1);
     }
   }
   T.sync();
@@ -2648,7 +2833,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
 // residual) instead of repeating the whole derivative sweep.
 DOMPC_PHASE void refresh_mu(const Thr& T, const Prob& Q, double dmu) {
   const KArgs& A = *Q.A;
-  const int GS = T.gs, ng = T.nt / GS, gid = T.tid / GS, lane = T.tid % GS;
+  const int GS = T.gs, ng = T.nt / GS, gid = group_index(T.tid, GS), lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   for (int e = gid; e < A.n_edges; e += ng) {
     if (!mk_e(A, e)) continue;
@@ -3408,7 +3593,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   }
 
   // ---- outputs (unscaled multipliers, CasADi sign convention)
-  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = (double)c_ftb; tr[7] = (double)c_acc; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; } }
+  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = (double)c_ftb; tr[7] = (double)c_acc; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; double* t3 = A.trace + 8 * (A.trace_cap - 3); for (int i = 0; i < 8; ++i) t3[i] = (double)T.prof[8 + i]; } }
   const double isf = 1.0 / Q.sf;
   // (sharded problem: every entry is written by exactly one rank, zeros elsewhere -> a SUM over the ranks is the full vector)
   if (A.x_out) for (int g = T.tid; g < nX; g += T.nt) A.x_out[(int64_t)b * nX + g] = sh_cnt(A, mk_x(A, g)) ? Q.x[g] : 0.0;

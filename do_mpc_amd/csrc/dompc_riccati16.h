@@ -199,7 +199,11 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
   long long pc0 = prof_clock();
+#if DOMPC_PROFILE
 #define R16_PN(i) if (threadIdx.x == 0) { const long long pc1 = prof_clock(); lds_prof[i] += pc1 - pc0; pc0 = pc1; }
+#else
+#define R16_PN(i)
+#endif
   d4 qt_s, F, f0;
   double fu, ry_s, qv_s;
   staged_tiles(Ls, lane, qt_s, F, f0, fu, ry_s, qv_s);
@@ -246,7 +250,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       QO[r] -= 2.0 * rw * DOMPC_RTERM[(i < j ? i : j) - NX];
   }
   const d4 qo0 = col_to_tile0(gv, lane);
-  R16_PN(4)
+  R16_PN(8)
   // ---- children, pass 1: Q_tot = Q_own + sum F' P_c F ,  q_tot = q_own + sum F'(P_c f + p_c)
   d4 QT = QO, qt0 = qo0;
   Val Vc;
@@ -258,7 +262,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     QT += tmul<KB_A>(F, Tm);
     qt0 += tmul<KB_A>(F, tv);
   }
-  R16_PN(5)
+  R16_PN(9)
   // ---- Cholesky of Q_vv (uniform arithmetic on values read with v_readlane), gains for this lane's column
   double L[NV * NV], kv[NV], Kj[NV];
   int bad = 0;
@@ -309,7 +313,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
 #pragma unroll
     for (int u = 0; u < NV; ++u) { kv[u] = -qv[u]; Kj[u] = (j < NA) ? -qx[u] : 0.0; }
   }
-  R16_PN(6)
+  R16_PN(10)
   // ---- Lc = [I;K], l0 = (0;kv) as tiles; operands of the rank-NV updates
   d4 Lc, l0;
 #pragma unroll
@@ -362,7 +366,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
 #pragma unroll
     for (int u = 0; u < NV; ++u) Nd[ND_KV + u] = kv[u];
   store_val(Q, n, out, lane);
-  R16_PN(7)
+  R16_PN(11)
 #undef R16_PN
   return bad;
 }
@@ -370,7 +374,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
 // Backward recursion of one problem (all wavefronts of the problem take part; same protocol as riccati_backward).
 __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double delta) {
   const KArgs& A = *Q.A;
-  const int ng = T.nt / 64, gid = T.tid / 64, lane = T.tid % 64;
+  const int ng = T.nt / 64, gid = group_index(T.tid, 64), lane = T.tid % 64;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / 64) * EL_SIZE;      // this wavefront's LDS region: two staging buffers
   T.sync();
   if (T.tid == 0) T.fset(0, 0);

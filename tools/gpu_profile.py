@@ -8,6 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("DOMPC_PROFILE", "1")      # the code object with the sub-phase counters compiled in
 import bench  # noqa: E402
 from do_mpc_amd.examples import CASES  # noqa: E402
 
@@ -33,10 +34,12 @@ def main():
     for nm, v in zip(("step rules", "accept"), tr[6:8]):
         print(f"  {nm:12s} {v / 1e6:9.2f} Mcycles  {100 * v / tot:5.1f} %")
     print(f"  total        {tot / 1e6:9.2f} Mcycles (problem 0)")
-    sub = mpc.S.trace(4096)[-2]
-    for nm, v in zip(("edge:model-eval", "edge:assemble+dual", "edge:gauss-jordan", "edge:condense+store",
-                      "node:own+stage", "node:coupling", "node:cholesky+K", "node:closed-loop+store"), sub[:8]):
-        print(f"    {nm:22s} {v / 1e6:9.2f} Mcycles")
+    sub = np.concatenate([mpc.S.trace(4096)[-2][:8], mpc.S.trace(4096)[-3][:8]])
+    names = {0: "edge:model-eval", 4: "edge:loads issued", 5: "edge:residual rows+H staging", 6: "edge:wait+build columns",
+             1: "edge:dual pieces", 2: "edge:gauss-jordan+W", 7: "edge:tile condensing", 3: "edge:record stores",
+             8: "node:own+stage", 9: "node:coupling", 10: "node:cholesky+K", 11: "node:closed-loop+store"}
+    for i in (0, 4, 5, 6, 1, 2, 7, 3, 8, 9, 10, 11):
+        print(f"    {names[i]:30s} {sub[i] / 1e6:9.2f} Mcycles")
 
 
 if __name__ == "__main__":
