@@ -517,6 +517,31 @@ DOMPC_DEV inline double ldoff(const double* base, unsigned idx) {
 #endif
 }
 
+// Entry of a small compile-time table (collocation coefficients, input scalings, rterm weights) at a LANE-DEPENDENT index,
+// entries [first, first + count): selects over values the optimiser cannot see through (an empty asm per entry).  An
+// indexed read is a vector load from constant memory + vmcnt(0) in the middle of a phase - a memory round trip that also
+// waits for every prefetch and store in flight (two of them were 30 % of the Riccati node update) - and a plain select
+// chain over literals is folded straight back into such a lookup-table load.
+template <int N>
+DOMPC_DEV inline double tab_sel(const double (&tab)[N], int idx, int first = 0, int count = N) {
+#ifndef DOMPC_HOST_EMU
+  double v = tab[first];
+  asm("" : "+v"(v));
+#pragma unroll
+  for (int i = 1; i < N; ++i) {
+    if (i < count) {
+      double t = tab[first + i];
+      asm("" : "+v"(t));
+      v = (idx == first + i) ? t : v;
+    }
+  }
+  return v;
+#else
+  (void)first; (void)count;
+  return tab[idx];
+#endif
+}
+
 // reciprocal of a normal, non-zero double: v_rcp_f64 + two Newton steps (5 instructions instead of the ~12 of the IEEE
 // division sequence; the result is within an ulp or two, no denormal / infinity handling - the callers exclude those)
 DOMPC_DEV inline double fast_rcp(double x) {
@@ -1072,12 +1097,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
 #pragma unroll
           for (int r = 0; r < R; ++r) t += bc[q][r] * Ld[EL_T0 + r];
           if (cx < R) {
-            {                                            // D[cx / NX + 1]: selects over literals, not a load from constant memory mid-phase
-              double dsel = DOMPC_D[1];
-#pragma unroll
-              for (int jq = 2; jq <= DEG; ++jq) dsel = ((int)cx / NX + 1 == jq) ? DOMPC_D[jq] : dsel;
-              t -= dsel * Ld[EL_T0 + R + cx % NX];
-            }
+            t -= DOMPC_D[cx / NX + 1] * Ld[EL_T0 + R + cx % NX];   // (measured: neither a select chain nor a load of the coefficient in the first batch of the edge pays - both slow the elimination that follows by more than the round trip they save)
             const int gi = woff + cx;
             const double xv = vx[q][0], l = vx[q][1], u = vx[q][2], zl_ = vx[q][3], zu_ = vx[q][4];
             Q.gf[gi] = 0.0;

@@ -18,7 +18,6 @@
 
 namespace dompc {
 namespace r16 {
-
 constexpr bool ENABLED = R16_ENABLED;      // (NYT <= 16, no nl_cons rows, not the tree-sharding build)
 
 #ifndef DOMPC_HOST_EMU
@@ -159,7 +158,7 @@ __device__ inline void load_node(const Prob& Q, int n, int lane, NodeIn& R) {
   const int gi = (jj < NX) ? xo + jj : (is_up ? uo + (jj - NX) : uo + (jj - NA));
   R.xv = Q.x[gi]; R.lo = Q.lb[gi]; R.hi = Q.ub[gi]; R.zlo = Q.zl[gi]; R.zhi = Q.zu[gi];
   const int iu = is_up ? jj - NX : (jj >= NA ? jj - NA : 0);
-  R.upv = (jj >= NX) ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / DOMPC_SU[iu]) : 0.0;
+  R.upv = (jj >= NX) ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / tab_sel(DOMPC_SU, iu)) : 0.0;
   R.nu = (jj < NX) ? ((ie >= 0) ? Q.lam[A.edge_row0[ie] + NW + jj] : Q.lam[jj]) : 0.0;
 }
 // tiles of the staged first child edge (LDS reads)
@@ -207,6 +206,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   d4 qt_s, F, f0;
   double fu, ry_s, qv_s;
   staged_tiles(Ls, lane, qt_s, F, f0, fu, ry_s, qv_s);
+  R16_PN(12)
   // ---- own quadratic: per-variable terms in column layout (lane: z-entry j)
   double dg = 0.0, gv = 0.0;
   {
@@ -216,16 +216,16 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     const int iu = is_up ? jj - NX : (jj >= NA ? jj - NA : 0);
     const double xv = R.xv, lo = R.lo, hi = R.hi, upv = R.upv;
     if (is_up) {
-      dg = 2.0 * rw * DOMPC_RTERM[iu];
-      gv = -2.0 * rw * DOMPC_RTERM[iu] * (xv - upv);
+      dg = 2.0 * rw * tab_sel(DOMPC_RTERM, iu);
+      gv = -2.0 * rw * tab_sel(DOMPC_RTERM, iu) * (xv - upv);
     } else {
       dg = sigma_of(xv, lo, hi, R.zlo, R.zhi) + delta;
       gv = bar_grad(xv, lo, hi, mu);
       if (jj < NX) {
         gv += (ie >= 0) ? -R.nu : R.nu;
       } else {
-        dg += 2.0 * rw * DOMPC_RTERM[iu];
-        gv += 2.0 * rw * DOMPC_RTERM[iu] * (xv - upv);
+        dg += 2.0 * rw * tab_sel(DOMPC_RTERM, iu);
+        gv += 2.0 * rw * tab_sel(DOMPC_RTERM, iu) * (xv - upv);
       }
     }
     const int yjj = yz(jj);
@@ -239,6 +239,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     }
     if (j >= NYT) { dg = 0.0; gv = 0.0; }
   }
+  R16_PN(13)
   d4 QO = qt_s;
   if (delta != 0.0) QO = load_qt(Q, cs, delta, lane);
   for (int c = 1; c < cc; ++c) QO += load_qt(Q, cs + c, delta, lane);
@@ -247,8 +248,9 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     const int i = g + 4 * r;
     if (i == j) QO[r] += dg;
     else if ((i >= NX && i < NA && j == i + NU) || (j >= NX && j < NA && i == j + NU))
-      QO[r] -= 2.0 * rw * DOMPC_RTERM[(i < j ? i : j) - NX];
+      QO[r] -= 2.0 * rw * tab_sel(DOMPC_RTERM, (i < j ? i : j) - NX);
   }
+  R16_PN(14)
   const d4 qo0 = col_to_tile0(gv, lane);
   R16_PN(8)
   // ---- children, pass 1: Q_tot = Q_own + sum F' P_c F ,  q_tot = q_own + sum F'(P_c f + p_c)

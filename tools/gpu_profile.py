@@ -37,8 +37,8 @@ def main():
     sub = np.concatenate([mpc.S.trace(4096)[-2][:8], mpc.S.trace(4096)[-3][:8]])
     names = {0: "edge:model-eval", 4: "edge:loads issued", 5: "edge:residual rows+H staging", 6: "edge:wait+build columns",
              1: "edge:dual pieces", 2: "edge:gauss-jordan+W", 7: "edge:tile condensing", 3: "edge:record stores",
-             8: "node:own+stage", 9: "node:coupling", 10: "node:cholesky+K", 11: "node:closed-loop+store"}
-    for i in (0, 4, 5, 6, 1, 2, 7, 3, 8, 9, 10, 11):
+             12: "node:staged tiles", 13: "node:own terms", 14: "node:own matrix", 8: "node:column to tile", 9: "node:coupling", 10: "node:cholesky+K", 11: "node:closed-loop+store"}
+    for i in (0, 4, 5, 6, 1, 2, 7, 3, 12, 13, 14, 8, 9, 10, 11):
         print(f"    {names[i]:30s} {sub[i] / 1e6:9.2f} Mcycles")
 
 
