@@ -284,7 +284,7 @@ __shared__ int lds_b;
 #ifndef DOMPC_PROFILE
 #define DOMPC_PROFILE 0             // 1: sub-phase shader-clock counters of the edge sweep / node update (tools/gpu_profile.py)
 #endif
-__shared__ long long lds_prof[16];
+__shared__ long long lds_prof[24];
 
 // slot of the calling workgroup: normal mode one workgroup per problem slot; wide mode (small batches) K = A.wide
 // workgroups per problem, all on one XCD when the dispatcher places block b on XCD b % 8 (affinity only - the barrier
@@ -695,7 +695,13 @@ constexpr bool MO_LDS = false;
 #endif
 constexpr int EL_MOS = ((EL_RY + NA + 1) / 2) * 2;                        // (16-byte aligned)
 constexpr int MO_STAGE = MO_LDS ? ((MO_SIZE + 127) / 128) * 128 : 0;
-constexpr int EL_SIZE = ((el_max(el_max(EL_MOS + MO_STAGE, RB_NEED), el_max(RF_NEED, R16_NEED)) + 7) / 8) * 8;
+// forward pass, same condition: the per-edge record [G_cc^-1 | W | w0 | Sigma_w | r_w] and the head of the model-output
+// record (point Hessians) of the NEXT edge are staged behind the step vectors while the current edge is computed
+constexpr int RF_EW = ((RF_NEED + 1) / 2) * 2;
+constexpr int EW_STAGE = MO_LDS ? ((EW_SIZE + 127) / 128) * 128 : 0;
+constexpr int RF_MOH = RF_EW + EW_STAGE;
+constexpr int MOH_STAGE = MO_LDS ? ((MO_LT + 127) / 128) * 128 : 0;
+constexpr int EL_SIZE = ((el_max(el_max(EL_MOS + MO_STAGE, RB_NEED), el_max(RF_MOH + MOH_STAGE, R16_NEED)) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {
   // collocation point (i*DEG + j-1) stored in slot sl, or -1 for element-start states and xkf
@@ -2525,6 +2531,14 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   constexpr int RF_DX = 0, RF_DV = RF_DX + NA, RF_DY = RF_DV + NV, RF_DNU = RF_DY + NA, RF_DW = RF_DNU + NX,
                 RF_RHS = RF_DW + NW1, RF_DXN = RF_RHS + NW1, RF_IN = RF_DXN + NA;
   static_assert(RF_IN + FW_N <= EL_SIZE, "forward working set must fit the per-group LDS region");
+  static_assert(RF_IN + FW_N <= RF_EW, "the staged edge records start behind the step vectors and chain-step operands");
+  long long pc0 = prof_clock();
+#if DOMPC_PROFILE
+#define DOMPC_PF(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
+#else
+#define DOMPC_PF(i)
+#endif
+  (void)pc0;
   // root
   if (T.tid == 0) {
     double* Nd = Q.ND(0);
@@ -2658,6 +2672,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     }
     T.sync();
   }
+  DOMPC_PF(16)
   // initial-condition multiplier step
   for (int a = T.tid; a < NX; a += T.nt) {
     const double* Nd = Q.ND(0);
@@ -2667,6 +2682,29 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   }
   // per edge: dw, d nu, d lambda, nl_cons steps.  Everything a lane needs from the per-edge record (its rows of W, Hww,
   // its column of the stored inverse block) and from the node steps is loaded in ONE batch at the top of the edge.
+#ifndef DOMPC_HOST_EMU
+  auto stage_fw = [&](int e) {               // LDS-DMA: 64 lanes x 16 B per instruction (see stage_mo)
+    const double* ew_ = Q.ew + (int64_t)e * EW_SIZE;
+    const double* mo_ = Q.MO(e);
+#pragma unroll
+    for (int q = 0; q < EW_STAGE / 128; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ew_ + 128 * q + 2 * lane),
+                                       (__attribute__((address_space(3))) void*)(Ld + RF_EW + 128 * q), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < MOH_STAGE / 128; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mo_ + 128 * q + 2 * lane),
+                                       (__attribute__((address_space(3))) void*)(Ld + RF_MOH + 128 * q), 16, 0, 0);
+  };
+#endif
+  int fw_staged = -1;                        // edge whose records are in (on their way into) the staging area
+  double dy0 = 0.0, dnu0 = 0.0;              // this lane's entry of dy / d nu of the edge, requested one edge ahead
+  bool have_pre = false;
+  auto load_dy = [&](int e, double& dy_, double& dnu_) {
+    const int n = A.edge_parent[e];
+    const int a0 = lane < NA ? lane : 0;
+    dy_ = (a0 < NX) ? Q.ND(n)[ND_DXT + a0] : Q.dx[A.node_u_off[n] + a0 - NX];
+    dnu_ = Q.dlam[A.edge_row0[e] + NW + (lane < NX ? lane : 0)];
+  };
   for (int e = gid; e < A.n_edges; e += ng) {
     if (!mk_e(A, e)) continue;
     const int n = A.edge_parent[e], cn = A.edge_child[e];
@@ -2677,6 +2715,16 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     constexpr int RPL = (NW1 + GS_C - 1) / GS_C;          // rows (= columns of G_w^-1) per lane: 1 on the device
     constexpr int LU1 = LU_N > 0 ? LU_N : 1;
     double wrow[RPL][NA + 1], hrow[RPL][NA], rw_r[RPL], sg_r[RPL], inv_c[RPL][LU1];
+#ifndef DOMPC_HOST_EMU
+    if (MO_LDS && fw_staged != e) { stage_fw(e); fw_staged = e; }
+    if (GS > 1 && !have_pre) load_dy(e, dy0, dnu0);
+    if (MO_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define EWV(i) (MO_LDS ? (double)Ld[RF_EW + (i)] : Q.EW(e, (i)))
+#define MHV(i) (MO_LDS ? (double)Ld[RF_MOH + (i)] : Q.MO(e)[(i)])
+#else
+#define EWV(i) Q.EW(e, (i))
+#define MHV(i) Q.MO(e)[(i)]
+#endif
     if (M > 0) {
 #pragma unroll
       for (int q = 0; q < RPL; ++q) {
@@ -2684,27 +2732,43 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         const int rc = r < NW ? r : 0;
         const int pt = point_of_slot(rc / NX);
 #pragma unroll
-        for (int b = 0; b < NA; ++b) wrow[q][b] = Q.EW(e, EW_W + rc * NA + b);
-        wrow[q][NA] = Q.EW(e, EW_W0 + rc);
-        rw_r[q] = Q.EW(e, EW_RW + rc);
-        sg_r[q] = Q.EW(e, EW_SIGW + rc);
-        const double* Hp = Q.MO(e) + MO_PT + (pt >= 0 ? pt : 0) * PT_STRIDE + NX + NX * NA;
+        for (int b = 0; b < NA; ++b) wrow[q][b] = EWV(EW_W + rc * NA + b);
+        wrow[q][NA] = EWV(EW_W0 + rc);
+        rw_r[q] = EWV(EW_RW + rc);
+        sg_r[q] = EWV(EW_SIGW + rc);
+        const int hp0 = MO_PT + (pt >= 0 ? pt : 0) * PT_STRIDE + NX + NX * NA;
 #pragma unroll
-        for (int b = 0; b < NA; ++b) hrow[q][b] = Hp[symi(rc % NX, b, NA)];
+        for (int b = 0; b < NA; ++b) hrow[q][b] = MHV(hp0 + symi(rc % NX, b, NA));
         const int rl = r < LU_N ? r : 0;
 #pragma unroll
-        for (int k2 = 0; k2 < LU_N; ++k2) inv_c[q][k2] = Q.EW(e, EW_LU + k2 * LU_N + rl);   // column r of the stored block
+        for (int k2 = 0; k2 < LU_N; ++k2) inv_c[q][k2] = EWV(EW_LU + k2 * LU_N + rl);   // column r of the stored block
         if (pt < 0) {
 #pragma unroll
           for (int b = 0; b < NA; ++b) hrow[q][b] = 0.0;
         }
       }
     }
+#undef EWV
+#undef MHV
+    double dy_n = 0.0, dnu_n = 0.0;
+    bool pre_n = false;
+#ifndef DOMPC_HOST_EMU
+    if (MO_LDS) {
+      // everything of this edge is in registers: hand the staging area to the next edge of this wavefront
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int e_nx = e + ng;
+      if (e_nx < A.n_edges && mk_e(A, e_nx)) {
+        stage_fw(e_nx);
+        fw_staged = e_nx;
+        if (GS > 1) { load_dy(e_nx, dy_n, dnu_n); pre_n = true; }
+      }
+    }
+#endif
     {
-      const int a0 = lane < NA ? lane : 0;
-      const double dy0 = (a0 < NX) ? Nd[ND_DXT + a0] : Q.dx[A.node_u_off[n] + a0 - NX];
-      const double dnu0 = Q.dlam[row0 + NW + (lane < NX ? lane : 0)];
       if (GS > 1) {
+#ifdef DOMPC_HOST_EMU
+        load_dy(e, dy0, dnu0);
+#endif
         if (lane < NA) Ld[RF_DY + lane] = dy0;
         if (chain_edge && lane < NX) Ld[RF_DNU + lane] = dnu0;
       } else {
@@ -2713,6 +2777,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
           for (int a = 0; a < NX; ++a) Ld[RF_DNU + a] = Q.dlam[row0 + NW + a];
       }
     }
+    DOMPC_PF(17)
     if (!chain_edge)
       for (int a = lane; a < NX; a += GS) {
         double t = Nc[ND_PV + a];
@@ -2736,6 +2801,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         }
       }
       T.gsync();
+      DOMPC_PF(18)
       // rhs = -(rw + (Sigma_w+delta) dw + Hww dw + Hwu du + S' dnu)
 #pragma unroll
       for (int q = 0; q < RPL; ++q) {
@@ -2752,6 +2818,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         }
       }
       T.gsync();
+      DOMPC_PF(19)
       // d lambda = G_w^-T rhs
 #pragma unroll
       for (int q = 0; q < RPL; ++q) {
@@ -2784,6 +2851,8 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       }
     }
     T.gsync();
+    dy0 = dy_n; dnu0 = dnu_n; have_pre = pre_n;
+    DOMPC_PF(20)
   }
   // dummies (variables in no constraint / cost): independent scalar Newton steps
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
@@ -3621,7 +3690,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   }
 
   // ---- outputs (unscaled multipliers, CasADi sign convention)
-  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = (double)c_ftb; tr[7] = (double)c_acc; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; double* t3 = A.trace + 8 * (A.trace_cap - 3); for (int i = 0; i < 8; ++i) t3[i] = (double)T.prof[8 + i]; } }
+  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = (double)c_ftb; tr[7] = (double)c_acc; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; double* t3 = A.trace + 8 * (A.trace_cap - 3); for (int i = 0; i < 8; ++i) t3[i] = (double)T.prof[8 + i]; double* t4 = A.trace + 8 * (A.trace_cap - 4); for (int i = 0; i < 8; ++i) t4[i] = (double)T.prof[16 + i]; } }
   const double isf = 1.0 / Q.sf;
   // (sharded problem: every entry is written by exactly one rank, zeros elsewhere -> a SUM over the ranks is the full vector)
   if (A.x_out) for (int g = T.tid; g < nX; g += T.nt) A.x_out[(int64_t)b * nX + g] = sh_cnt(A, mk_x(A, g)) ? Q.x[g] : 0.0;
