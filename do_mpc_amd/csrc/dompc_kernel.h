@@ -2873,10 +2873,18 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   T.sync();                                  // (every thread has read the previous sweep's verdict, see riccati_backward)
   if (T.tid == 0) T.fset(1, 0);
   T.sync();
+  long long pc0 = prof_clock();
+#if DOMPC_PROFILE
+#define DOMPC_PS(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
+#else
+#define DOMPC_PS(i)
+#endif
+  (void)pc0;
   if (!Q.soc)
     for (int g = T.tid; g < NX; g += T.nt) Q.c[g] = Q.x[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
   eval_models(T, Q);
   T.sync();
+  DOMPC_PS(21)
   for (int rep = 0; rep < A.trace_pad; ++rep) {      // measurement aid (DOMPC_EXTRA_TRAFFIC): extra read+write passes over the model-output records
     for (int i = T.tid; i < A.n_edges * MO_SIZE; i += T.nt) { volatile double* p_ = Q.mo + i; *p_ = *p_; }
     T.sync();
@@ -2895,6 +2903,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     }
   }
   T.sync();
+  DOMPC_PS(22)
   for (int n = T.tid; n < A.n_nodes; n += T.nt) {
     if (!mk_n(A, n)) continue;
     const int ci = cut_of(A, n);
@@ -2907,6 +2916,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     Q.rd[g] = -Q.zl[g] + Q.zu[g];
   }
   T.sync();
+  DOMPC_PS(23)
   if (sh_on(A)) {
     // cut parents: sum the child-dependent parts over the ranks; the failure flag rides along
     double* fl = A.xbuf + x_asm(A) + A.n_cut * ASM_N;
