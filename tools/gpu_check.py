@@ -8,11 +8,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from do_mpc_amd.examples import CASES  # noqa: E402
+from do_mpc_amd.examples import BASELINE_CASES, CASES  # noqa: E402
 
 
 def main():
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or list(BASELINE_CASES)      # (the cases with golden vectors)
     for name in names:
         ex = CASES[name]
         t = time.time()
