@@ -2,7 +2,7 @@
 
 Namespaces mirror the reference package (`do_mpc.model.Model`, `do_mpc.controller.MPC`).
 """
-from . import controller, model, simulator, structs, sym  # noqa: F401
+from . import controller, differentiator, model, simulator, structs, sym  # noqa: F401
 from .controller import MPC, MPCSettings  # noqa: F401
 from .model import Model  # noqa: F401
 from .simulator import Simulator  # noqa: F401

@@ -11,7 +11,7 @@ With real CasADi installed do not call install(); use the ctypes stub of INTEGRA
 import sys
 import types
 
-from . import controller, model, simulator, structs, sym
+from . import controller, differentiator, model, simulator, structs, sym
 
 _CASADI_NAMES = [
     "SX", "DM", "vertcat", "horzcat", "mtimes", "sum1", "sum2", "sumsqr", "dot", "exp", "log", "sqrt", "sin",
@@ -53,7 +53,8 @@ def install(force: bool = False):
         cas.__all__ = _CASADI_NAMES + ["MX", "inf", "pi"]
         tools = types.ModuleType("casadi.tools")
         tools.entry = structs.entry
-        tools.__all__ = ["entry"]
+        tools.indexf = differentiator.indexf
+        tools.__all__ = ["entry", "indexf"]
         cas.tools = tools
         sys.modules["casadi"] = cas
         sys.modules["casadi.tools"] = tools
@@ -70,14 +71,18 @@ def install(force: bool = False):
         m_sim.Simulator = simulator.Simulator
         m_est = types.ModuleType("do_mpc.estimator")
         m_est.StateFeedback = StateFeedback
-        dm.model, dm.controller, dm.simulator, dm.estimator = m_model, m_ctrl, m_sim, m_est
+        m_diff = types.ModuleType("do_mpc.differentiator")
+        m_diff.DoMPCDifferentiator = differentiator.DoMPCDifferentiator
+        dm.model, dm.controller, dm.simulator, dm.estimator, dm.differentiator = m_model, m_ctrl, m_sim, m_est, m_diff
         dm.__version__ = "5.1.1+dompc_amd"
         sys.modules["do_mpc"] = dm
         sys.modules["do_mpc.model"] = m_model
         sys.modules["do_mpc.controller"] = m_ctrl
         sys.modules["do_mpc.simulator"] = m_sim
         sys.modules["do_mpc.estimator"] = m_est
-        installed += ["do_mpc", "do_mpc.model", "do_mpc.controller", "do_mpc.simulator", "do_mpc.estimator"]
+        sys.modules["do_mpc.differentiator"] = m_diff
+        installed += ["do_mpc", "do_mpc.model", "do_mpc.controller", "do_mpc.simulator", "do_mpc.estimator",
+                      "do_mpc.differentiator"]
     return installed
 
 

@@ -1,0 +1,34 @@
+"""do_mpc_amd.differentiator on the TEST-ONLY host emulation of the kernels (the -m gpu twin: test_gpu_differentiator.py)."""
+import numpy as np
+import pytest
+
+import differentiator_common as dc
+from test_hostemu_parity import make_mpc
+
+
+@pytest.mark.parametrize("name", ["batch_reactor", "oscillating_masses", "industrial_poly"])
+def test_linear_parameter_sensitivities_match_the_oracles_sparse_kkt_solve(name):
+    dc.check_against_oracle_kkt(make_mpc, name)
+
+
+def test_sensitivities_match_finite_differences_of_complete_resolves():
+    dc.check_against_resolves(make_mpc, "batch_reactor", [("_x0", "S_s"), ("_u_prev", "inp"), ("_p", 0, "S_in")])
+
+
+def test_reference_surface_and_refusals():
+    """`sens_num["dxdp", indexf[...], indexf[...]]` as in examples/batch_reactor_differentiator/main.py:158-168."""
+    from do_mpc_amd.differentiator import DoMPCDifferentiator, indexf
+    mpc = dc.solved(make_mpc, "batch_reactor")
+    nd = DoMPCDifferentiator(mpc)
+    nd.settings.check_LICQ = False
+    nd.settings.check_rank = False
+    nd.settings.lin_solver = "scipy"
+    dx_dp, dlam_dp = nd.differentiate()
+    du0dx0 = nd.sens_num["dxdp", indexf["_u", 0, 0], indexf["_x0"]]
+    du0dup = nd.sens_num["dxdp", indexf["_u", 0, 0], indexf["_u_prev"]].full()
+    assert du0dx0.shape == (1, 4) and du0dup.shape == (1, 1)
+    assert np.array_equal(np.asarray(nd.sens_num["dxdp"]), np.asarray(dx_dp))
+    # the rterm pulls u0 towards u_prev: 0 < du0/du_prev < 1
+    assert 0.0 < du0dup[0, 0] < 1.0
+    with pytest.raises(NotImplementedError):
+        DoMPCDifferentiator(make_mpc("CSTR"))

@@ -1,0 +1,16 @@
+"""do_mpc_amd.differentiator on the HIP path (twin of test_differentiator.py)."""
+import pytest
+
+import differentiator_common as dc
+from test_gpu_parity import make_mpc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["batch_reactor", "industrial_poly"])
+def test_linear_parameter_sensitivities_match_the_oracles_sparse_kkt_solve(name):
+    dc.check_against_oracle_kkt(make_mpc, name)
+
+
+def test_sensitivities_match_finite_differences_of_complete_resolves():
+    dc.check_against_resolves(make_mpc, "batch_reactor", [("_x0", "S_s"), ("_u_prev", "inp"), ("_p", 0, "S_in")])

@@ -121,3 +121,29 @@ def test_unedited_template_simulator_closes_the_loop_like_main_py(name, compat):
         x0 = estimator.make_step(y_next)
         assert np.max(np.abs(u0.ravel() - g["mpc._u"][k]) / np.maximum(1, np.abs(g["mpc._u"][k]))) < 2e-6
         assert np.max(np.abs(x0.ravel() - g["mpc._x"][k + 1]) / np.maximum(1, np.abs(g["mpc._x"][k + 1]))) < 2e-6
+
+
+def test_unedited_batch_reactor_differentiator_templates_and_sensitivity_query(compat):
+    """examples/batch_reactor_differentiator: its template_model / template_mpc un-edited, then the calls its main.py makes
+    (main.py:131-168: DoMPCDifferentiator(mpc), settings, differentiate(), sens_num[...] with casadi.tools.indexf)."""
+    import do_mpc
+    from casadi.tools import indexf
+    d = os.path.join(REF, "batch_reactor_differentiator")
+    tm = _load(os.path.join(d, "template_model.py"), "ref_brd_tm")
+    tc = _load(os.path.join(d, "template_mpc.py"), "ref_brd_tc")
+    with hostemu.patched():
+        model = tm.template_model()
+        mpc = tc.template_mpc(model)
+    x0 = np.array([1.0, 0.5, 0.0, 120.0]).reshape(-1, 1)
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    mpc.make_step(x0)
+    nlp_diff = do_mpc.differentiator.DoMPCDifferentiator(mpc)
+    nlp_diff.settings.check_LICQ = False
+    nlp_diff.settings.check_rank = False
+    nlp_diff.settings.lin_solver = 'scipy'
+    nlp_diff.differentiate()
+    du0dx0_num = nlp_diff.sens_num["dxdp", indexf["_u", 0, 0], indexf["_x0"]]
+    du0du_prev_num = nlp_diff.sens_num["dxdp", indexf["_u", 0, 0], indexf["_u_prev"]].full()
+    assert du0dx0_num.shape == (model.n_u, model.n_x) and du0du_prev_num.shape == (model.n_u, model.n_u)
+    assert np.all(np.isfinite(du0dx0_num))
