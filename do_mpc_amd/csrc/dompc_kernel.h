@@ -716,9 +716,20 @@ DOMPC_DEV inline int point_of_slot(int sl) {
 // the reference, evaluated block-wise.
 DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
   const KArgs& A = *Q.A;
-  constexpr int NIT = (M == 0 ? 1 : NCOLL) + 3;
-  for (int it = T.tid; it < A.n_edges * NIT; it += T.nt) {
-    const int e = it / NIT, j = it % NIT;
+  // Work items in FUNCTION-MAJOR order: all collocation points, then all stage costs, the terminal costs of the
+  // last-stage edges, the nl_cons blocks.  (Edge-major order puts every function type into every wavefront, which then
+  // runs all of them one after the other with a fraction of its lanes; terminal-cost and nl_cons items of edges that have
+  // none were idle slots.)
+  constexpr int NPT = (M == 0 ? 1 : NCOLL);
+  const int E = A.n_edges;
+  const int e_last0 = E - (A.level_node_start[A.N + 1] - A.level_node_start[A.N]);      // first edge of the last stage (edges are ordered by stage)
+  const int n_dyn = E * NPT, n_lt = E, n_mt = E - e_last0, n_nl = (NE > 0) ? E : 0;
+  for (int it = T.tid; it < n_dyn + n_lt + n_mt + n_nl; it += T.nt) {
+    int kind, e, j = 0;
+    if (it < n_dyn) { kind = 0; e = it / NPT; j = it % NPT; }
+    else if (it < n_dyn + n_lt) { kind = 1; e = it - n_dyn; }
+    else if (it < n_dyn + n_lt + n_mt) { kind = 2; e = e_last0 + (it - n_dyn - n_lt); }
+    else { kind = 3; e = it - n_dyn - n_lt - n_mt; }
     if (!mk_e(A, e)) continue;
     const int n = A.edge_parent[e], cn = A.edge_child[e], k = A.edge_level[e];
     const double* xn = Q.x + A.node_x_off[n];
@@ -728,7 +739,7 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
     const double* tvp = Q.P + A.p_off_tvp + k * NTVP;
     const int row0 = A.edge_row0[e];
     double* mo = Q.MO(e);
-    if (j < NIT - 3) {
+    if (kind == 0) {
       double* pt = mo + MO_PT + j * PT_STRIDE;
       if (M == 0) {
         dompc_dyn(xn, un, tvp, pp, Q.lam + row0 + NW, pt, pt + NX, pt + NX + NX * NA);
@@ -737,9 +748,9 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
         dompc_dyn(w + slot_of(i, jj) * NX, un, tvp, pp, Q.lam + row0 + i * (DEG + 1) * NX + (jj - 1) * NX,
                   pt, pt + NX, pt + NX + NX * NA);
       }
-    } else if (j == NIT - 3) {
+    } else if (kind == 1) {
       dompc_lterm(xn, un, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NA);
-    } else if (j == NIT - 2) {
+    } else if (kind == 2) {
       if (k == A.N - 1)
         dompc_mterm(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1,
                     mo + MO_MT + 1 + NX);
