@@ -123,7 +123,7 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
     stamp = out + ".stamp"
     lb = os.environ.get("DOMPC_LB", "2")          # tuning aid: wavefronts per SIMD the kernel is compiled for
     prof = os.environ.get("DOMPC_PROFILE", "0")    # measurement aid: sub-phase cycle counters compiled in (tools/gpu_profile.py)
-    defs = os.environ.get("DOMPC_DEFS", "").split()  # measurement aid: extra -D switches for A/B builds (own file per set)
+    defs = os.environ.get("DOMPC_DEFS", "").split()  # measurement aid: extra -D switches / compiler flags (entries starting with '-') for A/B builds (own file per set)
     if defs or prof != "0":                       # (measurement builds live next to the product build, under their own names)
         tag = ("prof" if prof != "0" else "") + (hashlib.sha256(" ".join(defs).encode()).hexdigest()[:8] if defs else "")
         out = out[:-len(".hsaco")] + "_" + tag + ".hsaco"
@@ -136,7 +136,7 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
             return out
         if not (os.path.exists(hdr) and open(hdr).read() == header_text):
             _write_atomic(hdr, header_text)
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_LB={lb}", f"-DDOMPC_PROFILE={prof}", *[f"-D{d}" for d in defs],
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_LB={lb}", f"-DDOMPC_PROFILE={prof}", *[(d if d.startswith("-") else f"-D{d}") for d in defs],
                f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC, os.path.join(CSRC, "dompc_device.hip")]
         _compile_to(cmd, out, f"lowering model {model_hash} to {ARCH}")
         _write_atomic(stamp, dig)
