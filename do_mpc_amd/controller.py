@@ -90,6 +90,10 @@ class MPCData:
     def set_meta(self, **kw):
         self.meta_data.update(kw)
 
+    def init_storage(self):
+        """Drop all stored records (do_mpc.data.Data.init_storage, /root/reference/do_mpc/data.py:123-137)."""
+        self._rows = {}
+
     def update(self, **kw):
         for k, v in kw.items():
             if hasattr(v, "master"):
@@ -221,6 +225,11 @@ class MPC:
     x0 = property(lambda self: self._x0, lambda self, v: self._set_iter("_x0", v))
     u0 = property(lambda self: self._u0, lambda self, v: self._set_iter("_u0", v))
     z0 = property(lambda self: self._z0, lambda self, v: self._set_iter("_z0", v))
+
+    def reset_history(self) -> None:
+        """All stored records are removed, t0 = 0 (/root/reference/do_mpc/optimizer.py:441-446)."""
+        self.data.init_storage()
+        self._t0 = np.array([0.0])
 
     @property
     def t0(self):

@@ -57,3 +57,20 @@ def test_device_resident_batched_closed_loop_equals_the_per_sample_loops():
             x = s1.make_step(u).ravel()
             assert pc.relerr(u.ravel(), traj_u[k][b]) < 1e-7, (b, k)
             assert pc.relerr(x, traj_x[k][b]) < 1e-8, (b, k)
+
+
+def test_open_loop_sampling_is_one_batched_solve():
+    """do_mpc_amd.sampling on the HIP path: 256 (x0, u_prev) samples of the approximate-MPC open-loop sampler in one launch."""
+    from do_mpc_amd import sampling
+    ex = CASES["batch_reactor"]
+    mpc = ex.build_mpc(ex.build_model(), max_batch=256)
+    plan = sampling.sampling_plan_box(ex.X0 * 0.9, ex.X0 * 1.1, [0.0], [0.02], n_samples=256, seed=3)
+    res = sampling.open_loop_samples(mpc, plan)
+    assert res["status"].all()
+    one = ex.build_mpc(ex.build_model())
+    for i in (0, 17, 255):
+        one.reset_history()
+        one.x0 = plan["x0"][i]
+        one.u0 = plan["u_prev"][i]
+        one.set_initial_guess()
+        assert np.allclose(one.make_step(plan["x0"][i]).ravel(), res["u0"][i], rtol=1e-9, atol=1e-12)
