@@ -3006,7 +3006,7 @@ struct Comp { double smax, smin, sum_z; };      // thread-local partials or redu
 DOMPC_DEV inline void comp_add(Comp& C, double s, double z) { C.smax = fmax(C.smax, s); C.smin = fmin(C.smin, s); C.sum_z += z; }
 DOMPC_DEV inline double comp_err(const Comp& C, double mu) { return C.smax >= C.smin ? fmax(C.smax - mu, mu - C.smin) : 0.0; }
 
-// Strided loop over [0, n) by the threads of the problem, four elements per thread and trip: LOAD(u, g) pulls the
+// Strided loop over [0, n) by the threads of the problem, DOMPC_FW elements per thread and trip: LOAD(u, g) pulls the
 // operands of element g into slot u (all loads of a trip are issued before anything is computed from them - a plain
 // grid-stride loop keeps ONE dependent load -> compute -> store chain per thread in flight and spends its time
 // waiting for HBM), BODY(u, g) consumes slot u.

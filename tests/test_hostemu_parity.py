@@ -61,6 +61,23 @@ def test_second_order_correction_can_be_switched_off():
     assert pc.relerr(u0, nlp.u0_of(r4["x"])) > 1e-2    # (the two local minima are far apart)
 
 
+def test_second_order_corrections_on_the_benchmark_problems_do_not_move_their_solutions():
+    """industrial_poly cold solves of the benchmark's x0 batch: corrections are tried on some of them (accepted and rejected
+    ones - the rejected path restores the Newton direction from its copy); same solutions as without them (one optimum)."""
+    import bench
+    X0 = bench.synthetic_x0_batch(8)
+    res = []
+    for soc in (4, 0):
+        mpc = make_mpc("industrial_poly", max_batch=8, nlpsol_opts={"ipopt.max_soc": soc})
+        r = mpc.make_step_batch(X0)
+        assert np.all(r["stats"]["success"] != 0)
+        res.append(r)
+    st4, st0 = res[0]["stats"], res[1]["stats"]
+    assert st4["n_soc"].sum() >= 1 and st0["n_soc"].sum() == 0
+    assert np.array_equal(st4["n_sweeps"], st4["iter_count"] + 1 + st4["n_soc"])      # one sweep per iteration + the first + one per correction
+    assert pc.relerr(res[0]["u0"], res[1]["u0"]) < 1e-7
+
+
 def test_baseline_config_cstr_nominal_deg3_vs_oracle():
     # BASELINE.json configs[1]: CSTR nominal NMPC, N=20, collocation deg 3 (no fixture -> oracle)
     pc.check_against_oracle_solve(make_mpc, "CSTR", n_robust=0, collocation_deg=3)
