@@ -471,6 +471,7 @@ struct Prob {
   double sf;                                         // objective scaling
   double mu;
   int soc;                                           // second-order correction solve: the constraint residual c is an INPUT of the sweep
+  int slot;                                          // workspace slot of the problem (rebuilds this view inside outlined functions)
   DOMPC_DEV double& EW(int e, int i) const { return ew[(int64_t)e * EW_SIZE + i]; }
   DOMPC_DEV double* ES(int e) const { return es + (int64_t)e * ES_SIZE; }
   DOMPC_DEV double* ND(int n) const { return nd + (int64_t)n * ND_SIZE; }
@@ -488,7 +489,7 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   p.s = w + L.s; p.zsl = w + L.zsl; p.zsu = w + L.zsu; p.sl = w + L.sl; p.su = w + L.su;
   p.ds = w + L.ds; p.st = w + L.st; p.ds_sv = w + L.ds_sv;
   p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo;
-  p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0;
+  p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0; p.slot = slot;
   return p;
 }
 
@@ -791,6 +792,241 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #endif
 }
 
+// ================================================================================================
+// Single finite element: factorisation part of an edge - columns of [G_cc | G_y r | I] in registers, dual-residual pieces,
+// register-resident Gauss-Jordan (with its pivoting fallback), W | w0 into LDS, G_cc^-1 to the forward record.
+// Its own function on the device (phase_edge_factor, noinline): the elimination is the most register- and schedule-
+// sensitive code of the kernel (adding four live values in front of it cost 15 %, removing its never-executed fallback
+// made it 7x slower when it shared a function with the assembly and condensing code); on its own it gets the whole
+// register file and a schedule that does not depend on what surrounds the call.
+// In: Ld[EL_T1] residual rows, Ld[EL_T0] multipliers of the edge's rows, the staged model-output record; this lane's
+// per-variable data (vx: its extended column, ex / nu_a: end-point column on the first NX lanes).
+constexpr int EF_R = DEG * NX, EF_NCX = 2 * EF_R + NA + 1, EF_CPX = (EF_NCX + GS_C - 1) / GS_C;
+DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane, int GS, ldsd* Ld, const double (&vx)[EF_CPX][5],
+                                      const double (&ex)[5], double nu_a) {
+  const KArgs& A = *Q.A;
+  const int woff = A.edge_w_off[e];
+  const double* nu_e = Q.lam + A.edge_row0[e] + NW;
+  const double* mo = Q.MO(e);
+  (void)mo;
+#ifndef DOMPC_HOST_EMU
+  const ldsd* mol = Ld + EL_MOS;
+#define MOV(i) (MO_LDS ? (double)mol[(i)] : mo[(i)])
+#else
+#define MOV(i) mo[(i)]
+#endif
+  const bool act = true;
+  int fail = 0;
+  (void)act;
+  constexpr int R = DEG * NX, RA = R > 0 ? R : 1;
+  constexpr int NRHS = NA + 1;
+  constexpr int NCX = 2 * R + NRHS;                      // extended columns: G_cc | G_y r | I
+  constexpr int CPX = (NCX + GS_C - 1) / GS_C;
+  constexpr double GJ_U = 0.01;
+  double bc[CPX][RA];
+  // column cx of the collocation rows (row r = (jj, a): point j = jj + 1, state a), straight from the model-output
+  // record (optimizer.py:951-963):  G_cc (slot sl, state b): [sl == jj] J_jj[a][b] - [a == b] C[sl+1][j];
+  // G_y: x_n columns -[a == yb] C[0][j], u_n columns J_jj[a][yb];  r: the residuals (staged in LDS by the lanes
+  // that computed them);  I.  One unconditional load per entry (clamped address) + selects: no divergent branches.
+  // (all global loads first, in one batch - fetch_cols(), called before anything of this edge is computed: loads
+  //  issued between dependent selects / branches are waited for one by one; the first version of this assembly
+  //  spent 40 serialized memory round trips per edge that way)
+  double jv[CPX][RA], cd[CPX][DEG > 0 ? DEG : 1];
+  auto fetch_cols = [&]() {
+#pragma unroll
+    for (int q = 0; q < CPX; ++q) {
+      const unsigned cx = (unsigned)lane + (unsigned)q * (unsigned)GS;
+      const bool isG = cx < (unsigned)R, isY = cx >= (unsigned)R && cx < (unsigned)(R + NA);
+      const unsigned jcol = isG ? cx % (unsigned)NX : (isY ? cx - (unsigned)R : 0u);   // column of the point Jacobian this lane reads
+      const unsigned sl1 = isG ? cx / (unsigned)NX + 1u : 0u;
+#pragma unroll
+      for (int r = 0; r < R; ++r) jv[q][r] = MOV((unsigned)(MO_PT + (r / NX) * PT_STRIDE + NX + (r % NX) * NA) + jcol);
+#pragma unroll
+      for (int jj = 0; jj < DEG; ++jj) cd[q][jj] = DOMPC_C[sl1 * (unsigned)(DEG + 1) + (unsigned)(jj + 1)];
+    }
+  };
+  auto build_cols = [&]() {
+#pragma unroll
+    for (int q = 0; q < CPX; ++q) {
+      const int cx = lane + q * GS;
+      const bool isG = cx < R, isY = cx >= R && cx < R + NA, isR = cx == R + NA;
+      const int sl = isG ? cx / NX : -1, b = isG ? cx % NX : -1, yb = isY ? cx - R : -1;
+      const int unit_row = cx - (R + NRHS);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int jj = r / NX, a = r % NX;
+        const bool useJ = isG ? (sl == jj) : (isY && yb >= NX);
+        double v = useJ ? jv[q][r] : 0.0;
+        v -= (a == b) ? cd[q][jj] : 0.0;
+        v -= (a == yb) ? DOMPC_C[0 * (DEG + 1) + (jj + 1)] : 0.0;
+        v = (unit_row == r) ? 1.0 : v;
+        bc[q][r] = v;
+      }
+      if (isR) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) bc[q][r] = Ld[EL_T1 + r];
+      }
+    }
+  };
+  auto eliminate = [&](bool pivoting) -> int {           // returns 1: threshold test failed / singular block
+    int badl = 0;
+#pragma unroll
+    for (int kk = 0; kk < R; ++kk) {
+      const int qk = kk / GS_C, lk = kk % GS_C;          // column kk lives in slot qk of lane lk
+      if (pivoting) {
+        int pr = kk;
+        double best = fabs(bc[qk][kk]);
+#pragma unroll
+        for (int r = kk + 1; r < R; ++r) {
+          const double a = fabs(bc[qk][r]);
+          if (a > best) { best = a; pr = r; }
+        }
+        if (lane == lk && !(best > 1e-300)) badl = 1;
+#ifndef DOMPC_HOST_EMU
+        pr = __builtin_amdgcn_readlane(pr, lk);
+#endif
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) {                  // rows kk <-> pr (the appended identity is permuted along)
+          const double t = bc[q][kk];
+          double nk = t;
+#pragma unroll
+          for (int r = kk + 1; r < R; ++r) {
+            const bool hit = (r == pr);
+            nk = hit ? bc[q][r] : nk;
+            bc[q][r] = hit ? t : bc[q][r];
+          }
+          bc[q][kk] = nk;
+        }
+      } else {
+        double m = 0.0;
+#pragma unroll
+        for (int r = kk + 1; r < R; ++r) m = fmax(m, fabs(bc[qk][r]));
+        const double akk = fabs(bc[qk][kk]);
+        if (lane == lk && !(akk >= GJ_U * m && akk > 1e-300)) badl = 1;
+      }
+      double f[RA];
+#pragma unroll
+      for (int r = 0; r < R; ++r) f[r] = lane_bcast(bc[qk][r], lk);
+      const double pinv = fast_rcp((fabs(f[kk]) > 1e-300) ? f[kk] : 1.0);
+#pragma unroll
+      for (int q = 0; q < CPX; ++q) {
+        const double prow = bc[q][kk] * pinv;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (r != kk) bc[q][r] = fma(-f[r], prow, bc[q][r]);
+        bc[q][kk] = prow;
+      }
+    }
+#ifndef DOMPC_HOST_EMU
+    return __ballot(badl) != 0ull;
+#else
+    return badl;
+#endif
+  };
+  fetch_cols();
+  if (act) {
+    build_cols();
+    // dual-residual pieces: column c of G_w / G_y times the multipliers of the edge's rows (continuity rows:
+    // -D_{sl+1} on the diagonal of the G_cc columns, -D_0 for the x_n columns, +1 for the end-point columns)
+#pragma unroll
+    for (int q = 0; q < CPX; ++q) {
+      const int cx = lane + q * GS;
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) t += bc[q][r] * Ld[EL_T0 + r];
+      if (cx < R) {
+        t -= DOMPC_D[cx / NX + 1] * Ld[EL_T0 + R + cx % NX];   // (measured: neither a select chain nor a load of the coefficient in the first batch of the edge pays - both slow the elimination that follows by more than the round trip they save)
+        const int gi = woff + cx;
+        const double xv = vx[q][0], l = vx[q][1], u = vx[q][2], zl_ = vx[q][3], zu_ = vx[q][4];
+        Q.gf[gi] = 0.0;
+        Q.rd[gi] = t - zl_ + zu_;
+        Ld[EL_RW + cx] = t + bar_grad(xv, l, u, mu);
+        Ld[EL_SG + cx] = sigma_of(xv, l, u, zl_, zu_);
+      } else if (cx < R + NA) {
+        const int yb = cx - R;
+        if (yb < NX) t -= DOMPC_D[0] * Ld[EL_T0 + R + yb];
+        Ld[EL_RY + yb] = t;          // completed in phase 7
+      }
+    }
+    for (int a = lane; a < NX; a += GS) {               // end-point (xkf) columns
+      const int col = R + a, gi = woff + col;
+      const double t = Ld[EL_T0 + R + a] + (GS > 1 ? nu_a : nu_e[a]);
+      double xv, l, u, zl_, zu_;
+      if (GS > 1) { xv = ex[0]; l = ex[1]; u = ex[2]; zl_ = ex[3]; zu_ = ex[4]; }
+      else { xv = Q.x[gi]; l = Q.lb[gi]; u = Q.ub[gi]; zl_ = Q.zl[gi]; zu_ = Q.zu[gi]; }
+      Q.gf[gi] = 0.0;
+      Q.rd[gi] = t - zl_ + zu_;
+      Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu);
+      Ld[EL_SG + col] = sigma_of(xv, l, u, zl_, zu_);
+    }
+  }
+  if (act) {
+    if (eliminate(false)) {
+      fetch_cols();
+      build_cols();
+      if (eliminate(true)) fail = 1;
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int q = 0; q < CPX; ++q) {
+      const int cx = lane + q * GS;
+      if (cx >= R && cx < R + NRHS) {
+        // right-hand sides: W = -G_w^-1 G_y, w0 = -G_w^-1 r_g; continuity row a = assembled entry + sum_r D_r row((r-1)NX+a)
+        const int col = MX_W + (cx - R);
+#pragma unroll
+        for (int a_ = 0; a_ < NX; ++a_) {
+          const int yb = cx - R;                       // assembled entry of the continuity row: -D_0 / the residual
+          double t = (yb == NA) ? Ld[EL_T1 + R + a_] : ((yb == a_) ? -DOMPC_D[0] : 0.0);
+#pragma unroll
+          for (int r = 1; r <= DEG; ++r) t += DOMPC_D[r] * bc[q][(r - 1) * NX + a_];
+          Ld[EL_MX + (R + a_) * MX_LD + col] = -t;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) Ld[EL_MX + r * MX_LD + col] = -bc[q][r];
+      } else if (cx >= R + NRHS && cx < NCX) {
+        const int col = cx - (R + NRHS);                 // column `col` of G_cc^-1 (kept for the multiplier recovery)
+#pragma unroll
+        for (int r = 0; r < R; ++r) Q.EW(e, EW_LU + r * LU_N + col) = bc[q][r];
+      }
+    }
+  }
+#undef MOV
+  return fail;
+}
+
+#ifndef DOMPC_HOST_EMU
+__device__ inline KArgs kernel_args(const void* kp);
+__device__ __attribute__((noinline)) int phase_edge_factor(const void* kp, int slot, int e, int soc, double sf, double mu,
+                                                           double v0, double v1, double v2, double v3, double v4,
+                                                           double x0, double x1, double x2, double x3, double x4, double nu_a) {
+  const KArgs A = kernel_args(kp);
+  Prob Q = make_prob(A, __builtin_amdgcn_readfirstlane(slot), nullptr);
+  Q.sf = ufl(sf);
+  Q.soc = __builtin_amdgcn_readfirstlane(soc);
+  const int lane = (int)(threadIdx.x & 63u);
+  ldsd* Ld = (ldsd*)lds_pool + (int64_t)(threadIdx.x >> 6) * EL_SIZE;
+  const double vx[EF_CPX][5] = {{v0, v1, v2, v3, v4}};
+  const double ex[5] = {x0, x1, x2, x3, x4};
+  return edge_factor_body(Q, __builtin_amdgcn_readfirstlane(e), ufl(mu), lane, 64, Ld, vx, ex, nu_a);
+}
+#endif
+DOMPC_DEV inline int run_edge_factor(const Thr& T, const Prob& Q, int e, double mu, int lane, int GS, ldsd* Ld,
+                                     const double (&vx)[EF_CPX][5], const double (&ex)[5], double nu_a) {
+#ifndef DOMPC_HOST_EMU
+  if constexpr (EF_CPX == 1) {
+    (void)lane; (void)GS; (void)Ld;
+    return phase_edge_factor(T.kp, Q.slot, e, Q.soc, Q.sf, mu, vx[0][0], vx[0][1], vx[0][2], vx[0][3], vx[0][4],
+                             ex[0], ex[1], ex[2], ex[3], ex[4], nu_a);
+  } else {
+    return edge_factor_body(Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
+  }
+#else
+  (void)T;
+  return edge_factor_body(Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
+#endif
+}
+
 #ifndef DOMPC_HOST_EMU
 // request the copy of the model-output record of edge e into the wavefront's staging area (LDS-DMA: global_load_lds_dwordx4,
 // 64 lanes x 16 B per instruction, no staging registers; completion is awaited with s_waitcnt vmcnt).  The last piece may run
@@ -909,111 +1145,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       // pivoting and explicit row interchanges (rare; measured: never on the BASELINE workloads).
       // (The LDS variant - column per lane re-read and re-written every step, packed pivot keys - spent two thirds of
       // its ~600 instructions per pair of steps on the redundant pivot search; this one issues ~85 per step.)
-      constexpr int R = DEG * NX, RA = R > 0 ? R : 1;
-      constexpr int NRHS = NA + 1;
-      constexpr int NCX = 2 * R + NRHS;                      // extended columns: G_cc | G_y r | I
-      constexpr int CPX = (NCX + GS_C - 1) / GS_C;
-      constexpr double GJ_U = 0.01;
-      double bc[CPX][RA];
-      // column cx of the collocation rows (row r = (jj, a): point j = jj + 1, state a), straight from the model-output
-      // record (optimizer.py:951-963):  G_cc (slot sl, state b): [sl == jj] J_jj[a][b] - [a == b] C[sl+1][j];
-      // G_y: x_n columns -[a == yb] C[0][j], u_n columns J_jj[a][yb];  r: the residuals (staged in LDS by the lanes
-      // that computed them);  I.  One unconditional load per entry (clamped address) + selects: no divergent branches.
-      // (all global loads first, in one batch - fetch_cols(), called before anything of this edge is computed: loads
-      //  issued between dependent selects / branches are waited for one by one; the first version of this assembly
-      //  spent 40 serialized memory round trips per edge that way)
-      double jv[CPX][RA], cd[CPX][DEG > 0 ? DEG : 1];
-      auto fetch_cols = [&]() {
-#pragma unroll
-        for (int q = 0; q < CPX; ++q) {
-          const unsigned cx = (unsigned)lane + (unsigned)q * (unsigned)GS;
-          const bool isG = cx < (unsigned)R, isY = cx >= (unsigned)R && cx < (unsigned)(R + NA);
-          const unsigned jcol = isG ? cx % (unsigned)NX : (isY ? cx - (unsigned)R : 0u);   // column of the point Jacobian this lane reads
-          const unsigned sl1 = isG ? cx / (unsigned)NX + 1u : 0u;
-#pragma unroll
-          for (int r = 0; r < R; ++r) jv[q][r] = MOV((unsigned)(MO_PT + (r / NX) * PT_STRIDE + NX + (r % NX) * NA) + jcol);
-#pragma unroll
-          for (int jj = 0; jj < DEG; ++jj) cd[q][jj] = DOMPC_C[sl1 * (unsigned)(DEG + 1) + (unsigned)(jj + 1)];
-        }
-      };
-      auto build_cols = [&]() {
-#pragma unroll
-        for (int q = 0; q < CPX; ++q) {
-          const int cx = lane + q * GS;
-          const bool isG = cx < R, isY = cx >= R && cx < R + NA, isR = cx == R + NA;
-          const int sl = isG ? cx / NX : -1, b = isG ? cx % NX : -1, yb = isY ? cx - R : -1;
-          const int unit_row = cx - (R + NRHS);
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int jj = r / NX, a = r % NX;
-            const bool useJ = isG ? (sl == jj) : (isY && yb >= NX);
-            double v = useJ ? jv[q][r] : 0.0;
-            v -= (a == b) ? cd[q][jj] : 0.0;
-            v -= (a == yb) ? DOMPC_C[0 * (DEG + 1) + (jj + 1)] : 0.0;
-            v = (unit_row == r) ? 1.0 : v;
-            bc[q][r] = v;
-          }
-          if (isR) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) bc[q][r] = Ld[EL_T1 + r];
-          }
-        }
-      };
-      auto eliminate = [&](bool pivoting) -> int {           // returns 1: threshold test failed / singular block
-        int badl = 0;
-#pragma unroll
-        for (int kk = 0; kk < R; ++kk) {
-          const int qk = kk / GS_C, lk = kk % GS_C;          // column kk lives in slot qk of lane lk
-          if (pivoting) {
-            int pr = kk;
-            double best = fabs(bc[qk][kk]);
-#pragma unroll
-            for (int r = kk + 1; r < R; ++r) {
-              const double a = fabs(bc[qk][r]);
-              if (a > best) { best = a; pr = r; }
-            }
-            if (lane == lk && !(best > 1e-300)) badl = 1;
-#ifndef DOMPC_HOST_EMU
-            pr = __builtin_amdgcn_readlane(pr, lk);
-#endif
-#pragma unroll
-            for (int q = 0; q < CPX; ++q) {                  // rows kk <-> pr (the appended identity is permuted along)
-              const double t = bc[q][kk];
-              double nk = t;
-#pragma unroll
-              for (int r = kk + 1; r < R; ++r) {
-                const bool hit = (r == pr);
-                nk = hit ? bc[q][r] : nk;
-                bc[q][r] = hit ? t : bc[q][r];
-              }
-              bc[q][kk] = nk;
-            }
-          } else {
-            double m = 0.0;
-#pragma unroll
-            for (int r = kk + 1; r < R; ++r) m = fmax(m, fabs(bc[qk][r]));
-            const double akk = fabs(bc[qk][kk]);
-            if (lane == lk && !(akk >= GJ_U * m && akk > 1e-300)) badl = 1;
-          }
-          double f[RA];
-#pragma unroll
-          for (int r = 0; r < R; ++r) f[r] = lane_bcast(bc[qk][r], lk);
-          const double pinv = fast_rcp((fabs(f[kk]) > 1e-300) ? f[kk] : 1.0);
-#pragma unroll
-          for (int q = 0; q < CPX; ++q) {
-            const double prow = bc[q][kk] * pinv;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-              if (r != kk) bc[q][r] = fma(-f[r], prow, bc[q][r]);
-            bc[q][kk] = prow;
-          }
-        }
-#ifndef DOMPC_HOST_EMU
-        return __ballot(badl) != 0ull;
-#else
-        return badl;
-#endif
-      };
+      constexpr int R = DEG * NX;
+      constexpr int CPX = EF_CPX;
       // Operands of the residual rows that live outside the model-output record (iterate, multipliers; second-order
       // correction: the corrected residual), requested in one batch with the per-variable data below.  A load issued
       // between stores, or one load -> LDS store pair per loop trip, costs a full memory round trip each (stores count in
@@ -1060,7 +1193,6 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
 #ifndef DOMPC_HOST_EMU
         if (MO_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staged record (and everything above) has landed
 #endif
-        fetch_cols();
       }
       DOMPC_PH(4)
       // residual rows (collocation, continuity, end point): computed by one lane each, written to g and staged in LDS
@@ -1102,75 +1234,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
       DOMPC_PH(5)
       T.gsync();
-      if (act) {
-        build_cols();
-        DOMPC_PH(6)
-        // dual-residual pieces: column c of G_w / G_y times the multipliers of the edge's rows (continuity rows:
-        // -D_{sl+1} on the diagonal of the G_cc columns, -D_0 for the x_n columns, +1 for the end-point columns)
-#pragma unroll
-        for (int q = 0; q < CPX; ++q) {
-          const int cx = lane + q * GS;
-          double t = 0.0;
-#pragma unroll
-          for (int r = 0; r < R; ++r) t += bc[q][r] * Ld[EL_T0 + r];
-          if (cx < R) {
-            t -= DOMPC_D[cx / NX + 1] * Ld[EL_T0 + R + cx % NX];   // (measured: neither a select chain nor a load of the coefficient in the first batch of the edge pays - both slow the elimination that follows by more than the round trip they save)
-            const int gi = woff + cx;
-            const double xv = vx[q][0], l = vx[q][1], u = vx[q][2], zl_ = vx[q][3], zu_ = vx[q][4];
-            Q.gf[gi] = 0.0;
-            Q.rd[gi] = t - zl_ + zu_;
-            Ld[EL_RW + cx] = t + bar_grad(xv, l, u, mu);
-            Ld[EL_SG + cx] = sigma_of(xv, l, u, zl_, zu_);
-          } else if (cx < R + NA) {
-            const int yb = cx - R;
-            if (yb < NX) t -= DOMPC_D[0] * Ld[EL_T0 + R + yb];
-            Ld[EL_RY + yb] = t;          // completed in phase 7
-          }
-        }
-        for (int a = lane; a < NX; a += GS) {               // end-point (xkf) columns
-          const int col = R + a, gi = woff + col;
-          const double t = Ld[EL_T0 + R + a] + (GS > 1 ? nu_a : nu_e[a]);
-          double xv, l, u, zl_, zu_;
-          if (GS > 1) { xv = ex[0]; l = ex[1]; u = ex[2]; zl_ = ex[3]; zu_ = ex[4]; }
-          else { xv = Q.x[gi]; l = Q.lb[gi]; u = Q.ub[gi]; zl_ = Q.zl[gi]; zu_ = Q.zu[gi]; }
-          Q.gf[gi] = 0.0;
-          Q.rd[gi] = t - zl_ + zu_;
-          Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu);
-          Ld[EL_SG + col] = sigma_of(xv, l, u, zl_, zu_);
-        }
-      }
-      DOMPC_PH(1)
-      if (act) {
-        if (eliminate(false)) {
-          fetch_cols();
-          build_cols();
-          if (eliminate(true)) fail = 1;
-        }
-      }
-      if (act) {
-#pragma unroll
-        for (int q = 0; q < CPX; ++q) {
-          const int cx = lane + q * GS;
-          if (cx >= R && cx < R + NRHS) {
-            // right-hand sides: W = -G_w^-1 G_y, w0 = -G_w^-1 r_g; continuity row a = assembled entry + sum_r D_r row((r-1)NX+a)
-            const int col = MX_W + (cx - R);
-#pragma unroll
-            for (int a_ = 0; a_ < NX; ++a_) {
-              const int yb = cx - R;                       // assembled entry of the continuity row: -D_0 / the residual
-              double t = (yb == NA) ? Ld[EL_T1 + R + a_] : ((yb == a_) ? -DOMPC_D[0] : 0.0);
-#pragma unroll
-              for (int r = 1; r <= DEG; ++r) t += DOMPC_D[r] * bc[q][(r - 1) * NX + a_];
-              Ld[EL_MX + (R + a_) * MX_LD + col] = -t;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) Ld[EL_MX + r * MX_LD + col] = -bc[q][r];
-          } else if (cx >= R + NRHS && cx < NCX) {
-            const int col = cx - (R + NRHS);                 // column `col` of G_cc^-1 (kept for the multiplier recovery)
-#pragma unroll
-            for (int r = 0; r < R; ++r) Q.EW(e, EW_LU + r * LU_N + col) = bc[q][r];
-          }
-        }
-      }
+      DOMPC_PH(6)
+      if (act) fail |= run_edge_factor(T, Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
       T.gsync();
     } else {
     // ---- phase 2: assemble Mx = [G_w | G_y | r_g] and the residual rows; the point Hessians needed by the
