@@ -117,6 +117,9 @@ def model_dir(model_hash: str) -> str:
 def model_code_object(header_text: str, model_hash: str, force: bool = False, opt: str = "-O3", shard: bool = False) -> str:
     """Per-model gfx950 code object (hsaco) from the generated header + the kernel sources.
     shard=True: the variant with tree-sharding support (ownership masks, cross-rank exchanges)."""
+    forced = os.environ.get("DOMPC_CODE_OBJECT")     # measurement aid: use this code object as it is (A/B against an older kernel)
+    if forced and not shard:
+        return forced
     d = model_dir(model_hash)
     hdr = os.path.join(d, "model_gen.h")
     out = os.path.join(d, f"dompc_{ARCH}{'_shard' if shard else ''}.hsaco")

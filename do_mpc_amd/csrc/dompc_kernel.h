@@ -701,7 +701,10 @@ constexpr int MO_STAGE = MO_LDS ? ((MO_SIZE + 127) / 128) * 128 : 0;
 constexpr int RF_EW = ((RF_NEED + 1) / 2) * 2;
 constexpr int EW_STAGE = MO_LDS ? ((EW_SIZE + 127) / 128) * 128 : 0;
 constexpr int RF_MOH = RF_EW + EW_STAGE;
-constexpr int MOH_STAGE = MO_LDS ? ((MO_LT + 127) / 128) * 128 : 0;
+// (only the packed point Hessians are needed: one 16-byte aligned window of MOH_PW doubles per collocation point)
+constexpr int MOH_H0 = NX + NX * NA;                                    // offset of the packed Hessian inside a point record
+constexpr int MOH_PW = ((NA_T + 1 + 127) / 128) * 128;                  // window per point (start rounded down to an even index)
+constexpr int MOH_STAGE = MO_LDS ? NCOLL * MOH_PW : 0;
 constexpr int EL_SIZE = ((el_max(el_max(EL_MOS + MO_STAGE, RB_NEED), el_max(RF_MOH + MOH_STAGE, R16_NEED)) + 7) / 8) * 8;
 
 DOMPC_DEV inline int point_of_slot(int sl) {
@@ -2767,9 +2770,12 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ew_ + 128 * q + 2 * lane),
                                        (__attribute__((address_space(3))) void*)(Ld + RF_EW + 128 * q), 16, 0, 0);
 #pragma unroll
-    for (int q = 0; q < MOH_STAGE / 128; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mo_ + 128 * q + 2 * lane),
-                                       (__attribute__((address_space(3))) void*)(Ld + RF_MOH + 128 * q), 16, 0, 0);
+    for (int pq = 0; pq < NCOLL * (MOH_PW / 128); ++pq) {
+      const int pt = pq / (MOH_PW / 128), q = pq % (MOH_PW / 128);
+      const int src0 = ((MO_PT + pt * PT_STRIDE + MOH_H0) & ~1) + 128 * q;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mo_ + src0 + 2 * lane),
+                                       (__attribute__((address_space(3))) void*)(Ld + RF_MOH + pt * MOH_PW + 128 * q), 16, 0, 0);
+    }
   };
 #endif
   int fw_staged = -1;                        // edge whose records are in (on their way into) the staging area
@@ -2796,10 +2802,11 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     if (GS > 1 && !have_pre) load_dy(e, dy0, dnu0);
     if (MO_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #define EWV(i) (MO_LDS ? (double)Ld[RF_EW + (i)] : Q.EW(e, (i)))
-#define MHV(i) (MO_LDS ? (double)Ld[RF_MOH + (i)] : Q.MO(e)[(i)])
+#define MHV(pt_, k_) (MO_LDS ? (double)Ld[RF_MOH + (pt_) * MOH_PW + ((MO_PT + (pt_) * PT_STRIDE + MOH_H0) & 1) + (k_)] \
+                             : Q.MO(e)[MO_PT + (pt_) * PT_STRIDE + MOH_H0 + (k_)])
 #else
 #define EWV(i) Q.EW(e, (i))
-#define MHV(i) Q.MO(e)[(i)]
+#define MHV(pt_, k_) Q.MO(e)[MO_PT + (pt_) * PT_STRIDE + MOH_H0 + (k_)]
 #endif
     if (M > 0) {
 #pragma unroll
@@ -2812,9 +2819,9 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         wrow[q][NA] = EWV(EW_W0 + rc);
         rw_r[q] = EWV(EW_RW + rc);
         sg_r[q] = EWV(EW_SIGW + rc);
-        const int hp0 = MO_PT + (pt >= 0 ? pt : 0) * PT_STRIDE + NX + NX * NA;
+        const int ptc = pt >= 0 ? pt : 0;
 #pragma unroll
-        for (int b = 0; b < NA; ++b) hrow[q][b] = MHV(hp0 + symi(rc % NX, b, NA));
+        for (int b = 0; b < NA; ++b) hrow[q][b] = MHV(ptc, symi(rc % NX, b, NA));
         const int rl = r < LU_N ? r : 0;
 #pragma unroll
         for (int k2 = 0; k2 < LU_N; ++k2) inv_c[q][k2] = EWV(EW_LU + k2 * LU_N + rl);   // column r of the stored block
