@@ -834,7 +834,8 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
   // (all global loads first, in one batch - fetch_cols(), called before anything of this edge is computed: loads
   //  issued between dependent selects / branches are waited for one by one; the first version of this assembly
   //  spent 40 serialized memory round trips per edge that way)
-  double jv[CPX][RA], cd[CPX][DEG > 0 ? DEG : 1];
+  double cd[CPX][DEG > 0 ? DEG : 1];
+  unsigned jcol_[CPX];
   auto fetch_cols = [&]() {
 #pragma unroll
     for (int q = 0; q < CPX; ++q) {
@@ -842,10 +843,26 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
       const bool isG = cx < (unsigned)R, isY = cx >= (unsigned)R && cx < (unsigned)(R + NA);
       const unsigned jcol = isG ? cx % (unsigned)NX : (isY ? cx - (unsigned)R : 0u);   // column of the point Jacobian this lane reads
       const unsigned sl1 = isG ? cx / (unsigned)NX + 1u : 0u;
+      jcol_[q] = jcol;
+#if !defined(DOMPC_HOST_EMU)
+      // the diagonal collocation coefficient of this column by selects over opaque values: an indexed read of the constant
+      // table would be the only global load of this function - a full memory round trip in front of the elimination
 #pragma unroll
-      for (int r = 0; r < R; ++r) jv[q][r] = MOV((unsigned)(MO_PT + (r / NX) * PT_STRIDE + NX + (r % NX) * NA) + jcol);
+      for (int jj = 0; jj < DEG; ++jj) {
+        double v = DOMPC_C[jj + 1];
+        asm("" : "+v"(v));
+#pragma unroll
+        for (int s1 = 1; s1 <= DEG; ++s1) {
+          double t = DOMPC_C[s1 * (DEG + 1) + jj + 1];
+          asm("" : "+v"(t));
+          v = (sl1 == (unsigned)s1) ? t : v;
+        }
+        cd[q][jj] = v;
+      }
+#else
 #pragma unroll
       for (int jj = 0; jj < DEG; ++jj) cd[q][jj] = DOMPC_C[sl1 * (unsigned)(DEG + 1) + (unsigned)(jj + 1)];
+#endif
     }
   };
   auto build_cols = [&]() {
@@ -859,7 +876,8 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
       for (int r = 0; r < R; ++r) {
         const int jj = r / NX, a = r % NX;
         const bool useJ = isG ? (sl == jj) : (isY && yb >= NX);
-        double v = useJ ? jv[q][r] : 0.0;
+        const double jv_ = MOV((unsigned)(MO_PT + (r / NX) * PT_STRIDE + NX + (r % NX) * NA) + jcol_[q]);   // (entry of the point Jacobian, read where it is used: no second 20-entry array alive next to the column)
+        double v = useJ ? jv_ : 0.0;
         v -= (a == b) ? cd[q][jj] : 0.0;
         v -= (a == yb) ? DOMPC_C[0 * (DEG + 1) + (jj + 1)] : 0.0;
         v = (unit_row == r) ? 1.0 : v;
