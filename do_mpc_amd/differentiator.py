@@ -112,7 +112,9 @@ class DoMPCDifferentiator:
         mu = float(st["mu"]) / float(st.get("obj_scaling", 1.0))
         lb, ub = mpc._lb_opt_x.master.copy(), mpc._ub_opt_x.master.copy()
         hl, hu = np.isfinite(lb), np.isfinite(ub)
-        relax, cvt = 1e-8, 1e-4                                    # bound_relax_factor, constr_viol_tol (IPOPT defaults)
+        opts = getattr(mpc.S, "options", None)                       # the relaxation the solver applied to the bounds
+        relax = float(getattr(opts, "bound_relax_factor", 1e-8))
+        cvt = float(getattr(opts, "constr_viol_tol", 1e-4))
         lb[hl] -= np.minimum(cvt, relax * np.maximum(1.0, np.abs(lb[hl])))
         ub[hu] += np.minimum(cvt, relax * np.maximum(1.0, np.abs(ub[hu])))
         dl, du = np.where(hl, x - lb, 1.0), np.where(hu, ub - x, 1.0)
