@@ -54,3 +54,29 @@ def to_dataframe(samples: Dict[str, np.ndarray]):
     import pandas as pd
     n = len(samples["status"])
     return pd.DataFrame({k: ([v[i] for i in range(n)] if np.ndim(v) > 1 else v) for k, v in samples.items()})
+
+
+def closed_loop_samples(mpc, simulator, plan: Dict[str, np.ndarray], trajectory_length: int, device: int = 0) -> Dict[str, np.ndarray]:
+    """Closed-loop sampling of the approximate-MPC module (_ampc_sampler.py:384-470: per sample `trajectory_length` steps of
+    mpc.make_step -> simulator.make_step -> state feedback from (x0, u_prev), stopped at the first failed solve) for the whole
+    plan at once: controller and plant advance all samples together on the GPU (`BatchClosedLoop`).  Returns per sample the
+    state trajectory x[T+1], the applied inputs u[T], the previous inputs u_prev[T] (the regression features of the
+    reference: `u_prev_total`), the per-step solver success and `n_valid` = number of steps before the first failure."""
+    from .closed_loop import BatchClosedLoop
+    X0 = np.asarray(plan["x0"], float)
+    UP = np.asarray(plan["u_prev"], float)
+    n, T = X0.shape[0], int(trajectory_length)
+    loop = BatchClosedLoop(mpc, simulator, X0, device=device, U_prev0=UP)
+    x = np.zeros((n, T + 1, X0.shape[1]))
+    u = np.zeros((n, T, UP.shape[1]))
+    up = np.zeros((n, T, UP.shape[1]))
+    ok = np.zeros((n, T), bool)
+    x[:, 0], cur_up = X0, UP.copy()
+    for k in range(T):
+        r = loop.step()
+        up[:, k] = cur_up
+        u[:, k], x[:, k + 1] = r["u0"], r["x"]
+        ok[:, k] = (r["stats"]["success"] != 0) & (r["plant_status"] == 0)
+        cur_up = r["u0"]
+    n_valid = np.where(ok.all(axis=1), T, np.argmin(ok, axis=1))
+    return {"id": np.asarray(plan.get("id", np.arange(n))), "x": x, "u": u, "u_prev": up, "success": ok, "n_valid": n_valid}

@@ -74,3 +74,30 @@ def test_open_loop_sampling_is_one_batched_solve():
         one.u0 = plan["u_prev"][i]
         one.set_initial_guess()
         assert np.allclose(one.make_step(plan["x0"][i]).ravel(), res["u0"][i], rtol=1e-9, atol=1e-12)
+
+
+def test_closed_loop_sampling_equals_per_sample_loops():
+    """do_mpc_amd.sampling.closed_loop_samples: 6 (x0, u_prev) samples x 3 closed-loop steps in batched launches against the
+    per-sample loop of the reference's sampler (mpc.make_step -> simulator.make_step -> state feedback)."""
+    from do_mpc_amd import sampling
+    ex = CASES["batch_reactor"]
+    model = ex.build_model()
+    mpc = ex.build_mpc(model, max_batch=6)
+    sim = sc.make_simulator("batch_reactor", hostemu=False, model=model)
+    plan = sampling.sampling_plan_box(ex.X0 * 0.95, ex.X0 * 1.05, [0.0], [0.02], n_samples=6, seed=5)
+    res = sampling.closed_loop_samples(mpc, sim, plan, trajectory_length=3)
+    assert res["success"].all() and (res["n_valid"] == 3).all()
+    one = ex.build_mpc(model)
+    sim1 = sc.make_simulator("batch_reactor", hostemu=False, model=model)
+    for i in (0, 5):
+        x0 = plan["x0"][i].copy()
+        one.reset_history()
+        one.x0 = x0
+        one.u0 = plan["u_prev"][i]
+        one.set_initial_guess()
+        sim1.x0 = x0
+        for k in range(3):
+            u0 = one.make_step(x0)
+            assert np.allclose(u0.ravel(), res["u"][i, k], rtol=1e-7, atol=1e-10)
+            x0 = np.asarray(sim1.make_step(u0)).ravel()
+            assert np.allclose(x0, res["x"][i, k + 1], rtol=1e-7, atol=1e-10)
