@@ -675,7 +675,10 @@ constexpr int EL_HP = EL_QT;                                           // staged
 constexpr int EL_NHP = (NI * DEG > 2 ? NI * DEG : 2);
 constexpr int EL_PV = EL_QT + EL_NHP * NA * NA;                        // pivot rows (NW)
 constexpr int EL_RY = EL_PV + NW;                                      // G_y' lambda (NA), completed in phase 7
-constexpr bool R16_ENABLED = (NYT <= 16) && (NE == 0) && (NS == 0) && (DOMPC_SHARD == 0);   // dompc_riccati16.h (device)
+#ifndef DOMPC_R16_NL
+#define DOMPC_R16_NL 1                 // matrix-core Riccati pass also for models with nl_cons rows / slack variables
+#endif
+constexpr bool R16_ENABLED = (NYT <= 16) && (NV <= 4) && (DOMPC_R16_NL ? (NE <= 4) : (NE == 0 && NS == 0)) && (DOMPC_SHARD == 0);   // dompc_riccati16.h (device)
 #ifndef DOMPC_HOST_EMU
 constexpr bool RB_IN_LDS = !R16_ENABLED;
 #else

@@ -11,14 +11,15 @@
 // movement (P_c is symmetric, F' P_c F = tmul(F, tmul(P_c, F)), L' Q L = tmul(L, tmul(Q, L)), ...).
 // Vectors travel as column 0 of a second tile through the same products.
 // This replaces the generic LDS-staged riccati_node() (dompc_kernel.h; still used by the host emulation, by models
-// with more than 16 node variables or nl_cons rows, and by the tree-sharding build) - the algebra is the same:
+// with more than 16 node variables, more than 4 decision variables per node or more than 4 nl_cons rows, and by the
+// tree-sharding build) - the algebra is the same:
 //     Q_tot = Q_own + sum_c F_c' P_c F_c ,  K = -Q_vv^-1 Q_vx ,
 //     P = Lc' Q_own Lc + sum_c Acl_c' P_c Acl_c   (closed-loop "Joseph" form, Lc = [I;K], Acl = F Lc).
 #pragma once
 
 namespace dompc {
 namespace r16 {
-constexpr bool ENABLED = R16_ENABLED;      // (NYT <= 16, no nl_cons rows, not the tree-sharding build)
+constexpr bool ENABLED = R16_ENABLED;      // (NYT <= 16, at most 4 nl_cons rows, not the tree-sharding build)
 
 #ifndef DOMPC_HOST_EMU
 constexpr int KB_A = (NA + 3) / 4, KB_Y = (NYT + 3) / 4;
@@ -155,10 +156,12 @@ __device__ inline void load_node(const Prob& Q, int n, int lane, NodeIn& R) {
   const int ie = A.node_in_edge[n], pn = A.node_parent[n];
   const bool is_up = (j >= NX && j < NA);
   const int jj = j < NYT ? j : 0;
-  const int gi = (jj < NX) ? xo + jj : (is_up ? uo + (jj - NX) : uo + (jj - NA));
+  const int eo = NS > 0 ? A.node_eps_off[n] : 0;
+  const bool is_eps = NS > 0 && jj >= NA + NU;
+  const int gi = (jj < NX) ? xo + jj : (is_up ? uo + (jj - NX) : (is_eps ? eo + (jj - NA - NU) : uo + (jj - NA)));
   R.xv = Q.x[gi]; R.lo = Q.lb[gi]; R.hi = Q.ub[gi]; R.zlo = Q.zl[gi]; R.zhi = Q.zu[gi];
-  const int iu = is_up ? jj - NX : (jj >= NA ? jj - NA : 0);
-  R.upv = (jj >= NX) ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / tab_sel(DOMPC_SU, iu)) : 0.0;
+  const int iu = is_up ? jj - NX : ((jj >= NA && !is_eps) ? jj - NA : 0);
+  R.upv = (jj >= NX && !is_eps) ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / tab_sel(DOMPC_SU, iu)) : 0.0;
   R.nu = (jj < NX) ? ((ie >= 0) ? Q.lam[A.edge_row0[ie] + NW + jj] : Q.lam[jj]) : 0.0;
 }
 // tiles of the staged first child edge (LDS reads)
@@ -213,7 +216,8 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     const int ie = A.node_in_edge[n];
     const bool is_up = (j >= NX && j < NA);
     const int jj = j < NYT ? j : 0;
-    const int iu = is_up ? jj - NX : (jj >= NA ? jj - NA : 0);
+    const bool is_eps = NS > 0 && jj >= NA + NU;
+    const int iu = is_up ? jj - NX : ((jj >= NA && !is_eps) ? jj - NA : 0);
     const double xv = R.xv, lo = R.lo, hi = R.hi, upv = R.upv;
     if (is_up) {
       dg = 2.0 * rw * tab_sel(DOMPC_RTERM, iu);
@@ -223,6 +227,8 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       gv = bar_grad(xv, lo, hi, mu);
       if (jj < NX) {
         gv += (ie >= 0) ? -R.nu : R.nu;
+      } else if (is_eps) {
+        if constexpr (NS > 0) gv += cc * Q.sf * tab_sel(DOMPC_EPS_PEN, jj - NA - NU);      // slack penalty (one term per outgoing edge)
       } else {
         dg += 2.0 * rw * tab_sel(DOMPC_RTERM, iu);
         gv += 2.0 * rw * tab_sel(DOMPC_RTERM, iu) * (xv - upv);
@@ -235,6 +241,22 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       for (int c = 1; c < cc; ++c) {
         const double* S_ = Q.ES(cs + c);
         gv += S_[ES_RY + yjj] + S_[ES_QV + yjj] + (delta != 0.0 ? delta * wtw0_entry(Q, cs + c, yjj) : 0.0);
+      }
+    }
+    if constexpr (NE > 0) {
+      // nl_cons rows of the child edges, condensed through their slacks: gradient share  J~'((Sigma_s + delta) r_d + r_s)
+      // with J~ = [J_d over (x, u) | -1 at the slack variable of the row]  (same algebra as riccati_node, dompc_kernel.h)
+      for (int c = 0; c < cc; ++c) {
+        const int e = cs + c;
+        const double* S_ = Q.ES(e);
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+          const double sg = S_[ES_SIGS + q] + delta;
+          const bool slack_here = NS > 0 && jj >= NA + NU && DOMPC_NL_SLACK[q] == jj - NA - NU;
+          const double jc = (yjj >= 0) ? Q.EW(e, EW_JD + q * NA + yjj) : (slack_here ? -1.0 : 0.0);
+          gv += jc * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
+          if (slack_here) gv -= Q.lam[A.edge_row0[e] + NW + NX + q];
+        }
       }
     }
     if (j >= NYT) { dg = 0.0; gv = 0.0; }
@@ -251,6 +273,27 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       QO[r] -= 2.0 * rw * tab_sel(DOMPC_RTERM, (i < j ? i : j) - NX);
   }
   R16_PN(14)
+  if constexpr (NE > 0) {
+    // ... and the Hessian share  sum_q (Sigma_s + delta) J~_q' J~_q  as rank-one updates of the own tile
+    const int jz = j < NYT ? j : 0, yj = yz(jz);
+    for (int c = 0; c < cc; ++c) {
+      const int e = cs + c;
+      const double* S_ = Q.ES(e);
+#pragma unroll
+      for (int q = 0; q < NE; ++q) {
+        const double sg = S_[ES_SIGS + q] + delta;
+        const double jc = (j >= NYT) ? 0.0 : ((yj >= 0) ? Q.EW(e, EW_JD + q * NA + yj)
+                                                        : ((NS > 0 && jz >= NA + NU && DOMPC_NL_SLACK[q] == jz - NA - NU) ? -1.0 : 0.0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = g + 4 * r, iz = i < NYT ? i : 0, yi = yz(iz);
+          const double jr = (i >= NYT) ? 0.0 : ((yi >= 0) ? Q.EW(e, EW_JD + q * NA + yi)
+                                                          : ((NS > 0 && iz >= NA + NU && DOMPC_NL_SLACK[q] == iz - NA - NU) ? -1.0 : 0.0));
+          QO[r] += sg * jr * jc;
+        }
+      }
+    }
+  }
   const d4 qo0 = col_to_tile0(gv, lane);
   R16_PN(8)
   // ---- children, pass 1: Q_tot = Q_own + sum F' P_c F ,  q_tot = q_own + sum F'(P_c f + p_c)
