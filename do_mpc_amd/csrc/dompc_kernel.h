@@ -5,7 +5,7 @@
 //
 // What it replaces in the reference (everything CasADi/IPOPT/MUMPS do inside
 // `r = self.S(**kwargs)`, /root/reference/do_mpc/optimizer.py:770):
-//   nlp_f / nlp_g / nlp_grad_f / nlp_jac_g / nlp_hess_l   -> eval_edge()  (per edge, per collocation point)
+//   nlp_f / nlp_g / nlp_grad_f / nlp_jac_g / nlp_hess_l   -> eval_models() + eval_edge_coop()  (per edge, per collocation point)
 //   MUMPS LDL^T of the sparse KKT matrix                  -> condense (LU of the collocation block) +
 //                                                            riccati_backward()/forward() on the tree
 //   IPOPT's filter line search / mu update / termination  -> solve_problem()
@@ -23,8 +23,11 @@
 
 namespace dompc {
 
-// Phase functions.  (Measured on MI355X: keeping them out of line with __attribute__((noinline)) makes
-// the Thr/Prob descriptors live in scratch and doubles the time of the LDS loops, so they are inlined.)
+// Building blocks of the phases.  They are `inline`; the phases themselves (phase_sweep, phase_edge_factor, phase_backward,
+// phase_forward, the line-search passes) are separate NOINLINE device functions that rebuild their context (kernel
+// arguments, Thr, Prob) from uniform sources - passing the descriptors by reference puts them into scratch and doubled
+// the time of the LDS loops in a round-1 attempt; sharing one register allocation between the phases cost even more
+// (DESIGN.md section 4).
 #ifndef DOMPC_HOST_EMU
 #define DOMPC_PHASE __device__ inline
 #else
