@@ -659,7 +659,9 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   // small batches: several workgroups per problem so that one make_step can use many CUs
   const char* wenv = getenv("DOMPC_WIDE");
   // enough workgroups that every wavefront owns about two edges, fewer when the batch itself fills the chip
-  int K = wenv ? atoi(wenv) : (B <= 8 ? 32 : (B <= 32 ? 8 : (B <= 64 ? 4 : 1)));
+  // (measured on MI355X, single cold industrial_poly step, round-2 kernels: K = 4 / 8 / 16 / 32 -> 27.1 / 23.4 / 22.6 / 26.0 ms;
+  //  CSTR 9.1 / - / 8.3 / 10.2 ms - the device-scope barriers grow with K faster than the phases shrink)
+  int K = wenv ? atoi(wenv) : (B <= 8 ? 16 : (B <= 32 ? 8 : (B <= 64 ? 4 : 1)));
   if (!wenv && K > h->d.n_edges / 8) K = h->d.n_edges / 8 > 1 ? h->d.n_edges / 8 : 1;
   if (K > 32) K = 32;
   if (K > 1 && B <= 64 && B <= h->n_slots) {
