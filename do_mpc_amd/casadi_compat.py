@@ -11,7 +11,7 @@ With real CasADi installed do not call install(); use the ctypes stub of INTEGRA
 import sys
 import types
 
-from . import controller, differentiator, model, simulator, structs, sym
+from . import controller, differentiator, model, sampling, simulator, structs, sym
 
 _CASADI_NAMES = [
     "SX", "DM", "vertcat", "horzcat", "mtimes", "sum1", "sum2", "sumsqr", "dot", "exp", "log", "sqrt", "sin",
@@ -73,7 +73,11 @@ def install(force: bool = False):
         m_est.StateFeedback = StateFeedback
         m_diff = types.ModuleType("do_mpc.differentiator")
         m_diff.DoMPCDifferentiator = differentiator.DoMPCDifferentiator
+        m_samp = types.ModuleType("do_mpc.sampling")
+        m_samp.SamplingPlanner, m_samp.Sampler, m_samp.DataHandler = (sampling.SamplingPlanner, sampling.Sampler,
+                                                                      sampling.DataHandler)
         dm.model, dm.controller, dm.simulator, dm.estimator, dm.differentiator = m_model, m_ctrl, m_sim, m_est, m_diff
+        dm.sampling = m_samp
         dm.__version__ = "5.1.1+dompc_amd"
         sys.modules["do_mpc"] = dm
         sys.modules["do_mpc.model"] = m_model
@@ -81,8 +85,9 @@ def install(force: bool = False):
         sys.modules["do_mpc.simulator"] = m_sim
         sys.modules["do_mpc.estimator"] = m_est
         sys.modules["do_mpc.differentiator"] = m_diff
+        sys.modules["do_mpc.sampling"] = m_samp
         installed += ["do_mpc", "do_mpc.model", "do_mpc.controller", "do_mpc.simulator", "do_mpc.estimator",
-                      "do_mpc.differentiator"]
+                      "do_mpc.differentiator", "do_mpc.sampling"]
     return installed
 
 

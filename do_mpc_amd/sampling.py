@@ -80,3 +80,297 @@ def closed_loop_samples(mpc, simulator, plan: Dict[str, np.ndarray], trajectory_
         cur_up = r["u0"]
     n_valid = np.where(ok.all(axis=1), T, np.argmin(ok, axis=1))
     return {"id": np.asarray(plan.get("id", np.arange(n))), "x": x, "u": u, "u_prev": up, "success": ok, "n_valid": n_valid}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The reference's sampling tool chain (`do_mpc.sampling`): plan -> samples on disk -> post-processed table.
+# Same class and method names, file names and table layout as /root/reference/do_mpc/sampling/{_samplingplanner,_sampler,
+# _datahandler}.py so that a plan written by one side is read by the other; pinned by the reference's own golden
+# (testing/results/res_sampling_test_test_fun.pkl -> tests/golden/sampling_test_fun.json).  The one addition is
+# `Sampler.set_batch_function`: a function that is handed every pending row of the plan AT ONCE (columns as arrays) and
+# returns one result per row - the shape `open_loop_samples` / `make_step_batch` want: one launch for the whole plan
+# instead of `n_samples` solver calls.
+import copy as _copy
+import inspect as _inspect
+import itertools as _itertools
+import logging as _logging
+import os as _os
+import pickle as _pickle
+
+
+def _is_callable_or_none(f, allow_none=True):
+    import types as _t
+    return isinstance(f, (_t.FunctionType, _t.BuiltinFunctionType)) or (allow_none and f is None)
+
+
+class _Settable:
+    """`set_param(**kwargs)` over a fixed list of keys; unknown keys only warn (reference behaviour)."""
+    _keys = ()
+
+    def set_param(self, **kwargs) -> None:
+        for k, v in kwargs.items():
+            if k in self._keys:
+                setattr(self, k, v)
+            else:
+                print("Warning: Key {} does not exist for {}.".format(k, type(self).__name__))
+
+    @property
+    def data_dir(self):
+        return self._data_dir
+
+    @data_dir.setter
+    def data_dir(self, val):
+        self._data_dir = val
+        if self._make_dir:
+            _os.makedirs(val, exist_ok=True)
+
+    _make_dir = True
+
+    def _sample_file(self, sample_id):
+        ext = {"pickle": ".pkl", "mat": ".mat"}[self.save_format]
+        return "{}{}_{}{}".format(self.data_dir, self.sample_name, sample_id, ext)
+
+
+def _dump_pickle(path, obj):
+    with open(path if path.endswith(".pkl") else path + ".pkl", "wb") as f:
+        _pickle.dump(obj, f)
+
+
+class SamplingPlanner(_Settable):
+    """_samplingplanner.py:13-280.  A plan is a list of dicts {var: value, ..., 'id': zero-padded running number}."""
+    _keys = ("overwrite", "id_precision")
+
+    def __init__(self, **kwargs):
+        self.sampling_vars, self.sampling_var_names, self.sampling_plan = [], [], []
+        self.data_fields = list(self._keys)
+        self.data_dir, self.overwrite, self.id_precision = "./", False, 3
+        self.set_param(**kwargs)
+
+    def set_sampling_var(self, name: str, fun_var_pdf=None) -> None:
+        assert isinstance(name, str), "name must be str, you have {}".format(type(name))
+        assert _is_callable_or_none(fun_var_pdf), "fun_var_pdf must be a function or None, you have {}".format(type(fun_var_pdf))
+        self.sampling_vars.append({"name": name, "fun_var_pdf": fun_var_pdf})
+        self.sampling_var_names.append(name)
+
+    def add_sampling_case(self, **kwargs) -> list:
+        unknown = [k for k in kwargs if k not in self.sampling_var_names]
+        if unknown:
+            raise Exception("{} is not a valid sampling variable. Introduce sampling variables with set_sampling_var."
+                            .format(unknown[0]))
+        case = dict(kwargs)                                   # given values first, drawn values after (order of the golden)
+        for var in self.sampling_vars:
+            if var["name"] not in kwargs:
+                assert var["fun_var_pdf"] is not None, ("Cannot augment sampling_case for missing variable {}. Variable "
+                                                        "generating function is missing.".format(var["name"]))
+                case[var["name"]] = var["fun_var_pdf"]()
+        case["id"] = str(len(self.sampling_plan)).zfill(self.id_precision)
+        self.sampling_plan.append(case)
+        return self.sampling_plan
+
+    def gen_sampling_plan(self, n_samples: int) -> list:
+        assert isinstance(n_samples, int), "n_samples must be int, you have {}".format(type(n_samples))
+        assert n_samples > 0, "n_samples must be larger than 0."
+        for _ in range(n_samples):
+            self.add_sampling_case()
+        return self.sampling_plan
+
+    def product(self, **kwargs) -> list:
+        if not all(isinstance(v, list) for v in kwargs.values()):
+            raise ValueError("keyword values must be lists")
+        if not all(k in self.sampling_var_names for k in kwargs):
+            raise ValueError("keyword names must be existing sampling variables")
+        for combo in _itertools.product(*kwargs.values()):
+            self.add_sampling_case(**dict(zip(kwargs.keys(), combo)))
+        return self.sampling_plan
+
+    def export(self, sampling_plan_name: str) -> None:
+        assert isinstance(sampling_plan_name, str), "sampling_plan_name must be of type str. You have {}.".format(
+            type(sampling_plan_name))
+        stem = self.data_dir + _os.path.splitext(sampling_plan_name)[0]
+        suffixes = [""] if self.overwrite else _itertools.chain([""], map(str, range(1, 10000)))
+        for s in suffixes:                                    # first free name unless overwriting
+            if self.overwrite or not _os.path.isfile(stem + s + ".pkl"):
+                _dump_pickle(stem + s + ".pkl", self.sampling_plan)
+                return
+
+
+class Sampler(_Settable):
+    """_sampler.py:14-232: evaluates the sample function for every row of a plan and stores one file per row
+    (`<sample_name>_<id>.pkl|.mat` under `data_dir`); rows whose file exists are skipped unless `overwrite`."""
+    _keys = ("overwrite", "sample_name", "save_format", "print_progress")
+
+    def __init__(self, sampling_plan: list, **kwargs):
+        assert isinstance(sampling_plan, list), "sampling_plan must be a list"
+        assert all(isinstance(r, dict) for r in sampling_plan), "All elements of sampling plan must be a dictionary."
+        self.sampling_plan = sampling_plan
+        self.sampling_vars = list(sampling_plan[0].keys())
+        self.n_samples = len(sampling_plan)
+        self.completion_list = []
+        self.flags = {"set_sample_function": False}
+        self.data_fields = list(self._keys)
+        self.data_dir, self.sample_name, self.save_format = "./", "sample", "pickle"
+        self.overwrite, self.print_progress, self.n_processes = False, True, 1
+        self.sample_function = self.batch_function = None
+        self.set_param(**kwargs)
+
+    def _check_args(self, fun, what):
+        assert _is_callable_or_none(fun, allow_none=False), what + " must be a function"
+        extra = set(_inspect.getfullargspec(fun).args) - set(self.sampling_vars)
+        assert not extra, ("{} must only contain keyword arguments that appear as sample vars in the sampling_plan. "
+                           "You have the unknown arguments: {}".format(what, extra))
+
+    def set_sample_function(self, sample_function) -> None:
+        self._check_args(sample_function, "sample_function")
+        self.sample_function = sample_function
+        self.flags["set_sample_function"] = True
+
+    def set_batch_function(self, batch_function) -> None:
+        """`batch_function(**columns)`: every argument is the array of that sampling variable over the pending rows; returns
+        a sequence with one result per row.  Used by `sample_data` instead of the row-by-row loop."""
+        self._check_args(batch_function, "batch_function")
+        self.batch_function = batch_function
+        self.flags["set_sample_function"] = True
+
+    def _pending(self, idx):
+        return self.overwrite or not _os.path.isfile(self._sample_file(self.sampling_plan[idx]["id"]))
+
+    def _store(self, idx, result):
+        sid = self.sampling_plan[idx]["id"]
+        name = self._sample_file(sid)
+        if self.save_format == "pickle":
+            _dump_pickle(name, result)
+        else:
+            import scipy.io as sio
+            sio.savemat(name, {"res": result})
+        self.completion_list.append(sid)
+
+    def _progress(self):
+        if self.print_progress:
+            done, n = len(self.completion_list), max(1, self.n_samples)
+            fill = int(50 * done // n)
+            print("\rProgress: |{}{}| {:.1f}% Complete".format("█" * fill, "-" * (50 - fill), 100.0 * done / n),
+                  end="\n" if done == n else "\r")
+
+    def sample_idx(self, idx: int) -> None:
+        assert self.flags["set_sample_function"], ("Cannot sample before setting the sample function with "
+                                                   "Sampler.set_sample_function")
+        assert 0 <= idx <= len(self.sampling_plan), "Invalid value for idx. Must be between 0 and {}. You have {}".format(
+            len(self.sampling_plan), idx)
+        if self._pending(idx):
+            row = {k: v for k, v in self.sampling_plan[idx].items() if k != "id"}
+            if self.sample_function is not None:
+                result = self.sample_function(**row)
+            else:
+                result = self.batch_function(**{k: np.asarray([v]) for k, v in self._wanted(row).items()})[0]
+            self._store(idx, result)
+        self._progress()
+
+    def _wanted(self, row):
+        names = _inspect.getfullargspec(self.batch_function).args
+        return {k: row[k] for k in names}
+
+    def sample_data(self) -> None:
+        if self.batch_function is None:
+            for i in range(len(self.sampling_plan)):
+                self.sample_idx(i)
+            return
+        todo = [i for i in range(len(self.sampling_plan)) if self._pending(i)]
+        if todo:
+            names = _inspect.getfullargspec(self.batch_function).args
+            cols = {k: np.asarray([self.sampling_plan[i][k] for i in todo]) for k in names}
+            results = self.batch_function(**cols)
+            assert len(results) == len(todo), "batch_function must return one result per row of the plan"
+            for i, r in zip(todo, results):
+                self._store(i, r)
+        self._progress()
+
+
+class DataHandler(_Settable):
+    """_datahandler.py:17-330: lazy loading of the stored samples + named post-processing functions; `dh[...]` and
+    `dh.filter(input_filter, output_filter)` return lists of {plan row..., name: post-processed value...}."""
+    _keys = ("data_dir", "sample_name", "save_format")
+    _make_dir = False
+
+    def __init__(self, sampling_plan, **kwargs):
+        self.flags = {"set_post_processing": False}
+        self.data_fields = list(self._keys)
+        self.data_dir, self.sample_name, self.save_format = "./", "sample", "pickle"
+        self.sampling_plan = sampling_plan
+        self.sampling_vars = list(sampling_plan[0].keys())
+        self.post_processing = {}
+        self._cache = {}
+        self.set_param(**kwargs)
+
+    @property
+    def pre_loaded_data(self):
+        return {"id": list(self._cache.keys()), "data": list(self._cache.values())}
+
+    def set_post_processing(self, name: str, post_processing_function) -> None:
+        assert isinstance(name, str), "name must be str, you have {}".format(type(name))
+        assert _is_callable_or_none(post_processing_function, allow_none=False), (
+            "post_processing_function must be a function, you have {}".format(type(post_processing_function)))
+        n_args = len(_inspect.signature(post_processing_function).parameters)
+        self.post_processing[name] = {"function": post_processing_function, "n_args": n_args}
+        self.flags["set_post_processing"] = True
+
+    def _load(self, sample_id):
+        name = self._sample_file(sample_id)
+        try:
+            if self.save_format == "pickle":
+                with open(name, "rb") as f:
+                    return _pickle.load(f)
+            import scipy.io as sio
+            return sio.loadmat(name)
+        except FileNotFoundError:
+            _logging.warning("Could not find or load file: {}. Check data_dir parameter and make sure sample has already "
+                             "been generated.".format(name))
+            return None
+
+    def _result(self, row):
+        if row["id"] not in self._cache:
+            self._cache[row["id"]] = self._load(row["id"])
+        return self._cache[row["id"]]
+
+    def _table_row(self, row):
+        result = self._result(row)
+        out = _copy.copy(row)
+        if not self.flags["set_post_processing"]:
+            out["res"] = result
+            return out
+        for name, pp in self.post_processing.items():
+            if result is None:
+                out[name] = None
+            elif pp["n_args"] == 1:
+                out[name] = pp["function"](result)
+            elif pp["n_args"] == 2:
+                out[name] = pp["function"](row, result)
+        return out
+
+    def __getitem__(self, ind):
+        if isinstance(ind, int):
+            rows = [self.sampling_plan[ind]]
+        elif isinstance(ind, slice):
+            rows = self.sampling_plan[ind]
+        elif isinstance(ind, (tuple, list)):
+            rows = [self.sampling_plan[i] for i in ind]
+        else:
+            raise Exception("ind must be of type int, tuple, slice or list. You have {}".format(type(ind)))
+        return [self._table_row(r) for r in rows]
+
+    def filter(self, input_filter=None, output_filter=None) -> list:
+        assert _is_callable_or_none(input_filter), "input_filter must be a function, you have {}".format(type(input_filter))
+        assert _is_callable_or_none(output_filter), "output_filter must be a function, you have {}".format(type(output_filter))
+
+        def passes(fun, values):
+            if fun is None:
+                return True
+            names = fun.__code__.co_varnames[:fun.__code__.co_argcount]
+            return fun(**{n: values[n] for n in names}) == True   # noqa: E712  (the filters may return numpy bools)
+
+        out = []
+        for row in self.sampling_plan:
+            if passes(input_filter, row):
+                t = self._table_row(row)
+                if passes(output_filter, t):
+                    out.append(t)
+        return out

@@ -147,3 +147,15 @@ def test_unedited_batch_reactor_differentiator_templates_and_sensitivity_query(c
     du0du_prev_num = nlp_diff.sens_num["dxdp", indexf["_u", 0, 0], indexf["_u_prev"]].full()
     assert du0dx0_num.shape == (model.n_u, model.n_x) and du0du_prev_num.shape == (model.n_u, model.n_u)
     assert np.all(np.isfinite(du0dx0_num))
+
+
+def test_unedited_sampling_tool_chain_script_reproduces_its_golden_table(compat, tmp_path, monkeypatch):
+    """examples/tools/sampling/regular/test_fun/sampling_test.py un-edited (`do_mpc.sampling.SamplingPlanner / Sampler /
+    DataHandler`), compared for equality with the reference's stored table like testing/test_sampling_tools.py:55-67."""
+    import pickle
+    mod = _load(os.path.join(REF, "tools", "sampling", "regular", "test_fun", "sampling_test.py"), "ref_sampling_test")
+    monkeypatch.chdir(tmp_path)                          # the script writes ./sample_results/
+    res, res1, res2 = mod.main()
+    with open("/root/reference/testing/results/res_sampling_test_test_fun.pkl", "rb") as f:
+        ref = pickle.load(f)
+    assert res == ref["res"] and res1 == ref["res1"] and res2 == ref["res2"]

@@ -25,3 +25,133 @@ def test_open_loop_samples_equal_single_make_steps():
         assert one.solver_stats["iter_count"] == res["iter_count"][i]
     df = sampling.to_dataframe(res)
     assert list(df.columns) == ["id", "x0", "u_prev", "u0", "status", "iter_count", "t_wall", "t_make_step"] and len(df) == 6
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The reference's sampling tool chain (plan -> samples on disk -> table), pinned by its own golden table.
+import json
+import os
+import pickle
+
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampling_test_fun.json")
+
+
+def _tool_chain(tmp_path, batched):
+    """The steps of examples/tools/sampling/regular/test_fun/sampling_test.py:10-49 (testing/test_sampling_tools.py)."""
+    np.random.seed(123)
+    d = str(tmp_path) + os.sep
+    sp = sampling.SamplingPlanner()
+    sp.set_param(overwrite=True)
+    sp.data_dir = d
+    sp.set_sampling_var("alpha", lambda: np.random.randn())
+    sp.set_sampling_var("beta", lambda: np.random.randint(0, 5))
+    sp.gen_sampling_plan(n_samples=10)
+    sp.add_sampling_case(alpha=10)
+    sp.add_sampling_case(beta=10)
+    plan = sp.add_sampling_case(alpha=2, beta=2)
+    sampler = sampling.Sampler(plan, overwrite=True, print_progress=False)
+    sampler.data_dir = d
+    calls = []
+    if batched:
+        def whole_plan(alpha, beta):
+            calls.append(len(alpha))
+            return list((alpha * beta).tolist())
+        sampler.set_batch_function(whole_plan)
+    else:
+        def one_row(alpha, beta):
+            calls.append(1)
+            return alpha * beta
+        sampler.set_sample_function(one_row)
+    sampler.sample_data()
+    dh = sampling.DataHandler(plan)
+    dh.data_dir = d
+    dh.set_post_processing("res_1", lambda x: x)
+    dh.set_post_processing("res_2", lambda x: x ** 2)
+    return dh[:], dh.filter(input_filter=lambda alpha: alpha < 0), dh.filter(output_filter=lambda res_1: res_1 < 0), calls, plan
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_sampling_tool_chain_reproduces_the_reference_table(tmp_path, batched):
+    res, res1, res2, calls, plan = _tool_chain(tmp_path, batched)
+    ref = json.load(open(GOLDEN))
+    assert res == ref["res"] and res1 == ref["res1"] and res2 == ref["res2"]      # equality, like the reference's test
+    assert calls == ([13] if batched else [1] * 13)
+    assert sorted(os.listdir(tmp_path)) == ["sample_%03d.pkl" % i for i in range(13)]
+    assert pickle.load(open(os.path.join(tmp_path, "sample_012.pkl"), "rb")) == 4
+
+
+def test_sampler_skips_existing_samples_and_handler_reports_missing_ones(tmp_path):
+    d = str(tmp_path) + os.sep
+    sp = sampling.SamplingPlanner(id_precision=2)
+    sp.set_sampling_var("a")
+    sp.set_sampling_var("b", lambda: 7)
+    with pytest.raises(AssertionError):
+        sp.add_sampling_case(b=1)                       # `a` has no generating function
+    with pytest.raises(Exception, match="not a valid sampling variable"):
+        sp.add_sampling_case(c=1)
+    plan = sp.product(a=[1, 2, 3], b=[10, 20])
+    assert [r["id"] for r in plan] == ["%02d" % i for i in range(6)] and plan[3] == {"a": 2, "b": 20, "id": "03"}
+    sp.data_dir = d
+    sp.export("plan.pkl"); sp.export("plan")
+    assert sorted(f for f in os.listdir(d) if f.startswith("plan")) == ["plan.pkl", "plan1.pkl"]
+    assert pickle.load(open(d + "plan1.pkl", "rb")) == plan
+
+    seen = []
+    s = sampling.Sampler(plan[:4], print_progress=False, sample_name="run")
+    s.data_dir = d
+    with pytest.raises(AssertionError):
+        s.set_sample_function(lambda a, zeta: 0)        # unknown argument
+    with pytest.raises(AssertionError):
+        s.sample_idx(0)                                 # no sample function yet
+    s.set_sample_function(lambda a, b: seen.append((a, b)) or a + b)
+    s.sample_idx(2)
+    s.sample_data()
+    assert seen == [(2, 10), (1, 10), (1, 20), (2, 20)] and s.completion_list == ["02", "00", "01", "03"]
+    s.sample_data()
+    assert len(seen) == 4                               # files exist, overwrite is off
+
+    dh = sampling.DataHandler(plan, sample_name="run")
+    dh.data_dir = d
+    assert dh[1] == [{"a": 1, "b": 20, "id": "01", "res": 21}]           # no post-processing: raw result under 'res'
+    assert dh[5][0]["res"] is None                                      # not sampled yet
+    dh.set_post_processing("double", lambda r: 2 * r)
+    dh.set_post_processing("with_row", lambda row, r: r - row["a"])
+    tab = dh[[0, 5]]
+    assert tab[0] == {"a": 1, "b": 10, "id": "00", "double": 22, "with_row": 10}
+    assert tab[1] == {"a": 3, "b": 20, "id": "05", "double": None, "with_row": None}
+    assert [r["id"] for r in dh.filter(input_filter=lambda a, b: a == 2 and b == 10)] == ["02"]
+    assert dh.pre_loaded_data["id"][:2] == ["01", "05"]
+
+
+def test_sampler_batch_function_runs_the_whole_plan_as_one_solver_batch(tmp_path):
+    """The reference's approximate-MPC sampler is a `Sampler` whose sample function calls `mpc.make_step` per row
+    (_ampc_sampler.py:283-320); with `set_batch_function` the same plan is one `make_step_batch` launch."""
+    ex = CASES["batch_reactor"]
+    with hostemu.patched():
+        mpc = ex.build_mpc(ex.build_model(), max_batch=5)
+    rng = np.random.default_rng(0)
+    sp = sampling.SamplingPlanner()
+    sp.set_sampling_var("x0", lambda: ex.X0 * rng.uniform(0.9, 1.1, size=4))
+    sp.set_sampling_var("u_prev", lambda: rng.uniform(0.0, 0.02, size=1))
+    plan = sp.gen_sampling_plan(5)
+    launches = []
+
+    def solve_rows(x0, u_prev):
+        r = sampling.open_loop_samples(mpc, {"x0": x0, "u_prev": u_prev})
+        launches.append(len(x0))
+        return [{"u0": r["u0"][i], "status": bool(r["status"][i]), "iter_count": int(r["iter_count"][i])} for i in range(len(x0))]
+
+    s = sampling.Sampler(plan, print_progress=False)
+    s.data_dir = str(tmp_path) + os.sep
+    s.set_batch_function(solve_rows)
+    s.sample_data()
+    assert launches == [5]
+    dh = sampling.DataHandler(plan)
+    dh.data_dir = s.data_dir
+    dh.set_post_processing("u0", lambda r: r["u0"])
+    dh.set_post_processing("ok", lambda r: r["status"])
+    tab = dh[:]
+    direct = sampling.open_loop_samples(mpc, {"x0": np.array([r["x0"] for r in plan]), "u_prev": np.array([r["u_prev"] for r in plan])})
+    assert all(t["ok"] for t in tab) and np.array_equal(np.array([t["u0"] for t in tab]), direct["u0"])

@@ -10,7 +10,10 @@ The pickles hold do_mpc.data.MPCData objects whose classes need CasADi to
 unpickle.  CasADi is not available here, so every non-numpy class is replaced
 by a stub that just records its state; all numeric payloads are plain ndarrays.
 
-Output: tests/golden/<case>.npz  (small, committed).
+Output: tests/golden/<case>.npz  (small, committed), and tests/golden/sampling_test_fun.json - the table the reference's
+sampling tool chain produces for examples/tools/sampling/regular/test_fun/sampling_test.py
+(results/res_sampling_test_test_fun.pkl, compared for equality by testing/test_sampling_tools.py:55-67; plain
+dicts of floats / ints / strings, written with repr-exact floats).
 Run:    python tools/extract_golden.py
 """
 import io
@@ -80,6 +83,15 @@ def main():
         path = os.path.join(OUT, case + ".npz")
         np.savez_compressed(path, **out)
         print(case, "->", path, {k: v.shape for k, v in out.items() if v.ndim > 0})
+    import json
+    with open(os.path.join(REF, "res_sampling_test_test_fun.pkl"), "rb") as f:
+        tab = pickle.load(f)
+    plain = {name: [{k: (v.item() if isinstance(v, np.generic) else v) for k, v in row.items()} for row in rows]
+             for name, rows in tab.items()}
+    path = os.path.join(OUT, "sampling_test_fun.json")
+    with open(path, "w") as f:
+        json.dump(plain, f, indent=1)
+    print("sampling_test_fun ->", path, {k: len(v) for k, v in plain.items()})
 
 
 if __name__ == "__main__":
