@@ -14,7 +14,7 @@ import types
 from . import controller, differentiator, model, sampling, simulator, structs, sym
 
 _CASADI_NAMES = [
-    "SX", "DM", "vertcat", "horzcat", "mtimes", "sum1", "sum2", "sumsqr", "dot", "exp", "log", "sqrt", "sin",
+    "SX", "DM", "vertcat", "horzcat", "vertsplit", "mtimes", "sum1", "sum2", "sumsqr", "dot", "exp", "log", "sqrt", "sin",
     "cos", "tan", "tanh", "sinh", "cosh", "asin", "acos", "atan", "atan2", "sign", "fabs", "fmin", "fmax", "jacobian",
     "gradient", "hessian", "substitute", "Function",
 ]

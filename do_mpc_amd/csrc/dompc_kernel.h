@@ -3491,7 +3491,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   int status = 2, it = 0, n_reg = 0, n_ls_fail = 0, n_sweeps = 0, n_trials = 0, n_soc = 0;
 
   // ---- bounds (relaxed, bound_relax_factor), starting point pushed inside, z = 1
-  double cnt[2] = {0.0, 0.0};
+  double cnt[3] = {0.0, 0.0, 0.0};
   for (int g = T.tid; g < nX; g += T.nt) {
     double l = A.lbx[g], u = A.ubx[g];
     if (l > -INFINITY) l -= fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(l)));
@@ -3516,6 +3516,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
     const int g = A.dummy_idx[d];
     if (sh_cnt(A, mk_x(A, g))) cnt[0] -= (Q.lb[g] > -INFINITY ? 1.0 : 0.0) + (Q.ub[g] < INFINITY ? 1.0 : 0.0);
+    if (!(Q.lb[g] > -INFINITY) && !(Q.ub[g] < INFINITY)) cnt[2] += 1.0;   // a free one: see `singular0` below
     Q.x[g] = fmin(fmax(x0[g], A.lbx[g]), A.ubx[g]);           // the caller's value, projected onto its box
     Q.lb[g] = -INFINITY; Q.ub[g] = INFINITY; Q.zl[g] = 0.0; Q.zu[g] = 0.0;
   }
@@ -3545,9 +3546,16 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     T.sync();
   }
   {
-    const int ops[2] = {R_SUM, R_SUM};
+    const int ops[3] = {R_SUM, R_SUM, R_SUM};
     wg_reduce(T, cnt, ops);
   }
+  // A variable that is in no constraint, no cost term and has no bound is a zero row and column of the reference's
+  // primal-dual matrix: its linear solver reports a singular system at delta_w = 0 in EVERY iteration and IPOPT
+  // regularises (delta_w from the wrong-inertia rule, IpPDPerturbationHandler: PerturbForSingularity).  The structured
+  // factorisation here never sees those variables, so the first attempt of an iteration is declared failed instead -
+  // same delta_w sequence, same iterates (rotating-masses example: no state bounds, golden reproduced to 1e-9 instead
+  // of 2e-5).
+  const bool singular0 = cnt[2] > 0.0;
   const double n_bounds = cnt[0] + cnt[1];
   const double n_dual = (double)A.n_g + n_bounds;
 
@@ -3640,7 +3648,9 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     double delta = 0.0;
     bool first_try = true, dir_ok = true;
     while (true) {
-      c_t = prof_clock(); const int fail = run_backward(T, Q, b, slot, mu, delta); c_bwd += prof_clock() - c_t;
+      c_t = prof_clock();
+      const int fail = (singular0 && delta == 0.0) ? 1 : run_backward(T, Q, b, slot, mu, delta);
+      c_bwd += prof_clock() - c_t;
       if (!fail) break;
       if (delta == 0.0) {
         delta = (delta_last == 0.0) ? O.delta_w_0 : fmax(O.delta_w_min, O.kappa_w_minus * delta_last);

@@ -1,4 +1,4 @@
-"""The four BASELINE workloads and three more of the reference's shipped NMPC examples (bicycle models, kite),
+"""The four BASELINE workloads and four more of the reference's shipped NMPC examples (bicycle models, kite, rotating masses),
 restated on do_mpc_amd's Model/MPC surface.
 
 Each module has `build_model()` and `build_mpc(model, **settings_overrides)` plus `X0`, the
@@ -6,9 +6,9 @@ example's initial state.  Equations/settings follow the reference examples (cite
 the un-edited reference templates themselves run through do_mpc_amd.casadi_compat in
 tests/test_reference_templates.py when /root/reference is present.
 """
-from . import batch_reactor, bicycle, cstr, industrial_poly, kite, oscillating_masses  # noqa: F401
+from . import batch_reactor, bicycle, cstr, industrial_poly, kite, oscillating_masses, rotating_masses  # noqa: F401
 
 CASES = {"industrial_poly": industrial_poly, "CSTR": cstr, "batch_reactor": batch_reactor,
          "oscillating_masses": oscillating_masses, "kinematic_bicycle": bicycle.kinematic,
-         "dynamic_bicycle": bicycle.dynamic, "kite": kite}
+         "dynamic_bicycle": bicycle.dynamic, "kite": kite, "rotating_masses": rotating_masses}
 BASELINE_CASES = ("industrial_poly", "CSTR", "batch_reactor", "oscillating_masses")

@@ -1,0 +1,79 @@
+"""Three rotating discs coupled by springs, driven by two stepper motors; NMPC tracking a time-varying set-point for
+the middle disc (the controller of the reference's MHE + MPC example).
+
+Equations / tuning: /root/reference/examples/rotating_oscillating_masses_mhe_mpc/template_model.py:34-99,
+template_mpc.py:34-106, main.py:52-63.  The only shipped MPC example with time-varying parameters on the path: the
+set-point `phi_2_set` is a random staircase (seed 999) read over the horizon; the model also declares the measurement
+weights `P_v` (5x5 `_tvp`) and `P_p` (`_p`) that only its estimator uses - they are kept so that the parameter vector
+has the reference's layout.  Two values of the inertia `Theta_1` are declared but `n_robust = 0`: one scenario, nominal.
+"""
+import numpy as np
+
+from .. import MPC, Model
+from ..sym import DM, vertcat, vertsplit
+
+N_TRAJ = 400
+X0 = np.zeros(8)                                       # main.py:58 (the controller starts from the estimator's x0 = 0)
+
+
+def setpoint_trajectory():
+    """template_mpc.py:63-73."""
+    rng = np.random.RandomState(999)
+    traj = [0.0]
+    for _ in range(N_TRAJ):
+        nxt = (0.5 - rng.rand()) * np.pi
+        switch = rng.rand() >= 0.95
+        traj.append((1 - switch) * traj[-1] + switch * nxt)
+    return np.array(traj)
+
+
+def build_model(symvar_type="SX"):
+    mdl = Model("continuous", symvar_type)
+    phi = vertcat(*[mdl.set_variable("_x", "phi_%d" % i) for i in (1, 2, 3)])
+    dphi = mdl.set_variable("_x", "dphi", shape=(3, 1))
+    phi_m_set = mdl.set_variable("_u", "phi_m_set", shape=(2, 1))
+    phi_m = mdl.set_variable("_x", "phi_m", shape=(2, 1))
+    mdl.set_variable("_tvp", "phi_2_set")
+    mdl.set_variable("_p", "P_p")
+    mdl.set_variable("_tvp", "P_v", shape=(5, 5))
+    mdl.set_meas("phi_1_meas", phi)
+    mdl.set_meas("phi_m_set_meas", phi_m_set)
+    th = [mdl.set_variable("_p", "Theta_%d" % i) for i in (1, 2, 3)]
+    c = np.array([2.697, 2.66, 3.05, 2.86]) * 1e-3       # spring constants
+    d = np.array([6.78, 8.01, 8.82]) * 1e-5              # friction
+    for i in range(3):
+        mdl.set_rhs("phi_%d" % (i + 1), dphi[i])
+    left = [phi_m[0], phi[0], phi[1]]
+    right = [phi[1], phi[2], phi_m[1]]
+    mdl.set_rhs("dphi", vertcat(*[-c[i] / th[i] * (phi[i] - left[i]) - c[i + 1] / th[i] * (phi[i] - right[i])
+                                  - d[i] / th[i] * dphi[i] for i in range(3)]))
+    mdl.set_rhs("phi_m", 1 / 1e-2 * (phi_m_set - phi_m))
+    mdl.setup()
+    return mdl
+
+
+def build_mpc(model, silence_solver=True, **overrides):
+    mpc = MPC(model)
+    st = mpc.settings
+    st.n_robust, st.n_horizon, st.t_step, st.store_full_solution = 0, 20, 0.1, True
+    for k, v in overrides.items():
+        setattr(st, k, v)
+    if silence_solver:
+        st.supress_ipopt_output()
+    mpc.set_objective(mterm=DM(1), lterm=(model.x["phi_2"] - model.tvp["phi_2_set"]) ** 2)
+    mpc.set_rterm(phi_m_set=1e-2)
+    traj = setpoint_trajectory()
+    tvp_template = mpc.get_tvp_template()
+
+    def tvp_fun(t_now):
+        ind = int(t_now / st.t_step)
+        tvp_template["_tvp", :-1] = vertsplit(traj[ind:ind + st.n_horizon])   # (every entry of the stage, like the template)
+        return tvp_template
+
+    mpc.set_tvp_fun(tvp_fun)
+    mpc.set_uncertainty_values(Theta_1=2.25e-4 * np.array([1.0, 1.1]), Theta_2=2.25e-4 * np.array([1.0]),
+                               Theta_3=2.25e-4 * np.array([1.0]))
+    mpc.bounds["lower", "_u", "phi_m_set"] = -5
+    mpc.bounds["upper", "_u", "phi_m_set"] = 5
+    mpc.setup()
+    return mpc

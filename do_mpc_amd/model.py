@@ -82,6 +82,7 @@ class VarGroup:
 
 
 _VAR_TYPES = ("_x", "_u", "_z", "_p", "_tvp", "_w", "_v")
+_LONG_VAR_TYPES = {"states": "_x", "inputs": "_u", "algebraic": "_z", "parameter": "_p", "timevarying_parameter": "_tvp"}
 
 
 class Model:
@@ -113,9 +114,11 @@ class Model:
 
     # ---------------------------------------------------------------- queries
     def __getitem__(self, ind):
+        """`model['x']`, `model['x', 'tvp']`: the variable groups themselves (name-indexable, `.cat` for the vector),
+        like the structures the reference hands out (_model.py:165-200)."""
         if isinstance(ind, tuple):
-            return [self._getvar(i).cat for i in ind]
-        return self._getvar(ind).cat
+            return [self._getvar(i) for i in ind]
+        return self._getvar(ind)
 
     def _getvar(self, var_name: str) -> VarGroup:
         if var_name.startswith("_"):
@@ -153,6 +156,7 @@ class Model:
         assert isinstance(var_type, str), "var_type must be str, you have: {}".format(type(var_type))
         assert isinstance(var_name, str), "var_name must be str, you have: {}".format(type(var_name))
         assert isinstance(shape, (tuple, int)), "shape must be tuple or int, you have: {}".format(type(shape))
+        var_type = _LONG_VAR_TYPES.get(var_type, var_type)          # long names (_model.py:596-601)
         if var_type not in _VAR_TYPES:
             raise Exception("Trying to set non-existing variable var_type: {} with var_name {}".format(var_type, var_name))
         if isinstance(shape, int):
@@ -218,7 +222,7 @@ class Model:
             if self.alg_list else sym.SX([], (0, 1))
         if self._alg.numel() != self.n_z:
             raise Exception(f"{self.n_z} algebraic states but {self._alg.numel()} algebraic equations")
-        _x, _u, _z, _tvp, _p, _w, _v = self["x", "u", "z", "tvp", "p", "w", "v"]
+        _x, _u, _z, _tvp, _p, _w, _v = (self._getvar(k).cat for k in ("x", "u", "z", "tvp", "p", "w", "v"))
         self._rhs_fun = sym.Function("rhs_fun", [_x, _u, _z, _tvp, _p, _w], [self._rhs])
         self._alg_fun = sym.Function("alg_fun", [_x, _u, _z, _tvp, _p, _w], [self._alg])
         self._aux_expression_fun = sym.Function("aux_expression_fun", [_x, _u, _z, _tvp, _p], [self._aux.cat])

@@ -207,6 +207,8 @@ class NumStruct:
             v = v.reshape(-1)
         elif v.size == idx.size:
             v = v.reshape(idx.shape)
+        elif idx.ndim == 2 and v.size == idx.shape[0]:
+            v = v.reshape(-1, 1)          # a list of scalars over a sliced repeat: one value per block (casadi payload unpacking)
         self.master[idx] = v
 
     def get(self, *key) -> np.ndarray:

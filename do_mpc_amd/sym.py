@@ -722,6 +722,15 @@ def vertcat(*args) -> SX:
     return SX(data, (n, m))
 
 
+def vertsplit(x, incr: int = 1) -> list:
+    """`casadi.vertsplit(x, incr)`: the row blocks of x (numeric input -> DM blocks, symbolic -> SX blocks)."""
+    if isinstance(x, SX):
+        return [x[i:i + incr, :] for i in range(0, x.shape[0], incr)]
+    a = x.arr if isinstance(x, DM) else np.asarray(x, dtype=float)
+    a = a.reshape(-1, 1) if a.ndim < 2 else a
+    return [DM(a[i:i + incr, :]) for i in range(0, a.shape[0], incr)]
+
+
 def horzcat(*args) -> SX:
     parts = [_sx(a) for a in args]
     parts = [p for p in parts if p.numel() > 0]

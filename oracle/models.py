@@ -246,7 +246,32 @@ def case_kite(**over):
     return d
 
 
-CASES = {"industrial_poly": case_industrial_poly, "CSTR": case_CSTR,
+def case_rotating_masses(**over):
+    """/root/reference/examples/rotating_oscillating_masses_mhe_mpc/template_model.py:34-99, template_mpc.py:34-106:
+    three spring-coupled discs, two motors, set-point for the middle disc as a time-varying parameter.  The 5x5 `_tvp`
+    P_v and the `_p` P_p belong to the example's estimator; declared so that the parameter vector has the same layout."""
+    x = sp.symbols("phi_1 phi_2 phi_3 dphi_0 dphi_1 dphi_2 phi_m_0 phi_m_1")
+    u = sp.symbols("phi_m_set_0 phi_m_set_1")
+    p = sp.symbols("P_p Theta_1 Theta_2 Theta_3")
+    tvp = (sp.Symbol("phi_2_set"),) + sp.symbols("P_v_0:25")
+    phi, dphi, phi_m = x[0:3], x[3:6], x[6:8]
+    th = p[1:]
+    c = np.array([2.697, 2.66, 3.05, 2.86]) * 1e-3
+    d = np.array([6.78, 8.01, 8.82]) * 1e-5
+    left, right = [phi_m[0], phi[0], phi[1]], [phi[1], phi[2], phi_m[1]]
+    rhs = list(dphi) + [-c[i] / th[i] * (phi[i] - left[i]) - c[i + 1] / th[i] * (phi[i] - right[i]) - d[i] / th[i] * dphi[i]
+                        for i in range(3)] + [1 / 1e-2 * (u[i] - phi_m[i]) for i in range(2)]
+    dd = _base(name="rotating_masses", x=x, u=u, p=p, tvp=tvp, rhs=rhs, lterm=(phi[1] - tvp[0]) ** 2, mterm=sp.Integer(1),
+               rterm=np.array([1e-2, 1e-2]), n_horizon=20, n_robust=0, t_step=0.1,
+               x_lb=-np.inf * np.ones(8), x_ub=np.inf * np.ones(8), u_lb=-5.0 * np.ones(2), u_ub=5.0 * np.ones(2),
+               x_scaling=np.ones(8), u_scaling=np.ones(2), x0=np.zeros(8), aux={},
+               uncertainty={"Theta_1": 2.25e-4 * np.array([1.0, 1.1]), "Theta_2": 2.25e-4 * np.array([1.0]),
+                            "Theta_3": 2.25e-4 * np.array([1.0])})
+    dd.update(over)
+    return dd
+
+
+CASES = {"rotating_masses": case_rotating_masses, "industrial_poly": case_industrial_poly, "CSTR": case_CSTR,
          "batch_reactor": case_batch_reactor, "oscillating_masses": case_oscillating_masses,
          "kinematic_bicycle": case_kinematic_bicycle, "dynamic_bicycle": case_dynamic_bicycle, "kite": case_kite}
 

@@ -79,6 +79,8 @@ class OracleNLP:
     def __init__(self, case):
         self.case = c = case
         self.nx, self.nu, self.np_ = len(c["x"]), len(c["u"]), len(c["p"])
+        self.ntvp = len(c.get("tvp", ()))
+        self.nq = self.np_ + self.ntvp            # per-edge parameter columns: scenario parameters, then the stage's _tvp
         nx, nu = self.nx, self.nu
         self.N = N = c["n_horizon"]
         self.discrete = c["model_type"] == "discrete"
@@ -104,8 +106,9 @@ class OracleNLP:
         self.off_eps = self.off_u + N * self.S_u * nu
         self.n_opt_x = self.off_eps + self.n_eps * S * self.n_slack
         self.p_off_x0 = 0
-        self.p_off_p = nx  # ntvp == 0
-        self.p_off_uprev = nx + n_comb * self.np_
+        self.p_off_tvp = nx                         # _tvp: N+1 stages (_mpc.py:1160-1165)
+        self.p_off_p = nx + (N + 1) * self.ntvp
+        self.p_off_uprev = self.p_off_p + n_comb * self.np_
         self.n_opt_p = self.p_off_uprev + nu
 
         # ---- tree (optimizer.py:1011-1048)
@@ -155,6 +158,9 @@ class OracleNLP:
         sub = {c["x"][i]: xs[i] * float(self.sx[i]) for i in range(nx)}
         sub.update({c["u"][i]: us[i] * float(self.su[i]) for i in range(nu)})
         sub.update({c["p"][i]: ps[i] for i in range(self.np_)})
+        tv = sp.symbols(f"tv0:{self.ntvp}") if self.ntvp else ()
+        sub.update({c["tvp"][i]: tv[i] for i in range(self.ntvp)})
+        ps = tuple(ps) + tuple(tv)
         v = list(xs) + list(us)
         args = list(xs) + list(us) + list(ps)
         scale = 1.0 if self.discrete else self.h
@@ -175,7 +181,8 @@ class OracleNLP:
         self.G = _Lam(G, args)
         self.JG = _Lam([sp.diff(g, a) for g in G for a in v], args)
         self.HG = _Lam([sp.diff(g, a, b) for g in G for a in v for b in v], args)
-        self.aux = {k: sp.lambdify(list(c["x"]) + list(c["u"]) + list(c["p"]), e, "numpy") for k, e in c["aux"].items()}
+        self.aux = {k: sp.lambdify(list(c["x"]) + list(c["u"]) + list(c["p"]) + list(c.get("tvp", ())), e, "numpy")
+                    for k, e in c["aux"].items()}
 
     # ------------------------------------------------------------------ bounds (_mpc.py:1061-1095)
     def _build_bounds(self):
@@ -245,9 +252,14 @@ class OracleNLP:
             self.col_next = nxt
 
     # ------------------------------------------------------------------ evaluation pieces
-    def _pvals(self, p):
-        P = p[self.p_off_p:self.p_off_uprev].reshape(self.n_comb, self.np_)
-        return P[self.pidx]  # (E, np)
+    def _pvals(self, p, terminal=False):
+        """(E, nq): the edge's scenario parameters and the _tvp of its stage k (of stage k+1 for the terminal cost:
+        _mpc.py:1254-1256 evaluates mterm with opt_p['_tvp', n_horizon])."""
+        P = p[self.p_off_p:self.p_off_uprev].reshape(self.n_comb, self.np_)[self.pidx]
+        if self.ntvp:
+            T = p[self.p_off_tvp:self.p_off_p].reshape(self.N + 1, self.ntvp)
+            P = np.concatenate([P, T[self.edges[:, 0] + (1 if terminal else 0)]], axis=1)
+        return P
 
     def _stage_cols(self, x, p):
         """columns for (x_parent,u,p) per edge -> list of 1-D arrays."""
@@ -270,11 +282,11 @@ class OracleNLP:
         xs = Xpt[:, :, 1:, :].reshape(E * ni * deg, self.nx)
         us = np.repeat(U, ni * deg, axis=0)
         ps = np.repeat(P, ni * deg, axis=0)
-        cols = [xs[:, i] for i in range(self.nx)] + [us[:, i] for i in range(self.nu)] + [ps[:, i] for i in range(self.np_)]
+        cols = [xs[:, i] for i in range(self.nx)] + [us[:, i] for i in range(self.nu)] + [ps[:, i] for i in range(self.nq)]
         return cols, E * ni * deg
 
     def _st_args(self, Xp, U, P):
-        return [Xp[:, i] for i in range(self.nx)] + [U[:, i] for i in range(self.nu)] + [P[:, i] for i in range(self.np_)], self.E
+        return [Xp[:, i] for i in range(self.nx)] + [U[:, i] for i in range(self.nu)] + [P[:, i] for i in range(self.nq)], self.E
 
     # ------------------------------------------------------------------ NLP functions
     def f(self, x, p):
@@ -285,7 +297,8 @@ class OracleNLP:
         obj = np.sum(w * self.L(cols, n)[0])
         last = k == self.N - 1
         Xc = x[self.col_xch[:, None] + np.arange(self.nx)]
-        colm = [Xc[:, i] for i in range(self.nx)] + [P[:, i] for i in range(self.np_)]
+        Pm = self._pvals(p, terminal=True)
+        colm = [Xc[:, i] for i in range(self.nx)] + [Pm[:, i] for i in range(self.nq)]
         obj += np.sum((w * self.Mt(colm, n)[0])[last])
         up = p[self.p_off_uprev:] / self.su
         Uprev = np.where((self.col_uprev >= 0)[:, None], x[np.maximum(self.col_uprev, 0)[:, None] + np.arange(self.nu)], up)
@@ -308,7 +321,8 @@ class OracleNLP:
         np.add.at(g, self.col_u[:, None] + np.arange(nu), gl[nx:].T)
         last = k == self.N - 1
         Xc = x[self.col_xch[:, None] + np.arange(nx)]
-        colm = [Xc[:, i] for i in range(nx)] + [P[:, i] for i in range(self.np_)]
+        Pm = self._pvals(p, terminal=True)
+        colm = [Xc[:, i] for i in range(nx)] + [Pm[:, i] for i in range(self.nq)]
         gm = self.gM(colm, n) * w
         np.add.at(g, self.col_xch[last][:, None] + np.arange(nx), gm[:, last].T)
         up = p[self.p_off_uprev:] / self.su
@@ -438,7 +452,8 @@ class OracleNLP:
         put_block(vcols, vcols, HL)
         last = k == self.N - 1
         Xc = x[self.col_xch[:, None] + np.arange(nx)]
-        colm = [Xc[:, i] for i in range(nx)] + [P[:, i] for i in range(self.np_)]
+        Pm = self._pvals(p, terminal=True)
+        colm = [Xc[:, i] for i in range(nx)] + [Pm[:, i] for i in range(self.nq)]
         HM = self.HM(colm, n).T.reshape(E, nx, nx) * w[:, None, None]
         cc = self.col_xch[:, None] + np.arange(nx)
         put_block(cc[last], cc[last], HM[last])
@@ -475,9 +490,11 @@ class OracleNLP:
         return sps.csr_matrix((V[keep], (R[keep], Cc[keep])), shape=(self.n_opt_x, self.n_opt_x))
 
     # ------------------------------------------------------------------ protocol helpers
-    def opt_p(self, x0, u_prev=None):
+    def opt_p(self, x0, u_prev=None, tvp=None):
         p = np.zeros(self.n_opt_p)
         p[:self.nx] = np.asarray(x0, float).ravel()
+        if tvp is not None:
+            p[self.p_off_tvp:self.p_off_p] = np.asarray(tvp, float).reshape(self.N + 1, self.ntvp).ravel()
         p[self.p_off_p:self.p_off_uprev] = self.p_values.ravel()
         if u_prev is not None:
             p[self.p_off_uprev:] = np.asarray(u_prev, float).ravel()

@@ -47,6 +47,17 @@ def golden(name):
     return np.load(os.path.join(GOLD, name + ".npz"))
 
 
+def golden_opt_p(name, g, k, n_opt_p):
+    """opt_p of golden step k in the current layout.  The rotating-masses golden was stored by a release whose parameter
+    struct had N `_tvp` stages; today's (_mpc.py:1160-1165) has N+1, the last one only read by mterm (constant here)."""
+    P = g["mpc.opt_p_num"][k]
+    if P.size == n_opt_p:
+        return P
+    assert name == "rotating_masses" and n_opt_p - P.size == 26
+    cut = 8 + 20 * 26
+    return np.concatenate([P[:cut], np.zeros(26), P[cut:]])
+
+
 def relerr(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
 
@@ -70,7 +81,7 @@ def check_golden_replay(make_mpc, name, steps):
         assert relerr(u0, U[k]) < U_RTOL, (name, k, u0, U[k])
         assert relerr(mpc.opt_x_num_unscaled.master[used], OX[k][used]) < X_RTOL
         assert np.max(np.abs(mpc.lam_g_num - LG[k])) < 1e-2 * max(1.0, np.max(np.abs(LG[k])))
-        assert np.allclose(mpc.opt_p_num.master, g["mpc.opt_p_num"][k], rtol=0, atol=1e-12)
+        assert np.allclose(mpc.opt_p_num.master, golden_opt_p(name, g, k, mpc.opt_p_num.master.size), rtol=0, atol=1e-12)
         mpc.u0 = U[k]
     # stored records have the reference's shapes
     assert mpc.data["_u"].shape == (steps, mpc.model.n_u)
@@ -93,7 +104,9 @@ def check_against_oracle_solve(make_mpc, name, x0_scale=1.0, oracle_opts=None, *
     mpc.set_initial_guess()
     u0 = mpc.make_step(x0).ravel()
     assert mpc.solver_stats["success"], mpc.solver_stats
-    r = ipm.solve(nlp, nlp.initial_guess(x0), nlp.opt_p(x0, np.zeros(nlp.nu)), opts=oracle_opts)
+    p_in = mpc.opt_p_num.master.copy()                 # (x0, _tvp over the horizon, scenario parameters, u_prev = 0)
+    assert p_in.size == nlp.n_opt_p and (nlp.ntvp > 0 or np.array_equal(p_in, nlp.opt_p(x0, np.zeros(nlp.nu))))
+    r = ipm.solve(nlp, nlp.initial_guess(x0), p_in, opts=oracle_opts)
     assert r["stats"]["success"]
     assert relerr(u0, nlp.u0_of(r["x"])) < U_RTOL, (u0, nlp.u0_of(r["x"]))
     if oracle_opts:      # non-convex case: same local solution, not merely the same first input
@@ -160,7 +173,7 @@ def check_sweep_blocks(mpc, name, to_dev, from_dev, B=3, seed=1):
     s = nlp.scaling_vector()
     X = np.stack([g["mpc._opt_x_num"][k % 5] / s * (1 + 1e-3 * rng.standard_normal(ps.n_opt_x)) for k in range(B)])
     LAM = np.stack([g["mpc._lam_g_num"][k % 5] for k in range(B)])
-    P = np.stack([g["mpc.opt_p_num"][k % 5] for k in range(B)])
+    P = np.stack([golden_opt_p(name, g, k % 5, nlp.n_opt_p) for k in range(B)])
     blk = mpc.S.sweep_block_doubles
     dX, dL, dP = to_dev(X), to_dev(LAM), to_dev(P)
     dG, dB = to_dev(np.zeros((B, ps.n_g))), to_dev(np.zeros((B, ps.n_edges, blk)))

@@ -36,12 +36,13 @@ def test_native_code_is_what_runs():
     assert mpc.S.num_slots >= 1 and mpc.S.workspace_bytes > 0
 
 
-@pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 5), ("industrial_poly", 5)])
+@pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 5), ("industrial_poly", 5),
+                                        ("rotating_masses", 5)])
 def test_golden_replay(name, steps):
     pc.check_golden_replay(make_mpc, name, steps)
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly", "rotating_masses"])
 def test_newton_direction_matches_sparse_kkt_solve(name):
     pc.check_newton_step(make_mpc, name)
 

@@ -15,12 +15,13 @@ def make_mpc(name, **kw):
         return ex.build_mpc(ex.build_model(), **kw)
 
 
-@pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 3), ("industrial_poly", 2)])
+@pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 3), ("industrial_poly", 2),
+                                        ("rotating_masses", 5)])
 def test_golden_replay(name, steps):
     pc.check_golden_replay(make_mpc, name, steps)
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly", "rotating_masses"])
 def test_newton_direction_matches_sparse_kkt_solve(name):
     pc.check_newton_step(make_mpc, name)
 
@@ -31,7 +32,7 @@ def test_newton_direction_with_inertia_correction(name):
     pc.check_newton_step(make_mpc, name, delta=0.05)
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly", "rotating_masses"])
 def test_sweep_blocks_match_oracle_jacobian(name):
     mpc = make_mpc(name)
     pc.check_sweep_blocks(mpc, name, pc.HostArr, lambda d: d.a)

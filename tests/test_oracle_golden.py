@@ -19,6 +19,7 @@ import os
 import numpy as np
 import pytest
 
+from parity_common import golden_opt_p
 from oracle import ipm
 from oracle.models import CASES
 from oracle.nlp import OracleNLP, collocation_coeffs
@@ -43,11 +44,12 @@ def test_radau_coefficients():
     assert np.allclose(D, [0, 0, 1])
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly", "rotating_masses"])
 def test_golden_point_is_kkt_point_of_restated_nlp(name):
     nlp = _nlp(name)
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    X, LG, P = g["mpc._opt_x_num"], g["mpc._lam_g_num"], g["mpc.opt_p_num"]
+    X, LG = g["mpc._opt_x_num"], g["mpc._lam_g_num"]
+    P = np.stack([golden_opt_p(name, g, k, nlp.n_opt_p) for k in range(X.shape[0])])
     assert (nlp.n_opt_x, nlp.n_g, nlp.n_opt_p) == (X.shape[1], LG.shape[1], P.shape[1])
     s = nlp.scaling_vector()
     for k in range(X.shape[0]):
@@ -64,17 +66,19 @@ def test_golden_point_is_kkt_point_of_restated_nlp(name):
 
 
 @pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 3),
-                                        ("industrial_poly", 2)])
+                                        ("industrial_poly", 2), ("rotating_masses", 5)])
 def test_open_loop_replay_matches_golden_u(name, steps):
     case = CASES[name]()
     nlp = _nlp(name)
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    U, Xs, P, LG = g["mpc._u"], g["mpc._x"], g["mpc.opt_p_num"], g["mpc._lam_g_num"]
+    U, Xs, LG = g["mpc._u"], g["mpc._x"], g["mpc._lam_g_num"]
     xg = nlp.initial_guess(case["x0"])
     u_prev = np.zeros(nlp.nu)
     for k in range(steps):
-        p = nlp.opt_p(Xs[k], u_prev)
-        assert np.allclose(p, P[k], rtol=0, atol=1e-12)
+        Pk = golden_opt_p(name, g, k, nlp.n_opt_p)
+        tvp = Pk[nlp.p_off_tvp:nlp.p_off_p] if nlp.ntvp else None      # (the set-point staircase the reference read)
+        p = nlp.opt_p(Xs[k], u_prev, tvp)
+        assert np.allclose(p, Pk, rtol=0, atol=1e-12)
         r = ipm.solve(nlp, xg, p)
         assert r["stats"]["success"]
         u0 = nlp.u0_of(r["x"])

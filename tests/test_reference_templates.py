@@ -20,7 +20,8 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree n
 
 DIRS = {"industrial_poly": "industrial_poly", "CSTR": "CSTR", "batch_reactor": "batch_reactor",
         "oscillating_masses": "oscillating_masses_discrete", "kinematic_bicycle": "kinematic_bicycle_model",
-        "dynamic_bicycle": "dynamic_bicycle_model", "kite": "kite"}
+        "dynamic_bicycle": "dynamic_bicycle_model", "kite": "kite",
+        "rotating_masses": "rotating_oscillating_masses_mhe_mpc"}
 MPC_ARGS = {"kite": (10.0, 6.0)}           # template_mpc(model, w_ref, E_0, h_min=100): main.py draws them at random
 
 

@@ -31,6 +31,7 @@ CASES = {
     "CSTR": "results_CSTR.pkl",
     "batch_reactor": "results_batch_reactor.pkl",
     "oscillating_masses": "results_oscillatingMasses.pkl",
+    "rotating_masses": "results_rotatingMasses.pkl",
 }
 
 
