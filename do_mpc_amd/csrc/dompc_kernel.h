@@ -474,6 +474,9 @@ struct Prob {
   double sf;                                         // objective scaling
   double mu;
   int soc;                                           // second-order correction solve: the constraint residual c is an INPUT of the sweep
+  double dsw;                                        // inertia correction that the sweep has already folded into the condensed blocks
+                                                     // (Sigma_w + dsw in Q~, q~ and in the stored Sigma_w): the Riccati passes add
+                                                     // only delta - dsw on the eliminated variables (0 in the common case)
   int slot;                                          // workspace slot of the problem (rebuilds this view inside outlined functions)
   DOMPC_DEV double& EW(int e, int i) const { return ew[(int64_t)e * EW_SIZE + i]; }
   DOMPC_DEV double* ES(int e) const { return es + (int64_t)e * ES_SIZE; }
@@ -492,7 +495,7 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   p.s = w + L.s; p.zsl = w + L.zsl; p.zsu = w + L.zsu; p.sl = w + L.sl; p.su = w + L.su;
   p.ds = w + L.ds; p.st = w + L.st; p.ds_sv = w + L.ds_sv;
   p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo;
-  p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0; p.slot = slot;
+  p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0; p.dsw = 0.0; p.slot = slot;
   return p;
 }
 
@@ -1467,7 +1470,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
             const int row = p * NX + (i < NX ? i : 0);
             const double wv = Wm(row, j < NA ? j : 0), w0v = Wm(row, NA);
             const double hv = MOV(MO_PT + p * PT_STRIDE + NX + NX * NA + symi(i < NA ? i : 0, j < NA ? j : 0, NA));
-            const double sg = Ld[EL_SG + row], rw = Ld[EL_RW + row];
+            const double sg = Ld[EL_SG + row] + Q.dsw, rw = Ld[EL_RW + row];
             Z[r] = (i < NX) ? (j < NA ? wv : 0.0) : ((i < NA && j == i) ? 1.0 : 0.0);
             z0[r] = (j == 0 && i < NX) ? w0v : 0.0;
             H[r] = (i < NA && j < NA) ? hv + ((i == j && i < NX) ? sg : 0.0) : 0.0;
@@ -1485,7 +1488,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
             const int i = g + 4 * r;
             const int row = (M - 1) * NX + (i < NX ? i : 0);
             const double wv = Wm(row, j < NA ? j : 0), w0v = Wm(row, NA);
-            const double sg = Ld[EL_SG + row], rw = Ld[EL_RW + row];
+            const double sg = Ld[EL_SG + row] + Q.dsw, rw = Ld[EL_RW + row];
             Wk[r] = (i < NX && j < NA) ? wv : 0.0;
             SWk[r] = (i < NX && j < NA) ? sg * wv : 0.0;
             sv0[r] = (j == 0 && i < NX) ? sg * w0v + rw : 0.0;
@@ -1518,7 +1521,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     if (act) {
       for (int it = lane; it < NW * (NA + 1); it += GS) {
         const int row = it / (NA + 1), b = it % (NA + 1);
-        double t = Ld[EL_SG + row] * Ld[EL_MX + row * MX_LD + MX_W + b];
+        double t = (Ld[EL_SG + row] + Q.dsw) * Ld[EL_MX + row * MX_LD + MX_W + b];
         if (b == NA) {            // the w0 column: small mat-vec on the vector units
           const int sl = row / NX, a = row % NX;
           const int p = point_of_slot(sl);
@@ -1643,7 +1646,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       for (int it = lane; it < NW * NA; it += GS) Q.EW(e, EW_W + it) = Ld[EL_MX + (it / NA) * MX_LD + MX_W + it % NA];
       for (int r = lane; r < NW; r += GS) {
         Q.EW(e, EW_W0 + r) = Ld[EL_MX + r * MX_LD + MX_W + NA];
-        Q.EW(e, EW_SIGW + r) = Ld[EL_SG + r];
+        Q.EW(e, EW_SIGW + r) = Ld[EL_SG + r] + Q.dsw;
         Q.EW(e, EW_RW + r) = Ld[EL_RW + r];
       }
     }
@@ -1880,7 +1883,7 @@ DOMPC_DEV inline void node_prefetch(const Prob& Q, int n, double delta, int lane
   const int xo = A.node_x_off[n], uo = A.node_u_off[n];
   const int eo = NS > 0 ? A.node_eps_off[n] : -1;
   const int ie = A.node_in_edge[n], pn = A.node_parent[n];
-  const bool wd = delta != 0.0;
+  const bool wd = delta != Q.dsw;                    // (delta - dsw on the eliminated variables: see Prob::dsw)
 #pragma unroll
   for (int q = 0; q < RN_IPL; ++q) {
     const int it = lane + q * GS;
@@ -1933,6 +1936,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
                                   bool child_staged, const NodePre& R) {
   using namespace rb;
   const KArgs& A = *Q.A;
+  const double dxw = delta - Q.dsw;                   // share of delta that the condensed blocks do not hold yet (Prob::dsw)
   double* Nd = Q.ND(n);
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
@@ -1953,11 +1957,11 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
     const int yi = yidx(itc / NYT), yj = yidx(itc % NYT);
     const bool valid = it < NYT * NYT && yi >= 0 && yj >= 0;
     const int idx = valid ? yi * NA + yj : 0;
-    double v = R.qt[q] + delta * R.wtw[q];
+    double v = R.qt[q] + dxw * R.wtw[q];
     for (int c = 1; c < cc; ++c) {
       const double* S_ = Q.ES(cs + c);
       double t = S_[ES_QT + idx];
-      if (delta != 0.0 && valid) t += delta * wtw_entry(Q, cs + c, yi, yj);
+      if (dxw != 0.0 && valid) t += dxw * wtw_entry(Q, cs + c, yi, yj);
       v += t;
     }
     qacc[q] = valid ? v : 0.0;
@@ -1987,11 +1991,11 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
         gv += cc * Q.sf * DOMPC_EPS_PEN[i - NA - NU];
       }
     }
-    gv += R.pv[v][7] + R.pv[v][8] + delta * R.pv[v][9];
+    gv += R.pv[v][7] + R.pv[v][8] + dxw * R.pv[v][9];
     if (yi >= 0)
       for (int c = 1; c < cc; ++c) {
         const double* S_ = Q.ES(cs + c);
-        gv += S_[ES_RY + yi] + S_[ES_QV + yi] + (delta != 0.0 ? delta * wtw0_entry(Q, cs + c, yi) : 0.0);
+        gv += S_[ES_RY + yi] + S_[ES_QV + yi] + (dxw != 0.0 ? dxw * wtw0_entry(Q, cs + c, yi) : 0.0);
       }
     gvv[v] = gv;
     dgv[v] = dg;
@@ -2253,6 +2257,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
                                       int GS, int phase) {
   using namespace rb;
   const KArgs& A = *Q.A;
+  const double dxw = delta - Q.dsw;
   double* Nd = Q.ND(n);
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const int ci = A.node_cut[n];
@@ -2305,7 +2310,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
         if (!counted(c)) continue;
         const int e = cs + c;
         const double* S_ = Q.ES(e);
-        if (yi >= 0) gv += S_[ES_RY + yi] + S_[ES_QV + yi] + (delta != 0.0 ? delta * wtw0_entry(Q, e, yi) : 0.0);
+        if (yi >= 0) gv += S_[ES_RY + yi] + S_[ES_QV + yi] + (dxw != 0.0 ? dxw * wtw0_entry(Q, e, yi) : 0.0);
         if (NE > 0) {
           const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
           for (int q = 0; q < NE; ++q) {
@@ -2332,7 +2337,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
         const double* S_ = Q.ES(e);
         if (yi >= 0 && yj >= 0) {
           v += S_[ES_QT + yi * NA + yj];
-          if (delta != 0.0) v += delta * wtw_entry(Q, e, yi, yj);
+          if (dxw != 0.0) v += dxw * wtw_entry(Q, e, yi, yj);
         }
         if (NE > 0)
           for (int qq = 0; qq < NE; ++qq) {
@@ -2625,6 +2630,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
 // One group of lanes per node (level by level), then one group per edge.
 DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double delta) {
   const KArgs& A = *Q.A;
+  const double dxw = delta - Q.dsw;
   const int GS = T.gs, ng = T.nt / GS, gid = group_index(T.tid, GS), lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   // operands of a chain-node step, staged in LDS: own gains [K | kv], the child edge's [A B | c], the first NX rows of
@@ -2915,7 +2921,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         const int r = lane + q * GS;
         if (r < NW) {
           const int sl = r / NX;
-          double t = rw_r[q] + (sg_r[q] + delta) * Ld[RF_DW + r];
+          double t = rw_r[q] + (sg_r[q] + dxw) * Ld[RF_DW + r];      // (the stored Sigma_w already holds Prob::dsw)
           if (r >= (M - 1) * NX) t += Ld[RF_DNU + r - (M - 1) * NX];
 #pragma unroll
           for (int b = 0; b < NX; ++b) t += hrow[q][b] * Ld[RF_DW + sl * NX + b];
@@ -3387,19 +3393,22 @@ struct PhaseRet3 { unsigned gen, nred, xseq; double v0, v1, v2; };
   T.gen = ufl(gen); T.nred = ufl(nred); T.xseq = ufl(xseq);                         \
   Prob Q = make_prob(A, ufl(slot), A.p + (int64_t)ufl(b) * A.n_opt_p);              \
   Q.sf = ufl(sf);
-__device__ __attribute__((noinline)) PhaseRet phase_sweep(const void* kp, int b, int slot, double sf, double mu, int soc, unsigned gen, unsigned nred, unsigned xseq) {
+__device__ __attribute__((noinline)) PhaseRet phase_sweep(const void* kp, int b, int slot, double sf, double mu, double dsw, int soc, unsigned gen, unsigned nred, unsigned xseq) {
   DOMPC_PHASE_PROLOGUE
   Q.soc = ufl(soc);
+  Q.dsw = ufl(dsw);
   const int rc = sweep(T, Q, ufl(mu));
   return PhaseRet{T.gen, T.nred, T.xseq, rc};
 }
-__device__ __attribute__((noinline)) PhaseRet phase_backward(const void* kp, int b, int slot, double sf, double mu, double delta, unsigned gen, unsigned nred, unsigned xseq) {
+__device__ __attribute__((noinline)) PhaseRet phase_backward(const void* kp, int b, int slot, double sf, double mu, double delta, double dsw, unsigned gen, unsigned nred, unsigned xseq) {
   DOMPC_PHASE_PROLOGUE
+  Q.dsw = ufl(dsw);
   const int rc = riccati_backward(T, Q, ufl(mu), ufl(delta));
   return PhaseRet{T.gen, T.nred, T.xseq, rc};
 }
-__device__ __attribute__((noinline)) PhaseRet phase_forward(const void* kp, int b, int slot, double sf, double mu, double delta, unsigned gen, unsigned nred, unsigned xseq) {
+__device__ __attribute__((noinline)) PhaseRet phase_forward(const void* kp, int b, int slot, double sf, double mu, double delta, double dsw, unsigned gen, unsigned nred, unsigned xseq) {
   DOMPC_PHASE_PROLOGUE
+  Q.dsw = ufl(dsw);
   riccati_forward(T, Q, ufl(mu), ufl(delta));
   return PhaseRet{T.gen, T.nred, T.xseq, 0};
 }
@@ -3425,9 +3434,11 @@ __device__ __attribute__((noinline)) PhaseRet3 phase_accept(const void* kp, int 
   const auto r_ = fn(T.kp, b, slot, Q.sf, __VA_ARGS__, T.gen, T.nred, T.xseq);            \
   T.gen = ufl(r_.gen); T.nred = ufl(r_.nred); T.xseq = ufl(r_.xseq);
 #endif
-DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu, int soc = 0) {
+// dsw: the inertia correction this sweep folds into the condensed blocks; remembered in Q for the Riccati passes
+DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu, int soc = 0, double dsw = 0.0) {
+  Q.dsw = dsw;
 #ifndef DOMPC_HOST_EMU
-  DOMPC_PHASE_CALL(phase_sweep, mu, soc)
+  DOMPC_PHASE_CALL(phase_sweep, mu, dsw, soc)
   return ufl(r_.rc);
 #else
   (void)b; (void)slot;
@@ -3439,7 +3450,7 @@ DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu
 }
 DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta) {
 #ifndef DOMPC_HOST_EMU
-  DOMPC_PHASE_CALL(phase_backward, mu, delta)
+  DOMPC_PHASE_CALL(phase_backward, mu, delta, Q.dsw)
   return ufl(r_.rc);
 #else
   (void)b; (void)slot;
@@ -3475,7 +3486,7 @@ DOMPC_DEV inline Comp run_accept(const Thr& T, const Prob& Q, int b, int slot, d
 }
 DOMPC_DEV inline void run_forward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta) {
 #ifndef DOMPC_HOST_EMU
-  DOMPC_PHASE_CALL(phase_forward, mu, delta)
+  DOMPC_PHASE_CALL(phase_forward, mu, delta, Q.dsw)
 #else
   (void)b; (void)slot;
   riccati_forward(T, Q, mu, delta);
@@ -3564,7 +3575,10 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   Q.sf = 1.0;
   long long c_sweep = 0, c_bwd = 0, c_fwd = 0, c_ls = 0, c_meas = 0, c_ftb = 0, c_acc = 0, c_t = 0; const long long c_start = prof_clock();
   if (T.tid == 0) T.fset(6, abort_requested(A));      // (read by everybody at the top of the loop, barriers in between)
-  int bad = run_sweep(T, Q, b, slot, mu);
+  // (singular0: every iteration is regularised and delta_w is known before its sweep - folded into the condensed blocks
+  //  there, Prob::dsw, instead of W'W being formed on demand by the Riccati pass: that path costs as much as the pass)
+  auto delta_after = [&](double last) { return last == 0.0 ? O.delta_w_0 : fmax(O.delta_w_min, O.kappa_w_minus * last); };
+  int bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(0.0) : 0.0);
   ++n_sweeps;
   if (O.obj_scaling) {
     double gm[1] = {0.0};
@@ -3574,7 +3588,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     wg_reduce(T, gm, ops);
     if (gm[0] > O.nlp_scaling_max_gradient) {
       Q.sf = fmax(O.nlp_scaling_max_gradient / gm[0], 1e-8);
-      bad = run_sweep(T, Q, b, slot, mu);
+      bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(0.0) : 0.0);
       ++n_sweeps;
     }
   }
@@ -3653,7 +3667,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       c_bwd += prof_clock() - c_t;
       if (!fail) break;
       if (delta == 0.0) {
-        delta = (delta_last == 0.0) ? O.delta_w_0 : fmax(O.delta_w_min, O.kappa_w_minus * delta_last);
+        delta = delta_after(delta_last);
       } else {
         delta *= (delta_last == 0.0 && first_try) ? O.kappa_w_plus_bar : O.kappa_w_plus;
         first_try = false;   // (IPOPT: the larger factor only on the very first increase)
@@ -3754,7 +3768,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         bool soc_ok = false;
         for (int k = 0; k < O.max_soc; ++k) {
           ++n_soc; ++n_sweeps;
-          if (run_sweep(T, Q, b, slot, mu, 1)) break;
+          if (run_sweep(T, Q, b, slot, mu, 1, delta)) break;
           if (run_backward(T, Q, b, slot, mu, delta)) break;
           run_forward(T, Q, b, slot, mu, delta);
           double q5[5];
@@ -3811,7 +3825,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     T.sync();
     c_acc += prof_clock() - c_t;
     ++it;
-    c_t = prof_clock(); bad = run_sweep(T, Q, b, slot, mu); c_sweep += prof_clock() - c_t;
+    c_t = prof_clock(); bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(delta_last) : 0.0); c_sweep += prof_clock() - c_t;
     ++n_sweeps;
     c_t = prof_clock(); E = measure(T, Q, &Cp); c_meas += prof_clock() - c_t;
   }

@@ -63,8 +63,9 @@ __device__ inline void load_edge(const Prob& Q, int e, int lane, d4& F, d4& f0, 
   fu = v;
 }
 
-// condensed Hessian block of edge e scattered into the z x z tile (+ delta W'W under inertia correction)
-__device__ inline d4 load_qt(const Prob& Q, int e, double delta, int lane) {
+// condensed Hessian block of edge e scattered into the z x z tile (+ dxw W'W: the share of an inertia correction that the
+// sweep has not folded into the block, Prob::dsw)
+__device__ inline d4 load_qt(const Prob& Q, int e, double dxw, int lane) {
   const int g = lane >> 4, j = lane & 15;
   const double* S_ = Q.ES(e);
   const int yj = yz(j);
@@ -75,7 +76,7 @@ __device__ inline d4 load_qt(const Prob& Q, int e, double delta, int lane) {
     const int yi = yz(i);
     const bool valid = i < NYT && j < NYT && yi >= 0 && yj >= 0;
     double v = valid ? S_[ES_QT + yi * NA + yj] : 0.0;
-    if (delta != 0.0 && valid) v += delta * wtw_entry(Q, e, yi, yj);
+    if (dxw != 0.0 && valid) v += dxw * wtw_entry(Q, e, yi, yj);
     t[r] = v;
   }
   return t;
@@ -200,6 +201,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   const int g = lane >> 4, j = lane & 15;
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
+  const double dxw = delta - Q.dsw;
   long long pc0 = prof_clock();
 #if DOMPC_PROFILE
 #define R16_PN(i) if (threadIdx.x == 0) { const long long pc1 = prof_clock(); lds_prof[i] += pc1 - pc0; pc0 = pc1; }
@@ -237,10 +239,10 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     const int yjj = yz(jj);
     gv += ry_s + qv_s;
     if (yjj >= 0) {
-      if (delta != 0.0) gv += delta * wtw0_entry(Q, cs, yjj);
+      if (dxw != 0.0) gv += dxw * wtw0_entry(Q, cs, yjj);
       for (int c = 1; c < cc; ++c) {
         const double* S_ = Q.ES(cs + c);
-        gv += S_[ES_RY + yjj] + S_[ES_QV + yjj] + (delta != 0.0 ? delta * wtw0_entry(Q, cs + c, yjj) : 0.0);
+        gv += S_[ES_RY + yjj] + S_[ES_QV + yjj] + (dxw != 0.0 ? dxw * wtw0_entry(Q, cs + c, yjj) : 0.0);
       }
     }
     if constexpr (NE > 0) {
@@ -263,8 +265,8 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   }
   R16_PN(13)
   d4 QO = qt_s;
-  if (delta != 0.0) QO = load_qt(Q, cs, delta, lane);
-  for (int c = 1; c < cc; ++c) QO += load_qt(Q, cs + c, delta, lane);
+  if (dxw != 0.0) QO = load_qt(Q, cs, dxw, lane);
+  for (int c = 1; c < cc; ++c) QO += load_qt(Q, cs + c, dxw, lane);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = g + 4 * r;
