@@ -3502,7 +3502,24 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   int status = 2, it = 0, n_reg = 0, n_ls_fail = 0, n_sweeps = 0, n_trials = 0, n_soc = 0;
 
   // ---- bounds (relaxed, bound_relax_factor), starting point pushed inside, z = 1
-  double cnt[3] = {0.0, 0.0, 0.0};
+  double cnt[2] = {0.0, 0.0};
+  // A variable that is in no constraint, no cost term and has no bound (the collocation slots of the initial node in
+  // every continuous model: _mpc.py:1061-1078 leaves stage 0 unbounded) is a zero row and column of the reference's
+  // primal-dual matrix: its linear solver reports a singular system at delta_w = 0 in EVERY iteration and IPOPT
+  // regularises (delta_w from the wrong-inertia rule, IpPDPerturbationHandler: PerturbForSingularity).  The structured
+  // factorisation here never sees those variables, so the first attempt of an iteration is declared failed instead -
+  // same delta_w sequence, same iterates (batch_reactor / rotating-masses goldens: 1e-11 instead of 1e-6 / 2e-5).
+  bool singular0;
+  {
+    double fr[1] = {0.0};
+    for (int d = T.tid; d < A.n_dummy; d += T.nt) {
+      const int g = A.dummy_idx[d];
+      if (!(A.lbx[g] > -INFINITY) && !(A.ubx[g] < INFINITY)) fr[0] += 1.0;
+    }
+    const int ops[1] = {R_SUM};
+    wg_reduce(T, fr, ops);
+    singular0 = fr[0] > 0.0;
+  }
   for (int g = T.tid; g < nX; g += T.nt) {
     double l = A.lbx[g], u = A.ubx[g];
     if (l > -INFINITY) l -= fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(l)));
@@ -3521,13 +3538,16 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   for (int r = T.tid; r < A.n_g; r += T.nt) Q.lam[r] = 0.0;
   T.sync();
   // Variables that appear in no constraint and no cost term (unused scenario slots of the reference's opt_x struct,
-  // SURVEY.md App. A.7) are not determined by the NLP: with a one-sided bound the barrier alone drives them to
-  // +-1e160 over a few warm-started solves.  They are taken out of the problem: no bounds, no multipliers, value
-  // = the caller's x0 entry projected onto its box.
+  // SURVEY.md App. A.7) are not determined by the NLP, only by the barrier terms of their bounds.  Under `singular0` they
+  // stay in the problem like in the reference - their barrier terms enter the line search, the step-size rules and the
+  // error measures, and the delta_w of every iteration keeps their steps finite (CSTR golden: a one-sided one wanders to
+  // 5e4 over five steps).  Without that regularisation (discrete models) the barrier alone drives a one-sided one to
+  // +-1e160 over a few warm-started solves: there they are taken out - no bounds, no multipliers, value = the caller's
+  // x0 entry projected onto its box.
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
     const int g = A.dummy_idx[d];
+    if (singular0) continue;
     if (sh_cnt(A, mk_x(A, g))) cnt[0] -= (Q.lb[g] > -INFINITY ? 1.0 : 0.0) + (Q.ub[g] < INFINITY ? 1.0 : 0.0);
-    if (!(Q.lb[g] > -INFINITY) && !(Q.ub[g] < INFINITY)) cnt[2] += 1.0;   // a free one: see `singular0` below
     Q.x[g] = fmin(fmax(x0[g], A.lbx[g]), A.ubx[g]);           // the caller's value, projected onto its box
     Q.lb[g] = -INFINITY; Q.ub[g] = INFINITY; Q.zl[g] = 0.0; Q.zu[g] = 0.0;
   }
@@ -3557,16 +3577,9 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     T.sync();
   }
   {
-    const int ops[3] = {R_SUM, R_SUM, R_SUM};
+    const int ops[2] = {R_SUM, R_SUM};
     wg_reduce(T, cnt, ops);
   }
-  // A variable that is in no constraint, no cost term and has no bound is a zero row and column of the reference's
-  // primal-dual matrix: its linear solver reports a singular system at delta_w = 0 in EVERY iteration and IPOPT
-  // regularises (delta_w from the wrong-inertia rule, IpPDPerturbationHandler: PerturbForSingularity).  The structured
-  // factorisation here never sees those variables, so the first attempt of an iteration is declared failed instead -
-  // same delta_w sequence, same iterates (rotating-masses example: no state bounds, golden reproduced to 1e-9 instead
-  // of 2e-5).
-  const bool singular0 = cnt[2] > 0.0;
   const double n_bounds = cnt[0] + cnt[1];
   const double n_dual = (double)A.n_g + n_bounds;
 

@@ -426,5 +426,5 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
     res["stats"] = dict(success=success, return_status=status, iter_count=it,
                         t_wall_total=time.perf_counter() - t_start, n_eval=n_eval,
                         n_ls_fail=stats["n_ls_fail"], n_reg=stats["n_reg"], n_soc=stats["n_soc"], mu=mu,
-                        obj_scaling=sf)
+                        obj_scaling=sf, iters=stats["iters"])
     return res

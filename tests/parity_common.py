@@ -19,6 +19,10 @@ from oracle.nlp import OracleNLP
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 U_RTOL, X_RTOL, STEP_TOL = 1e-6, 1e-5, 1e-6
+# Golden replays that follow IPOPT's iterates step by step (same inertia-correction sequence, no nl_cons slacks, no bounded
+# unused variables whose barrier terms the product leaves out): agreement at the level of the arithmetic, not of the
+# termination tolerance.  (u0, full primal solution), relative to max(1, |.|); measured 2e-12 / 6e-11.
+TIGHT_GOLDEN = {"batch_reactor": (1e-9, 1e-8), "rotating_masses": (1e-9, 1e-8)}
 
 _oracle_cache = {}
 
@@ -78,8 +82,9 @@ def check_golden_replay(make_mpc, name, steps):
         u0 = mpc.make_step(Xs[k]).ravel()
         st = mpc.solver_stats
         assert st["success"], st
-        assert relerr(u0, U[k]) < U_RTOL, (name, k, u0, U[k])
-        assert relerr(mpc.opt_x_num_unscaled.master[used], OX[k][used]) < X_RTOL
+        u_tol, x_tol = TIGHT_GOLDEN.get(name, (U_RTOL, X_RTOL))
+        assert relerr(u0, U[k]) < u_tol, (name, k, u0, U[k])
+        assert relerr(mpc.opt_x_num_unscaled.master[used], OX[k][used]) < x_tol
         assert np.max(np.abs(mpc.lam_g_num - LG[k])) < 1e-2 * max(1.0, np.max(np.abs(LG[k])))
         assert np.allclose(mpc.opt_p_num.master, golden_opt_p(name, g, k, mpc.opt_p_num.master.size), rtol=0, atol=1e-12)
         mpc.u0 = U[k]
@@ -121,6 +126,26 @@ def check_against_oracle_solve(make_mpc, name, x0_scale=1.0, oracle_opts=None, *
     assert np.max(np.abs(gv[eq])) < 1e-7
     rd = nlp.grad(x, p) + nlp.jac(x, p).T @ mpc.lam_g_num + mpc.lam_x_num
     assert np.max(np.abs(rd)) < 1e-5 * max(1.0, np.max(np.abs(mpc.lam_g_num)))
+    return mpc
+
+
+def check_same_iterates_as_oracle(make_mpc, name, oracle_opts=None, tol=1e-8):
+    """Cold solve of golden step 0: the product and the oracle take the SAME iterations (count, every variable of the final
+    iterate incl. the unused ones, multipliers) - every algorithmic detail of the device driver against the restatement
+    that is pinned to IPOPT's goldens.  industrial_poly: oracle with `ls_mult_init=False`, the one IPOPT default the
+    product does not restate (least-squares multiplier start; kept by IPOPT on this problem, discarded on the others)."""
+    mpc = make_mpc(name)
+    nlp = oracle_nlp(name)
+    x0 = golden(name)["mpc._x"][0]
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    mpc.make_step(x0)
+    st = mpc.solver_stats
+    r = ipm.solve(nlp, nlp.initial_guess(x0), mpc.opt_p_num.master.copy(), opts=oracle_opts)
+    assert st["success"] and r["stats"]["success"]
+    assert st["iter_count"] == r["stats"]["iter_count"] and st["n_reg"] == r["stats"]["n_reg"]
+    assert relerr(mpc.opt_x_num.master, r["x"]) < tol
+    assert np.max(np.abs(mpc.lam_g_num - r["lam_g"])) < 1e-5 * max(1.0, np.max(np.abs(r["lam_g"])))   # (measured 9e-7)
     return mpc
 
 

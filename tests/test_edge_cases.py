@@ -66,7 +66,8 @@ def test_repeated_solves_on_one_handle_are_reproducible():
         mpc.x0 = ex.X0
         mpc.u0 = np.zeros(2)
         mpc._t0 = mpc._t0 * 0
-        mpc.set_initial_guess()
+        mpc.opt_x_num.master[:] = 0.0      # set_initial_guess fills _x / _u only (_mpc.py:969-971): the slack and unused slots
+        mpc.set_initial_guess()            # would carry the previous solution, and they are part of the barrier problem
         out.append((mpc.make_step(ex.X0).ravel().copy(), mpc.opt_x_num.master.copy(), mpc.solver_stats["iter_count"]))
     for u, x, it in out[1:]:
         assert np.array_equal(u, out[0][0]) and np.array_equal(x, out[0][1]) and it == out[0][2]

@@ -38,6 +38,15 @@ def test_sweep_blocks_match_oracle_jacobian(name):
     pc.check_sweep_blocks(mpc, name, pc.HostArr, lambda d: d.a)
 
 
+@pytest.mark.parametrize("name,opts", [("batch_reactor", None), ("rotating_masses", None),
+                                       ("industrial_poly", dict(ls_mult_init=False))])
+def test_same_iterates_as_the_oracle(name, opts):
+    """IPOPT regularises every iteration of these problems (free unused variables make its matrix singular at delta_w = 0);
+    the driver mirrors the delta_w sequence and keeps the bounded unused variables in the barrier problem."""
+    mpc = pc.check_same_iterates_as_oracle(make_mpc, name, oracle_opts=opts)
+    assert mpc.solver_stats["n_reg"] == mpc.solver_stats["iter_count"]
+
+
 @pytest.mark.parametrize("name,over", pc.NONCONVEX_CASES)
 def test_nonconvex_examples_reach_the_oracles_local_solution(name, over):
     """Second-order correction + inertia correction: same local minimum as the IPOPT-default oracle with exact inertia."""

@@ -11,6 +11,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
+  [ $i -gt ${DOMPC_PMC_PASSES:-99} ] && break
   timeout -k 5 ${DOMPC_PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $line --output-format csv -d $OUT/q$i -- $CMD > $OUT/q$i.log 2>&1
 done <<'PASSES'
 FETCH_SIZE
