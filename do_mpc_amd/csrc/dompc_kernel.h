@@ -473,7 +473,10 @@ struct Prob {
   int e_pad;
   double sf;                                         // objective scaling
   double mu;
-  int soc;                                           // second-order correction solve: the constraint residual c is an INPUT of the sweep
+  int soc;                                           // bit 0: the constraint residual c is an INPUT of the sweep (second-order correction)
+                                                     // bit 1: the Hessians of the objective terms (lterm, mterm, rterm) are left out -
+                                                     //        with lambda = 0, z = 0 and delta = dsw = 1 the system of the
+                                                     //        least-squares multiplier estimate [I A'; A 0] (solve_problem)
   double dsw;                                        // inertia correction that the sweep has already folded into the condensed blocks
                                                      // (Sigma_w + dsw in Q~, q~ and in the stored Sigma_w): the Riccati passes add
                                                      // only delta - dsw on the eliminated variables (0 in the common case)
@@ -1086,6 +1089,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   const double* tvp = Q.P + A.p_off_tvp + k * NTVP;
   const int row0 = A.edge_row0[ee];
   const double om = A.edge_omega[ee] * Q.sf;
+  const double omh = (Q.soc & 2) ? 0.0 : om;          // weight of the objective HESSIANS (Prob::soc bit 1)
   const double* lam_e = Q.lam + row0;
   const double* nu_e = Q.lam + row0 + NW;
   const double* yd = Q.lam + row0 + NW + NX;
@@ -1148,7 +1152,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       for (int i = lane; i < NX * NA; i += GS) S_[ES_AB + i] = pt[NX + i];
       for (int i = lane; i < NA * NA; i += GS) {
         const int ip = symi(i / NA, i % NA, NA);
-        double v = pt[NX + NX * NA + ip] + om * mo[MO_LT + 1 + NA + ip];
+        double v = pt[NX + NX * NA + ip] + omh * mo[MO_LT + 1 + NA + ip];
         if (NE > 0) v += mo[MO_NL + NE + NE * NA + ip];
         S_[ES_QT + i] = v;
       }
@@ -1457,7 +1461,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           const int i = g + 4 * r;
           const bool in = i < NA && j < NA;
           const int ip = in ? symi(i, j, NA) : 0;
-          double v = om * MOV(MO_LT + 1 + NA + ip);
+          double v = omh * MOV(MO_LT + 1 + NA + ip);
           if (NE > 0) v += MOV(MO_NL + NE + NE * NA + ip);
           QTt[r] = in ? v : 0.0;
         }
@@ -1573,7 +1577,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         const int it = lane + qi * GS;
         if (it < NA * NA) {
           const int a1 = it / NA, b = it % NA;
-          double q = om * qlt[qi] + Ld[EL_QT + it];
+          double q = omh * qlt[qi] + Ld[EL_QT + it];
           if (NE > 0) q += qnl[qi];
           if (a1 >= NX && b >= NX) q += Ld[EL_HUU + (a1 - NX) * NU + (b - NX)];
           if (a1 >= NX) q += Ld[EL_U1 + (a1 - NX) * NA + b];
@@ -1675,7 +1679,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
 #pragma unroll
         for (int q = 0; q < MHL; ++q) {
           const int a = lane + q * GS;
-          if (a < NX * NX) S_[ES_MH + a] = om * pf_mh[q];
+          if (a < NX * NX) S_[ES_MH + a] = omh * pf_mh[q];
         }
       }
     } else {
@@ -1688,7 +1692,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     }
     if (k == A.N - 1) {
       for (int a = lane; a < NX; a += GS) S_[ES_MG + a] = om * mo[MO_MT + 1 + a];
-      for (int a = lane; a < NX * NX; a += GS) S_[ES_MH + a] = om * mo[MO_MT + 1 + NX + symi(a / NX, a % NX, NX)];
+      for (int a = lane; a < NX * NX; a += GS) S_[ES_MH + a] = omh * mo[MO_MT + 1 + NX + symi(a / NX, a % NX, NX)];
     }
     }
     if (lane == 0) {
@@ -1940,6 +1944,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
   double* Nd = Q.ND(n);
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
+  const double rwh = (Q.soc & 2) ? 0.0 : rw;          // weight of the rterm HESSIAN (Prob::soc bit 1)
   long long pc0 = prof_clock();
 #if DOMPC_PROFILE
 #define DOMPC_PN(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
@@ -1978,14 +1983,14 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
     const double upv = R.pv[v][6];
     double dg, gv;
     if (is_up) {
-      dg = 2.0 * rw * DOMPC_RTERM[i - NX];
+      dg = 2.0 * rwh * DOMPC_RTERM[i - NX];
       gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - upv);                    // xv = u_n of the same input
     } else {
       dg = sigma_of(xv, lo, hi, zlo, zhi) + delta;
       gv = bar_grad(xv, lo, hi, mu);
       if (i < NX) gv += (A.node_in_edge[n] >= 0) ? -R.pv[v][5] : R.pv[v][5];
       else if (i < NA + NU) {
-        dg += 2.0 * rw * DOMPC_RTERM[i - NA];
+        dg += 2.0 * rwh * DOMPC_RTERM[i - NA];
         gv += 2.0 * rw * DOMPC_RTERM[i - NA] * (xv - upv);
       } else {
         gv += cc * Q.sf * DOMPC_EPS_PEN[i - NA - NU];
@@ -2062,8 +2067,8 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
       const int i = it / NYT, j = it % NYT;
       double v = qacc[q];
       if (i == j) v += Ld[RB_QF + i * NYT + i];
-      else if (i >= NX && i < NA && j == i + NU) v -= 2.0 * rw * DOMPC_RTERM[i - NX];
-      else if (j >= NX && j < NA && i == j + NU) v -= 2.0 * rw * DOMPC_RTERM[j - NX];
+      else if (i >= NX && i < NA && j == i + NU) v -= 2.0 * rwh * DOMPC_RTERM[i - NX];
+      else if (j >= NX && j < NA && i == j + NU) v -= 2.0 * rwh * DOMPC_RTERM[j - NX];
       Ld[RB_QO + it] = v;
     }
   }
@@ -2279,6 +2284,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
   if (phase == 1) {
     const bool own = A.shard_rank == 0;
     const double rw = node_rweight(Q, n);
+    const double rwh = (Q.soc & 2) ? 0.0 : rw;
     const int xo = A.node_x_off[n], uo = A.node_u_off[n];
     const int eo = NS > 0 ? A.node_eps_off[n] : -1;
     const int ie = A.node_in_edge[n];
@@ -2292,14 +2298,14 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
       if (own) {
         const double xv = Q.x[g], lo = Q.lb[g], hi = Q.ub[g];
         if (is_up) {
-          dg = 2.0 * rw * DOMPC_RTERM[i - NX];
+          dg = 2.0 * rwh * DOMPC_RTERM[i - NX];
           gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - up[i - NX]);
         } else {
           dg = sigma_of(xv, lo, hi, Q.zl[g], Q.zu[g]) + delta;
           gv = bar_grad(xv, lo, hi, mu);
           if (i < NX) gv += (ie >= 0) ? -Q.lam[A.edge_row0[ie] + NW + i] : Q.lam[i];
           else if (i < NA + NU) {
-            dg += 2.0 * rw * DOMPC_RTERM[i - NA];
+            dg += 2.0 * rwh * DOMPC_RTERM[i - NA];
             gv += 2.0 * rw * DOMPC_RTERM[i - NA] * (xv - up[i - NA]);
           } else {
             gv += cc * Q.sf * DOMPC_EPS_PEN[i - NA - NU];
@@ -2351,8 +2357,8 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
           }
       }
       if (i == j) v += Ld[RB_QF + i * NYT + i];
-      else if (own && i >= NX && i < NA && j == i + NU) v -= 2.0 * rw * DOMPC_RTERM[i - NX];
-      else if (own && j >= NX && j < NA && i == j + NU) v -= 2.0 * rw * DOMPC_RTERM[j - NX];
+      else if (own && i >= NX && i < NA && j == i + NU) v -= 2.0 * rwh * DOMPC_RTERM[i - NX];
+      else if (own && j >= NX && j < NA && i == j + NU) v -= 2.0 * rwh * DOMPC_RTERM[j - NX];
       Ld[RB_QO + it] = v;
     }
     T.gsync();
@@ -3400,9 +3406,10 @@ __device__ __attribute__((noinline)) PhaseRet phase_sweep(const void* kp, int b,
   const int rc = sweep(T, Q, ufl(mu));
   return PhaseRet{T.gen, T.nred, T.xseq, rc};
 }
-__device__ __attribute__((noinline)) PhaseRet phase_backward(const void* kp, int b, int slot, double sf, double mu, double delta, double dsw, unsigned gen, unsigned nred, unsigned xseq) {
+__device__ __attribute__((noinline)) PhaseRet phase_backward(const void* kp, int b, int slot, double sf, double mu, double delta, double dsw, int mode, unsigned gen, unsigned nred, unsigned xseq) {
   DOMPC_PHASE_PROLOGUE
   Q.dsw = ufl(dsw);
+  Q.soc = ufl(mode);
   const int rc = riccati_backward(T, Q, ufl(mu), ufl(delta));
   return PhaseRet{T.gen, T.nred, T.xseq, rc};
 }
@@ -3448,13 +3455,16 @@ DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu
   return rc;
 #endif
 }
-DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta) {
+// mode: Prob::soc of the sweep whose records the pass works on (only bit 1 matters here: objective Hessians left out)
+DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta, int mode = 0) {
 #ifndef DOMPC_HOST_EMU
-  DOMPC_PHASE_CALL(phase_backward, mu, delta, Q.dsw)
+  DOMPC_PHASE_CALL(phase_backward, mu, delta, Q.dsw, mode)
   return ufl(r_.rc);
 #else
   (void)b; (void)slot;
-  return riccati_backward(T, Q, mu, delta);
+  Prob Qm = Q;
+  Qm.soc = mode;
+  return riccati_backward(T, Qm, mu, delta);
 #endif
 }
 DOMPC_DEV inline void run_step_rules(const Thr& T, const Prob& Q, int b, int slot, double mu, double (&r5)[5]) {
@@ -3604,6 +3614,47 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(0.0) : 0.0);
       ++n_sweeps;
     }
+  }
+  // ---- least-squares estimate of the constraint multipliers at the starting point (IPOPT section 3.6, option
+  // constr_mult_init_max):  [I A'; A 0] (w, y) = -(grad f - z_L + z_U, 0),  y discarded if |y|_inf is above the limit.
+  // The same structured solve as a Newton step, on a system in which the Hessian block is the identity: lambda = 0 (no
+  // constraint curvature), objective Hessians left out (Prob::soc bit 1), z = 0 (no Sigma), delta = dsw = 1; the residual
+  // is an input and zero (bit 0); the barrier gradient -mu/(x-l) + mu/(u-x) is the wanted -z_L + z_U = -1 + 1 when every
+  // finite bound is moved one unit away from the point and mu = 1.  Models without nl_cons rows (their slack variables
+  // would need the same treatment; IPOPT discards the estimate on the CSTR and kite examples anyway).
+  if (NE == 0 && O.constr_mult_init_max > 0.0 && !bad) {
+    for (int g = T.tid; g < nX; g += T.nt) {
+      if (Q.lb[g] > -INFINITY) Q.lb[g] = Q.x[g] - 1.0;
+      if (Q.ub[g] < INFINITY) Q.ub[g] = Q.x[g] + 1.0;
+      Q.zl[g] = 0.0; Q.zu[g] = 0.0;
+    }
+    for (int r = T.tid; r < A.n_g; r += T.nt) Q.c[r] = 0.0;
+    T.sync();
+    int ls_bad = run_sweep(T, Q, b, slot, 1.0, 3, 1.0);
+    ++n_sweeps;
+    if (!ls_bad) ls_bad = run_backward(T, Q, b, slot, 1.0, 1.0, 2);
+    if (!ls_bad) run_forward(T, Q, b, slot, 1.0, 1.0);
+    double ym[1] = {0.0};
+    for (int r = T.tid; r < A.n_g; r += T.nt) {
+      const double y = Q.dlam[r];
+      ym[0] = fmax(ym[0], (y == y) ? fabs(y) : INFINITY);
+    }
+    {
+      const int ops[1] = {R_MAX};
+      wg_reduce(T, ym, ops);
+    }
+    const bool keep = !ls_bad && ym[0] <= O.constr_mult_init_max;
+    for (int r = T.tid; r < A.n_g; r += T.nt) Q.lam[r] = keep ? Q.dlam[r] : 0.0;
+    for (int g = T.tid; g < nX; g += T.nt) {             // bounds and bound multipliers back to their starting values
+      double l = A.lbx[g], u = A.ubx[g];
+      const bool hl = Q.lb[g] > -INFINITY, hu = Q.ub[g] < INFINITY;   // (unused variables that were taken out stay out)
+      if (hl) Q.lb[g] = l - fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(l)));
+      if (hu) Q.ub[g] = u + fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(u)));
+      Q.zl[g] = hl ? 1.0 : 0.0; Q.zu[g] = hu ? 1.0 : 0.0;
+    }
+    T.sync();
+    bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(0.0) : 0.0);
+    ++n_sweeps;
   }
   const double mu_min = fmin(O.tol, O.compl_inf_tol * Q.sf) / (O.kappa_eps + 1.0);
   double tau = fmax(O.tau_min, 1.0 - mu);

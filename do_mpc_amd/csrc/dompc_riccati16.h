@@ -201,6 +201,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   const int g = lane >> 4, j = lane & 15;
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
+  const double rwh = (Q.soc & 2) ? 0.0 : rw;          // weight of the rterm HESSIAN (Prob::soc bit 1: least-squares multiplier solve)
   const double dxw = delta - Q.dsw;
   long long pc0 = prof_clock();
 #if DOMPC_PROFILE
@@ -222,7 +223,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     const int iu = is_up ? jj - NX : ((jj >= NA && !is_eps) ? jj - NA : 0);
     const double xv = R.xv, lo = R.lo, hi = R.hi, upv = R.upv;
     if (is_up) {
-      dg = 2.0 * rw * tab_sel(DOMPC_RTERM, iu);
+      dg = 2.0 * rwh * tab_sel(DOMPC_RTERM, iu);
       gv = -2.0 * rw * tab_sel(DOMPC_RTERM, iu) * (xv - upv);
     } else {
       dg = sigma_of(xv, lo, hi, R.zlo, R.zhi) + delta;
@@ -232,7 +233,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       } else if (is_eps) {
         if constexpr (NS > 0) gv += cc * Q.sf * tab_sel(DOMPC_EPS_PEN, jj - NA - NU);      // slack penalty (one term per outgoing edge)
       } else {
-        dg += 2.0 * rw * tab_sel(DOMPC_RTERM, iu);
+        dg += 2.0 * rwh * tab_sel(DOMPC_RTERM, iu);
         gv += 2.0 * rw * tab_sel(DOMPC_RTERM, iu) * (xv - upv);
       }
     }
@@ -272,7 +273,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     const int i = g + 4 * r;
     if (i == j) QO[r] += dg;
     else if ((i >= NX && i < NA && j == i + NU) || (j >= NX && j < NA && i == j + NU))
-      QO[r] -= 2.0 * rw * tab_sel(DOMPC_RTERM, (i < j ? i : j) - NX);
+      QO[r] -= 2.0 * rwh * tab_sel(DOMPC_RTERM, (i < j ? i : j) - NX);
   }
   R16_PN(14)
   if constexpr (NE > 0) {

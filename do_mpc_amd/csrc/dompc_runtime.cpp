@@ -177,6 +177,7 @@ extern "C" void dompc_default_options(dompc_options* o) {
   o->nlp_scaling_max_gradient = 100.0; o->delta_w_0 = 1e-4; o->delta_w_min = 1e-20; o->delta_w_max = 1e20;
   o->kappa_w_minus = 1.0 / 3.0; o->kappa_w_plus = 8.0; o->kappa_w_plus_bar = 100.0;
   o->max_iter = 3000; o->acceptable_iter = 15; o->obj_scaling = 1; o->max_soc = 4;
+  o->constr_mult_init_max = 1000.0;
 }
 
 extern "C" const char* dompc_status_string(int32_t s) {

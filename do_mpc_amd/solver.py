@@ -28,7 +28,8 @@ class Options(C.Structure):
         "tol", "dual_inf_tol", "constr_viol_tol", "compl_inf_tol", "acceptable_tol", "mu_init", "kappa_mu",
         "theta_mu", "kappa_eps", "tau_min", "bound_push", "bound_frac", "bound_relax_factor",
         "nlp_scaling_max_gradient", "delta_w_0", "delta_w_min", "delta_w_max", "kappa_w_minus", "kappa_w_plus",
-        "kappa_w_plus_bar")] + [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "obj_scaling", "max_soc")]
+        "kappa_w_plus_bar")] + [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "obj_scaling", "max_soc")] + [
+        ("constr_mult_init_max", C.c_double)]
 
 
 class ProblemDesc(C.Structure):
@@ -76,6 +77,7 @@ _IPOPT_OPTS = {
     "ipopt.acceptable_iter": "acceptable_iter",
     "ipopt.first_hessian_perturbation": "delta_w_0", "ipopt.min_hessian_perturbation": "delta_w_min",
     "ipopt.max_hessian_perturbation": "delta_w_max", "ipopt.max_soc": "max_soc",
+    "ipopt.constr_mult_init_max": "constr_mult_init_max",
 }
 
 

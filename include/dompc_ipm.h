@@ -59,6 +59,9 @@ typedef struct dompc_options {
   int32_t acceptable_iter;   /* ipopt.acceptable_iter          15    */
   int32_t obj_scaling;       /* gradient-based objective scaling on/off (1) */
   int32_t max_soc;           /* ipopt.max_soc: second-order correction attempts per iteration   4 (0 = off) */
+  double constr_mult_init_max; /* ipopt.constr_mult_init_max: least-squares multiplier estimate at the starting point,
+                                  discarded if its max-norm is above this value   1000 (0 = start from lambda = 0);
+                                  models with nl_cons rows always start from lambda = 0 */
 } dompc_options;
 
 /* Description of one multi-stage problem class (fixed at MPC.setup()). All pointers are host

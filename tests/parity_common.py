@@ -22,7 +22,9 @@ U_RTOL, X_RTOL, STEP_TOL = 1e-6, 1e-5, 1e-6
 # Golden replays that follow IPOPT's iterates step by step (same inertia-correction sequence, no nl_cons slacks, no bounded
 # unused variables whose barrier terms the product leaves out): agreement at the level of the arithmetic, not of the
 # termination tolerance.  (u0, full primal solution), relative to max(1, |.|); measured 2e-12 / 6e-11.
-TIGHT_GOLDEN = {"batch_reactor": (1e-9, 1e-8), "rotating_masses": (1e-9, 1e-8)}
+TIGHT_GOLDEN = {"batch_reactor": (1e-9, 1e-8), "rotating_masses": (1e-9, 1e-8),
+                "industrial_poly": (1e-8, X_RTOL)}   # (u0 2e-10; one weakly determined terminal state is 5e-7 from the golden -
+                                                     #  in the oracle's solution as well, the two agree to 1e-11)
 
 _oracle_cache = {}
 
@@ -132,8 +134,8 @@ def check_against_oracle_solve(make_mpc, name, x0_scale=1.0, oracle_opts=None, *
 def check_same_iterates_as_oracle(make_mpc, name, oracle_opts=None, tol=1e-8):
     """Cold solve of golden step 0: the product and the oracle take the SAME iterations (count, every variable of the final
     iterate incl. the unused ones, multipliers) - every algorithmic detail of the device driver against the restatement
-    that is pinned to IPOPT's goldens.  industrial_poly: oracle with `ls_mult_init=False`, the one IPOPT default the
-    product does not restate (least-squares multiplier start; kept by IPOPT on this problem, discarded on the others)."""
+    that is pinned to IPOPT's goldens.  industrial_poly is the case on which IPOPT keeps its least-squares multiplier
+    estimate of the starting point (discarded on the others: max-norm above constr_mult_init_max)."""
     mpc = make_mpc(name)
     nlp = oracle_nlp(name)
     x0 = golden(name)["mpc._x"][0]
