@@ -3636,6 +3636,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (!ls_bad) run_forward(T, Q, b, slot, 1.0, 1.0);
     double ym[1] = {0.0};
     for (int r = T.tid; r < A.n_g; r += T.nt) {
+      if (!mk_g(A, r)) continue;                        // (tree sharding: the rows this rank computes)
       const double y = Q.dlam[r];
       ym[0] = fmax(ym[0], (y == y) ? fabs(y) : INFINITY);
     }
