@@ -36,6 +36,8 @@ struct KArgs {
   dompc_options opt;
   // debug (mode 1): one Newton step at the given point
   int32_t mode;
+  int32_t dbg_at_solution;   // mode 1: slacks of the nl_cons rows s = d(x), their multipliers mu / distance (a converged point
+                             // of the barrier problem) instead of the pushed starting values
   const double *dbg_lam, *dbg_zl, *dbg_zu;
   double dbg_mu, dbg_delta;
   double *dbg_dx, *dbg_dlam, *dbg_rd, *dbg_c;

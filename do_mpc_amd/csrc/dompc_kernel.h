@@ -3951,6 +3951,18 @@ DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A) {
         double pu = hu ? O.bound_push * fmax(1.0, fabs(u)) : 0.0;
         if (hl && hu) { pl = fmin(pl, O.bound_frac * (u - l)); pu = fmin(pu, O.bound_frac * (u - l)); }
         double sv = Q.ct[row];
+        if (A.dbg_at_solution) {
+          // a converged point: the row residual d(x) - s vanishes, the slack is strictly inside the bounds the solver
+          // relaxed (bound_relax_factor), complementarity holds at the given barrier parameter
+          const double lr = hl ? l - fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(l))) : l;
+          const double ur = hu ? u + fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(u))) : u;
+          const double tiny = 1e-12 * fmax(1.0, fabs(sv));
+          if (hl) sv = fmax(sv, lr + tiny);
+          if (hu) sv = fmin(sv, ur - tiny);
+          Q.s[si] = sv; Q.sl[si] = lr; Q.su[si] = ur;
+          Q.zsl[si] = hl ? A.dbg_mu / (sv - lr) : 0.0; Q.zsu[si] = hu ? A.dbg_mu / (ur - sv) : 0.0;
+          continue;
+        }
         if (hl) sv = fmax(sv, l + pl);
         if (hu) sv = fmin(sv, u - pu);
         Q.s[si] = sv; Q.sl[si] = l; Q.su[si] = u;

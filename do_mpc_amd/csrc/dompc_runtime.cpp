@@ -743,10 +743,10 @@ extern "C" int dompc_sweep_batch_device(dompc_handle* h, int32_t B, const double
   return launch(h, A, grid, h->block, stream);
 }
 
-extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const double* lam_g, const double* zl,
-                                       const double* zu, const double* lbx, const double* ubx, const double* lbg,
-                                       const double* ubg, const double* p, double mu, double delta_w, double* dx,
-                                       double* dlam, double* rd, double* c) {
+static int newton_step_impl(dompc_handle* h, const double* x, const double* lam_g, const double* zl,
+                            const double* zu, const double* lbx, const double* ubx, const double* lbg,
+                            const double* ubg, const double* p, double mu, double delta_w, double* dx,
+                            double* dlam, double* rd, double* c, int at_solution) {
   if (!h) return 1;
 #ifndef DOMPC_HOST_EMU
   HIPCHK(h, hipSetDevice(h->d.device));
@@ -770,7 +770,7 @@ extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const d
   A.dbg_lam = h->s_dbg[0]; A.dbg_zl = h->s_dbg[1]; A.dbg_zu = h->s_dbg[2];
   A.dbg_dx = h->s_dbg[3]; A.dbg_dlam = h->s_dbg[4]; A.dbg_rd = h->s_dbg[5]; A.dbg_c = h->s_dbg[6];
   A.dbg_mu = mu; A.dbg_delta = delta_w;
-  A.batch = 1; A.mode = 1;
+  A.batch = 1; A.mode = 1; A.dbg_at_solution = at_solution;
   if (launch(h, A, 1, 256, main_stream(h))) return 1;
   if (dx) rc |= d2h(h, dx, h->s_dbg[3], sizeof(double) * d.n_opt_x);
   if (dlam) rc |= d2h(h, dlam, h->s_dbg[4], sizeof(double) * d.n_g);
@@ -778,6 +778,18 @@ extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const d
   if (c) rc |= d2h(h, c, h->s_dbg[6], sizeof(double) * d.n_g);
   if (rc || dev_sync(h)) return 1;
   return 0;
+}
+
+extern "C" int dompc_debug_newton_step(dompc_handle* h, const double* x, const double* lam_g, const double* zl,
+                                       const double* zu, const double* lbx, const double* ubx, const double* lbg,
+                                       const double* ubg, const double* p, double mu, double delta_w, double* dx,
+                                       double* dlam, double* rd, double* c) {
+  return newton_step_impl(h, x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p, mu, delta_w, dx, dlam, rd, c, 0);
+}
+extern "C" int dompc_newton_step_at_solution(dompc_handle* h, const double* x, const double* lam_g, const double* zl,
+                                             const double* zu, const double* lbx, const double* ubx, const double* lbg,
+                                             const double* ubg, const double* p, double mu, double* dx, double* dlam) {
+  return newton_step_impl(h, x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p, mu, 0.0, dx, dlam, nullptr, nullptr, 1);
 }
 
 // Iteration trace of problem 0 of the last solve call: rows of 8 doubles

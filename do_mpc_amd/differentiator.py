@@ -16,12 +16,13 @@ and the Newton direction the kernels return at a point v is d(p) = -K(p)^-1 F(v;
     dv/dp_j = [d(p + h e_j) - d(p)] / h        exactly for every parameter that enters F linearly (x0, u_prev: any h),
             ~ [d(p + h e_j) - d(p - h e_j)] / 2h  for the others (_p, _tvp: O(h^2), the matrix changes by O(h |F|) ~ 0).
 
-One `dompc_debug_newton_step` call per column (+1), all at the solution point - no symbolic KKT matrix, no dense solve.
+One `dompc_newton_step_at_solution` call per column (+1), all at the solution point - no symbolic KKT matrix, no dense
+solve.  Models with nl_cons rows: the slack variables of the rows take their values at the solution (s = d(x), multipliers
+mu / distance) inside the call, the soft-constraint variables `_eps` are ordinary decision variables.
 Strict complementarity is assumed like in the reference (`check_SC`): a bound whose multiplier is not clearly separated
 from zero gets the sensitivities of the barrier problem (a smoothed active set), not a kink.
 
-Limits: models with nl_cons rows are refused (the debug entry point re-initialises their slack variables); the multiplier
-sensitivities cover the rows of g (`dlam_dp`), not the bound multipliers.
+Limits: the multiplier sensitivities cover the rows of g (`dlam_dp`), not the bound multipliers.
 """
 from dataclasses import dataclass
 
@@ -89,8 +90,6 @@ class DoMPCDifferentiator:
         self.optimizer = optimizer
         self.settings = DifferentiatorSettings(**kwargs)
         ps = optimizer.structure
-        if ps.ne > 0:
-            raise NotImplementedError("DoMPCDifferentiator: models with nl_cons rows are not supported yet")
         self.x_scaling_factors = optimizer.opt_x_scaling.master.copy()
         self.sens_num = _SensNum(self)
         self.n_x, self.n_p, self.n_g = ps.n_opt_x, ps.n_opt_p, ps.n_g
@@ -134,7 +133,7 @@ class DoMPCDifferentiator:
         p0 = mpc.opt_p_num.master.copy()
 
         def direction(p):
-            dx, dlam, _, _ = mpc.S.debug_newton_step(x, lam, zl, zu, lb, ub, lbg, ubg, p, mu, 0.0)
+            dx, dlam = mpc.S.newton_step_at_solution(x, lam, zl, zu, lb, ub, lbg, ubg, p, mu)
             if not np.all(np.isfinite(dx)):
                 raise RuntimeError("DoMPCDifferentiator: the KKT matrix at the solution has the wrong inertia")
             return dx, dlam

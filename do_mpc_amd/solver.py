@@ -104,6 +104,8 @@ def _load(lib_path: str) -> C.CDLL:
     lib.dompc_sweep_block_doubles.restype = C.c_int64
     lib.dompc_debug_newton_step.argtypes = [vp] + [vp] * 9 + [C.c_double, C.c_double] + [vp] * 4
     lib.dompc_debug_newton_step.restype = C.c_int
+    lib.dompc_newton_step_at_solution.argtypes = [vp] + [vp] * 9 + [C.c_double] + [vp] * 2
+    lib.dompc_newton_step_at_solution.restype = C.c_int
     lib.dompc_debug_get_trace.argtypes = [vp, vp, C.c_int32]
     lib.dompc_debug_get_trace.restype = C.c_int
     lib.dompc_abort.argtypes = [vp, C.c_int32]
@@ -385,6 +387,16 @@ class HipIpmSolver:
         return out[:n_rows]
 
     # ------------------------------------------------------------------ parity hook
+    def newton_step_at_solution(self, x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p, mu):
+        """Newton direction (dx, dlam) of the primal-dual system at a converged point of the barrier problem
+        (`dompc_newton_step_at_solution`: slack variables of the nl_cons rows at their values of the point)."""
+        ps = self.structure
+        a = [_f64(v) for v in (x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p)]
+        dx = np.empty(ps.n_opt_x)
+        dlam = np.empty(ps.n_g)
+        self._check(self._lib.dompc_newton_step_at_solution(self._h, *[_ptr(v) for v in a], float(mu), _ptr(dx), _ptr(dlam)))
+        return dx, dlam
+
     def debug_newton_step(self, x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p, mu, delta_w=0.0):
         ps = self.structure
         a = [_f64(v) for v in (x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p)]

@@ -165,6 +165,16 @@ int dompc_debug_newton_step(dompc_handle* h,
                             const double* p, double mu, double delta_w,
                             double* dx, double* dlam, double* rd, double* c);
 
+/* Newton direction of the primal-dual system at a CONVERGED point of the barrier problem (x, lam_g, z_l, z_u at barrier
+ * parameter mu; bounds as the solver relaxed them): like dompc_debug_newton_step, but the slack variables of the nl_cons
+ * rows take their values at the point (s = d(x), multipliers mu / distance to the relaxed row bounds) instead of the pushed
+ * starting values.  The building block of the parametric sensitivities (do_mpc/differentiator/_nlpdifferentiator.py:
+ * 792-841 solves the same system densely): dv/dp_j = [d(p + h e_j) - d(p)] / h.  Host buffers. */
+int dompc_newton_step_at_solution(dompc_handle* h,
+                                  const double* x, const double* lam_g, const double* zl, const double* zu,
+                                  const double* lbx, const double* ubx, const double* lbg, const double* ubg,
+                                  const double* p, double mu, double* dx, double* dlam);
+
 /* Iteration trace of problem 0 of the last solve: rows of 8 doubles (it, mu, E0, inf_pr, inf_du,
  * +-alpha (negative: line search failed), delta_w, obj). */
 int dompc_debug_get_trace(dompc_handle* h, double* out, int32_t max_rows);

@@ -15,7 +15,12 @@ def test_sensitivities_match_finite_differences_of_complete_resolves():
     dc.check_against_resolves(make_mpc, "batch_reactor", [("_x0", "S_s"), ("_u_prev", "inp"), ("_p", 0, "S_in")])
 
 
-def test_reference_surface_and_refusals():
+def test_sensitivities_of_a_model_with_nl_cons_rows_and_soft_constraints():
+    """CSTR (nl_cons row with a slack variable `_eps`, 9 scenarios): du0/dx0 and du0/du_prev against re-solves."""
+    dc.check_against_resolves(make_mpc, "CSTR", [("_x0", "C_b"), ("_x0", "T_R"), ("_u_prev", "Q_dot")])
+
+
+def test_reference_surface():
     """`sens_num["dxdp", indexf[...], indexf[...]]` as in examples/batch_reactor_differentiator/main.py:158-168."""
     from do_mpc_amd.differentiator import DoMPCDifferentiator, indexf
     mpc = dc.solved(make_mpc, "batch_reactor")
@@ -30,5 +35,4 @@ def test_reference_surface_and_refusals():
     assert np.array_equal(np.asarray(nd.sens_num["dxdp"]), np.asarray(dx_dp))
     # the rterm pulls u0 towards u_prev: 0 < du0/du_prev < 1
     assert 0.0 < du0dup[0, 0] < 1.0
-    with pytest.raises(NotImplementedError):
-        DoMPCDifferentiator(make_mpc("CSTR"))
+

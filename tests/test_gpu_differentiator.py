@@ -14,3 +14,7 @@ def test_linear_parameter_sensitivities_match_the_oracles_sparse_kkt_solve(name)
 
 def test_sensitivities_match_finite_differences_of_complete_resolves():
     dc.check_against_resolves(make_mpc, "batch_reactor", [("_x0", "S_s"), ("_u_prev", "inp"), ("_p", 0, "S_in")])
+
+
+def test_sensitivities_of_a_model_with_nl_cons_rows_and_soft_constraints():
+    dc.check_against_resolves(make_mpc, "CSTR", [("_x0", "C_b"), ("_u_prev", "Q_dot")])
