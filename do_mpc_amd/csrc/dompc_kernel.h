@@ -3601,8 +3601,30 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   // (singular0: every iteration is regularised and delta_w is known before its sweep - folded into the condensed blocks
   //  there, Prob::dsw, instead of W'W being formed on demand by the Riccati pass: that path costs as much as the pass)
   auto delta_after = [&](double last) { return last == 0.0 ? O.delta_w_0 : fmax(O.delta_w_min, O.kappa_w_minus * last); };
-  int bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(0.0) : 0.0);
-  ++n_sweeps;
+  // ---- first sweep: gradient-based objective scaling and, for models without nl_cons rows, the least-squares estimate of
+  // the constraint multipliers at the starting point (IPOPT section 3.6, option constr_mult_init_max):
+  //     [I A'; A 0] (w, y) = -(grad f - z_L + z_U, 0),   y discarded if |y|_inf is above the limit.
+  // The same structured solve as a Newton step, on a system in which the Hessian block is the identity: lambda = 0 (no
+  // constraint curvature), objective Hessians left out (Prob::soc bit 1), z = 0 (no Sigma), delta = dsw = 1; the residual
+  // is an input and zero (bit 0); the barrier gradient -mu/(x-l) + mu/(u-x) is the wanted -z_L + z_U = -1 + 1 when every
+  // finite bound is moved one unit away from the point and mu = 1.  (nl_cons rows: their slack variables would need the
+  // same treatment; IPOPT discards the estimate on the CSTR and kite examples anyway.)  The sweep of that solve is the one
+  // that delivers the gradient for the objective scaling, so the estimate costs two Riccati passes and no extra sweep.
+  const bool ls_init = NE == 0 && O.constr_mult_init_max > 0.0;
+  if (ls_init) {
+    for (int g = T.tid; g < nX; g += T.nt) {
+      if (Q.lb[g] > -INFINITY) Q.lb[g] = Q.x[g] - 1.0;
+      if (Q.ub[g] < INFINITY) Q.ub[g] = Q.x[g] + 1.0;
+      Q.zl[g] = 0.0; Q.zu[g] = 0.0;
+    }
+    for (int r = T.tid; r < A.n_g; r += T.nt) Q.c[r] = 0.0;
+    T.sync();
+  }
+  auto first_sweep = [&]() {
+    ++n_sweeps;
+    return ls_init ? run_sweep(T, Q, b, slot, 1.0, 3, 1.0) : run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(0.0) : 0.0);
+  };
+  int bad = first_sweep();
   if (O.obj_scaling) {
     double gm[1] = {0.0};
     for (int g = T.tid; g < nX; g += T.nt)
@@ -3611,27 +3633,11 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     wg_reduce(T, gm, ops);
     if (gm[0] > O.nlp_scaling_max_gradient) {
       Q.sf = fmax(O.nlp_scaling_max_gradient / gm[0], 1e-8);
-      bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(0.0) : 0.0);
-      ++n_sweeps;
+      bad = first_sweep();
     }
   }
-  // ---- least-squares estimate of the constraint multipliers at the starting point (IPOPT section 3.6, option
-  // constr_mult_init_max):  [I A'; A 0] (w, y) = -(grad f - z_L + z_U, 0),  y discarded if |y|_inf is above the limit.
-  // The same structured solve as a Newton step, on a system in which the Hessian block is the identity: lambda = 0 (no
-  // constraint curvature), objective Hessians left out (Prob::soc bit 1), z = 0 (no Sigma), delta = dsw = 1; the residual
-  // is an input and zero (bit 0); the barrier gradient -mu/(x-l) + mu/(u-x) is the wanted -z_L + z_U = -1 + 1 when every
-  // finite bound is moved one unit away from the point and mu = 1.  Models without nl_cons rows (their slack variables
-  // would need the same treatment; IPOPT discards the estimate on the CSTR and kite examples anyway).
-  if (NE == 0 && O.constr_mult_init_max > 0.0 && !bad) {
-    for (int g = T.tid; g < nX; g += T.nt) {
-      if (Q.lb[g] > -INFINITY) Q.lb[g] = Q.x[g] - 1.0;
-      if (Q.ub[g] < INFINITY) Q.ub[g] = Q.x[g] + 1.0;
-      Q.zl[g] = 0.0; Q.zu[g] = 0.0;
-    }
-    for (int r = T.tid; r < A.n_g; r += T.nt) Q.c[r] = 0.0;
-    T.sync();
-    int ls_bad = run_sweep(T, Q, b, slot, 1.0, 3, 1.0);
-    ++n_sweeps;
+  if (ls_init) {
+    int ls_bad = bad;
     if (!ls_bad) ls_bad = run_backward(T, Q, b, slot, 1.0, 1.0, 2);
     if (!ls_bad) run_forward(T, Q, b, slot, 1.0, 1.0);
     double ym[1] = {0.0};
