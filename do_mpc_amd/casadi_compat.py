@@ -50,7 +50,9 @@ def install(force: bool = False):
         cas.MX = sym.SX                      # both symbol flavours map onto the same scalar DAG
         cas.inf = float("inf")
         cas.pi = 3.141592653589793
-        cas.__all__ = _CASADI_NAMES + ["MX", "inf", "pi"]
+        import os as _os
+        cas.os, cas.sys = _os, sys           # (leak out of the real package's star import; triple_tank_ekf/template_model.py:25-27 relies on it)
+        cas.__all__ = _CASADI_NAMES + ["MX", "inf", "pi", "os", "sys"]
         tools = types.ModuleType("casadi.tools")
         tools.entry = structs.entry
         tools.indexf = differentiator.indexf

@@ -78,6 +78,10 @@ def _rows(a, n: int, B: int):
     return a, False
 
 
+def _flat_struct(v, n):
+    return np.asarray(v.master if hasattr(v, "master") else v, dtype=float).reshape(-1)[:n] if n else np.zeros(0)
+
+
 class Simulator:
     def __init__(self, model: Model):
         assert model.flags["setup"] is True, "Model for simulator was not setup. After the complete model creation call model.setup()."
@@ -88,6 +92,8 @@ class Simulator:
         self._x0 = model._x(0.0)
         self._u0 = model._u(0.0)
         self._t0 = np.array([0.0])
+        from .controller import MPCData                 # per-step records like the reference's simulator.data (simulator.py:833-841)
+        self.data = MPCData(model)
         self.flags = {"set_tvp_fun": False, "set_p_fun": False, "setup": False, "first_step": True}
         self._h = None
         self._lib = None
@@ -193,6 +199,11 @@ class Simulator:
             pass
 
     # ------------------------------------------------------------------ runtime
+    def set_initial_guess(self) -> None:
+        """Initial guess of the algebraic states for the DAE solver (simulator.py:603-620).  Models with algebraic states
+        are refused at setup, so there is nothing to initialise; kept because every main.py of the reference calls it."""
+        assert self.flags["setup"], "Simulator was not setup yet. Please call Simulator.setup()."
+
     def make_step_batch(self, X, U=None, P=None, TVP=None, W=None, V=None) -> dict:
         """Advance B samples by one control interval.  X: [B][nx]; U, P, TVP, W, V: [B][n] or one row shared by all
         samples (P / TVP default to p_fun(t0) / tvp_fun(t0)).  Returns {'x', 'y', 'status', 'n_steps'}."""
@@ -236,11 +247,18 @@ class Simulator:
             u0 = np.zeros((0, 1))
         u0 = np.asarray(u0.master if hasattr(u0, "master") else u0, dtype=float)
         assert u0.size == m.n_u, "u0 has incorrect shape. You have: {}, expected: {}".format(u0.shape, (m.n_u, 1))
-        r = self.make_step_batch(self._x0.master[None, :], U=u0.reshape(-1),
+        t0 = float(self._t0[0])
+        p0 = _flat_struct(self.p_fun(t0), m.n_p)
+        tvp0 = _flat_struct(self.tvp_fun(t0), m.n_tvp)
+        r = self.make_step_batch(self._x0.master[None, :], U=u0.reshape(-1), P=p0, TVP=tvp0,
                                  W=None if w0 is None else np.asarray(w0, float).reshape(-1),
                                  V=None if v0 is None else np.asarray(v0, float).reshape(-1))
         if r["status"][0] != 0:
             raise RuntimeError("plant integration did not reach t_step (step limit or NaN right-hand side)")
+        # records of the step: state BEFORE the step, the inputs and parameters it used, the new measurement (simulator.py:833-841)
+        aux0 = m._aux_expression_fun.eval(self._x0.master, u0.reshape(-1), np.zeros(0), tvp0, p0)[0]
+        self.data.update(_x=self._x0.master.copy(), _u=u0.reshape(-1), _z=np.zeros(0), _tvp=tvp0, _p=p0, _y=r["y"][0],
+                         _aux=np.asarray(aux0, float).reshape(-1), _time=self._t0.copy())
         self._x0.master[:] = r["x"][0]
         self._u0.master[:] = u0.reshape(-1)
         self._t0 = self._t0 + self.settings.t_step

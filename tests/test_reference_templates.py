@@ -160,3 +160,41 @@ def test_unedited_sampling_tool_chain_script_reproduces_its_golden_table(compat,
     with open("/root/reference/testing/results/res_sampling_test_test_fun.pkl", "rb") as f:
         ref = pickle.load(f)
     assert res == ref["res"] and res1 == ref["res1"] and res2 == ref["res2"]
+
+
+def test_unedited_triple_tank_model_and_simulator_reproduce_the_golden_plant_trajectory(compat):
+    """examples/triple_tank_ekf: template_model.py (discrete model with sign / sqrt / fabs, one `_p`, one `_tvp`, a
+    measurement) and template_simulator.py (p_fun, a tvp_fun that switches at t = 50) un-edited on the batched plant kernel's
+    host emulation, driven like testing/test_triple_tank_EKF.py:88-101 (200 steps, constant input, seeded measurement
+    noise) - states and noisy measurements against results_triple_tank_ekf.pkl."""
+    import simulator_common as sc
+    from do_mpc_amd import build
+    import do_mpc
+    d = os.path.join(REF, "triple_tank_ekf")
+    tm = _load(os.path.join(d, "template_model.py"), "ref_tt_tm")
+    tsim = _load(os.path.join(d, "template_simulator.py"), "ref_tt_ts")
+    model = tm.template_model()
+    orig_setup = do_mpc.simulator.Simulator.setup
+
+    def setup_on_hostemu(self):
+        hdr = self._lower()
+        h = hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0]
+        orig_setup(self, _lib_path=build.plant_hostemu_library(hdr, h, sc.OUT), _code_object="")
+    do_mpc.simulator.Simulator.setup = setup_on_hostemu
+    try:
+        simulator = tsim.template_simulator(model)
+    finally:
+        do_mpc.simulator.Simulator.setup = orig_setup
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "triple_tank.npz"))
+    simulator.x0 = np.array([2, 2.8, 2.7]).reshape([-1, 1])
+    simulator.set_initial_guess()
+    np.random.seed(42)
+    ys = []
+    for k in range(200):
+        u0 = np.array([0.0001, 0.0001]).reshape([-1, 1])
+        ys.append(np.asarray(simulator.make_step(u0, v0=0.001 * np.random.randn(model.n_v, 1))).ravel())
+    X, Y = simulator.data["_x"], np.array(ys)
+    assert X.shape == g["simulator._x"].shape
+    assert np.max(np.abs(X - g["simulator._x"])) < 1e-8          # (the tolerance of the reference's own test)
+    assert np.max(np.abs(Y - g["simulator._y"])) < 1e-8
+    assert np.array_equal(simulator.data["_tvp"], g["simulator._tvp"]) and np.array_equal(simulator.data["_p"], g["simulator._p"])

@@ -32,6 +32,7 @@ CASES = {
     "batch_reactor": "results_batch_reactor.pkl",
     "oscillating_masses": "results_oscillatingMasses.pkl",
     "rotating_masses": "results_rotatingMasses.pkl",
+    "triple_tank": "results_triple_tank_ekf.pkl",
 }
 
 
