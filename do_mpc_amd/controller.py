@@ -113,6 +113,40 @@ class MPCData:
         rows = self._rows.get(key, [])
         return np.vstack(rows) if rows else np.zeros((0, 0))
 
+    def prediction(self, ind: tuple, t_ind: int = -1) -> np.ndarray:
+        """Predicted trajectory of one variable from the stored optimal solutions (do_mpc.data.MPCData.prediction,
+        /root/reference/do_mpc/data.py:246-374): `data.prediction(('_x', 'T_R'))` -> array [n_size][n_horizon(+1)][n_scenario]
+        of the solution stored at time index `t_ind`; the scenario axis follows the leaves of the tree through
+        `structure_scenario` (the stage-k column of leaf j is its ancestor at stage k).  Needs `store_full_solution`."""
+        assert isinstance(ind, tuple), "Query index must be of type tuple."
+        lay_x, lay_p, lay_aux = self._layouts
+        sc = np.asarray(self.meta_data["structure_scenario"], dtype=int)           # [N+1][n_leaves]
+        rows = self._rows
+
+        def stored(key, size):
+            return np.vstack(rows[key])[t_ind] if rows.get(key) else np.zeros(size)
+
+        kind = ind[0]
+        if kind in ("_x", "_z"):
+            idx = lay_x.resolve((kind, slice(None), slice(None), -1) + tuple(ind[1:]))        # [stage][scenario slot][element]
+            cols = sc[:idx.shape[0], :]
+            src = stored("_opt_x_num", lay_x.size)
+        elif kind == "_u":
+            idx = lay_x.resolve((kind, slice(None), slice(None)) + tuple(ind[1:]))
+            cols = sc[:-1, [0]] if self.meta_data.get("open_loop") else sc[:-1, :]
+            src = stored("_opt_x_num", lay_x.size)
+        elif kind == "_aux":
+            idx = lay_aux.resolve((kind, slice(None), slice(None)) + tuple(ind[1:]))
+            cols = sc[:-1, :]
+            src = stored("_opt_aux_num", lay_aux.size)
+        elif kind == "_tvp":
+            idx = lay_p.resolve((kind, slice(None)) + tuple(ind[1:]))
+            return stored("opt_p_num", lay_p.size)[idx.reshape(1, -1, 1)]
+        else:
+            raise ValueError("Index {} not recognized.".format(kind))
+        stage = np.arange(idx.shape[0])[:, None]
+        return src[np.moveaxis(idx[stage, cols, :], -1, 0)]
+
     def __getattr__(self, key):
         if key.startswith("__"):
             raise AttributeError(key)
@@ -517,6 +551,7 @@ class MPC:
         meta = {k: v for k, v in asdict(self.settings).items()}
         meta["structure_scenario"] = self.scenario_tree["structure_scenario"]
         self.data.set_meta(**meta)
+        self.data._layouts = (self._opt_x_layout, self._opt_p_layout, self._opt_aux_layout)
         self.flags["setup"] = True
 
     # ------------------------------------------------------------------ runtime
