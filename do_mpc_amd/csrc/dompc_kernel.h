@@ -9,7 +9,10 @@
 //   MUMPS LDL^T of the sparse KKT matrix                  -> condense (LU of the collocation block) +
 //                                                            riccati_backward()/forward() on the tree
 //   IPOPT's filter line search / mu update / termination  -> solve_problem()
-// The algorithm constants are IPOPT's defaults (Waechter & Biegler 2006), see include/dompc_ipm.h.
+// The algorithm constants are IPOPT's defaults (Waechter & Biegler 2006), see include/dompc_ipm.h.  Restated details
+// that decide whether the iterates (not only the limit point) are IPOPT's: the delta_w sequence on the systems that are
+// singular at delta_w = 0 (`singular0`), the unused variables' barrier terms, the second-order correction, the
+// least-squares multiplier estimate of the starting point - all in solve_problem(); DESIGN.md section 2.
 //
 // The file is compiled twice from the same text:
 //   * by hipcc --offload-arch=gfx950 into the per-model code object (product path), and
