@@ -198,3 +198,43 @@ def test_unedited_triple_tank_model_and_simulator_reproduce_the_golden_plant_tra
     assert np.max(np.abs(X - g["simulator._x"])) < 1e-8          # (the tolerance of the reference's own test)
     assert np.max(np.abs(Y - g["simulator._y"])) < 1e-8
     assert np.array_equal(simulator.data["_tvp"], g["simulator._tvp"]) and np.array_equal(simulator.data["_p"], g["simulator._p"])
+
+
+def test_unedited_approximate_mpc_controller_is_sampled_as_one_batch(compat):
+    """examples/CSTR_approximate_mpc: its template_model / template_mpc un-edited (nominal CSTR, no nl_cons); the open-loop
+    sampling of do_mpc.approximateMPC.AMPCSampler (_ampc_sampler.py:234-345: (x0, u_prev) uniform in the box of the bounds,
+    one cold make_step per sample) as ONE batched solve = the per-sample loop."""
+    from do_mpc_amd import sampling
+    d = os.path.join(REF, "CSTR_approximate_mpc")
+    tm = _load(os.path.join(d, "template_model.py"), "ref_ampc_tm")
+    tc = _load(os.path.join(d, "template_mpc.py"), "ref_ampc_tc")
+    model = tm.template_model()
+    with hostemu.patched():
+        one = tc.template_mpc(model, silence_solver=True)
+        tc2 = _load(os.path.join(d, "template_mpc.py"), "ref_ampc_tc2")
+        orig = tc2.do_mpc.controller.MPC.__init__
+
+        def with_batch(self, *a, **k):                  # (the template does not know about max_batch; same object otherwise)
+            orig(self, *a, **k)
+            self.settings.max_batch = 4
+        tc2.do_mpc.controller.MPC.__init__ = with_batch
+        try:
+            mpc = tc2.template_mpc(model, silence_solver=True)
+        finally:
+            tc2.do_mpc.controller.MPC.__init__ = orig
+    lbx, ubx = one._x_lb.master, one._x_ub.master
+    lbu, ubu = one._u_lb.master, one._u_ub.master
+    assert np.all(np.isfinite(np.concatenate([lbx, ubx, lbu, ubu])))
+    plan = sampling.sampling_plan_box(lbx, ubx, lbu, ubu, n_samples=4, seed=1)
+    res = sampling.open_loop_samples(mpc, plan)
+    for i in range(4):
+        one.reset_history()
+        one.x0 = plan["x0"][i]
+        one.u0 = plan["u_prev"][i]
+        one.set_initial_guess()
+        u0 = one.make_step(plan["x0"][i]).ravel()
+        assert bool(one.solver_stats["success"]) == bool(res["status"][i])
+        if res["status"][i]:
+            assert np.allclose(u0, res["u0"][i], rtol=1e-9, atol=1e-9)
+            assert one.solver_stats["iter_count"] == res["iter_count"][i]
+    assert res["status"].sum() >= 2
