@@ -80,6 +80,9 @@ def install(force: bool = False):
                                                                       sampling.DataHandler)
         dm.model, dm.controller, dm.simulator, dm.estimator, dm.differentiator = m_model, m_ctrl, m_sim, m_est, m_diff
         dm.sampling = m_samp
+        m_ampc = types.ModuleType("do_mpc.approximateMPC")      # (the data-generation half; the torch model is out of scope)
+        m_ampc.AMPCSampler = sampling.AMPCSampler
+        dm.approximateMPC = m_ampc
         dm.__version__ = "5.1.1+dompc_amd"
         sys.modules["do_mpc"] = dm
         sys.modules["do_mpc.model"] = m_model
@@ -88,8 +91,9 @@ def install(force: bool = False):
         sys.modules["do_mpc.estimator"] = m_est
         sys.modules["do_mpc.differentiator"] = m_diff
         sys.modules["do_mpc.sampling"] = m_samp
+        sys.modules["do_mpc.approximateMPC"] = m_ampc
         installed += ["do_mpc", "do_mpc.model", "do_mpc.controller", "do_mpc.simulator", "do_mpc.estimator",
-                      "do_mpc.differentiator", "do_mpc.sampling"]
+                      "do_mpc.differentiator", "do_mpc.sampling", "do_mpc.approximateMPC"]
     return installed
 
 

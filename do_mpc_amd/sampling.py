@@ -374,3 +374,162 @@ class DataHandler(_Settable):
                 if passes(output_filter, t):
                     out.append(t)
         return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The data-generation half of the reference's approximate-MPC module (`do_mpc.approximateMPC.AMPCSampler`,
+# /root/reference/do_mpc/approximateMPC/_ampc_sampler.py:41-526; its neural-network half is out of scope): same settings,
+# same files (`<data_dir>/<name>/sampling_plan_<name>.pkl`, `samples_<name>/sample_<id>.pkl`, `data_<name>_all.pkl`,
+# `data_<name>_opt.pkl`), but the plan is solved as batched launches instead of one `make_step` per row.
+from dataclasses import dataclass as _dataclass, field as _field
+
+
+@_dataclass
+class SamplerSettings:
+    """_ampcsettings.py:60-120."""
+    n_samples: int = None
+    dataset_name: str = None
+    trajectory_length: int = None
+    closed_loop_flag: bool = False
+    data_dir: str = _os.path.join(".", "sampling")
+    overwrite_sampler: bool = True
+    lbx: list = None
+    ubx: list = None
+    lbu: list = None
+    ubu: list = None
+    lbp: list = None
+    ubp: list = None
+    chunk: int = None                      # (addition) rows per launch; default: the controller's `max_batch`
+
+    def check_for_mandatory_settings(self):
+        if self.n_samples is None:
+            raise ValueError("n_samples must be set")
+        if self.dataset_name is None:
+            raise ValueError("dataset_name must be set")
+        if self.closed_loop_flag and self.trajectory_length is None:
+            raise ValueError("trajectory_length must be set for closed-loop sampling")
+
+
+class AMPCSampler:
+    def __init__(self, mpc, simulator=None):
+        """`simulator`: the plant of the closed-loop sampling (a set-up `do_mpc_amd.simulator.Simulator`); by default one is
+        built from the controller's model with its `t_step`, `p_fun` and `tvp_fun` like the reference does (n_robust = 0)."""
+        self.mpc = mpc
+        self._settings = SamplerSettings()
+        st = self._settings
+        st.lbx, st.ubx = mpc._x_lb.master.reshape(-1, 1).copy(), mpc._x_ub.master.reshape(-1, 1).copy()
+        st.lbu, st.ubu = mpc._u_lb.master.reshape(-1, 1).copy(), mpc._u_ub.master.reshape(-1, 1).copy()
+        self.simulator = simulator
+        self.flags = {"setup": False}
+
+    settings = property(lambda self: self._settings)
+
+    def setup(self):
+        assert self.flags["setup"] is False, "Setup can only be once."
+        st = self._settings
+        st.check_for_mandatory_settings()
+        for nm, what in (("lbx", "lower bounds for state"), ("ubx", "upper bounds for state"),
+                         ("lbu", "lower bounds for input"), ("ubu", "upper bounds for input")):
+            assert not np.any(np.isinf(getattr(st, nm))), "There are missing {} variables that forms your sampling box.".format(what)
+        if st.closed_loop_flag and self.simulator is None:
+            if self.mpc.settings.n_robust != 0:
+                raise NotImplementedError("AMPCSampler: closed-loop sampling with n_robust > 0 draws plant parameters per step "
+                                          "(_ampc_sampler.py:431-440); pass a configured simulator instead")
+            from .simulator import Simulator
+            sim = Simulator(self.mpc.model)
+            sim.settings.t_step = self.mpc.settings.t_step
+            if self.mpc.model.n_tvp:
+                sim.set_tvp_fun(lambda t: self.mpc.tvp_fun(t)["_tvp", 0])
+            if self.mpc.model.n_p:
+                sim.set_p_fun(lambda t: self.mpc.p_fun(t)["_p", 0])
+            sim.setup()
+            self.simulator = sim
+        self.flags["setup"] = True
+
+    # ---- files ---------------------------------------------------------------------------------------------------
+    def _dirs(self):
+        name = self._settings.dataset_name
+        base = _os.path.join(self._settings.data_dir, name)
+        return name, base, _os.path.join(base, "samples_" + name)
+
+    def approx_mpc_sampling_plan_box(self):
+        """(x0, u_prev) uniform in the box of the bounds, exported like _ampc_sampler.py:234-273."""
+        assert self.flags["setup"], "Sampler was not setup yet. Please call Sampler.setup()."
+        st = self._settings
+        name, base, _ = self._dirs()
+        sp = SamplingPlanner(overwrite=st.overwrite_sampler, id_precision=int(np.ceil(np.log10(st.n_samples))))
+        sp.data_dir = base + _os.sep
+        sp.set_sampling_var("x0", lambda: np.random.uniform(st.lbx, st.ubx))
+        sp.set_sampling_var("u_prev", lambda: np.random.uniform(st.lbu, st.ubu))
+        sp.gen_sampling_plan(n_samples=st.n_samples)
+        sp.export("sampling_plan_" + name)
+
+    def _plan(self):
+        name, base, _ = self._dirs()
+        with open(_os.path.join(base, "sampling_plan_" + name + ".pkl"), "rb") as f:
+            return _pickle.load(f)
+
+    def _run(self, batch_function, post):
+        import pandas as pd
+        st = self._settings
+        name, base, samples = self._dirs()
+        plan = self._plan()
+        sampler = Sampler(plan, overwrite=st.overwrite_sampler, sample_name="sample", print_progress=False)
+        sampler.data_dir = samples + _os.sep
+        sampler.set_batch_function(batch_function)
+        sampler.sample_data()
+        dh = DataHandler(plan, sample_name="sample")
+        dh.data_dir = samples + _os.sep
+        for key, fun in post.items():
+            dh.set_post_processing(key, fun)
+        pd.DataFrame(dh[:]).to_pickle(_os.path.join(base, "data_" + name + "_all.pkl"))
+        pd.DataFrame(dh.filter(output_filter=lambda status: status == True)).to_pickle(   # noqa: E712
+            _os.path.join(base, "data_" + name + "_opt.pkl"))
+
+    def _chunks(self, n):
+        c = self._settings.chunk or int(getattr(self.mpc.settings, "max_batch", 1) or 1)
+        return [(lo, min(n, lo + c)) for lo in range(0, n, c)]
+
+    def approx_mpc_open_loop_sampling(self):
+        """_ampc_sampler.py:275-360: per row (u0, stats) with stats = {t_make_step, success, iter_count, t_wall_total}."""
+        mpc = self.mpc
+
+        def solve_rows(x0, u_prev):
+            x0, u_prev = x0.reshape(len(x0), -1), u_prev.reshape(len(u_prev), -1)
+            out = []
+            for lo, hi in self._chunks(len(x0)):
+                r = open_loop_samples(mpc, {"x0": x0[lo:hi], "u_prev": u_prev[lo:hi]})
+                out += [(r["u0"][i].reshape(-1, 1), {"t_make_step": float(r["t_make_step"][i]), "success": bool(r["status"][i]),
+                                                    "iter_count": int(r["iter_count"][i]), "t_wall_total": float(r["t_wall"][i])})
+                        for i in range(hi - lo)]
+            return out
+
+        self._run(solve_rows, {"u0": lambda x: x[0], "status": lambda x: x[1]["success"],
+                               "t_make_step": lambda x: x[1]["t_make_step"], "t_wall": lambda x: x[1]["t_wall_total"],
+                               "iter_count": lambda x: x[1]["iter_count"]})
+
+    def approx_mpc_closed_loop_sampling(self):
+        """_ampc_sampler.py:362-526: per row the closed-loop trajectory from (x0, u_prev); table columns x0 (states along the
+        trajectory), u_prev, u0 and status, one table row per valid step like the reference's post-processing."""
+        mpc, T = self.mpc, int(self._settings.trajectory_length)
+
+        def run_rows(x0, u_prev):
+            x0, u_prev = x0.reshape(len(x0), -1), u_prev.reshape(len(u_prev), -1)
+            out = []
+            for lo, hi in self._chunks(len(x0)):
+                r = closed_loop_samples(mpc, self.simulator, {"x0": x0[lo:hi], "u_prev": u_prev[lo:hi]}, T)
+                out += [{"x": r["x"][i], "u": r["u"][i], "u_prev": r["u_prev"][i], "success": r["success"][i],
+                         "n_valid": int(r["n_valid"][i])} for i in range(hi - lo)]
+            return out
+
+        self._run(run_rows, {"x_traj": lambda x: x["x"][:max(x["n_valid"], 1)], "u_prev_traj": lambda x: x["u_prev"][:max(x["n_valid"], 1)],
+                             "u0_traj": lambda x: x["u"][:max(x["n_valid"], 1)], "status": lambda x: x["n_valid"] == len(x["u"]),
+                             "n_valid": lambda x: x["n_valid"]})
+
+    def default_sampling(self):
+        assert self.flags["setup"], "MPC was not setup yet. Please call Sampler.setup()."
+        self.approx_mpc_sampling_plan_box()
+        if self._settings.closed_loop_flag:
+            self.approx_mpc_closed_loop_sampling()
+        else:
+            self.approx_mpc_open_loop_sampling()

@@ -155,3 +155,67 @@ def test_sampler_batch_function_runs_the_whole_plan_as_one_solver_batch(tmp_path
     tab = dh[:]
     direct = sampling.open_loop_samples(mpc, {"x0": np.array([r["x0"] for r in plan]), "u_prev": np.array([r["u_prev"] for r in plan])})
     assert all(t["ok"] for t in tab) and np.array_equal(np.array([t["u0"] for t in tab]), direct["u0"])
+
+
+def test_ampc_sampler_writes_the_reference_files_from_batched_solves(tmp_path, monkeypatch):
+    """do_mpc.approximateMPC.AMPCSampler surface (_ampc_sampler.py:41-526): settings, setup(), default_sampling() and the
+    files it leaves behind; the rows equal single make_step calls (open loop) / the batched closed loop."""
+    import pandas as pd
+    import simulator_common as sc
+    ex = CASES["batch_reactor"]
+    with hostemu.patched():
+        mpc = ex.build_mpc(ex.build_model(), max_batch=4)
+        one = ex.build_mpc(ex.build_model())
+    for nm, lo, hi in (("X_s", 0.5, 2.0), ("S_s", 0.2, 1.0), ("P_s", 0.0, 1.0), ("V_s", 100.0, 140.0)):
+        mpc.bounds["lower", "_x", nm], mpc.bounds["upper", "_x", nm] = lo, hi
+    s = sampling.AMPCSampler(mpc)
+    s.settings.n_samples, s.settings.dataset_name, s.settings.data_dir = 6, "unit", str(tmp_path)
+    np.random.seed(5)
+    s.setup()
+    s.default_sampling()
+    base = os.path.join(tmp_path, "unit")
+    assert sorted(os.listdir(base)) == ["data_unit_all.pkl", "data_unit_opt.pkl", "samples_unit", "sampling_plan_unit.pkl"]
+    assert sorted(os.listdir(os.path.join(base, "samples_unit"))) == ["sample_%d.pkl" % i for i in range(6)]
+    df = pd.read_pickle(os.path.join(base, "data_unit_all.pkl"))
+    assert list(df.columns) == ["x0", "u_prev", "id", "u0", "status", "t_make_step", "t_wall", "iter_count"] and len(df) == 6
+    assert len(pd.read_pickle(os.path.join(base, "data_unit_opt.pkl"))) == int(df["status"].sum())
+    for i in (0, 3, 5):
+        one.reset_history()
+        one.x0, one.u0 = df["x0"][i], df["u_prev"][i]
+        one.set_initial_guess()
+        u0 = one.make_step(df["x0"][i])
+        assert bool(one.solver_stats["success"]) == bool(df["status"][i])
+        if df["status"][i]:
+            assert np.allclose(u0, df["u0"][i], rtol=1e-9, atol=1e-12) and one.solver_stats["iter_count"] == df["iter_count"][i]
+
+    # closed loop: tables and files (the batched loop itself needs the GPU - `closed_loop_samples`, test_gpu_simulator.py;
+    # here it is replaced by per-sample loops of the single-sample controller and plant on the host emulation)
+    sim = sc.make_simulator("batch_reactor", hostemu=True)
+
+    def per_sample_loops(mpc_, simulator, plan, T, device=0):
+        n = len(plan["x0"])
+        x, u, up = np.zeros((n, T + 1, 4)), np.zeros((n, T, 1)), np.zeros((n, T, 1))
+        for i in range(n):
+            one.reset_history()
+            one.x0, one.u0 = plan["x0"][i], plan["u_prev"][i]
+            simulator.x0 = plan["x0"][i]
+            one.set_initial_guess()
+            x[i, 0], cur = plan["x0"][i], plan["u_prev"][i]
+            for k in range(T):
+                up[i, k] = cur
+                u0 = one.make_step(x[i, k])
+                x[i, k + 1] = np.asarray(simulator.make_step(u0)).ravel()
+                u[i, k], cur = u0.ravel(), u0.ravel()
+        return {"x": x, "u": u, "u_prev": up, "success": np.ones((n, T), bool), "n_valid": np.full(n, T)}
+
+    monkeypatch.setattr(sampling, "closed_loop_samples", per_sample_loops)
+    c = sampling.AMPCSampler(mpc, simulator=sim)
+    c.settings.n_samples, c.settings.dataset_name, c.settings.data_dir = 3, "cl", str(tmp_path)
+    c.settings.closed_loop_flag, c.settings.trajectory_length = True, 2
+    c.setup()
+    c.default_sampling()
+    dfc = pd.read_pickle(os.path.join(tmp_path, "cl", "data_cl_all.pkl"))
+    assert len(dfc) == 3 and dfc["x_traj"][0].shape[1] == 4 and dfc["u0_traj"][0].shape[1] == 1
+    assert dfc["status"].all() and all(t.shape == (2, 1) for t in dfc["u0_traj"])
+    assert np.array_equal(dfc["u_prev_traj"][1][1], dfc["u0_traj"][1][0])       # the previous input of step 1 = the input of step 0
+    assert np.array_equal(dfc["x_traj"][2][0], dfc["x0"][2].ravel())
