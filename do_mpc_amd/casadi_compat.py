@@ -27,11 +27,16 @@ class StateFeedback:
     def __init__(self, model):
         self.model = model
         self._x0 = model._x(0.0)
+        self.data = controller.MPCData(model)
 
     x0 = property(lambda self: self._x0, lambda self, v: self._x0.master.__setitem__(slice(None), _flat(v)))
 
     def make_step(self, y0):
+        self.data.update(_x=_flat(y0))
         return y0
+
+    def reset_history(self):
+        self.data.init_storage()
 
 
 def _flat(v):
@@ -80,6 +85,10 @@ def install(force: bool = False):
                                                                       sampling.DataHandler)
         dm.model, dm.controller, dm.simulator, dm.estimator, dm.differentiator = m_model, m_ctrl, m_sim, m_est, m_diff
         dm.sampling = m_samp
+        from . import data as _data
+        m_data = types.ModuleType("do_mpc.data")
+        m_data.save_results, m_data.load_results, m_data.MPCData = _data.save_results, _data.load_results, _data.MPCData
+        dm.data = m_data
         m_ampc = types.ModuleType("do_mpc.approximateMPC")      # (the data-generation half; the torch model is out of scope)
         m_ampc.AMPCSampler = sampling.AMPCSampler
         dm.approximateMPC = m_ampc
@@ -92,8 +101,9 @@ def install(force: bool = False):
         sys.modules["do_mpc.differentiator"] = m_diff
         sys.modules["do_mpc.sampling"] = m_samp
         sys.modules["do_mpc.approximateMPC"] = m_ampc
+        sys.modules["do_mpc.data"] = m_data
         installed += ["do_mpc", "do_mpc.model", "do_mpc.controller", "do_mpc.simulator", "do_mpc.estimator",
-                      "do_mpc.differentiator", "do_mpc.sampling", "do_mpc.approximateMPC"]
+                      "do_mpc.differentiator", "do_mpc.sampling", "do_mpc.approximateMPC", "do_mpc.data"]
     return installed
 
 

@@ -967,6 +967,11 @@ class Function:
                     raise ValueError("Function inputs must be purely symbolic")
         self._np = None
 
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_np"] = None                     # the compiled numpy callable is rebuilt on first use after unpickling
+        return st
+
     def n_in(self):
         return len(self.inputs)
 

@@ -50,3 +50,37 @@ def test_prediction_of_vector_valued_and_time_varying_entries():
     assert tv.shape == (1, N + 1, 1)
     assert np.array_equal(tv[0, :, 0], np.asarray(mpc.opt_p_num["_tvp", :, "phi_2_set"]).ravel())
     assert not np.array_equal(mpc.data.prediction(("_x", "phi_2"), t_ind=0), mpc.data.prediction(("_x", "phi_2"), t_ind=1))
+
+
+def test_results_are_saved_and_loaded_like_in_the_examples(tmp_path):
+    """do_mpc.data.save_results / load_results (data.py:376-460) and a pickled model (the reference's test_pickle_unpickle):
+    the last lines of every examples/*/main.py."""
+    import pickle
+    import simulator_common as sc
+    from do_mpc_amd import data
+    from do_mpc_amd.examples import CASES
+    ex = CASES["batch_reactor"]
+    model = pickle.loads(pickle.dumps(ex.build_model()))                 # model -> file -> model, then the controller from it
+    import hostemu
+    with hostemu.patched():
+        mpc = ex.build_mpc(model)
+    sim = sc.make_simulator("batch_reactor", hostemu=True, model=model)
+    g = pc.golden("batch_reactor")
+    x0 = g["mpc._x"][0]
+    mpc.x0, sim.x0 = x0, x0
+    mpc.set_initial_guess()
+    for k in range(2):
+        u0 = mpc.make_step(x0)
+        x0 = sim.make_step(u0)
+    assert pc.relerr(mpc.data["_u"], g["mpc._u"][:2]) < 1e-6
+    d = str(tmp_path) + "/"
+    data.save_results([mpc, sim], "run", d)
+    data.save_results([mpc, sim], "run", d)
+    data.save_results([mpc], "run", d, overwrite=True)
+    import os
+    assert sorted(os.listdir(d)) == ["001_run.pkl", "run.pkl"]
+    res = data.load_results(d + "001_run.pkl")
+    assert set(res) == {"mpc", "simulator"}
+    assert np.array_equal(res["mpc"]["_u"], mpc.data["_u"]) and np.array_equal(res["simulator"]["_x"], sim.data["_x"])
+    assert np.array_equal(res["mpc"].prediction(("_x", "X_s")), mpc.data.prediction(("_x", "X_s")))
+    assert res["mpc"]["_x", "S_s"].shape == (2, 1) and set(data.load_results(d + "run.pkl")) == {"mpc"}
