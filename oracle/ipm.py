@@ -261,6 +261,7 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
         rhs = -np.concatenate([rx, c])
         delta_w, delta_c = 0.0, 0.0
         first_try = True
+        tried_c = False
         while True:
             Hreg = W + sps.diags(sigma + delta_w)
             K = sps.bmat([[Hreg, A.T], [A, -delta_c * sps.identity(m) if delta_c > 0 else None]], format="csc")
@@ -272,8 +273,18 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
                 sol += lu.solve(rhs - K @ sol)
                 ok = np.all(np.isfinite(sol))
             except RuntimeError:
+                # singular system (IpPDPerturbationHandler::PerturbForSingularity while the kind of degeneracy is unknown):
+                # first delta_c > 0 with delta_w = 0; if that is singular too, delta_c back to 0 and delta_w from the
+                # wrong-inertia rule.  (A system that is singular because of zero rows AND columns of the Hessian block -
+                # the unused variables of the do-mpc NLP - always ends in the second case: delta_c = 0.)
                 ok = False
-                if delta_c == 0.0:
+                if o.get("ipopt_delta_c_sequence", True):
+                    if not tried_c and delta_w == 0.0:
+                        tried_c = True
+                        delta_c = o["delta_c_bar"] * mu ** o["kappa_c"]
+                        continue
+                    delta_c = 0.0
+                elif delta_c == 0.0:
                     delta_c = o["delta_c_bar"] * mu ** o["kappa_c"]
             if ok and o["inertia"] == "ldl":
                 if _n_negative(K) == m:
