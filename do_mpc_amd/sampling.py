@@ -438,10 +438,21 @@ class AMPCSampler:
             from .simulator import Simulator
             sim = Simulator(self.mpc.model)
             sim.settings.t_step = self.mpc.settings.t_step
-            if self.mpc.model.n_tvp:
-                sim.set_tvp_fun(lambda t: self.mpc.tvp_fun(t)["_tvp", 0])
-            if self.mpc.model.n_p:
-                sim.set_p_fun(lambda t: self.mpc.p_fun(t)["_p", 0])
+            m = self.mpc.model                              # plant parameters = the controller's: stage 0 / first scenario
+            if m.n_tvp:
+                tv = sim.get_tvp_template()
+
+                def tvp_fun(t):
+                    tv.master[:] = np.asarray(self.mpc.tvp_fun(t).master, float).reshape(-1)[:m.n_tvp]
+                    return tv
+                sim.set_tvp_fun(tvp_fun)
+            if m.n_p:
+                pt = sim.get_p_template()
+
+                def p_fun(t):
+                    pt.master[:] = np.asarray(self.mpc.p_fun(t).master, float).reshape(-1)[:m.n_p]
+                    return pt
+                sim.set_p_fun(p_fun)
             sim.setup()
             self.simulator = sim
         self.flags["setup"] = True
