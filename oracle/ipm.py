@@ -290,7 +290,12 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
                 if _n_negative(K) == m:
                     break
             elif ok:
-                dv = sol[:nv]
+                # (variables that appear in no constraint and no Hessian entry - the unused slots of the do-mpc NLP - are
+                #  decoupled 1x1 blocks with the pivot sigma + delta_w > 0: they cannot spoil the inertia, but with
+                #  delta_w ~ 1e-12 their tiny curvature dominated this test and rejected correct factorisations; the exact
+                #  count, inertia="ldl", accepts those)
+                coupled = (np.diff(A.tocsc().indptr) > 0) | (np.diff(W.tocsr().indptr) > 0)
+                dv = sol[:nv] * coupled
                 curv = dv @ (Hreg @ dv)
                 if curv >= 1e-11 * (dv @ dv) or (dv @ dv) == 0.0:
                     break

@@ -39,12 +39,11 @@ def test_sweep_blocks_match_oracle_jacobian(name):
 
 
 @pytest.mark.parametrize("name,opts", [("batch_reactor", None), ("rotating_masses", None),
-                                       ("industrial_poly", None), ("CSTR", dict(inertia="ldl"))])
+                                       ("industrial_poly", None), ("CSTR", None)])
 def test_same_iterates_as_the_oracle(name, opts):
     """IPOPT regularises every iteration of these problems (free unused variables make its matrix singular at delta_w = 0);
     the driver mirrors the delta_w sequence and keeps the bounded unused variables in the barrier problem."""
-    over = {"n_horizon": 6} if name == "CSTR" else {}      # (dense LDL' of the oracle: seconds at 6 stages, minutes at 20)
-    mpc = pc.check_same_iterates_as_oracle(make_mpc, name, oracle_opts=opts, **over)
+    mpc = pc.check_same_iterates_as_oracle(make_mpc, name, oracle_opts=opts)
     assert mpc.solver_stats["n_reg"] == mpc.solver_stats["iter_count"]
 
 
