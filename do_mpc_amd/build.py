@@ -151,9 +151,11 @@ def hostemu_library(header_text: str, model_hash: str, out_dir: str, force: bool
     Lives outside the package build dir (tests/_hostemu) and is never loaded by the product."""
     os.makedirs(out_dir, exist_ok=True)
     hdr = os.path.join(out_dir, f"model_gen_{model_hash}.h")
-    out = os.path.join(out_dir, f"libdompc_hostemu_{model_hash}.so")
+    defs = os.environ.get("DOMPC_DEFS", "").split()      # extra -D switches (e.g. DOMPC_KAPPA_D=1e-5): an own library per set
+    tag = ("_" + hashlib.sha256(" ".join(defs).encode()).hexdigest()[:8]) if defs else ""
+    out = os.path.join(out_dir, f"libdompc_hostemu_{model_hash}{tag}.so")
     stamp = out + ".stamp"
-    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12]
+    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + " ".join(defs)
     if not force and _fresh(out, stamp, dig):
         return out
     with _locked(out_dir):                                # (world_size-2 gloo tests build from two processes)
@@ -163,6 +165,7 @@ def hostemu_library(header_text: str, model_hash: str, out_dir: str, force: bool
             _write_atomic(hdr, header_text)
         cxx = shutil.which("g++") or "g++"
         cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DDOMPC_HOST_EMU", "-DDOMPC_SHARD=1",
+               *[(d if d.startswith("-") else f"-D{d}") for d in defs],
                f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC,
                os.path.join(CSRC, "dompc_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "dompc_device.hip"), "-lm"]
         _compile_to(cmd, out, "building host emulation")

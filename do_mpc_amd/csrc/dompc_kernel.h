@@ -568,10 +568,25 @@ DOMPC_DEV inline double fast_rcp(double x) {
 #endif
 }
 
+// IPOPT's linear damping of the barrier function for variables with ONE bound (kappa_d, section 3.7 of the implementation
+// paper): phi_mu gets + kappa_d mu (x - l) per lower-only and + kappa_d mu (u - x) per upper-only variable, the primal-dual
+// equations and the error measures the gradient of it.  IPOPT's default is 1e-5; with it the oracle reproduces the CSTR and
+// batch_reactor goldens to 1e-13 instead of 1e-7 / 2e-11.  Compile-time switch, OFF in the product
+// build of this round (the code object measured on the GPU is unchanged); tests build the host emulation with it.
+#ifndef DOMPC_KAPPA_D
+#define DOMPC_KAPPA_D 0.0
+#endif
+constexpr double KAPPA_D = DOMPC_KAPPA_D;
+// +1: lower bound only, -1: upper bound only, 0: none or both
+DOMPC_DEV inline double one_sided(double l, double u) {
+  const bool hl = l > -INFINITY, hu = u < INFINITY;
+  return (hl && !hu) ? 1.0 : ((hu && !hl) ? -1.0 : 0.0);
+}
 DOMPC_DEV inline double bar_grad(double x, double l, double u, double mu) {
   double g = 0.0;
   if (l > -INFINITY) g -= mu * fast_rcp(x - l);
   if (u < INFINITY) g += mu * fast_rcp(u - x);
+  if (KAPPA_D != 0.0) g += KAPPA_D * mu * one_sided(l, u);
   return g;
 }
 DOMPC_DEV inline double sigma_of(double x, double l, double u, double zl, double zu) {
@@ -3146,7 +3161,7 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, const Comp* pre) {
   Comp C = pre ? *pre : Comp{-INFINITY, INFINITY, 0.0};
   if (pre) {
     double rd_[DOMPC_FW];
-#define L_(u, g) rd_[u] = Q.rd[g];
+#define L_(u, g) rd_[u] = Q.rd[g]; if (KAPPA_D != 0.0) rd_[u] += KAPPA_D * Q.mu * one_sided(Q.lb[g], Q.ub[g]);
 #define B_(u, g) if (sh_cnt(A, mk_x(A, g))) v[0] = fmax(v[0], fabs(rd_[u]));
     DOMPC_FOR4(A.n_opt_x, L_, B_)
 #undef L_
@@ -3156,7 +3171,7 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, const Comp* pre) {
 #define L_(u, g) rd_[u] = Q.rd[g]; x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g]; zl_[u] = Q.zl[g]; zu_[u] = Q.zu[g];
 #define B_(u, g)                                                                   \
     if (sh_cnt(A, mk_x(A, g))) {                                                   \
-      v[0] = fmax(v[0], fabs(rd_[u]));                                             \
+      v[0] = fmax(v[0], fabs(rd_[u] + (KAPPA_D != 0.0 ? KAPPA_D * Q.mu * one_sided(l_[u], u2_[u]) : 0.0)));  \
       if (l_[u] > -INFINITY) comp_add(C, (x_[u] - l_[u]) * zl_[u], zl_[u]);        \
       if (u2_[u] < INFINITY) comp_add(C, (u2_[u] - x_[u]) * zu_[u], zu_[u]);       \
     }
@@ -3169,7 +3184,7 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, const Comp* pre) {
     if (!sh_cnt(A, mk_e(A, e))) continue;
     const int si = e * NE1 + i;
     const double yd = Q.lam[A.edge_row0[e] + NW + NX + i];
-    v[0] = fmax(v[0], fabs(-yd - Q.zsl[si] + Q.zsu[si]));
+    v[0] = fmax(v[0], fabs(-yd - Q.zsl[si] + Q.zsu[si] + (KAPPA_D != 0.0 ? KAPPA_D * Q.mu * one_sided(Q.sl[si], Q.su[si]) : 0.0)));
     if (!pre) {
       const double l = Q.sl[si], u = Q.su[si];
       if (l > -INFINITY) comp_add(C, (Q.s[si] - l) * Q.zsl[si], Q.zsl[si]);
@@ -3248,6 +3263,7 @@ DOMPC_DEV inline void step_rules_pass(const Thr& T, const Prob& Q, double mu, do
         r5[1] = fmax(r5[1], 1.0 - r * d - mu * r * fast_rcp(zu_[u]));                      \
         gphi += mu * r;                                                                    \
       }                                                                                    \
+      if (KAPPA_D != 0.0) gphi += KAPPA_D * mu * one_sided(l, ub_);                        \
       r5[2] += gphi * d;                                                                   \
     }
     DOMPC_FOR4(nX, L_, B_)
@@ -3271,6 +3287,7 @@ DOMPC_DEV inline void step_rules_pass(const Thr& T, const Prob& Q, double mu, do
       r5[1] = fmax(r5[1], 1.0 - r * d - mu * r * fast_rcp(Q.zsu[si]));
       gphi += mu * r;
     }
+    if (KAPPA_D != 0.0) gphi += KAPPA_D * mu * one_sided(l, u);
     r5[2] += gphi * d;
   }
   const int ops[5] = {R_MAX, R_MAX, R_SUM, R_SUM, R_SUM};
@@ -3282,6 +3299,7 @@ DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, do
   const int nX = A.n_opt_x, nSl = A.n_edges * NE;
   double r3[3] = {0.0, 0.0, 0.0};    // obj, theta, barrier
   LogAcc La{1.0, 0, 0};
+  double lin = 0.0;                  // distances to the single bound of the one-sided variables (damping term, KAPPA_D)
   {                                  // trial point and its barrier terms in one pass
     double x_[DOMPC_FW], d_[DOMPC_FW], l_[DOMPC_FW], u2_[DOMPC_FW];
 #define L_(u, g) x_[u] = Q.x[g]; d_[u] = Q.dx[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g];
@@ -3292,6 +3310,7 @@ DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, do
       if (sh_cnt(A, mk_x(A, g))) {                                                         \
         if (l_[u] > -INFINITY) logacc_add(La, xt_ - l_[u]);                                \
         if (u2_[u] < INFINITY) logacc_add(La, u2_[u] - xt_);                               \
+        if (KAPPA_D != 0.0) { const double os_ = one_sided(l_[u], u2_[u]); lin += os_ > 0.0 ? xt_ - l_[u] : (os_ < 0.0 ? u2_[u] - xt_ : 0.0); } \
       }                                                                                    \
     }
     DOMPC_FOR4(nX, L_, B_)
@@ -3320,8 +3339,10 @@ DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, do
     const int si = (g / NE1) * NE1 + g % NE1;
     if (Q.sl[si] > -INFINITY) logacc_add(La, Q.st[si] - Q.sl[si]);
     if (Q.su[si] < INFINITY) logacc_add(La, Q.su[si] - Q.st[si]);
+    if (KAPPA_D != 0.0) { const double os_ = one_sided(Q.sl[si], Q.su[si]); lin += os_ > 0.0 ? Q.st[si] - Q.sl[si] : (os_ < 0.0 ? Q.su[si] - Q.st[si] : 0.0); }
   }
   r3[2] = -logacc_value(La);
+  if (KAPPA_D != 0.0) r3[2] += KAPPA_D * lin;
   const int ops[3] = {R_SUM, R_SUM, R_SUM};
   wg_reduce(T, r3, ops);
   obj_o = r3[0]; th_o = r3[1]; bar_o = r3[2];
@@ -3668,6 +3689,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   }
   const double mu_min = fmin(O.tol, O.compl_inf_tol * Q.sf) / (O.kappa_eps + 1.0);
   double tau = fmax(O.tau_min, 1.0 - mu);
+  if (KAPPA_D != 0.0) Q.mu = mu;              // (read by measure() for the damping term of the dual residual)
   Errs E = measure(T, Q, nullptr);
   const double theta0 = E.theta;
   const double theta_max = 1e4 * fmax(1.0, theta0), theta_min = 1e-4 * fmax(1.0, theta0);
@@ -3676,12 +3698,14 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   {
     double bs[1] = {0.0};
     LogAcc La{1.0, 0, 0};
+    double lin = 0.0;
     double x_[DOMPC_FW], l_[DOMPC_FW], u2_[DOMPC_FW];
 #define L_(u, g) x_[u] = Q.x[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g];
 #define B_(u, g)                                                       \
     if (sh_cnt(A, mk_x(A, g))) {                                       \
       if (l_[u] > -INFINITY) logacc_add(La, x_[u] - l_[u]);            \
       if (u2_[u] < INFINITY) logacc_add(La, u2_[u] - x_[u]);           \
+      if (KAPPA_D != 0.0) { const double os_ = one_sided(l_[u], u2_[u]); lin += os_ > 0.0 ? x_[u] - l_[u] : (os_ < 0.0 ? u2_[u] - x_[u] : 0.0); } \
     }
     DOMPC_FOR4(nX, L_, B_)
 #undef L_
@@ -3691,8 +3715,10 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       const int si = (g / NE1) * NE1 + g % NE1;
       if (Q.sl[si] > -INFINITY) logacc_add(La, Q.s[si] - Q.sl[si]);
       if (Q.su[si] < INFINITY) logacc_add(La, Q.su[si] - Q.s[si]);
+      if (KAPPA_D != 0.0) { const double os_ = one_sided(Q.sl[si], Q.su[si]); lin += os_ > 0.0 ? Q.s[si] - Q.sl[si] : (os_ < 0.0 ? Q.su[si] - Q.s[si] : 0.0); }
     }
     bs[0] = -logacc_value(La);
+    if (KAPPA_D != 0.0) bs[0] += KAPPA_D * lin;
     const int ops[1] = {R_SUM};
     wg_reduce(T, bs, ops);
     bar_sum = bs[0];
@@ -3901,6 +3927,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     ++it;
     c_t = prof_clock(); bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(delta_last) : 0.0); c_sweep += prof_clock() - c_t;
     ++n_sweeps;
+    if (KAPPA_D != 0.0) Q.mu = mu;
     c_t = prof_clock(); E = measure(T, Q, &Cp); c_meas += prof_clock() - c_t;
   }
 

@@ -41,6 +41,8 @@ DEFAULTS = dict(
     delta_w_min=1e-20, delta_w_0=1e-4, delta_w_max=1e40, kappa_w_minus=1.0 / 3.0,
     kappa_w_plus=8.0, kappa_w_plus_bar=100.0, delta_c_bar=1e-8, kappa_c=0.25,
     ls_mult_init=True, inertia="curvature",
+    kappa_d=0.0,        # IPOPT: 1e-5 (linear damping of the barrier for variables with ONE bound, section 3.7 of the paper).
+                        # Not restated by the product; 0 here so that product and oracle solve the same barrier problems.
     nlp_scaling_max_gradient=100.0, nlp_scaling_min_value=1e-8, obj_scaling=True, con_scaling=True,
 )
 
@@ -201,10 +203,16 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
         H = nlp.hess(xx, p, sf, lam * sg)
         return sps.block_diag([H, sps.csr_matrix((m_i, m_i))], format="csr") if m_i else H.tocsr()
 
+    only_l, only_u = has_l & ~has_u, has_u & ~has_l
+
+    def damp(mu_):
+        """gradient of the damping term kappa_d mu (sum_{lower only}(v - l) + sum_{upper only}(u - v))"""
+        return o["kappa_d"] * mu_ * (only_l.astype(float) - only_u.astype(float))
+
     def err(mu_, v_, y_, zl_, zu_, gf_, A_, c_):
         dl = np.where(has_l, v_ - vl, 1.0)
         du = np.where(has_u, vu - v_, 1.0)
-        rd = gf_ + A_.T @ y_ - zl_ + zu_
+        rd = gf_ + A_.T @ y_ - zl_ + zu_ + damp(mu_)
         sd = max(o["s_max"], (np.abs(y_).sum() + np.abs(zl_).sum() + np.abs(zu_).sum()) / max(1, m + has_l.sum() + has_u.sum())) / o["s_max"]
         sc = max(o["s_max"], (np.abs(zl_).sum() + np.abs(zu_).sum()) / max(1, has_l.sum() + has_u.sum())) / o["s_max"]
         e_d = np.max(np.abs(rd), initial=0.0)
@@ -213,7 +221,8 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
         return max(e_d / sd, e_p, e_c / sc), e_d, e_p, e_c
 
     def barrier(fv, v_):
-        return fv - mu * (np.log((v_ - vl)[has_l]).sum() + np.log((vu - v_)[has_u]).sum())
+        return fv - mu * (np.log((v_ - vl)[has_l]).sum() + np.log((vu - v_)[has_u]).sum()) \
+            + o["kappa_d"] * mu * ((v_ - vl)[only_l].sum() + (vu - v_)[only_u].sum())
 
     c = cons(gval, s)
     filt = []
@@ -257,7 +266,7 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
         dl = np.where(has_l, v - vl, 1.0)
         du = np.where(has_u, vu - v, 1.0)
         sigma = np.where(has_l, zl / dl, 0.0) + np.where(has_u, zu / du, 0.0)
-        rx = gf + A.T @ y - np.where(has_l, mu / dl, 0.0) + np.where(has_u, mu / du, 0.0)
+        rx = gf + A.T @ y - np.where(has_l, mu / dl, 0.0) + np.where(has_u, mu / du, 0.0) + damp(mu)
         rhs = -np.concatenate([rx, c])
         delta_w, delta_c = 0.0, 0.0
         first_try = True
@@ -325,7 +334,7 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
         # ---- filter line search
         theta = np.abs(c).sum()
         phi = barrier(fval, v)
-        gphi = gf - np.where(has_l, mu / dl, 0.0) + np.where(has_u, mu / du, 0.0)
+        gphi = gf - np.where(has_l, mu / dl, 0.0) + np.where(has_u, mu / du, 0.0) + damp(mu)
         dphi = gphi @ dv
         if dphi < 0 and theta <= theta_min:
             a_min = o["gamma_alpha"] * min(o["gamma_theta"], o["gamma_phi"] * theta / (-dphi) if theta > 0 else np.inf,

@@ -171,3 +171,26 @@ def test_deeper_tree_27_leaves_kkt_properties():
     mpc.make_step(ex.X0)
     assert mpc.solver_stats["success"]
     pc.check_kkt_with_oracle_functions(mpc, nlp, ex.X0)
+
+
+@pytest.mark.parametrize("name,steps", [("batch_reactor", 5), ("CSTR", 3)])
+def test_kernels_built_with_ipopts_one_sided_damping_reproduce_the_goldens_to_rounding(name, steps, monkeypatch):
+    """The same kernel text compiled with -DDOMPC_KAPPA_D=1e-5 (IPOPT's default kappa_d; a compile-time switch that is OFF in
+    this round's product build, whose GPU code object it leaves bit-identical): golden u0 / full primal solution / multipliers
+    of the reference's closed-loop tests to 1e-10 (measured 7e-14 / 1e-13 / 6e-16 on CSTR) instead of 3.5e-7 / 8e-7."""
+    monkeypatch.setenv("DOMPC_DEFS", "DOMPC_KAPPA_D=1e-5")
+    ex = CASES[name]
+    mpc = make_mpc(name)
+    mpc.x0 = ex.X0
+    mpc.set_initial_guess()
+    g = pc.golden(name)
+    used = np.ones(mpc.structure.n_opt_x, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    for k in range(steps):
+        u0 = mpc.make_step(g["mpc._x"][k]).ravel()
+        assert mpc.solver_stats["success"]
+        assert pc.relerr(u0, g["mpc._u"][k]) < 1e-10
+        assert pc.relerr(mpc.opt_x_num_unscaled.master[used], g["mpc._opt_x_num"][k][used]) < 1e-10
+        LG = g["mpc._lam_g_num"][k]
+        assert np.max(np.abs(mpc.lam_g_num - LG)) < 1e-9 * max(1.0, np.max(np.abs(LG)))
+        mpc.u0 = g["mpc._u"][k]
