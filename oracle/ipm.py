@@ -41,8 +41,7 @@ DEFAULTS = dict(
     delta_w_min=1e-20, delta_w_0=1e-4, delta_w_max=1e40, kappa_w_minus=1.0 / 3.0,
     kappa_w_plus=8.0, kappa_w_plus_bar=100.0, delta_c_bar=1e-8, kappa_c=0.25,
     ls_mult_init=True, inertia="curvature",
-    kappa_d=0.0,        # IPOPT: 1e-5 (linear damping of the barrier for variables with ONE bound, section 3.7 of the paper).
-                        # Not restated by the product; 0 here so that product and oracle solve the same barrier problems.
+    kappa_d=1e-5,       # linear damping of the barrier for variables with ONE bound (section 3.7 of the paper)
     nlp_scaling_max_gradient=100.0, nlp_scaling_min_value=1e-8, obj_scaling=True, con_scaling=True,
 )
 

@@ -173,24 +173,14 @@ def test_deeper_tree_27_leaves_kkt_properties():
     pc.check_kkt_with_oracle_functions(mpc, nlp, ex.X0)
 
 
-@pytest.mark.parametrize("name,steps", [("batch_reactor", 5), ("CSTR", 3)])
-def test_kernels_built_with_ipopts_one_sided_damping_reproduce_the_goldens_to_rounding(name, steps, monkeypatch):
-    """The same kernel text compiled with -DDOMPC_KAPPA_D=1e-5 (IPOPT's default kappa_d; a compile-time switch that is OFF in
-    this round's product build, whose GPU code object it leaves bit-identical): golden u0 / full primal solution / multipliers
-    of the reference's closed-loop tests to 1e-10 (measured 7e-14 / 1e-13 / 6e-16 on CSTR) instead of 3.5e-7 / 8e-7."""
-    monkeypatch.setenv("DOMPC_DEFS", "DOMPC_KAPPA_D=1e-5")
-    ex = CASES[name]
-    mpc = make_mpc(name)
-    mpc.x0 = ex.X0
+def test_without_ipopts_one_sided_damping_the_cstr_golden_is_only_reached_to_1e_7(monkeypatch):
+    """-DDOMPC_KAPPA_D=0 compiles the damping term kappa_d mu (x - l) of one-sided bounds out of the kernels (IPOPT section 3.7,
+    default 1e-5 here as there): the CSTR golden, reproduced to 7e-14 with it (test_golden_replay), is then 3.5e-7 away -
+    the soft-constraint and row slacks sit at their single bound and the optimum is sensitive to the barrier problem."""
+    monkeypatch.setenv("DOMPC_DEFS", "DOMPC_KAPPA_D=0")
+    mpc = make_mpc("CSTR")
+    mpc.x0 = CASES["CSTR"].X0
     mpc.set_initial_guess()
-    g = pc.golden(name)
-    used = np.ones(mpc.structure.n_opt_x, bool)
-    used[mpc.structure.tables["dummy_idx"]] = False
-    for k in range(steps):
-        u0 = mpc.make_step(g["mpc._x"][k]).ravel()
-        assert mpc.solver_stats["success"]
-        assert pc.relerr(u0, g["mpc._u"][k]) < 1e-10
-        assert pc.relerr(mpc.opt_x_num_unscaled.master[used], g["mpc._opt_x_num"][k][used]) < 1e-10
-        LG = g["mpc._lam_g_num"][k]
-        assert np.max(np.abs(mpc.lam_g_num - LG)) < 1e-9 * max(1.0, np.max(np.abs(LG)))
-        mpc.u0 = g["mpc._u"][k]
+    g = pc.golden("CSTR")
+    u0 = mpc.make_step(g["mpc._x"][0]).ravel()
+    assert 1e-8 < pc.relerr(u0, g["mpc._u"][0]) < 1e-6

@@ -90,16 +90,16 @@ def test_open_loop_replay_matches_golden_u(name, steps):
 
 @pytest.mark.parametrize("name,steps", [("batch_reactor", 5), ("CSTR", 3)])
 def test_with_ipopts_damping_of_one_sided_bounds_the_oracle_reproduces_the_goldens_to_rounding(name, steps):
-    """kappa_d = 1e-5 (IPOPT's default: linear damping of the barrier for variables with one bound) is the last detail that
-    separates the restated algorithm from IPOPT on these two cases: 1e-13 instead of 2e-11 (batch_reactor) / 1.4e-7 (CSTR).
-    Asserted at 1e-10 on every variable that is in a constraint, u0 and the multipliers."""
+    """kappa_d = 1e-5 (IPOPT's default: linear damping of the barrier for variables with one bound) was the last detail that
+    separated the restated algorithm from IPOPT on these two cases: 1e-13 instead of 2e-11 (batch_reactor) / 1.4e-7 (CSTR)
+    without it.  Asserted at 1e-10 on every variable that is in a constraint, u0 and the multipliers."""
     nlp = _nlp(name)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     s = nlp.scaling_vector()
     xg = nlp.initial_guess(g["mpc._x"][0])
     for k in range(steps):
         p = golden_opt_p(name, g, k, nlp.n_opt_p)
-        r = ipm.solve(nlp, xg, p, opts=dict(kappa_d=1e-5))
+        r = ipm.solve(nlp, xg, p)
         assert r["stats"]["success"]
         X = g["mpc._opt_x_num"][k] / s
         used = np.diff(nlp.jac(X, p).tocsc().indptr) > 0
