@@ -69,22 +69,131 @@ def sweep_bytes_per_problem(ps) -> int:
     return 8 * (reads + writes) * ps.n_edges
 
 
-def cpu_baseline(sample: int = 4) -> dict:
-    """Oracle (numpy/scipy restatement of NLP + IPOPT algorithm) on the same workload, bounded sample."""
+def _cpu_worker(job):
+    """one process = one core: cold make_step solves of the oracle (scipy SuperLU and BLAS pinned to one thread)"""
+    idx, n_per = job
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[v] = "1"
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    import warnings
+    warnings.filterwarnings("ignore")
     from oracle import ipm
     from oracle.models import CASES
     from oracle.nlp import OracleNLP
     nlp = OracleNLP(CASES["industrial_poly"]())
-    X0 = synthetic_x0_batch(sample)
+    X0 = synthetic_x0_batch(idx * n_per + n_per)[idx * n_per:]
     t0 = time.perf_counter()
     n_ok = 0
-    for i in range(sample):
+    for i in range(n_per):
         r = ipm.solve(nlp, nlp.initial_guess(X0[i]), nlp.opt_p(X0[i], np.zeros(nlp.nu)))
         n_ok += int(r["stats"]["success"])
-    dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "MPC steps/s", "cores": 1, "kind": "port",
-            "sample": f"{sample} cold make_step solves of the same workload (oracle/ipm.py, scipy sparse LU), "
-                      f"{n_ok}/{sample} converged, {dt:.1f} s"}
+    return n_ok, time.perf_counter() - t0
+
+
+def cpu_baseline(per_core: int = 2, max_cores: int = 0) -> dict:
+    """The CPU oracle (oracle/: numpy/scipy restatement of the reference's NLP + IPOPT's algorithm, general sparse LU of
+    the KKT matrix like IPOPT/MUMPS) on the same workload, the x0 batch fanned over one worker PROCESS per host core - the
+    way the reference itself parallelises make_step (examples/.../mp_sampling_closed_loop_02.py:69-70).
+    Bounded sample: `per_core` cold solves per core (about 10-20 s of wall time).  value = aggregate steps/s of all cores."""
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    host_cores = cores
+    cores = min(cores, max_cores or int(os.environ.get("DOMPC_CPU_BASELINE_CORES", "64")))   # (bounded: one 6 s model build + 0.3 GB per process)
+    ctx = mp.get_context("spawn")                 # (no fork after the HIP runtime is up)
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(i, per_core) for i in range(cores)])
+    wall = time.perf_counter() - t0
+    n = cores * per_core
+    n_ok = sum(r[0] for r in res)
+    t_solve = sum(r[1] for r in res)               # core-seconds inside the solves
+    t_par = max(r[1] for r in res)                 # the slowest worker's solve time = the parallel region
+    return {"value": n / t_par, "unit": "MPC steps/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+            "per_core": n / t_solve,
+            "sample": f"{n} cold make_step solves of the same workload ({per_core} per core, one process per core, "
+                      f"{cores} cores; oracle/ipm.py: Python port of IPOPT's algorithm, scipy SuperLU, 1 thread each), "
+                      f"{n_ok}/{n} converged, parallel region {t_par:.1f} s, {wall:.1f} s incl. process start-up"}
+
+
+def live_traffic(args, B: int):
+    """HBM bytes of ONE launch of dompc_solve_kernel at this batch size, measured NOW: two extra passes of this script (one
+    step each) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, MI355X_MICROARCH.md
+    section HBM; counter unit KB; FETCH_SIZE counts half of the bytes of coalesced reads on gfx950 - calibrated on this
+    project's 8 B/lane pattern in profiles/pmc_calibration.json: x2.0 / x1.0).  Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    tot = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="dompc_pmc_", dir="/tmp")
+        cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--batch", str(B), "--variant", args.variant,
+               "--no-cpu-baseline", "--no-traffic", "--no-b1"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                               timeout=float(os.environ.get("DOMPC_PMC_TIMEOUT", "300")))
+        except Exception as e:      # noqa: BLE001
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"{counter} pass failed: {type(e).__name__}"
+        val, rows = 0.0, 0
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "dompc_solve" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                    val += float(row["Counter_Value"])
+                    rows += 1
+        shutil.rmtree(d, ignore_errors=True)
+        if rows == 0:
+            return None, f"{counter} pass produced no rows (rc {r.returncode}): {r.stdout[-200:]}"
+        tot[counter] = val
+    byt = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
+    return byt, (f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one launch each at this batch size "
+                 f"(FETCH_SIZE {tot['FETCH_SIZE']:.6g} KB x2.0, WRITE_SIZE {tot['WRITE_SIZE']:.6g} KB x1.0)")
+
+
+def make_step_b1(mpc, ex, n_warm: int = 4) -> dict:
+    """The other half of the metric: wall time of ONE MPC.make_step (B = 1, through dompc_solve: host buffers in, u0 out,
+    K workgroups cooperating on the problem).  cold = first step from set_initial_guess; warm = the following steps, closed
+    on the MPC's own prediction (x0 <- predicted state of scenario 0, previous solution as initial guess, optimizer.py:754-768)."""
+    ps = mpc.structure
+    mpc.x0 = ex.X0
+    mpc.u0 = np.zeros(ps.nu)
+    mpc.set_initial_guess()
+    mpc.make_step(ex.X0)                         # untimed: wide-mode launch path, page-in
+    mpc.x0 = ex.X0
+    mpc.u0 = np.zeros(ps.nu)
+    mpc._t0 = mpc._t0 * 0
+    mpc.set_initial_guess()
+    t0 = time.perf_counter()
+    mpc.make_step(ex.X0)
+    cold = (time.perf_counter() - t0) * 1e3
+    ok = bool(mpc.solver_stats["success"])
+    it_cold = int(mpc.solver_stats["iter_count"])
+    warm, it_warm = [], []
+    for _ in range(n_warm):
+        i1 = ps.ix(1, 0, ps.M)
+        x1 = mpc.opt_x_num.master[i1:i1 + ps.nx] * mpc._x_scaling.master
+        t0 = time.perf_counter()
+        mpc.make_step(x1)
+        warm.append((time.perf_counter() - t0) * 1e3)
+        ok = ok and bool(mpc.solver_stats["success"])
+        it_warm.append(int(mpc.solver_stats["iter_count"]))
+    return {"cold": cold, "warm": float(np.mean(warm)), "unit": "ms", "iters_cold": it_cold,
+            "iters_warm": float(np.mean(it_warm)), "converged": ok,
+            "note": "host wall time of MPC.make_step (one problem, dompc_solve, host buffers; latency-bound: device-scope "
+                    "barriers between the workgroups of the problem)"}
 
 
 def main():
@@ -101,6 +210,8 @@ def main():
     ap.add_argument("--n-robust", type=int, default=5, help="--variant tree: depth of the branching part (3^n leaves)")
     ap.add_argument("--cut-level", type=int, default=0, help="--variant tree: level whose nodes are the sub-tree roots (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--no-b1", action="store_true", help="skip the single-problem make_step latency")
     ap.add_argument("--max-soc", type=int, default=None,
                     help="measurement aid: ipopt.max_soc (default: IPOPT's 4; 0 switches the second-order correction off)")
     args = ap.parse_args()
@@ -186,15 +297,9 @@ def main():
         sweep_b = sweep_bytes_per_problem(ps)
         alg_bytes = float(stats["n_sweeps"].astype(np.float64).sum()) * sweep_b
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("batch") == B and rec.get("variant") == args.variant:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_note = None, "not measured (--no-traffic or N > 1)"
+        if not args.no_traffic and world == 1:
+            traffic, traffic_note = live_traffic(args, B)
         out = {
             "metric": "MPC steps/sec (make_step wall-time), industrial_poly robust multi-stage",
             "value": B * world * args.steps / dt, "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps,
@@ -205,16 +310,26 @@ def main():
                                    f"9 scenarios, N=20, Radau deg 2)",
                        "batch_per_gpu": B, "n_opt_x": ps.n_opt_x, "n_g": ps.n_g, "edges": ps.n_edges,
                        "start": "cold (set_initial_guess semantics)", "parallelism": f"x0-batch shards x{world}",
-                       "problem_slots": S.num_slots},
+                       "problem_slots": S.num_slots,
+                       "x0_batch": "seed 99: masses x(1 + 2 % U(-1,1)), temperatures +- 1 K U(-1,1), T_adiab recomputed "
+                                   "(SURVEY 8(d) asks for 2 % relative on every state: on Kelvin temperatures that leaves the "
+                                   "+-2 K reactor band and makes the robust problem infeasible, also for IPOPT)"},
             "solve": {"converged": n_ok, "of": B, "iters_mean": float(stats["iter_count"].mean()),
                       "iters_max": int(stats["iter_count"].max()),
                       "sweeps_per_solve": float(stats["n_sweeps"].mean()), "trials_per_solve": float(stats["n_trials"].mean()),
                       "u0_first": [float(v) for v in u0[0]]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "dompc_solve_kernel",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic_over_algorithmic": (traffic / alg_bytes if traffic else None),
+                         "kernel": "dompc_solve_kernel",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "sweep_bytes_per_problem": sweep_b},
         }
+        if not args.no_b1 and world == 1:
+            try:
+                out["make_step_ms_b1"] = make_step_b1(mpc, ex)
+            except Exception as e:      # noqa: BLE001
+                out["make_step_ms_b1"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         else:

@@ -26,6 +26,12 @@ U_RTOL, X_RTOL, STEP_TOL = 1e-6, 1e-5, 1e-6
 TIGHT_GOLDEN = {"batch_reactor": (1e-9, 1e-8), "rotating_masses": (1e-9, 1e-8), "CSTR": (1e-9, 1e-8),
                 "industrial_poly": (1e-8, X_RTOL)}   # (u0 2e-10; one weakly determined terminal state is 5e-7 from the golden -
                                                      #  in the oracle's solution as well, the two agree to 1e-11)
+# constraint multipliers vs the golden lam_g, relative to max(1, max|lam_g|).  Measured (host emulation = HIP path to the
+# last digits): batch_reactor 5e-15, CSTR 6e-16, rotating masses 3e-14, oscillating masses 4e-9 (discrete model: no
+# delta_w sequence to mirror, the goldens are IPOPT's iterates at its own termination), industrial_poly 2.1e-7 (the weakly
+# determined terminal temperatures, see above).
+LAM_RTOL = {"batch_reactor": 1e-11, "rotating_masses": 1e-11, "CSTR": 1e-11, "oscillating_masses": 1e-7,
+            "industrial_poly": 2e-6}
 
 _oracle_cache = {}
 
@@ -88,7 +94,8 @@ def check_golden_replay(make_mpc, name, steps):
         u_tol, x_tol = TIGHT_GOLDEN.get(name, (U_RTOL, X_RTOL))
         assert relerr(u0, U[k]) < u_tol, (name, k, u0, U[k])
         assert relerr(mpc.opt_x_num_unscaled.master[used], OX[k][used]) < x_tol
-        assert np.max(np.abs(mpc.lam_g_num - LG[k])) < 1e-2 * max(1.0, np.max(np.abs(LG[k])))
+        assert np.max(np.abs(mpc.lam_g_num - LG[k])) < LAM_RTOL[name] * max(1.0, np.max(np.abs(LG[k]))), (
+            name, k, np.max(np.abs(mpc.lam_g_num - LG[k])))
         assert np.allclose(mpc.opt_p_num.master, golden_opt_p(name, g, k, mpc.opt_p_num.master.size), rtol=0, atol=1e-12)
         mpc.u0 = U[k]
     # stored records have the reference's shapes

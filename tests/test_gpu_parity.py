@@ -60,7 +60,7 @@ def test_sweep_blocks_match_oracle_jacobian(name):
 
 
 @pytest.mark.parametrize("name,opts", [("batch_reactor", None), ("rotating_masses", None),
-                                       ("industrial_poly", None)])
+                                       ("industrial_poly", None), ("CSTR", None)])
 def test_same_iterates_as_the_oracle(name, opts):
     """IPOPT regularises every iteration of these problems (free unused variables make its matrix singular at delta_w = 0);
     the driver mirrors the delta_w sequence and keeps the bounded unused variables in the barrier problem."""
