@@ -94,7 +94,7 @@ def _cpu_worker(job):
     return n_ok, time.perf_counter() - t0
 
 
-def cpu_baseline(per_core: int = 2, max_cores: int = 0) -> dict:
+def cpu_baseline(per_core: int = 1, max_cores: int = 0) -> dict:
     """The CPU oracle (oracle/: numpy/scipy restatement of the reference's NLP + IPOPT's algorithm, general sparse LU of
     the KKT matrix like IPOPT/MUMPS) on the same workload, the x0 batch fanned over one worker PROCESS per host core - the
     way the reference itself parallelises make_step (examples/.../mp_sampling_closed_loop_02.py:69-70).

@@ -64,32 +64,31 @@ constexpr int GS_C = 1;
 // stored part of G_w^-1 (row-major LU_N x LU_N).  Single finite element: G_w^-1 = [[Gi, 0], [-E Gi, I]] with the
 // continuity rows E = -[D_1 I ... D_DEG I], so only Gi = G_cc^-1 (collocation block) is kept - 400 instead of
 // 900 doubles per industrial_poly edge written by every sweep and read by every forward pass.
+// Round 3: W = -G_w^-1 G_y and w0 = -G_w^-1 r are NOT stored any more (420 doubles per industrial_poly edge, written by
+// every sweep and read back by every forward pass): the forward pass forms dw = -G_w^-1 (G_y dy + r) from the stored
+// inverse, the u-columns of the point Jacobians (model-output record) and the residual vector.
 constexpr int LU_N = (NI == 1 && DEG > 0) ? DEG * NX : NW;
 constexpr int EW_LU = 0;
-constexpr int EW_W = EW_LU + LU_N * LU_N;    // NW x NA, row-major
-constexpr int EW_W0 = EW_W + NW * NA;
-constexpr int EW_SIGW = EW_W0 + NW;          // (the lambda-weighted Hessian blocks are read from the model-output record)
+constexpr int EW_SIGW = EW_LU + LU_N * LU_N; // Sigma_w + dsw      (the lambda-weighted Hessian blocks are read from the model-output record)
 constexpr int EW_RW = EW_SIGW + NW;
 constexpr int EW_JD = EW_RW + NW;            // NE x NA
 constexpr int EW_SIZE = ((EW_JD + NE * NA + 1 + 7) / 8) * 8;      // records start on 64-byte boundaries
 
 // per-edge shared (contiguous per edge) --------------------------------------------------------
+// The head [A B | c | Q~ | q~ + r_y] is what the backward Riccati pass reads (staged by LDS-DMA, dompc_riccati16.h).
 constexpr int ES_AB = 0;                     // NX x NA
 constexpr int ES_CV = ES_AB + NX * NA;
-constexpr int ES_QT = ES_CV + NX;            // NA x NA
-constexpr int ES_QV = ES_QT + NA * NA;
-constexpr int ES_RY = ES_QV + NA;          // G_y' lam + sf*omega*grad l + Jd' yd      (NA)
+constexpr int ES_QT = ES_CV + NX;            // NA x NA symmetric, packed upper triangle (symi)
+constexpr int ES_QV = ES_QT + NA * (NA + 1) / 2;       // condensed gradient q~ PLUS r_y (the Riccati pass only needs the sum)       (NA)
+constexpr int ES_RY = ES_QV + NA;            // G_y' lam + sf*omega*grad l + Jd' yd      (NA)   (dual residual assembly)
 constexpr int ES_GFY = ES_RY + NA;           // sf*omega*grad l                            (NA)
-constexpr int ES_MG = ES_GFY + NA;           // sf*omega*grad m (last edges)               (NX)
+constexpr int ES_QVB = ES_GFY + NA;          // W' b, b = barrier gradient of w per unit mu: q~(mu + dmu) = q~ + dmu W'b   (NA)
+constexpr int ES_MG = ES_QVB + NA;           // sf*omega*grad m (last edges)               (NX)
 constexpr int ES_MH = ES_MG + NX;            // sf*omega*hess m                            (NX x NX)
 constexpr int ES_SIGS = ES_MH + NX * NX;     // NE
 constexpr int ES_RDN = ES_SIGS + NE;         // d - s
 constexpr int ES_RSN = ES_RDN + NE;          // -yd - mu/(s-sl) + mu/(su-s)
-constexpr int ES_TP = ES_RSN + NE;           // NA x NA : P_c * Atilde (y columns)
-constexpr int ES_TV = ES_TP + NA * NA;       // NA : P_c*ctilde + p_c
-constexpr int ES_ACL = ES_TV + NA;          // NA x NA : Atilde * [I;K] (closed-loop map)
-constexpr int ES_CCL = ES_ACL + NA * NA;     // NA : Atilde*[0;kv] + ctilde
-constexpr int ES_OBJ = ES_CCL + NA;
+constexpr int ES_OBJ = ES_RSN + NE;
 constexpr int ES_SIZE = ((ES_OBJ + 1 + 7) / 8) * 8;
 
 // per-edge model-output record (global): results of the lowered model functions at the current iterate,
@@ -103,6 +102,19 @@ constexpr int MO_LT = MO_PT + (NI * DEG > 0 ? NI * DEG : 1) * PT_STRIDE;   // lt
 constexpr int MO_MT = MO_LT + 1 + NA + NA_T;                                 // mterm: val, g[NX], H (packed)
 constexpr int MO_NL = MO_MT + 1 + NX + NX_T;                                 // nlcons: d[NE], Jd[NE*NA], H (packed)
 constexpr int MO_SIZE = ((MO_NL + NE + NE * NA + NA_T + 7) / 8) * 8;
+// Compact form of the record (single finite element, continuous model): only the entries that depend on the iterate
+// travel through HBM - the generated dompc_*_c functions write them one after the other (lowering.py: compact()); the
+// structural zeros and model constants of the dense layout above (149 + 9 of the 231 entries of an industrial_poly
+// collocation point, the whole Hessian of its linear stage cost) live in a dense IMAGE of the record that every
+// wavefront keeps in its LDS region: initialised once per phase (mo_image_init), the variable entries of the current
+// edge scattered into it (mo_expand).  All consumers read the image through the dense indices.
+constexpr bool MO_COMPACT = (NI == 1) && (M > 0);
+constexpr int MOC_LT = NCOLL * DOMPC_DYN_NV;
+constexpr int MOC_MT = MOC_LT + DOMPC_LT_NV;
+constexpr int MOC_NL = MOC_MT + DOMPC_MT_NV;
+constexpr int MOC_N = MOC_NL + DOMPC_NL_NV;
+constexpr int MOC_SIZE = ((MOC_N + 7) / 8) * 8 > 0 ? ((MOC_N + 7) / 8) * 8 : 8;
+constexpr int MO_REC = MO_COMPACT ? MOC_SIZE : MO_SIZE;          // doubles per edge in global memory
 
 // per node -------------------------------------------------------------------------------------
 constexpr int ND_P = 0;                      // NA x NA
@@ -133,8 +145,8 @@ DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad,
   L.ew = take((int64_t)EW_SIZE * e_pad);
   L.es = take((int64_t)ES_SIZE * n_edges);
   L.nd = take((int64_t)ND_SIZE * n_nodes);
-  L.mo = take((int64_t)MO_SIZE * n_edges);
-  o += 128;                       // slack: block-granular staging reads of the last records may run past their end
+  L.mo = take((int64_t)MO_REC * n_edges);
+  o += 256;                       // slack: block-granular staging reads of the last records may run past their end
   L.total = o;
   return L;
 }
@@ -487,7 +499,7 @@ struct Prob {
   DOMPC_DEV double& EW(int e, int i) const { return ew[(int64_t)e * EW_SIZE + i]; }
   DOMPC_DEV double* ES(int e) const { return es + (int64_t)e * ES_SIZE; }
   DOMPC_DEV double* ND(int n) const { return nd + (int64_t)n * ND_SIZE; }
-  DOMPC_DEV double* MO(int e) const { return mo + (int64_t)e * MO_SIZE; }
+  DOMPC_DEV double* MO(int e) const { return mo + (int64_t)e * MO_REC; }
 };
 
 DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
@@ -690,16 +702,25 @@ static_assert(NW <= 64, "collocation block larger than 64 unknowns per edge is n
 // (single finite element: the matrix is assembled and eliminated in registers, LDS only holds W | w0 afterwards)
 constexpr int MX_LD = (NI == 1) ? NA + 1 : NC;                         // leading dimension of the LDS matrix
 constexpr int MX_W = (NI == 1) ? 0 : NW;                               // column offset of [W | w0] inside it
+#ifndef DOMPC_HOST_EMU
+constexpr bool TILE_CONDENSE = (NI == 1) && (DEG >= 1) && (NA <= 16);   // condensing on the matrix cores with register tiles (eval_edge_coop)
+#else
+constexpr bool TILE_CONDENSE = false;
+#endif
+// (the regions of the LDS-staged generic condensing - T1 beyond its first NW entries, U1, HUU, QT/HP - do not exist in the
+//  matrix-core variant: 750 doubles per wavefront for industrial_poly)
 constexpr int EL_MX = 0;
-constexpr int EL_T1 = EL_MX + NW * MX_LD;                              // Hww W  (NW x NA)
-constexpr int EL_T0 = EL_T1 + NW * NA;                                 // Hww w0 (NW)
+constexpr int EL_T1 = EL_MX + NW * MX_LD;                              // Hww W  (NW x NA); first NW entries: the residual rows
+constexpr int EL_T0 = EL_T1 + (TILE_CONDENSE ? NW : NW * NA);          // Hww w0 (NW)
 constexpr int EL_RW = EL_T0 + NW;                                      // Newton-form gradient of w (NW)
 constexpr int EL_SG = EL_RW + NW;                                      // Sigma_w (NW)
-constexpr int EL_U1 = EL_SG + NW;                                      // Huw W (NU x NA), Huw w0 (NU)
-constexpr int EL_HUU = EL_U1 + NU * NA + NU;                           // sum_p Huu_p (NU x NU)
-constexpr int EL_QT = EL_HUU + NU * NU;                                // W'T1 (NA x NA), W'W (NA x NA)
+constexpr int EL_BB = EL_SG + NW;                                      // barrier gradient of w per unit mu (NW)
+constexpr int EL_QV = EL_BB + NW;                                      // q~ (NA) and W'b (NA): stored by phase 7 (q~ together with r_y)
+constexpr int EL_U1 = EL_QV + 2 * NA;                                  // Huw W (NU x NA), Huw w0 (NU)
+constexpr int EL_HUU = EL_U1 + (TILE_CONDENSE ? 0 : NU * NA + NU);     // sum_p Huu_p (NU x NU)
+constexpr int EL_QT = EL_HUU + (TILE_CONDENSE ? 0 : NU * NU);          // W'T1 (NA x NA), W'W (NA x NA)
 constexpr int EL_HP = EL_QT;                                           // staged point Hessians H_p (NA x NA each): dead before QT is written
-constexpr int EL_NHP = (NI * DEG > 2 ? NI * DEG : 2);
+constexpr int EL_NHP = TILE_CONDENSE ? 0 : (NI * DEG > 2 ? NI * DEG : 2);
 constexpr int EL_PV = EL_QT + EL_NHP * NA * NA;                        // pivot rows (NW)
 constexpr int EL_RY = EL_PV + NW;                                      // G_y' lambda (NA), completed in phase 7
 #ifndef DOMPC_R16_NL
@@ -713,29 +734,83 @@ constexpr bool RB_IN_LDS = true;
 #endif
 constexpr int RB_NEED = RB_IN_LDS ? 2 * (NYT * NYT + NYT) + 5 * NA * NA + 6 * NA + NV * NA + NV + NE * (NA + 4) : 0;   // = rb::RB_SIZE (asserted there)
 // forward pass: step vectors + staged operands of a chain-node step (riccati_forward); matrix-core Riccati: two staging buffers
-constexpr int RF_NEED = 3 * NA + NV + NX + 2 * NW1 + (NV * NA + NV) + 2 * (NX * NA + NX);
-constexpr int R16_STAGE = ((NX * NA + NX + NA * NA + 3 * NA + 127) / 128) * 128;      // staged head of an edge record (dompc_riccati16.h)
+constexpr int RF_NEED = 3 * NA + NV + NX + 3 * NW1 + (NV * NA + NV) + 2 * (NX * NA + NX);
+constexpr int R16_STAGE = ((ES_QV + NA + 127) / 128) * 128;          // staged head of an edge record [A B | c | Q~ | q~ + r_y] (dompc_riccati16.h)
 constexpr int R16_NEED = R16_ENABLED ? 2 * R16_STAGE : 0;
 constexpr int el_max(int a, int b) { return a > b ? a : b; }
-// single finite element, device: the model-output record of the edge is copied into LDS by the LDS-DMA path one edge
-// ahead (eval_edge_coop), 64 lanes x 16 B per instruction
+// Dense image of the model-output record (MO_COMPACT) in the wavefront's LDS region; device: the compact record of the edge
+// is copied into a staging buffer next to it by the LDS-DMA path one edge ahead (eval_edge_coop), 64 lanes x 16 B per
+// instruction, and scattered into the image at the top of the edge
 #ifndef DOMPC_HOST_EMU
-constexpr bool MO_LDS = (NI == 1) && (M > 0);
+constexpr bool MO_LDS = MO_COMPACT;
 #else
 constexpr bool MO_LDS = false;
 #endif
-constexpr int EL_MOS = ((EL_RY + NA + 1) / 2) * 2;                        // (16-byte aligned)
-constexpr int MO_STAGE = MO_LDS ? ((MO_SIZE + 127) / 128) * 128 : 0;
-// forward pass, same condition: the per-edge record [G_cc^-1 | W | w0 | Sigma_w | r_w] and the head of the model-output
-// record (point Hessians) of the NEXT edge are staged behind the step vectors while the current edge is computed
+constexpr int MO_IMG = MO_COMPACT ? MO_SIZE : 0;
+constexpr int MOC_STAGE = MO_LDS ? ((MOC_SIZE + 127) / 128) * 128 : 0;
+constexpr int EL_MOS = ((EL_RY + NA + 1) / 2) * 2;                        // image (16-byte aligned)
+constexpr int EL_MOC = EL_MOS + MO_IMG;                                   // staging buffer of the compact record
+// forward pass, same condition: the per-edge record [G_cc^-1 | Sigma_w | r_w] and the compact model-output record of the
+// NEXT edge are staged behind the step vectors while the current edge is computed; the image follows
 constexpr int RF_EW = ((RF_NEED + 1) / 2) * 2;
 constexpr int EW_STAGE = MO_LDS ? ((EW_SIZE + 127) / 128) * 128 : 0;
-constexpr int RF_MOH = RF_EW + EW_STAGE;
-// (only the packed point Hessians are needed: one 16-byte aligned window of MOH_PW doubles per collocation point)
+constexpr int RF_MOC = RF_EW + EW_STAGE;
+constexpr int RF_IMG = RF_MOC + MOC_STAGE;
 constexpr int MOH_H0 = NX + NX * NA;                                    // offset of the packed Hessian inside a point record
-constexpr int MOH_PW = ((NA_T + 1 + 127) / 128) * 128;                  // window per point (start rounded down to an even index)
-constexpr int MOH_STAGE = MO_LDS ? NCOLL * MOH_PW : 0;
-constexpr int EL_SIZE = ((el_max(el_max(EL_MOS + MO_STAGE, RB_NEED), el_max(RF_MOH + MOH_STAGE, R16_NEED)) + 7) / 8) * 8;
+constexpr int EL_SIZE = ((el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)) + 7) / 8) * 8;
+
+// ---- dense image of a compact model-output record
+// dense index (MO_PT / MO_LT / MO_MT / MO_NL layout) of compact entry k
+DOMPC_DEV inline int moc_dense_index(int k) {
+  constexpr int NVD = DOMPC_DYN_NV > 0 ? DOMPC_DYN_NV : 1;
+  if (k < MOC_LT) return MO_PT + (k / NVD) * PT_STRIDE + DOMPC_DYN_VIDX[k % NVD];
+  if (k < MOC_MT) return MO_LT + DOMPC_LT_VIDX[k - MOC_LT];
+  if (k < MOC_NL) return MO_MT + DOMPC_MT_VIDX[k - MOC_MT];
+  return MO_NL + DOMPC_NL_VIDX[k - MOC_NL];
+}
+constexpr int MOC_PL = (MOC_N + GS_C - 1) / GS_C > 0 ? (MOC_N + GS_C - 1) / GS_C : 1;     // compact entries per lane
+struct MocMap { int idx[MOC_PL]; };
+// this lane's scatter targets (looked up ONCE per phase: the tables live in constant memory)
+DOMPC_DEV inline MocMap moc_map(int lane, int GS) {
+  MocMap m;
+#pragma unroll
+  for (int q = 0; q < MOC_PL; ++q) {
+    const int k = lane + q * GS;
+    m.idx[q] = moc_dense_index(k < MOC_N ? k : 0);
+  }
+  return m;
+}
+// image <- zeros + the model's constants (once per phase and wavefront; the variable entries are overwritten per edge)
+DOMPC_DEV inline void mo_image_init(ldsd* img, int lane, int GS) {
+  for (int i = lane; i < MO_SIZE; i += GS) img[i] = 0.0;
+#ifndef DOMPC_HOST_EMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#endif
+  for (int i = lane; i < NCOLL * DOMPC_DYN_NC; i += GS)
+    img[MO_PT + (i / (DOMPC_DYN_NC > 0 ? DOMPC_DYN_NC : 1)) * PT_STRIDE + DOMPC_DYN_CIDX[i % (DOMPC_DYN_NC > 0 ? DOMPC_DYN_NC : 1)]] =
+        DOMPC_DYN_CVAL[i % (DOMPC_DYN_NC > 0 ? DOMPC_DYN_NC : 1)];
+  for (int i = lane; i < DOMPC_LT_NC; i += GS) img[MO_LT + DOMPC_LT_CIDX[i]] = DOMPC_LT_CVAL[i];
+  for (int i = lane; i < DOMPC_MT_NC; i += GS) img[MO_MT + DOMPC_MT_CIDX[i]] = DOMPC_MT_CVAL[i];
+  for (int i = lane; i < DOMPC_NL_NC; i += GS) img[MO_NL + DOMPC_NL_CIDX[i]] = DOMPC_NL_CVAL[i];
+#ifndef DOMPC_HOST_EMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+// variable entries of one edge -> image.  `src`: the compact record (device: its staged copy in LDS; host: global memory)
+template <class SRC>
+DOMPC_DEV inline void mo_expand(ldsd* img, SRC src, const MocMap& m, int lane, int GS) {
+#pragma unroll
+  for (int q = 0; q < MOC_PL; ++q) {
+    const int k = lane + q * GS;
+    if (k < MOC_N) img[m.idx[q]] = src[k];
+  }
+#ifndef DOMPC_HOST_EMU
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
 
 DOMPC_DEV inline int point_of_slot(int sl) {
   // collocation point (i*DEG + j-1) stored in slot sl, or -1 for element-start states and xkf
@@ -773,7 +848,19 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
     const double* tvp = Q.P + A.p_off_tvp + k * NTVP;
     const int row0 = A.edge_row0[e];
     double* mo = Q.MO(e);
-    if (kind == 0) {
+    if constexpr (MO_COMPACT) {
+      // compact record: [variable entries of point 0 | point 1 | ... | stage cost | terminal cost | nl_cons]
+      if (kind == 0) {
+        const int jj = j % (DEG > 0 ? DEG : 1) + 1;
+        dompc_dyn_c(w + slot_of(0, jj) * NX, un, tvp, pp, Q.lam + row0 + (jj - 1) * NX, mo + j * DOMPC_DYN_NV);
+      } else if (kind == 1) {
+        dompc_lterm_c(xn, un, tvp, pp, mo + MOC_LT);
+      } else if (kind == 2) {
+        if (k == A.N - 1) dompc_mterm_c(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MOC_MT);
+      } else if (NE > 0) {
+        dompc_nlcons_c(xn, un, tvp, pp, Q.lam + row0 + NW + NX, mo + MOC_NL);
+      }
+    } else if (kind == 0) {
       double* pt = mo + MO_PT + j * PT_STRIDE;
       if (M == 0) {
         dompc_dyn(xn, un, tvp, pp, Q.lam + row0 + NW, pt, pt + NX, pt + NX + NX * NA);
@@ -806,9 +893,6 @@ __device__ inline d4 tile_mul(const d4& At, const d4& B) {      // At' * B over 
   for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(At[kb], B[kb], acc, 0, 0, 0);
   return acc;
 }
-constexpr bool TILE_CONDENSE = (NI == 1) && (DEG >= 1) && (NA <= 16);
-#else
-constexpr bool TILE_CONDENSE = false;
 #endif
 
 // value of `v` in lane `src` (wave-uniform, here a compile-time constant) for every lane: two v_readlane_b32, the
@@ -842,12 +926,8 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
   const double* nu_e = Q.lam + A.edge_row0[e] + NW;
   const double* mo = Q.MO(e);
   (void)mo;
-#ifndef DOMPC_HOST_EMU
-  const ldsd* mol = Ld + EL_MOS;
-#define MOV(i) (MO_LDS ? (double)mol[(i)] : mo[(i)])
-#else
-#define MOV(i) mo[(i)]
-#endif
+  const ldsd* mol = Ld + EL_MOS;          // (dense image of the compact record, see mo_expand)
+#define MOV(i) (MO_COMPACT ? (double)mol[(i)] : mo[(i)])
   const bool act = true;
   int fail = 0;
   (void)act;
@@ -992,6 +1072,7 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
         Q.gf[gi] = 0.0;
         Q.rd[gi] = t - zl_ + zu_;
         Ld[EL_RW + cx] = t + bar_grad(xv, l, u, mu);
+        Ld[EL_BB + cx] = bar_grad(xv, l, u, 1.0);
         Ld[EL_SG + cx] = sigma_of(xv, l, u, zl_, zu_);
       } else if (cx < R + NA) {
         const int yb = cx - R;
@@ -1008,6 +1089,7 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
       Q.gf[gi] = 0.0;
       Q.rd[gi] = t - zl_ + zu_;
       Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu);
+      Ld[EL_BB + col] = bar_grad(xv, l, u, 1.0);
       Ld[EL_SG + col] = sigma_of(xv, l, u, zl_, zu_);
     }
   }
@@ -1085,15 +1167,15 @@ DOMPC_DEV inline int run_edge_factor(const Thr& T, const Prob& Q, int e, double 
 __device__ inline void stage_mo(const Prob& Q, int e, int lane, ldsd* Ld) {
   const double* src = Q.MO(e);
 #pragma unroll
-  for (int q = 0; q < MO_STAGE / 128; ++q)
+  for (int q = 0; q < MOC_STAGE / 128; ++q)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 128 * q + 2 * lane),
-                                     (__attribute__((address_space(3))) void*)(Ld + EL_MOS + 128 * q), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(Ld + EL_MOC + 128 * q), 16, 0, 0);
 }
 #endif
 
 // `staged_e` (device, single finite element): the edge whose model-output record is in (or on its way into) the staging area
 // of this wavefront; the function requests the record of `e_next` as soon as it has read the last entry of its own.
-DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, double mu, int lane, int GS, ldsd* Ld, int& staged_e) {
+DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, double mu, int lane, int GS, ldsd* Ld, int& staged_e, const MocMap& mm) {
   const KArgs& A = *Q.A;
   const bool act = e >= 0;
   const int ee = act ? e : 0;
@@ -1123,16 +1205,16 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   const bool last_stage = (k == A.N - 1);
   (void)pf_xn; (void)pf_w; (void)pf_wend; (void)pf_xc; (void)pf_lam; (void)pf_c; (void)pf_cend;
   (void)pf_ltg; (void)pf_mg; (void)pf_mh; (void)pf_lt0; (void)pf_mt0; (void)last_stage;
-  // the model-output record of this edge: staged in LDS (device, single finite element - requested by the previous edge
-  // of this wavefront / the prologue of the sweep, see stage_mo) or read from global memory
-#ifndef DOMPC_HOST_EMU
+  // the model-output record of this edge: the dense image in LDS (compact record: staged by the previous edge of this
+  // wavefront / the prologue of the sweep, see stage_mo, and scattered into the image below) or global memory
   const ldsd* mol = Ld + EL_MOS;
-#define MOV(i) (MO_LDS ? (double)mol[(i)] : mo[(i)])
-#else
-#define MOV(i) mo[(i)]
+#define MOV(i) (MO_COMPACT ? (double)mol[(i)] : mo[(i)])
+#ifdef DOMPC_HOST_EMU
+  if (MO_COMPACT && act) mo_expand(Ld + EL_MOS, mo, mm, lane, GS);
 #endif
+  (void)mm;
 #ifndef DOMPC_HOST_EMU
-  constexpr int PF_LINES = (MO_SIZE * 8 + 127) / 128, PF_N = (PF_LINES + 63) / 64;
+  constexpr int PF_LINES = (MO_REC * 8 + 127) / 128, PF_N = (PF_LINES + 63) / 64;
   unsigned pf_tok[PF_N];
 #pragma unroll
   for (int q = 0; q < PF_N; ++q) pf_tok[q] = 0u;
@@ -1169,16 +1251,18 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
       for (int i = lane; i < NX * NA; i += GS) S_[ES_AB + i] = pt[NX + i];
       for (int i = lane; i < NA * NA; i += GS) {
+        if (i / NA > i % NA) continue;             // (packed upper triangle)
         const int ip = symi(i / NA, i % NA, NA);
         double v = pt[NX + NX * NA + ip] + omh * mo[MO_LT + 1 + NA + ip];
         if (NE > 0) v += mo[MO_NL + NE + NE * NA + ip];
-        S_[ES_QT + i] = v;
+        S_[ES_QT + ip] = v;
       }
       for (int b = lane; b < NA; b += GS) {
         double t = 0.0;
         for (int a = 0; a < NX; ++a) t += pt[NX + a * NA + b] * nu_e[a];
         Ld[EL_RY + b] = t;          // completed in phase 7
-        S_[ES_QV + b] = 0.0;
+        Ld[EL_QV + b] = 0.0;
+        Ld[EL_QV + NA + b] = 0.0;
       }
     }
   } else {
@@ -1243,7 +1327,10 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         }
         fetch_rest();
 #ifndef DOMPC_HOST_EMU
-        if (MO_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staged record (and everything above) has landed
+        if (MO_LDS) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staged record (and everything above) has landed
+          mo_expand(Ld + EL_MOS, (const ldsd*)(Ld + EL_MOC), mm, lane, GS);
+        }
 #endif
       }
       DOMPC_PH(4)
@@ -1289,6 +1376,12 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       DOMPC_PH(6)
       if (act) fail |= run_edge_factor(T, Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
       T.gsync();
+#ifndef DOMPC_HOST_EMU
+      // the compact record of the edge this wavefront handles next: on its way into the staging buffer (free since the
+      // expansion above) during the condensing phases and the stores of this edge.  Not earlier: the out-of-line
+      // factorisation waits for every outstanding memory operation at its entry (calling convention).
+      if (MO_LDS && e_next >= 0) { stage_mo(Q, e_next, lane, Ld); staged_e = e_next; }
+#endif
     } else {
     // ---- phase 2: assemble Mx = [G_w | G_y | r_g] and the residual rows; the point Hessians needed by the
     //      condensing phases are staged in LDS with the same batch of global loads
@@ -1347,6 +1440,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         Q.gf[gi] = 0.0;
         Q.rd[gi] = t - Q.zl[gi] + Q.zu[gi];
         Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu);
+        Ld[EL_BB + col] = bar_grad(xv, l, u, 1.0);
         Ld[EL_SG + col] = sigma_of(xv, l, u, Q.zl[gi], Q.zu[gi]);
       }
       for (int b = lane; b < NA; b += GS) {
@@ -1492,11 +1586,11 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
             const int row = p * NX + (i < NX ? i : 0);
             const double wv = Wm(row, j < NA ? j : 0), w0v = Wm(row, NA);
             const double hv = MOV(MO_PT + p * PT_STRIDE + NX + NX * NA + symi(i < NA ? i : 0, j < NA ? j : 0, NA));
-            const double sg = Ld[EL_SG + row] + Q.dsw, rw = Ld[EL_RW + row];
+            const double sg = Ld[EL_SG + row] + Q.dsw, rw = Ld[EL_RW + row], bb = Ld[EL_BB + row];
             Z[r] = (i < NX) ? (j < NA ? wv : 0.0) : ((i < NA && j == i) ? 1.0 : 0.0);
             z0[r] = (j == 0 && i < NX) ? w0v : 0.0;
             H[r] = (i < NA && j < NA) ? hv + ((i == j && i < NX) ? sg : 0.0) : 0.0;
-            rwv[r] = (j == 0 && i < NX) ? rw : 0.0;
+            rwv[r] = (i < NX) ? (j == 0 ? rw : (j == 1 ? bb : 0.0)) : 0.0;      // (column 1: the part of the gradient that is linear in mu -> W'b)
           }
           const d4 HZ = tile_mul<KB_A>(H, Z);
           const d4 hz0 = tile_mul<KB_A>(H, z0) + rwv;
@@ -1510,10 +1604,10 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
             const int i = g + 4 * r;
             const int row = (M - 1) * NX + (i < NX ? i : 0);
             const double wv = Wm(row, j < NA ? j : 0), w0v = Wm(row, NA);
-            const double sg = Ld[EL_SG + row] + Q.dsw, rw = Ld[EL_RW + row];
+            const double sg = Ld[EL_SG + row] + Q.dsw, rw = Ld[EL_RW + row], bb = Ld[EL_BB + row];
             Wk[r] = (i < NX && j < NA) ? wv : 0.0;
             SWk[r] = (i < NX && j < NA) ? sg * wv : 0.0;
-            sv0[r] = (j == 0 && i < NX) ? sg * w0v + rw : 0.0;
+            sv0[r] = (i < NX) ? (j == 0 ? sg * w0v + rw : (j == 1 ? bb : 0.0)) : 0.0;
           }
           QTt += tile_mul<KB_X>(Wk, SWk);
           qv0 += tile_mul<KB_X>(Wk, sv0);
@@ -1521,8 +1615,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = g + 4 * r;
-          if (i < NA && j < NA) S_[ES_QT + i * NA + j] = QTt[r];
-          if (i < NA && j == 0) S_[ES_QV + i] = qv0[r];
+          if (i <= j && j < NA) S_[ES_QT + symi(i, j, NA)] = QTt[r];
+          if (i < NA && j < 2) Ld[EL_QV + j * NA + i] = qv0[r];             // q~ and W'b: stored by phase 7
         }
       }
 #endif
@@ -1600,14 +1694,17 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           if (a1 >= NX && b >= NX) q += Ld[EL_HUU + (a1 - NX) * NU + (b - NX)];
           if (a1 >= NX) q += Ld[EL_U1 + (a1 - NX) * NA + b];
           if (b >= NX) q += Ld[EL_U1 + (b - NX) * NA + a1];
-          S_[ES_QT + it] = q;
+          if (a1 <= b) S_[ES_QT + symi(a1, b, NA)] = q;
         }
       }
       for (int a1 = lane; a1 < NA; a1 += GS) {
         double q = 0.0;
         for (int row = 0; row < NW; ++row) q += Ld[EL_MX + row * MX_LD + MX_W + a1] * (Ld[EL_RW + row] + Ld[EL_T0 + row]);
         if (a1 >= NX) q += Ld[EL_U1 + NU * NA + a1 - NX];
-        S_[ES_QV + a1] = q;
+        Ld[EL_QV + a1] = q;                   // stored by phase 7 together with r_y
+        double qb = 0.0;                      // W'b: the part of q~ that is linear in mu (refresh_mu)
+        for (int row = 0; row < NW; ++row) qb += Ld[EL_MX + row * MX_LD + MX_W + a1] * Ld[EL_BB + row];
+        Ld[EL_QV + NA + a1] = qb;
       }
     }
     }
@@ -1637,12 +1734,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
     }
 #ifndef DOMPC_HOST_EMU
-    if constexpr (MO_LDS && NE == 0) {
-      // the record of the edge this wavefront handles next: on its way into LDS while the stores of this edge drain
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (every read of the current record has returned)
-      if (e_next >= 0) { stage_mo(Q, e_next, lane, Ld); staged_e = e_next; }
-    }
-    // (other device variants) touch the model-output record of the edge this wavefront handles next (one dword per
+    // (device variants without the compact record) touch the model-output record of the edge this wavefront handles next (one dword per
     // 128-byte line): by the time its assembly starts the lines sit in L2 instead of HBM.  The values are consumed (never
     // true) at the end of the function so that the loads stay where they are.
     if constexpr (!MO_LDS) {
@@ -1665,9 +1757,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       // forward-pass data (interleaved per-edge workspace)
       if (NI != 1)       // (single element: G_cc^-1 went to the record straight from the registers)
         for (int it = lane; it < LU_N * LU_N; it += GS) Q.EW(e, EW_LU + it) = Ld[EL_MX + (it / LU_N) * NC + it % LU_N];
-      for (int it = lane; it < NW * NA; it += GS) Q.EW(e, EW_W + it) = Ld[EL_MX + (it / NA) * MX_LD + MX_W + it % NA];
       for (int r = lane; r < NW; r += GS) {
-        Q.EW(e, EW_W0 + r) = Ld[EL_MX + r * MX_LD + MX_W + NA];
         Q.EW(e, EW_SIGW + r) = Ld[EL_SG + r] + Q.dsw;
         Q.EW(e, EW_RW + r) = Ld[EL_RW + r];
       }
@@ -1686,6 +1776,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
             for (int i = 0; i < NE; ++i) r += MOV(MO_NL + NE + i * NA + a) * yd[i];
           S_[ES_GFY + a] = om * pf_ltg[q];
           S_[ES_RY + a] = r;
+          S_[ES_QV + a] = Ld[EL_QV + a] + r;
+          S_[ES_QVB + a] = Ld[EL_QV + NA + a];
         }
       }
       if (last_stage) {
@@ -1707,6 +1799,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         for (int i = 0; i < NE; ++i) r += mo[MO_NL + NE + i * NA + a] * yd[i];
       S_[ES_GFY + a] = om * mo[MO_LT + 1 + a];
       S_[ES_RY + a] = r;
+      S_[ES_QV + a] = Ld[EL_QV + a] + r;
+      S_[ES_QVB + a] = Ld[EL_QV + NA + a];
     }
     if (k == A.N - 1) {
       for (int a = lane; a < NX; a += GS) S_[ES_MG + a] = om * mo[MO_MT + 1 + a];
@@ -1743,12 +1837,6 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
 #pragma unroll
     for (int q = 0; q < PF_N; ++q) acc |= pf_tok[q] == 0x7ff8deadu ? 1u : 0u;
     if (acc && mu < 0.0) fail = 1;
-  }
-#endif
-#ifndef DOMPC_HOST_EMU
-  if constexpr (MO_LDS && NE > 0) {          // (nl_cons rows: the record is read until the end of the edge)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (e_next >= 0) { stage_mo(Q, e_next, lane, Ld); staged_e = e_next; }
   }
 #endif
   DOMPC_PH(3)
@@ -1870,22 +1958,11 @@ constexpr int RN_NLN = NE * (NA + 4);          // nl_cons data of a child edge: 
 constexpr int RN_NLP = NE > 0 ? (RN_NLN + GS_C - 1) / GS_C : 1;
 constexpr int RN_ABN = NX * (NA + 1);          // [A | B | c] of a child edge
 constexpr int RN_ABP = (RN_ABN + GS_C - 1) / GS_C;
-// W'W and W'w0 of an edge enter only under inertia correction (Q(delta) = Q + delta W'W, a handful of iterations per
-// solve at most): they are formed on demand from the stored W instead of being written by every sweep.
-DOMPC_DEV inline double wtw_entry(const Prob& Q, int e, int yi, int yj) {
-  double t = 0.0;
-  for (int r = 0; r < NW; ++r) t += Q.EW(e, EW_W + r * NA + yi) * Q.EW(e, EW_W + r * NA + yj);
-  return t;
-}
-DOMPC_DEV inline double wtw0_entry(const Prob& Q, int e, int yi) {
-  double t = 0.0;
-  for (int r = 0; r < NW; ++r) t += Q.EW(e, EW_W + r * NA + yi) * Q.EW(e, EW_W0 + r);
-  return t;
-}
-
+// (An inertia correction that the last sweep has not folded into the condensed blocks - Q~(delta) = Q~ + delta W'W - is
+//  handled by REPEATING the sweep with Prob::dsw = delta (solve_problem): W is not kept beyond the sweep any more.)
 struct NodePre {
-  double qt[RN_IPL], wtw[RN_IPL];
-  double pv[RN_VPL][10];                       // x, lb, ub, zl, zu, nu_in, u_prev, RY, QV, WTW0
+  double qt[RN_IPL];
+  double pv[RN_VPL][10];                       // x, lb, ub, zl, zu, nu_in, u_prev, -, q~ + r_y, -
   double nl[RN_NLP];
   double ab[RN_ABP];
 };
@@ -1905,15 +1982,14 @@ DOMPC_DEV inline void node_prefetch(const Prob& Q, int n, double delta, int lane
   const int xo = A.node_x_off[n], uo = A.node_u_off[n];
   const int eo = NS > 0 ? A.node_eps_off[n] : -1;
   const int ie = A.node_in_edge[n], pn = A.node_parent[n];
-  const bool wd = delta != Q.dsw;                    // (delta - dsw on the eliminated variables: see Prob::dsw)
+  (void)delta;
 #pragma unroll
   for (int q = 0; q < RN_IPL; ++q) {
     const int it = lane + q * GS;
     const int itc = it < NYT * NYT ? it : 0;
     const int yi = yidx(itc / NYT), yj = yidx(itc % NYT);
-    const int idx = (yi >= 0 && yj >= 0) ? yi * NA + yj : 0;
+    const int idx = (yi >= 0 && yj >= 0) ? symi(yi, yj, NA) : 0;
     R.qt[q] = S_[ES_QT + idx];
-    R.wtw[q] = (wd && yi >= 0 && yj >= 0) ? wtw_entry(Q, e, yi, yj) : 0.0;
   }
 #pragma unroll
   for (int v = 0; v < RN_VPL; ++v) {
@@ -1931,9 +2007,9 @@ DOMPC_DEV inline void node_prefetch(const Prob& Q, int n, double delta, int lane
     const int iu = is_up ? i - NX : (i >= NA && i < NA + NU ? i - NA : 0);
     const bool hu = i >= NX && i < NA + NU;
     R.pv[v][6] = hu ? (pn >= 0 ? Q.x[A.node_u_off[pn] + iu] : Q.P[A.p_off_uprev + iu] / DOMPC_SU[iu]) : 0.0;
-    R.pv[v][7] = yi >= 0 ? S_[ES_RY + yi] : 0.0;
+    R.pv[v][7] = 0.0;
     R.pv[v][8] = yi >= 0 ? S_[ES_QV + yi] : 0.0;
-    R.pv[v][9] = (yi >= 0 && wd) ? wtw0_entry(Q, e, yi) : 0.0;
+    R.pv[v][9] = 0.0;
   }
   if (NE > 0) {
 #pragma unroll
@@ -1958,7 +2034,6 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
                                   bool child_staged, const NodePre& R) {
   using namespace rb;
   const KArgs& A = *Q.A;
-  const double dxw = delta - Q.dsw;                   // share of delta that the condensed blocks do not hold yet (Prob::dsw)
   double* Nd = Q.ND(n);
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
@@ -1979,14 +2054,9 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
     const int itc = it < NYT * NYT ? it : 0;
     const int yi = yidx(itc / NYT), yj = yidx(itc % NYT);
     const bool valid = it < NYT * NYT && yi >= 0 && yj >= 0;
-    const int idx = valid ? yi * NA + yj : 0;
-    double v = R.qt[q] + dxw * R.wtw[q];
-    for (int c = 1; c < cc; ++c) {
-      const double* S_ = Q.ES(cs + c);
-      double t = S_[ES_QT + idx];
-      if (dxw != 0.0 && valid) t += dxw * wtw_entry(Q, cs + c, yi, yj);
-      v += t;
-    }
+    const int idx = valid ? symi(yi, yj, NA) : 0;
+    double v = R.qt[q];
+    for (int c = 1; c < cc; ++c) v += Q.ES(cs + c)[ES_QT + idx];
     qacc[q] = valid ? v : 0.0;
   }
   // per-variable terms (diagonal + gradient): lanes 0..NYT-1
@@ -2014,12 +2084,9 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
         gv += cc * Q.sf * DOMPC_EPS_PEN[i - NA - NU];
       }
     }
-    gv += R.pv[v][7] + R.pv[v][8] + dxw * R.pv[v][9];
+    gv += R.pv[v][8];
     if (yi >= 0)
-      for (int c = 1; c < cc; ++c) {
-        const double* S_ = Q.ES(cs + c);
-        gv += S_[ES_RY + yi] + S_[ES_QV + yi] + (dxw != 0.0 ? dxw * wtw0_entry(Q, cs + c, yi) : 0.0);
-      }
+      for (int c = 1; c < cc; ++c) gv += Q.ES(cs + c)[ES_QV + yi];
     gvv[v] = gv;
     dgv[v] = dg;
   }
@@ -2280,7 +2347,6 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
                                       int GS, int phase) {
   using namespace rb;
   const KArgs& A = *Q.A;
-  const double dxw = delta - Q.dsw;
   double* Nd = Q.ND(n);
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const int ci = A.node_cut[n];
@@ -2334,7 +2400,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
         if (!counted(c)) continue;
         const int e = cs + c;
         const double* S_ = Q.ES(e);
-        if (yi >= 0) gv += S_[ES_RY + yi] + S_[ES_QV + yi] + (dxw != 0.0 ? dxw * wtw0_entry(Q, e, yi) : 0.0);
+        if (yi >= 0) gv += S_[ES_QV + yi];
         if (NE > 0) {
           const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
           for (int q = 0; q < NE; ++q) {
@@ -2359,10 +2425,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
         if (!counted(c)) continue;
         const int e = cs + c;
         const double* S_ = Q.ES(e);
-        if (yi >= 0 && yj >= 0) {
-          v += S_[ES_QT + yi * NA + yj];
-          if (dxw != 0.0) v += dxw * wtw_entry(Q, e, yi, yj);
-        }
+        if (yi >= 0 && yj >= 0) v += S_[ES_QT + symi(yi, yj, NA)];
         if (NE > 0)
           for (int qq = 0; qq < NE; ++qq) {
             const double sg = S_[ES_SIGS + qq] + delta;
@@ -2654,7 +2717,6 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
 // One group of lanes per node (level by level), then one group per edge.
 DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double delta) {
   const KArgs& A = *Q.A;
-  const double dxw = delta - Q.dsw;
   const int GS = T.gs, ng = T.nt / GS, gid = group_index(T.tid, GS), lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   // operands of a chain-node step, staged in LDS: own gains [K | kv], the child edge's [A B | c], the first NX rows of
@@ -2662,7 +2724,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   constexpr int FW_K = NV * NA + NV, FW_AB = NX * NA + NX, FW_N = FW_K + 2 * FW_AB;
   constexpr int FW_PL = (FW_N + GS_C - 1) / GS_C;
   constexpr int RF_DX = 0, RF_DV = RF_DX + NA, RF_DY = RF_DV + NV, RF_DNU = RF_DY + NA, RF_DW = RF_DNU + NX,
-                RF_RHS = RF_DW + NW1, RF_DXN = RF_RHS + NW1, RF_IN = RF_DXN + NA;
+                RF_RHS = RF_DW + NW1, RF_G = RF_RHS + NW1, RF_DXN = RF_G + NW1, RF_IN = RF_DXN + NA;
   static_assert(RF_IN + FW_N <= EL_SIZE, "forward working set must fit the per-group LDS region");
   static_assert(RF_IN + FW_N <= RF_EW, "the staged edge records start behind the step vectors and chain-step operands");
   long long pc0 = prof_clock();
@@ -2813,8 +2875,12 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     for (int b = 0; b < NA; ++b) t += Nd[ND_P + a * NA + b] * Nd[ND_DXT + b];
     Q.dlam[a] = -t;
   }
-  // per edge: dw, d nu, d lambda, nl_cons steps.  Everything a lane needs from the per-edge record (its rows of W, Hww,
-  // its column of the stored inverse block) and from the node steps is loaded in ONE batch at the top of the edge.
+  // per edge: dw, d nu, d lambda, nl_cons steps.  The collocation steps come from the stored inverse block,
+  //     dw = -G_w^-1 (G_y dy + r),   G_y dy: -C_0j dx / -D_0 dx on the rows of the first element, J_u du on the collocation rows,
+  // (W = -G_w^-1 G_y itself is not kept beyond the sweep), the multiplier steps from its transpose.  Everything a lane needs
+  // from the per-edge record (its row AND its column of the stored inverse block, Sigma_w, r_w), from the model-output
+  // record (its row of H_ww / H_wu, its entries of J_u - read from the dense image, mo_expand) and from the node steps is
+  // loaded in ONE batch at the top of the edge.
 #ifndef DOMPC_HOST_EMU
   auto stage_fw = [&](int e) {               // LDS-DMA: 64 lanes x 16 B per instruction (see stage_mo)
     const double* ew_ = Q.ew + (int64_t)e * EW_SIZE;
@@ -2824,23 +2890,24 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ew_ + 128 * q + 2 * lane),
                                        (__attribute__((address_space(3))) void*)(Ld + RF_EW + 128 * q), 16, 0, 0);
 #pragma unroll
-    for (int pq = 0; pq < NCOLL * (MOH_PW / 128); ++pq) {
-      const int pt = pq / (MOH_PW / 128), q = pq % (MOH_PW / 128);
-      const int src0 = ((MO_PT + pt * PT_STRIDE + MOH_H0) & ~1) + 128 * q;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mo_ + src0 + 2 * lane),
-                                       (__attribute__((address_space(3))) void*)(Ld + RF_MOH + pt * MOH_PW + 128 * q), 16, 0, 0);
-    }
+    for (int q = 0; q < MOC_STAGE / 128; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mo_ + 128 * q + 2 * lane),
+                                       (__attribute__((address_space(3))) void*)(Ld + RF_MOC + 128 * q), 16, 0, 0);
   };
 #endif
+  const MocMap mm = moc_map(lane, GS);
+  if (MO_COMPACT && M > 0) mo_image_init(Ld + RF_IMG, lane, GS);
   int fw_staged = -1;                        // edge whose records are in (on their way into) the staging area
-  double dy0 = 0.0, dnu0 = 0.0;              // this lane's entry of dy / d nu of the edge, requested one edge ahead
+  double dy0 = 0.0, dnu0 = 0.0, cr0 = 0.0;   // this lane's entry of dy / d nu / the residual of the edge, requested one edge ahead
   bool have_pre = false;
-  auto load_dy = [&](int e, double& dy_, double& dnu_) {
+  auto load_dy = [&](int e, double& dy_, double& dnu_, double& cr_) {
     const int n = A.edge_parent[e];
     const int a0 = lane < NA ? lane : 0;
     dy_ = (a0 < NX) ? Q.ND(n)[ND_DXT + a0] : Q.dx[A.node_u_off[n] + a0 - NX];
     dnu_ = Q.dlam[A.edge_row0[e] + NW + (lane < NX ? lane : 0)];
+    cr_ = Q.c[A.edge_row0[e] + (lane < NW ? lane : 0)];
   };
+  (void)fw_staged; (void)have_pre; (void)cr0;
   for (int e = gid; e < A.n_edges; e += ng) {
     if (!mk_e(A, e)) continue;
     const int n = A.edge_parent[e], cn = A.edge_child[e];
@@ -2850,44 +2917,53 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     const bool chain_edge = A.edge_level[e] >= cl;          // its d nu was formed by the chain walk
     constexpr int RPL = (NW1 + GS_C - 1) / GS_C;          // rows (= columns of G_w^-1) per lane: 1 on the device
     constexpr int LU1 = LU_N > 0 ? LU_N : 1;
-    double wrow[RPL][NA + 1], hrow[RPL][NA], rw_r[RPL], sg_r[RPL], inv_c[RPL][LU1];
+    constexpr int NU1 = NU > 0 ? NU : 1;
+    constexpr int ELR = (DEG + 1) * NX > 0 ? (DEG + 1) * NX : 1;      // rows of one finite element
+    double hrow[RPL][NA], ju[RPL][NU1], rw_r[RPL], sg_r[RPL], inv_c[RPL][LU1], inv_r[RPL][LU1], c_r[RPL];
 #ifndef DOMPC_HOST_EMU
     if (MO_LDS && fw_staged != e) { stage_fw(e); fw_staged = e; }
-    if (GS > 1 && !have_pre) load_dy(e, dy0, dnu0);
-    if (MO_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (GS > 1 && !have_pre) load_dy(e, dy0, dnu0, cr0);
+    if (MO_LDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      mo_expand(Ld + RF_IMG, (const ldsd*)(Ld + RF_MOC), mm, lane, GS);
+    }
 #define EWV(i) (MO_LDS ? (double)Ld[RF_EW + (i)] : Q.EW(e, (i)))
-#define MHV(pt_, k_) (MO_LDS ? (double)Ld[RF_MOH + (pt_) * MOH_PW + ((MO_PT + (pt_) * PT_STRIDE + MOH_H0) & 1) + (k_)] \
-                             : Q.MO(e)[MO_PT + (pt_) * PT_STRIDE + MOH_H0 + (k_)])
 #else
+    if (MO_COMPACT && M > 0) mo_expand(Ld + RF_IMG, Q.MO(e), mm, lane, GS);
 #define EWV(i) Q.EW(e, (i))
-#define MHV(pt_, k_) Q.MO(e)[MO_PT + (pt_) * PT_STRIDE + MOH_H0 + (k_)]
 #endif
+#define MOVF(i) (MO_COMPACT ? (double)Ld[RF_IMG + (i)] : Q.MO(e)[(i)])
     if (M > 0) {
 #pragma unroll
       for (int q = 0; q < RPL; ++q) {
         const int r = lane + q * GS;
         const int rc = r < NW ? r : 0;
         const int pt = point_of_slot(rc / NX);
-#pragma unroll
-        for (int b = 0; b < NA; ++b) wrow[q][b] = EWV(EW_W + rc * NA + b);
-        wrow[q][NA] = EWV(EW_W0 + rc);
         rw_r[q] = EWV(EW_RW + rc);
         sg_r[q] = EWV(EW_SIGW + rc);
         const int ptc = pt >= 0 ? pt : 0;
 #pragma unroll
-        for (int b = 0; b < NA; ++b) hrow[q][b] = MHV(ptc, symi(rc % NX, b, NA));
+        for (int b = 0; b < NA; ++b) hrow[q][b] = MOVF(MO_PT + ptc * PT_STRIDE + MOH_H0 + symi(rc % NX, b, NA));
+#pragma unroll
+        for (int u = 0; u < NU; ++u) ju[q][u] = MOVF(MO_PT + ptc * PT_STRIDE + NX + (rc % NX) * NA + NX + u);
         const int rl = r < LU_N ? r : 0;
 #pragma unroll
-        for (int k2 = 0; k2 < LU_N; ++k2) inv_c[q][k2] = EWV(EW_LU + k2 * LU_N + rl);   // column r of the stored block
+        for (int k2 = 0; k2 < LU_N; ++k2) {
+          inv_c[q][k2] = EWV(EW_LU + k2 * LU_N + rl);     // column r of the stored block (multiplier steps)
+          inv_r[q][k2] = EWV(EW_LU + rl * LU_N + k2);     // row r (collocation steps)
+        }
         if (pt < 0) {
 #pragma unroll
           for (int b = 0; b < NA; ++b) hrow[q][b] = 0.0;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) ju[q][u] = 0.0;
         }
+        c_r[q] = (GS > 1) ? 0.0 : Q.c[row0 + rc];
       }
     }
 #undef EWV
-#undef MHV
-    double dy_n = 0.0, dnu_n = 0.0;
+#undef MOVF
+    double dy_n = 0.0, dnu_n = 0.0, cr_n = 0.0;
     bool pre_n = false;
 #ifndef DOMPC_HOST_EMU
     if (MO_LDS) {
@@ -2897,17 +2973,16 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       if (e_nx < A.n_edges && mk_e(A, e_nx)) {
         stage_fw(e_nx);
         fw_staged = e_nx;
-        if (GS > 1) { load_dy(e_nx, dy_n, dnu_n); pre_n = true; }
+        if (GS > 1) { load_dy(e_nx, dy_n, dnu_n, cr_n); pre_n = true; }
       }
     }
 #endif
     {
       if (GS > 1) {
-#ifdef DOMPC_HOST_EMU
-        load_dy(e, dy0, dnu0);
-#endif
         if (lane < NA) Ld[RF_DY + lane] = dy0;
         if (chain_edge && lane < NX) Ld[RF_DNU + lane] = dnu0;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) c_r[q] = cr0;
       } else {
         for (int a = 0; a < NA; ++a) Ld[RF_DY + a] = (a < NX) ? Nd[ND_DXT + a] : Q.dx[A.node_u_off[n] + a - NX];
         if (chain_edge)
@@ -2926,15 +3001,51 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     T.gsync();
     if (M > 0) {
       const int woff = A.edge_w_off[e];
+      // g = G_y dy + r on the rows of the stored block
 #pragma unroll
       for (int q = 0; q < RPL; ++q) {
         const int r = lane + q * GS;
-        if (r < NW) {
-          double t = wrow[q][NA];
+        if (r < LU_N) {
+          const int i = r / ELR, rr = r % ELR, jj = rr / NX, a = rr % NX;
+          double t = c_r[q];
+          if (jj < DEG) {
 #pragma unroll
-          for (int b = 0; b < NA; ++b) t += wrow[q][b] * Ld[RF_DY + b];
+            for (int u = 0; u < NU; ++u) t += ju[q][u] * Ld[RF_DY + NX + u];
+            if (i == 0) t -= ((NI == 1) ? tab_sel(DOMPC_C, jj + 1, DEG > 0 ? 1 : 0, DEG > 0 ? DEG : 1) : DOMPC_C[jj + 1]) * Ld[RF_DY + a];
+          } else if (i == 0) {
+            t -= DOMPC_D[0] * Ld[RF_DY + a];
+          }
+          Ld[RF_G + r] = t;
+        }
+      }
+      T.gsync();
+      // dw = -G_w^-1 g: the rows of the stored block ...
+#pragma unroll
+      for (int q = 0; q < RPL; ++q) {
+        const int r = lane + q * GS;
+        if (r < LU_N) {
+          double t = 0.0;
+#pragma unroll
+          for (int k2 = 0; k2 < LU_N; ++k2) t -= inv_r[q][k2] * Ld[RF_G + k2];
           Ld[RF_DW + r] = t;
           Q.dx[woff + r] = t;
+        }
+      }
+      if (LU_N < NW) {
+        // ... and (single finite element: G_w^-1 = [[Gi, 0], [-E Gi, I]]) the end-point rows from the continuity equation
+        //     dw_e = sum_s D_s dw_s + D_0 dx - r_e
+        T.gsync();
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+          const int r = lane + q * GS;
+          if (r >= LU_N && r < NW) {
+            const int a = r - LU_N;
+            double t = DOMPC_D[0] * Ld[RF_DY + a] - c_r[q];
+#pragma unroll
+            for (int s_ = 1; s_ <= DEG; ++s_) t += DOMPC_D[s_] * Ld[RF_DW + (s_ - 1) * NX + a];
+            Ld[RF_DW + r] = t;
+            Q.dx[woff + r] = t;
+          }
         }
       }
       T.gsync();
@@ -2945,7 +3056,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         const int r = lane + q * GS;
         if (r < NW) {
           const int sl = r / NX;
-          double t = rw_r[q] + (sg_r[q] + dxw) * Ld[RF_DW + r];      // (the stored Sigma_w already holds Prob::dsw)
+          double t = rw_r[q] + sg_r[q] * Ld[RF_DW + r];      // (the stored Sigma_w holds the inertia correction, Prob::dsw = delta)
           if (r >= (M - 1) * NX) t += Ld[RF_DNU + r - (M - 1) * NX];
 #pragma unroll
           for (int b = 0; b < NX; ++b) t += hrow[q][b] * Ld[RF_DW + sl * NX + b];
@@ -2988,7 +3099,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       }
     }
     T.gsync();
-    dy0 = dy_n; dnu0 = dnu_n; have_pre = pre_n;
+    dy0 = dy_n; dnu0 = dnu_n; cr0 = cr_n; have_pre = pre_n;
     DOMPC_PF(20)
   }
   // dummies (variables in no constraint / cost): independent scalar Newton steps
@@ -3023,7 +3134,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   T.sync();
   DOMPC_PS(21)
   for (int rep = 0; rep < A.trace_pad; ++rep) {      // measurement aid (DOMPC_EXTRA_TRAFFIC): extra read+write passes over the model-output records
-    for (int i = T.tid; i < A.n_edges * MO_SIZE; i += T.nt) { volatile double* p_ = Q.mo + i; *p_ = *p_; }
+    for (int i = T.tid; i < A.n_edges * MO_REC; i += T.nt) { volatile double* p_ = Q.mo + i; *p_ = *p_; }
     T.sync();
   }
   {
@@ -3031,12 +3142,14 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / T.gs) * EL_SIZE;
     const int rounds = (A.n_edges + ng - 1) / ng;
     int staged_e = -1;
+    const MocMap mm = moc_map(lane, T.gs);
+    if (MO_COMPACT) mo_image_init(Ld + EL_MOS, lane, T.gs);
     for (int rd = 0; rd < rounds; ++rd) {
       const int e = rd * ng + gid;
       const int en = e + ng;
       const bool mine = e < A.n_edges && mk_e(A, e);
       if (sh_on(A) && !mine) continue;                  // sharded: another rank's edge (no workgroup barrier inside)
-      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld, staged_e)) T.fset(1, 1);
+      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld, staged_e, mm)) T.fset(1, 1);
     }
   }
   T.sync();
@@ -3082,18 +3195,10 @@ DOMPC_PHASE void refresh_mu(const Thr& T, const Prob& Q, double dmu) {
       const int woff = A.edge_w_off[e];
       for (int r = lane; r < NW; r += GS) {
         const int gi = woff + r;
-        const double b = bar_grad(Q.x[gi], Q.lb[gi], Q.ub[gi], 1.0);
-        Ld[r] = b;
-        Q.EW(e, EW_RW + r) += dmu * b;
+        Q.EW(e, EW_RW + r) += dmu * bar_grad(Q.x[gi], Q.lb[gi], Q.ub[gi], 1.0);
       }
-      T.gsync();
       double* S_ = Q.ES(e);
-      for (int a = lane; a < NA; a += GS) {
-        double t = 0.0;
-        for (int r = 0; r < NW; ++r) t += Q.EW(e, EW_W + r * NA + a) * Ld[r];
-        S_[ES_QV + a] += dmu * t;
-      }
-      T.gsync();
+      for (int a = lane; a < NA; a += GS) S_[ES_QV + a] += dmu * S_[ES_QVB + a];      // (W'b was formed by the sweep)
     }
     if (NE > 0) {
       double* S_ = Q.ES(e);
@@ -3773,6 +3878,13 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         first_try = false;   // (IPOPT: the larger factor only on the very first increase)
         if (delta > O.delta_w_max) { dir_ok = false; break; }
       }
+      if (NW > 0 && delta != Q.dsw) {
+        // the condensed blocks hold another inertia correction (Q~(delta) = Q~ + delta W'W, q~ likewise): the sweep is
+        // repeated with this one folded in - W is not kept beyond the sweep, so the Riccati pass cannot add the
+        // difference itself.  Rare: under `singular0` the first delta of an iteration is known before its sweep.
+        ++n_sweeps;
+        if (run_sweep(T, Q, b, slot, mu, 0, delta)) { dir_ok = false; break; }
+      }
     }
     if (!dir_ok) { status = 3; break; }
     if (delta > 0.0) { delta_last = delta; ++n_reg; }
@@ -4008,7 +4120,7 @@ DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A) {
     T.sync();
   }
   Q.sf = 1.0;
-  run_sweep(T, Q, 0, 0, A.dbg_mu);
+  run_sweep(T, Q, 0, 0, A.dbg_mu, 0, A.dbg_delta);
   const int fail = run_backward(T, Q, 0, 0, A.dbg_mu, A.dbg_delta);
   run_forward(T, Q, 0, 0, A.dbg_mu, A.dbg_delta);
   for (int g = T.tid; g < nX; g += T.nt) {
@@ -4048,8 +4160,8 @@ DOMPC_DEV inline void sweep_problem(const Thr& T, const KArgs& A, int b, int slo
     double v;
     if (i < NX * NA) v = S_[ES_AB + i];
     else if (i < NX * NA + NX) v = S_[ES_CV + i - NX * NA];
-    else if (i < NX * NA + NX + NA * NA) v = S_[ES_QT + i - NX * NA - NX];
-    else v = S_[ES_QV + i - NX * NA - NX - NA * NA] + S_[ES_RY + i - NX * NA - NX - NA * NA];
+    else if (i < NX * NA + NX + NA * NA) v = S_[ES_QT + symi((i - NX * NA - NX) / NA, (i - NX * NA - NX) % NA, NA)];
+    else v = S_[ES_QV + i - NX * NA - NX - NA * NA];
     bl[it] = v;
   }
   T.sync();

@@ -63,9 +63,8 @@ __device__ inline void load_edge(const Prob& Q, int e, int lane, d4& F, d4& f0, 
   fu = v;
 }
 
-// condensed Hessian block of edge e scattered into the z x z tile (+ dxw W'W: the share of an inertia correction that the
-// sweep has not folded into the block, Prob::dsw)
-__device__ inline d4 load_qt(const Prob& Q, int e, double dxw, int lane) {
+// condensed Hessian block of edge e (packed upper triangle) scattered into the z x z tile
+__device__ inline d4 load_qt(const Prob& Q, int e, int lane) {
   const int g = lane >> 4, j = lane & 15;
   const double* S_ = Q.ES(e);
   const int yj = yz(j);
@@ -75,9 +74,7 @@ __device__ inline d4 load_qt(const Prob& Q, int e, double dxw, int lane) {
     const int i = g + 4 * r;
     const int yi = yz(i);
     const bool valid = i < NYT && j < NYT && yi >= 0 && yj >= 0;
-    double v = valid ? S_[ES_QT + yi * NA + yj] : 0.0;
-    if (dxw != 0.0 && valid) v += dxw * wtw_entry(Q, e, yi, yj);
-    t[r] = v;
+    t[r] = valid ? S_[ES_QT + symi(yi, yj, NA)] : 0.0;
   }
   return t;
 }
@@ -132,12 +129,12 @@ __device__ inline Val leaf(const Prob& Q, int n, double mu, double delta, int la
 // scenario chain (they arrive during the ~50 matrix-core instructions of the child's update instead of costing a
 // memory round trip at the start of every node):
 //   * the node's own variable data (column layout: lane l, z-entry l & 15) - NodeIn, 7 registers;
-//   * the head of the first child edge's record [A B | c | Q~ | q~ | r_y] (ES_STAGE doubles, contiguous) - copied
+//   * the head of the first child edge's record [A B | c | Q~ packed | q~ + r_y] (ES_STAGE doubles, contiguous) - copied
 //     asynchronously into the wavefront's LDS region by the LDS-DMA path (global_load_lds_dwordx4: no staging
 //     registers), two buffers alternating between consecutive nodes.
-constexpr int ES_STAGE = R16_STAGE;                 // doubles: whole 64 lanes x 16 B pieces covering [0, ES_RY + NA)
-static_assert(ES_RY + NA <= ES_STAGE && ES_QV + NA <= ES_STAGE && ES_QT + NA * NA <= ES_STAGE && ES_CV + NX <= ES_STAGE,
-              "the staged head of the edge record must contain A, B, c, Q~, q~, r_y");
+constexpr int ES_STAGE = R16_STAGE;                 // doubles: whole 64 lanes x 16 B pieces covering [0, ES_QV + NA)
+static_assert(ES_QV + NA <= ES_STAGE && ES_QT + NA_T <= ES_QV && ES_CV + NX <= ES_QT,
+              "the staged head of the edge record must contain A, B, c, Q~, q~ + r_y");
 // (a piece may run past the end of a short record into the following records of the same workspace slot - never used;
 //  ws_layout() keeps 128 doubles of slack behind the last array)
 static_assert(!R16_ENABLED || 2 * ES_STAGE <= EL_SIZE, "two staging buffers must fit the wavefront's LDS region");
@@ -166,7 +163,7 @@ __device__ inline void load_node(const Prob& Q, int n, int lane, NodeIn& R) {
   R.nu = (jj < NX) ? ((ie >= 0) ? Q.lam[A.edge_row0[ie] + NW + jj] : Q.lam[jj]) : 0.0;
 }
 // tiles of the staged first child edge (LDS reads)
-__device__ inline void staged_tiles(const ldsd* Ls, int lane, d4& qt, d4& F, d4& f0, double& fu, double& ry, double& qv) {
+__device__ inline void staged_tiles(const ldsd* Ls, int lane, d4& qt, d4& F, d4& f0, double& fu, double& qv) {
   const int g = lane >> 4, j = lane & 15;
   const int yj = yz(j);
 #pragma unroll
@@ -174,7 +171,7 @@ __device__ inline void staged_tiles(const ldsd* Ls, int lane, d4& qt, d4& F, d4&
     const int i = g + 4 * r;
     const int yi = yz(i);
     const bool valid = i < NYT && j < NYT && yi >= 0 && yj >= 0;
-    const double q_ = Ls[ES_QT + (valid ? yi * NA + yj : 0)];
+    const double q_ = Ls[ES_QT + (valid ? symi(yi, yj, NA) : 0)];
     qt[r] = valid ? q_ : 0.0;
     const double ab = Ls[ES_AB + ((i < NX && yj >= 0) ? i * NA + yj : 0)];
     double fv = (i < NX && yj >= 0 && j < NYT) ? ab : 0.0;
@@ -190,8 +187,7 @@ __device__ inline void staged_tiles(const ldsd* Ls, int lane, d4& qt, d4& F, d4&
     fu = v;
   }
   const int yjj = (j < NYT) ? yj : -1;
-  ry = (yjj >= 0) ? Ls[ES_RY + (yjj >= 0 ? yjj : 0)] : 0.0;
-  qv = (yjj >= 0) ? Ls[ES_QV + (yjj >= 0 ? yjj : 0)] : 0.0;
+  qv = (yjj >= 0) ? Ls[ES_QV + (yjj >= 0 ? yjj : 0)] : 0.0;      // (q~ + r_y)
 }
 
 // One node update.  `first`: value function of the first child when it is already in registers (chain walk), else
@@ -202,7 +198,6 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   const int cs = A.node_child_start[n], cc = A.node_child_count[n];
   const double rw = node_rweight(Q, n);
   const double rwh = (Q.soc & 2) ? 0.0 : rw;          // weight of the rterm HESSIAN (Prob::soc bit 1: least-squares multiplier solve)
-  const double dxw = delta - Q.dsw;
   long long pc0 = prof_clock();
 #if DOMPC_PROFILE
 #define R16_PN(i) if (threadIdx.x == 0) { const long long pc1 = prof_clock(); lds_prof[i] += pc1 - pc0; pc0 = pc1; }
@@ -210,8 +205,8 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
 #define R16_PN(i)
 #endif
   d4 qt_s, F, f0;
-  double fu, ry_s, qv_s;
-  staged_tiles(Ls, lane, qt_s, F, f0, fu, ry_s, qv_s);
+  double fu, qv_s;
+  staged_tiles(Ls, lane, qt_s, F, f0, fu, qv_s);
   R16_PN(12)
   // ---- own quadratic: per-variable terms in column layout (lane: z-entry j)
   double dg = 0.0, gv = 0.0;
@@ -238,14 +233,9 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       }
     }
     const int yjj = yz(jj);
-    gv += ry_s + qv_s;
-    if (yjj >= 0) {
-      if (dxw != 0.0) gv += dxw * wtw0_entry(Q, cs, yjj);
-      for (int c = 1; c < cc; ++c) {
-        const double* S_ = Q.ES(cs + c);
-        gv += S_[ES_RY + yjj] + S_[ES_QV + yjj] + (dxw != 0.0 ? dxw * wtw0_entry(Q, cs + c, yjj) : 0.0);
-      }
-    }
+    gv += qv_s;
+    if (yjj >= 0)
+      for (int c = 1; c < cc; ++c) gv += Q.ES(cs + c)[ES_QV + yjj];
     if constexpr (NE > 0) {
       // nl_cons rows of the child edges, condensed through their slacks: gradient share  J~'((Sigma_s + delta) r_d + r_s)
       // with J~ = [J_d over (x, u) | -1 at the slack variable of the row]  (same algebra as riccati_node, dompc_kernel.h)
@@ -266,8 +256,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   }
   R16_PN(13)
   d4 QO = qt_s;
-  if (dxw != 0.0) QO = load_qt(Q, cs, dxw, lane);
-  for (int c = 1; c < cc; ++c) QO += load_qt(Q, cs + c, dxw, lane);
+  for (int c = 1; c < cc; ++c) QO += load_qt(Q, cs + c, lane);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = g + 4 * r;

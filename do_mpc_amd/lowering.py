@@ -103,6 +103,28 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         return outs
 
     parts: List[str] = []
+    tables: List[str] = []
+
+    def compact(tag: str, sig: str, dense_outs):
+        """Compact twin of a derivative function.  `dense_outs` = [(index inside the function's dense output block, node)]:
+        the entries that depend on the inputs are written one after the other into `o` (DOMPC_<tag>_NV values, dense index
+        of entry k in DOMPC_<tag>_VIDX[k]); the others are compile-time constants of the model - zeros by structure, weights
+        of a quadratic cost - and are listed once (DOMPC_<tag>_CIDX / _CVAL, non-zero ones only).  The kernels keep a dense
+        image of the record in LDS, initialised with the constants once per phase, and move only the variable entries
+        through HBM (csrc/dompc_kernel.h: MO_COMPACT) - for industrial_poly 82 of the 231 entries of a collocation point."""
+        var = [(i, n) for i, n in dense_outs if n.op != "const"]
+        cst = [(i, n.val) for i, n in dense_outs if n.op == "const" and n.val != 0.0]
+        body = sym.emit_c([(f"o[{k}]", n) for k, (_, n) in enumerate(var)], binds, indent="  ")
+        parts.append(f"DOMPC_FN {sig} {{\n{body}\n}}\n")
+        tables.append(f"#define DOMPC_{tag}_NV {len(var)}")
+        tables.append(f"#define DOMPC_{tag}_NC {len(cst)}")
+        tables.append(_fmt_array(f"DOMPC_{tag}_VIDX", [i for i, _ in var], "int"))
+        tables.append(_fmt_array(f"DOMPC_{tag}_CIDX", [i for i, _ in cst], "int"))
+        tables.append(_fmt_array(f"DOMPC_{tag}_CVAL", [v for _, v in cst]))
+
+    def packed(H, n):
+        return [H[i][j] for i in range(n) for j in range(i, n)]
+
     sig_dyn_args = "const double* xs, const double* us, const double* tvp, const double* pp"
     outs = [(f"f[{i}]", f[i]) for i in range(nx)]
     parts.append(emit_fn(f"void dompc_dyn_f({sig_dyn_args}, double* f)", outs))
@@ -110,6 +132,9 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     outs += [(f"J[{i * na + j}]", Jf[i][j]) for i in range(nx) for j in range(na)]
     outs += hess_outs(Hf, na)
     parts.append(emit_fn(f"void dompc_dyn({sig_dyn_args}, const double* lam, double* f, double* J, double* H)", outs))
+    # (dense block of a point: f | J row-major | H packed - PT_STRIDE in csrc/dompc_kernel.h)
+    compact("DYN", f"void dompc_dyn_c({sig_dyn_args}, const double* lam, double* o)",
+            list(enumerate(list(f) + [Jf[i][j] for i in range(nx) for j in range(na)] + packed(Hf, na))))
 
     # stage cost (unweighted; omega applied by the kernel)
     lt = scaled([lterm])[0]
@@ -118,6 +143,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         "\n}\n", "\n  return val;\n}\n"))
     outs = [("val[0]", lt)] + [(f"g[{i}]", gl[i]) for i in range(na)] + hess_outs(Hl, na)
     parts.append(emit_fn(f"void dompc_lterm({sig_dyn_args}, double* val, double* g, double* H)", outs))
+    compact("LT", f"void dompc_lterm_c({sig_dyn_args}, double* o)", list(enumerate([lt] + list(gl[:na]) + packed(Hl, na))))
 
     mt = scaled([mterm])[0]
     if sym.depends_on([mt], us):
@@ -128,6 +154,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         "\n}\n", "\n  return val;\n}\n"))
     outs = [("val[0]", mt)] + [(f"g[{i}]", gm[i]) for i in range(nx)] + hess_outs(Hm, nx)
     parts.append(emit_fn(f"void dompc_mterm({sig_m}, double* val, double* g, double* H)", outs))
+    compact("MT", f"void dompc_mterm_c({sig_m}, double* o)", list(enumerate([mt] + list(gm[:nx]) + packed(Hm, nx))))
 
     # nonlinear constraints (the "- eps" part is linear and handled by the kernel)
     if ne:
@@ -143,7 +170,12 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         outs += [(f"Jd[{i * na + j}]", Jd[i][j]) for i in range(ne) for j in range(na)]
         outs += hess_outs(Hd, na)
         parts.append(emit_fn(f"void dompc_nlcons({sig_dyn_args}, const double* lam, double* d, double* Jd, double* H)", outs))
+        compact("NL", f"void dompc_nlcons_c({sig_dyn_args}, const double* lam, double* o)",
+                list(enumerate(list(d) + [Jd[i][j] for i in range(ne) for j in range(na)] + packed(Hd, na))))
     else:
+        parts.append(f"DOMPC_FN void dompc_nlcons_c({sig_dyn_args}, const double* lam, double* o) {{}}\n")
+        tables += ["#define DOMPC_NL_NV 0", "#define DOMPC_NL_NC 0", _fmt_array("DOMPC_NL_VIDX", [], "int"),
+                   _fmt_array("DOMPC_NL_CIDX", [], "int"), _fmt_array("DOMPC_NL_CVAL", [])]
         parts.append(f"DOMPC_FN void dompc_nlcons_f({sig_dyn_args}, double* d) {{}}\n")
         parts.append(f"DOMPC_FN void dompc_nlcons({sig_dyn_args}, const double* lam, double* d, double* Jd, double* H) {{}}\n")
 
@@ -166,7 +198,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         _fmt_array("DOMPC_NL_SLACK", nl_slack_index, "int"),
         "",
     ]
-    text = "\n".join(hdr) + "\n" + "\n".join(parts)
+    text = "\n".join(hdr) + "\n" + "\n".join(tables) + "\n\n" + "\n".join(parts)
     digest = hashlib.sha256(text.encode()).hexdigest()[:16]
     return text + f"\n#define DOMPC_MODEL_HASH \"{digest}\"\n"
 
