@@ -53,7 +53,7 @@ extern "C" __global__ void dompc_model_info_kernel(const int32_t* in, int64_t* o
 extern "C" __global__ void __launch_bounds__(256, DOMPC_LB) dompc_solve_kernel(dompc::KArgs A) {
   using namespace dompc;
   const int POOL = A.pool_doubles;
-  if (threadIdx.x < 24) lds_prof[threadIdx.x] = 0;
+  if (threadIdx.x < 32) lds_prof[threadIdx.x] = 0;
   if (threadIdx.x < 8) lds_flags[threadIdx.x] = 0;
   // defined LDS contents at kernel start (the pool of the previous kernel on this CU is still in there)
   for (int i = threadIdx.x; i < POOL; i += blockDim.x) lds_pool[i] = (i >= A.lds_fill_lo && i < A.lds_fill_hi) ? A.lds_fill : 0.0;

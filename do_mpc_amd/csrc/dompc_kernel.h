@@ -302,7 +302,7 @@ __shared__ int lds_b;
 #ifndef DOMPC_PROFILE
 #define DOMPC_PROFILE 0             // 1: sub-phase shader-clock counters of the edge sweep / node update (tools/gpu_profile.py)
 #endif
-__shared__ long long lds_prof[24];
+__shared__ long long lds_prof[32];
 
 // slot of the calling workgroup: normal mode one workgroup per problem slot; wide mode (small batches) K = A.wide
 // workgroups per problem, all on one XCD when the dispatcher places block b on XCD b % 8 (affinity only - the barrier
@@ -710,7 +710,10 @@ constexpr bool TILE_CONDENSE = false;
 // (the regions of the LDS-staged generic condensing - T1 beyond its first NW entries, U1, HUU, QT/HP - do not exist in the
 //  matrix-core variant: 750 doubles per wavefront for industrial_poly)
 constexpr int EL_MX = 0;
-constexpr int EL_T1 = EL_MX + NW * MX_LD;                              // Hww W  (NW x NA); first NW entries: the residual rows
+// (blocked elimination on the matrix cores, edge_factor_mfma: the W | w0 region doubles as its panel buffer - 4 columns of the
+//  padded collocation block - plus one row of 64 dual-residual products)
+constexpr int GJ_LDS = (NI == 1 && DEG >= 1) ? 4 * (((DEG * NX + 3) / 4) * 4) + 64 : 0;
+constexpr int EL_T1 = EL_MX + (NW * MX_LD > GJ_LDS ? NW * MX_LD : GJ_LDS);   // Hww W  (NW x NA); first NW entries: the residual rows
 constexpr int EL_T0 = EL_T1 + (TILE_CONDENSE ? NW : NW * NA);          // Hww w0 (NW)
 constexpr int EL_RW = EL_T0 + NW;                                      // Newton-form gradient of w (NW)
 constexpr int EL_SG = EL_RW + NW;                                      // Sigma_w (NW)
@@ -909,6 +912,274 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #endif
 }
 
+#ifndef DOMPC_HOST_EMU
+// ================================================================================================
+// Blocked Gauss-Jordan of the collocation block on the FP64 matrix cores (round 3).
+// The register-resident elimination below (one extended column per lane, the pivot column broadcast with v_readlane) issues
+// ~60 vector instructions per pivot - two thirds of them broadcasts - and was the largest single phase of the solve (27 %).
+// Here the extended matrix  [G_cc (padded to a multiple of 4) | G_y r | I]  lives in 16x16 tiles in the accumulator layout
+// of v_mfma_f64_16x16x4_f64 (lane l, register r: element ((l >> 4) + 4 r, l & 15) of the tile) and FOUR pivots are
+// eliminated per step with rank-4 updates:
+//     P  = A[panel rows, panel cols]  (4 x 4),      C~ = A[:, panel cols] - E_panel   (E_panel: unit rows of the panel),
+//     A <- A - (C~ P^-1) A[panel rows, :]           (non-panel rows: A - C P^-1 R; panel rows: P^-1 R)
+// - the panel ROWS are register (p % 4) of the tiles of tile row p / 4, i.e. already the B operand of the instruction;
+// - the panel COLUMNS go through LDS once per step (20 x 4 doubles): every lane reads P (broadcast reads), factorises it in
+//   uniform arithmetic (LU without pivoting, threshold test on its pivots), solves for ITS column k = l >> 4 of P^-1 and
+//   forms its entries (row l & 15 of each tile row, column k) of C~ P^-1 - the A operand;
+// - 8 (later 6) MFMAs per step instead of ~240 vector instructions for the same four pivots.
+// Natural pivot order (the diagonal of G_cc = h J - C (x) I carries the collocation coefficients); a failed threshold test
+// returns 1 and the caller repeats the factorisation with the register-resident elimination and partial pivoting.
+// Out: W | w0 (collocation rows; the caller derives the continuity rows) in LDS, G_cc^-1 in the forward record.
+#ifndef DOMPC_MFMA_GJ
+#define DOMPC_MFMA_GJ 1
+#endif
+#ifndef DOMPC_GJ_SB
+#define DOMPC_GJ_SB 0               // 1: scheduling barriers at the step boundaries of the blocked elimination (measurement aid)
+#endif
+#if DOMPC_GJ_SB
+#define GJ_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define GJ_SB()
+#endif
+constexpr int GJ_R = DEG * NX, GJ_RP = ((GJ_R + 3) / 4) * 4, GJ_NRHS = NA + 1;
+constexpr int GJ_NC = GJ_RP + GJ_NRHS + GJ_R;                      // columns: [G_cc padded | G_y r | I]
+constexpr bool MFMA_GJ = (NI == 1) && (DEG >= 1) && (GJ_RP <= 32) && (GJ_NC <= 64) && (DOMPC_MFMA_GJ != 0);
+constexpr int GJ_MT = (GJ_RP + 15) / 16, GJ_NT = (GJ_NC + 15) / 16;
+static_assert(!MFMA_GJ || GJ_RP * 4 + 64 <= EL_T1 - EL_MX, "the panel buffer and the dual-residual row share the W | w0 region of the edge working set");
+
+// Register budget: the function is called per edge from the sweep; it must stay within the ~148 caller-saved VGPRs (every
+// other register it touches costs a scratch round trip per call).  When the padded block has 16 + 4 rows (industrial_poly)
+// the four rows of the second tile row are PACKED into one accumulator tile - register ni of tile X holds rows 16..19 of
+// tile column ni; the MFMA that updates it gets an A operand that is zero outside rows 4 ni .. 4 ni + 3 - instead of four
+// tiles with one live register each (8 instead of 32 VGPRs).
+constexpr bool GJ_PACK = (GJ_MT == 2) && (GJ_RP == 20) && (GJ_NT <= 4);
+constexpr int GJ_MTF = GJ_PACK ? 1 : GJ_MT;                          // full tile rows
+
+// column descriptor of tile column ni for this lane: kind 0: G_cc (slot sl, state b), 1: y column b, 2: residual,
+// 3: unit column b, 4: padding
+struct GjCol { int kind, sl, b; };
+__device__ inline GjCol gj_col(int ni, int lc) {
+  constexpr int R = GJ_R, RP = GJ_RP, NRHS = GJ_NRHS;
+  const int col = 16 * ni + lc;
+  GjCol c{4, 0, 0};
+  if (col < R) { c.kind = 0; c.sl = col / NX; c.b = col - c.sl * NX; }
+  else if (col < RP) { c.kind = 4; c.b = col; }
+  else if (col < RP + NA) { c.kind = 1; c.b = col - RP; }
+  else if (col == RP + NA) { c.kind = 2; }
+  else if (col < RP + NRHS + R) { c.kind = 3; c.b = col - (RP + NRHS); }
+  return c;
+}
+// element (row, column of tile column ni) of [G_cc | G_y r | I] from the image (optimizer.py:951-963, see build_cols below)
+__device__ inline double gj_element(const ldsd* mol, const ldsd* Ld, int row, int ni, int lc) {
+  constexpr int R = GJ_R;
+  constexpr int DG = DEG > 0 ? DEG : 1;
+  const GjCol c = gj_col(ni, lc);
+  const bool real = row < R;
+  const int rowc = real ? row : 0;
+  const int jj = rowc / NX, a = rowc - jj * NX;
+  const int jcol = (c.kind == 0 || c.kind == 1) ? c.b : 0;
+  const double jv = mol[(unsigned)(MO_PT + NX) + (unsigned)(jj * PT_STRIDE + a * NA + jcol)];
+  const bool useJ = (c.kind == 0) ? (c.sl == jj) : (c.kind == 1 && c.b >= NX);
+  double v = useJ ? jv : 0.0;
+  if (c.kind == 0) {
+    // C[sl + 1][jj + 1] by selects over opaque values (no constant-table load)
+    double cc = 0.0;
+#pragma unroll
+    for (int s1 = 1; s1 <= DEG; ++s1)
+#pragma unroll
+      for (int j1 = 1; j1 <= DEG; ++j1) {
+        double t = DOMPC_C[s1 * (DEG + 1) + j1];
+        asm("" : "+v"(t));
+        cc = (c.sl + 1 == s1 && jj + 1 == j1) ? t : cc;
+      }
+    v -= (a == c.b) ? cc : 0.0;
+  }
+  if (c.kind == 1) v -= (a == c.b) ? tab_sel(DOMPC_C, jj + 1, DEG > 0 ? 1 : 0, DG) : 0.0;      // C[0][jj + 1]
+  if (c.kind == 2) v = Ld[EL_T1 + rowc];
+  if (c.kind == 3) v = (c.b == row) ? 1.0 : 0.0;
+  if (c.kind == 4) v = 0.0;
+  if (!real) v = (16 * ni + lc == row) ? 1.0 : 0.0;         // padding rows: unit diagonal
+  return v;
+}
+
+template <class DUAL>
+__device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld, DUAL&& dual_from) {
+  constexpr int R = GJ_R, RP = GJ_RP, MT = GJ_MTF > 0 ? GJ_MTF : 1, NT = GJ_NT > 0 ? GJ_NT : 1;      // (at least one tile: the function is compiled for every model)
+  constexpr double GJ_U = 0.01;
+  const ldsd* mol = Ld + EL_MOS;                  // dense image of the model-output record
+  ldsd* pan = Ld + EL_MX;                         // panel columns of the current step, RP x 4 row-major
+#if DOMPC_PROFILE
+  long long pc0_ = clock64();
+#define GJ_PH(i) if (threadIdx.x == 0) { const long long pc1_ = clock64(); lds_prof[i] += pc1_ - pc0_; pc0_ = pc1_; }
+#else
+#define GJ_PH(i)
+#endif
+  const int lr = lane >> 4, lc = lane & 15;
+  d4 T[MT][NT];
+  d4 X = {0.0, 0.0, 0.0, 0.0};                    // GJ_PACK: register ni = rows 16..19 of tile column ni
+  // ---- tiles of [G_cc | G_y r | I]
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+        T[mi][ni][r] = (16 * mi + 4 * r >= RP) ? 0.0 : gj_element(mol, Ld, 16 * mi + 4 * r + lr, ni, lc);
+  if constexpr (GJ_PACK) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) X[ni] = gj_element(mol, Ld, 16 + lr, ni, lc);
+  }
+  GJ_PH(25)
+  {
+    // ---- dual-residual pieces: lambda' [G_cc | G_y] on the matrix cores.  A operand: the multipliers of the collocation rows
+    // in row 0 of a 16 x 4 block per k-block; B operand: the tile registers themselves (register r of tile row mi = rows
+    // 16 mi + 4 r ...).  Row 0 of the result tiles goes through LDS to the lanes that own the columns (dual_from).
+    constexpr int NDT = (RP + NA + 15) / 16 < NT ? (RP + NA + 15) / 16 : NT;
+    d4 acc[NDT];
+#pragma unroll
+    for (int ni = 0; ni < NDT; ++ni) acc[ni] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < RP / 4; ++kb) {
+      const int row = 4 * kb + lr;
+      const double lam = Ld[EL_T0 + (row < R ? row : 0)];
+      const double a = (lc == 0 && row < R) ? lam : 0.0;
+#pragma unroll
+      for (int ni = 0; ni < NDT; ++ni) {
+        const double b = (GJ_PACK && kb >= 4) ? X[ni] : T[(GJ_PACK && kb >= 4) ? 0 : kb / 4][ni][kb % 4];
+        acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[ni], 0, 0, 0);
+      }
+    }
+    ldsd* du = Ld + EL_MX + 4 * RP;                 // (behind the panel buffer; the W | w0 region is written after the last step)
+    if (lr == 0) {
+#pragma unroll
+      for (int ni = 0; ni < NDT; ++ni) du[16 * ni + lc] = acc[ni][0];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    dual_from((const ldsd*)du);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  GJ_PH(24)
+  double viol = -1.0, pmin = 1.0;
+  // ---- RP / 4 steps of four pivots
+#pragma unroll
+  for (int p = 0; p < RP / 4; ++p) {
+    GJ_SB();
+    const int mip = p / 4, rp = p % 4, nip = p / 4, c0 = 4 * (p % 4);
+    const bool prow_x = GJ_PACK && mip == 1;       // (the panel rows live in the packed tile)
+    // panel columns -> LDS
+    if (lc >= c0 && lc < c0 + 4) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * mi + 4 * r < RP) pan[(16 * mi + 4 * r + lr) * 4 + (lc - c0)] = T[mi][nip][r];
+      if constexpr (GJ_PACK) pan[(16 + lr) * 4 + (lc - c0)] = X[nip];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // the panel rows as they are now: B operands of the update
+    double Rb[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) Rb[ni] = prow_x ? X[ni] : T[prow_x ? 0 : mip][ni][rp];
+    // P, LU in uniform arithmetic
+    double a_[4][4], iu[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a_[i][j] = pan[(4 * p + i) * 4 + j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double m = 0.0;
+#pragma unroll
+      for (int i = k + 1; i < 4; ++i) m = fmax(m, fabs(a_[i][k]));
+      viol = fmax(viol, fma(GJ_U, m, -fabs(a_[k][k])));      // > 0: |a_kk| < GJ_U max|a_ik|
+      pmin = fmin(pmin, fabs(a_[k][k]));
+      iu[k] = fast_rcp(a_[k][k]);
+#pragma unroll
+      for (int i = k + 1; i < 4; ++i) {
+        a_[i][k] *= iu[k];
+#pragma unroll
+        for (int j = k + 1; j < 4; ++j) a_[i][j] = fma(-a_[i][k], a_[k][j], a_[i][j]);
+      }
+    }
+    // column k = lr of P^-1:  L y = e_k, U x = y
+    double x_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double t = (lr == i) ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < i; ++j) t = fma(-a_[i][j], x_[j], t);
+      x_[i] = t;
+    }
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+      double t = x_[i];
+#pragma unroll
+      for (int j = i + 1; j < 4; ++j) t = fma(-a_[i][j], x_[j], t);
+      x_[i] = t * iu[i];
+    }
+    GJ_SB();             // (the LU factors are dead: do not hoist the loads below above them)
+    // this lane's entries of -(C~ P^-1): row lc of every full tile row (packed rows: row 16 + (lc & 3)), column lr
+    auto cprime = [&](int row) {
+      const int rowc = row < RP ? row : 0;
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double cj = pan[rowc * 4 + j] - ((row == 4 * p + j) ? 1.0 : 0.0);
+        t = fma(cj, x_[j], t);
+      }
+      return (row < RP) ? -t : 0.0;
+    };
+    double cp[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) cp[mi] = cprime(16 * mi + lc);
+    double cpx = 0.0;
+    if constexpr (GJ_PACK) cpx = cprime(16 + (lc & 3));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // rank-4 update of the tiles that still hold columns to the right of the panel
+    // (the tile column that holds the NEXT panel first: its columns are needed at the top of the next step, whose LU
+    //  arithmetic then runs under the remaining matrix-core instructions)
+#pragma unroll
+    for (int o = 0; o < NT; ++o) {
+      const int nxt = (p + 1) / 4 < NT ? (p + 1) / 4 : 0;
+      const int ni = (o == 0) ? nxt : (o <= nxt ? o - 1 : o);
+      if (16 * (ni + 1) <= 4 * (p + 1)) continue;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) T[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(cp[mi], Rb[ni], T[mi][ni], 0, 0, 0);
+      if constexpr (GJ_PACK) X = __builtin_amdgcn_mfma_f64_16x16x4f64(((lc >> 2) == ni) ? cpx : 0.0, Rb[ni], X, 0, 0, 0);
+    }
+  }
+  GJ_PH(26)
+  if (!(viol <= 0.0 && pmin > 1e-300)) return 1;        // (NaN-safe: a failed test or a vanishing pivot)
+  // ---- W | w0 (collocation rows) -> LDS, G_cc^-1 -> forward record
+  auto put = [&](int row, int ni, double v) {
+    const GjCol c = gj_col(ni, lc);
+    if (row < R) {
+      if (c.kind == 1 || c.kind == 2) Ld[EL_MX + row * MX_LD + MX_W + (c.kind == 2 ? NA : c.b)] = -v;
+      if (c.kind == 3) Q.EW(e, EW_LU + row * LU_N + c.b) = v;
+    }
+  };
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    if (16 * ni + 15 < RP) continue;             // (columns of the eliminated block)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * mi + 4 * r < RP) put(16 * mi + 4 * r + lr, ni, T[mi][ni][r]);
+    if constexpr (GJ_PACK) put(16 + lr, ni, X[ni]);
+  }
+  GJ_PH(27)
+#undef GJ_PH
+  return 0;
+}
+#else
+constexpr bool MFMA_GJ = false;
+#endif
+
 // ================================================================================================
 // Single finite element: factorisation part of an edge - columns of [G_cc | G_y r | I] in registers, dual-residual pieces,
 // register-resident Gauss-Jordan (with its pivoting fallback), W | w0 into LDS, G_cc^-1 to the forward record.
@@ -919,6 +1190,10 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 // In: Ld[EL_T1] residual rows, Ld[EL_T0] multipliers of the edge's rows, the staged model-output record; this lane's
 // per-variable data (vx: its extended column, ex / nu_a: end-point column on the first NX lanes).
 constexpr int EF_R = DEG * NX, EF_NCX = 2 * EF_R + NA + 1, EF_CPX = (EF_NCX + GS_C - 1) / GS_C;
+// MODE 0: everything with the register-resident elimination (host emulation, models outside the matrix-core variant);
+// MODE 1 (device, MFMA_GJ): dual-residual pieces + blocked elimination on the matrix cores, returns 2 if its threshold test
+//        fails; MODE 2 (device, MFMA_GJ): the repeat in that case - columns, elimination with partial pivoting, outputs.
+template <int MODE>
 DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane, int GS, ldsd* Ld, const double (&vx)[EF_CPX][5],
                                       const double (&ex)[5], double nu_a) {
   const KArgs& A = *Q.A;
@@ -931,6 +1206,9 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
   const bool act = true;
   int fail = 0;
   (void)act;
+#if DOMPC_PROFILE && !defined(DOMPC_HOST_EMU)
+  const long long pc_ef0 = clock64();
+#endif
   constexpr int R = DEG * NX, RA = R > 0 ? R : 1;
   constexpr int NRHS = NA + 1;
   constexpr int NCX = 2 * R + NRHS;                      // extended columns: G_cc | G_y r | I
@@ -1054,17 +1332,16 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
     return badl;
 #endif
   };
-  fetch_cols();
-  if (act) {
-    build_cols();
-    // dual-residual pieces: column c of G_w / G_y times the multipliers of the edge's rows (continuity rows:
-    // -D_{sl+1} on the diagonal of the G_cc columns, -D_0 for the x_n columns, +1 for the end-point columns)
+  if (MODE != 1) fetch_cols();
+  // dual-residual pieces: column c of G_w / G_y times the multipliers of the edge's rows (continuity rows:
+  // -D_{sl+1} on the diagonal of the G_cc columns, -D_0 for the x_n columns, +1 for the end-point columns).
+  // `col_dot(q, cx)`: the collocation rows' share of column cx (MODE 0: from the column in registers; MODE 1: formed by
+  // the matrix cores from the tiles, edge_factor_mfma)
+  auto dual_pieces = [&](auto col_dot) {
 #pragma unroll
     for (int q = 0; q < CPX; ++q) {
       const int cx = lane + q * GS;
-      double t = 0.0;
-#pragma unroll
-      for (int r = 0; r < R; ++r) t += bc[q][r] * Ld[EL_T0 + r];
+      double t = col_dot(q, cx);
       if (cx < R) {
         t -= DOMPC_D[cx / NX + 1] * Ld[EL_T0 + R + cx % NX];   // (measured: neither a select chain nor a load of the coefficient in the first batch of the edge pays - both slow the elimination that follows by more than the round trip they save)
         const int gi = woff + cx;
@@ -1092,7 +1369,44 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
       Ld[EL_BB + col] = bar_grad(xv, l, u, 1.0);
       Ld[EL_SG + col] = sigma_of(xv, l, u, zl_, zu_);
     }
+  };
+  if (act && MODE == 0) {
+    build_cols();
+    dual_pieces([&](int q, int) {
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) t += bc[q][r] * Ld[EL_T0 + r];
+      return t;
+    });
   }
+#ifndef DOMPC_HOST_EMU
+  if constexpr (MODE == 1) {
+    // blocked elimination on the matrix cores (edge_factor_mfma); if its threshold test fails the caller repeats the
+    // factorisation with the register-resident elimination and partial pivoting (MODE 2, its own out-of-line function:
+    // this one stays within the caller-saved registers - a callee pays a scratch round trip for every other one it touches)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (edge_factor_mfma(Q, e, lane, Ld, [&](const ldsd* du) {
+          dual_pieces([&](int, int cx) { return (double)du[cx < R ? cx : (cx < R + NA ? GJ_RP + (cx - R) : 0)]; });
+        })) return 2;
+    {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // continuity rows of W | w0:  W_e = D_0 [I 0] + sum_s D_s W_s ,  w0_e = -r_e + sum_s D_s w0_s
+      for (int it = lane; it < NX * NRHS; it += GS) {
+        const int a_ = it / NRHS, c = it % NRHS;
+        double t = (c == NA) ? -Ld[EL_T1 + R + a_] : ((c == a_) ? DOMPC_D[0] : 0.0);
+#pragma unroll
+        for (int s_ = 1; s_ <= DEG; ++s_) t += DOMPC_D[s_] * Ld[EL_MX + ((s_ - 1) * NX + a_) * MX_LD + MX_W + c];
+        Ld[EL_MX + (R + a_) * MX_LD + MX_W + c] = t;
+      }
+      return 0;
+    }
+  } else if constexpr (MODE == 2) {
+    build_cols();
+    if (eliminate(true)) fail = 1;
+  } else
+#endif
   if (act) {
     if (eliminate(false)) {
       fetch_cols();
@@ -1130,33 +1444,47 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
 
 #ifndef DOMPC_HOST_EMU
 __device__ inline KArgs kernel_args(const void* kp);
-__device__ __attribute__((noinline)) int phase_edge_factor(const void* kp, int slot, int e, int soc, double sf, double mu,
-                                                           double v0, double v1, double v2, double v3, double v4,
-                                                           double x0, double x1, double x2, double x3, double x4, double nu_a) {
-  const KArgs A = kernel_args(kp);
-  Prob Q = make_prob(A, __builtin_amdgcn_readfirstlane(slot), nullptr);
-  Q.sf = ufl(sf);
-  Q.soc = __builtin_amdgcn_readfirstlane(soc);
-  const int lane = (int)(threadIdx.x & 63u);
-  ldsd* Ld = (ldsd*)lds_pool + (int64_t)(threadIdx.x >> 6) * EL_SIZE;
-  const double vx[EF_CPX][5] = {{v0, v1, v2, v3, v4}};
-  const double ex[5] = {x0, x1, x2, x3, x4};
-  return edge_factor_body(Q, __builtin_amdgcn_readfirstlane(e), ufl(mu), lane, 64, Ld, vx, ex, nu_a);
-}
+#define DOMPC_EF_ARGS const void* kp, int slot, int e, int soc, double sf, double mu, double v0, double v1, double v2, double v3, double v4, \
+                      double x0, double x1, double x2, double x3, double x4, double nu_a
+#define DOMPC_EF_BODY(MODE_)                                                                                     \
+  const KArgs A = kernel_args(kp);                                                                               \
+  Prob Q = make_prob(A, __builtin_amdgcn_readfirstlane(slot), nullptr);                                          \
+  Q.sf = ufl(sf);                                                                                                \
+  Q.soc = __builtin_amdgcn_readfirstlane(soc);                                                                   \
+  const int lane = (int)(threadIdx.x & 63u);                                                                     \
+  ldsd* Ld = (ldsd*)lds_pool + (int64_t)(threadIdx.x >> 6) * EL_SIZE;                                            \
+  const double vx[EF_CPX][5] = {{v0, v1, v2, v3, v4}};                                                           \
+  const double ex[5] = {x0, x1, x2, x3, x4};                                                                     \
+  return edge_factor_body<MODE_>(Q, __builtin_amdgcn_readfirstlane(e), ufl(mu), lane, 64, Ld, vx, ex, nu_a);
+__device__ __attribute__((noinline)) int phase_edge_factor(DOMPC_EF_ARGS) { DOMPC_EF_BODY(MFMA_GJ ? 1 : 0) }
+__device__ __attribute__((noinline)) int phase_edge_factor_pivot(DOMPC_EF_ARGS) { DOMPC_EF_BODY(MFMA_GJ ? 2 : 0) }
+#undef DOMPC_EF_BODY
+#undef DOMPC_EF_ARGS
 #endif
 DOMPC_DEV inline int run_edge_factor(const Thr& T, const Prob& Q, int e, double mu, int lane, int GS, ldsd* Ld,
                                      const double (&vx)[EF_CPX][5], const double (&ex)[5], double nu_a) {
 #ifndef DOMPC_HOST_EMU
   if constexpr (EF_CPX == 1) {
     (void)lane; (void)GS; (void)Ld;
-    return phase_edge_factor(T.kp, Q.slot, e, Q.soc, Q.sf, mu, vx[0][0], vx[0][1], vx[0][2], vx[0][3], vx[0][4],
+#ifndef DOMPC_EF_INLINE
+#define DOMPC_EF_INLINE 0          // 1: the matrix-core factorisation inside the sweep function (no call, no callee-saved registers to save per edge)
+#endif
+    int rc;
+    if constexpr (MFMA_GJ && DOMPC_EF_INLINE)
+      rc = edge_factor_body<1>(Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
+    else
+      rc = phase_edge_factor(T.kp, Q.slot, e, Q.soc, Q.sf, mu, vx[0][0], vx[0][1], vx[0][2], vx[0][3], vx[0][4],
                              ex[0], ex[1], ex[2], ex[3], ex[4], nu_a);
+    if (MFMA_GJ && __builtin_amdgcn_readfirstlane(rc) == 2)          // (threshold test of the blocked elimination failed: rare)
+      rc = phase_edge_factor_pivot(T.kp, Q.slot, e, Q.soc, Q.sf, mu, vx[0][0], vx[0][1], vx[0][2], vx[0][3], vx[0][4],
+                                   ex[0], ex[1], ex[2], ex[3], ex[4], nu_a);
+    return rc;
   } else {
-    return edge_factor_body(Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
+    return edge_factor_body<0>(Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
   }
 #else
   (void)T;
-  return edge_factor_body(Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
+  return edge_factor_body<0>(Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
 #endif
 }
 
@@ -1567,6 +1895,9 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         constexpr int KB_A = (NA + 3) / 4, KB_X = (NX + 3) / 4;
         const int g = lane >> 4, j = lane & 15;
         auto Wm = [&](int row, int col) -> double { return Ld[EL_MX + row * MX_LD + MX_W + col]; };
+        // (NA + 2 <= 16: the vector parts ride in the spare columns of the matrix tiles - column NA: (H + Sigma) z0 + r_w
+        //  -> q~, column NA + 1: b -> W'b - so a point costs 8 MFMAs instead of 16, the end-point slot 3 instead of 6)
+        constexpr bool VCOL = NA + 2 <= 16;
         d4 QTt, qv0 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                  // stage-cost and nl_cons Hessians (packed in the model-output record)
@@ -1584,18 +1915,24 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           for (int r = 0; r < 4; ++r) {
             const int i = g + 4 * r;
             const int row = p * NX + (i < NX ? i : 0);
-            const double wv = Wm(row, j < NA ? j : 0), w0v = Wm(row, NA);
+            const double wv = Wm(row, j <= NA ? j : 0), w0v = VCOL ? 0.0 : Wm(row, NA);
             const double hv = MOV(MO_PT + p * PT_STRIDE + NX + NX * NA + symi(i < NA ? i : 0, j < NA ? j : 0, NA));
             const double sg = Ld[EL_SG + row] + Q.dsw, rw = Ld[EL_RW + row], bb = Ld[EL_BB + row];
-            Z[r] = (i < NX) ? (j < NA ? wv : 0.0) : ((i < NA && j == i) ? 1.0 : 0.0);
+            Z[r] = (i < NX) ? (j < NA + (VCOL ? 1 : 0) ? wv : 0.0) : ((i < NA && j == i) ? 1.0 : 0.0);      // VCOL: [W_p | w0_p]
             z0[r] = (j == 0 && i < NX) ? w0v : 0.0;
             H[r] = (i < NA && j < NA) ? hv + ((i == j && i < NX) ? sg : 0.0) : 0.0;
-            rwv[r] = (i < NX) ? (j == 0 ? rw : (j == 1 ? bb : 0.0)) : 0.0;      // (column 1: the part of the gradient that is linear in mu -> W'b)
+            const int jv = VCOL ? NA : 0;
+            rwv[r] = (i < NX) ? (j == jv ? rw : (j == jv + 1 ? bb : 0.0)) : 0.0;      // (second vector column: the part of the gradient that is linear in mu -> W'b)
           }
-          const d4 HZ = tile_mul<KB_A>(H, Z);
-          const d4 hz0 = tile_mul<KB_A>(H, z0) + rwv;
-          QTt += tile_mul<KB_A>(Z, HZ);
-          qv0 += tile_mul<KB_A>(Z, hz0);
+          if constexpr (VCOL) {
+            const d4 HZ = tile_mul<KB_A>(H, Z) + rwv;
+            QTt += tile_mul<KB_A>(Z, HZ);
+          } else {
+            const d4 HZ = tile_mul<KB_A>(H, Z);
+            const d4 hz0 = tile_mul<KB_A>(H, z0) + rwv;
+            QTt += tile_mul<KB_A>(Z, HZ);
+            qv0 += tile_mul<KB_A>(Z, hz0);
+          }
         }
         {
           d4 Wk, SWk, sv0;
@@ -1603,20 +1940,23 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           for (int r = 0; r < 4; ++r) {
             const int i = g + 4 * r;
             const int row = (M - 1) * NX + (i < NX ? i : 0);
-            const double wv = Wm(row, j < NA ? j : 0), w0v = Wm(row, NA);
+            const double wv = Wm(row, j <= NA ? j : 0), w0v = Wm(row, NA);
             const double sg = Ld[EL_SG + row] + Q.dsw, rw = Ld[EL_RW + row], bb = Ld[EL_BB + row];
-            Wk[r] = (i < NX && j < NA) ? wv : 0.0;
-            SWk[r] = (i < NX && j < NA) ? sg * wv : 0.0;
-            sv0[r] = (i < NX) ? (j == 0 ? sg * w0v + rw : (j == 1 ? bb : 0.0)) : 0.0;
+            Wk[r] = (i < NX && j < NA + (VCOL ? 1 : 0)) ? wv : 0.0;
+            const double vec0 = sg * w0v + rw;
+            SWk[r] = (i < NX) ? (j < NA ? sg * wv : ((VCOL && j == NA) ? vec0 : ((VCOL && j == NA + 1) ? bb : 0.0))) : 0.0;
+            sv0[r] = (i < NX) ? (j == 0 ? vec0 : (j == 1 ? bb : 0.0)) : 0.0;
           }
           QTt += tile_mul<KB_X>(Wk, SWk);
-          qv0 += tile_mul<KB_X>(Wk, sv0);
+          if constexpr (!VCOL) qv0 += tile_mul<KB_X>(Wk, sv0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = g + 4 * r;
           if (i <= j && j < NA) S_[ES_QT + symi(i, j, NA)] = QTt[r];
-          if (i < NA && j < 2) Ld[EL_QV + j * NA + i] = qv0[r];             // q~ and W'b: stored by phase 7
+          // q~ and W'b: stored by phase 7
+          if constexpr (VCOL) { if (i < NA && (j == NA || j == NA + 1)) Ld[EL_QV + (j - NA) * NA + i] = QTt[r]; }
+          else { if (i < NA && j < 2) Ld[EL_QV + j * NA + i] = qv0[r]; }
         }
       }
 #endif
@@ -4044,7 +4384,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   }
 
   // ---- outputs (unscaled multipliers, CasADi sign convention)
-  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = (double)c_ftb; tr[7] = (double)c_acc; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; double* t3 = A.trace + 8 * (A.trace_cap - 3); for (int i = 0; i < 8; ++i) t3[i] = (double)T.prof[8 + i]; double* t4 = A.trace + 8 * (A.trace_cap - 4); for (int i = 0; i < 8; ++i) t4[i] = (double)T.prof[16 + i]; } }
+  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = (double)c_ftb; tr[7] = (double)c_acc; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; double* t3 = A.trace + 8 * (A.trace_cap - 3); for (int i = 0; i < 8; ++i) t3[i] = (double)T.prof[8 + i]; double* t4 = A.trace + 8 * (A.trace_cap - 4); for (int i = 0; i < 8; ++i) t4[i] = (double)T.prof[16 + i]; if (A.trace_cap > 12) { double* t5 = A.trace + 8 * (A.trace_cap - 5); for (int i = 0; i < 8; ++i) t5[i] = (double)T.prof[24 + i]; } } }
   const double isf = 1.0 / Q.sf;
   // (sharded problem: every entry is written by exactly one rank, zeros elsewhere -> a SUM over the ranks is the full vector)
   if (A.x_out) for (int g = T.tid; g < nX; g += T.nt) A.x_out[(int64_t)b * nX + g] = sh_cnt(A, mk_x(A, g)) ? Q.x[g] : 0.0;
