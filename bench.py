@@ -250,7 +250,7 @@ def main():
     P[:, :ps.nx] = X0
     P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(0.0).master
     Xi = np.zeros((B, ps.n_opt_x))
-    Xi[:, :ps.off_u].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
+    Xi[:, :ps.off_z].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
     dev = torch.device("cuda", local_rank)
     tX0 = torch.from_numpy(Xi).to(dev)
     tP = torch.from_numpy(P).to(dev)

@@ -81,7 +81,7 @@ def _compile_to(cmd_without_out, out: str, what: str) -> None:
 
 def _sources_digest() -> str:
     h = hashlib.sha256()
-    for fn in ("dompc_kernel.h", "dompc_riccati16.h", "dompc_kargs.h", "dompc_device.hip", "dompc_runtime.cpp",
+    for fn in ("dompc_kernel.h", "dompc_dae.h", "dompc_riccati16.h", "dompc_kargs.h", "dompc_device.hip", "dompc_runtime.cpp",
                "dompc_plant.hip", "dompc_plant_args.h", "dompc_plant_runtime.cpp"):
         with open(os.path.join(CSRC, fn), "rb") as f:
             h.update(f.read())

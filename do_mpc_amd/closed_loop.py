@@ -35,7 +35,7 @@ class BatchClosedLoop:
         P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(t0).master
         P[:, ps.p_off_uprev:] = 0.0 if U_prev0 is None else np.asarray(U_prev0, float).reshape(B, ps.nu)
         Xi = np.zeros((B, ps.n_opt_x))
-        Xi[:, :ps.off_u].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
+        Xi[:, :ps.off_z].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
         Xi[:, ps.off_u:ps.off_eps].reshape(B, -1, ps.nu)[:] = (P[:, ps.p_off_uprev:] / mpc._u_scaling.master)[:, None, :]   # (mpc.u0 = u_prev; set_initial_guess)
         self.P, self.guess = t(P), t(Xi)                      # opt_p per sample; initial guess = set_initial_guess semantics
         self.X = t(X0)                                        # plant states

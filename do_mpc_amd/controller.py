@@ -399,6 +399,13 @@ class MPC:
             raise NotImplementedError("structured HIP backend: integer inputs (MINLP/bonmin) are not supported")
         if s.nl_cons_check_colloc_points and self.nl_cons_list:
             raise NotImplementedError("structured HIP backend: nl_cons_check_colloc_points is not lowered yet")
+        if m.n_z and s.n_robust > 0 and self.n_combinations > 1:
+            zn = m._z.cat.nodes()
+            if sym.depends_on(self.lterm.nodes(), zn) or any(sym.depends_on(c["expr"].nodes(), zn) for c in self.nl_cons_list):
+                # (_mpc.py:1213 vs 1241, 1252: the dynamics read `_z[k, child]`, stage cost and nl_cons `_z[k, s]` of the PARENT's
+                #  scenario index - on a branching tree that couples an edge with the unknowns of a different edge)
+                raise NotImplementedError("structured HIP backend: a stage cost / nl_cons that depends on algebraic states "
+                                          "is supported for scenario chains (n_robust = 0) only")
         if s.state_discretization != "collocation" and m.model_type == "continuous":
             raise Exception("Unknown state_discretization: {}".format(s.state_discretization))
         self._check_validity()
@@ -474,7 +481,7 @@ class MPC:
         self._nlp_cons_ub = np.zeros(ps.n_g)
         if ps.ne:
             for e in range(ps.n_edges):
-                r0 = ps.tables["edge_row0"][e] + ps.M * ps.nx + ps.nx
+                r0 = ps.tables["edge_row0"][e] + ps.rows_block + ps.nx
                 self._nlp_cons_lb[r0:r0 + ps.ne] = self._nl_cons_lb
                 self._nlp_cons_ub[r0:r0 + ps.ne] = self._nl_cons_ub
         self._opt_x_num = NumStruct(self._opt_x_layout, 0.0)
@@ -528,6 +535,9 @@ class MPC:
             rhs = sym.substitute(m._rhs, m._w.cat, sym.SX.zeros(m.n_w, 1)).nodes()     # _w = 0 in the MPC (_mpc.py:1166)
         else:
             rhs = m._rhs.nodes()
+        alg = m._alg.nodes() if m.n_z else []
+        if m.n_z and m.n_w and sym.depends_on(alg, m._w.cat.nodes()):
+            alg = sym.substitute(m._alg, m._w.cat, sym.SX.zeros(m.n_w, 1)).nodes()
         nl_exprs = list(self._nl_rows)
         return lowering.lower_model(
             nx=m.n_x, nu=m.n_u, np_=m.n_p, ntvp=m.n_tvp,
@@ -536,12 +546,11 @@ class MPC:
             nl_slack_index=self._nl_slack_index, eps_penalty=self._eps_pen,
             sx=self._x_scaling.master, su=self._u_scaling.master, rterm=self.rterm_factor.master,
             h_scale=h, deg=s.collocation_deg, ni=s.collocation_ni, discrete=discrete, C=C, D=D,
-            name=type(m).__name__)
+            name=type(m).__name__, nz=m.n_z, z_sym=m._z.cat.nodes(), alg=alg, sz=self._z_scaling.master,
+            sp=self._p_scaling.master)
 
     def create_nlp(self, _solver_factory=None) -> None:
         assert self.flags["prepare_nlp"], "call prepare_nlp() first"
-        if np.any(self._p_scaling.master != 1.0):
-            raise NotImplementedError("structured HIP backend: _p scaling")
         self.generated_header = self._lower()
         self.model_hash = self.generated_header.rsplit('DOMPC_MODEL_HASH "', 1)[1].split('"')[0]
         factory = _solver_factory or HipIpmSolver
@@ -591,7 +600,7 @@ class MPC:
     def _eval_aux(self, opt_x_unscaled: NumStruct, opt_p: NumStruct) -> np.ndarray:
         """opt_aux_expression_fun (_mpc.py:1277-1284, 1331): aux at every (k, s)."""
         m, ps, N = self.model, self.structure, self.settings.n_horizon
-        X = opt_x_unscaled.master[:ps.off_u].reshape(N + 1, ps.S, ps.M + 1, ps.nx)[:N, :, -1, :]
+        X = opt_x_unscaled.master[:ps.off_z].reshape(N + 1, ps.S, ps.M + 1, ps.nx)[:N, :, -1, :]
         U = opt_x_unscaled.master[ps.off_u:ps.off_eps].reshape(N, ps.S, ps.nu)
         TV = opt_p.master[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
         Pm = opt_p.master[ps.p_off_p:ps.p_off_uprev].reshape(ps.n_comb, ps.np_)
@@ -613,7 +622,11 @@ class MPC:
         Uf = U[kk, src_s.reshape(-1)].T
         Tf = TV[kk].T
         Pf = Pm[pidx.reshape(-1)].T
-        Zf = np.zeros((0, N * ps.S))
+        if ps.nz:      # (_mpc.py:1277-1284: `_z[k, s, -1]`)
+            Z = opt_x_unscaled.master[ps.off_z:ps.off_u].reshape(N, ps.S, max(ps.M, 1), ps.nz)[:, :, -1, :]
+            Zf = Z[kk, src_s.reshape(-1)].T
+        else:
+            Zf = np.zeros((0, N * ps.S))
         out = m._aux_expression_fun.eval(Xf, Uf, Zf, Tf, Pf)[0]
         if out.ndim == 1:
             out = np.repeat(out[:, None], N * ps.S, axis=1)
@@ -680,7 +693,7 @@ class MPC:
         if opt_x_init is None:
             init = NumStruct(self._opt_x_layout, 0.0)
             Xi = np.tile(init.master, (B, 1))
-            xblk = Xi[:, :ps.off_u].reshape(B, -1, ps.nx)
+            xblk = Xi[:, :ps.off_z].reshape(B, -1, ps.nx)
             xblk[:] = (X0 / self._x_scaling.master)[:, None, :]
             ublk = Xi[:, ps.off_u:ps.off_eps].reshape(B, -1, ps.nu)
             ublk[:] = (P[:, ps.p_off_uprev:] / self._u_scaling.master)[:, None, :]

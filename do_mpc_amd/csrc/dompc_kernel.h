@@ -38,12 +38,19 @@ namespace dompc {
 #endif
 
 constexpr int NX = DOMPC_NX, NU = DOMPC_NU, NP = DOMPC_NP, NTVP = DOMPC_NTVP;
-constexpr int NE = DOMPC_NE, NS = DOMPC_NS;
+constexpr int NE = DOMPC_NE, NS = DOMPC_NS, NZ = DOMPC_NZ;
 constexpr int DEG = DOMPC_DEG, NI = DOMPC_NI, M = DOMPC_M;
 constexpr int NA = NX + NU;          // (x,u) of a stage == augmented state (x,u_prev)
 constexpr int NV = NU + NS;          // decision variables of a node: u then eps
 constexpr int NYT = NA + NV;         // node quadratic: (x, u_prev, u, eps)
-constexpr int NW = M * NX;           // collocation unknowns of an edge (incl. the xkf slot)
+// Algebraic states (DAE models, optimizer.py:905-983): every stored point of an interval has its own z (max(M, 1) per edge,
+// _mpc.py:1130) and its own algebraic rows; they are edge unknowns like the collocation states and are eliminated with them
+// (dense path eval_edge_dae - the optimised single-element path is for NZ == 0).
+constexpr int MZ = NZ > 0 ? (M > 0 ? M : 1) : 0;     // z slots of an edge
+constexpr int NWX = M * NX;          // collocation states of an edge (incl. the xkf slot)
+constexpr int NW = NWX + MZ * NZ;    // eliminated unknowns of an edge = rows of its square constraint block; order: x slots, then z slots
+constexpr int NF = NX + NZ;          // outputs of the dynamics at a point: [h f / sx ; alg]
+constexpr int NAV = NA + NZ;         // inputs of a point function: (x, u, z)
 constexpr int NCOLL = NI * DEG;      // collocation points evaluated per edge
 constexpr int RPE = NW + NX + NE;    // constraint rows per edge
 constexpr int NE1 = NE > 0 ? NE : 1;
@@ -67,12 +74,19 @@ constexpr int GS_C = 1;
 // Round 3: W = -G_w^-1 G_y and w0 = -G_w^-1 r are NOT stored any more (420 doubles per industrial_poly edge, written by
 // every sweep and read back by every forward pass): the forward pass forms dw = -G_w^-1 (G_y dy + r) from the stored
 // inverse, the u-columns of the point Jacobians (model-output record) and the residual vector.
-constexpr int LU_N = (NI == 1 && DEG > 0) ? DEG * NX : NW;
+constexpr int LU_N = (NI == 1 && DEG > 0 && NZ == 0) ? DEG * NX : NW;
 constexpr int EW_LU = 0;
 constexpr int EW_SIGW = EW_LU + LU_N * LU_N; // Sigma_w + dsw      (the lambda-weighted Hessian blocks are read from the model-output record)
 constexpr int EW_RW = EW_SIGW + NW;
 constexpr int EW_JD = EW_RW + NW;            // NE x NA
-constexpr int EW_SIZE = ((EW_JD + NE * NA + 1 + 7) / 8) * 8;      // records start on 64-byte boundaries
+// DAE models (dense path): W, w0, the rows of the edge Hessian that belong to the eliminated unknowns (over [w | y], Sigma_w
+// and the inertia correction on the diagonal), the Jacobians of the end-point rows and of the nl_cons rows w.r.t. w
+constexpr int EW_W = EW_JD + NE * NA;        // NW x NA
+constexpr int EW_W0 = EW_W + (NZ > 0 ? NW * NA : 0);
+constexpr int EW_HW = EW_W0 + (NZ > 0 ? NW : 0);                 // NW x (NW + NA)
+constexpr int EW_EWJ = EW_HW + (NZ > 0 ? NW * (NW + NA) : 0);    // NX x NW
+constexpr int EW_JDW = EW_EWJ + (NZ > 0 ? NX * NW : 0);          // NE x NW
+constexpr int EW_SIZE = ((EW_JDW + (NZ > 0 ? NE * NW : 0) + 1 + 7) / 8) * 8;      // records start on 64-byte boundaries
 
 // per-edge shared (contiguous per edge) --------------------------------------------------------
 // The head [A B | c | Q~ | q~ + r_y] is what the backward Riccati pass reads (staged by LDS-DMA, dompc_riccati16.h).
@@ -94,21 +108,22 @@ constexpr int ES_SIZE = ((ES_OBJ + 1 + 7) / 8) * 8;
 // per-edge model-output record (global): results of the lowered model functions at the current iterate,
 // written by the thread-parallel evaluation phase and copied into LDS by the edge groups
 // symmetric blocks of the model-output record are packed (upper triangle, row by row) by the generated code
-constexpr int NA_T = NA * (NA + 1) / 2, NX_T = NX * (NX + 1) / 2;
+constexpr int NA_T = NA * (NA + 1) / 2, NX_T = NX * (NX + 1) / 2, NAV_T = NAV * (NAV + 1) / 2;
 DOMPC_HD constexpr int symi(int i, int j, int n) { return i <= j ? i * n - i * (i - 1) / 2 + j - i : j * n - j * (j - 1) / 2 + i - j; }
-constexpr int PT_STRIDE = NX + NX * NA + NA_T;              // f, J, H (packed) of one collocation point
+constexpr int PT_STRIDE = NF + NF * NAV + NAV_T;            // F, J, H (packed) of one point (NZ == 0: f (NX), J (NX x NA), H over (x, u))
+constexpr int NPT_E = (M == 0) ? 1 : (NZ > 0 ? NI * (DEG + 1) : NI * DEG);    // points evaluated per edge (DAE: also point 0 of every element - its algebraic rows)
 constexpr int MO_PT = 0;
-constexpr int MO_LT = MO_PT + (NI * DEG > 0 ? NI * DEG : 1) * PT_STRIDE;   // lterm: val, g[NA], H[NA*NA]
-constexpr int MO_MT = MO_LT + 1 + NA + NA_T;                                 // mterm: val, g[NX], H (packed)
-constexpr int MO_NL = MO_MT + 1 + NX + NX_T;                                 // nlcons: d[NE], Jd[NE*NA], H (packed)
-constexpr int MO_SIZE = ((MO_NL + NE + NE * NA + NA_T + 7) / 8) * 8;
+constexpr int MO_LT = MO_PT + NPT_E * PT_STRIDE;                             // lterm: val, g[NAV], H (packed)
+constexpr int MO_MT = MO_LT + 1 + NAV + NAV_T;                               // mterm: val, g[NX], H (packed)
+constexpr int MO_NL = MO_MT + 1 + NX + NX_T;                                 // nlcons: d[NE], Jd[NE*NAV], H (packed)
+constexpr int MO_SIZE = ((MO_NL + NE + NE * NAV + NAV_T + 7) / 8) * 8;
 // Compact form of the record (single finite element, continuous model): only the entries that depend on the iterate
 // travel through HBM - the generated dompc_*_c functions write them one after the other (lowering.py: compact()); the
 // structural zeros and model constants of the dense layout above (149 + 9 of the 231 entries of an industrial_poly
 // collocation point, the whole Hessian of its linear stage cost) live in a dense IMAGE of the record that every
 // wavefront keeps in its LDS region: initialised once per phase (mo_image_init), the variable entries of the current
 // edge scattered into it (mo_expand).  All consumers read the image through the dense indices.
-constexpr bool MO_COMPACT = (NI == 1) && (M > 0);
+constexpr bool MO_COMPACT = (NI == 1) && (M > 0) && (NZ == 0);
 constexpr int MOC_LT = NCOLL * DOMPC_DYN_NV;
 constexpr int MOC_MT = MOC_LT + DOMPC_LT_NV;
 constexpr int MOC_NL = MOC_MT + DOMPC_MT_NV;
@@ -608,6 +623,8 @@ DOMPC_DEV inline double sigma_of(double x, double l, double u, double zl, double
   return sg;
 }
 
+#include "dompc_dae.h"       // edge phases of models with algebraic states (dense path)
+
 // ================================================================================================
 // Trial evaluation: constraint residuals + objective share of one edge at `xv` (no derivatives).
 // nlp_g / nlp_f of the reference for the rows/terms owned by edge e.
@@ -624,7 +641,7 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
   const double om = A.edge_omega[e] * Q.sf;
   double f[NX];
   if (M == 0) {
-    dompc_dyn_f(xn, un, tvp, pp, f);
+    dompc_dyn_f(xn, un, nullptr, tvp, pp, f);
     for (int a = 0; a < NX; ++a) cv[row0 + a] = f[a] - xc[a];
   } else {
     for (int i = 0; i < NI; ++i) {
@@ -632,7 +649,7 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
       const int rb = row0 + i * (DEG + 1) * NX;
       for (int j = 1; j <= DEG; ++j) {
         const double* xij = w + slot_of(i, j) * NX;
-        dompc_dyn_f(xij, un, tvp, pp, f);
+        dompc_dyn_f(xij, un, nullptr, tvp, pp, f);
         for (int a = 0; a < NX; ++a) {
           double xp = DOMPC_C[0 * (DEG + 1) + j] * xi0[a];
           for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + j] * w[slot_of(i, r) * NX + a];
@@ -648,11 +665,11 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
     }
     for (int a = 0; a < NX; ++a) cv[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
   }
-  double obj = om * dompc_lterm_f(xn, un, tvp, pp);
+  double obj = om * dompc_lterm_f(xn, un, nullptr, tvp, pp);
   if (k == A.N - 1) obj += om * dompc_mterm_f(xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
   if (NE > 0) {
     double d[NE1];
-    dompc_nlcons_f(xn, un, tvp, pp, d);
+    dompc_nlcons_f(xn, un, nullptr, tvp, pp, d);
     const double* eps = (NS > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
       if (DOMPC_NL_SLACK[i] >= 0) d[i] -= eps[DOMPC_NL_SLACK[i]];
@@ -703,7 +720,7 @@ static_assert(NW <= 64, "collocation block larger than 64 unknowns per edge is n
 constexpr int MX_LD = (NI == 1) ? NA + 1 : NC;                         // leading dimension of the LDS matrix
 constexpr int MX_W = (NI == 1) ? 0 : NW;                               // column offset of [W | w0] inside it
 #ifndef DOMPC_HOST_EMU
-constexpr bool TILE_CONDENSE = (NI == 1) && (DEG >= 1) && (NA <= 16);   // condensing on the matrix cores with register tiles (eval_edge_coop)
+constexpr bool TILE_CONDENSE = (NI == 1) && (DEG >= 1) && (NA <= 16) && (NZ == 0);   // condensing on the matrix cores with register tiles (eval_edge_coop)
 #else
 constexpr bool TILE_CONDENSE = false;
 #endif
@@ -760,7 +777,10 @@ constexpr int EW_STAGE = MO_LDS ? ((EW_SIZE + 127) / 128) * 128 : 0;
 constexpr int RF_MOC = RF_EW + EW_STAGE;
 constexpr int RF_IMG = RF_MOC + MOC_STAGE;
 constexpr int MOH_H0 = NX + NX * NA;                                    // offset of the packed Hessian inside a point record
-constexpr int EL_SIZE = ((el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)) + 7) / 8) * 8;
+// DAE models: dense edge working set of eval_edge_dae (= dae::DG_SIZE, asserted in sweep())
+constexpr int DAE_NEED = NZ > 0 ? NW * (2 * NW + NA + 1) + (NW + NA) * (NW + NA) + (NW + NA) * (NA + 2) + 2 * (NW + NA) + 3 * NW
+                                      + NX * NW + NX * NA + NX + NE * NW + NE * NA + NW : 0;
+constexpr int EL_SIZE = ((el_max(el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)), DAE_NEED) + 7) / 8) * 8;
 
 // ---- dense image of a compact model-output record
 // dense index (MO_PT / MO_LT / MO_MT / MO_NL layout) of compact entry k
@@ -832,7 +852,7 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
   // last-stage edges, the nl_cons blocks.  (Edge-major order puts every function type into every wavefront, which then
   // runs all of them one after the other with a fraction of its lanes; terminal-cost and nl_cons items of edges that have
   // none were idle slots.)
-  constexpr int NPT = (M == 0 ? 1 : NCOLL);
+  constexpr int NPT = NPT_E;
   const int E = A.n_edges;
   const int e_last0 = E - (A.level_node_start[A.N + 1] - A.level_node_start[A.N]);      // first edge of the last stage (edges are ordered by stage)
   const int n_dyn = E * NPT, n_lt = E, n_mt = E - e_last0, n_nl = (NE > 0) ? E : 0;
@@ -843,6 +863,7 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
     else if (it < n_dyn + n_lt + n_mt) { kind = 2; e = e_last0 + (it - n_dyn - n_lt); }
     else { kind = 3; e = it - n_dyn - n_lt - n_mt; }
     if (!mk_e(A, e)) continue;
+    if constexpr (NZ > 0) { dae_eval_item(Q, kind, e, j); continue; }
     const int n = A.edge_parent[e], cn = A.edge_child[e], k = A.edge_level[e];
     const double* xn = Q.x + A.node_x_off[n];
     const double* un = Q.x + A.node_u_off[n];
@@ -855,31 +876,31 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
       // compact record: [variable entries of point 0 | point 1 | ... | stage cost | terminal cost | nl_cons]
       if (kind == 0) {
         const int jj = j % (DEG > 0 ? DEG : 1) + 1;
-        dompc_dyn_c(w + slot_of(0, jj) * NX, un, tvp, pp, Q.lam + row0 + (jj - 1) * NX, mo + j * DOMPC_DYN_NV);
+        dompc_dyn_c(w + slot_of(0, jj) * NX, un, nullptr, tvp, pp, Q.lam + row0 + (jj - 1) * NX, mo + j * DOMPC_DYN_NV);
       } else if (kind == 1) {
-        dompc_lterm_c(xn, un, tvp, pp, mo + MOC_LT);
+        dompc_lterm_c(xn, un, nullptr, tvp, pp, mo + MOC_LT);
       } else if (kind == 2) {
         if (k == A.N - 1) dompc_mterm_c(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MOC_MT);
       } else if (NE > 0) {
-        dompc_nlcons_c(xn, un, tvp, pp, Q.lam + row0 + NW + NX, mo + MOC_NL);
+        dompc_nlcons_c(xn, un, nullptr, tvp, pp, Q.lam + row0 + NW + NX, mo + MOC_NL);
       }
     } else if (kind == 0) {
       double* pt = mo + MO_PT + j * PT_STRIDE;
       if (M == 0) {
-        dompc_dyn(xn, un, tvp, pp, Q.lam + row0 + NW, pt, pt + NX, pt + NX + NX * NA);
+        dompc_dyn(xn, un, nullptr, tvp, pp, Q.lam + row0 + NW, pt, pt + NX, pt + NX + NX * NA);
       } else {
         const int i = j / DEG, jj = j % DEG + 1;
-        dompc_dyn(w + slot_of(i, jj) * NX, un, tvp, pp, Q.lam + row0 + i * (DEG + 1) * NX + (jj - 1) * NX,
+        dompc_dyn(w + slot_of(i, jj) * NX, un, nullptr, tvp, pp, Q.lam + row0 + i * (DEG + 1) * NX + (jj - 1) * NX,
                   pt, pt + NX, pt + NX + NX * NA);
       }
     } else if (kind == 1) {
-      dompc_lterm(xn, un, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NA);
+      dompc_lterm(xn, un, nullptr, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NA);
     } else if (kind == 2) {
       if (k == A.N - 1)
         dompc_mterm(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1,
                     mo + MO_MT + 1 + NX);
     } else if (NE > 0) {
-      dompc_nlcons(xn, un, tvp, pp, Q.lam + row0 + NW + NX, mo + MO_NL, mo + MO_NL + NE, mo + MO_NL + NE + NE * NA);
+      dompc_nlcons(xn, un, nullptr, tvp, pp, Q.lam + row0 + NW + NX, mo + MO_NL, mo + MO_NL + NE, mo + MO_NL + NE + NE * NA);
     }
   }
 }
@@ -943,7 +964,7 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #endif
 constexpr int GJ_R = DEG * NX, GJ_RP = ((GJ_R + 3) / 4) * 4, GJ_NRHS = NA + 1;
 constexpr int GJ_NC = GJ_RP + GJ_NRHS + GJ_R;                      // columns: [G_cc padded | G_y r | I]
-constexpr bool MFMA_GJ = (NI == 1) && (DEG >= 1) && (GJ_RP <= 32) && (GJ_NC <= 64) && (DOMPC_MFMA_GJ != 0);
+constexpr bool MFMA_GJ = (NI == 1) && (DEG >= 1) && (NZ == 0) && (GJ_RP <= 32) && (GJ_NC <= 64) && (DOMPC_MFMA_GJ != 0);
 constexpr int GJ_MT = (GJ_RP + 15) / 16, GJ_NT = (GJ_NC + 15) / 16;
 static_assert(!MFMA_GJ || GJ_RP * 4 + 64 <= EL_T1 - EL_MX, "the panel buffer and the dual-residual row share the W | w0 region of the edge working set");
 
@@ -3255,6 +3276,23 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     const double* Nc = Q.ND(cn);
     const int row0 = A.edge_row0[e];
     const bool chain_edge = A.edge_level[e] >= cl;          // its d nu was formed by the chain walk
+    if constexpr (NZ > 0) {
+      // DAE model: dense path (dompc_dae.h) - dy of the parent node and d nu of the end-point rows staged, then the edge
+      for (int a = lane; a < NA; a += GS) Ld[dae::DF_DY + a] = (a < NX) ? Nd[ND_DXT + a] : Q.dx[A.node_u_off[n] + a - NX];
+      for (int a = lane; a < NX; a += GS) {
+        double t;
+        if (chain_edge) t = Q.dlam[row0 + NW + a];
+        else {
+          t = Nc[ND_PV + a];
+          for (int b = 0; b < NA; ++b) t += Nc[ND_P + a * NA + b] * Nc[ND_DXT + b];
+          Q.dlam[row0 + NW + a] = t;
+        }
+        Ld[dae::DF_DNU + a] = t;
+      }
+      T.gsync();
+      forward_edge_dae(T, Q, e, delta, lane, GS, Ld);
+      continue;
+    }
     constexpr int RPL = (NW1 + GS_C - 1) / GS_C;          // rows (= columns of G_w^-1) per lane: 1 on the device
     constexpr int LU1 = LU_N > 0 ? LU_N : 1;
     constexpr int NU1 = NU > 0 ? NU : 1;
@@ -3489,6 +3527,11 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
       const int en = e + ng;
       const bool mine = e < A.n_edges && mk_e(A, e);
       if (sh_on(A) && !mine) continue;                  // sharded: another rank's edge (no workgroup barrier inside)
+      if constexpr (NZ > 0) {
+        static_assert(NZ == 0 || dae::DG_SIZE == DAE_NEED, "LDS working set of the dense DAE path");
+        if (eval_edge_dae(T, Q, mine ? e : -1, mu, lane, T.gs, Ld)) T.fset(1, 1);
+        continue;
+      }
       if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld, staged_e, mm)) T.fset(1, 1);
     }
   }
@@ -3531,10 +3574,10 @@ DOMPC_PHASE void refresh_mu(const Thr& T, const Prob& Q, double dmu) {
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
   for (int e = gid; e < A.n_edges; e += ng) {
     if (!mk_e(A, e)) continue;
-    if (M > 0) {
-      const int woff = A.edge_w_off[e];
+    if (NW > 0) {
+      const int woff = A.edge_w_off[e], zoff = (NZ > 0) ? edge_zoff(A, e) : 0;
       for (int r = lane; r < NW; r += GS) {
-        const int gi = woff + r;
+        const int gi = wvar(woff, zoff, r);
         Q.EW(e, EW_RW + r) += dmu * bar_grad(Q.x[gi], Q.lb[gi], Q.ub[gi], 1.0);
       }
       double* S_ = Q.ES(e);
@@ -3673,7 +3716,7 @@ DOMPC_DEV inline double trial_edges(const Thr& T, const Prob& Q) {
   for (int e = T.tid; e < A.n_edges; e += T.nt) {
     const int m = mk_e(A, e);
     if (!m) continue;
-    const double fe = eval_edge_f(Q, e, Q.xt, Q.st, Q.ct);
+    const double fe = (NZ > 0) ? dae_edge_f(Q, e, Q.xt, Q.st, Q.ct) : eval_edge_f(Q, e, Q.xt, Q.st, Q.ct);
     if (sh_cnt(A, m)) f += fe;
   }
   for (int n = T.tid; n < A.n_nodes; n += T.nt)
@@ -4035,7 +4078,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   if (NE > 0) {
     for (int e = T.tid; e < A.n_edges; e += T.nt) {
       for (int i = 0; i < NE; ++i) Q.s[e * NE1 + i] = 0.0;
-      eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
+      if (NZ > 0) dae_edge_f(Q, e, Q.x, Q.s, Q.ct); else eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
       for (int i = 0; i < NE; ++i) {
         const int row = A.edge_row0[e] + NW + NX + i, si = e * NE1 + i;
         double l = A.lbg[row], u = A.ubg[row];
@@ -4430,7 +4473,7 @@ DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A) {
   if (NE > 0) {
     for (int e = T.tid; e < A.n_edges; e += T.nt) {
       for (int i = 0; i < NE; ++i) Q.s[e * NE1 + i] = 0.0;
-      eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
+      if (NZ > 0) dae_edge_f(Q, e, Q.x, Q.s, Q.ct); else eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
       for (int i = 0; i < NE; ++i) {
         const int row = A.edge_row0[e] + NW + NX + i, si = e * NE1 + i;
         const double l = A.lbg[row], u = A.ubg[row];

@@ -256,6 +256,15 @@ static void* own_stream(dompc_handle* h) {
 #endif
 }
 
+// largest workgroup size <= `block` whose LDS pool (one edge working set per wavefront) fits the 160 KiB of a CU - models with
+// a large dense edge working set (DAE path: 45 kB per wavefront for the double inverted pendulum) run with fewer wavefronts
+// per workgroup
+static int fit_block(const dompc_handle* h, int block) {
+  const int64_t lds_max = 160 * 1024 - 4096;                     // (static LDS of the kernel: filter, flags, counters)
+  while (block > 64 && (int64_t)(block / 64) * h->el_size * (int64_t)sizeof(double) > lds_max) block /= 2;
+  return block;
+}
+
 // `block` threads per workgroup (a multiple of 64): the LDS pool is sized for block/64 wavefronts
 static int launch(dompc_handle* h, dompc::KArgs& A, int grid, int block, void* stream_v) {
 #ifndef DOMPC_HOST_EMU
@@ -373,7 +382,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     return resident;
   };
   h->slots64 = resident_at(64);
-  h->slots256 = resident_at(256);
+  h->slots256 = resident_at(fit_block(h, 256));
   {
     // batches of >= BATCH_ONE_WAVE problems run one wavefront per problem and need that many more slots
     const int resident = h->block_auto ? (max_batch >= BATCH_ONE_WAVE ? h->slots64 : h->slots256) : resident_at(h->block);
@@ -645,8 +654,8 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   A.x0 = x0; A.lbx = lbx; A.ubx = ubx; A.lbg = lbg; A.ubg = ubg; A.p = p;
   A.x_out = x; A.g_out = g; A.lam_x_out = lam_x; A.lam_g_out = lam_g; A.f_out = f; A.stats = stats;
   A.batch = B; A.mode = 0;
-  const int block = h->block_auto ? (B >= BATCH_ONE_WAVE ? 64 : 256) : h->block;
-  const int cap = (h->block_auto && block == 256 && h->slots256 < h->n_slots) ? h->slots256 : h->n_slots;   // resident workgroups at this block size
+  const int block = fit_block(h, h->block_auto ? (B >= BATCH_ONE_WAVE ? 64 : 256) : h->block);
+  const int cap = (h->block_auto && block != 64 && h->slots256 < h->n_slots) ? h->slots256 : h->n_slots;   // resident workgroups at this block size
   int grid = B < cap ? B : cap;
   A.wide = 1;
   if (h->sharded) {
@@ -673,7 +682,7 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
     HIPCHK(h, hipMemsetAsync(A.wide_flags, 0, sizeof(int32_t) * 8 * 64, st));
   }
 #endif
-  if (launch(h, A, grid, (A.wide > 1 || h->sharded) ? 256 : block, stream)) return 1;
+  if (launch(h, A, grid, (A.wide > 1 || h->sharded) ? fit_block(h, 256) : block, stream)) return 1;
 #ifndef DOMPC_HOST_EMU
   if (h->sharded) return serve_exchanges(h, (hipStream_t)stream);
 #endif
@@ -740,7 +749,7 @@ extern "C" int dompc_sweep_batch_device(dompc_handle* h, int32_t B, const double
   A.p = p; A.sw_x = x; A.sw_lam = lam; A.sw_g = g; A.sw_blocks = blocks;
   A.batch = B; A.mode = 2;
   const int grid = B < h->n_slots ? B : h->n_slots;
-  return launch(h, A, grid, h->block, stream);
+  return launch(h, A, grid, fit_block(h, h->block), stream);
 }
 
 static int newton_step_impl(dompc_handle* h, const double* x, const double* lam_g, const double* zl,
@@ -771,7 +780,7 @@ static int newton_step_impl(dompc_handle* h, const double* x, const double* lam_
   A.dbg_dx = h->s_dbg[3]; A.dbg_dlam = h->s_dbg[4]; A.dbg_rd = h->s_dbg[5]; A.dbg_c = h->s_dbg[6];
   A.dbg_mu = mu; A.dbg_delta = delta_w;
   A.batch = 1; A.mode = 1; A.dbg_at_solution = at_solution;
-  if (launch(h, A, 1, 256, main_stream(h))) return 1;
+  if (launch(h, A, 1, fit_block(h, 256), main_stream(h))) return 1;
   if (dx) rc |= d2h(h, dx, h->s_dbg[3], sizeof(double) * d.n_opt_x);
   if (dlam) rc |= d2h(h, dlam, h->s_dbg[4], sizeof(double) * d.n_g);
   if (rd) rc |= d2h(h, rd, h->s_dbg[5], sizeof(double) * d.n_opt_x);

@@ -6,9 +6,11 @@ example's initial state.  Equations/settings follow the reference examples (cite
 the un-edited reference templates themselves run through do_mpc_amd.casadi_compat in
 tests/test_reference_templates.py when /root/reference is present.
 """
-from . import batch_reactor, bicycle, cstr, industrial_poly, kite, oscillating_masses, rotating_masses  # noqa: F401
+from . import (batch_reactor, bicycle, cstr, dip, industrial_poly, kite, oscillating_masses, oscillating_masses_dae,  # noqa: F401
+               rotating_masses)
 
 CASES = {"industrial_poly": industrial_poly, "CSTR": cstr, "batch_reactor": batch_reactor,
          "oscillating_masses": oscillating_masses, "kinematic_bicycle": bicycle.kinematic,
-         "dynamic_bicycle": bicycle.dynamic, "kite": kite, "rotating_masses": rotating_masses}
+         "dynamic_bicycle": bicycle.dynamic, "kite": kite, "rotating_masses": rotating_masses,
+         "oscillating_masses_dae": oscillating_masses_dae, "dip": dip}
 BASELINE_CASES = ("industrial_poly", "CSTR", "batch_reactor", "oscillating_masses")

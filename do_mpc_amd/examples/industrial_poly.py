@@ -32,28 +32,31 @@ def build_model(symvar_type="SX"):
     k0 = mdl.set_variable("_p", "k_0")
 
     mW, mA, mP, TR, TS, TM, TEK, TAWT = (s[k] for k in ("m_W", "m_A", "m_P", "T_R", "T_S", "Tout_M", "T_EK", "Tout_AWT"))
-    m_tot = mW + mA + mP
+    # (operations associated exactly like the reference template, so that the un-edited template_model.py lowers to the SAME
+    #  generated header - and therefore the same gfx950 code object - as this restatement; tests/test_reference_templates.py)
     conv = mP / (mA + mP)
-    gel = K_U1 * (1 - conv) + K_U2 * conv
+    m_tot = mW + mA + mP
+    gel = (K_U1 * (1 - conv)) + (K_U2 * conv)
     k_reactor = k0 * exp(-E_ACT / (R_GAS * TR)) * gel
-    k_loop = k0 * exp(-E_ACT / (R_GAS * TEK)) * gel
-    k_wall = (mW / m_tot) * K_WS + (mA / m_tot) * K_AS + (mP / m_tot) * K_PS
-    r_reactor = k_reactor * (mA - (mA * M_AWT) / (mW + mA + mP))
-    r_loop = 1.0 * k_loop * (mA / m_tot) * M_AWT
+    k_loop = k0 * exp(-E_ACT / (R_GAS * TEK)) * ((K_U1 * (1 - conv)) + (K_U2 * conv))
+    k_wall = ((mW / m_tot) * K_WS) + ((mA / m_tot) * K_AS) + ((mP / m_tot) * K_PS)
+    P_1 = 1.0
+    hold_up = mA - ((mA * M_AWT) / (mW + mA + mP))          # monomer outside the external heat exchanger
 
     d_mW = feed * W_WF
-    d_mA = feed * W_AF - r_reactor - r_loop
-    d_mP = r_reactor + r_loop
-    d_TR = 1.0 / (CP_R * m_tot) * (feed * CP_F * (T_FEED - TR) - k_wall * A_JACKET * (TR - TS)
-                                   - FM_AWT * CP_R * (TR - TEK) + dH * r_reactor)
     mdl.set_rhs("m_W", d_mW)
+    d_mA = (feed * W_AF) - (k_reactor * hold_up) - (P_1 * k_loop * (mA / m_tot) * M_AWT)
     mdl.set_rhs("m_A", d_mA)
+    d_mP = (k_reactor * hold_up) + (P_1 * k_loop * (mA / m_tot) * M_AWT)
     mdl.set_rhs("m_P", d_mP)
+    d_TR = 1. / (CP_R * m_tot) * ((feed * CP_F * (T_FEED - TR)) - (k_wall * A_JACKET * (TR - TS))
+                                  - (FM_AWT * CP_R * (TR - TEK)) + (dH * k_reactor * hold_up))
     mdl.set_rhs("T_R", d_TR)
-    mdl.set_rhs("T_S", 1.0 / (CP_S * M_STEEL) * (k_wall * A_JACKET * (TR - TS) - k_wall * A_JACKET * (TS - TM)))
-    mdl.set_rhs("Tout_M", 1.0 / (CP_W * M_M_KW) * (FM_M_KW * CP_W * (T_jacket_in - TM) + k_wall * A_JACKET * (TS - TM)))
-    mdl.set_rhs("T_EK", 1.0 / (CP_R * M_AWT) * (FM_AWT * CP_R * (TR - TEK) - ALFA * (TEK - TAWT) + r_loop * dH))
-    mdl.set_rhs("Tout_AWT", 1.0 / (CP_W * M_AWT_KW) * (FM_AWT_KW * CP_W * (T_ehe_in - TAWT) - ALFA * (TAWT - TEK)))
+    mdl.set_rhs("T_S", 1. / (CP_S * M_STEEL) * ((k_wall * A_JACKET * (TR - TS)) - (k_wall * A_JACKET * (TS - TM))))
+    mdl.set_rhs("Tout_M", 1. / (CP_W * M_M_KW) * ((FM_M_KW * CP_W * (T_jacket_in - TM)) + (k_wall * A_JACKET * (TS - TM))))
+    mdl.set_rhs("T_EK", 1. / (CP_R * M_AWT) * ((FM_AWT * CP_R * (TR - TEK)) - (ALFA * (TEK - TAWT))
+                                               + (P_1 * k_loop * (mA / m_tot) * M_AWT * dH)))
+    mdl.set_rhs("Tout_AWT", 1. / (CP_W * M_AWT_KW) * ((FM_AWT_KW * CP_W * (T_ehe_in - TAWT)) - (ALFA * (TAWT - TEK))))
     mdl.set_rhs("accum_monom", feed)
     mdl.set_rhs("T_adiab", dH / (m_tot * CP_R) * d_mA - (d_mA + d_mW + d_mP) * (mA * dH / (m_tot * m_tot * CP_R)) + d_TR)
     mdl.setup()

@@ -46,22 +46,33 @@ def _sym_hessian_upper(L: sym.Node, v: List[sym.Node]):
 
 def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, mterm, nl_exprs,
                 nl_slack_index, eps_penalty, sx, su, rterm, h_scale, deg, ni, discrete, C, D,
-                name="model") -> str:
+                name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None) -> str:
     """Return the text of the generated header.
 
-    x_sym/u_sym/tvp_sym/p_sym: lists of sym.Node (the model's own symbols, unscaled).
-    rhs: list[nx] of Node; lterm, mterm: Node; nl_exprs: list[ne] of Node (without the -eps part).
+    x_sym/u_sym/z_sym/tvp_sym/p_sym: lists of sym.Node (the model's own symbols, unscaled).
+    rhs: list[nx] of Node; alg: list[nz] of Node (algebraic equations of a DAE model, optimizer.py:812-813, unscaled rows);
+    lterm, mterm: Node; nl_exprs: list[ne] of Node (without the -eps part).
+    sp: `_p` scaling - the reference multiplies the parameters by it in the model equations only (optimizer.py:808-812:
+    `_p_unscaled = _p * _p_scaling` feeds rhs / alg; cost and nl_cons read opt_p['_p'] as it is, _mpc.py:1230-1275).
+
+    Point functions take the stage variables as v = (x (nx), u (nu), z (nz)): for a model without algebraic states
+    that is the (x, u) of the optimised kernels, with them the algebraic block is appended (dense DAE path of the kernels).
     """
     ne = len(nl_exprs)
     ns = len(eps_penalty)
     na = nx + nu
+    nav = na + nz                    # inputs of a point function
+    nf = nx + nz                     # outputs of the dynamics at a point: [h f / sx ; alg]
+    sz = np.ones(nz) if (sz is None or len(sz) == 0) else np.asarray(sz, float)
+    sp = np.ones(np_) if sp is None else np.asarray(sp, float)
     xs, bx = _bind("xs", nx)
     us, bu = _bind("us", nu)
+    zs, bz = _bind("zs", nz)
     tv, bt = _bind("tvp", ntvp)
     pp, bp = _bind("pp", np_)
-    lam, bl = _bind("lam", max(nx, ne, 1))
+    lam, bl = _bind("lam", max(nf, ne, 1))
     binds = {}
-    for b in (bx, bu, bt, bp, bl):
+    for b in (bx, bu, bz, bt, bp, bl):
         binds.update(b)
     # unscaled model symbols -> scaled kernel symbols
     mapping = {}
@@ -69,23 +80,30 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         mapping[s.idx] = sym.mul(xs[i], sym.const(sx[i]))
     for i, s in enumerate(u_sym):
         mapping[s.idx] = sym.mul(us[i], sym.const(su[i]))
+    for i, s in enumerate(z_sym):
+        mapping[s.idx] = sym.mul(zs[i], sym.const(sz[i]))
     for i, s in enumerate(tvp_sym):
         mapping[s.idx] = tv[i]
     for i, s in enumerate(p_sym):
         mapping[s.idx] = pp[i]
+    mapping_dyn = dict(mapping)      # model equations: parameters times their scaling
+    for i, s in enumerate(p_sym):
+        if sp[i] != 1.0:
+            mapping_dyn[s.idx] = sym.mul(pp[i], sym.const(sp[i]))
 
-    def scaled(nodes):
-        out = sym.substitute_nodes(list(nodes), mapping)
+    def scaled(nodes, mp=None):
+        out = sym.substitute_nodes(list(nodes), mapping if mp is None else mp)
         free = [s for s in sym.free_symbols(out) if s.idx not in binds]
         if free:
-            raise Exception(f"expression depends on symbols outside (_x,_u,_tvp,_p): {free}")
+            raise Exception(f"expression depends on symbols outside (_x,_u,_z,_tvp,_p): {free}")
         return out
 
-    v = xs + us
-    f = [sym.mul(sym.div(e, sym.const(sx[i])), sym.const(h_scale)) for i, e in enumerate(scaled(rhs))]
+    v = xs + us + zs
+    f = [sym.mul(sym.div(e, sym.const(sx[i])), sym.const(h_scale)) for i, e in enumerate(scaled(rhs, mapping_dyn))]
+    f += list(scaled(alg, mapping_dyn))
     Jf = sym.forward_jacobian(f, v)
     Lf = sym.ZERO
-    for i in range(nx):
+    for i in range(nf):
         Lf = sym.add(Lf, sym.mul(lam[i], f[i]))
     _, Hf = _sym_hessian_upper(Lf, v)
 
@@ -125,28 +143,28 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     def packed(H, n):
         return [H[i][j] for i in range(n) for j in range(i, n)]
 
-    sig_dyn_args = "const double* xs, const double* us, const double* tvp, const double* pp"
-    outs = [(f"f[{i}]", f[i]) for i in range(nx)]
+    sig_dyn_args = "const double* xs, const double* us, const double* zs, const double* tvp, const double* pp"
+    outs = [(f"f[{i}]", f[i]) for i in range(nf)]
     parts.append(emit_fn(f"void dompc_dyn_f({sig_dyn_args}, double* f)", outs))
-    outs = [(f"f[{i}]", f[i]) for i in range(nx)]
-    outs += [(f"J[{i * na + j}]", Jf[i][j]) for i in range(nx) for j in range(na)]
-    outs += hess_outs(Hf, na)
+    outs = [(f"f[{i}]", f[i]) for i in range(nf)]
+    outs += [(f"J[{i * nav + j}]", Jf[i][j]) for i in range(nf) for j in range(nav)]
+    outs += hess_outs(Hf, nav)
     parts.append(emit_fn(f"void dompc_dyn({sig_dyn_args}, const double* lam, double* f, double* J, double* H)", outs))
     # (dense block of a point: f | J row-major | H packed - PT_STRIDE in csrc/dompc_kernel.h)
     compact("DYN", f"void dompc_dyn_c({sig_dyn_args}, const double* lam, double* o)",
-            list(enumerate(list(f) + [Jf[i][j] for i in range(nx) for j in range(na)] + packed(Hf, na))))
+            list(enumerate(list(f) + [Jf[i][j] for i in range(nf) for j in range(nav)] + packed(Hf, nav))))
 
     # stage cost (unweighted; omega applied by the kernel)
     lt = scaled([lterm])[0]
     gl, Hl = _sym_hessian_upper(lt, v)
     parts.append(emit_fn(f"double dompc_lterm_f({sig_dyn_args})", [("double val", lt)]).replace(
         "\n}\n", "\n  return val;\n}\n"))
-    outs = [("val[0]", lt)] + [(f"g[{i}]", gl[i]) for i in range(na)] + hess_outs(Hl, na)
+    outs = [("val[0]", lt)] + [(f"g[{i}]", gl[i]) for i in range(nav)] + hess_outs(Hl, nav)
     parts.append(emit_fn(f"void dompc_lterm({sig_dyn_args}, double* val, double* g, double* H)", outs))
-    compact("LT", f"void dompc_lterm_c({sig_dyn_args}, double* o)", list(enumerate([lt] + list(gl[:na]) + packed(Hl, na))))
+    compact("LT", f"void dompc_lterm_c({sig_dyn_args}, double* o)", list(enumerate([lt] + list(gl[:nav]) + packed(Hl, nav))))
 
     mt = scaled([mterm])[0]
-    if sym.depends_on([mt], us):
+    if sym.depends_on([mt], us + zs):
         raise Exception("mterm contains invalid symbolic variables as inputs. Must contain only: _x, _tvp, _p")
     gm, Hm = _sym_hessian_upper(mt, xs)
     sig_m = "const double* xs, const double* tvp, const double* pp"
@@ -167,11 +185,11 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         outs = [(f"d[{i}]", d[i]) for i in range(ne)]
         parts.append(emit_fn(f"void dompc_nlcons_f({sig_dyn_args}, double* d)", outs))
         outs = [(f"d[{i}]", d[i]) for i in range(ne)]
-        outs += [(f"Jd[{i * na + j}]", Jd[i][j]) for i in range(ne) for j in range(na)]
-        outs += hess_outs(Hd, na)
+        outs += [(f"Jd[{i * nav + j}]", Jd[i][j]) for i in range(ne) for j in range(nav)]
+        outs += hess_outs(Hd, nav)
         parts.append(emit_fn(f"void dompc_nlcons({sig_dyn_args}, const double* lam, double* d, double* Jd, double* H)", outs))
         compact("NL", f"void dompc_nlcons_c({sig_dyn_args}, const double* lam, double* o)",
-                list(enumerate(list(d) + [Jd[i][j] for i in range(ne) for j in range(na)] + packed(Hd, na))))
+                list(enumerate(list(d) + [Jd[i][j] for i in range(ne) for j in range(nav)] + packed(Hd, nav))))
     else:
         parts.append(f"DOMPC_FN void dompc_nlcons_c({sig_dyn_args}, const double* lam, double* o) {{}}\n")
         tables += ["#define DOMPC_NL_NV 0", "#define DOMPC_NL_NC 0", _fmt_array("DOMPC_NL_VIDX", [], "int"),
@@ -186,7 +204,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         "#include <math.h>",
         f"#define DOMPC_MODEL_NAME \"{name}\"",
         f"#define DOMPC_NX {nx}", f"#define DOMPC_NU {nu}", f"#define DOMPC_NP {np_}",
-        f"#define DOMPC_NTVP {ntvp}", f"#define DOMPC_NE {ne}", f"#define DOMPC_NS {ns}",
+        f"#define DOMPC_NTVP {ntvp}", f"#define DOMPC_NE {ne}", f"#define DOMPC_NS {ns}", f"#define DOMPC_NZ {nz}",
         f"#define DOMPC_DEG {deg if not discrete else 0}", f"#define DOMPC_NI {ni if not discrete else 1}",
         f"#define DOMPC_M {M}", f"#define DOMPC_DISCRETE {1 if discrete else 0}",
         _fmt_array("DOMPC_C", np.asarray(C).reshape(-1) if not discrete else [0.0]),

@@ -180,6 +180,7 @@ class HipIpmSolver:
         self._keep.append(om)
         d.edge_omega = om.ctypes.data_as(_f64p)
         d.code_object_path = (_code_object or "").encode()
+        self.code_object_path = _code_object or ""          # the gfx950 code object of this problem class (named by the model hash)
         d.model_hash = model_hash.encode()
         d.device, d.max_batch, d.n_slots, d.block_threads = device, max_batch, n_slots, block_threads
         self._lib.dompc_default_options(C.byref(d.opts))

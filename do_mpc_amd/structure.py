@@ -122,8 +122,22 @@ class ProblemStructure:
         return self.p_off_uprev + self.nu
 
     @property
+    def MZ(self):
+        """z slots of an interval (_mpc.py:1130: max(n_total_coll_points, 1))"""
+        return max(self.M, 1) if self.nz else 0
+
+    @property
+    def rows_block(self):
+        """rows of an interval's own constraint block (optimizer.py:943-983: collocation, algebraic, continuity rows;
+        discrete models: the algebraic rows) = number of its eliminated unknowns"""
+        return self.M * self.nx + self.MZ * self.nz
+
+    @property
     def rows_per_edge(self):
-        return self.M * self.nx + self.nx + self.ne
+        return self.rows_block + self.nx + self.ne
+
+    def iz(self, k, s, c):
+        return self.off_z + ((k * self.S + s) * max(self.M, 1) + c) * self.nz
 
     @property
     def n_g(self):
@@ -161,8 +175,6 @@ def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust,
                                   "(shared input) and is not tree-structured")
     if single_slack and ns > 0 and N > 1:
         raise NotImplementedError("structured HIP backend: nl_cons_single_slack couples all stages")
-    if nz > 0:
-        raise NotImplementedError("structured HIP backend: algebraic states (_z) are not lowered yet")
 
     n_branches = [n_comb if k < n_robust else 1 for k in range(N)]
     n_scen = [n_comb ** min(k, n_robust) for k in range(N + 1)]
@@ -184,7 +196,8 @@ def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust,
     child_scenario = -np.ones((N, S, n_branches[0] if N else 1), dtype=int)
     branch_offset = -np.ones((N, S), dtype=int)
     structure_scenario = np.zeros((N + 1, S), dtype=int)
-    rpe = M * nx + nx + ne
+    rpe = ps.rows_per_edge
+    e_zoff = []
     for k in range(N + 1):
         for s in range(n_scen[k]):
             n = level_start[k] + s
@@ -217,6 +230,7 @@ def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust,
                 e_child.append(cn)
                 e_pidx.append(b + boff)
                 e_woff.append(ps.ix(k + 1, c, 0))
+                e_zoff.append(ps.iz(k, c, 0) if nz else 0)     # (_mpc.py:1213: the dynamics use `_z[k, child, :]`)
                 e_level.append(k)
                 e_omega.append(1.0 / n_scen[k + 1])
 
@@ -228,6 +242,7 @@ def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust,
         edge_pidx=np.array(e_pidx, np.int32), edge_w_off=np.array(e_woff, np.int32),
         edge_row0=np.array(e_row0, np.int32), edge_level=np.array(e_level, np.int32),
         edge_omega=np.array(e_omega, np.float64),
+        edge_z_off=np.array(e_zoff, np.int32),       # (host-side only: the kernels derive it, dompc_dae.h:edge_zoff)
     )
     # variables that appear in no constraint and no cost term
     used = np.zeros(ps.n_opt_x, bool)
@@ -239,6 +254,9 @@ def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust,
             used[node_eps_off[n]:node_eps_off[n] + ns] = True
     for w in e_woff:
         used[w:w + M * nx] = True
+    if nz:
+        for z in e_zoff:
+            used[z:z + ps.MZ * nz] = True
     ps.tables["dummy_idx"] = np.where(~used)[0].astype(np.int32)
     ps.scenario_tree = {
         "structure_scenario": structure_scenario, "n_branches": n_branches, "n_scenarios": n_scen,
@@ -304,6 +322,9 @@ def shard_tables(ps: ProblemStructure, rank: int = 0, world: int = 1, cut_level:
     for e in range(n_edges):
         w = int(T["edge_w_off"][e])
         x_mask[w:w + M * nx] = edge_mask[e]
+        if ps.nz:
+            z = int(T["edge_z_off"][e])
+            x_mask[z:z + ps.MZ * ps.nz] = edge_mask[e]
         r0 = int(T["edge_row0"][e])
         g_mask[r0:r0 + rpe] = edge_mask[e]
     return dict(cut_level=c, n_cut=int(n_cut), rank=int(rank), world=int(world), node_mask=node_mask, edge_mask=edge_mask,

@@ -271,7 +271,72 @@ def case_rotating_masses(**over):
     return dd
 
 
-CASES = {"rotating_masses": case_rotating_masses, "industrial_poly": case_industrial_poly, "CSTR": case_CSTR,
+def case_oscillating_masses_dae(**over):
+    """/root/reference/examples/oscillating_masses_discrete_dae/template_model.py:34-75, template_mpc.py:34-74: the discrete
+    masses with the successor state as algebraic variable, x+ = z, 0 = z - A x - B u."""
+    d = case_oscillating_masses()
+    x, u = d["x"], d["u"]
+    z = sp.symbols("x_next_0 x_next_1 x_next_2 x_next_3")
+    A = np.array([[0.763, 0.460, 0.115, 0.020], [-0.899, 0.763, 0.420, 0.115], [0.115, 0.020, 0.763, 0.460],
+                  [0.420, 0.115, -0.899, 0.763]])
+    B = np.array([0.014, 0.063, 0.221, 0.367])
+    d.update(name="oscillating_masses_dae", z=z, rhs=list(z),
+             alg=[z[i] - sum(A[i, j] * x[j] for j in range(4)) - B[i] * u[0] for i in range(4)], z_scaling=np.ones(4))
+    d.update(over)
+    return d
+
+
+def case_dip(**over):
+    """/root/reference/examples/double_inverted_pendulum/template_model.py:34-146, template_mpc.py:34-100 and the obstacle /
+    initial state of testing/test_DIP.py:70-90: cart with two rods, accelerations as algebraic states (Euler-Lagrange)."""
+    pos, th0, th1, dpos, dth0, dth1 = x = sp.symbols("pos theta_0 theta_1 dpos dtheta_0 dtheta_1")
+    ddpos, ddth0, ddth1 = z = sp.symbols("ddpos ddtheta_0 ddtheta_1")
+    u = (sp.Symbol("force"),)
+    m1, m2 = p = sp.symbols("m1 m2")
+    tvp = (sp.Symbol("pos_set"),)
+    m0, L1, L2 = 0.6, 0.5, 0.5
+    l1, l2 = L1 / 2, L2 / 2
+    J1, J2 = (0.2 * l1 ** 2) / 3, (0.2 * l2 ** 2) / 3
+    g = 9.80665
+    h1 = m0 + m1 + m2
+    h2 = m1 * l1 + m2 * L1
+    h3 = m2 * l2
+    h4 = m1 * l1 ** 2 + m2 * L1 ** 2 + J1
+    h5 = m2 * l2 * L1
+    h6 = m2 * l2 ** 2 + J2
+    h7 = (m1 * l1 + m2 * L1) * g
+    h8 = m2 * l2 * g
+    alg = [h1 * ddpos + h2 * ddth0 * sp.cos(th0) + h3 * ddth1 * sp.cos(th1)
+           - (h2 * dth0 ** 2 * sp.sin(th0) + h3 * dth1 ** 2 * sp.sin(th1) + u[0]),
+           h2 * sp.cos(th0) * ddpos + h4 * ddth0 + h5 * sp.cos(th0 - th1) * ddth1
+           - (h7 * sp.sin(th0) - h5 * dth1 ** 2 * sp.sin(th0 - th1)),
+           h3 * sp.cos(th1) * ddpos + h5 * sp.cos(th0 - th1) * ddth0 + h6 * ddth1
+           - (h5 * dth0 ** 2 * sp.sin(th0 - th1) + h8 * sp.sin(th1))]
+    E_kin = (sp.Rational(1, 2) * m0 * dpos ** 2
+             + sp.Rational(1, 2) * m1 * ((dpos + l1 * dth0 * sp.cos(th0)) ** 2 + (l1 * dth0 * sp.sin(th0)) ** 2)
+             + sp.Rational(1, 2) * J1 * dth0 ** 2
+             + sp.Rational(1, 2) * m2 * ((dpos + L1 * dth0 * sp.cos(th0) + l2 * dth1 * sp.cos(th1)) ** 2
+                                         + (L1 * dth0 * sp.sin(th0) + l2 * dth1 * sp.sin(th1)) ** 2)
+             + sp.Rational(1, 2) * J2 * dth0 ** 2)
+    E_pot = m1 * g * l1 * sp.cos(th0) + m2 * g * (L1 * sp.cos(th0) + l2 * sp.cos(th1))
+    ox, oy, orad = 0.0, 0.6, 0.3
+    n0, n1 = (pos, 0.0), (pos + L1 * sp.sin(th0), L1 * sp.cos(th0))
+    n2 = (n1[0] + L2 * sp.sin(th1), n1[1] + L2 * sp.cos(th1))
+    dist = [sp.sqrt((nx_ - ox) ** 2 + (ny_ - oy) ** 2) - orad * 1.05 for nx_, ny_ in (n0, n1, n2)]
+    m_var = 0.2 * np.array([1, 0.95, 1.05])
+    d = _base(name="dip", x=x, u=u, z=z, p=p, tvp=tvp, rhs=[dpos, dth0, dth1, ddpos, ddth0, ddth1], alg=alg,
+              lterm=-E_pot + 10 * (pos - tvp[0]) ** 2, mterm=E_kin - E_pot, rterm=np.array([0.1]),
+              n_horizon=100, n_robust=0, t_step=0.04, collocation_deg=3,
+              x_lb=-np.inf * np.ones(6), x_ub=np.inf * np.ones(6), u_lb=np.array([-4.0]), u_ub=np.array([4.0]),
+              x_scaling=np.ones(6), u_scaling=np.ones(1), z_scaling=np.ones(3),
+              x0=np.array([0.0, 0.9 * np.pi, 0.9 * np.pi, 0.0, 0.0, 0.0]), aux={},
+              nl_cons=[dict(expr=-dd, ub=0.0, soft=False) for dd in dist],
+              uncertainty={"m1": m_var, "m2": m_var})
+    d.update(over)
+    return d
+
+
+CASES = {"oscillating_masses_dae": case_oscillating_masses_dae, "dip": case_dip, "rotating_masses": case_rotating_masses, "industrial_poly": case_industrial_poly, "CSTR": case_CSTR,
          "batch_reactor": case_batch_reactor, "oscillating_masses": case_oscillating_masses,
          "kinematic_bicycle": case_kinematic_bicycle, "dynamic_bicycle": case_dynamic_bicycle, "kite": case_kite}
 

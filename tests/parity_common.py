@@ -16,6 +16,7 @@ from do_mpc_amd.examples import CASES
 from oracle import ipm
 from oracle.models import CASES as ORACLE_CASES
 from oracle.nlp import OracleNLP
+from oracle.nlp_dae import OracleNLPDae
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 U_RTOL, X_RTOL, STEP_TOL = 1e-6, 1e-5, 1e-6
@@ -24,6 +25,8 @@ U_RTOL, X_RTOL, STEP_TOL = 1e-6, 1e-5, 1e-6
 # termination tolerance.  (u0, full primal solution), relative to max(1, |.|); measured 7e-17 / 1e-14 (batch_reactor),
 # 7e-14 / 1e-13 (CSTR, since IPOPT's damping of one-sided bounds is restated), 1e-12 / 1e-11 (rotating masses).
 TIGHT_GOLDEN = {"batch_reactor": (1e-9, 1e-8), "rotating_masses": (1e-9, 1e-8), "CSTR": (1e-9, 1e-8),
+                "oscillating_masses_dae": (1e-9, 1e-8),      # discrete DAE (algebraic successor state): measured 3e-17 / 1e-16 / multipliers 9e-16
+                "dip": (1e-7, X_RTOL),                        # double inverted pendulum (DAE, non-convex swing-up, 133 iterations): u0 1e-8, primal 4e-7 / 3e-6
                 "industrial_poly": (1e-8, X_RTOL)}   # (u0 2e-10; one weakly determined terminal state is 5e-7 from the golden -
                                                      #  in the oracle's solution as well, the two agree to 1e-11)
 # constraint multipliers vs the golden lam_g, relative to max(1, max|lam_g|).  Measured (host emulation = HIP path to the
@@ -31,6 +34,7 @@ TIGHT_GOLDEN = {"batch_reactor": (1e-9, 1e-8), "rotating_masses": (1e-9, 1e-8), 
 # delta_w sequence to mirror, the goldens are IPOPT's iterates at its own termination), industrial_poly 2.1e-7 (the weakly
 # determined terminal temperatures, see above).
 LAM_RTOL = {"batch_reactor": 1e-11, "rotating_masses": 1e-11, "CSTR": 1e-11, "oscillating_masses": 1e-7,
+            "oscillating_masses_dae": 1e-11, "dip": 1e-6,
             "industrial_poly": 2e-6}
 
 _oracle_cache = {}
@@ -52,7 +56,8 @@ PAIRED_P = [[950.0, 7.0], [950.0 * 1.30, 7.0 * 1.30], [950.0 * 0.70, 7.0 * 0.70]
 def oracle_nlp(name, **over):
     key = (name, tuple(sorted((k, str(v)) for k, v in over.items())))
     if key not in _oracle_cache:
-        _oracle_cache[key] = OracleNLP(ORACLE_CASES[name](**over))
+        case = ORACLE_CASES[name](**over)
+        _oracle_cache[key] = (OracleNLPDae if case.get("z") else OracleNLP)(case)       # (models with algebraic states: oracle/nlp_dae.py)
     return _oracle_cache[key]
 
 

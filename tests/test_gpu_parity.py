@@ -37,12 +37,13 @@ def test_native_code_is_what_runs():
 
 
 @pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 5), ("industrial_poly", 5),
-                                        ("rotating_masses", 5)])
+                                        ("rotating_masses", 5), ("oscillating_masses_dae", 5), ("dip", 2)])
 def test_golden_replay(name, steps):
     pc.check_golden_replay(make_mpc, name, steps)
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly", "rotating_masses"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly", "rotating_masses",
+                                  "oscillating_masses_dae"])
 def test_newton_direction_matches_sparse_kkt_solve(name):
     pc.check_newton_step(make_mpc, name)
 
@@ -163,7 +164,7 @@ def test_batch_larger_than_slot_count_round_robins():
     P[:, :4] = X0
     P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(0.0).master
     Xi = np.zeros((37, ps.n_opt_x))
-    Xi[:, :ps.off_u].reshape(37, -1, 4)[:] = X0[:, None, :]
+    Xi[:, :ps.off_z].reshape(37, -1, 4)[:] = X0[:, None, :]
     r = mpc.S.solve_batch(Xi, mpc._lb_opt_x.master, mpc._ub_opt_x.master, mpc._nlp_cons_lb, mpc._nlp_cons_ub, P)
     assert r["stats"]["success"].all(), r["stats"][r["stats"]["success"] == 0]
     nlp = pc.oracle_nlp("batch_reactor")
@@ -262,3 +263,18 @@ def test_closed_loop_reproduces_the_reference_trajectory(name):
     from test_closed_loop import CL_RTOL, run_closed_loop
     wu, wx = run_closed_loop(make_mpc, name)
     assert wu < CL_RTOL and wx < CL_RTOL
+
+
+def test_code_objects_are_the_ones_the_unedited_templates_lower_to():
+    """tests/golden/template_hashes.json holds the model hashes that the reference's UN-EDITED template_model.py /
+    template_mpc.py lower to (tools/template_hashes.py, checked against the templates themselves by
+    tests/test_reference_templates.py where /root/reference exists).  The in-repo cases lower to the same text, so the golden
+    replays / oracle comparisons of this module run exactly the templates' gfx950 code objects - on the real GPU."""
+    import json
+    import os
+    pinned = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "template_hashes.json")))
+    assert len(pinned) >= 10
+    for name, h in pinned.items():
+        mpc = make_mpc(name)
+        assert mpc.model_hash == h, (name, mpc.model_hash, h)
+        assert os.path.basename(os.path.dirname(mpc.S.code_object_path)) == h

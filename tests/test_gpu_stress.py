@@ -26,7 +26,7 @@ def _batch_reactor_inputs(mpc, n=37):
     P[:, :4] = X0
     P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(0.0).master
     Xi = np.zeros((n, ps.n_opt_x))
-    Xi[:, :ps.off_u].reshape(n, -1, 4)[:] = X0[:, None, :]
+    Xi[:, :ps.off_z].reshape(n, -1, 4)[:] = X0[:, None, :]
     return Xi, P
 
 

@@ -16,12 +16,13 @@ def make_mpc(name, **kw):
 
 
 @pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 3), ("industrial_poly", 2),
-                                        ("rotating_masses", 5)])
+                                        ("rotating_masses", 5), ("oscillating_masses_dae", 5), ("dip", 2)])
 def test_golden_replay(name, steps):
     pc.check_golden_replay(make_mpc, name, steps)
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly", "rotating_masses"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "industrial_poly", "rotating_masses",
+                                  "oscillating_masses_dae"])
 def test_newton_direction_matches_sparse_kkt_solve(name):
     pc.check_newton_step(make_mpc, name)
 

@@ -23,6 +23,7 @@ from parity_common import golden_opt_p
 from oracle import ipm
 from oracle.models import CASES
 from oracle.nlp import OracleNLP, collocation_coeffs
+from oracle.nlp_dae import OracleNLPDae
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 U_RTOL = 1e-6
@@ -32,7 +33,8 @@ _cache = {}
 
 def _nlp(name):
     if name not in _cache:
-        _cache[name] = OracleNLP(CASES[name]())
+        case = CASES[name]()
+        _cache[name] = (OracleNLPDae if case.get("z") else OracleNLP)(case)      # (`_z`: the general interval function, oracle/nlp_dae.py)
     return _cache[name]
 
 
@@ -44,7 +46,8 @@ def test_radau_coefficients():
     assert np.allclose(D, [0, 0, 1])
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly", "rotating_masses"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly", "rotating_masses",
+                                  "oscillating_masses_dae", "dip"])
 def test_golden_point_is_kkt_point_of_restated_nlp(name):
     nlp = _nlp(name)
     g = np.load(os.path.join(GOLD, name + ".npz"))
@@ -66,7 +69,7 @@ def test_golden_point_is_kkt_point_of_restated_nlp(name):
 
 
 @pytest.mark.parametrize("name,steps", [("oscillating_masses", 5), ("batch_reactor", 5), ("CSTR", 3),
-                                        ("industrial_poly", 2), ("rotating_masses", 5)])
+                                        ("industrial_poly", 2), ("rotating_masses", 5), ("oscillating_masses_dae", 5)])
 def test_open_loop_replay_matches_golden_u(name, steps):
     case = CASES[name]()
     nlp = _nlp(name)
@@ -108,3 +111,23 @@ def test_with_ipopts_damping_of_one_sided_bounds_the_oracle_reproduces_the_golde
         LG = g["mpc._lam_g_num"][k]
         assert np.max(np.abs(r["lam_g"] - LG)) < 1e-9 * max(1.0, np.max(np.abs(LG)))
         xg = r["x"]
+
+
+def test_dae_oracle_reproduces_the_discrete_dae_golden_to_rounding():
+    """The general interval function (oracle/nlp_dae.py: algebraic rows, `_z` block) on the reference's discrete DAE example:
+    primal solution incl. the algebraic states and every multiplier at 1e-12 (measured 1e-16) - and the same problem with the
+    algebraic state substituted (oracle/nlp.py) gives the same inputs."""
+    nlp, ode = _nlp("oscillating_masses_dae"), _nlp("oscillating_masses")
+    g = np.load(os.path.join(GOLD, "oscillating_masses_dae.npz"))
+    xg, u_prev = nlp.initial_guess(g["mpc._x"][0]), np.zeros(1)
+    for k in range(5):
+        p = nlp.opt_p(g["mpc._x"][k], u_prev)
+        assert np.array_equal(p, g["mpc.opt_p_num"][k])
+        r = ipm.solve(nlp, xg, p)
+        assert r["stats"]["success"]
+        assert np.max(np.abs(r["x"] * nlp.scaling_vector() - g["mpc._opt_x_num"][k])) < 1e-12
+        assert np.max(np.abs(r["lam_g"] - g["mpc._lam_g_num"][k])) < 1e-12
+        if k == 0:
+            ro = ipm.solve(ode, ode.initial_guess(g["mpc._x"][0]), ode.opt_p(g["mpc._x"][0], u_prev))
+            assert np.max(np.abs(ode.u0_of(ro["x"]) - nlp.u0_of(r["x"]))) < 1e-9
+        xg, u_prev = r["x"], g["mpc._u"][k]

@@ -1,8 +1,14 @@
 """The reference's shipped template_model.py / template_mpc.py run UN-EDITED on this backend.
 
 Needs /root/reference (present in the build container, absent on the GPU box -> skipped there).
-The files are imported from where they lie; nothing is copied.  Each template must give the same structure, bounds, scalings and model function values as the
-in-repo restatement in do_mpc_amd/examples/, and on the host emulation the un-edited template reproduces the golden u0.
+The files are imported from where they lie; nothing is copied.  Each template must give the same structure, bounds and
+scalings as the in-repo restatement in do_mpc_amd/examples/ AND THE SAME GENERATED HEADER, character by character (the
+restatements associate their operations like the templates; the expression DAG is hash-consed, so equal expressions give
+equal text): the model hash - the name of the gfx950 code object - is the same, i.e. every `-m gpu` parity test of an
+in-repo case (tests/test_gpu_parity.py: golden replays, Newton directions, oracle solves) runs EXACTLY the code object that
+the un-edited template lowers to.  The hashes are pinned in tests/golden/template_hashes.json, which the GPU box checks
+against the code objects it runs (tests/test_gpu_parity.py::test_code_objects_are_the_ones_the_unedited_templates_lower_to).
+On the host emulation the un-edited templates also reproduce the golden u0 / closed loops directly.
 """
 import importlib.util
 import os
@@ -21,8 +27,11 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree n
 DIRS = {"industrial_poly": "industrial_poly", "CSTR": "CSTR", "batch_reactor": "batch_reactor",
         "oscillating_masses": "oscillating_masses_discrete", "kinematic_bicycle": "kinematic_bicycle_model",
         "dynamic_bicycle": "dynamic_bicycle_model", "kite": "kite",
-        "rotating_masses": "rotating_oscillating_masses_mhe_mpc"}
+        "rotating_masses": "rotating_oscillating_masses_mhe_mpc",
+        "oscillating_masses_dae": "oscillating_masses_discrete_dae", "dip": "double_inverted_pendulum"}       # DAE models (`_z`)
 MPC_ARGS = {"kite": (10.0, 6.0)}           # template_mpc(model, w_ref, E_0, h_min=100): main.py draws them at random
+MODEL_ARGS = {"dip": ([{"x": 0., "y": 0.6, "r": 0.3}],)}     # template_model(obstacles): the obstacle of testing/test_DIP.py:70-73
+HASHES = os.path.join(os.path.dirname(__file__), "golden", "template_hashes.json")
 
 
 def _load(path, name):
@@ -45,9 +54,13 @@ def test_unedited_templates_lower_to_the_same_model(name, compat):
     tm = _load(os.path.join(d, "template_model.py"), f"ref_{name}_template_model")
     tc = _load(os.path.join(d, "template_mpc.py"), f"ref_{name}_template_mpc")
     with hostemu.patched():
-        ref_model = tm.template_model()
+        ref_model = tm.template_model(*MODEL_ARGS.get(name, ()))
         ref_mpc = tc.template_mpc(ref_model, *MPC_ARGS.get(name, ()), silence_solver=True)
         ours = CASES[name].build_mpc(CASES[name].build_model())
+    # the un-edited template and the in-repo restatement lower to the same text -> the same gfx950 code object
+    assert ref_mpc.generated_header == ours.generated_header
+    import json
+    assert json.load(open(HASHES))[name] == ref_mpc.model_hash, "re-run tools/template_hashes.py"
     assert ref_mpc.structure.n_opt_x == ours.structure.n_opt_x
     assert ref_mpc.structure.n_g == ours.structure.n_g
     assert np.array_equal(ref_mpc._lb_opt_x.master, ours._lb_opt_x.master)
@@ -61,7 +74,7 @@ def test_unedited_templates_lower_to_the_same_model(name, compat):
         x = ours._x0.master * 0 + CASES[name].X0 * (1 + 0.01 * rng.standard_normal(m1.n_x)) + 0.01 * rng.standard_normal(m1.n_x)
         u = 0.5 * (ours._u_lb.master + ours._u_ub.master) * (1 + 0.01 * rng.standard_normal(m1.n_u))
         p = ours.p_fun(0.0).master[:m1.n_p]
-        z = np.zeros(0)
+        z = 0.1 * rng.standard_normal(m1.n_z)
         args = (x, u, z, np.zeros(m1.n_tvp), p, np.zeros(m1.n_w))
         r1 = m1._rhs_fun.eval(*args)[0]
         r2 = m2._rhs_fun.eval(*args)[0]

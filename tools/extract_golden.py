@@ -33,6 +33,8 @@ CASES = {
     "oscillating_masses": "results_oscillatingMasses.pkl",
     "rotating_masses": "results_rotatingMasses.pkl",
     "triple_tank": "results_triple_tank_ekf.pkl",
+    "oscillating_masses_dae": "results_oscillatingMasses_dae.pkl",      # DAE models (`_z`): discrete, and
+    "dip": "results_dip.pkl",                                           # double inverted pendulum (collocation, nl_cons, tvp)
 }
 
 

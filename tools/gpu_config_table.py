@@ -58,7 +58,7 @@ def run(label, name, kw, Bs, out):
         P[:, ps.p_off_tvp:ps.p_off_p] = mpc.tvp_fun(0.0).master
         P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(0.0).master
         Xi = np.zeros((B, ps.n_opt_x))
-        Xi[:, :ps.off_u].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
+        Xi[:, :ps.off_z].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
         tXi = torch.from_numpy(Xi).to(dev)
         tP = torch.from_numpy(P).to(dev)
         tX = torch.empty((B, ps.n_opt_x), dtype=torch.float64, device=dev)

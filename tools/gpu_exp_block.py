@@ -28,7 +28,7 @@ for block in blocks:
         P[:, :ps.nx] = X0
         P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(0.0).master
         Xi = np.zeros((B, ps.n_opt_x))
-        Xi[:, :ps.off_u].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
+        Xi[:, :ps.off_z].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
         t = {k: torch.from_numpy(v).to(dev) for k, v in dict(x0=Xi, p=P, lbx=mpc._lb_opt_x.master, ubx=mpc._ub_opt_x.master,
                                                              lbg=mpc._nlp_cons_lb, ubg=mpc._nlp_cons_ub).items()}
         tX = torch.empty((B, ps.n_opt_x), dtype=torch.float64, device=dev)

@@ -26,7 +26,7 @@ for rep in range(reps):
     ps = mpc.structure
     P = np.tile(mpc.opt_p_num.master, (37, 1)); P[:, :4] = X0
     P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(0.0).master
-    Xi = np.zeros((37, ps.n_opt_x)); Xi[:, :ps.off_u].reshape(37, -1, 4)[:] = X0[:, None, :]
+    Xi = np.zeros((37, ps.n_opt_x)); Xi[:, :ps.off_z].reshape(37, -1, 4)[:] = X0[:, None, :]
     r = mpc.S.solve_batch(Xi, mpc._lb_opt_x.master, mpc._ub_opt_x.master, mpc._nlp_cons_lb, mpc._nlp_cons_ub, P)
     st = r["stats"]
     bad = np.where(st["success"] == 0)[0]
