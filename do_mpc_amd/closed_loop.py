@@ -52,11 +52,33 @@ class BatchClosedLoop:
         self.p_plant = t(simulator.p_fun(ts).master if m.n_p else np.zeros(1))
         self.tvp_plant = t(simulator.tvp_fun(ts).master if m.n_tvp else np.zeros(1))
         self.k = 0
+        # loop time: the reference's per-sample loop re-evaluates tvp_fun / p_fun at the current time in EVERY make_step of
+        # controller and plant (_mpc.py:1009-1019, simulator.py:790-800) - a set-point staircase over the horizon moves along
+        self.t_mpc0, self.t_sim0 = t0, ts
+        self.dt_mpc, self.dt_sim = float(mpc.settings.t_step), float(simulator.settings.t_step)
+        self._p_row = P[0].copy()                             # host image of one opt_p row (its _tvp / _p blocks are re-uploaded)
+
+    def _refresh_time_varying(self):
+        """_tvp / _p of controller and plant at the current loop time -> device (same values for every sample of the batch)"""
+        ps, m, torch = self.ps, self.sim.model, self.torch
+        tm, ts = self.t_mpc0 + self.k * self.dt_mpc, self.t_sim0 + self.k * self.dt_sim
+        if ps.ntvp or ps.np_:
+            row = self._p_row
+            row[ps.p_off_tvp:ps.p_off_p] = self.mpc.tvp_fun(tm).master
+            row[ps.p_off_p:ps.p_off_uprev] = self.mpc.p_fun(tm).master
+            blk = torch.from_numpy(row[ps.p_off_tvp:ps.p_off_uprev].copy()).to(self.dev)
+            self.P[:, ps.p_off_tvp:ps.p_off_uprev] = blk
+        if m.n_p:
+            self.p_plant.copy_(torch.from_numpy(np.ascontiguousarray(self.sim.p_fun(ts).master, dtype=np.float64)).to(self.dev))
+        if m.n_tvp:
+            self.tvp_plant.copy_(torch.from_numpy(np.ascontiguousarray(self.sim.tvp_fun(ts).master, dtype=np.float64)).to(self.dev))
 
     def step(self) -> dict:
         """one control step of all B loops; returns the solver statistics (numpy record array) and the plant status"""
         torch, ps, S = self.torch, self.ps, self.mpc.S
         stream = torch.cuda.current_stream()
+        if self.k > 0:
+            self._refresh_time_varying()
         S.solve_batch_device(self.B, self.guess.data_ptr(), self.lbx.data_ptr(), self.ubx.data_ptr(), self.lbg.data_ptr(),
                              self.ubg.data_ptr(), self.P.data_ptr(), self.sol.data_ptr(), 0, 0, 0, self.f.data_ptr(),
                              self.stats.data_ptr(), stream=stream.cuda_stream)

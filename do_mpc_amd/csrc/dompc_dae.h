@@ -314,7 +314,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     const double t = Ld[DG_GL + c] + Ld[DG_GF + c];
     Q.gf[gi] = Ld[DG_GF + c];
     Q.rd[gi] = t - zl_ + zu_;
-    Ld[DG_RW + c] = t + bar_grad(xv, l, u, mu);
+    Ld[DG_RW + c] = t + bar_grad(xv, l, u, mu, !(Q.soc & 2));
     Ld[DG_BB + c] = bar_grad(xv, l, u, 1.0);
     Ld[DG_SG + c] = sigma_of(xv, l, u, zl_, zu_) + Q.dsw;
   }

@@ -609,11 +609,14 @@ DOMPC_DEV inline double one_sided(double l, double u) {
   const bool hl = l > -INFINITY, hu = u < INFINITY;
   return (hl && !hu) ? 1.0 : ((hu && !hl) ? -1.0 : 0.0);
 }
-DOMPC_DEV inline double bar_grad(double x, double l, double u, double mu) {
+// `damp` = false: without the damping term - the least-squares multiplier estimate of the starting point (solve_problem,
+// Prob::soc bit 1) uses the barrier gradient at mu = 1 with the bounds one unit away as a stand-in for -z_L + z_U = -1 + 1;
+// IPOPT's estimate has no damping term
+DOMPC_DEV inline double bar_grad(double x, double l, double u, double mu, bool damp = true) {
   double g = 0.0;
   if (l > -INFINITY) g -= mu * fast_rcp(x - l);
   if (u < INFINITY) g += mu * fast_rcp(u - x);
-  if (KAPPA_D != 0.0) g += KAPPA_D * mu * one_sided(l, u);
+  if (KAPPA_D != 0.0 && damp) g += KAPPA_D * mu * one_sided(l, u);
   return g;
 }
 DOMPC_DEV inline double sigma_of(double x, double l, double u, double zl, double zu) {
@@ -1369,7 +1372,7 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
         const double xv = vx[q][0], l = vx[q][1], u = vx[q][2], zl_ = vx[q][3], zu_ = vx[q][4];
         Q.gf[gi] = 0.0;
         Q.rd[gi] = t - zl_ + zu_;
-        Ld[EL_RW + cx] = t + bar_grad(xv, l, u, mu);
+        Ld[EL_RW + cx] = t + bar_grad(xv, l, u, mu, !(Q.soc & 2));
         Ld[EL_BB + cx] = bar_grad(xv, l, u, 1.0);
         Ld[EL_SG + cx] = sigma_of(xv, l, u, zl_, zu_);
       } else if (cx < R + NA) {
@@ -1386,7 +1389,7 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
       else { xv = Q.x[gi]; l = Q.lb[gi]; u = Q.ub[gi]; zl_ = Q.zl[gi]; zu_ = Q.zu[gi]; }
       Q.gf[gi] = 0.0;
       Q.rd[gi] = t - zl_ + zu_;
-      Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu);
+      Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu, !(Q.soc & 2));
       Ld[EL_BB + col] = bar_grad(xv, l, u, 1.0);
       Ld[EL_SG + col] = sigma_of(xv, l, u, zl_, zu_);
     }
@@ -1788,7 +1791,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         const double xv = Q.x[gi], l = Q.lb[gi], u = Q.ub[gi];
         Q.gf[gi] = 0.0;
         Q.rd[gi] = t - Q.zl[gi] + Q.zu[gi];
-        Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu);
+        Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu, !(Q.soc & 2));
         Ld[EL_BB + col] = bar_grad(xv, l, u, 1.0);
         Ld[EL_SG + col] = sigma_of(xv, l, u, Q.zl[gi], Q.zu[gi]);
       }
@@ -2436,7 +2439,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
       gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - upv);                    // xv = u_n of the same input
     } else {
       dg = sigma_of(xv, lo, hi, zlo, zhi) + delta;
-      gv = bar_grad(xv, lo, hi, mu);
+      gv = bar_grad(xv, lo, hi, mu, !(Q.soc & 2));
       if (i < NX) gv += (A.node_in_edge[n] >= 0) ? -R.pv[v][5] : R.pv[v][5];
       else if (i < NA + NU) {
         dg += 2.0 * rwh * DOMPC_RTERM[i - NA];
@@ -2747,7 +2750,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
           gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - up[i - NX]);
         } else {
           dg = sigma_of(xv, lo, hi, Q.zl[g], Q.zu[g]) + delta;
-          gv = bar_grad(xv, lo, hi, mu);
+          gv = bar_grad(xv, lo, hi, mu, !(Q.soc & 2));
           if (i < NX) gv += (ie >= 0) ? -Q.lam[A.edge_row0[ie] + NW + i] : Q.lam[i];
           else if (i < NA + NU) {
             dg += 2.0 * rwh * DOMPC_RTERM[i - NA];
@@ -3012,7 +3015,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
       } else {
         double v = 0.0;
         if (i < NX)
-          v = S_[ES_MG + i] - Q.lam[A.edge_row0[ie] + NW + i] + bar_grad(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], mu);
+          v = S_[ES_MG + i] - Q.lam[A.edge_row0[ie] + NW + i] + bar_grad(Q.x[xo + i], Q.lb[xo + i], Q.ub[xo + i], mu, !(Q.soc & 2));
         Nd[ND_PV + i] = v;
       }
     }
@@ -3484,7 +3487,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
     const int g = A.dummy_idx[d];
     const double sg = sigma_of(Q.x[g], Q.lb[g], Q.ub[g], Q.zl[g], Q.zu[g]) + delta;
-    Q.dx[g] = sg > 0.0 ? -bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu) / sg : 0.0;
+    Q.dx[g] = sg > 0.0 ? -bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu, !(Q.soc & 2)) / sg : 0.0;
   }
   T.sync();
   // (the bound multiplier steps dz are functions of (x, bound, z, dx, mu): formed where they are used - dz_lo / dz_up)

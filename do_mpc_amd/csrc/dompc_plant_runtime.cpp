@@ -177,12 +177,19 @@ extern "C" int dompc_plant_step_batch(dompc_plant* h, int32_t B, const double* x
   PHIP(h, hipSetDevice(d.device));
 #endif
   if (B > h->cap) {
-    for (void* q : {(void*)h->s_x, (void*)h->s_u, (void*)h->s_tvp, (void*)h->s_p, (void*)h->s_w, (void*)h->s_v, (void*)h->s_xn,
-                    (void*)h->s_y, (void*)h->s_st})
+    //  the staging buffers are invalid from here until ALL new ones exist: capacity 0 and null pointers first, so
+    // that a failed allocation cannot leave a later call (B <= old capacity) copying into freed device memory
+    h->cap = 0;
+    void** slots[] = {(void**)&h->s_x, (void**)&h->s_u, (void**)&h->s_tvp, (void**)&h->s_p, (void**)&h->s_w, (void**)&h->s_v,
+                      (void**)&h->s_xn, (void**)&h->s_y, (void**)&h->s_st};
+    for (void** sp : slots) {
+      void* q = *sp;
+      *sp = nullptr;
       if (q) {
         for (size_t i = 0; i < h->allocs.size(); ++i)
           if (h->allocs[i] == q) { h->allocs.erase(h->allocs.begin() + i); pfree(q); break; }
       }
+    }
     const size_t n = (size_t)B * sizeof(double);
     if (palloc(h, (void**)&h->s_x, n * d.nx) || palloc(h, (void**)&h->s_u, n * d.nu) || palloc(h, (void**)&h->s_tvp, n * d.ntvp) ||
         palloc(h, (void**)&h->s_p, n * d.np) || palloc(h, (void**)&h->s_w, n * d.nw) || palloc(h, (void**)&h->s_v, n * d.nv) ||

@@ -112,7 +112,7 @@ __device__ inline Val leaf(const Prob& Q, int n, double mu, double delta, int la
   const int jj = j < NX ? j : 0;
   const double xv = Q.x[xo + jj], lo = Q.lb[xo + jj], hi = Q.ub[xo + jj];
   const double dg = sigma_of(xv, lo, hi, Q.zl[xo + jj], Q.zu[xo + jj]) + delta;
-  const double gv = (j < NX) ? S_[ES_MG + jj] - Q.lam[A.edge_row0[ie] + NW + jj] + bar_grad(xv, lo, hi, mu) : 0.0;
+  const double gv = (j < NX) ? S_[ES_MG + jj] - Q.lam[A.edge_row0[ie] + NW + jj] + bar_grad(xv, lo, hi, mu, !(Q.soc & 2)) : 0.0;
   Val V;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -222,7 +222,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       gv = -2.0 * rw * tab_sel(DOMPC_RTERM, iu) * (xv - upv);
     } else {
       dg = sigma_of(xv, lo, hi, R.zlo, R.zhi) + delta;
-      gv = bar_grad(xv, lo, hi, mu);
+      gv = bar_grad(xv, lo, hi, mu, !(Q.soc & 2));
       if (jj < NX) {
         gv += (ie >= 0) ? -R.nu : R.nu;
       } else if (is_eps) {

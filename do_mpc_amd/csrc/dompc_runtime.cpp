@@ -121,14 +121,19 @@ static int dev_sync_watchdog(dompc_handle* h, hipStream_t st) {
     if (q == hipSuccess) break;
     if (q != hipErrorNotReady) { h->error = std::string("hipStreamQuery: ") + hipGetErrorString(q); return 1; }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (!raised && dt > h->watchdog_s) { __atomic_store_n(h->abort_word, 1, __ATOMIC_RELEASE); raised = true; }
+    if (!raised && dt > h->watchdog_s) { int32_t z_ = 0; __atomic_compare_exchange_n(h->abort_word, &z_, 1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); raised = true; }   // (0 -> 1: a user's request, 2, is left alone)
     if (raised && dt > h->watchdog_s + 30.0) {
       h->error = "watchdog: the solver kernel did not finish and did not react to the stop request";
       return 1;
     }
     if (dt > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(dt > 0.2 ? 500 : 20));
   }
-  if (raised) __atomic_store_n(h->abort_word, 0, __ATOMIC_RELEASE);
+  if (raised) {
+    // only the watchdog's own request is withdrawn (compare-exchange 1 -> 0: a user's dompc_abort(h, 1) writes 2 and stays -
+    // it is documented as sticky until dompc_abort(h, 0)); the caller learns about it through the error string and status 6
+    int32_t expect = 1;
+    __atomic_compare_exchange_n(h->abort_word, &expect, 0, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+  }
   return 0;
 }
 static int dev_zero(dompc_handle* h, void* p, size_t bytes, hipStream_t s) {
@@ -155,7 +160,7 @@ static int dev_sync(dompc_handle*) { return 0; }
 
 extern "C" int dompc_abort(dompc_handle* h, int32_t stop) {
   if (!h || !h->abort_word) return 1;
-  __atomic_store_n(h->abort_word, stop ? 1 : 0, __ATOMIC_RELEASE);
+  __atomic_store_n(h->abort_word, stop ? 2 : 0, __ATOMIC_RELEASE);     // (2: the user's request - the watchdog only withdraws its own 1)
   return 0;
 }
 
@@ -388,7 +393,8 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     const int resident = h->block_auto ? (max_batch >= BATCH_ONE_WAVE ? h->slots64 : h->slots256) : resident_at(h->block);
     h->n_slots = d.n_slots > 0 ? d.n_slots : (max_batch < resident ? max_batch : resident);
   }
-  if (const char* se = getenv("DOMPC_SLOTS")) h->n_slots = atoi(se);
+  if (const char* se = getenv("DOMPC_SLOTS")) { const int v = atoi(se); if (v >= 1) h->n_slots = v; }      // (tuning aid; nonsense values are ignored)
+  if (h->n_slots < 1) h->n_slots = 1;
 #ifdef DOMPC_HOST_EMU
   h->n_slots = 1;
 #endif
@@ -611,7 +617,7 @@ static int serve_exchanges(dompc_handle* h, hipStream_t st) {
   while (true) {
     if ((++polls & 0xfffu) == 0) {               // watchdog (see dev_sync_watchdog)
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (!raised && dt > h->watchdog_s) { __atomic_store_n(h->abort_word, 1, __ATOMIC_RELEASE); raised = true; }
+      if (!raised && dt > h->watchdog_s) { int32_t z_ = 0; __atomic_compare_exchange_n(h->abort_word, &z_, 1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); raised = true; }   // (0 -> 1: a user's request, 2, is left alone)
       if (raised && dt > h->watchdog_s + 30.0) { h->error = "watchdog: the sharded solve did not finish"; rc = 1; break; }
     }
     const uint32_t r = w[0];
@@ -636,7 +642,7 @@ static int serve_exchanges(dompc_handle* h, hipStream_t st) {
     }
   }
   hipEventDestroy(done);
-  if (raised) __atomic_store_n(h->abort_word, 0, __ATOMIC_RELEASE);
+  if (raised) { int32_t expect = 1; __atomic_compare_exchange_n(h->abort_word, &expect, 0, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); }
   return rc;
 }
 #endif

@@ -71,15 +71,21 @@ def closed_loop_samples(mpc, simulator, plan: Dict[str, np.ndarray], trajectory_
     u = np.zeros((n, T, UP.shape[1]))
     up = np.zeros((n, T, UP.shape[1]))
     ok = np.zeros((n, T), bool)
+    iters = np.zeros((n, T), int)
     x[:, 0], cur_up = X0, UP.copy()
+    import time as _time
+    t_start = _time.perf_counter()
     for k in range(T):
         r = loop.step()
         up[:, k] = cur_up
         u[:, k], x[:, k + 1] = r["u0"], r["x"]
         ok[:, k] = (r["stats"]["success"] != 0) & (r["plant_status"] == 0)
+        iters[:, k] = r["stats"]["iter_count"]
         cur_up = r["u0"]
+    t_loop = _time.perf_counter() - t_start
     n_valid = np.where(ok.all(axis=1), T, np.argmin(ok, axis=1))
-    return {"id": np.asarray(plan.get("id", np.arange(n))), "x": x, "u": u, "u_prev": up, "success": ok, "n_valid": n_valid}
+    return {"id": np.asarray(plan.get("id", np.arange(n))), "x": x, "u": u, "u_prev": up, "success": ok, "n_valid": n_valid,
+            "iter_count": iters, "t_loop": t_loop}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -529,12 +535,28 @@ class AMPCSampler:
             out = []
             for lo, hi in self._chunks(len(x0)):
                 r = closed_loop_samples(mpc, self.simulator, {"x0": x0[lo:hi], "u_prev": u_prev[lo:hi]}, T)
+                share = r["t_loop"] / max(hi - lo, 1)       # wall time of the batched loop, per sample
                 out += [{"x": r["x"][i], "u": r["u"][i], "u_prev": r["u_prev"][i], "success": r["success"][i],
-                         "n_valid": int(r["n_valid"][i])} for i in range(hi - lo)]
+                         "n_valid": int(r["n_valid"][i]), "iter_count": r["iter_count"][i], "t": share} for i in range(hi - lo)]
             return out
 
-        self._run(run_rows, {"x_traj": lambda x: x["x"][:max(x["n_valid"], 1)], "u_prev_traj": lambda x: x["u_prev"][:max(x["n_valid"], 1)],
-                             "u0_traj": lambda x: x["u"][:max(x["n_valid"], 1)], "status": lambda x: x["n_valid"] == len(x["u"]),
+        # the reference's table (_ampc_sampler.py:497-503): u0 = simulator.data['_u'], x0 = simulator.data['_x'] (one row per
+        # executed plant step), u_prev = u_prev_total (trajectory_length rows, zero behind the step that failed), status /
+        # iter_count of the last solve, t_make_step / t_wall of the sample; `n_valid` is an extra column
+        def executed(x):
+            return x["n_valid"]                                 # plant steps that were executed (the failed solve's step is not)
+
+        def u_prev_total(x):
+            out = np.zeros_like(x["u_prev"])
+            n = min(x["n_valid"] + 1, len(out))                # (assigned before every solve, including the one that failed)
+            out[:n] = x["u_prev"][:n]
+            return out
+
+        def last(x):
+            return min(x["n_valid"], len(x["u"]) - 1)
+        self._run(run_rows, {"u0": lambda x: x["u"][:executed(x)], "x0": lambda x: x["x"][:executed(x)], "u_prev": u_prev_total,
+                             "status": lambda x: bool(x["n_valid"] == len(x["u"])), "t_make_step": lambda x: x["t"],
+                             "t_wall": lambda x: x["t"], "iter_count": lambda x: int(x["iter_count"][last(x)]),
                              "n_valid": lambda x: x["n_valid"]})
 
     def default_sampling(self):

@@ -191,6 +191,14 @@ class HipIpmSolver:
                 setattr(d.opts, f, type(getattr(d.opts, f))(v))
             elif k == "dompc.obj_scaling":
                 d.opts.obj_scaling = int(v)
+            elif k == "ipopt.kappa_d":
+                # IPOPT's damping of one-sided bounds is a compile-time constant of the kernels (DOMPC_KAPPA_D = 1e-5, IPOPT's
+                # default; -DDOMPC_KAPPA_D=... through DOMPC_DEFS builds another value): say so instead of ignoring it silently
+                if float(v) != 1e-5:
+                    import warnings
+                    warnings.warn("ipopt.kappa_d = %r is not applied: the kernels are built with kappa_d = 1e-5 "
+                                  "(DOMPC_DEFS='DOMPC_KAPPA_D=%r' builds a code object with this value)" % (v, v))
+                self.ignored_options.append(k)
             else:
                 self.ignored_options.append(k)     # print levels, linear solver, ... : no meaning here
         self.options = d.opts

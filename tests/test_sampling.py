@@ -206,7 +206,8 @@ def test_ampc_sampler_writes_the_reference_files_from_batched_solves(tmp_path, m
                 u0 = one.make_step(x[i, k])
                 x[i, k + 1] = np.asarray(simulator.make_step(u0)).ravel()
                 u[i, k], cur = u0.ravel(), u0.ravel()
-        return {"x": x, "u": u, "u_prev": up, "success": np.ones((n, T), bool), "n_valid": np.full(n, T)}
+        return {"x": x, "u": u, "u_prev": up, "success": np.ones((n, T), bool), "n_valid": np.full(n, T),
+                "iter_count": np.full((n, T), 7), "t_loop": 0.5}
 
     monkeypatch.setattr(sampling, "closed_loop_samples", per_sample_loops)
     c = sampling.AMPCSampler(mpc, simulator=sim)
@@ -215,7 +216,10 @@ def test_ampc_sampler_writes_the_reference_files_from_batched_solves(tmp_path, m
     c.setup()
     c.default_sampling()
     dfc = pd.read_pickle(os.path.join(tmp_path, "cl", "data_cl_all.pkl"))
-    assert len(dfc) == 3 and dfc["x_traj"][0].shape[1] == 4 and dfc["u0_traj"][0].shape[1] == 1
-    assert dfc["status"].all() and all(t.shape == (2, 1) for t in dfc["u0_traj"])
-    assert np.array_equal(dfc["u_prev_traj"][1][1], dfc["u0_traj"][1][0])       # the previous input of step 1 = the input of step 0
-    assert np.array_equal(dfc["x_traj"][2][0], dfc["x0"][2].ravel())
+    # the reference's column names (_ampc_sampler.py:497-503): its approximate-MPC trainer reads x0 / u_prev / u0
+    assert set(dfc.columns) >= {"id", "x0", "u0", "u_prev", "status", "t_make_step", "t_wall", "iter_count", "n_valid"}
+    assert len(dfc) == 3 and dfc["x0"][0].shape == (2, 4) and dfc["u0"][0].shape == (2, 1) and dfc["u_prev"][0].shape == (2, 1)
+    assert dfc["status"].all() and (dfc["iter_count"] == 7).all() and (dfc["t_make_step"] > 0).all()
+    assert np.array_equal(dfc["u_prev"][1][1], dfc["u0"][1][0])       # the previous input of step 1 = the input of step 0
+    plan = pd.read_pickle(os.path.join(tmp_path, "cl", "sampling_plan_cl.pkl"))
+    assert np.array_equal(dfc["x0"][2][0], np.asarray(plan[2]["x0"]).ravel())     # trajectory starts at the plan's x0

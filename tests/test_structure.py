@@ -57,4 +57,14 @@ def test_unsupported_couplings_are_refused_loudly():
     with pytest.raises(NotImplementedError):
         build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=5, n_comb=3, n_robust=1, discrete=False, open_loop=True)
     with pytest.raises(NotImplementedError):
-        build_structure(nx=2, nu=1, nz=1, np_=1, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=5, n_comb=1, n_robust=0, discrete=False)
+        build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=1, ns=1, deg=2, ni=1, N=5, n_comb=1, n_robust=0, discrete=False, single_slack=True)
+
+
+def test_algebraic_states_layout():
+    """`_z[k][s][c]` follows `_x` (_mpc.py:1126-1134); an interval's block has M (nx + nz) rows (optimizer.py:943-983), a
+    discrete DAE nz; the sizes of the reference's DAE goldens (results_dip.pkl: 4330 / 4506, results_oscillatingMasses_dae: 67 / 60)"""
+    dip = build_structure(nx=6, nu=1, nz=3, np_=2, ntvp=1, ne=3, ns=0, deg=3, ni=1, N=100, n_comb=9, n_robust=0, discrete=False)
+    assert (dip.n_opt_x, dip.n_g, dip.n_opt_p) == (4330, 4506, 126) and dip.rows_block == 36 and dip.MZ == 4
+    assert dip.tables["edge_z_off"][0] == dip.off_z and dip.tables["edge_z_off"][1] == dip.off_z + 4 * 3
+    osc = build_structure(nx=4, nu=1, nz=4, np_=0, ntvp=0, ne=0, ns=0, deg=0, ni=1, N=7, n_comb=1, n_robust=0, discrete=True)
+    assert (osc.n_opt_x, osc.n_g) == (67, 60) and osc.rows_block == 4 and osc.MZ == 1
