@@ -24,7 +24,7 @@ from typing import Callable, Dict, List, Optional, Union
 import numpy as np
 
 from . import lowering, sym
-from .model import Model
+from .model import Model, VarGroup
 from .solver import HipIpmSolver
 from .structs import Entry, Layout, NumStruct
 from .structure import build_structure, lagrange_collocation
@@ -170,6 +170,11 @@ class MPC:
         self._x_scaling, self._u_scaling = m._x(1.0), m._u(1.0)
         self._z_scaling, self._p_scaling = m._z(1.0), m._p(1.0)
         self.rterm_factor = m._u(0.0)
+        # symbols of the previous input for user-defined rterm expressions (_mpc.py: `self.u_prev`, same names and shapes as _u)
+        self.u_prev = VarGroup("_u_prev")
+        for nm in m._u.names:
+            self.u_prev.add(nm, sym.SX.sym("u_prev_" + nm, *m._u.vars[nm].shape))
+        self.rterm_expr = None
         self._x0, self._u0, self._z0, self._t0 = m._x(0.0), m._u(0.0), m._z(0.0), np.array([0.0])
         self.nl_cons_list: List[dict] = []
         self.slack_vars_list: List[dict] = []
@@ -294,8 +299,13 @@ class MPC:
     def set_rterm(self, rterm=None, **kwargs) -> None:
         assert self.flags["setup"] is False, "Cannot call .set_rterm after .setup()."
         if rterm is not None:
-            raise NotImplementedError("structured HIP backend: a user-defined rterm expression is not lowered yet; "
-                                      "use the quadratic form set_rterm(u_name=weight, ...)")
+            # user-defined penalty (_mpc.py:593-677): scalar expression in _x, _u, mpc.u_prev, _tvp, _p
+            rterm = sym.SX(rterm)
+            assert rterm.shape == (1, 1), "rterm must have shape=(1,1). You have {}".format(rterm.shape)
+            self.rterm_expr = rterm
+            self.flags["rterm_fun"] = True
+            self.flags["set_rterm"] = True
+            return
         for key, val in kwargs.items():
             assert key in self.model._u.keys(), \
                 "Must pass keywords that refer to input names defined in model. Valid is: {}. You have: {}".format(self.model._u.keys(), key)
@@ -547,7 +557,9 @@ class MPC:
             sx=self._x_scaling.master, su=self._u_scaling.master, rterm=self.rterm_factor.master,
             h_scale=h, deg=s.collocation_deg, ni=s.collocation_ni, discrete=discrete, C=C, D=D,
             name=type(m).__name__, nz=m.n_z, z_sym=m._z.cat.nodes(), alg=alg, sz=self._z_scaling.master,
-            sp=self._p_scaling.master)
+            sp=self._p_scaling.master,
+            rterm_expr=(self.rterm_expr.nodes()[0] if self.rterm_expr is not None else None),
+            uprev_sym=self.u_prev.cat.nodes())
 
     def create_nlp(self, _solver_factory=None) -> None:
         assert self.flags["prepare_nlp"], "call prepare_nlp() first"
@@ -576,6 +588,8 @@ class MPC:
         every rank builds the same MPC, calls shard_tree(rank, world) once after setup() and then make_step(x0) with
         identical x0; the ranks meet in torch.distributed all-reduces (backend nccl = RCCL) during the solve."""
         assert self.flags["setup"] is True, "MPC was not setup yet. Please call MPC.setup()."
+        if self.rterm_expr is not None:
+            raise NotImplementedError("structured HIP backend: tree sharding with a user-defined rterm expression")
         if not getattr(self.S, "shard_capable", False):
             # the sharding-aware kernel is a second code object of the same model (build.py): swap the solver
             ctor = dict(self.S._ctor)

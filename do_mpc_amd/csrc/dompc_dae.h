@@ -46,7 +46,8 @@ constexpr int DG_RE = DG_EY + NX * NA;                        // NX: end-point r
 constexpr int DG_JDW = DG_RE + NX;                            // NE x NW
 constexpr int DG_JDY = DG_JDW + NE * NW;                      // NE x NA
 constexpr int DG_CK = DG_JDY + NE * NA;                       // NW: pivot column copy
-constexpr int DG_SIZE = DG_CK + NW;
+constexpr int DG_RT = DG_CK + NW;                             // user-defined rterm of the edge (RT_LEN)
+constexpr int DG_SIZE = DG_RT + RT_LEN;
 // forward pass
 constexpr int DF_DY = 0, DF_DNU = DF_DY + NA, DF_DW = DF_DNU + NX, DF_RHS = DF_DW + NW, DF_DYD = DF_RHS + NW, DF_SIZE = DF_DYD + NE1;
 
@@ -167,6 +168,7 @@ DOMPC_DEV inline double dae_edge_f(const Prob& Q, int e, const double* xv, const
   }
   double obj = om * dompc_lterm_f(xn, un, zb + (MZ - 1) * NZ, tvp, pp);
   if (k == A.N - 1) obj += om * dompc_mterm_f(xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
+  if (RT_CUSTOM) obj += edge_rterm_f(Q, e, xv);
   if (NE > 0) {
     double d[NE1];
     dompc_nlcons_f(xn, un, zb, tvp, pp, d);
@@ -273,9 +275,16 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     if (v < NW) Ld[DG_JDW + q * NW + v] = jv;
     else Ld[DG_JDY + q * NA + (v - NW)] = jv;
   }
-  // objective gradient: stage cost over (x_n, u, z_last)
+  // objective gradient: stage cost over (x_n, u, z_last); user-defined rterm over (x_n, u) (its u_prev part and its Hessian go
+  // to the node level through the record)
   for (int i = lane; i < NAV; i += GS) Ld[DG_GF + vtarget_stage(i, true)] = om * mo[MO_LT + 1 + i];
+  if (RT_CUSTOM && lane == 0) edge_rterm_eval(Q, e, Ld + DG_RT);
   T.gsync();
+  if (RT_CUSTOM) {
+    for (int a = lane; a < NA; a += GS) Ld[DG_GF + NW + a] += Ld[DG_RT + 1 + a];
+    edge_rterm_store(Ld + DG_RT, S_, lane, GS);
+    T.gsync();
+  }
   // ---- Hessian of the edge's Lagrangian terms over [w | y]: one function after the other (their supports overlap)
   for (int p = 0; p < NPT_E; ++p) {
     const int el = (M == 0) ? 0 : p / (DEG + 1), jj = (M == 0) ? 0 : p % (DEG + 1);
@@ -411,6 +420,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
   if (lane == 0) {
     double obj = om * mo[MO_LT];
     if (last_stage) obj += om * mo[MO_MT];
+    if (RT_CUSTOM) obj += Ld[DG_RT];
     if (NE > 0) {
       const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
       for (int i = 0; i < NE; ++i) {

@@ -49,6 +49,11 @@ constexpr int NYT = NA + NV;         // node quadratic: (x, u_prev, u, eps)
 constexpr int MZ = NZ > 0 ? (M > 0 ? M : 1) : 0;     // z slots of an edge
 constexpr int NWX = M * NX;          // collocation states of an edge (incl. the xkf slot)
 constexpr int NW = NWX + MZ * NZ;    // eliminated unknowns of an edge = rows of its square constraint block; order: x slots, then z slots
+// user-defined input penalty rterm(x, u, u_prev, tvp, p) (_mpc.py:593-677, 1263-1269) instead of the quadratic default:
+// value / gradient / Hessian over r = (x, u, u_prev) per edge (lowering.py: dompc_rterm)
+constexpr bool RT_CUSTOM = DOMPC_RTERM_CUSTOM != 0;
+constexpr int NR = NA + NU, NR_T = NR * (NR + 1) / 2;
+constexpr int RT_LEN = RT_CUSTOM ? 1 + NR + NR_T : 0;
 constexpr int NF = NX + NZ;          // outputs of the dynamics at a point: [h f / sx ; alg]
 constexpr int NAV = NA + NZ;         // inputs of a point function: (x, u, z)
 constexpr int NCOLL = NI * DEG;      // collocation points evaluated per edge
@@ -103,7 +108,9 @@ constexpr int ES_SIGS = ES_MH + NX * NX;     // NE
 constexpr int ES_RDN = ES_SIGS + NE;         // d - s
 constexpr int ES_RSN = ES_RDN + NE;          // -yd - mu/(s-sl) + mu/(su-s)
 constexpr int ES_OBJ = ES_RSN + NE;
-constexpr int ES_SIZE = ((ES_OBJ + 1 + 7) / 8) * 8;
+constexpr int ES_RTUP = ES_OBJ + 1;                          // user-defined rterm: sf*omega * d rterm / d u_prev          (NU)
+constexpr int ES_RTH = ES_RTUP + (RT_CUSTOM ? NU : 0);       // ... and its Hessian over (x, u, u_prev), packed             (NR_T)
+constexpr int ES_SIZE = ((ES_RTH + (RT_CUSTOM ? NR_T : 0) + 7) / 8) * 8;
 
 // per-edge model-output record (global): results of the lowered model functions at the current iterate,
 // written by the thread-parallel evaluation phase and copied into LDS by the edge groups
@@ -626,6 +633,9 @@ DOMPC_DEV inline double sigma_of(double x, double l, double u, double zl, double
   return sg;
 }
 
+DOMPC_DEV inline double edge_rterm_f(const Prob& Q, int e, const double* xv);      // (user-defined rterm, defined below)
+DOMPC_DEV inline void edge_rterm_eval(const Prob& Q, int e, ldsd* dst);
+DOMPC_DEV inline void edge_rterm_store(const ldsd* src, double* S_, int lane, int GS);
 #include "dompc_dae.h"       // edge phases of models with algebraic states (dense path)
 
 // ================================================================================================
@@ -670,6 +680,7 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
   }
   double obj = om * dompc_lterm_f(xn, un, nullptr, tvp, pp);
   if (k == A.N - 1) obj += om * dompc_mterm_f(xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
+  if (RT_CUSTOM) obj += edge_rterm_f(Q, e, xv);
   if (NE > 0) {
     double d[NE1];
     dompc_nlcons_f(xn, un, nullptr, tvp, pp, d);
@@ -698,6 +709,7 @@ DOMPC_DEV inline double node_rweight(const Prob& Q, int n) {
 }
 DOMPC_DEV inline double node_rterm_f(const Prob& Q, int n, const double* xv) {
   const KArgs& A = *Q.A;
+  if (RT_CUSTOM) return 0.0;                       // (user-defined rterm: part of the edges' objective shares, edge_rterm_f)
   if (A.node_u_off[n] < 0) return 0.0;
   double tmp[NU];
   const double* up = uprev_ptr(Q, n, xv, tmp);
@@ -706,6 +718,35 @@ DOMPC_DEV inline double node_rterm_f(const Prob& Q, int n, const double* xv) {
   double v = 0.0;
   for (int i = 0; i < NU; ++i) v += rw * DOMPC_RTERM[i] * (u[i] - up[i]) * (u[i] - up[i]);
   return v;
+}
+
+// user-defined rterm of edge e (parent node n): omega_k rterm(x_n, u_n, u_prev, tvp_k, p_e) with x, u unscaled inside the
+// generated function and u_prev SCALED (_mpc.py:1263-1269)
+DOMPC_DEV inline double edge_rterm_f(const Prob& Q, int e, const double* xv) {
+  const KArgs& A = *Q.A;
+  const int n = A.edge_parent[e];
+  double tmp[NU > 0 ? NU : 1];
+  const double* up = uprev_ptr(Q, n, xv, tmp);
+  return A.edge_omega[e] * Q.sf * dompc_rterm_f(xv + A.node_x_off[n], xv + A.node_u_off[n], up, Q.P + A.p_off_tvp + A.edge_level[e] * NTVP,
+                                                Q.P + A.p_off_p + A.edge_pidx[e] * NP);
+}
+// ... with derivatives, weighted (Hessian: zero in the least-squares multiplier solve, Prob::soc bit 1), by ONE lane into
+// dst[0 .. RT_LEN): value, gradient over (x, u, u_prev), packed Hessian
+DOMPC_DEV inline void edge_rterm_eval(const Prob& Q, int e, ldsd* dst) {
+  const KArgs& A = *Q.A;
+  const int n = A.edge_parent[e];
+  const double om = A.edge_omega[e] * Q.sf, omh = (Q.soc & 2) ? 0.0 : om;
+  double tmp[NU > 0 ? NU : 1], out[RT_LEN > 0 ? RT_LEN : 1];
+  const double* up = uprev_ptr(Q, n, Q.x, tmp);
+  dompc_rterm(Q.x + A.node_x_off[n], Q.x + A.node_u_off[n], up, Q.P + A.p_off_tvp + A.edge_level[e] * NTVP,
+              Q.P + A.p_off_p + A.edge_pidx[e] * NP, out, out + 1, out + 1 + NR);
+  for (int i = 0; i < 1 + NR; ++i) dst[i] = om * out[i];
+  for (int i = 0; i < NR_T; ++i) dst[1 + NR + i] = omh * out[1 + NR + i];
+}
+// record part: d/d u_prev and the Hessian go to the node level (assembly, Riccati recursion)
+DOMPC_DEV inline void edge_rterm_store(const ldsd* src, double* S_, int lane, int GS) {
+  for (int i = lane; i < NU; i += GS) S_[ES_RTUP + i] = src[1 + NA + i];
+  for (int i = lane; i < NR_T; i += GS) S_[ES_RTH + i] = src[1 + NR + i];
 }
 
 // ================================================================================================
@@ -746,10 +787,13 @@ constexpr int EL_HP = EL_QT;                                           // staged
 constexpr int EL_NHP = TILE_CONDENSE ? 0 : (NI * DEG > 2 ? NI * DEG : 2);
 constexpr int EL_PV = EL_QT + EL_NHP * NA * NA;                        // pivot rows (NW)
 constexpr int EL_RY = EL_PV + NW;                                      // G_y' lambda (NA), completed in phase 7
+constexpr int EL_RT = EL_RY + NA;                                      // user-defined rterm of the edge: value, gradient, Hessian (RT_LEN)
 #ifndef DOMPC_R16_NL
 #define DOMPC_R16_NL 1                 // matrix-core Riccati pass also for models with nl_cons rows / slack variables
 #endif
-constexpr bool R16_ENABLED = (NYT <= 16) && (NV <= 4) && (DOMPC_R16_NL ? (NE <= 4) : (NE == 0 && NS == 0)) && (DOMPC_SHARD == 0);   // dompc_riccati16.h (device)
+// (a user-defined rterm expression is not supported by tree sharding: the cut-parent update keeps the analytic form;
+//  MPC.shard_tree refuses it)
+constexpr bool R16_ENABLED = (NYT <= 16) && (NV <= 4) && (DOMPC_R16_NL ? (NE <= 4) : (NE == 0 && NS == 0)) && (DOMPC_SHARD == 0) && !RT_CUSTOM;   // dompc_riccati16.h (device)
 #ifndef DOMPC_HOST_EMU
 constexpr bool RB_IN_LDS = !R16_ENABLED;
 #else
@@ -771,7 +815,7 @@ constexpr bool MO_LDS = false;
 #endif
 constexpr int MO_IMG = MO_COMPACT ? MO_SIZE : 0;
 constexpr int MOC_STAGE = MO_LDS ? ((MOC_SIZE + 127) / 128) * 128 : 0;
-constexpr int EL_MOS = ((EL_RY + NA + 1) / 2) * 2;                        // image (16-byte aligned)
+constexpr int EL_MOS = ((EL_RT + RT_LEN + 1) / 2) * 2;                    // image (16-byte aligned)
 constexpr int EL_MOC = EL_MOS + MO_IMG;                                   // staging buffer of the compact record
 // forward pass, same condition: the per-edge record [G_cc^-1 | Sigma_w | r_w] and the compact model-output record of the
 // NEXT edge are staged behind the step vectors while the current edge is computed; the image follows
@@ -782,7 +826,7 @@ constexpr int RF_IMG = RF_MOC + MOC_STAGE;
 constexpr int MOH_H0 = NX + NX * NA;                                    // offset of the packed Hessian inside a point record
 // DAE models: dense edge working set of eval_edge_dae (= dae::DG_SIZE, asserted in sweep())
 constexpr int DAE_NEED = NZ > 0 ? NW * (2 * NW + NA + 1) + (NW + NA) * (NW + NA) + (NW + NA) * (NA + 2) + 2 * (NW + NA) + 3 * NW
-                                      + NX * NW + NX * NA + NX + NE * NW + NE * NA + NW : 0;
+                                      + NX * NW + NX * NA + NX + NE * NW + NE * NA + NW + RT_LEN : 0;
 constexpr int EL_SIZE = ((el_max(el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)), DAE_NEED) + 7) / 8) * 8;
 
 // ---- dense image of a compact model-output record
@@ -2129,16 +2173,22 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   }
   T.gsync();
   // ---- phase 7: stage cost / terminal cost / nl_cons shares (few values: lanes 0..)
+  if (RT_CUSTOM) {                         // user-defined rterm: one lane evaluates it (value, gradient, Hessian) into LDS
+    if (act && lane == 0) edge_rterm_eval(Q, e, Ld + EL_RT);
+    T.gsync();
+    if (act) edge_rterm_store(Ld + EL_RT, S_, lane, GS);
+  }
   if (act) {
     if constexpr (PF) {                    // (operands in registers since the first load batch of the edge)
 #pragma unroll
       for (int q = 0; q < APL; ++q) {
         const int a = lane + q * GS;
         if (a < NA) {
-          double r = Ld[EL_RY + a] + om * pf_ltg[q];
+          const double grt = RT_CUSTOM ? (double)Ld[EL_RT + 1 + a] : 0.0;       // d rterm / d (x_n, u_n)
+          double r = Ld[EL_RY + a] + om * pf_ltg[q] + grt;
           if (NE > 0)
             for (int i = 0; i < NE; ++i) r += MOV(MO_NL + NE + i * NA + a) * yd[i];
-          S_[ES_GFY + a] = om * pf_ltg[q];
+          S_[ES_GFY + a] = om * pf_ltg[q] + grt;
           S_[ES_RY + a] = r;
           S_[ES_QV + a] = Ld[EL_QV + a] + r;
           S_[ES_QVB + a] = Ld[EL_QV + NA + a];
@@ -2158,10 +2208,11 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
     } else {
     for (int a = lane; a < NA; a += GS) {
-      double r = Ld[EL_RY + a] + om * mo[MO_LT + 1 + a];
+      const double grt = RT_CUSTOM ? (double)Ld[EL_RT + 1 + a] : 0.0;           // d rterm / d (x_n, u_n)
+      double r = Ld[EL_RY + a] + om * mo[MO_LT + 1 + a] + grt;
       if (NE > 0)
         for (int i = 0; i < NE; ++i) r += mo[MO_NL + NE + i * NA + a] * yd[i];
-      S_[ES_GFY + a] = om * mo[MO_LT + 1 + a];
+      S_[ES_GFY + a] = om * mo[MO_LT + 1 + a] + grt;
       S_[ES_RY + a] = r;
       S_[ES_QV + a] = Ld[EL_QV + a] + r;
       S_[ES_QVB + a] = Ld[EL_QV + NA + a];
@@ -2174,6 +2225,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     if (lane == 0) {
       double obj = PF ? om * pf_lt0 : om * mo[MO_LT];
       if (k == A.N - 1) obj += PF ? om * pf_mt0 : om * mo[MO_MT];
+      if (RT_CUSTOM) obj += Ld[EL_RT];
       if (NE > 0) {
         const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
         for (int i = 0; i < NE; ++i) {
@@ -2235,9 +2287,16 @@ DOMPC_DEV inline void assemble_children(const Prob& Q, int n, bool counted_only,
     for (int i = 0; i < NU; ++i) { out[2 * NX + i] += S_[ES_GFY + NX + i]; out[2 * NX + NU + i] += S_[ES_RY + NX + i]; }
     const int cn = A.edge_child[e];
     if (A.node_u_off[cn] >= 0) {                   // the child's rterm w.r.t. its u_prev = u_n
-      const double rwc = node_rweight(Q, cn);
-      for (int i = 0; i < NU; ++i)
-        out[2 * NX + 2 * NU + i] -= 2.0 * rwc * DOMPC_RTERM[i] * (Q.x[A.node_u_off[cn] + i] - Q.x[uo + i]);
+      if (RT_CUSTOM) {                             // (user-defined: one term per edge leaving the child)
+        for (int j2 = 0; j2 < A.node_child_count[cn]; ++j2) {
+          const double* S2 = Q.ES(A.node_child_start[cn] + j2);
+          for (int i = 0; i < NU; ++i) out[2 * NX + 2 * NU + i] += S2[ES_RTUP + i];
+        }
+      } else {
+        const double rwc = node_rweight(Q, cn);
+        for (int i = 0; i < NU; ++i)
+          out[2 * NX + 2 * NU + i] -= 2.0 * rwc * DOMPC_RTERM[i] * (Q.x[A.node_u_off[cn] + i] - Q.x[uo + i]);
+      }
     }
     if (NS > 0) {
       const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
@@ -2269,7 +2328,7 @@ DOMPC_DEV inline void assemble_finish(const Prob& Q, int n, const double* in) {
   const double* up = uprev_ptr(Q, n, Q.x, tmp);
   const double rw = node_rweight(Q, n);
   for (int i = 0; i < NU; ++i) {
-    const double rt = 2.0 * rw * DOMPC_RTERM[i] * (Q.x[uo + i] - up[i]) + in[2 * NX + 2 * NU + i];
+    const double rt = (RT_CUSTOM ? 0.0 : 2.0 * rw * DOMPC_RTERM[i] * (Q.x[uo + i] - up[i])) + in[2 * NX + 2 * NU + i];    // (user-defined rterm: own share is in the edges' GFY / RY)
     Q.gf[uo + i] = in[2 * NX + i] + rt;
     Q.rd[uo + i] = in[2 * NX + NU + i] + rt - Q.zl[uo + i] + Q.zu[uo + i];
   }
@@ -2435,15 +2494,22 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
     const double upv = R.pv[v][6];
     double dg, gv;
     if (is_up) {
-      dg = 2.0 * rwh * DOMPC_RTERM[i - NX];
-      gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - upv);                    // xv = u_n of the same input
+      if (RT_CUSTOM) {       // user-defined rterm: d / d u_prev of every edge leaving the node (its Hessian joins the matrix below)
+        dg = 0.0; gv = 0.0;
+        for (int c = 0; c < cc; ++c) gv += Q.ES(cs + c)[ES_RTUP + (i - NX)];
+      } else {
+        dg = 2.0 * rwh * DOMPC_RTERM[i - NX];
+        gv = -2.0 * rw * DOMPC_RTERM[i - NX] * (xv - upv);                    // xv = u_n of the same input
+      }
     } else {
       dg = sigma_of(xv, lo, hi, zlo, zhi) + delta;
       gv = bar_grad(xv, lo, hi, mu, !(Q.soc & 2));
       if (i < NX) gv += (A.node_in_edge[n] >= 0) ? -R.pv[v][5] : R.pv[v][5];
       else if (i < NA + NU) {
-        dg += 2.0 * rwh * DOMPC_RTERM[i - NA];
-        gv += 2.0 * rw * DOMPC_RTERM[i - NA] * (xv - upv);
+        if (!RT_CUSTOM) {    // (user-defined: the (x, u) part of the gradient is in the edges' r_y)
+          dg += 2.0 * rwh * DOMPC_RTERM[i - NA];
+          gv += 2.0 * rw * DOMPC_RTERM[i - NA] * (xv - upv);
+        }
       } else {
         gv += cc * Q.sf * DOMPC_EPS_PEN[i - NA - NU];
       }
@@ -2516,8 +2582,16 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
       const int i = it / NYT, j = it % NYT;
       double v = qacc[q];
       if (i == j) v += Ld[RB_QF + i * NYT + i];
-      else if (i >= NX && i < NA && j == i + NU) v -= 2.0 * rwh * DOMPC_RTERM[i - NX];
-      else if (j >= NX && j < NA && i == j + NU) v -= 2.0 * rwh * DOMPC_RTERM[j - NX];
+      if (RT_CUSTOM) {
+        // Hessian of the user-defined rterm over (x, u, u_prev), summed over the edges leaving the node
+        auto rz = [](int t) { return t < NX ? t : (t < NA ? NA + (t - NX) : (t < NA + NU ? NX + (t - NA) : -1)); };
+        const int ri = rz(i), rj = rz(j);
+        if (ri >= 0 && rj >= 0)
+          for (int c = 0; c < cc; ++c) v += Q.ES(cs + c)[ES_RTH + symi(ri, rj, NR)];
+      } else if (i != j) {
+        if (i >= NX && i < NA && j == i + NU) v -= 2.0 * rwh * DOMPC_RTERM[i - NX];
+        else if (j >= NX && j < NA && i == j + NU) v -= 2.0 * rwh * DOMPC_RTERM[j - NX];
+      }
       Ld[RB_QO + it] = v;
     }
   }

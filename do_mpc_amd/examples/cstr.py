@@ -40,7 +40,7 @@ def build_model(symvar_type="SX"):
     return mdl
 
 
-def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_deg=2, track_sign=1.0, **overrides):
+def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_deg=2, track_sign=1.0, custom_rterm=None, **overrides):
     """track_sign=-1 turns the tracking cost into a concave one (C_b is pushed AWAY from 0.6, bounded only by the
     box): a non-convex test problem whose reduced Hessian needs inertia correction in most iterations."""
     mpc = MPC(model)
@@ -60,7 +60,10 @@ def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_
     mpc.scaling["_u", "F"] = 100
     track = track_sign * (model.x["C_b"] - 0.6) ** 2
     mpc.set_objective(mterm=track, lterm=track)
-    mpc.set_rterm(F=0.1, Q_dot=1e-3)
+    if custom_rterm is not None:          # user-defined input penalty: expression in model.x / model.u / mpc.u_prev (_mpc.py:593-677)
+        mpc.set_rterm(rterm=(RTERM_VARIANTS[custom_rterm] if isinstance(custom_rterm, str) else custom_rterm)(model, mpc))
+    else:
+        mpc.set_rterm(F=0.1, Q_dot=1e-3)
     for k, v in dict(C_a=0.1, C_b=0.1, T_R=50, T_K=50).items():
         mpc.bounds["lower", "_x", k] = v
     for k, v in dict(C_a=2, C_b=2, T_K=140).items():
@@ -76,3 +79,19 @@ def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_
 
 
 X0 = np.array([0.8, 0.5, 134.14, 130.0])
+
+
+def _rterm_default_as_expression(model, mpc):
+    """the default quadratic penalty written as an expression: r' (u / u_scaling - u_prev)^2 - unscaled u, SCALED u_prev
+    (the reference evaluates a user-defined rterm that way, _mpc.py:1263-1269)"""
+    return 0.1 * (model.u["F"] / 100.0 - mpc.u_prev["F"]) ** 2 + 1e-3 * (model.u["Q_dot"] / 2000.0 - mpc.u_prev["Q_dot"]) ** 2
+
+
+def _rterm_custom(model, mpc):
+    """not a quadratic, depends on a state: weights the input move by the reactor temperature, quartic term, input coupling"""
+    dF = model.u["F"] / 100.0 - mpc.u_prev["F"]
+    dQ = model.u["Q_dot"] / 2000.0 - mpc.u_prev["Q_dot"]
+    return 0.1 * (1 + 0.01 * model.x["T_R"]) * dF ** 2 + 1e-3 * dQ ** 2 + 0.5 * dF ** 4 + 0.02 * dF * dQ
+
+
+RTERM_VARIANTS = {"default_as_expression": _rterm_default_as_expression, "custom": _rterm_custom}

@@ -25,7 +25,7 @@ def build_model(symvar_type="SX"):
     return mdl
 
 
-def build_mpc(model, silence_solver=True, n_horizon=7, **overrides):
+def build_mpc(model, silence_solver=True, n_horizon=7, custom_rterm=None, **overrides):
     mpc = MPC(model)
     st = mpc.settings
     st.n_robust, st.n_horizon, st.t_step = 0, n_horizon, 0.5
@@ -35,7 +35,10 @@ def build_mpc(model, silence_solver=True, n_horizon=7, **overrides):
     if silence_solver:
         st.supress_ipopt_output()
     mpc.set_objective(mterm=model.aux["cost"], lterm=model.aux["cost"])
-    mpc.set_rterm(u=1e-4)
+    if custom_rterm is not None:          # user-defined input penalty: expression in model.x / model.u / mpc.u_prev (_mpc.py:593-677)
+        mpc.set_rterm(rterm=(RTERM_VARIANTS[custom_rterm] if isinstance(custom_rterm, str) else custom_rterm)(model, mpc))
+    else:
+        mpc.set_rterm(u=1e-4)
     limit = np.array([[4.0], [10.0], [4.0], [10.0]])
     mpc.bounds["lower", "_x", "x"] = -limit
     mpc.bounds["upper", "_x", "x"] = limit
@@ -51,3 +54,11 @@ def _x0():
 
 
 X0 = _x0()
+
+
+def _rterm_custom(model, mpc):
+    du = model.u["u"] - mpc.u_prev["u"]
+    return 1e-2 * du ** 2 + 1e-1 * du ** 4 + 1e-2 * model.x["x", 0] ** 2 * du ** 2
+
+
+RTERM_VARIANTS = {"custom": _rterm_custom}

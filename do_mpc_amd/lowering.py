@@ -46,7 +46,7 @@ def _sym_hessian_upper(L: sym.Node, v: List[sym.Node]):
 
 def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, mterm, nl_exprs,
                 nl_slack_index, eps_penalty, sx, su, rterm, h_scale, deg, ni, discrete, C, D,
-                name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None) -> str:
+                name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None, rterm_expr=None, uprev_sym=()) -> str:
     """Return the text of the generated header.
 
     x_sym/u_sym/z_sym/tvp_sym/p_sym: lists of sym.Node (the model's own symbols, unscaled).
@@ -54,6 +54,10 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     lterm, mterm: Node; nl_exprs: list[ne] of Node (without the -eps part).
     sp: `_p` scaling - the reference multiplies the parameters by it in the model equations only (optimizer.py:808-812:
     `_p_unscaled = _p * _p_scaling` feeds rhs / alg; cost and nl_cons read opt_p['_p'] as it is, _mpc.py:1230-1275).
+
+    rterm_expr / uprev_sym: user-defined input penalty rterm(x, u, u_prev, z, tvp, p) (_mpc.py:593-677) and the symbols of
+    `mpc.u_prev`; None: the default quadratic form with the weights `rterm`.  The reference evaluates it with UNSCALED x, u, z
+    and the SCALED previous input (_mpc.py:1263-1269: `opt_p['_u_prev'] / u_scaling` resp. `opt_x['_u', k-1, ...]`).
 
     Point functions take the stage variables as v = (x (nx), u (nu), z (nz)): for a model without algebraic states
     that is the (x, u) of the optimised kernels, with them the algebraic block is appended (dense DAE path of the kernels).
@@ -68,11 +72,12 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     xs, bx = _bind("xs", nx)
     us, bu = _bind("us", nu)
     zs, bz = _bind("zs", nz)
+    ups, bup = _bind("ups", nu)
     tv, bt = _bind("tvp", ntvp)
     pp, bp = _bind("pp", np_)
     lam, bl = _bind("lam", max(nf, ne, 1))
     binds = {}
-    for b in (bx, bu, bz, bt, bp, bl):
+    for b in (bx, bu, bz, bup, bt, bp, bl):
         binds.update(b)
     # unscaled model symbols -> scaled kernel symbols
     mapping = {}
@@ -86,6 +91,8 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         mapping[s.idx] = tv[i]
     for i, s in enumerate(p_sym):
         mapping[s.idx] = pp[i]
+    for i, s in enumerate(uprev_sym):
+        mapping[s.idx] = ups[i]          # (scaled, as the reference passes it)
     mapping_dyn = dict(mapping)      # model equations: parameters times their scaling
     for i, s in enumerate(p_sym):
         if sp[i] != 1.0:
@@ -197,6 +204,27 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         parts.append(f"DOMPC_FN void dompc_nlcons_f({sig_dyn_args}, double* d) {{}}\n")
         parts.append(f"DOMPC_FN void dompc_nlcons({sig_dyn_args}, const double* lam, double* d, double* Jd, double* H) {{}}\n")
 
+    # user-defined input penalty: value, gradient and Hessian over (x, u, u_prev); z-dependence is not lowered
+    if rterm_expr is not None:
+        rt = scaled([rterm_expr])[0]
+        if sym.depends_on([rt], zs):
+            raise NotImplementedError("structured HIP backend: an rterm expression that depends on algebraic states")
+        vr = xs + us + ups
+        nr = len(vr)
+        gr, Hr = _sym_hessian_upper(rt, vr)
+        sig_r = "const double* xs, const double* us, const double* ups, const double* tvp, const double* pp"
+        parts.append(emit_fn(f"double dompc_rterm_f({sig_r})", [("double val", rt)]).replace("\n}\n", "\n  return val;\n}\n"))
+        outs = [("val[0]", rt)] + [(f"g[{i}]", gr[i]) for i in range(nr)] + hess_outs(Hr, nr)
+        parts.append(emit_fn(f"void dompc_rterm({sig_r}, double* val, double* g, double* H)", outs))
+        compact("RT", f"void dompc_rterm_c({sig_r}, double* o)", list(enumerate([rt] + list(gr[:nr]) + packed(Hr, nr))))
+    else:
+        sig_r = "const double* xs, const double* us, const double* ups, const double* tvp, const double* pp"
+        parts.append(f"DOMPC_FN double dompc_rterm_f({sig_r}) {{ return 0.0; }}\n")
+        parts.append(f"DOMPC_FN void dompc_rterm({sig_r}, double* val, double* g, double* H) {{}}\n")
+        parts.append(f"DOMPC_FN void dompc_rterm_c({sig_r}, double* o) {{}}\n")
+        tables += ["#define DOMPC_RT_NV 0", "#define DOMPC_RT_NC 0", _fmt_array("DOMPC_RT_VIDX", [], "int"),
+                   _fmt_array("DOMPC_RT_CIDX", [], "int"), _fmt_array("DOMPC_RT_CVAL", [])]
+
     M = 0 if discrete else (deg + 1) * ni
     hdr = [
         "// GENERATED by do_mpc_amd/lowering.py - do not edit.",
@@ -205,6 +233,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         f"#define DOMPC_MODEL_NAME \"{name}\"",
         f"#define DOMPC_NX {nx}", f"#define DOMPC_NU {nu}", f"#define DOMPC_NP {np_}",
         f"#define DOMPC_NTVP {ntvp}", f"#define DOMPC_NE {ne}", f"#define DOMPC_NS {ns}", f"#define DOMPC_NZ {nz}",
+        f"#define DOMPC_RTERM_CUSTOM {1 if rterm_expr is not None else 0}",
         f"#define DOMPC_DEG {deg if not discrete else 0}", f"#define DOMPC_NI {ni if not discrete else 1}",
         f"#define DOMPC_M {M}", f"#define DOMPC_DISCRETE {1 if discrete else 0}",
         _fmt_array("DOMPC_C", np.asarray(C).reshape(-1) if not discrete else [0.0]),

@@ -181,6 +181,19 @@ class OracleNLP:
         self.G = _Lam(G, args)
         self.JG = _Lam([sp.diff(g, a) for g in G for a in v], args)
         self.HG = _Lam([sp.diff(g, a, b) for g in G for a in v for b in v], args)
+        # user-defined input penalty rterm(x, u, u_prev, tvp, p) (_mpc.py:593-677): evaluated with unscaled x, u and the SCALED
+        # previous input (_mpc.py:1263-1269); case key "rterm_expr" over the symbols case["u_prev"]
+        self.R = None
+        if c.get("rterm_expr") is not None:
+            ups = sp.symbols(f"ups0:{nu}")
+            subr = dict(sub)
+            subr.update({c["u_prev"][i]: ups[i] for i in range(nu)})
+            Rx = sp.sympify(c["rterm_expr"]).subs(subr)
+            vr = list(xs) + list(us) + list(ups)
+            argr = vr + list(ps)
+            self.R = _Lam([Rx], argr)
+            self.gR = _Lam([sp.diff(Rx, a) for a in vr], argr)
+            self.HR = _Lam([sp.diff(Rx, a, b) for a in vr for b in vr], argr)
         self.aux = {k: sp.lambdify(list(c["x"]) + list(c["u"]) + list(c["p"]) + list(c.get("tvp", ())), e, "numpy")
                     for k, e in c["aux"].items()}
 
@@ -302,12 +315,19 @@ class OracleNLP:
         obj += np.sum((w * self.Mt(colm, n)[0])[last])
         up = p[self.p_off_uprev:] / self.su
         Uprev = np.where((self.col_uprev >= 0)[:, None], x[np.maximum(self.col_uprev, 0)[:, None] + np.arange(self.nu)], up)
-        obj += np.sum(w[:, None] * np.asarray(self.case["rterm"]) * (U - Uprev) ** 2)
+        if self.R is not None:
+            obj += np.sum(w * self.R(self._r_args(Xp, U, Uprev, P), n)[0])
+        else:
+            obj += np.sum(w[:, None] * np.asarray(self.case["rterm"]) * (U - Uprev) ** 2)
         if self.n_slack:
             Eps = x[self.col_eps[:, None] + np.arange(self.n_slack)]
             pen = np.array([self.nl[i]["penalty"] for i in self.soft])
             obj += np.sum(Eps * pen)
         return float(obj)
+
+    def _r_args(self, Xp, U, Uprev, P):
+        return [Xp[:, i] for i in range(self.nx)] + [U[:, i] for i in range(self.nu)] + [Uprev[:, i] for i in range(self.nu)] + \
+               [P[:, i] for i in range(self.nq)]
 
     def grad(self, x, p):
         nx, nu = self.nx, self.nu
@@ -328,9 +348,15 @@ class OracleNLP:
         up = p[self.p_off_uprev:] / self.su
         has = self.col_uprev >= 0
         Uprev = np.where(has[:, None], x[np.maximum(self.col_uprev, 0)[:, None] + np.arange(nu)], up)
-        d = 2.0 * w[:, None] * np.asarray(self.case["rterm"]) * (U - Uprev)
-        np.add.at(g, self.col_u[:, None] + np.arange(nu), d)
-        np.add.at(g, self.col_uprev[has][:, None] + np.arange(nu), -d[has])
+        if self.R is not None:
+            gr = (self.gR(self._r_args(Xp, U, Uprev, P), n) * w).T                   # (E, nx + 2 nu)
+            np.add.at(g, self.col_xpar[:, None] + np.arange(nx), gr[:, :nx])
+            np.add.at(g, self.col_u[:, None] + np.arange(nu), gr[:, nx:nx + nu])
+            np.add.at(g, self.col_uprev[has][:, None] + np.arange(nu), gr[has][:, nx + nu:])
+        else:
+            d = 2.0 * w[:, None] * np.asarray(self.case["rterm"]) * (U - Uprev)
+            np.add.at(g, self.col_u[:, None] + np.arange(nu), d)
+            np.add.at(g, self.col_uprev[has][:, None] + np.arange(nu), -d[has])
         if self.n_slack:
             pen = np.array([self.nl[i]["penalty"] for i in self.soft])
             np.add.at(g, self.col_eps[:, None] + np.arange(self.n_slack), np.tile(pen, (self.E, 1)))
@@ -458,14 +484,25 @@ class OracleNLP:
         cc = self.col_xch[:, None] + np.arange(nx)
         put_block(cc[last], cc[last], HM[last])
         # rterm
-        r2 = 2.0 * w[:, None] * np.asarray(self.case["rterm"])
         ucols = self.col_u[:, None] + np.arange(nu)
-        R.append(ucols.ravel()); Cc.append(ucols.ravel()); V.append(r2.ravel())
         has = self.col_uprev >= 0
         pcols = self.col_uprev[has][:, None] + np.arange(nu)
-        R.append(pcols.ravel()); Cc.append(pcols.ravel()); V.append(r2[has].ravel())
-        R.append(ucols[has].ravel()); Cc.append(pcols.ravel()); V.append(-r2[has].ravel())
-        R.append(pcols.ravel()); Cc.append(ucols[has].ravel()); V.append(-r2[has].ravel())
+        if self.R is not None:
+            U = x[ucols]
+            up = p[self.p_off_uprev:] / self.su
+            Uprev = np.where(has[:, None], x[np.maximum(self.col_uprev, 0)[:, None] + np.arange(nu)], up)
+            HR = self.HR(self._r_args(Xp, U, Uprev, P), n).T.reshape(E, nx + 2 * nu, nx + 2 * nu) * w[:, None, None]
+            xu = np.concatenate([self.col_xpar[:, None] + np.arange(nx), ucols], axis=1)       # (x, u) part on every edge
+            put_block(xu, xu, HR[:, :nx + nu, :nx + nu])
+            put_block(xu[has], pcols, HR[has][:, :nx + nu, nx + nu:])                         # u_prev is a variable for k > 0
+            put_block(pcols, xu[has], HR[has][:, nx + nu:, :nx + nu])
+            put_block(pcols, pcols, HR[has][:, nx + nu:, nx + nu:])
+        else:
+            r2 = 2.0 * w[:, None] * np.asarray(self.case["rterm"])
+            R.append(ucols.ravel()); Cc.append(ucols.ravel()); V.append(r2.ravel())
+            R.append(pcols.ravel()); Cc.append(pcols.ravel()); V.append(r2[has].ravel())
+            R.append(ucols[has].ravel()); Cc.append(pcols.ravel()); V.append(-r2[has].ravel())
+            R.append(pcols.ravel()); Cc.append(ucols[has].ravel()); V.append(-r2[has].ravel())
         lamE = lam[nx:].reshape(E, self.rows_per_edge)
         if self.discrete:
             HF = self.HF(cols, n).T.reshape(E, nx, nv, nv)

@@ -276,3 +276,67 @@ def check_kkt_with_oracle_functions(mpc, nlp, x0):
     active = np.isfinite(dist)
     assert np.max(np.abs(lam_x[active]) * np.maximum(dist[active], 0.0)) < 1e-6     # complementarity
     assert np.all(lam_x[~active] == 0.0)
+
+
+# ---- user-defined input penalty (set_rterm(rterm=expr), _mpc.py:593-677, 1263-1269) -----------------------------------------
+def _oracle_rterm(name, which):
+    import sympy as sp
+    c = ORACLE_CASES[name]()
+    up = sp.symbols("u_prev_0:%d" % len(c["u"]))
+    if name == "CSTR":
+        F, Qd = c["u"]
+        TR = c["x"][2]
+        dF, dQ = F / 100.0 - up[0], Qd / 2000.0 - up[1]
+        expr = (0.1 * dF ** 2 + 1e-3 * dQ ** 2) if which == "default" else \
+            (0.1 * (1 + 0.01 * TR) * dF ** 2 + 1e-3 * dQ ** 2 + 0.5 * dF ** 4 + 0.02 * dF * dQ)
+    else:
+        du = c["u"][0] - up[0]
+        expr = 1e-2 * du ** 2 + 1e-1 * du ** 4 + 1e-2 * c["x"][0] ** 2 * du ** 2
+    return dict(u_prev=up, rterm_expr=expr)
+
+
+def check_custom_rterm_equal_to_default(make_mpc):
+    """The default penalty written as a user expression must give the default path's solution (CSTR tree: branching nodes,
+    input scalings, soft constraint) - the expression path (generated dompc_rterm, per-edge records, node-level Hessian) against
+    the analytic one."""
+    ex = CASES["CSTR"]
+    sols = []
+    for kw in ({}, {"custom_rterm": "default_as_expression"}):      # (do_mpc_amd/examples/cstr.py: RTERM_VARIANTS)
+        mpc = make_mpc("CSTR", **kw)
+        mpc.x0 = ex.X0
+        mpc.u0 = np.array([20.0, -3000.0])             # a non-zero previous input: the k = 0 term reads the parameter
+        mpc.set_initial_guess()
+        mpc.make_step(ex.X0)
+        assert mpc.solver_stats["success"]
+        sols.append((mpc.opt_x_num.master.copy(), mpc.lam_g_num.copy(), mpc.solver_stats["iter_count"]))
+    used = np.ones(sols[0][0].size, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    assert sols[0][2] == sols[1][2]
+    assert relerr(sols[1][0][used], sols[0][0][used]) < 1e-9
+    assert np.max(np.abs(sols[1][1] - sols[0][1])) < 1e-8 * max(1.0, np.max(np.abs(sols[0][1])))
+
+
+def check_custom_rterm_vs_oracle(make_mpc, name):
+    """A genuinely user-defined penalty (quartic, state-dependent, coupling two inputs) against the oracle's solve of the same NLP"""
+    ex = CASES[name]
+    mpc = make_mpc(name, custom_rterm="custom")                     # (do_mpc_amd/examples/{cstr,oscillating_masses}.py: RTERM_VARIANTS)
+    key = ("rterm", name)
+    if key not in _oracle_cache:
+        _oracle_cache[key] = OracleNLP(ORACLE_CASES[name](**_oracle_rterm(name, "custom")))
+    nlp = _oracle_cache[key]
+    u_prev = np.array([20.0, -3000.0]) if name == "CSTR" else np.array([0.2])
+    mpc.x0 = ex.X0
+    mpc.u0 = u_prev
+    mpc.set_initial_guess()
+    u0 = mpc.make_step(ex.X0).ravel()
+    assert mpc.solver_stats["success"], mpc.solver_stats
+    p = mpc.opt_p_num.master.copy()
+    assert np.allclose(p, nlp.opt_p(ex.X0, u_prev), rtol=0, atol=1e-12)
+    r = ipm.solve(nlp, nlp.initial_guess(ex.X0, u_prev), p)
+    assert r["stats"]["success"]
+    used = np.ones(nlp.n_opt_x, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    assert relerr(u0, nlp.u0_of(r["x"])) < U_RTOL, (u0, nlp.u0_of(r["x"]))
+    assert relerr(mpc.opt_x_num.master[used], r["x"][used]) < X_RTOL
+    assert mpc.solver_stats["iter_count"] == r["stats"]["iter_count"]
+    return mpc

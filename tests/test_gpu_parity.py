@@ -219,7 +219,9 @@ def test_wide_mode_equals_single_workgroup_mode(monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,kw,cut,native", [("CSTR", {}, 1, False), ("CSTR", {}, 1, True),
-                                                ("industrial_poly", {"n_robust": 2, "uncertainty": "paired"}, 2, True)])
+                                                ("industrial_poly", {"n_robust": 2, "uncertainty": "paired"}, 2, True),
+                                                # BASELINE configs[4]: the 243-leaf tree, 27 sub-trees below cut level 3 (9 cut parents)
+                                                ("industrial_poly", {"n_robust": 5, "uncertainty": "paired"}, 3, True)])
 def test_tree_sharded_solve_on_one_gpu_matches_the_plain_solve(name, kw, cut, native):
     """the tree-sharding kernel variant with a cut and world = 1.  Every exchange goes through the
     device<->host handshake (pinned request/acknowledge words, host service loop) and an RCCL all-reduce on a
@@ -278,3 +280,12 @@ def test_code_objects_are_the_ones_the_unedited_templates_lower_to():
         mpc = make_mpc(name)
         assert mpc.model_hash == h, (name, mpc.model_hash, h)
         assert os.path.basename(os.path.dirname(mpc.S.code_object_path)) == h
+
+
+def test_user_defined_rterm_written_as_the_default_gives_the_default_solution():
+    pc.check_custom_rterm_equal_to_default(make_mpc)
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "CSTR"])
+def test_user_defined_rterm_vs_oracle(name):
+    pc.check_custom_rterm_vs_oracle(make_mpc, name)

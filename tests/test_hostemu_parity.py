@@ -185,3 +185,12 @@ def test_without_ipopts_one_sided_damping_the_cstr_golden_is_only_reached_to_1e_
     g = pc.golden("CSTR")
     u0 = mpc.make_step(g["mpc._x"][0]).ravel()
     assert 1e-8 < pc.relerr(u0, g["mpc._u"][0]) < 1e-6
+
+
+def test_user_defined_rterm_written_as_the_default_gives_the_default_solution():
+    pc.check_custom_rterm_equal_to_default(make_mpc)
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "CSTR"])
+def test_user_defined_rterm_vs_oracle(name):
+    pc.check_custom_rterm_vs_oracle(make_mpc, name)
