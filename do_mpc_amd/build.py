@@ -127,8 +127,8 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
     lb = os.environ.get("DOMPC_LB", "2")          # tuning aid: wavefronts per SIMD the kernel is compiled for
     prof = os.environ.get("DOMPC_PROFILE", "0")    # measurement aid: sub-phase cycle counters compiled in (tools/gpu_profile.py)
     defs = os.environ.get("DOMPC_DEFS", "").split()  # measurement aid: extra -D switches / compiler flags (entries starting with '-') for A/B builds (own file per set)
-    if defs or prof != "0":                       # (measurement builds live next to the product build, under their own names)
-        tag = ("prof" if prof != "0" else "") + (hashlib.sha256(" ".join(defs).encode()).hexdigest()[:8] if defs else "")
+    if defs or prof != "0" or lb != "2":          # (measurement builds live next to the product build, under their own names)
+        tag = ("prof" if prof != "0" else "") + (("lb" + lb) if lb != "2" else "") + (hashlib.sha256(" ".join(defs).encode()).hexdigest()[:8] if defs else "")
         out = out[:-len(".hsaco")] + "_" + tag + ".hsaco"
         stamp = out + ".stamp"
     dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt + ("S" if shard else "") + "lb" + lb + "p" + prof + " ".join(defs)

@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 from do_mpc_amd import build as nb
 for defs in sys.argv[1:]:
+    lb = "2"
+    if defs.startswith("LB="):                 # "LB=3 DEF1 DEF2": resident wavefronts per SIMD the kernel is compiled for
+        lb, _, defs = defs[3:].partition(" ")
+    os.environ["DOMPC_LB"] = lb
     for prof in ("0", "1"):
         os.environ["DOMPC_PROFILE"] = prof
         os.environ["DOMPC_DEFS"] = defs
