@@ -407,8 +407,16 @@ class MPC:
         s.check_for_mandatory_settings()
         if self.flags["MINLP"]:
             raise NotImplementedError("structured HIP backend: integer inputs (MINLP/bonmin) are not supported")
-        if s.nl_cons_check_colloc_points and self.nl_cons_list:
-            raise NotImplementedError("structured HIP backend: nl_cons_check_colloc_points is not lowered yet")
+        # nl_cons_check_colloc_points (_mpc.py:1229-1237): the rows are evaluated at every stored point of the interval,
+        # `_x[k+1, s, i]`, `_z[k, s, i]` with the PARENT's scenario index s - the edge's own unknowns only on a scenario chain
+        self._nl_colloc = bool(s.nl_cons_check_colloc_points and self.nl_cons_list and m.model_type == "continuous")
+        if s.nl_cons_check_colloc_points and self.nl_cons_list and m.model_type == "discrete":
+            # (the reference loops over range(n_total_coll_points) = range(0) there: the rows silently disappear from its NLP)
+            raise NotImplementedError("structured HIP backend: nl_cons_check_colloc_points with a discrete model (the reference "
+                                      "drops the nl_cons rows in that combination); switch the setting off")
+        if self._nl_colloc and s.n_robust > 0 and self.n_combinations > 1:
+            raise NotImplementedError("structured HIP backend: nl_cons_check_colloc_points is supported for scenario chains "
+                                      "(one parameter combination) only")
         if m.n_z and s.n_robust > 0 and self.n_combinations > 1:
             zn = m._z.cat.nodes()
             if sym.depends_on(self.lterm.nodes(), zn) or any(sym.depends_on(c["expr"].nodes(), zn) for c in self.nl_cons_list):
@@ -455,7 +463,8 @@ class MPC:
         self._eps_pen = per_element("penalty") if self.n_eps else np.zeros(0)
 
         discrete = m.model_type == "discrete"
-        ps = build_structure(nx=m.n_x, nu=m.n_u, nz=m.n_z, np_=m.n_p, ntvp=m.n_tvp, ne=len(self._nl_rows),
+        n_eval = (s.collocation_deg + 1) * s.collocation_ni if self._nl_colloc else 1      # evaluations of the rows per edge
+        ps = build_structure(nx=m.n_x, nu=m.n_u, nz=m.n_z, np_=m.n_p, ntvp=m.n_tvp, ne=len(self._nl_rows) * n_eval,
                              ns=self.n_eps, deg=s.collocation_deg, ni=s.collocation_ni, N=s.n_horizon,
                              n_comb=self.n_combinations, n_robust=s.n_robust, discrete=discrete,
                              open_loop=bool(s.open_loop), single_slack=bool(s.nl_cons_single_slack))
@@ -492,8 +501,8 @@ class MPC:
         if ps.ne:
             for e in range(ps.n_edges):
                 r0 = ps.tables["edge_row0"][e] + ps.rows_block + ps.nx
-                self._nlp_cons_lb[r0:r0 + ps.ne] = self._nl_cons_lb
-                self._nlp_cons_ub[r0:r0 + ps.ne] = self._nl_cons_ub
+                self._nlp_cons_lb[r0:r0 + ps.ne] = np.tile(self._nl_cons_lb, n_eval)
+                self._nlp_cons_ub[r0:r0 + ps.ne] = np.tile(self._nl_cons_ub, n_eval)
         self._opt_x_num = NumStruct(self._opt_x_layout, 0.0)
         self.opt_x_num_unscaled = NumStruct(self._opt_x_layout, 0.0)
         self._opt_p_num = NumStruct(self._opt_p_layout, 0.0)
@@ -559,7 +568,7 @@ class MPC:
             name=type(m).__name__, nz=m.n_z, z_sym=m._z.cat.nodes(), alg=alg, sz=self._z_scaling.master,
             sp=self._p_scaling.master,
             rterm_expr=(self.rterm_expr.nodes()[0] if self.rterm_expr is not None else None),
-            uprev_sym=self.u_prev.cat.nodes())
+            uprev_sym=self.u_prev.cat.nodes(), nl_colloc=self._nl_colloc)
 
     def create_nlp(self, _solver_factory=None) -> None:
         assert self.flags["prepare_nlp"], "call prepare_nlp() first"

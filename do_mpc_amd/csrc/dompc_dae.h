@@ -80,6 +80,13 @@ DOMPC_DEV inline int vtarget_stage(int i, bool last_z) {
   if (i < NA) return NW + i;
   return NWX + (last_z ? (MZ - 1) : 0) * NZ + (i - NA);
 }
+// inputs of nl_cons evaluation `blk`: (x_n, u, z of the first point), or with nl_cons_check_colloc_points (x slot blk, u, z slot blk)
+DOMPC_DEV inline int vtarget_nl(int blk, int i) {
+  if (!NL_COLLOC) return vtarget_stage(i, false);
+  if (i < NX) return blk * NX + i;
+  if (i < NA) return NW + i;
+  return NWX + blk * NZ + (i - NA);
+}
 }  // namespace dae
 
 // model evaluation of one work item of a DAE model (eval_models): dense records, multipliers gathered per point
@@ -115,7 +122,11 @@ DOMPC_DEV inline void dae_eval_item(const Prob& Q, int kind, int e, int j) {
     if (k == A.N - 1)
       dompc_mterm(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1, mo + MO_MT + 1 + NX);
   } else if (NE > 0) {
-    dompc_nlcons(xn, un, zb, tvp, pp, Q.lam + row0 + NW + NX, mo + MO_NL, mo + MO_NL + NE, mo + MO_NL + NE + NE * NAV);
+    for (int blk = 0; blk < NLB; ++blk) {
+      double* o = mo + MO_NL + blk * NL_STRIDE;
+      dompc_nlcons(NL_COLLOC ? w + blk * NX : xn, un, zb + (NL_COLLOC ? blk * NZ : 0), tvp, pp, Q.lam + row0 + NW + NX + blk * NEB,
+                   o, o + NEB, o + NEB + NEB * NAV);
+    }
   }
 }
 
@@ -171,10 +182,11 @@ DOMPC_DEV inline double dae_edge_f(const Prob& Q, int e, const double* xv, const
   if (RT_CUSTOM) obj += edge_rterm_f(Q, e, xv);
   if (NE > 0) {
     double d[NE1];
-    dompc_nlcons_f(xn, un, zb, tvp, pp, d);
+    for (int blk = 0; blk < NLB; ++blk)
+      dompc_nlcons_f(NL_COLLOC ? w + blk * NX : xn, un, zb + (NL_COLLOC ? blk * NZ : 0), tvp, pp, d + blk * NEB);
     const double* eps = (NS > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
-      if (DOMPC_NL_SLACK[i] >= 0) d[i] -= eps[DOMPC_NL_SLACK[i]];
+      if (nl_slack(i) >= 0) d[i] -= eps[nl_slack(i)];
       cv[row0 + NW + NX + i] = d[i] - sv[e * NE1 + i];
     }
     for (int q = 0; q < NS; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
@@ -270,8 +282,8 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
   // nl_cons Jacobian split into the w part and the y part
   for (int it = lane; it < NE * NAV; it += GS) {
     const int q = it / NAV, i = it % NAV;
-    const int v = vtarget_stage(i, false);
-    const double jv = mo[MO_NL + NE + q * NAV + i];
+    const int v = vtarget_nl(q / NEB1, i);
+    const double jv = mo[MO_NL + (q / NEB1) * NL_STRIDE + NEB + (q % NEB1) * NAV + i];
     if (v < NW) Ld[DG_JDW + q * NW + v] = jv;
     else Ld[DG_JDY + q * NA + (v - NW)] = jv;
   }
@@ -301,11 +313,13 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
   }
   T.gsync();
   if (NE > 0) {
-    for (int it = lane; it < NAV * NAV; it += GS) {
-      const int i1 = it / NAV, i2 = it % NAV;
-      Hm(vtarget_stage(i1, false), vtarget_stage(i2, false)) += mo[MO_NL + NE + NE * NAV + symi(i1, i2, NAV)];
+    for (int blk = 0; blk < NLB; ++blk) {
+      for (int it = lane; it < NAV * NAV; it += GS) {
+        const int i1 = it / NAV, i2 = it % NAV;
+        Hm(vtarget_nl(blk, i1), vtarget_nl(blk, i2)) += mo[MO_NL + blk * NL_STRIDE + NEB + NEB * NAV + symi(i1, i2, NAV)];
+      }
+      T.gsync();
     }
-    T.gsync();
   }
   // ---- constraint part of the Lagrangian gradient: [G_w G_y]' lambda + [E_w E_y]' nu + [Jd_w Jd_y]' y_d
   for (int v = lane; v < NWY; v += GS) {
@@ -424,8 +438,8 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     if (NE > 0) {
       const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
       for (int i = 0; i < NE; ++i) {
-        double d = mo[MO_NL + i];
-        if (DOMPC_NL_SLACK[i] >= 0) d -= eps[DOMPC_NL_SLACK[i]];
+        double d = mo[MO_NL + (i / NEB1) * NL_STRIDE + i % NEB1];
+        if (nl_slack(i) >= 0) d -= eps[nl_slack(i)];
         const int si = e * NE1 + i;
         const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
         double rdn = (Q.soc & 1) ? Q.c[row0 + NW + NX + i] : d - sv;
@@ -462,7 +476,7 @@ DOMPC_DEV inline void forward_edge_dae(const Thr& T, const Prob& Q, int e, doubl
   for (int i = lane; i < NE; i += GS) {
     double t = S_[ES_RDN + i];
     for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_JD + i * NA + b) * Ld[DF_DY + b];
-    if (DOMPC_NL_SLACK[i] >= 0) t -= Q.dx[A.node_eps_off[n] + DOMPC_NL_SLACK[i]];
+    if (nl_slack(i) >= 0) t -= Q.dx[A.node_eps_off[n] + nl_slack(i)];
     Q.ds[e * NE1 + i] = t;
     const double dyd = (S_[ES_SIGS + i] + delta) * t + S_[ES_RSN + i];
     Q.dlam[row0 + NW + NX + i] = dyd;

@@ -38,8 +38,24 @@ namespace dompc {
 #endif
 
 constexpr int NX = DOMPC_NX, NU = DOMPC_NU, NP = DOMPC_NP, NTVP = DOMPC_NTVP;
-constexpr int NE = DOMPC_NE, NS = DOMPC_NS, NZ = DOMPC_NZ;
+constexpr int NS = DOMPC_NS, NZ = DOMPC_NZ;
 constexpr int DEG = DOMPC_DEG, NI = DOMPC_NI, M = DOMPC_M;
+// nl_cons rows of an edge: ONE evaluation of the user's expressions at (x_n, u, z of the first point) (_mpc.py:1239-1246) or,
+// with nl_cons_check_colloc_points, one evaluation per stored point i of the interval at (_x[k+1,s,i], u, _z[k,s,i])
+// (_mpc.py:1229-1237; chain problems only: the reference indexes the points with the PARENT's scenario).  Rows that depend on
+// the edge unknowns are handled by the dense edge path (dompc_dae.h), like the algebraic states.
+#ifndef DOMPC_NL_COLLOC
+#define DOMPC_NL_COLLOC 0
+#endif
+constexpr int NEB = DOMPC_NE;                               // rows of one evaluation
+constexpr int NLB = (DOMPC_NL_COLLOC && M > 0) ? M : 1;     // evaluations per edge
+constexpr int NE = NEB * NLB;
+constexpr bool NL_COLLOC = DOMPC_NL_COLLOC && M > 0 && NEB > 0;
+#ifndef DOMPC_FORCE_DENSE
+#define DOMPC_FORCE_DENSE 0        // test aid: 1 = a model without algebraic states through the dense edge path as well
+#endif
+constexpr bool DENSE_EDGE = DOMPC_NZ > 0 || NL_COLLOC || DOMPC_FORCE_DENSE;      // edge path: dense (dompc_dae.h) instead of the single-element fast path
+DOMPC_HD inline int nl_slack(int i) { return DOMPC_NL_SLACK[NLB == 1 ? i : i % NEB]; }
 constexpr int NA = NX + NU;          // (x,u) of a stage == augmented state (x,u_prev)
 constexpr int NV = NU + NS;          // decision variables of a node: u then eps
 constexpr int NYT = NA + NV;         // node quadratic: (x, u_prev, u, eps)
@@ -58,7 +74,7 @@ constexpr int NF = NX + NZ;          // outputs of the dynamics at a point: [h f
 constexpr int NAV = NA + NZ;         // inputs of a point function: (x, u, z)
 constexpr int NCOLL = NI * DEG;      // collocation points evaluated per edge
 constexpr int RPE = NW + NX + NE;    // constraint rows per edge
-constexpr int NE1 = NE > 0 ? NE : 1;
+constexpr int NE1 = NE > 0 ? NE : 1, NEB1 = NEB > 0 ? NEB : 1;
 constexpr int NS1 = NS > 0 ? NS : 1;
 constexpr int NW1 = NW > 0 ? NW : 1;
 constexpr int MAX_FILTER = 48;
@@ -79,7 +95,7 @@ constexpr int GS_C = 1;
 // Round 3: W = -G_w^-1 G_y and w0 = -G_w^-1 r are NOT stored any more (420 doubles per industrial_poly edge, written by
 // every sweep and read back by every forward pass): the forward pass forms dw = -G_w^-1 (G_y dy + r) from the stored
 // inverse, the u-columns of the point Jacobians (model-output record) and the residual vector.
-constexpr int LU_N = (NI == 1 && DEG > 0 && NZ == 0) ? DEG * NX : NW;
+constexpr int LU_N = (NI == 1 && DEG > 0 && !DENSE_EDGE) ? DEG * NX : NW;
 constexpr int EW_LU = 0;
 constexpr int EW_SIGW = EW_LU + LU_N * LU_N; // Sigma_w + dsw      (the lambda-weighted Hessian blocks are read from the model-output record)
 constexpr int EW_RW = EW_SIGW + NW;
@@ -87,11 +103,11 @@ constexpr int EW_JD = EW_RW + NW;            // NE x NA
 // DAE models (dense path): W, w0, the rows of the edge Hessian that belong to the eliminated unknowns (over [w | y], Sigma_w
 // and the inertia correction on the diagonal), the Jacobians of the end-point rows and of the nl_cons rows w.r.t. w
 constexpr int EW_W = EW_JD + NE * NA;        // NW x NA
-constexpr int EW_W0 = EW_W + (NZ > 0 ? NW * NA : 0);
-constexpr int EW_HW = EW_W0 + (NZ > 0 ? NW : 0);                 // NW x (NW + NA)
-constexpr int EW_EWJ = EW_HW + (NZ > 0 ? NW * (NW + NA) : 0);    // NX x NW
-constexpr int EW_JDW = EW_EWJ + (NZ > 0 ? NX * NW : 0);          // NE x NW
-constexpr int EW_SIZE = ((EW_JDW + (NZ > 0 ? NE * NW : 0) + 1 + 7) / 8) * 8;      // records start on 64-byte boundaries
+constexpr int EW_W0 = EW_W + (DENSE_EDGE ? NW * NA : 0);
+constexpr int EW_HW = EW_W0 + (DENSE_EDGE ? NW : 0);                 // NW x (NW + NA)
+constexpr int EW_EWJ = EW_HW + (DENSE_EDGE ? NW * (NW + NA) : 0);    // NX x NW
+constexpr int EW_JDW = EW_EWJ + (DENSE_EDGE ? NX * NW : 0);          // NE x NW
+constexpr int EW_SIZE = ((EW_JDW + (DENSE_EDGE ? NE * NW : 0) + 1 + 7) / 8) * 8;      // records start on 64-byte boundaries
 
 // per-edge shared (contiguous per edge) --------------------------------------------------------
 // The head [A B | c | Q~ | q~ + r_y] is what the backward Riccati pass reads (staged by LDS-DMA, dompc_riccati16.h).
@@ -118,19 +134,20 @@ constexpr int ES_SIZE = ((ES_RTH + (RT_CUSTOM ? NR_T : 0) + 7) / 8) * 8;
 constexpr int NA_T = NA * (NA + 1) / 2, NX_T = NX * (NX + 1) / 2, NAV_T = NAV * (NAV + 1) / 2;
 DOMPC_HD constexpr int symi(int i, int j, int n) { return i <= j ? i * n - i * (i - 1) / 2 + j - i : j * n - j * (j - 1) / 2 + i - j; }
 constexpr int PT_STRIDE = NF + NF * NAV + NAV_T;            // F, J, H (packed) of one point (NZ == 0: f (NX), J (NX x NA), H over (x, u))
-constexpr int NPT_E = (M == 0) ? 1 : (NZ > 0 ? NI * (DEG + 1) : NI * DEG);    // points evaluated per edge (DAE: also point 0 of every element - its algebraic rows)
+constexpr int NPT_E = (M == 0) ? 1 : (DENSE_EDGE ? NI * (DEG + 1) : NI * DEG);    // points evaluated per edge (DAE: also point 0 of every element - its algebraic rows)
 constexpr int MO_PT = 0;
 constexpr int MO_LT = MO_PT + NPT_E * PT_STRIDE;                             // lterm: val, g[NAV], H (packed)
 constexpr int MO_MT = MO_LT + 1 + NAV + NAV_T;                               // mterm: val, g[NX], H (packed)
-constexpr int MO_NL = MO_MT + 1 + NX + NX_T;                                 // nlcons: d[NE], Jd[NE*NAV], H (packed)
-constexpr int MO_SIZE = ((MO_NL + NE + NE * NAV + NAV_T + 7) / 8) * 8;
+constexpr int MO_NL = MO_MT + 1 + NX + NX_T;                                 // nlcons, per evaluation: d[NEB], Jd[NEB*NAV], H (packed)
+constexpr int NL_STRIDE = NEB + NEB * NAV + NAV_T;
+constexpr int MO_SIZE = ((MO_NL + NLB * NL_STRIDE + 7) / 8) * 8;
 // Compact form of the record (single finite element, continuous model): only the entries that depend on the iterate
 // travel through HBM - the generated dompc_*_c functions write them one after the other (lowering.py: compact()); the
 // structural zeros and model constants of the dense layout above (149 + 9 of the 231 entries of an industrial_poly
 // collocation point, the whole Hessian of its linear stage cost) live in a dense IMAGE of the record that every
 // wavefront keeps in its LDS region: initialised once per phase (mo_image_init), the variable entries of the current
 // edge scattered into it (mo_expand).  All consumers read the image through the dense indices.
-constexpr bool MO_COMPACT = (NI == 1) && (M > 0) && (NZ == 0);
+constexpr bool MO_COMPACT = (NI == 1) && (M > 0) && !DENSE_EDGE;
 constexpr int MOC_LT = NCOLL * DOMPC_DYN_NV;
 constexpr int MOC_MT = MOC_LT + DOMPC_LT_NV;
 constexpr int MOC_NL = MOC_MT + DOMPC_MT_NV;
@@ -686,7 +703,7 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
     dompc_nlcons_f(xn, un, nullptr, tvp, pp, d);
     const double* eps = (NS > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
-      if (DOMPC_NL_SLACK[i] >= 0) d[i] -= eps[DOMPC_NL_SLACK[i]];
+      if (nl_slack(i) >= 0) d[i] -= eps[nl_slack(i)];
       cv[row0 + NW + NX + i] = d[i] - sv[e * NE1 + i];
     }
     for (int q = 0; q < NS; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
@@ -764,7 +781,7 @@ static_assert(NW <= 64, "collocation block larger than 64 unknowns per edge is n
 constexpr int MX_LD = (NI == 1) ? NA + 1 : NC;                         // leading dimension of the LDS matrix
 constexpr int MX_W = (NI == 1) ? 0 : NW;                               // column offset of [W | w0] inside it
 #ifndef DOMPC_HOST_EMU
-constexpr bool TILE_CONDENSE = (NI == 1) && (DEG >= 1) && (NA <= 16) && (NZ == 0);   // condensing on the matrix cores with register tiles (eval_edge_coop)
+constexpr bool TILE_CONDENSE = (NI == 1) && (DEG >= 1) && (NA <= 16) && !DENSE_EDGE;   // condensing on the matrix cores with register tiles (eval_edge_coop)
 #else
 constexpr bool TILE_CONDENSE = false;
 #endif
@@ -825,7 +842,7 @@ constexpr int RF_MOC = RF_EW + EW_STAGE;
 constexpr int RF_IMG = RF_MOC + MOC_STAGE;
 constexpr int MOH_H0 = NX + NX * NA;                                    // offset of the packed Hessian inside a point record
 // DAE models: dense edge working set of eval_edge_dae (= dae::DG_SIZE, asserted in sweep())
-constexpr int DAE_NEED = NZ > 0 ? NW * (2 * NW + NA + 1) + (NW + NA) * (NW + NA) + (NW + NA) * (NA + 2) + 2 * (NW + NA) + 3 * NW
+constexpr int DAE_NEED = DENSE_EDGE ? NW * (2 * NW + NA + 1) + (NW + NA) * (NW + NA) + (NW + NA) * (NA + 2) + 2 * (NW + NA) + 3 * NW
                                       + NX * NW + NX * NA + NX + NE * NW + NE * NA + NW + RT_LEN : 0;
 constexpr int EL_SIZE = ((el_max(el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)), DAE_NEED) + 7) / 8) * 8;
 
@@ -910,7 +927,7 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
     else if (it < n_dyn + n_lt + n_mt) { kind = 2; e = e_last0 + (it - n_dyn - n_lt); }
     else { kind = 3; e = it - n_dyn - n_lt - n_mt; }
     if (!mk_e(A, e)) continue;
-    if constexpr (NZ > 0) { dae_eval_item(Q, kind, e, j); continue; }
+    if constexpr (DENSE_EDGE) { dae_eval_item(Q, kind, e, j); continue; }
     const int n = A.edge_parent[e], cn = A.edge_child[e], k = A.edge_level[e];
     const double* xn = Q.x + A.node_x_off[n];
     const double* un = Q.x + A.node_u_off[n];
@@ -1011,7 +1028,7 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #endif
 constexpr int GJ_R = DEG * NX, GJ_RP = ((GJ_R + 3) / 4) * 4, GJ_NRHS = NA + 1;
 constexpr int GJ_NC = GJ_RP + GJ_NRHS + GJ_R;                      // columns: [G_cc padded | G_y r | I]
-constexpr bool MFMA_GJ = (NI == 1) && (DEG >= 1) && (NZ == 0) && (GJ_RP <= 32) && (GJ_NC <= 64) && (DOMPC_MFMA_GJ != 0);
+constexpr bool MFMA_GJ = (NI == 1) && (DEG >= 1) && !DENSE_EDGE && (GJ_RP <= 32) && (GJ_NC <= 64) && (DOMPC_MFMA_GJ != 0);
 constexpr int GJ_MT = (GJ_RP + 15) / 16, GJ_NT = (GJ_NC + 15) / 16;
 static_assert(!MFMA_GJ || GJ_RP * 4 + 64 <= EL_T1 - EL_MX, "the panel buffer and the dual-residual row share the W | w0 region of the edge working set");
 
@@ -2230,7 +2247,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
         for (int i = 0; i < NE; ++i) {
           double d = MOV(MO_NL + i);
-          if (DOMPC_NL_SLACK[i] >= 0) d -= eps[DOMPC_NL_SLACK[i]];
+          if (nl_slack(i) >= 0) d -= eps[nl_slack(i)];
           const int si = e * NE1 + i;
           const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
           const double rdn = Q.soc ? Q.c[row0 + NW + NX + i] : d - sv;
@@ -2302,7 +2319,7 @@ DOMPC_DEV inline void assemble_children(const Prob& Q, int n, bool counted_only,
       const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
       for (int q = 0; q < NS; ++q)
         for (int i = 0; i < NE; ++i)
-          if (DOMPC_NL_SLACK[i] == q) out[2 * NX + 3 * NU + q] -= yd[i];
+          if (nl_slack(i) == q) out[2 * NX + 3 * NU + q] -= yd[i];
     }
   }
 }
@@ -2539,7 +2556,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
           const double sg = Ld[NL_SG + q] + delta;
           double ji = 0.0;
           if (yi >= 0) ji = Ld[NL_JD + q * NA + yi];
-          else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) { ji = -1.0; gv -= Ld[NL_YD + q]; }
+          else if (i >= NA + NU && nl_slack(q) == i - NA - NU) { ji = -1.0; gv -= Ld[NL_YD + q]; }
           gv += ji * (sg * Ld[NL_RD + q] + Ld[NL_RS + q]);
         }
         gvv[v] = gv;
@@ -2555,9 +2572,9 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
           const double sg = Ld[NL_SG + qq] + delta;
           double ji = 0.0, jj = 0.0;
           if (yi >= 0) ji = Ld[NL_JD + qq * NA + yi];
-          else if (i >= NA + NU && DOMPC_NL_SLACK[qq] == i - NA - NU) ji = -1.0;
+          else if (i >= NA + NU && nl_slack(qq) == i - NA - NU) ji = -1.0;
           if (yj >= 0) jj = Ld[NL_JD + qq * NA + yj];
-          else if (j >= NA + NU && DOMPC_NL_SLACK[qq] == j - NA - NU) jj = -1.0;
+          else if (j >= NA + NU && nl_slack(qq) == j - NA - NU) jj = -1.0;
           v += sg * ji * jj;
         }
         qacc[q] = v;
@@ -2845,7 +2862,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
             const double sg = S_[ES_SIGS + q] + delta;
             double ji = 0.0;
             if (yi >= 0) ji = Q.EW(e, EW_JD + q * NA + yi);
-            else if (i >= NA + NU && DOMPC_NL_SLACK[q] == i - NA - NU) { ji = -1.0; gv -= yd[q]; }
+            else if (i >= NA + NU && nl_slack(q) == i - NA - NU) { ji = -1.0; gv -= yd[q]; }
             gv += ji * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
           }
         }
@@ -2869,9 +2886,9 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
             const double sg = S_[ES_SIGS + qq] + delta;
             double ji = 0.0, jj = 0.0;
             if (yi >= 0) ji = Q.EW(e, EW_JD + qq * NA + yi);
-            else if (i >= NA + NU && DOMPC_NL_SLACK[qq] == i - NA - NU) ji = -1.0;
+            else if (i >= NA + NU && nl_slack(qq) == i - NA - NU) ji = -1.0;
             if (yj >= 0) jj = Q.EW(e, EW_JD + qq * NA + yj);
-            else if (j >= NA + NU && DOMPC_NL_SLACK[qq] == j - NA - NU) jj = -1.0;
+            else if (j >= NA + NU && nl_slack(qq) == j - NA - NU) jj = -1.0;
             v += sg * ji * jj;
           }
       }
@@ -3353,8 +3370,8 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     const double* Nc = Q.ND(cn);
     const int row0 = A.edge_row0[e];
     const bool chain_edge = A.edge_level[e] >= cl;          // its d nu was formed by the chain walk
-    if constexpr (NZ > 0) {
-      // DAE model: dense path (dompc_dae.h) - dy of the parent node and d nu of the end-point rows staged, then the edge
+    if constexpr (DENSE_EDGE) {
+      // DAE model / rows on the edge unknowns: dense path (dompc_dae.h) - dy of the parent node and d nu of the end-point rows staged, then the edge
       for (int a = lane; a < NA; a += GS) Ld[dae::DF_DY + a] = (a < NX) ? Nd[ND_DXT + a] : Q.dx[A.node_u_off[n] + a - NX];
       for (int a = lane; a < NX; a += GS) {
         double t;
@@ -3548,7 +3565,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       for (int i = lane; i < NE; i += GS) {
         double t = S_[ES_RDN + i];
         for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_JD + i * NA + b) * Ld[RF_DY + b];
-        if (DOMPC_NL_SLACK[i] >= 0) t -= Q.dx[A.node_eps_off[n] + DOMPC_NL_SLACK[i]];
+        if (nl_slack(i) >= 0) t -= Q.dx[A.node_eps_off[n] + nl_slack(i)];
         Q.ds[e * NE1 + i] = t;
         Q.dlam[row0 + NW + NX + i] = (S_[ES_SIGS + i] + delta) * t + S_[ES_RSN + i];
       }
@@ -3604,8 +3621,8 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
       const int en = e + ng;
       const bool mine = e < A.n_edges && mk_e(A, e);
       if (sh_on(A) && !mine) continue;                  // sharded: another rank's edge (no workgroup barrier inside)
-      if constexpr (NZ > 0) {
-        static_assert(NZ == 0 || dae::DG_SIZE == DAE_NEED, "LDS working set of the dense DAE path");
+      if constexpr (DENSE_EDGE) {
+        static_assert(!DENSE_EDGE || dae::DG_SIZE == DAE_NEED, "LDS working set of the dense DAE path");
         if (eval_edge_dae(T, Q, mine ? e : -1, mu, lane, T.gs, Ld)) T.fset(1, 1);
         continue;
       }
@@ -3793,7 +3810,7 @@ DOMPC_DEV inline double trial_edges(const Thr& T, const Prob& Q) {
   for (int e = T.tid; e < A.n_edges; e += T.nt) {
     const int m = mk_e(A, e);
     if (!m) continue;
-    const double fe = (NZ > 0) ? dae_edge_f(Q, e, Q.xt, Q.st, Q.ct) : eval_edge_f(Q, e, Q.xt, Q.st, Q.ct);
+    const double fe = DENSE_EDGE ? dae_edge_f(Q, e, Q.xt, Q.st, Q.ct) : eval_edge_f(Q, e, Q.xt, Q.st, Q.ct);
     if (sh_cnt(A, m)) f += fe;
   }
   for (int n = T.tid; n < A.n_nodes; n += T.nt)
@@ -4155,7 +4172,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   if (NE > 0) {
     for (int e = T.tid; e < A.n_edges; e += T.nt) {
       for (int i = 0; i < NE; ++i) Q.s[e * NE1 + i] = 0.0;
-      if (NZ > 0) dae_edge_f(Q, e, Q.x, Q.s, Q.ct); else eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
+      if (DENSE_EDGE) dae_edge_f(Q, e, Q.x, Q.s, Q.ct); else eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
       for (int i = 0; i < NE; ++i) {
         const int row = A.edge_row0[e] + NW + NX + i, si = e * NE1 + i;
         double l = A.lbg[row], u = A.ubg[row];
@@ -4550,7 +4567,7 @@ DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A) {
   if (NE > 0) {
     for (int e = T.tid; e < A.n_edges; e += T.nt) {
       for (int i = 0; i < NE; ++i) Q.s[e * NE1 + i] = 0.0;
-      if (NZ > 0) dae_edge_f(Q, e, Q.x, Q.s, Q.ct); else eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
+      if (DENSE_EDGE) dae_edge_f(Q, e, Q.x, Q.s, Q.ct); else eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
       for (int i = 0; i < NE; ++i) {
         const int row = A.edge_row0[e] + NW + NX + i, si = e * NE1 + i;
         const double l = A.lbg[row], u = A.ubg[row];

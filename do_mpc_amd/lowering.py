@@ -46,7 +46,7 @@ def _sym_hessian_upper(L: sym.Node, v: List[sym.Node]):
 
 def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, mterm, nl_exprs,
                 nl_slack_index, eps_penalty, sx, su, rterm, h_scale, deg, ni, discrete, C, D,
-                name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None, rterm_expr=None, uprev_sym=()) -> str:
+                name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None, rterm_expr=None, uprev_sym=(), nl_colloc=False) -> str:
     """Return the text of the generated header.
 
     x_sym/u_sym/z_sym/tvp_sym/p_sym: lists of sym.Node (the model's own symbols, unscaled).
@@ -234,6 +234,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         f"#define DOMPC_NX {nx}", f"#define DOMPC_NU {nu}", f"#define DOMPC_NP {np_}",
         f"#define DOMPC_NTVP {ntvp}", f"#define DOMPC_NE {ne}", f"#define DOMPC_NS {ns}", f"#define DOMPC_NZ {nz}",
         f"#define DOMPC_RTERM_CUSTOM {1 if rterm_expr is not None else 0}",
+        *(["#define DOMPC_NL_COLLOC 1      // nl_cons rows at every stored point of the interval (DOMPC_NE rows per point)"] if nl_colloc and ne and not discrete else []),
         f"#define DOMPC_DEG {deg if not discrete else 0}", f"#define DOMPC_NI {ni if not discrete else 1}",
         f"#define DOMPC_M {M}", f"#define DOMPC_DISCRETE {1 if discrete else 0}",
         _fmt_array("DOMPC_C", np.asarray(C).reshape(-1) if not discrete else [0.0]),

@@ -22,7 +22,8 @@ from .nlp import _Lam, collocation_coeffs
 
 class OracleNLPDae:
     def __init__(self, case):
-        self.case = c = case
+        self.case = c = dict(case)
+        c.setdefault("z", ()); c.setdefault("alg", ())        # (a model without algebraic states: nl_cons rows at the collocation points)
         self.nx, self.nu, self.nz, self.np_ = len(c["x"]), len(c["u"]), len(c["z"]), len(c["p"])
         self.ntvp = len(c.get("tvp", ()))
         self.nq = self.np_ + self.ntvp
@@ -36,9 +37,14 @@ class OracleNLPDae:
         self.n_comb = n_comb = self.p_values.shape[0]
         n_robust = c["n_robust"]
         self.S = S = n_comb ** n_robust
-        assert not c["open_loop"] and not c["nl_cons_single_slack"] and not c["nl_cons_check_colloc_points"]
+        assert not c["open_loop"] and not c["nl_cons_single_slack"]
         self.nl = c["nl_cons"]
-        self.ne = len(self.nl)
+        # nl_cons rows per edge: one evaluation at (x_n, u, z first point), or with nl_cons_check_colloc_points one per stored
+        # point i of the interval at (`_x[k+1, s, i]`, u, `_z[k, s, i]`), s = the PARENT's scenario index (_mpc.py:1229-1246)
+        self.neb = len(self.nl)
+        self.nlb = M if (c["nl_cons_check_colloc_points"] and self.neb and not self.discrete) else 1
+        self.nl_colloc = self.nlb > 1 or bool(c["nl_cons_check_colloc_points"] and self.neb and not self.discrete)
+        self.ne = self.neb * self.nlb
         self.soft = [i for i, nc in enumerate(self.nl) if nc["soft"]]
         self.n_slack = len(self.soft)
         self.n_eps = N
@@ -162,7 +168,7 @@ class OracleNLPDae:
             for e in range(self.E):
                 sl = slice(r0 + e * self.rows_per_edge, r0 + e * self.rows_per_edge + self.ne)
                 lbg[sl] = -np.inf
-                ubg[sl] = [nc["ub"] for nc in self.nl]
+                ubg[sl] = np.tile([nc["ub"] for nc in self.nl], self.nlb)
         self.lbg, self.ubg = lbg, ubg
 
     # ------------------------------------------------------------------ static index arrays (one row per edge)
@@ -180,6 +186,14 @@ class OracleNLPDae:
         self.row0 = nx + np.arange(self.E) * self.rows_per_edge
         self.col_eps = np.array([self.ieps(kk, ss) for kk, ss in zip(k, s)]) if self.n_slack else None
         self.col_uprev = np.array([self.iu(kk - 1, self.parent[kk, ss]) if kk > 0 else -1 for kk, ss in zip(k, s)])
+
+    def _nl_cols(self, blk):
+        """opt_x columns of the (x, u, z) inputs of nl_cons evaluation `blk` of every edge"""
+        if not self.nl_colloc:
+            return self.col_xpar, self.col_u, self.col_zn
+        k, s = self.edges[:, 0], self.edges[:, 1]
+        return (np.array([self.ix(kk + 1, ss, blk) for kk, ss in zip(k, s)]), self.col_u,
+                np.array([self.iz(kk, ss, blk) for kk, ss in zip(k, s)]))
 
     def _col_x(self, el, j):
         return self.col_xpar if (self.discrete or (el == 0 and j == 0)) else self.col_blk + self.slot(el, j) * self.nx
@@ -292,14 +306,15 @@ class OracleNLPDae:
                 rr = el * self.ELR + nz + deg * (nx + nz) + np.arange(nx)
                 G[:, rr] = x[self._col_next(el)[:, None] + np.arange(nx)] - xf
             G[:, self.rows_block:self.rows_block + nx] = x[(self.col_blk + (M - 1) * nx)[:, None] + np.arange(nx)] - Xc
-        if self.ne:
-            cols, n = self._args(x, self.col_xpar, self.col_u, self.col_zn, P)
+        for blk in range(self.nlb if self.ne else 0):
+            cols, n = self._args(x, *self._nl_cols(blk), P)
             gv = self.G(cols, n).T
             if self.n_slack:
                 Eps = x[self.col_eps[:, None] + np.arange(self.n_slack)]
                 for q, i in enumerate(self.soft):
                     gv[:, i] -= Eps[:, q]
-            G[:, self.rows_per_edge - self.ne:] = gv
+            r0 = self.rows_per_edge - self.ne + blk * self.neb
+            G[:, r0:r0 + self.neb] = gv
         return out
 
     def jac(self, x, p):
@@ -337,12 +352,13 @@ class OracleNLPDae:
             rr = self.row0[:, None] + self.rows_block + ar
             put(rr, (self.col_blk + (M - 1) * nx)[:, None] + ar, np.ones((E, nx)))
             put(rr, self.col_xch[:, None] + ar, -np.ones((E, nx)))
-        if self.ne:
-            cols, n = self._args(x, self.col_xpar, self.col_u, self.col_zn, P)
-            JG = self.JG(cols, n).T.reshape(E, self.ne, nav)
-            vc = self._vcols(self.col_xpar, self.col_u, self.col_zn)
-            r0 = self.row0 + self.rows_per_edge - self.ne
-            put((r0[:, None] + np.arange(self.ne)[None, :])[:, :, None], vc[:, None, :], JG)
+        for blk in range(self.nlb if self.ne else 0):
+            cx, cu, cz = self._nl_cols(blk)
+            cols, n = self._args(x, cx, cu, cz, P)
+            JG = self.JG(cols, n).T.reshape(E, self.neb, nav)
+            vc = self._vcols(cx, cu, cz)
+            r0 = self.row0 + self.rows_per_edge - self.ne + blk * self.neb
+            put((r0[:, None] + np.arange(self.neb)[None, :])[:, :, None], vc[:, None, :], JG)
             for q, i in enumerate(self.soft):
                 put(r0 + i, self.col_eps + q, -np.ones(E))
         R, Cc, V = np.concatenate(R), np.concatenate(Cc), np.concatenate(V)
@@ -393,11 +409,13 @@ class OracleNLPDae:
                 lamp[:, :nx] = lamE[:, rc]
             vc = self._vcols(colx, self.col_u, colz)
             put_block(vc, vc, np.einsum("ei,eiab->eab", lamp, HF))
-        if self.ne:
-            cols, n = self._args(x, self.col_xpar, self.col_u, self.col_zn, P)
-            HG = self.HG(cols, n).T.reshape(E, self.ne, nav, nav)
-            vc = self._vcols(self.col_xpar, self.col_u, self.col_zn)
-            put_block(vc, vc, np.einsum("ei,eiab->eab", lamE[:, self.rows_per_edge - self.ne:], HG))
+        for blk in range(self.nlb if self.ne else 0):
+            cx, cu, cz = self._nl_cols(blk)
+            cols, n = self._args(x, cx, cu, cz, P)
+            HG = self.HG(cols, n).T.reshape(E, self.neb, nav, nav)
+            vc = self._vcols(cx, cu, cz)
+            r0 = self.rows_per_edge - self.ne + blk * self.neb
+            put_block(vc, vc, np.einsum("ei,eiab->eab", lamE[:, r0:r0 + self.neb], HG))
         R, Cc, V = np.concatenate(R), np.concatenate(Cc), np.concatenate(V)
         keep = V != 0.0
         return sps.csr_matrix((V[keep], (R[keep], Cc[keep])), shape=(self.n_opt_x, self.n_opt_x))

@@ -57,7 +57,8 @@ def oracle_nlp(name, **over):
     key = (name, tuple(sorted((k, str(v)) for k, v in over.items())))
     if key not in _oracle_cache:
         case = ORACLE_CASES[name](**over)
-        _oracle_cache[key] = (OracleNLPDae if case.get("z") else OracleNLP)(case)       # (models with algebraic states: oracle/nlp_dae.py)
+        dense = case.get("z") or case.get("nl_cons_check_colloc_points")          # (algebraic states / rows at the collocation points: oracle/nlp_dae.py)
+        _oracle_cache[key] = (OracleNLPDae if dense else OracleNLP)(case)
     return _oracle_cache[key]
 
 
@@ -116,7 +117,7 @@ def check_against_oracle_solve(make_mpc, name, x0_scale=1.0, oracle_opts=None, *
     `oracle_opts`: options of oracle.ipm.solve (non-convex cases: inertia="ldl", see NONCONVEX_CASES)."""
     ex = CASES[name]
     mpc = make_mpc(name, **over)
-    o_over = {k: v for k, v in over.items() if k in ("n_horizon", "n_robust", "collocation_deg", "collocation_ni")}
+    o_over = {k: v for k, v in over.items() if k in ("n_horizon", "n_robust", "collocation_deg", "collocation_ni", "nl_cons_check_colloc_points")}
     nlp = oracle_nlp(name, **o_over)
     assert (nlp.n_opt_x, nlp.n_g) == (mpc.structure.n_opt_x, mpc.structure.n_g)
     x0 = ex.X0 * x0_scale
@@ -339,4 +340,34 @@ def check_custom_rterm_vs_oracle(make_mpc, name):
     assert relerr(u0, nlp.u0_of(r["x"])) < U_RTOL, (u0, nlp.u0_of(r["x"]))
     assert relerr(mpc.opt_x_num.master[used], r["x"][used]) < X_RTOL
     assert mpc.solver_stats["iter_count"] == r["stats"]["iter_count"]
+    return mpc
+
+
+NL_COLLOC_CASES = [("CSTR", dict(n_robust=0, nl_cons_check_colloc_points=True), np.array([0.9, 0.4, 140.5, 138.0])),
+                   ("dip", dict(n_horizon=40, nl_cons_check_colloc_points=True), None)]
+
+
+def check_nl_cons_at_collocation_points(make_mpc, name, over, x0):
+    """`nl_cons_check_colloc_points` (_mpc.py:1229-1237): the rows are evaluated at every stored point of the interval - rows on
+    the edge unknowns, dense edge path.  Same iterations as the oracle's solve of the restated NLP (oracle/nlp_dae.py), final
+    iterate and multipliers; CSTR from a start with T_R above the soft limit: rows at the collocation points end active (lam = 0.2)."""
+    mpc = make_mpc(name, **over)
+    nlp = oracle_nlp(name, **over)
+    assert (nlp.n_opt_x, nlp.n_g) == (mpc.structure.n_opt_x, mpc.structure.n_g) and nlp.nlb == mpc.structure.M
+    x0 = CASES[name].X0 if x0 is None else x0
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    mpc.make_step(x0)
+    st = mpc.solver_stats
+    r = ipm.solve(nlp, nlp.initial_guess(x0), mpc.opt_p_num.master.copy())
+    assert st["success"] and r["stats"]["success"]
+    assert st["iter_count"] == r["stats"]["iter_count"] and st["n_reg"] == r["stats"]["n_reg"]
+    used = np.ones(nlp.n_opt_x, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    assert relerr(mpc.opt_x_num.master[used], r["x"][used]) < 1e-9                      # (measured 6e-12 / 4e-13)
+    assert np.max(np.abs(mpc.lam_g_num - r["lam_g"])) < 1e-7 * max(1.0, np.max(np.abs(r["lam_g"])))   # (measured 1e-9 / 2e-15)
+    rows = nlp.row0[:, None] + nlp.rows_per_edge - nlp.ne + np.arange(nlp.ne)[None, :]
+    assert np.array_equal(mpc._nlp_cons_ub[rows], nlp.ubg[rows])
+    if name == "CSTR":
+        assert np.max(np.abs(mpc.lam_g_num[rows])) > 0.1                                 # (a row at a collocation point ends active)
     return mpc

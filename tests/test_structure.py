@@ -60,6 +60,35 @@ def test_unsupported_couplings_are_refused_loudly():
         build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=1, ns=1, deg=2, ni=1, N=5, n_comb=1, n_robust=0, discrete=False, single_slack=True)
 
 
+def test_nl_cons_at_collocation_points_rows_and_refusals():
+    """nl_cons_check_colloc_points (_mpc.py:1229-1237): M evaluations of the rows per edge; refused where the reference's own
+    indexing leaves the edge (branching tree: `_x[k+1, s, i]` with the parent's s) or drops the rows (discrete model)"""
+    from do_mpc_amd import controller
+    from do_mpc_amd.examples import CASES
+    import __graft_entry__ as ge
+    orig = controller.HipIpmSolver
+    controller.HipIpmSolver = ge._NoSolver
+    try:
+        ex = CASES["CSTR"]
+        a = ex.build_mpc(ex.build_model(), n_robust=0)
+        b = ex.build_mpc(ex.build_model(), n_robust=0, nl_cons_check_colloc_points=True)
+        assert b.structure.ne == 3 * a.structure.ne and b.structure.n_g == a.structure.n_g + 2 * a.structure.n_edges
+        assert "#define DOMPC_NL_COLLOC 1" in b.generated_header and "DOMPC_NL_COLLOC" not in a.generated_header
+        with pytest.raises(NotImplementedError, match="scenario chains"):
+            ex.build_mpc(ex.build_model(), n_robust=1, nl_cons_check_colloc_points=True)
+        model = CASES["oscillating_masses"].build_model()
+        mpc = controller.MPC(model)
+        mpc.settings.n_robust, mpc.settings.n_horizon, mpc.settings.t_step = 0, 5, 0.5
+        mpc.settings.nl_cons_check_colloc_points = True
+        mpc.set_objective(mterm=model.aux["cost"], lterm=model.aux["cost"])
+        mpc.set_rterm(u=1e-4)
+        mpc.set_nl_cons("first", model.x["x", 0], ub=3.0)
+        with pytest.raises(NotImplementedError, match="discrete"):
+            mpc.setup()
+    finally:
+        controller.HipIpmSolver = orig
+
+
 def test_algebraic_states_layout():
     """`_z[k][s][c]` follows `_x` (_mpc.py:1126-1134); an interval's block has M (nx + nz) rows (optimizer.py:943-983), a
     discrete DAE nz; the sizes of the reference's DAE goldens (results_dip.pkl: 4330 / 4506, results_oscillatingMasses_dae: 67 / 60)"""
