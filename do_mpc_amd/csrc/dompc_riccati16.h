@@ -9,7 +9,13 @@
 //     * as the A operand of k-block r  for the TRANSPOSED matrix (A[l&15][4r + (l>>4)] = M'[..]),
 // so  tmul(X, Y) = X' Y  is four back-to-back MFMAs on registers: products chain without LDS, barriers or data
 // movement (P_c is symmetric, F' P_c F = tmul(F, tmul(P_c, F)), L' Q L = tmul(L, tmul(Q, L)), ...).
-// Vectors travel as column 0 of a second tile through the same products.
+// Vectors ride INSIDE the matrix tiles (homogeneous coordinates): on gfx950 an FP64 MFMA has the throughput of the FP64 vector
+// ALU (64 cycles per 16x16x4), so a matrix-vector product in a tile of its own costs as much as the matrix-matrix product next
+// to it.  The value function of a node is ONE bordered symmetric tile  V = [[P, p], [p', *]]  (p in column NA and row NA - P is
+// NA x NA with NA <= 15); the child's map F = [A 0 B; 0 0 I] has structurally zero columns at the u_prev entries of z, so
+// column NX carries [c; 1 at row NA]:  F1' V F1  then holds F' P F outside row / column NX and F'(P c + p) in them; the gains
+// Lc = [I; K] and the closed-loop maps Acl = F Lc have free columns >= NA, column NA carries l0 = (0; kv) resp. [F l0 + c; 1].
+// 25 instead of 50 MFMAs per node and child.
 // This replaces the generic LDS-staged riccati_node() (dompc_kernel.h; still used by the host emulation, by models
 // with more than 16 node variables, more than 4 decision variables per node or more than 4 nl_cons rows, and by the
 // tree-sharding build) - the algebra is the same:
@@ -23,6 +29,9 @@ constexpr bool ENABLED = R16_ENABLED;      // (NYT <= 16, at most 4 nl_cons rows
 
 #ifndef DOMPC_HOST_EMU
 constexpr int KB_A = (NA + 3) / 4, KB_Y = (NYT + 3) / 4;
+constexpr int KB_H = (NA + 4) / 4;                 // k-blocks that cover the NA rows of a child's state AND the homogeneous row NA
+constexpr int HR = NA / 4, HG = NA % 4;            // register / lane group of tile row NA
+static_assert(!R16_ENABLED || NA <= 15, "the homogeneous row / column needs NA <= 15");
 template <int KB>
 __device__ inline d4 tmul(const d4& At, const d4& B) { return tile_mul<KB>(At, B); }      // At' * B (dompc_kernel.h)
 __device__ inline double rl(double v, int src) { return lane_bcast(v, src); }
@@ -30,22 +39,22 @@ __device__ inline double rl(double v, int src) { return lane_bcast(v, src); }
 // index of z-entry i inside y = (x_n, u_n) of the condensed edge blocks, or -1 (u_prev, eps)
 __device__ inline int yz(int i) { return (i < NX) ? i : ((i >= NA && i < NA + NU) ? NX + (i - NA) : -1); }
 
-// column-layout vector (lane l holds v[l & 15]) -> column 0 of a tile
-__device__ inline d4 col_to_tile0(double vc, int lane) {
+// column-layout vector (lane l holds v[l & 15]) -> column `col` of a tile (rows < nrow)
+__device__ inline d4 col_to_tile(double vc, int lane, int col, int nrow) {
   const int g = lane >> 4, j = lane & 15;
   d4 t;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const double s = __shfl(vc, g + 4 * r);
-    t[r] = (j == 0) ? s : 0.0;
+    t[r] = (j == col && g + 4 * r < nrow) ? s : 0.0;
   }
   return t;
 }
 
-struct Val { d4 P, p0; };      // value function of a node: P (tile), p (column 0 of a tile)
+typedef d4 Val;                // value function of a node: bordered tile [[P, p], [p', *]] (p in column NA and row NA)
 
 // F tile, c column and rank-update operand of edge e
-__device__ inline void load_edge(const Prob& Q, int e, int lane, d4& F, d4& f0, double& fu) {
+__device__ inline void load_edge(const Prob& Q, int e, int lane, d4& F, d4& cvr, double& fu) {
   const int g = lane >> 4, j = lane & 15;
   const double* S_ = Q.ES(e);
   const int yj = yz(j);
@@ -56,7 +65,7 @@ __device__ inline void load_edge(const Prob& Q, int e, int lane, d4& F, d4& f0, 
     if (i < NX) { if (yj >= 0 && j < NYT) fv = S_[ES_AB + i * NA + yj]; }
     else if (i < NA) fv = (j == NA + (i - NX)) ? 1.0 : 0.0;
     F[r] = fv;
-    f0[r] = (j == 0 && i < NX) ? S_[ES_CV + i] : 0.0;
+    cvr[r] = (i < NX) ? S_[ES_CV + i] : 0.0;
   }
   double v = 0.0;
   if (g < NU) { if (j < NX) v = S_[ES_AB + j * NA + NX + g]; else if (j < NA) v = (g == j - NX) ? 1.0 : 0.0; }
@@ -86,8 +95,10 @@ __device__ inline Val load_val(const Prob& Q, int n, int lane) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = g + 4 * r;
-    V.P[r] = (i < NA && j < NA) ? Nd[ND_P + i * NA + j] : 0.0;
-    V.p0[r] = (i < NA && j == 0) ? Nd[ND_PV + i] : 0.0;
+    double v = (i < NA && j < NA) ? Nd[ND_P + i * NA + j] : 0.0;
+    if (i < NA && j == NA) v = Nd[ND_PV + i];
+    if (i == NA && j < NA) v = Nd[ND_PV + j];
+    V[r] = v;
   }
   return V;
 }
@@ -97,8 +108,8 @@ __device__ inline void store_val(const Prob& Q, int n, const Val& V, int lane) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = g + 4 * r;
-    if (i < NA && j < NA) Nd[ND_P + i * NA + j] = V.P[r];
-    if (i < NA && j == 0) Nd[ND_PV + i] = V.p0[r];
+    if (i < NA && j < NA) Nd[ND_P + i * NA + j] = V[r];
+    if (i < NA && j == NA) Nd[ND_PV + i] = V[r];
   }
 }
 
@@ -113,15 +124,15 @@ __device__ inline Val leaf(const Prob& Q, int n, double mu, double delta, int la
   const double xv = Q.x[xo + jj], lo = Q.lb[xo + jj], hi = Q.ub[xo + jj];
   const double dg = sigma_of(xv, lo, hi, Q.zl[xo + jj], Q.zu[xo + jj]) + delta;
   const double gv = (j < NX) ? S_[ES_MG + jj] - Q.lam[A.edge_row0[ie] + NW + jj] + bar_grad(xv, lo, hi, mu, !(Q.soc & 2)) : 0.0;
-  Val V;
+  Val V = col_to_tile(gv, lane, NA, NX);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = g + 4 * r;
     double v = (i < NX && j < NX) ? S_[ES_MH + i * NX + j] : 0.0;
     if (i == j && j < NX) v += dg;
-    V.P[r] = v;
+    if (i == NA && j < NX) v = gv;
+    V[r] += v;
   }
-  V.p0 = col_to_tile0(gv, lane);
   return V;
 }
 
@@ -163,7 +174,7 @@ __device__ inline void load_node(const Prob& Q, int n, int lane, NodeIn& R) {
   R.nu = (jj < NX) ? ((ie >= 0) ? Q.lam[A.edge_row0[ie] + NW + jj] : Q.lam[jj]) : 0.0;
 }
 // tiles of the staged first child edge (LDS reads)
-__device__ inline void staged_tiles(const ldsd* Ls, int lane, d4& qt, d4& F, d4& f0, double& fu, double& qv) {
+__device__ inline void staged_tiles(const ldsd* Ls, int lane, d4& qt, d4& F, d4& cvr, double& fu, double& qv) {
   const int g = lane >> 4, j = lane & 15;
   const int yj = yz(j);
 #pragma unroll
@@ -178,7 +189,7 @@ __device__ inline void staged_tiles(const ldsd* Ls, int lane, d4& qt, d4& F, d4&
     if (i >= NX && i < NA) fv = (j == NA + (i - NX)) ? 1.0 : 0.0;
     F[r] = fv;
     const double cv = Ls[ES_CV + (i < NX ? i : 0)];
-    f0[r] = (j == 0 && i < NX) ? cv : 0.0;
+    cvr[r] = (i < NX) ? cv : 0.0;
   }
   {
     const double ab = Ls[ES_AB + ((j < NX && g < NU) ? j * NA + NX + g : 0)];
@@ -204,9 +215,9 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
 #else
 #define R16_PN(i)
 #endif
-  d4 qt_s, F, f0;
+  d4 qt_s, F, cvr;
   double fu, qv_s;
-  staged_tiles(Ls, lane, qt_s, F, f0, fu, qv_s);
+  staged_tiles(Ls, lane, qt_s, F, cvr, fu, qv_s);
   R16_PN(12)
   // ---- own quadratic: per-variable terms in column layout (lane: z-entry j)
   double dg = 0.0, gv = 0.0;
@@ -286,18 +297,27 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       }
     }
   }
-  const d4 qo0 = col_to_tile0(gv, lane);
+  const d4 qo0 = col_to_tile(gv, lane, NA, 16);            // own gradient as column NA of a tile (own part below)
   R16_PN(8)
-  // ---- children, pass 1: Q_tot = Q_own + sum F' P_c F ,  q_tot = q_own + sum F'(P_c f + p_c)
-  d4 QT = QO, qt0 = qo0;
+  // ---- children, pass 1: Q_tot = Q_own + sum F' P_c F ,  q_tot = q_own + sum F'(P_c f + p_c).  F1 = F with [c; 1 at the
+  //      homogeneous row] in its zero column NX: F1' V F1 = F' P F outside row / column NX, the vector in them
+  d4 QT = QO;
+  double qvs[NV];                      // decision-variable entries of q_tot (uniform)
+#pragma unroll
+  for (int u = 0; u < NV; ++u) qvs[u] = rl(gv, NA + u);
   Val Vc;
   for (int c = 0; c < cc; ++c) {
-    if (c > 0) load_edge(Q, cs + c, lane, F, f0, fu);
+    if (c > 0) load_edge(Q, cs + c, lane, F, cvr, fu);
     Vc = (c == 0 && first) ? *first : load_val(Q, A.edge_child[cs + c], lane);
-    const d4 Tm = tmul<KB_A>(Vc.P, F);
-    const d4 tv = tmul<KB_A>(Vc.P, f0) + Vc.p0;
-    QT += tmul<KB_A>(F, Tm);
-    qt0 += tmul<KB_A>(F, tv);
+    d4 F1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) F1[r] = (j == NX) ? ((g + 4 * r == NA) ? 1.0 : cvr[r]) : F[r];
+    const d4 Tm = tmul<KB_H>(Vc, F1);
+    const d4 Pr = tmul<KB_H>(F1, Tm);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) QT[r] += (j == NX || g + 4 * r == NX) ? 0.0 : Pr[r];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) qvs[u] += rl(Pr[(NA + u) / 4], 16 * ((NA + u) % 4) + NX);
   }
   R16_PN(9)
   // ---- Cholesky of Q_vv (uniform arithmetic on values read with v_readlane), gains for this lane's column
@@ -310,7 +330,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       const int i = NA + u;
 #pragma unroll
       for (int w = 0; w <= u; ++w) qvv[u * NV + w] = rl(QT[i / 4], 16 * (i % 4) + NA + w);
-      qv[u] = rl(qt0[i / 4], 16 * (i % 4));
+      qv[u] = qvs[u];
       qx[u] = __shfl(QT[i / 4], 16 * (i % 4) + j);
     }
     double Li[NV];                       // reciprocals of the Cholesky diagonal: every division below is a multiplication
@@ -351,44 +371,43 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     for (int u = 0; u < NV; ++u) { kv[u] = -qv[u]; Kj[u] = (j < NA) ? -qx[u] : 0.0; }
   }
   R16_PN(10)
-  // ---- Lc = [I;K], l0 = (0;kv) as tiles; operands of the rank-NV updates
-  d4 Lc, l0;
+  // ---- Lc = [I;K | l0 = (0;kv) in column NA] as a tile; operand of the rank-NV updates
+  d4 Lc;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int k = g + 4 * r;
-    double v = (k < NA) ? ((k == j) ? 1.0 : 0.0) : 0.0, w0 = 0.0;
+    double v = (k < NA) ? ((k == j) ? 1.0 : 0.0) : 0.0;
 #pragma unroll
     for (int u = 0; u < NV; ++u)
-      if (k == NA + u) { v = Kj[u]; w0 = kv[u]; }
+      if (k == NA + u) v = (j == NA) ? kv[u] : Kj[u];
     Lc[r] = v;
-    l0[r] = (j == 0) ? w0 : 0.0;
   }
-  double bK = 0.0, bkv = 0.0;
+  double bK = 0.0;
 #pragma unroll
   for (int u = 0; u < NV; ++u)
-    if (g == u) { bK = Kj[u]; bkv = (j == 0) ? kv[u] : 0.0; }
-  // ---- own part of the value function: Lc' Q_own Lc, Lc'(q_own + Q_own l0)
+    if (g == u) bK = (j == NA) ? kv[u] : Kj[u];
+  // ---- own part of the value function: Lc' Q_own Lc, Lc'(q_own + Q_own l0) in column NA; row NA completed by Lc' q_own
+  //      (z has no homogeneous entry - all 16 are variables -, so q_own enters the column by an addition and the row here)
   {
-    const d4 U = tmul<KB_Y>(QO, Lc);
-    const d4 u0 = tmul<KB_Y>(QO, l0) + qo0;
-    out.P = tmul<KB_Y>(Lc, U);
-    out.p0 = tmul<KB_Y>(Lc, u0);
+    const d4 U = tmul<KB_Y>(QO, Lc) + qo0;
+    out = tmul<KB_Y>(Lc, U);
+    double t = gv;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) t += Kj[u] * rl(gv, NA + u);
+    if (g == HG && j < NA) out[HR] += t;
   }
   // ---- children, pass 2: closed-loop maps Acl = F Lc, ccl = F l0 + f ; P += Acl' P_c Acl
   for (int c = cc - 1; c >= 0; --c) {
     if (c != cc - 1) {                       // (the last child of pass 1 is still in registers)
-      load_edge(Q, cs + c, lane, F, f0, fu);
+      load_edge(Q, cs + c, lane, F, cvr, fu);
       Vc = (c == 0 && first) ? *first : load_val(Q, A.edge_child[cs + c], lane);
     }
-    d4 Fy;
+    d4 Fy;                                   // [F over (x, u_prev) | c ; homogeneous 1]  ->  Acl = [F Lc | F l0 + c ; 1]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Fy[r] = (j < NA) ? F[r] : 0.0;
+    for (int r = 0; r < 4; ++r) Fy[r] = (j < NA) ? F[r] : ((j == NA) ? ((g + 4 * r == NA) ? 1.0 : cvr[r]) : 0.0);
     const d4 Acl = __builtin_amdgcn_mfma_f64_16x16x4f64(fu, bK, Fy, 0, 0, 0);
-    const d4 ccl = __builtin_amdgcn_mfma_f64_16x16x4f64(fu, bkv, f0, 0, 0, 0);
-    const d4 T2 = tmul<KB_A>(Vc.P, Acl);
-    const d4 tv2 = tmul<KB_A>(Vc.P, ccl) + Vc.p0;
-    out.P += tmul<KB_A>(Acl, T2);
-    out.p0 += tmul<KB_A>(Acl, tv2);
+    const d4 T2 = tmul<KB_H>(Vc, Acl);
+    out += tmul<KB_H>(Acl, T2);
   }
   // All global stores of the node at its very end, behind one wait for the operands that were requested for the NEXT
   // node (LDS-DMA copy, register prefetch): on gfx9 stores count in vmcnt like loads, so a wait for data issued after
