@@ -66,6 +66,7 @@ extern "C" __global__ void __launch_bounds__(256, DOMPC_LB) dompc_solve_kernel(d
   if (wide && slot >= A.batch) return;
   Thr T = make_thr(A);
   T.kp = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+  if (wide && A.mode != 1) dompc::xcd_census(T);
   if (A.mode == 1) {
     if (blockIdx.x == 0) dompc::debug_newton(T, A);
     return;

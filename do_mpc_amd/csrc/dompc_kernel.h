@@ -237,6 +237,9 @@ struct Thr {
   XCtx X;           // tree sharding: exchange buffer and handshake words (X.on == 0: not sharded)
   mutable unsigned xseq;
   const void* kp;   // device: the kernel's argument block in the kernarg segment (handed to the outlined phases)
+  // wide mode: every workgroup of the problem runs on the SAME XCD (verified at kernel start from HW_REG_XCC_ID, xcd_census):
+  // they share one L2, so the release side of the barrier needs no L2 write-back - the stores only have to have left the CU
+  mutable bool light = false;
   // flags: LDS words in a one-workgroup problem; global words shared by the K workgroups of a wide problem - those are
   // read and written with agent-scope atomics (a plain load could be served from this CU's L1).
   DOMPC_DEV void fset(int i, int v) const {
@@ -264,7 +267,7 @@ struct Thr {
       __syncthreads();
       ++gen;
       if (ltid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (!light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // (buffer_wbl2 sc1: 1.7 - 6.5 us per barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = gen * (unsigned)nwg;
@@ -338,6 +341,9 @@ extern __shared__ double lds_pool[];
 __shared__ double lds_filt[2 * MAX_FILTER];
 __shared__ int lds_flags[8];
 __shared__ int lds_b;
+#ifndef DOMPC_LIGHT_BARRIER
+#define DOMPC_LIGHT_BARRIER 1       // wide mode: barrier without the L2 write-back when the problem's workgroups share an XCD (0: always write back)
+#endif
 #ifndef DOMPC_PROFILE
 #define DOMPC_PROFILE 0             // 1: sub-phase shader-clock counters of the edge sweep / node update (tools/gpu_profile.py)
 #endif
@@ -360,7 +366,26 @@ __device__ inline Thr make_thr(const KArgs& A) {
   return Thr{j * (int)blockDim.x + (int)threadIdx.x, K * (int)blockDim.x, (ldsd*)lds_pool, (ldsd*)lds_filt,
              wide ? A.wide_flags + slot * 8 : lds_flags, (ldsd*)lds_pool, lds_prof, 64,
              (int)threadIdx.x, (int)blockDim.x, j, K, wide ? A.wide_bar + slot * 16 : nullptr,
-             wide ? A.wide_partials + (int64_t)slot * 2 * K * RED_MAX : nullptr, 0u, 0u, make_xctx(A), 0u, nullptr};
+             wide ? A.wide_partials + (int64_t)slot * 2 * K * RED_MAX : nullptr, 0u, 0u, make_xctx(A), 0u, nullptr,
+             (wide && DOMPC_LIGHT_BARRIER) ? __hip_atomic_load(A.wide_bar + slot * 16 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u : false};
+}
+// wide mode, once per launch: do all workgroups of this problem run on one XCD?  Every workgroup publishes its XCC id
+// (hardware register), the first workgroup writes the verdict (word 2 of the slot's barrier block: 1 = one XCD, 2 = several)
+// between two full barriers; make_thr of the outlined phases reads it back.  Placement is NOT assumed (the dispatcher puts
+// block b on XCD b % 8 today, slot_of_block): on any other placement the barrier keeps its L2 write-back.
+__device__ inline void xcd_census(const Thr& T) {
+  if (T.nwg <= 1 || !DOMPC_LIGHT_BARRIER) return;
+  if (T.ltid == 0) {
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;          // HW_REG_XCC_ID[3:0]
+    __hip_atomic_fetch_or(T.bar + 1, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  T.sync();
+  if (T.tid == 0) {
+    const unsigned m = __hip_atomic_load(T.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(T.bar + 2, (m & (m - 1u)) == 0u ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  T.sync();
+  T.light = __hip_atomic_load(T.bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
 }
 // wave-uniform copies of values that reach an outlined function in vector registers
 __device__ inline int ufl(int v) { return __builtin_amdgcn_readfirstlane(v); }
