@@ -11,7 +11,7 @@ With real CasADi installed do not call install(); use the ctypes stub of INTEGRA
 import sys
 import types
 
-from . import controller, differentiator, model, sampling, simulator, structs, sym
+from . import controller, differentiator, estimator, model, sampling, simulator, structs, sym
 
 _CASADI_NAMES = [
     "SX", "DM", "vertcat", "horzcat", "vertsplit", "mtimes", "sum1", "sum2", "sumsqr", "dot", "exp", "log", "sqrt", "sin",
@@ -78,6 +78,7 @@ def install(force: bool = False):
         m_sim.Simulator = simulator.Simulator
         m_est = types.ModuleType("do_mpc.estimator")
         m_est.StateFeedback = StateFeedback
+        m_est.MHE, m_est.MHESettings = estimator.MHE, estimator.MHESettings
         m_diff = types.ModuleType("do_mpc.differentiator")
         m_diff.DoMPCDifferentiator = differentiator.DoMPCDifferentiator
         m_samp = types.ModuleType("do_mpc.sampling")

@@ -153,6 +153,9 @@ class MPCData:
         rows = self.__dict__.get("_rows", {})
         if key in rows:
             return np.vstack(rows[key])
+        model = self.__dict__.get("model")
+        if model is not None and key in ("_x", "_u", "_z", "_y", "_p", "_tvp", "_aux"):      # nothing recorded yet: (0, n) like the reference
+            return np.zeros((0, model._getvar(key).size))
         raise AttributeError(key)
 
 
@@ -464,6 +467,9 @@ class MPC:
 
         discrete = m.model_type == "discrete"
         n_eval = (s.collocation_deg + 1) * s.collocation_ni if self._nl_colloc else 1      # evaluations of the rows per edge
+        est = getattr(self, "_estimator_opts", None) or {}          # (set by do_mpc_amd.estimator.MHE: free initial state etc.)
+        if est.get("nl_dup") and self._nl_rows:
+            n_eval += 1                                             # (_mhe.py:1186-1188: the rows of the last point once more)
         ps = build_structure(nx=m.n_x, nu=m.n_u, nz=m.n_z, np_=m.n_p, ntvp=m.n_tvp, ne=len(self._nl_rows) * n_eval,
                              ns=self.n_eps, deg=s.collocation_deg, ni=s.collocation_ni, N=s.n_horizon,
                              n_comb=self.n_combinations, n_robust=s.n_robust, discrete=discrete,
@@ -568,7 +574,9 @@ class MPC:
             name=type(m).__name__, nz=m.n_z, z_sym=m._z.cat.nodes(), alg=alg, sz=self._z_scaling.master,
             sp=self._p_scaling.master,
             rterm_expr=(self.rterm_expr.nodes()[0] if self.rterm_expr is not None else None),
-            uprev_sym=self.u_prev.cat.nodes(), nl_colloc=self._nl_colloc)
+            uprev_sym=self.u_prev.cat.nodes(), nl_colloc=self._nl_colloc,
+            **{k: v for k, v in (getattr(self, "_estimator_opts", None) or {}).items()
+               if k in ("arrival", "xprev_sym", "lterm_end", "nl_dup")})
 
     def create_nlp(self, _solver_factory=None) -> None:
         assert self.flags["prepare_nlp"], "call prepare_nlp() first"

@@ -77,15 +77,16 @@ DOMPC_DEV inline int vtarget(int el, int j, int i) {
 }
 // inputs of the stage cost: (x_n, u, z of the LAST point), of nl_cons: (x_n, u, z of the FIRST point)  (_mpc.py:1252, 1241)
 DOMPC_DEV inline int vtarget_stage(int i, bool last_z) {
+  if (LT_END && last_z && i < NX) return (M - 1) * NX + i;        // (estimator: the stage cost reads the END state of the interval)
   if (i < NA) return NW + i;
   return NWX + (last_z ? (MZ - 1) : 0) * NZ + (i - NA);
 }
 // inputs of nl_cons evaluation `blk`: (x_n, u, z of the first point), or with nl_cons_check_colloc_points (x slot blk, u, z slot blk)
 DOMPC_DEV inline int vtarget_nl(int blk, int i) {
   if (!NL_COLLOC) return vtarget_stage(i, false);
-  if (i < NX) return blk * NX + i;
+  if (i < NX) return nl_pt(blk) * NX + i;
   if (i < NA) return NW + i;
-  return NWX + blk * NZ + (i - NA);
+  return NWX + nl_pt(blk) * NZ + (i - NA);
 }
 }  // namespace dae
 
@@ -117,14 +118,14 @@ DOMPC_DEV inline void dae_eval_item(const Prob& Q, int kind, int e, int j) {
     double* pt = mo + MO_PT + j * PT_STRIDE;
     dompc_dyn(xp, un, zb + j * NZ, tvp, pp, lamv, pt, pt + NF, pt + NF + NF * NAV);
   } else if (kind == 1) {
-    dompc_lterm(xn, un, zb + (MZ - 1) * NZ, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NAV);
+    dompc_lterm(LT_END ? w + (M - 1) * NX : xn, un, zb + (MZ - 1) * NZ, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NAV);
   } else if (kind == 2) {
     if (k == A.N - 1)
       dompc_mterm(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1, mo + MO_MT + 1 + NX);
   } else if (NE > 0) {
     for (int blk = 0; blk < NLB; ++blk) {
       double* o = mo + MO_NL + blk * NL_STRIDE;
-      dompc_nlcons(NL_COLLOC ? w + blk * NX : xn, un, zb + (NL_COLLOC ? blk * NZ : 0), tvp, pp, Q.lam + row0 + NW + NX + blk * NEB,
+      dompc_nlcons(NL_COLLOC ? w + nl_pt(blk) * NX : xn, un, zb + (NL_COLLOC ? nl_pt(blk) * NZ : 0), tvp, pp, Q.lam + row0 + NW + NX + blk * NEB,
                    o, o + NEB, o + NEB + NEB * NAV);
     }
   }
@@ -177,13 +178,13 @@ DOMPC_DEV inline double dae_edge_f(const Prob& Q, int e, const double* xv, const
     }
     for (int a = 0; a < NX; ++a) cv[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
   }
-  double obj = om * dompc_lterm_f(xn, un, zb + (MZ - 1) * NZ, tvp, pp);
+  double obj = om * dompc_lterm_f(LT_END ? w + (M - 1) * NX : xn, un, zb + (MZ - 1) * NZ, tvp, pp);
   if (k == A.N - 1) obj += om * dompc_mterm_f(xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
   if (RT_CUSTOM) obj += edge_rterm_f(Q, e, xv);
   if (NE > 0) {
     double d[NE1];
     for (int blk = 0; blk < NLB; ++blk)
-      dompc_nlcons_f(NL_COLLOC ? w + blk * NX : xn, un, zb + (NL_COLLOC ? blk * NZ : 0), tvp, pp, d + blk * NEB);
+      dompc_nlcons_f(NL_COLLOC ? w + nl_pt(blk) * NX : xn, un, zb + (NL_COLLOC ? nl_pt(blk) * NZ : 0), tvp, pp, d + blk * NEB);
     const double* eps = (NS > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
       if (nl_slack(i) >= 0) d[i] -= eps[nl_slack(i)];

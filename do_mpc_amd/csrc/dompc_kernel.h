@@ -47,14 +47,36 @@ constexpr int DEG = DOMPC_DEG, NI = DOMPC_NI, M = DOMPC_M;
 #ifndef DOMPC_NL_COLLOC
 #define DOMPC_NL_COLLOC 0
 #endif
+// Estimators (moving horizon estimation, _mhe.py:1030-1211) run on the same kernels with three switches of the generated header:
+//   DOMPC_FREE_ROOT  the initial state is a free variable with an arrival cost dompc_aterm(x_0; previous estimate in the `_x0` slot of
+//                    opt_p) instead of the initial-condition rows (which stay in g as 0 = 0, multipliers 0);
+//   DOMPC_LT_END     the stage cost of an edge reads the END state of the interval (the measurement residual of stage k);
+//   DOMPC_NL_DUP     the nl_cons rows of the last evaluated point appear a second time (_mhe.py:1186-1188).
+#ifndef DOMPC_FREE_ROOT
+#define DOMPC_FREE_ROOT 0
+#endif
+#ifndef DOMPC_LT_END
+#define DOMPC_LT_END 0
+#endif
+#ifndef DOMPC_NL_DUP
+#define DOMPC_NL_DUP 0
+#endif
+#if !DOMPC_FREE_ROOT
+DOMPC_FN double dompc_aterm_f(const double*, const double*, const double*, const double*) { return 0.0; }
+DOMPC_FN void dompc_aterm(const double*, const double*, const double*, const double*, double*, double*, double*) {}
+#endif
+constexpr bool FREE_ROOT = DOMPC_FREE_ROOT != 0, LT_END = DOMPC_LT_END != 0 && M > 0;
 constexpr int NEB = DOMPC_NE;                               // rows of one evaluation
-constexpr int NLB = (DOMPC_NL_COLLOC && M > 0) ? M : 1;     // evaluations per edge
+constexpr int NLP = (DOMPC_NL_COLLOC && M > 0) ? M : 1;     // points at which the rows are evaluated
+constexpr bool NL_DUP = DOMPC_NL_DUP != 0 && NEB > 0;
+constexpr int NLB = NLP + (NL_DUP ? 1 : 0);                 // evaluations per edge
 constexpr int NE = NEB * NLB;
 constexpr bool NL_COLLOC = DOMPC_NL_COLLOC && M > 0 && NEB > 0;
+DOMPC_HD constexpr int nl_pt(int blk) { return blk < NLP ? blk : NLP - 1; }      // point of evaluation `blk`
 #ifndef DOMPC_FORCE_DENSE
 #define DOMPC_FORCE_DENSE 0        // test aid: 1 = a model without algebraic states through the dense edge path as well
 #endif
-constexpr bool DENSE_EDGE = DOMPC_NZ > 0 || NL_COLLOC || DOMPC_FORCE_DENSE;      // edge path: dense (dompc_dae.h) instead of the single-element fast path
+constexpr bool DENSE_EDGE = DOMPC_NZ > 0 || NL_COLLOC || NL_DUP || LT_END || DOMPC_FORCE_DENSE;      // edge path: dense (dompc_dae.h) instead of the single-element fast path
 DOMPC_HD inline int nl_slack(int i) { return DOMPC_NL_SLACK[NLB == 1 ? i : i % NEB]; }
 constexpr int NA = NX + NU;          // (x,u) of a stage == augmented state (x,u_prev)
 constexpr int NV = NU + NS;          // decision variables of a node: u then eps
@@ -161,7 +183,9 @@ constexpr int ND_PV = ND_P + NA * NA;
 constexpr int ND_K = ND_PV + NA;             // NV x NA
 constexpr int ND_KV = ND_K + NV * NA;
 constexpr int ND_DXT = ND_KV + NV;           // NA
-constexpr int ND_SIZE = ((ND_DXT + NA + 7) / 8) * 8;
+constexpr int ND_AT = ND_DXT + NA;           // FREE_ROOT, used in the root's record: arrival cost value, gradient (NX), Hessian (NX x NX), times the objective scaling
+constexpr int AT_LEN = FREE_ROOT ? 1 + NX + NX * NX : 0;
+constexpr int ND_SIZE = ((ND_AT + AT_LEN + 7) / 8) * 8;
 
 struct WsLayout {
   int64_t x, zl, zu, lb, ub, dx, gf, rd, xt, dx_sv;
@@ -835,7 +859,7 @@ constexpr int EL_RT = EL_RY + NA;                                      // user-d
 #endif
 // (a user-defined rterm expression is not supported by tree sharding: the cut-parent update keeps the analytic form;
 //  MPC.shard_tree refuses it)
-constexpr bool R16_ENABLED = (NYT <= 16) && (NV <= 4) && (DOMPC_R16_NL ? (NE <= 4) : (NE == 0 && NS == 0)) && (DOMPC_SHARD == 0) && !RT_CUSTOM;   // dompc_riccati16.h (device)
+constexpr bool R16_ENABLED = (NYT <= 16) && (NV <= 4) && (DOMPC_R16_NL ? (NE <= 4) : (NE == 0 && NS == 0)) && (DOMPC_SHARD == 0) && !RT_CUSTOM && !FREE_ROOT;   // dompc_riccati16.h (device)
 #ifndef DOMPC_HOST_EMU
 constexpr bool RB_IN_LDS = !R16_ENABLED;
 #else
@@ -2358,6 +2382,9 @@ DOMPC_DEV inline void assemble_finish(const Prob& Q, int n, const double* in) {
     if (ie >= 0) {
       rx -= Q.lam[A.edge_row0[ie] + NW + a];
       if (cc == 0) { const double mg = Q.ES(ie)[ES_MG + a]; gx += mg; rx += mg; }
+    } else if (FREE_ROOT) {
+      const double ga = Q.ND(0)[ND_AT + 1 + a];      // free initial state: gradient of the arrival cost
+      gx += ga; rx += ga;
     } else {
       rx += Q.lam[a];
     }
@@ -2557,6 +2584,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
       }
     }
     gv += R.pv[v][8];
+    if (FREE_ROOT && n == 0 && i0 < NX) gv += Nd[ND_AT + 1 + i];
     if (yi >= 0)
       for (int c = 1; c < cc; ++c) gv += Q.ES(cs + c)[ES_QV + yi];
     gvv[v] = gv;
@@ -2624,6 +2652,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
       const int i = it / NYT, j = it % NYT;
       double v = qacc[q];
       if (i == j) v += Ld[RB_QF + i * NYT + i];
+      if (FREE_ROOT && n == 0 && i < NX && j < NX) v += Nd[ND_AT + 1 + NX + i * NX + j];
       if (RT_CUSTOM) {
         // Hessian of the user-defined rterm over (x, u, u_prev), summed over the edges leaving the node
         auto rz = [](int t) { return t < NX ? t : (t < NA ? NA + (t - NX) : (t < NA + NU ? NX + (t - NA) : -1)); };
@@ -3190,6 +3219,42 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
     T.sync();
     if (T.fget(0) && (!sh_on(A) || k < A.cut_level - 1)) return 1;
   }
+  if (FREE_ROOT) {
+    // free initial state: its step minimises the root's value function (which holds the arrival cost),
+    // P_xx dx = -p_x; P_xx must be positive definite (inertia of the whole system) - else the caller raises delta_w
+    T.sync();
+    if (T.tid == 0) {
+      double* Nd = Q.ND(0);
+      constexpr int N1 = NX > 0 ? NX : 1;
+      double L[N1 * N1], y[N1];
+      bool bad = false;
+      for (int i = 0; i < NX; ++i)
+        for (int j = 0; j <= i; ++j) {
+          double t = Nd[ND_P + i * NA + j];
+          for (int q = 0; q < j; ++q) t -= L[i * NX + q] * L[j * NX + q];
+          if (i == j) {
+            if (!(t > 0.0)) { bad = true; t = 1.0; }
+            L[i * NX + i] = sqrt(t);
+          } else {
+            L[i * NX + j] = t / L[j * NX + j];
+          }
+        }
+      for (int i = 0; i < NX; ++i) {
+        double t = -Nd[ND_PV + i];
+        for (int q = 0; q < i; ++q) t -= L[i * NX + q] * y[q];
+        y[i] = t / L[i * NX + i];
+      }
+      for (int i = NX - 1; i >= 0; --i) {
+        double t = y[i];
+        for (int q = i + 1; q < NX; ++q) t -= L[q * NX + i] * y[q];
+        y[i] = t / L[i * NX + i];
+      }
+      for (int a = 0; a < NA; ++a) Nd[ND_DXT + a] = (a < NX) ? y[a] : 0.0;
+      if (bad) T.fset(0, 1);
+    }
+    T.sync();
+    if (T.fget(0)) return 1;
+  }
   return 0;
 }
 
@@ -3218,7 +3283,11 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   if (T.tid == 0) {
     double* Nd = Q.ND(0);
     const int xo = A.node_x_off[0];
-    for (int a = 0; a < NX; ++a) { Nd[ND_DXT + a] = -Q.c[a]; Q.dx[xo + a] = -Q.c[a]; }
+    if (FREE_ROOT) {                                         // (the step of the free initial state was formed at the end of the backward pass)
+      for (int a = 0; a < NX; ++a) Q.dx[xo + a] = Nd[ND_DXT + a];
+    } else {
+      for (int a = 0; a < NX; ++a) { Nd[ND_DXT + a] = -Q.c[a]; Q.dx[xo + a] = -Q.c[a]; }
+    }
     for (int a = NX; a < NA; ++a) Nd[ND_DXT + a] = 0.0;
   }
   T.sync();
@@ -3353,7 +3422,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     const double* Nd = Q.ND(0);
     double t = Nd[ND_PV + a];
     for (int b = 0; b < NA; ++b) t += Nd[ND_P + a * NA + b] * Nd[ND_DXT + b];
-    Q.dlam[a] = -t;
+    Q.dlam[a] = FREE_ROOT ? 0.0 : -t;
   }
   // per edge: dw, d nu, d lambda, nl_cons steps.  The collocation steps come from the stored inverse block,
   //     dw = -G_w^-1 (G_y dy + r),   G_y dy: -C_0j dx / -D_0 dx on the rows of the first element, J_u du on the collocation rows,
@@ -3626,7 +3695,18 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
 #endif
   (void)pc0;
   if (!Q.soc)
-    for (int g = T.tid; g < NX; g += T.nt) Q.c[g] = Q.x[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
+    for (int g = T.tid; g < NX; g += T.nt) Q.c[g] = FREE_ROOT ? 0.0 : Q.x[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
+  if (FREE_ROOT && T.tid == 0) {
+    // arrival cost of the free initial state (value, gradient, Hessian) into the root's node record
+    double* at = Q.ND(0) + ND_AT;
+    double hp[NX_T > 0 ? NX_T : 1], gr[NX > 0 ? NX : 1], val = 0.0;
+    dompc_aterm(Q.x + A.node_x_off[0], Q.P, Q.P + A.p_off_tvp, Q.P + A.p_off_p, &val, gr, hp);
+    const double wh = (Q.soc & 2) ? 0.0 : Q.sf;
+    at[0] = Q.sf * val;
+    for (int a = 0; a < NX; ++a) at[1 + a] = Q.sf * gr[a];
+    for (int a = 0; a < NX; ++a)
+      for (int b = 0; b < NX; ++b) at[1 + NX + a * NX + b] = wh * hp[symi(a, b, NX)];
+  }
   eval_models(T, Q);
   T.sync();
   DOMPC_PS(21)
@@ -3810,6 +3890,7 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, const Comp* pre) {
     if (sh_cnt(A, mk_e(A, e))) v[3] += Q.ES(e)[ES_OBJ];
   for (int n = T.tid; n < A.n_nodes; n += T.nt)
     if (sh_cnt(A, mk_n(A, n))) v[3] += node_rterm_f(Q, n, Q.x);
+  if (FREE_ROOT && T.tid == 0) v[3] += Q.ND(0)[ND_AT];
   v[5] = C.smax; v[6] = -C.smin; v[7] = C.sum_z;
   const int ops[8] = {R_MAX, R_MAX, R_SUM, R_SUM, R_SUM, R_MAX, R_MAX, R_SUM};
   wg_reduce(T, v, ops);
@@ -3930,7 +4011,8 @@ DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, do
     Q.st[si] = Q.s[si] + al * Q.ds[si];
   }
   T.sync();
-  for (int g = T.tid; g < NX; g += T.nt) Q.ct[g] = Q.xt[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
+  for (int g = T.tid; g < NX; g += T.nt) Q.ct[g] = FREE_ROOT ? 0.0 : Q.xt[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
+  if (FREE_ROOT && T.tid == 0) r3[0] += Q.sf * dompc_aterm_f(Q.xt + A.node_x_off[0], Q.P, Q.P + A.p_off_tvp, Q.P + A.p_off_p);
   r3[0] += trial_edges(T, Q);
   T.sync();
   {

@@ -1,0 +1,571 @@
+"""Moving horizon estimation with do_mpc.estimator.MHE's user surface on the MI355X IPM backend.
+
+Reference surface mirrored here (same names, argument meaning and error behaviour):
+  MHE(model, p_est_list)                       /root/reference/do_mpc/estimator/_mhe.py:150-233
+  set_objective / set_default_objective        :489-716
+  get_p_template / set_p_fun / get_y_template / set_y_fun / get_tvp_template / set_tvp_fun   :717-801, optimizer.py:588-676
+  bounds / scaling / set_nl_cons               optimizer.py:268-541 (with `_p_est` as a variable type)
+  setup / set_initial_guess / make_step        :864-993
+  opt_x = [_x | _z | _u | _w | _v | _eps | _p_est], opt_p = [_x_prev | _p_est_prev | _p_set | _tvp | _y_meas]   :1052-1094
+
+Below the surface the estimation problem runs on the kernels of the controller (structured interior point: per-interval
+elimination + Riccati recursion over the horizon, csrc/).  Its NLP (_mhe.py:1030-1211) is a chain like the controller's with
+four differences, each a switch of the generated header (csrc/dompc_kernel.h: DOMPC_FREE_ROOT / DOMPC_LT_END / DOMPC_NL_DUP):
+  * the initial state is FREE and carries the arrival cost; the previous estimate sits where the controller has x0;
+  * the estimated parameters `_p_est` are ONE variable for the whole horizon.  Here they ride as additional states with
+    d/dt = 0: every stored point of the horizon has its own copy, tied together by the (linear) collocation and continuity
+    rows of those states - the same feasible set, objective and barrier terms in the reduced space, hence the same solution
+    (the interior-point iterates differ from IPOPT's on the reference's formulation; solutions agree to the solver tolerance);
+  * the measurement rows  h(x_{k+1}, u_k, tvp_k, p) + v_k = y_k  are solved for the measurement noise v_k, which only
+    appears in the stage cost: the cost of stage k becomes a function of the END state of the interval (every measurement
+    must carry its noise term - `set_meas(..., meas_noise=True)`, the default);
+  * process noise `_w` is one more input of the interval.
+`opt_x_num`, `opt_p_num`, `lam_g_num` are handed out in the reference's layout.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from . import sym
+from .controller import MPC, MPCData, _Indexed
+from .model import Model, VarGroup
+from .structs import Entry, Layout, NumStruct
+
+
+@dataclass
+class MHESettings:
+    n_horizon: int = None
+    t_step: float = None
+    meas_from_data: bool = True
+    state_discretization: str = "collocation"
+    collocation_type: str = "radau"
+    collocation_deg: int = 2
+    collocation_ni: int = 1
+    nl_cons_check_colloc_points: bool = False
+    nl_cons_single_slack: bool = False
+    cons_check_colloc_points: bool = True
+    store_full_solution: bool = False
+    store_lagr_multiplier: bool = True
+    store_solver_stats: List[str] = field(default_factory=lambda: ["success", "t_wall_total"])
+    nlpsol_opts: Dict = field(default_factory=dict)
+    gpu_index: int = 0
+    max_batch: int = 1
+    block_threads: int = 0
+
+    def check_for_mandatory_settings(self):
+        if self.n_horizon is None:
+            raise ValueError("n_horizon must be set")
+        if self.t_step is None:
+            raise ValueError("t_step must be set")
+
+    def supress_ipopt_output(self):
+        self.nlpsol_opts.update({"ipopt.print_level": 0, "ipopt.sb": "yes", "print_time": 0})
+
+    def set_linear_solver(self, solver_name: str = "MA27"):
+        self.nlpsol_opts.update({"ipopt.linear_solver": solver_name})
+
+
+def _arr(v) -> np.ndarray:
+    return np.asarray(v.master if hasattr(v, "master") else v, dtype=float).reshape(-1)
+
+
+def _group(kind: str, items) -> VarGroup:
+    g = VarGroup(kind)
+    for n, v in items:
+        g.add(n, v)
+    return g
+
+
+class MHE:
+    def __init__(self, model: Model, p_est_list: list = [], settings: Optional[MHESettings] = None):
+        assert model.flags["setup"] is True, "Model for MHE was not setup. After the complete model creation call model.setup()."
+        if model.n_z:
+            raise NotImplementedError("structured HIP backend: MHE for models with algebraic states")
+        if model.model_type != "continuous":
+            raise NotImplementedError("structured HIP backend: MHE for discrete models (the stage cost of an interval reads its end state, "
+                                      "which is a node variable there)")
+        self.model = m = model
+        self.settings = self._settings = settings if settings is not None else MHESettings()
+        pn = [n for n in m._p.names if m._p.vars[n].numel() > 0]
+        for n in p_est_list:
+            assert n in pn, "The item {} in p_est_list is not a parameter of the model".format(n)
+        self._p_est = _group("_p_est", [(n, m._p.vars[n]) for n in pn if n in p_est_list])
+        self._p_set = _group("_p_set", [(n, m._p.vars[n]) for n in pn if n not in p_est_list])
+        self._p_est_prev = _group("_p_est_prev", [(n, sym.SX.sym(n + "_prev", *m._p.vars[n].shape)) for n in self._p_est.names])
+        self._x_prev = _group("_x_prev", [(n, sym.SX.sym(n + "_prev", *m._x.vars[n].shape)) for n in m._x.names])
+        self._x, self._w, self._v = m._x, m._w, m._v
+        self.n_p_est, self.n_p_set = self._p_est.size, self._p_set.size
+        self._x_lb, self._x_ub = m._x(-np.inf), m._x(np.inf)
+        self._u_lb, self._u_ub = m._u(-np.inf), m._u(np.inf)
+        self._z_lb, self._z_ub = m._z(-np.inf), m._z(np.inf)
+        self._p_est_lb, self._p_est_ub = self._p_est(-np.inf), self._p_est(np.inf)
+        self._x_scaling, self._u_scaling, self._z_scaling = m._x(1.0), m._u(1.0), m._z(1.0)
+        self._p_est_scaling, self._p_set_scaling = self._p_est(1.0), self._p_set(1.0)
+        self._x0, self._u0, self._z0, self._t0 = m._x(0.0), m._u(0.0), m._z(0.0), np.array([0.0])
+        self._p_est0 = self._p_est(0.0)
+        self.nl_cons_list: List[dict] = []
+        self.flags = {"setup": False, "set_objective": False, "set_tvp_fun": False, "set_p_fun": False, "set_y_fun": False,
+                      "set_initial_guess": False}
+        self.bounds = _Indexed(self._get_bounds, self._set_bounds)
+        self.scaling = _Indexed(self._get_scaling, self._set_scaling)
+        self.data = MPCData(model)
+        self.solver_stats: dict = {}
+
+    # ------------------------------------------------------------------ settings, bounds, scaling
+    def set_param(self, **kwargs) -> None:
+        assert self.flags["setup"] is False, "Setting parameters after setup is prohibited."
+        for key, value in kwargs.items():
+            if hasattr(self.settings, key):
+                setattr(self.settings, key, value)
+            else:
+                print("Warning: Key {} does not exist for MHE.".format(key))
+
+    def _bound_struct(self, ind):
+        assert isinstance(ind, tuple) and len(ind) >= 2, "Power index must include bound_type, var_type, var_name (as a tuple)."
+        bound_type, var_type, var_name = ind[0], ind[1], ind[2:]
+        if bound_type not in ("lower", "upper"):
+            raise Exception("Invalid power index {} for bound_type. Must be from (lower, upper).".format(bound_type))
+        tab = {("lower", "_x"): self._x_lb, ("upper", "_x"): self._x_ub, ("lower", "_u"): self._u_lb, ("upper", "_u"): self._u_ub,
+               ("lower", "_z"): self._z_lb, ("upper", "_z"): self._z_ub, ("lower", "_p_est"): self._p_est_lb, ("upper", "_p_est"): self._p_est_ub}
+        if (bound_type, var_type) not in tab:
+            raise Exception("Invalid power index {} for var_type. Must be from (_x, _u, _z, _p_est).".format(var_type))
+        return tab[(bound_type, var_type)], var_name
+
+    def _get_bounds(self, ind):
+        st, name = self._bound_struct(ind)
+        return st[name] if name else st
+
+    def _set_bounds(self, ind, val):
+        st, name = self._bound_struct(ind)
+        st[name] = val
+
+    def _scaling_struct(self, ind):
+        tab = {"_x": self._x_scaling, "_u": self._u_scaling, "_z": self._z_scaling, "_p_est": self._p_est_scaling, "_p_set": self._p_set_scaling}
+        if ind[0] not in tab:
+            raise Exception("Invalid power index {} for var_type. Must be from (_x, _u, _z, _p_est, _p_set).".format(ind[0]))
+        return tab[ind[0]], ind[1:]
+
+    def _get_scaling(self, ind):
+        st, name = self._scaling_struct(ind)
+        return st[name] if name else st
+
+    def _set_scaling(self, ind, val):
+        st, name = self._scaling_struct(ind)
+        st[name] = val
+
+    def _set_iter(self, attr, val):
+        st = getattr(self, attr)
+        if hasattr(val, "master"):
+            val = val.master
+        val = np.asarray(val, dtype=float).reshape(-1)
+        if val.size == 1 and st.size > 1:
+            val = np.full(st.size, float(val[0]))
+        assert val.size == st.size, "Wrong input with shape {}. Expected vector with {} elements".format(val.shape, st.size)
+        st.master[:] = val
+
+    x0 = property(lambda self: self._x0, lambda self, v: self._set_iter("_x0", v))
+    u0 = property(lambda self: self._u0, lambda self, v: self._set_iter("_u0", v))
+    z0 = property(lambda self: self._z0, lambda self, v: self._set_iter("_z0", v))
+    p_est0 = property(lambda self: self._p_est0, lambda self, v: self._set_iter("_p_est0", v))
+    t0 = property(lambda self: self._t0, lambda self, v: setattr(self, "_t0", np.array(v, dtype=float).reshape(-1)[:1]))
+
+    # ------------------------------------------------------------------ objective (_mhe.py:489-716)
+    def set_objective(self, stage_cost, arrival_cost) -> None:
+        stage_cost, arrival_cost = sym.SX(stage_cost), sym.SX(arrival_cost)
+        assert stage_cost.shape == (1, 1), "stage_cost must have shape=(1,1). You have {}".format(stage_cost.shape)
+        assert arrival_cost.shape == (1, 1), "arrival_cost must have shape=(1,1). You have {}".format(arrival_cost.shape)
+        assert self.flags["setup"] is False, "Cannot call .set_objective after .setup."
+        m = self.model
+        ok_stage = self._w.cat.nodes() + self._v.cat.nodes() + m._tvp.cat.nodes() + m._p.cat.nodes()
+        if [s for s in sym.free_symbols(stage_cost.nodes()) if s.idx not in {q.idx for q in ok_stage}]:
+            raise Exception("objective cost equation must be solely depending on w, v, p and tvp.")
+        ok_arr = m._x.cat.nodes() + self._x_prev.cat.nodes() + self._p_est_prev.cat.nodes() + m._p.cat.nodes()
+        if [s for s in sym.free_symbols(arrival_cost.nodes()) if s.idx not in {q.idx for q in ok_arr}]:
+            raise Exception("Arrival cost equation must be solely depending on x_0, x_prev, p_0, p_prev, p_set")
+        self.stage_cost, self.arrival_cost = stage_cost, arrival_cost
+        self.flags["set_objective"] = True
+
+    def set_default_objective(self, P_x, P_v=None, P_p=None, P_w=None) -> None:
+        m = self.model
+        n_x, n_w, n_v, n_p = m.n_x, m.n_w, m.n_v, self.n_p_est
+        as_sx = lambda P: P if isinstance(P, sym.SX) else sym.SX(np.asarray(P, dtype=float))      # noqa: E731
+        assert np.shape(P_x) == (n_x, n_x) or getattr(P_x, "shape", None) == (n_x, n_x), "P_x has wrong shape, must be {}".format((n_x, n_x))
+        stage_cost = sym.SX(0.0)
+        if P_v is None:
+            assert n_v == 0, "Must pass weighting factor P_v, since you have measurement noise on some measurements (configured in model)."
+        else:
+            v = self._v.cat
+            stage_cost = stage_cost + v.T @ as_sx(P_v) @ v
+        if P_w is None:
+            assert n_w == 0, "Must pass weighting factor P_w, since you have process noise on some states (configured in model)."
+        else:
+            w = self._w.cat
+            stage_cost = stage_cost + w.T @ as_sx(P_w) @ w
+        dx = self._x.cat - self._x_prev.cat
+        arrival_cost = dx.T @ as_sx(P_x) @ dx
+        if P_p is None:
+            assert n_p == 0, "Must pass weighting factor P_p, since you are trying to estimate parameters."
+        else:
+            dp = self._p_est.cat - self._p_est_prev.cat
+            Pp = as_sx(P_p)
+            arrival_cost = arrival_cost + dp.T @ (Pp.reshape((n_p, n_p)) if Pp.numel() == n_p * n_p else Pp) @ dp
+        self.set_objective(stage_cost, arrival_cost)
+
+    def set_nl_cons(self, expr_name: str, expr, ub: float = np.inf, soft_constraint: bool = False, penalty_term_cons: float = 1.0,
+                    maximum_violation: float = np.inf):
+        assert self.flags["setup"] is False, "Cannot call .set_expression after .setup_model."
+        self.nl_cons_list.append(dict(expr_name=expr_name, expr=expr, ub=ub, soft_constraint=soft_constraint,
+                                      penalty_term_cons=penalty_term_cons, maximum_violation=maximum_violation))
+        return sym.SX(expr)
+
+    # ------------------------------------------------------------------ templates / time-varying data (_mhe.py:717-801)
+    def get_p_template(self) -> NumStruct:
+        return self._p_set(0.0)
+
+    def set_p_fun(self, p_fun: Callable) -> None:
+        assert self.get_p_template().labels() == p_fun(0).labels(), "Incorrect output of p_fun. Use get_p_template to obtain the required structure."
+        self.p_fun = p_fun
+        self.flags["set_p_fun"] = True
+
+    def get_tvp_template(self) -> NumStruct:
+        return NumStruct(Layout([Entry("_tvp", struct=self.model._tvp.layout(), repeat=self.settings.n_horizon)]), 0.0)
+
+    def set_tvp_fun(self, tvp_fun: Callable) -> None:
+        assert self.get_tvp_template().labels() == tvp_fun(0).labels(), "Incorrect output of tvp_fun. Use get_tvp_template to obtain the required structure."
+        self.tvp_fun = tvp_fun
+        self.flags["set_tvp_fun"] = True
+
+    def get_y_template(self) -> NumStruct:
+        return NumStruct(Layout([Entry("y_meas", struct=self.model._y.layout(), repeat=self.settings.n_horizon)]), 0.0)
+
+    def set_y_fun(self, y_fun: Callable) -> None:
+        assert self.get_y_template().labels() == y_fun(0).labels(), "Incorrect output of y_fun. Use get_y_template to obtain the required structure."
+        self.y_fun = y_fun
+        self.flags["set_y_fun"] = True
+
+    def _check_validity(self):
+        if not self.flags["set_objective"]:
+            raise Exception("Objective is undefined. Please call .set_objective() or .set_default_objective() prior to .setup().")
+        if not self.flags["set_tvp_fun"]:
+            if self.model.n_tvp:
+                raise Exception("You have not supplied a function to obtain the time-varying parameters defined in model. Use .set_tvp_fun() prior to setup.")
+            _tvp = self.get_tvp_template()
+            self.set_tvp_fun(lambda t: _tvp)
+        if not self.flags["set_p_fun"]:
+            if self.n_p_set:
+                raise Exception("You have not supplied a function to obtain the parameters defined in model. Use .set_p_fun() prior to setup.")
+            _p = self.get_p_template()
+            self.set_p_fun(lambda t: _p)
+        if not self.flags["set_y_fun"]:
+            if not self.settings.meas_from_data:
+                raise Exception("You have not suppplied a measurement function. Use .set_y_fun or set parameter meas_from_data to True for default function.")
+            y_template = self.get_y_template()
+
+            def y_fun(t_now):           # (the last measurements of the data object, the oldest entries left at zero: _mhe.py:845-860)
+                n_steps = min(self.data["_y"].shape[0], self.settings.n_horizon)
+                for k in range(-n_steps, 0):
+                    y_template["y_meas", k] = self.data["_y"][k]
+                return y_template
+            self.set_y_fun(y_fun)
+
+    # ------------------------------------------------------------------ setup
+    def setup(self) -> None:
+        s, m = self.settings, self.model
+        s.check_for_mandatory_settings()
+        self._check_validity()
+        if s.nl_cons_single_slack:
+            raise NotImplementedError("structured HIP backend: nl_cons_single_slack couples all stages")
+        nx, nu, nw, nv, ny, npe = m.n_x, m.n_u, m.n_w, m.n_v, m.n_y, self.n_p_est
+        N = s.n_horizon
+        if any(float(q) != 1.0 for q in np.concatenate([self._p_est_scaling.master, self._p_set_scaling.master])):
+            raise NotImplementedError("structured HIP backend: parameter scaling in the estimator")
+        # ---- measurement noise as a function of (x, u, tvp, p, y_meas): every measurement must carry its own noise term
+        y_sym = sym.SX.sym("y_meas", ny, 1)
+        zero_v = sym.SX(np.zeros((nv, 1)))
+        h0 = sym.substitute(m._y.cat, m._v.cat, zero_v) if nv else m._y.cat
+        dy_dv = sym.jacobian(m._y.cat, m._v.cat) if nv else None
+        if ny != nv or not dy_dv.is_constant() or not np.array_equal(dy_dv.to_numpy().reshape(ny, nv), np.eye(ny)):
+            raise NotImplementedError("structured HIP backend: every measurement of the estimator model needs its own additive noise "
+                                      "term (set_meas(..., meas_noise=True)): the measurement rows are solved for it")
+        v_of = y_sym - h0                                            # v_k = y_k - h(x_{k+1}, u_k, tvp_k, p)
+        stage = sym.substitute(self.stage_cost, m._v.cat, v_of) if nv else self.stage_cost
+        # ---- the augmented model: states (x, p_est), inputs (u, w), tvp (tvp, y_meas), parameters p_set; symbols are shared
+        am = Model("continuous")
+        for n in m._x.names:
+            am._x.add(n, m._x.vars[n])
+        for n in self._p_est.names:
+            am._x.add(n, self._p_est.vars[n])
+        for n in m._u.names:
+            if m._u.vars[n].numel():
+                am._u.add(n, m._u.vars[n])
+        for n in m._w.names:
+            if m._w.vars[n].numel():
+                am._u.add(n, m._w.vars[n])
+        for n in m._tvp.names:
+            if m._tvp.vars[n].numel():
+                am._tvp.add(n, m._tvp.vars[n])
+        am._tvp.add("y_meas", y_sym)
+        for n in self._p_set.names:
+            am._p.add(n, self._p_set.vars[n])
+        for r in m.rhs_list:
+            am.rhs_list.append(dict(r))
+        for n in self._p_est.names:
+            am.rhs_list.append({"var_name": n, "expr": sym.SX(np.zeros(self._p_est.vars[n].shape))})
+        for n in m._aux.names:
+            if n != "default":
+                am._aux.add(n, m._aux.vars[n])
+        am.setup()
+        self._aug_model = am
+        # ---- the chain problem on the controller's machinery
+        mpc = MPC(am)
+        st = mpc.settings
+        st.n_horizon, st.t_step, st.n_robust, st.open_loop = N, s.t_step, 0, False
+        st.state_discretization, st.collocation_type = s.state_discretization, s.collocation_type
+        st.collocation_deg, st.collocation_ni = s.collocation_deg, s.collocation_ni
+        st.nl_cons_check_colloc_points, st.cons_check_colloc_points = s.nl_cons_check_colloc_points, s.cons_check_colloc_points
+        st.store_full_solution, st.nlpsol_opts = False, dict(s.nlpsol_opts)
+        st.gpu_index, st.max_batch, st.block_threads = s.gpu_index, s.max_batch, s.block_threads
+        mpc.set_objective(mterm=sym.SX(0.0), lterm=stage)
+        mpc.set_rterm(**{n: 0.0 for n in am._u.names if am._u.vars[n].numel()})
+        for c in self.nl_cons_list:
+            mpc.set_nl_cons(c["expr_name"], c["expr"], ub=c["ub"], soft_constraint=c["soft_constraint"],
+                            penalty_term_cons=c["penalty_term_cons"], maximum_violation=c["maximum_violation"])
+        mpc._x_scaling.master[:nx] = self._x_scaling.master
+        mpc._u_scaling.master[:nu] = self._u_scaling.master
+        mpc.set_tvp_fun(lambda t: mpc.get_tvp_template())
+        if am.n_p:
+            mpc.set_p_fun(lambda t: mpc.get_p_template(1))
+        mpc._estimator_opts = dict(arrival=self.arrival_cost.nodes()[0],
+                                   xprev_sym=self._x_prev.cat.nodes() + self._p_est_prev.cat.nodes(),
+                                   lterm_end=True, nl_dup=True)
+        mpc.setup()
+        self._mpc = mpc
+        self.S = mpc.S
+        ps = self._ps = mpc.structure
+        M = ps.M
+        # ---- the reference's layouts
+        xs_l, zs_l, us_l = m._x.layout(), m._z.layout(), m._u.layout()
+        self._eps_layout = mpc._eps_layout
+        self.n_eps = N
+        self._opt_x_layout = Layout([
+            Entry("_x", struct=xs_l, repeat=[N + 1, 1 + M]),
+            Entry("_z", struct=zs_l, repeat=[N, max(M, 1)]),
+            Entry("_u", struct=us_l, repeat=[N]),
+            Entry("_w", struct=m._w.layout(), repeat=[N]),
+            Entry("_v", struct=m._v.layout(), repeat=[N]),
+            Entry("_eps", struct=self._eps_layout, repeat=[self.n_eps]),
+            Entry("_p_est", struct=self._p_est.layout()),
+        ])
+        self._opt_p_layout = Layout([
+            Entry("_x_prev", struct=xs_l),
+            Entry("_p_est_prev", struct=self._p_est.layout()),
+            Entry("_p_set", struct=self._p_set.layout()),
+            Entry("_tvp", struct=m._tvp.layout(), repeat=N),
+            Entry("_y_meas", struct=m._y.layout(), repeat=N),
+        ])
+        self.n_opt_x, self.n_opt_p = self._opt_x_layout.size, self._opt_p_layout.size
+        self._opt_x_num = NumStruct(self._opt_x_layout, 0.0)
+        self.opt_x_num_unscaled = NumStruct(self._opt_x_layout, 0.0)
+        self._opt_p_num = NumStruct(self._opt_p_layout, 0.0)
+        self.opt_x_scaling = NumStruct(self._opt_x_layout, 1.0)
+        self.opt_x_scaling["_x"] = self._x_scaling.master
+        self.opt_x_scaling["_u"] = self._u_scaling.master
+        n_rows = ps.ne                                               # nl_cons rows of a stage (all evaluations)
+        self._rows_stage = M * nx + nx + ny + n_rows
+        self.n_opt_lagr = N * self._rows_stage
+        self.lam_g_num = np.zeros(self.n_opt_lagr)
+        # offsets inside the reference's opt_x
+        self._o_u = (N + 1) * (M + 1) * nx
+        self._o_w = self._o_u + N * nu
+        self._o_v = self._o_w + N * nw
+        self._o_eps = self._o_v + N * nv
+        self._o_p = self._o_eps + self.n_eps * self._eps_layout.size
+        self._po_pset = nx + npe
+        self._po_tvp = self._po_pset + self.n_p_set
+        self._po_y = self._po_tvp + N * m.n_tvp
+        # numeric helpers: measurement noise and its cost gradient at the solution
+        args = [am._x.cat, am._u.cat, am._tvp.cat, am._p.cat]
+        self._v_fun = sym.Function("v_of", args, [v_of])
+        dl_dv = sym.jacobian(self.stage_cost, m._v.cat).T if nv else sym.SX(np.zeros((0, 1)))
+        self._dldv_fun = sym.Function("dldv", [m._w.cat, m._v.cat, m._tvp.cat, m._p.cat], [dl_dv])
+        # (the reference's measurement rows read the NODE state x_{k+1}, here the stage cost reads the end slot of the interval:
+        #  the multipliers of the continuity rows differ by (dh/dx)' lambda_meas)
+        lam_y = sym.SX.sym("lam_y", ny, 1)
+        self._hx_fun = sym.Function("hx_lam", args + [lam_y], [sym.jacobian(h0, m._x.cat).T @ lam_y])
+        self._update_bounds()
+        meta = {k: getattr(s, k) for k in ("n_horizon", "t_step", "meas_from_data", "state_discretization", "collocation_type",
+                                           "collocation_deg", "collocation_ni", "nl_cons_check_colloc_points", "store_full_solution",
+                                           "store_lagr_multiplier")}
+        self.data.set_meta(**meta)
+        self.flags["setup"] = True
+
+    opt_x_num = property(lambda self: self._opt_x_num)
+    opt_p_num = property(lambda self: self._opt_p_num)
+
+    def _update_bounds(self):
+        """_mhe.py:995-1028 on the chain problem: state bounds on every stored point (cons_check_colloc_points) or on the
+        states `_x[1:N, -1]`; the bounds of `_p_est` on ONE of its copies (they are all equal at a feasible point)."""
+        mpc, ps, s = self._mpc, self._ps, self.settings
+        nx, nu, N, M = self.model.n_x, self.model.n_u, s.n_horizon, ps.M
+        NXA, NUA = ps.nx, ps.nu
+        lb, ub = mpc._lb_opt_x.master, mpc._ub_opt_x.master
+        lb[:], ub[:] = -np.inf, np.inf
+        XL, XU = lb[:ps.off_z].reshape(N + 1, M + 1, NXA), ub[:ps.off_z].reshape(N + 1, M + 1, NXA)
+        xl, xu = self._x_lb.master / self._x_scaling.master, self._x_ub.master / self._x_scaling.master
+        if s.cons_check_colloc_points:
+            XL[:, :, :nx], XU[:, :, :nx] = xl, xu
+        else:
+            XL[1:N, -1, :nx], XU[1:N, -1, :nx] = xl, xu
+        XL[0, -1, nx:], XU[0, -1, nx:] = self._p_est_lb.master, self._p_est_ub.master
+        UL, UU = lb[ps.off_u:ps.off_eps].reshape(N, NUA), ub[ps.off_u:ps.off_eps].reshape(N, NUA)
+        UL[:, :nu], UU[:, :nu] = self._u_lb.master / self._u_scaling.master, self._u_ub.master / self._u_scaling.master
+        if mpc.n_eps:
+            lb[ps.off_eps:].reshape(-1, mpc.n_eps)[:] = mpc._eps_lb
+            ub[ps.off_eps:].reshape(-1, mpc.n_eps)[:] = mpc._eps_ub
+
+    # ------------------------------------------------------------------ layouts: reference <-> chain problem
+    def _to_chain(self, ox: np.ndarray) -> np.ndarray:
+        ps, m, N = self._ps, self.model, self.settings.n_horizon
+        nx, nu, nw, M = m.n_x, m.n_u, m.n_w, ps.M
+        out = np.zeros(ps.n_opt_x)
+        X = out[:ps.off_z].reshape(N + 1, M + 1, ps.nx)
+        X[:, :, :nx] = ox[:self._o_u].reshape(N + 1, M + 1, nx)
+        X[:, :, nx:] = ox[self._o_p:]
+        U = out[ps.off_u:ps.off_eps].reshape(N, ps.nu)
+        U[:, :nu] = ox[self._o_u:self._o_w].reshape(N, nu)
+        if nw:
+            U[:, nu:] = ox[self._o_w:self._o_v].reshape(N, nw)
+        out[ps.off_eps:] = ox[self._o_eps:self._o_p]
+        return out
+
+    def _from_chain(self, cx: np.ndarray, opt_p_chain: np.ndarray) -> np.ndarray:
+        ps, m, N = self._ps, self.model, self.settings.n_horizon
+        nx, nu, nw, nv, M = m.n_x, m.n_u, m.n_w, m.n_v, ps.M
+        out = np.zeros(self.n_opt_x)
+        X = cx[:ps.off_z].reshape(N + 1, M + 1, ps.nx)
+        out[:self._o_u] = X[:, :, :nx].reshape(-1)
+        U = cx[ps.off_u:ps.off_eps].reshape(N, ps.nu)
+        out[self._o_u:self._o_w] = U[:, :nu].reshape(-1)
+        if nw:
+            out[self._o_w:self._o_v] = U[:, nu:].reshape(-1)
+        if nv:      # measurement noise of stage k from the end state of its interval
+            TV = opt_p_chain[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
+            Pm = opt_p_chain[ps.p_off_p:ps.p_off_uprev]
+            sx = np.concatenate([self._x_scaling.master, np.ones(ps.nx - nx)])
+            su = np.concatenate([self._u_scaling.master, np.ones(ps.nu - nu)])
+            V = self._v_fun.eval((X[1:, -1, :] * sx).T, (U * su).T, TV.T, np.tile(Pm[:, None], (1, N)))[0]
+            out[self._o_v:self._o_eps] = np.asarray(V).reshape(nv, N).T.reshape(-1)
+        out[self._o_eps:self._o_p] = cx[ps.off_eps:]
+        out[self._o_p:] = X[0, -1, nx:]
+        return out
+
+    def _lam_from_chain(self, lam_chain: np.ndarray, ox: np.ndarray, opt_p: NumStruct) -> np.ndarray:
+        """multipliers in the reference's row order; the measurement rows h + v - y = 0 carry -d(stage cost)/dv"""
+        ps, m, N = self._ps, self.model, self.settings.n_horizon
+        nx, nw, nv, ny, M = m.n_x, m.n_w, m.n_v, m.n_y, ps.M
+        out = np.zeros(self.n_opt_lagr).reshape(N, self._rows_stage)
+        L = lam_chain[ps.nx:].reshape(N, -1)                         # (the chain problem keeps nx dummy initial rows)
+        blk = L[:, :(M + 1) * ps.nx].reshape(N, M + 1, ps.nx)        # collocation / end-of-element rows, then continuity
+        out[:, :(M + 1) * nx] = blk[:, :, :nx].reshape(N, -1)
+        if nv:
+            W = ox[self._o_w:self._o_v].reshape(N, nw) if nw else np.zeros((N, 0))
+            V = ox[self._o_v:self._o_eps].reshape(N, nv)
+            TV = opt_p.master[self._po_tvp:self._po_y].reshape(N, m.n_tvp)
+            pm = np.zeros(m.n_p)
+            off = 0
+            for n in m._p.names:
+                k = m._p.vars[n].numel()
+                if k:
+                    src = ox[self._o_p:] if n in self._p_est.names else opt_p.master[self._po_pset:self._po_tvp]
+                    grp = self._p_est if n in self._p_est.names else self._p_set
+                    pm[off:off + k] = src[grp.offset(n):grp.offset(n) + k]
+                off += k
+            g = self._dldv_fun.eval(W.T, V.T, TV.T, np.tile(pm[:, None], (1, N)))[0]
+            lam_meas = -np.asarray(g).reshape(nv, N).T
+            out[:, (M + 1) * nx:(M + 1) * nx + ny] = lam_meas
+            cx, Pc = self._mpc.opt_x_num.master, self._mpc.opt_p_num.master
+            X = cx[:ps.off_z].reshape(N + 1, M + 1, ps.nx)[1:, -1, :] * np.concatenate([self._x_scaling.master, np.ones(ps.nx - nx)])
+            U = cx[ps.off_u:ps.off_eps].reshape(N, ps.nu) * np.concatenate([self._u_scaling.master, np.ones(ps.nu - m.n_u)])
+            TVc = Pc[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
+            hx = self._hx_fun.eval(X.T, U.T, TVc.T, np.tile(Pc[ps.p_off_p:ps.p_off_uprev][:, None], (1, N)), lam_meas.T)[0]
+            out[:, M * nx:(M + 1) * nx] += np.asarray(hx).reshape(nx, N).T
+        out[:, (M + 1) * nx + ny:] = L[:, (M + 1) * ps.nx:]
+        return out.reshape(-1)
+
+    # ------------------------------------------------------------------ runtime
+    def set_initial_guess(self) -> None:
+        assert self.flags["setup"] is True, "mhe was not setup yet. Please call mhe.setup()."
+        self._opt_x_num["_x"] = self._x0.master / self._x_scaling.master
+        self._opt_x_num["_u"] = self._u0.master / self._u_scaling.master
+        if self.n_p_est:
+            self._opt_x_num["_p_est"] = self._p_est0.master
+        self.flags["set_initial_guess"] = True
+
+    def solve(self) -> None:
+        """the NLP of the current opt_p_num from the initial guess opt_x_num (Optimizer.solve, optimizer.py:731-787)"""
+        mpc, ps, m, N = self._mpc, self._ps, self.model, self.settings.n_horizon
+        P = mpc.opt_p_num.master
+        P[:] = 0.0
+        P[:m.n_x] = _arr(self._opt_p_num["_x_prev"])
+        P[m.n_x:ps.nx] = _arr(self._opt_p_num["_p_est_prev"])
+        TV = P[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)
+        if m.n_tvp:
+            TV[:N, :m.n_tvp] = self._opt_p_num.master[self._po_tvp:self._po_y].reshape(N, m.n_tvp)
+        TV[:N, m.n_tvp:] = self._opt_p_num.master[self._po_y:].reshape(N, m.n_y)
+        P[ps.p_off_p:ps.p_off_uprev] = self._opt_p_num.master[self._po_pset:self._po_tvp]
+        mpc.opt_x_num.master[:] = self._to_chain(self._opt_x_num.master)
+        mpc.solve()
+        self.solver_stats = mpc.solver_stats
+        ox = self._from_chain(mpc.opt_x_num.master, P)
+        self._opt_x_num.master[:] = ox
+        self.opt_x_num_unscaled.master[:] = ox * self.opt_x_scaling.master
+        self.lam_g_num = self._lam_from_chain(mpc.lam_g_num, ox, self._opt_p_num)
+
+    def make_step(self, y0: np.ndarray) -> np.ndarray:
+        """_mhe.py:896-993: the current measurement in, the state estimate at the end of the horizon out"""
+        assert self.flags["setup"] is True, "optimizer was not setup yet. Please call optimizer.setup()."
+        y0 = np.asarray(y0.master if hasattr(y0, "master") else y0, dtype=float).reshape(-1)
+        assert y0.size == self.model.n_y, "Wrong input with shape {}. Expected vector with {} elements".format(y0.shape, self.model.n_y)
+        self.data.update(_y=y0)
+        t0 = float(self._t0[0])
+        x0, p_est0 = self._x0.master.copy(), self._p_est0.master.copy()
+        tvp0, p_set0, y_traj = self.tvp_fun(t0), self.p_fun(t0), self.y_fun(t0)
+        self._opt_p_num["_x_prev"] = _arr(self._opt_x_num["_x", 1, -1]) * self._x_scaling.master
+        nx_, npe_ = self.model.n_x, self.n_p_est
+        Pm = self._opt_p_num.master
+        Pm[nx_:nx_ + npe_] = p_est0
+        Pm[self._po_pset:self._po_tvp] = p_set0.master
+        Pm[self._po_tvp:self._po_y] = tvp0.master
+        Pm[self._po_y:] = y_traj.master
+        self.solve()
+        x_next = _arr(self._opt_x_num["_x", -1, -1]) * self._x_scaling.master
+        p_est_next = _arr(self._opt_x_num["_p_est"]) if self.n_p_est else np.zeros(0)
+        u0 = _arr(self._opt_x_num["_u", -1]) * self._u_scaling.master
+        p0 = np.zeros(self.model.n_p)
+        off = 0
+        for n in self.model._p.names:
+            k = self.model._p.vars[n].numel()
+            if k:
+                grp, src = (self._p_est, p_est0) if n in self._p_est.names else (self._p_set, p_set0.master)
+                p0[off:off + k] = src[grp.offset(n):grp.offset(n) + k]
+            off += k
+        self.data.update(_x=x0, _u=u0, _p=p0, _time=self._t0)
+        if self.model.n_tvp:
+            self.data.update(_tvp=_arr(tvp0["_tvp", -1]))
+        self.data.update(opt_p_num=self._opt_p_num.master.copy())
+        if self.settings.store_full_solution:
+            self.data.update(_opt_x_num=self.opt_x_num_unscaled.master.copy())
+        if self.settings.store_lagr_multiplier:
+            self.data.update(_lam_g_num=self.lam_g_num.copy())
+        for k in self.settings.store_solver_stats:
+            if k in self.solver_stats:
+                self.data.update(**{k: np.array([float(self.solver_stats[k])])})
+        self._t0 = self._t0 + self.settings.t_step
+        self._x0.master[:] = x_next
+        if self.n_p_est:
+            self._p_est0.master[:] = p_est_next
+        self._u0.master[:] = u0
+        return x_next.reshape(-1, 1)

@@ -77,3 +77,48 @@ def build_mpc(model, silence_solver=True, **overrides):
     mpc.bounds["upper", "_u", "phi_m_set"] = 5
     mpc.setup()
     return mpc
+
+
+def build_mhe(model, silence_solver=True, **overrides):
+    """The example's estimator (/root/reference/examples/rotating_oscillating_masses_mhe_mpc/template_mhe.py:34-104): horizon 10,
+    `Theta_1` estimated, default objective with P_x = 1e-4 I, the `_tvp` P_v = diag(1, 1, 1, 20, 20) and the parameter P_p = 1,
+    bounds on the motor set-points and the angular velocities, the box of Theta_1 as two nl_cons rows checked at the
+    collocation points; measurements from the data object."""
+    from ..estimator import MHE
+    mhe = MHE(model, ["Theta_1"])
+    st = mhe.settings
+    st.n_horizon, st.t_step, st.store_full_solution, st.nl_cons_check_colloc_points = 10, 0.1, True, True
+    for k, v in overrides.items():
+        setattr(st, k, v)
+    if silence_solver:
+        st.supress_ipopt_output()
+    mhe.set_default_objective(1e-4 * np.eye(8), model.tvp["P_v"], model.p["P_p"])
+    tvp_template = mhe.get_tvp_template()
+    tvp_template["_tvp", :, "P_v"] = np.diag(np.array([1, 1, 1, 20, 20]))
+    mhe.set_tvp_fun(lambda t_now: tvp_template)
+    p_template = mhe.get_p_template()
+
+    def p_fun(t_now):
+        p_template["Theta_2"] = 2.25e-4
+        p_template["Theta_3"] = 2.25e-4
+        p_template["P_p"] = np.eye(1)
+        return p_template
+
+    mhe.set_p_fun(p_fun)
+    y_template = mhe.get_y_template()
+
+    def y_fun(t_now):
+        n_steps = min(mhe.data["_y"].shape[0], st.n_horizon)
+        for k in range(-n_steps, 0):
+            y_template["y_meas", k] = mhe.data["_y"][k]
+        return y_template
+
+    mhe.set_y_fun(y_fun)
+    mhe.bounds["lower", "_u", "phi_m_set"] = -5
+    mhe.bounds["upper", "_u", "phi_m_set"] = 5
+    mhe.bounds["lower", "_x", "dphi"] = -6
+    mhe.bounds["upper", "_x", "dphi"] = 6
+    mhe.set_nl_cons("p_est_lb", -mhe._p_est["Theta_1"] + 1e-5, 0)
+    mhe.set_nl_cons("p_est_ub", mhe._p_est["Theta_1"] - 1e-3, 0)
+    mhe.setup()
+    return mhe

@@ -46,7 +46,8 @@ def _sym_hessian_upper(L: sym.Node, v: List[sym.Node]):
 
 def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, mterm, nl_exprs,
                 nl_slack_index, eps_penalty, sx, su, rterm, h_scale, deg, ni, discrete, C, D,
-                name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None, rterm_expr=None, uprev_sym=(), nl_colloc=False) -> str:
+                name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None, rterm_expr=None, uprev_sym=(), nl_colloc=False,
+                arrival=None, xprev_sym=(), lterm_end=False, nl_dup=False) -> str:
     """Return the text of the generated header.
 
     x_sym/u_sym/z_sym/tvp_sym/p_sym: lists of sym.Node (the model's own symbols, unscaled).
@@ -58,6 +59,12 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     rterm_expr / uprev_sym: user-defined input penalty rterm(x, u, u_prev, z, tvp, p) (_mpc.py:593-677) and the symbols of
     `mpc.u_prev`; None: the default quadratic form with the weights `rterm`.  The reference evaluates it with UNSCALED x, u, z
     and the SCALED previous input (_mpc.py:1263-1269: `opt_p['_u_prev'] / u_scaling` resp. `opt_x['_u', k-1, ...]`).
+
+    arrival / xprev_sym (estimators, _mhe.py:1118-1127): cost of the FREE initial state, an expression in the (unscaled) model
+    states and the symbols `xprev_sym` (the previous estimate, handed over in the `_x0` slot of opt_p); lterm_end: the stage
+    cost reads the END state of the interval instead of its first one (_mhe.py:1146-1147, 1190-1192: the measurement
+    residual of stage k lives at `_x[k+1, -1]`); nl_dup: the nl_cons rows of the last evaluated point are repeated
+    (_mhe.py:1186-1188).
 
     Point functions take the stage variables as v = (x (nx), u (nu), z (nz)): for a model without algebraic states
     that is the (x, u) of the optimised kernels, with them the algebraic block is appended (dense DAE path of the kernels).
@@ -204,6 +211,23 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         parts.append(f"DOMPC_FN void dompc_nlcons_f({sig_dyn_args}, double* d) {{}}\n")
         parts.append(f"DOMPC_FN void dompc_nlcons({sig_dyn_args}, const double* lam, double* d, double* Jd, double* H) {{}}\n")
 
+    # arrival cost of a free initial state: value, gradient, packed Hessian over the (scaled) initial state
+    xpv, bxp = _bind("xprev", nx)
+    binds.update(bxp)
+    sig_a = "const double* xs, const double* xprev, const double* tvp, const double* pp"
+    if arrival is not None:
+        mp_a = dict(mapping)
+        for i, s_ in enumerate(xprev_sym):
+            mp_a[s_.idx] = xpv[i]
+        at = scaled([arrival], mp_a)[0]
+        if sym.depends_on([at], us + zs):
+            raise Exception("the arrival cost must depend on the initial state, the previous estimate, _tvp and _p only")
+        ga, Ha = _sym_hessian_upper(at, xs)
+        parts.append(emit_fn(f"double dompc_aterm_f({sig_a})", [("double val", at)]).replace("\n}\n", "\n  return val;\n}\n"))
+        outs = [("val[0]", at)] + [(f"g[{i}]", ga[i]) for i in range(nx)] + hess_outs(Ha, nx)
+        parts.append(emit_fn(f"void dompc_aterm({sig_a}, double* val, double* g, double* H)", outs))
+    # (no arrival cost: csrc/dompc_kernel.h defines empty stand-ins - headers of controllers stay as they were)
+
     # user-defined input penalty: value, gradient and Hessian over (x, u, u_prev); z-dependence is not lowered
     if rterm_expr is not None:
         rt = scaled([rterm_expr])[0]
@@ -235,6 +259,9 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         f"#define DOMPC_NTVP {ntvp}", f"#define DOMPC_NE {ne}", f"#define DOMPC_NS {ns}", f"#define DOMPC_NZ {nz}",
         f"#define DOMPC_RTERM_CUSTOM {1 if rterm_expr is not None else 0}",
         *(["#define DOMPC_NL_COLLOC 1      // nl_cons rows at every stored point of the interval (DOMPC_NE rows per point)"] if nl_colloc and ne and not discrete else []),
+        *(["#define DOMPC_FREE_ROOT 1      // estimator: free initial state with the arrival cost dompc_aterm (no initial-condition rows)"] if arrival is not None else []),
+        *(["#define DOMPC_LT_END 1         // estimator: the stage cost reads the END state of the interval"] if lterm_end else []),
+        *(["#define DOMPC_NL_DUP 1         // estimator: the nl_cons rows of the last evaluated point once more"] if nl_dup and ne else []),
         f"#define DOMPC_DEG {deg if not discrete else 0}", f"#define DOMPC_NI {ni if not discrete else 1}",
         f"#define DOMPC_M {M}", f"#define DOMPC_DISCRETE {1 if discrete else 0}",
         _fmt_array("DOMPC_C", np.asarray(C).reshape(-1) if not discrete else [0.0]),

@@ -271,6 +271,34 @@ def case_rotating_masses(**over):
     return dd
 
 
+def case_rotating_masses_mhe(**over):
+    """The estimator of the same example: /root/reference/examples/rotating_oscillating_masses_mhe_mpc/template_mhe.py:34-104
+    (MHE with `Theta_1` estimated, default objective with the 5x5 `_tvp` P_v and the `_p` P_p as weights, bounds on the inputs
+    and the angular velocities, the box of Theta_1 as two nl_cons rows checked at the collocation points) on the model of
+    template_model.py:44-99 (measurements: the three disc angles and the two motor set-points, each with measurement noise)."""
+    d = case_rotating_masses()
+    x, u, p, tvp = d["x"], d["u"], d["p"], d["tvp"]
+    v = sp.symbols("v_0:5")
+    xp = sp.symbols("xprev_0:8")
+    pp = (sp.Symbol("Theta_1_prev"),)
+    meas = [x[0] + v[0], x[1] + v[1], x[2] + v[2], u[0] + v[3], u[1] + v[4]]
+    Pv = sp.Matrix(5, 5, lambda i, j: tvp[1 + i + 5 * j])             # (5, 5) entry of the `_tvp` struct, stored column by column
+    vv = sp.Matrix(v)
+    stage = (vv.T * Pv * vv)[0, 0]
+    dx = sp.Matrix([x[i] - xp[i] for i in range(8)])
+    arrival = 1e-4 * (dx.T * dx)[0, 0] + p[0] * (p[1] - pp[0]) ** 2    # P_x = 1e-4 I, P_p = the parameter `P_p`
+    x_lb, x_ub = -np.inf * np.ones(8), np.inf * np.ones(8)
+    x_lb[3:6], x_ub[3:6] = -6.0, 6.0
+    dd = dict(d)
+    dd.update(name="rotating_masses_mhe", v=v, w=(), meas=meas, p_est=[p[1]], x_prev=xp, p_est_prev=pp,
+              stage_cost=stage, arrival_cost=arrival, n_horizon=10, t_step=0.1, collocation_deg=2, collocation_ni=1,
+              nl_cons_check_colloc_points=True,
+              nl_cons=[dict(name="p_est_lb", expr=-p[1] + 1e-5, ub=0.0, soft=False), dict(name="p_est_ub", expr=p[1] - 1e-3, ub=0.0, soft=False)],
+              x_lb=x_lb, x_ub=x_ub, u_lb=-5.0 * np.ones(2), u_ub=5.0 * np.ones(2))
+    dd.update(over)
+    return dd
+
+
 def case_oscillating_masses_dae(**over):
     """/root/reference/examples/oscillating_masses_discrete_dae/template_model.py:34-75, template_mpc.py:34-74: the discrete
     masses with the successor state as algebraic variable, x+ = z, 0 = z - A x - B u."""

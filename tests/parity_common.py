@@ -371,3 +371,44 @@ def check_nl_cons_at_collocation_points(make_mpc, name, over, x0):
     if name == "CSTR":
         assert np.max(np.abs(mpc.lam_g_num[rows])) > 0.1                                 # (a row at a collocation point ends active)
     return mpc
+
+
+# ---------------------------------------------------------------------------------------------- moving horizon estimation
+def oracle_mhe():
+    from oracle.mhe import OracleMHE
+    from oracle.models import case_rotating_masses_mhe
+    if "mhe" not in _oracle_cache:
+        _oracle_cache["mhe"] = OracleMHE(case_rotating_masses_mhe())
+    return _oracle_cache["mhe"]
+
+
+def check_mhe_golden_replay(make_mhe, steps=5):
+    """The reference's estimator test (testing/test_rotating_oscillating_masses_mhe_mpc.py: x0 = 0, p_est0 = 1e-4, measurements of
+    the stored run fed one by one) on the product: every step's NLP parameters (previous estimates, measurement window) come out
+    of the product's own previous solutions, the full primal solution, the multipliers and the returned estimate are compared
+    with IPOPT's (results_rotatingMasses.pkl, `estimator` record).  Measured: primal 4e-16 / 1e-15 / 1e-9 / 1e-10 / 3e-9,
+    multipliers <= 1e-11."""
+    g = golden("rotating_masses")
+    OX, OP, LG, Y, XE = (g["estimator." + k] for k in ("_opt_x_num", "opt_p_num", "_lam_g_num", "_y", "_x"))
+    mhe = make_mhe()
+    assert (mhe.n_opt_x, mhe.n_opt_p, mhe.n_opt_lagr) == (OX.shape[1], OP.shape[1], LG.shape[1])
+    mhe.x0 = np.zeros(8)
+    mhe.p_est0 = 1e-4
+    mhe.set_initial_guess()
+    for k in range(steps):
+        x_est = mhe.make_step(Y[k]).ravel()
+        assert mhe.solver_stats["success"], mhe.solver_stats
+        assert np.max(np.abs(mhe.opt_p_num.master - OP[k])) < 1e-8, k
+        assert relerr(mhe.opt_x_num.master, OX[k]) < 1e-8, (k, relerr(mhe.opt_x_num.master, OX[k]))
+        assert np.max(np.abs(mhe.lam_g_num - LG[k])) < 1e-8 * max(1.0, np.max(np.abs(LG[k]))), k
+        assert relerr(x_est, OX[k][mhe._o_u - 8:mhe._o_u]) < 1e-8
+    assert relerr(mhe.data["_x"], XE[:steps]) < 1e-8            # (the reference's own assertion: estimator states of the run, 1e-8)
+    # the solution is a KKT point of the restated reference NLP (oracle/mhe.py) with the mapped multipliers
+    nlp = oracle_mhe()
+    x, p, lam = mhe.opt_x_num.master, mhe.opt_p_num.master, mhe.lam_g_num
+    eq = nlp.lbg == nlp.ubg
+    assert np.max(np.abs(nlp.g(x, p)[eq])) < 1e-9
+    rd = nlp.grad(x, p) + nlp.jac(x, p).T @ lam
+    inside = (x > nlp.lbx + 1e-6) & (x < nlp.ubx - 1e-6)
+    assert np.max(np.abs(rd[inside])) < 1e-7
+    return mhe

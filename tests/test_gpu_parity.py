@@ -277,7 +277,11 @@ def test_code_objects_are_the_ones_the_unedited_templates_lower_to():
     pinned = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "template_hashes.json")))
     assert len(pinned) >= 10
     for name, h in pinned.items():
-        mpc = make_mpc(name)
+        if name.endswith("_mhe"):          # (the estimator of the example: the chain problem of do_mpc_amd.estimator.MHE)
+            ex = CASES[name[:-4]]
+            mpc = ex.build_mhe(ex.build_model())._mpc
+        else:
+            mpc = make_mpc(name)
         assert mpc.model_hash == h, (name, mpc.model_hash, h)
         assert os.path.basename(os.path.dirname(mpc.S.code_object_path)) == h
 
@@ -312,3 +316,9 @@ def test_dense_edge_path_reproduces_the_fast_path(name, monkeypatch):
         sol.append((mpc.solver_stats["iter_count"], mpc.opt_x_num.master.copy(), mpc.lam_g_num.copy()))
     assert sol[0][0] == sol[1][0]
     assert pc.relerr(sol[0][1], sol[1][1]) < 1e-10 and pc.relerr(sol[0][2], sol[1][2]) < 1e-8
+
+
+def test_mhe_golden_replay():
+    """moving horizon estimation on the HIP path: the reference's estimator run (results_rotatingMasses.pkl) step by step"""
+    ex = CASES["rotating_masses"]
+    pc.check_mhe_golden_replay(lambda: ex.build_mhe(ex.build_model()))

@@ -82,6 +82,28 @@ def test_unedited_templates_lower_to_the_same_model(name, compat):
     assert "DOMPC_NX %d" % m1.n_x in ref_mpc.generated_header
 
 
+def test_unedited_mhe_template_lowers_to_the_same_estimator_and_replays_the_stored_run(compat):
+    """template_mhe.py of examples/rotating_oscillating_masses_mhe_mpc, un-edited (`do_mpc.estimator.MHE`, `mhe._p_est[...]`,
+    `mhe.data._y`-driven y_fun, default objective with symbolic weights): the chain problem it lowers to has the same generated
+    header as the in-repo restatement (do_mpc_amd/examples/rotating_masses.py:build_mhe) - the code object of the GPU parity
+    test - and, on the host emulation, reproduces the estimator record of the reference's test run"""
+    import parity_common as pc
+    d = os.path.join(REF, DIRS["rotating_masses"])
+    tm = _load(os.path.join(d, "template_model.py"), "ref_rot_template_model_mhe")
+    te = _load(os.path.join(d, "template_mhe.py"), "ref_rot_template_mhe")
+    ex = CASES["rotating_masses"]
+
+    def make():
+        with hostemu.patched():
+            return te.template_mhe(tm.template_model(), silence_solver=True)
+    with hostemu.patched():
+        ours = ex.build_mhe(ex.build_model())
+    mhe = pc.check_mhe_golden_replay(make)
+    assert mhe._mpc.generated_header == ours._mpc.generated_header
+    import json
+    assert json.load(open(HASHES))["rotating_masses_mhe"] == mhe._mpc.model_hash, "re-run tools/template_hashes.py"
+
+
 def test_unedited_industrial_poly_template_reproduces_golden_first_step(compat):
     d = os.path.join(REF, "industrial_poly")
     tm = _load(os.path.join(d, "template_model.py"), "ref_ip_template_model2")

@@ -32,6 +32,13 @@ def main():
         mpc = tc.template_mpc(tm.template_model(*MODEL_ARGS.get(name, ())), *MPC_ARGS.get(name, ()), silence_solver=True)
         out[name] = mpc.model_hash
         print(name, mpc.model_hash)
+    # the estimator of the MHE + MPC example: template_mhe.py -> the chain problem of do_mpc_amd.estimator.MHE
+    d = DIRS["rotating_masses"]
+    tm = _load(os.path.join(REF, d, "template_model.py"), "th_mhe_tm")
+    te = _load(os.path.join(REF, d, "template_mhe.py"), "th_mhe_te")
+    mhe = te.template_mhe(tm.template_model(), silence_solver=True)
+    out["rotating_masses_mhe"] = mhe._mpc.model_hash
+    print("rotating_masses_mhe", mhe._mpc.model_hash)
     with open(os.path.join(ROOT, "tests", "golden", "template_hashes.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 
