@@ -428,38 +428,59 @@ class MHE:
 
     # ------------------------------------------------------------------ layouts: reference <-> chain problem
     def _to_chain(self, ox: np.ndarray) -> np.ndarray:
+        """reference layout -> chain problem (a leading batch axis is carried through)"""
         ps, m, N = self._ps, self.model, self.settings.n_horizon
         nx, nu, nw, M = m.n_x, m.n_u, m.n_w, ps.M
-        out = np.zeros(ps.n_opt_x)
-        X = out[:ps.off_z].reshape(N + 1, M + 1, ps.nx)
-        X[:, :, :nx] = ox[:self._o_u].reshape(N + 1, M + 1, nx)
-        X[:, :, nx:] = ox[self._o_p:]
-        U = out[ps.off_u:ps.off_eps].reshape(N, ps.nu)
-        U[:, :nu] = ox[self._o_u:self._o_w].reshape(N, nu)
+        ox = np.asarray(ox, dtype=float)
+        lead = ox.shape[:-1]
+        out = np.zeros(lead + (ps.n_opt_x,))
+        X = out[..., :ps.off_z].reshape(lead + (N + 1, M + 1, ps.nx))
+        X[..., :nx] = ox[..., :self._o_u].reshape(lead + (N + 1, M + 1, nx))
+        X[..., nx:] = ox[..., None, None, self._o_p:]
+        U = out[..., ps.off_u:ps.off_eps].reshape(lead + (N, ps.nu))
+        U[..., :nu] = ox[..., self._o_u:self._o_w].reshape(lead + (N, nu))
         if nw:
-            U[:, nu:] = ox[self._o_w:self._o_v].reshape(N, nw)
-        out[ps.off_eps:] = ox[self._o_eps:self._o_p]
+            U[..., nu:] = ox[..., self._o_w:self._o_v].reshape(lead + (N, nw))
+        out[..., ps.off_eps:] = ox[..., self._o_eps:self._o_p]
         return out
+
+    def _p_to_chain(self, op: np.ndarray) -> np.ndarray:
+        """opt_p: [_x_prev | _p_est_prev | _p_set | _tvp (N) | _y_meas (N)] -> [_x0 = previous estimate of (x, p_est) |
+        _tvp = (tvp_k, y_k), N + 1 stages | _p = p_set | _u_prev = 0]"""
+        ps, m, N = self._ps, self.model, self.settings.n_horizon
+        op = np.asarray(op, dtype=float)
+        lead = op.shape[:-1]
+        P = np.zeros(lead + (ps.n_opt_p,))
+        P[..., :ps.nx] = op[..., :ps.nx]
+        TV = P[..., ps.p_off_tvp:ps.p_off_p].reshape(lead + (N + 1, ps.ntvp))
+        if m.n_tvp:
+            TV[..., :N, :m.n_tvp] = op[..., self._po_tvp:self._po_y].reshape(lead + (N, m.n_tvp))
+        TV[..., :N, m.n_tvp:] = op[..., self._po_y:].reshape(lead + (N, m.n_y))
+        P[..., ps.p_off_p:ps.p_off_uprev] = op[..., self._po_pset:self._po_tvp]
+        return P
 
     def _from_chain(self, cx: np.ndarray, opt_p_chain: np.ndarray) -> np.ndarray:
         ps, m, N = self._ps, self.model, self.settings.n_horizon
         nx, nu, nw, nv, M = m.n_x, m.n_u, m.n_w, m.n_v, ps.M
-        out = np.zeros(self.n_opt_x)
-        X = cx[:ps.off_z].reshape(N + 1, M + 1, ps.nx)
-        out[:self._o_u] = X[:, :, :nx].reshape(-1)
-        U = cx[ps.off_u:ps.off_eps].reshape(N, ps.nu)
-        out[self._o_u:self._o_w] = U[:, :nu].reshape(-1)
+        cx, opt_p_chain = np.asarray(cx, dtype=float), np.asarray(opt_p_chain, dtype=float)
+        lead = cx.shape[:-1]
+        out = np.zeros(lead + (self.n_opt_x,))
+        X = cx[..., :ps.off_z].reshape(lead + (N + 1, M + 1, ps.nx))
+        out[..., :self._o_u] = X[..., :nx].reshape(lead + (-1,))
+        U = cx[..., ps.off_u:ps.off_eps].reshape(lead + (N, ps.nu))
+        out[..., self._o_u:self._o_w] = U[..., :nu].reshape(lead + (-1,))
         if nw:
-            out[self._o_w:self._o_v] = U[:, nu:].reshape(-1)
+            out[..., self._o_w:self._o_v] = U[..., nu:].reshape(lead + (-1,))
         if nv:      # measurement noise of stage k from the end state of its interval
-            TV = opt_p_chain[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
-            Pm = opt_p_chain[ps.p_off_p:ps.p_off_uprev]
+            TV = opt_p_chain[..., ps.p_off_tvp:ps.p_off_p].reshape(lead + (N + 1, ps.ntvp))[..., :N, :]
+            Pm = np.broadcast_to(opt_p_chain[..., None, ps.p_off_p:ps.p_off_uprev], lead + (N, ps.np_))
             sx = np.concatenate([self._x_scaling.master, np.ones(ps.nx - nx)])
             su = np.concatenate([self._u_scaling.master, np.ones(ps.nu - nu)])
-            V = self._v_fun.eval((X[1:, -1, :] * sx).T, (U * su).T, TV.T, np.tile(Pm[:, None], (1, N)))[0]
-            out[self._o_v:self._o_eps] = np.asarray(V).reshape(nv, N).T.reshape(-1)
-        out[self._o_eps:self._o_p] = cx[ps.off_eps:]
-        out[self._o_p:] = X[0, -1, nx:]
+            cols = lambda a: np.moveaxis(a, -1, 0).reshape(a.shape[-1], -1)        # noqa: E731   (numel, batch * N)
+            V = np.asarray(self._v_fun.eval(cols(X[..., 1:, -1, :] * sx), cols(U * su), cols(TV), cols(Pm))[0])
+            out[..., self._o_v:self._o_eps] = np.moveaxis(V.reshape((nv,) + lead + (N,)), 0, -1).reshape(lead + (-1,))
+        out[..., self._o_eps:self._o_p] = cx[..., ps.off_eps:]
+        out[..., self._o_p:] = X[..., 0, -1, nx:]
         return out
 
     def _lam_from_chain(self, lam_chain: np.ndarray, ox: np.ndarray, opt_p: NumStruct) -> np.ndarray:
@@ -508,14 +529,7 @@ class MHE:
         """the NLP of the current opt_p_num from the initial guess opt_x_num (Optimizer.solve, optimizer.py:731-787)"""
         mpc, ps, m, N = self._mpc, self._ps, self.model, self.settings.n_horizon
         P = mpc.opt_p_num.master
-        P[:] = 0.0
-        P[:m.n_x] = _arr(self._opt_p_num["_x_prev"])
-        P[m.n_x:ps.nx] = _arr(self._opt_p_num["_p_est_prev"])
-        TV = P[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)
-        if m.n_tvp:
-            TV[:N, :m.n_tvp] = self._opt_p_num.master[self._po_tvp:self._po_y].reshape(N, m.n_tvp)
-        TV[:N, m.n_tvp:] = self._opt_p_num.master[self._po_y:].reshape(N, m.n_y)
-        P[ps.p_off_p:ps.p_off_uprev] = self._opt_p_num.master[self._po_pset:self._po_tvp]
+        P[:] = self._p_to_chain(self._opt_p_num.master)
         mpc.opt_x_num.master[:] = self._to_chain(self._opt_x_num.master)
         mpc.solve()
         self.solver_stats = mpc.solver_stats
@@ -523,6 +537,21 @@ class MHE:
         self._opt_x_num.master[:] = ox
         self.opt_x_num_unscaled.master[:] = ox * self.opt_x_scaling.master
         self.lam_g_num = self._lam_from_chain(mpc.lam_g_num, ox, self._opt_p_num)
+
+    def solve_batch(self, OPT_P: np.ndarray, OPT_X_INIT: np.ndarray) -> dict:
+        """B estimation problems of this estimator (same model / settings, different parameter vectors: previous estimates,
+        measurement windows, ...) in ONE device call - what a bank of estimators, or an estimator inside a batched closed loop,
+        needs.  OPT_P: (B, n_opt_p), OPT_X_INIT: (B, n_opt_x), both in the reference's layouts; returns the solutions in the same
+        layout, the estimates x(t_N) and p_est, and the solver statistics.  Needs `settings.max_batch >= B` at setup."""
+        mpc, m = self._mpc, self.model
+        OPT_P = np.asarray(OPT_P, dtype=float).reshape(-1, self.n_opt_p)
+        B = OPT_P.shape[0]
+        P = self._p_to_chain(OPT_P)
+        Xi = self._to_chain(np.asarray(OPT_X_INIT, dtype=float).reshape(B, self.n_opt_x))
+        r = self.S.solve_batch(Xi, mpc._lb_opt_x.master, mpc._ub_opt_x.master, mpc._nlp_cons_lb, mpc._nlp_cons_ub, P)
+        ox = self._from_chain(r["x"], P)
+        xN = ox[:, self._o_u - m.n_x:self._o_u] * self._x_scaling.master
+        return {"opt_x": ox, "x": xN, "p_est": ox[:, self._o_p:], "stats": r["stats"]}
 
     def make_step(self, y0: np.ndarray) -> np.ndarray:
         """_mhe.py:896-993: the current measurement in, the state estimate at the end of the horizon out"""

@@ -412,3 +412,21 @@ def check_mhe_golden_replay(make_mhe, steps=5):
     inside = (x > nlp.lbx + 1e-6) & (x < nlp.ubx - 1e-6)
     assert np.max(np.abs(rd[inside])) < 1e-7
     return mhe
+
+
+def check_mhe_batch(make_mhe):
+    """MHE.solve_batch: the five estimation problems of the stored run (each from the initial guess of the reference: the previous
+    stored solution, the documented guess for the first) in ONE call = IPOPT's stored solutions; problems repeated to fill a batch of 12"""
+    g = golden("rotating_masses")
+    OX, OP = g["estimator._opt_x_num"], g["estimator.opt_p_num"]
+    mhe = make_mhe(max_batch=16)
+    init0 = np.zeros(mhe.n_opt_x)
+    init0[mhe._o_p:] = 1e-4
+    idx = np.array([0, 1, 2, 3, 4, 4, 3, 2, 1, 0, 2, 4])
+    INIT = np.array([init0 if k == 0 else OX[k - 1] for k in idx])
+    r = mhe.solve_batch(OP[idx], INIT)
+    assert np.all(r["stats"]["success"] == 1)
+    for j, k in enumerate(idx):
+        assert relerr(r["opt_x"][j], OX[k]) < 1e-8, (j, k, relerr(r["opt_x"][j], OX[k]))
+        assert relerr(r["x"][j], OX[k][mhe._o_u - 8:mhe._o_u]) < 1e-8 and abs(r["p_est"][j, 0] - OX[k][-1]) < 1e-10
+    return mhe

@@ -322,3 +322,8 @@ def test_mhe_golden_replay():
     """moving horizon estimation on the HIP path: the reference's estimator run (results_rotatingMasses.pkl) step by step"""
     ex = CASES["rotating_masses"]
     pc.check_mhe_golden_replay(lambda: ex.build_mhe(ex.build_model()))
+
+
+def test_mhe_batch_of_estimation_problems():
+    ex = CASES["rotating_masses"]
+    pc.check_mhe_batch(lambda **kw: ex.build_mhe(ex.build_model(), **kw))

@@ -95,3 +95,7 @@ def test_mpc_plant_mhe_closed_loop_reproduces_the_reference_run():
         x_est = mhe.make_step(y).ravel()
         worst = np.maximum(worst, [pc.relerr(u0, g["mpc._u"][k]), pc.relerr(y, g["estimator._y"][k]), pc.relerr(mhe.data["_x"][k], g["estimator._x"][k])])
     assert np.all(worst < 1e-8), worst
+
+
+def test_mhe_batch_of_estimation_problems():
+    pc.check_mhe_batch(make_mhe)

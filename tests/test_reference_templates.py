@@ -82,6 +82,19 @@ def test_unedited_templates_lower_to_the_same_model(name, compat):
     assert "DOMPC_NX %d" % m1.n_x in ref_mpc.generated_header
 
 
+@pytest.mark.parametrize("name", ["industrial_poly", "CSTR", "rotating_masses"])
+def test_unedited_templates_with_mx_symbols_lower_to_the_same_model(name, compat):
+    """the reference's tests build every example twice, `template_model('SX')` and `template_model('MX')`
+    (testing/test_industrial_poly.py:57-63): both symbol types are the same scalar expression graph here - same generated header"""
+    import json
+    d = os.path.join(REF, DIRS[name])
+    tm = _load(os.path.join(d, "template_model.py"), f"ref_{name}_template_model_mx")
+    tc = _load(os.path.join(d, "template_mpc.py"), f"ref_{name}_template_mpc_mx")
+    with hostemu.patched():
+        mpc = tc.template_mpc(tm.template_model("MX"), silence_solver=True)
+    assert json.load(open(HASHES))[name] == mpc.model_hash
+
+
 def test_unedited_mhe_template_lowers_to_the_same_estimator_and_replays_the_stored_run(compat):
     """template_mhe.py of examples/rotating_oscillating_masses_mhe_mpc, un-edited (`do_mpc.estimator.MHE`, `mhe._p_est[...]`,
     `mhe.data._y`-driven y_fun, default objective with symbolic weights): the chain problem it lowers to has the same generated

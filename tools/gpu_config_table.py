@@ -96,6 +96,48 @@ def run(label, name, kw, Bs, out):
         torch.cuda.empty_cache()
 
 
+def run_mhe(Bs, out):
+    """moving horizon estimation (do_mpc_amd.estimator.MHE, rotating masses, horizon 10, one estimated parameter): B estimation
+    problems per launch - the five problems of the reference's stored run with perturbed measurement windows; "cold" = from the
+    documented initial guess (x = 0, p_est = 1e-4), "warm" = from the previous stored solution like the reference's loop"""
+    import torch
+    ex = CASES["rotating_masses"]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rotating_masses.npz"))
+    OX, OP = g["estimator._opt_x_num"], g["estimator.opt_p_num"]
+    mhe = ex.build_mhe(ex.build_model(), max_batch=max(Bs))
+    mpc, S, ps = mhe._mpc, mhe.S, mhe._ps
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)      # noqa: E731
+    tlbx, tubx, tlbg, tubg = t(mpc._lb_opt_x.master), t(mpc._ub_opt_x.master), t(mpc._nlp_cons_lb), t(mpc._nlp_cons_ub)
+    stream = torch.cuda.current_stream()
+    rng = np.random.default_rng(5)
+    for B in Bs:
+        idx = 1 + np.arange(B) % 4                                   # problems 1..4 (a stored previous solution exists)
+        P_ref = OP[idx].copy()
+        P_ref[:, mhe._po_y:] += 1e-3 * rng.standard_normal((B, P_ref.shape[1] - mhe._po_y))
+        init0 = np.zeros(mhe.n_opt_x)
+        init0[mhe._o_p:] = 1e-4
+        tP = t(mhe._p_to_chain(P_ref))
+        guesses = {"cold": t(mhe._to_chain(np.tile(init0, (B, 1)))), "warm": t(mhe._to_chain(OX[idx - 1]))}
+        tX = torch.empty((B, ps.n_opt_x), dtype=torch.float64, device=dev)
+        tF = torch.empty(B, dtype=torch.float64, device=dev)
+        tStats = torch.zeros(B * STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        row = {"config": "MHE rotating masses N=10, 1 estimated parameter", "B": B}
+        for kind, guess in guesses.items():
+            for rep in range(2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                S.solve_batch_device(B, guess.data_ptr(), tlbx.data_ptr(), tubx.data_ptr(), tlbg.data_ptr(), tubg.data_ptr(),
+                                     tP.data_ptr(), tX.data_ptr(), 0, 0, 0, tF.data_ptr(), tStats.data_ptr(), stream=stream.cuda_stream)
+                e1.record(stream)
+                torch.cuda.synchronize()
+            st = np.frombuffer(tStats.cpu().numpy().tobytes(), dtype=STATS_DTYPE)
+            ms = e0.elapsed_time(e1)
+            row.update({kind + "_ms": ms, kind + "_steps_s": B / ms * 1e3, kind + "_ok": int(st["success"].sum()), kind + "_iters": float(st["iter_count"].mean())})
+        out.append(row)
+        print(json.dumps(row), flush=True)
+
+
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else None
     bmax = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
@@ -103,6 +145,7 @@ def main():
     rows = []
     for label, name, kw in CONFIGS:
         run(label, name, kw, Bs, rows)
+    run_mhe([b for b in Bs if b <= 4096], rows)
     lines = ["| config | B | cold ms | cold steps/s | cold conv. | cold iters | warm ms | warm steps/s | warm conv. | warm iters |",
              "|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
