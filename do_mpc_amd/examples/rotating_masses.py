@@ -27,7 +27,9 @@ def setpoint_trajectory():
     return np.array(traj)
 
 
-def build_model(symvar_type="SX"):
+def build_model(symvar_type="SX", process_noise=False):
+    """process_noise: additive noise on the three angular accelerations (`set_rhs(..., process_noise=True)`; not in the reference's
+    example - the estimator variant build_mhe_w uses it)"""
     mdl = Model("continuous", symvar_type)
     phi = vertcat(*[mdl.set_variable("_x", "phi_%d" % i) for i in (1, 2, 3)])
     dphi = mdl.set_variable("_x", "dphi", shape=(3, 1))
@@ -46,7 +48,7 @@ def build_model(symvar_type="SX"):
     left = [phi_m[0], phi[0], phi[1]]
     right = [phi[1], phi[2], phi_m[1]]
     mdl.set_rhs("dphi", vertcat(*[-c[i] / th[i] * (phi[i] - left[i]) - c[i + 1] / th[i] * (phi[i] - right[i])
-                                  - d[i] / th[i] * dphi[i] for i in range(3)]))
+                                  - d[i] / th[i] * dphi[i] for i in range(3)]), process_noise=process_noise)
     mdl.set_rhs("phi_m", 1 / 1e-2 * (phi_m_set - phi_m))
     mdl.setup()
     return mdl
@@ -120,5 +122,36 @@ def build_mhe(model, silence_solver=True, **overrides):
     mhe.bounds["upper", "_x", "dphi"] = 6
     mhe.set_nl_cons("p_est_lb", -mhe._p_est["Theta_1"] + 1e-5, 0)
     mhe.set_nl_cons("p_est_ub", mhe._p_est["Theta_1"] - 1e-3, 0)
+    mhe.setup()
+    return mhe
+
+
+def build_mhe_w(model, silence_solver=True, **overrides):
+    """A second estimator on the model with process noise (build_model(process_noise=True)) for the paths the shipped example leaves
+    out: `_w` as decision variables with weight P_w, numeric weights, the box of Theta_1 as bounds of `_p_est`, an nl_cons row on a
+    state checked at the states only.  No stored run exists for it: compared with the oracle's solve of the restated NLP."""
+    from ..estimator import MHE
+    mhe = MHE(model, ["Theta_1"])
+    st = mhe.settings
+    st.n_horizon, st.t_step, st.store_full_solution, st.nl_cons_check_colloc_points = 6, 0.1, True, False
+    for k, v in overrides.items():
+        setattr(st, k, v)
+    if silence_solver:
+        st.supress_ipopt_output()
+    mhe.set_default_objective(1e-4 * np.eye(8), np.diag([1.0, 1.0, 1.0, 20.0, 20.0]), np.eye(1), 10.0 * np.eye(3))
+    tvp_template = mhe.get_tvp_template()
+    mhe.set_tvp_fun(lambda t_now: tvp_template)
+    p_template = mhe.get_p_template()
+    p_template["Theta_2"] = 2.25e-4
+    p_template["Theta_3"] = 2.25e-4
+    p_template["P_p"] = 1.0
+    mhe.set_p_fun(lambda t_now: p_template)
+    mhe.bounds["lower", "_u", "phi_m_set"] = -5
+    mhe.bounds["upper", "_u", "phi_m_set"] = 5
+    mhe.bounds["lower", "_x", "dphi"] = -6
+    mhe.bounds["upper", "_x", "dphi"] = 6
+    mhe.bounds["lower", "_p_est", "Theta_1"] = 1e-5
+    mhe.bounds["upper", "_p_est", "Theta_1"] = 1e-3
+    mhe.set_nl_cons("phi_1_ub", model.x["phi_1"] - 1.5, 0)
     mhe.setup()
     return mhe

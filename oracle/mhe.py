@@ -34,7 +34,8 @@ class OracleMHE:
         self.npe, self.nps, self.ntvp = npe, nps, len(c["tvp"])
         self.N = N = c["n_horizon"]
         self.deg = deg = c["collocation_deg"]
-        assert c["collocation_ni"] == 1 and not c.get("z") and c["nl_cons_check_colloc_points"]
+        assert c["collocation_ni"] == 1 and not c.get("z")
+        self.nl_colloc = bool(c["nl_cons_check_colloc_points"])
         self.M = M = deg + 1
         self.h = c["t_step"]
         self.tau, self.C, self.D = collocation_coeffs(deg, c["collocation_type"])
@@ -51,7 +52,8 @@ class OracleMHE:
         self.po_tvp = self.po_pset + nps
         self.po_y = self.po_tvp + N * self.ntvp
         self.n_opt_p = self.po_y + N * ny
-        self.rows_stage = M * nx + nx + ny + (M + 1) * ne
+        self.n_eval = (M if self.nl_colloc else 1) + 1          # evaluations of the nl_cons rows per stage (the last one twice, :1186-1188)
+        self.rows_stage = M * nx + nx + ny + self.n_eval * ne
         self.n_g = N * self.rows_stage
         self._build_stage()
         self._build_bounds()
@@ -94,10 +96,12 @@ class OracleMHE:
             rows.append(xe[a] - xb[a])
         for i in range(ny):                                             # measurement rows (meas_fun includes the noise v)
             rows.append(at(c["meas"][i], xb) - ym[i])
-        blocks = list(range(M)) + [M - 1]                               # (_mhe.py:1186-1188: the last point's rows once more)
-        for b in blocks:
+        # nl_cons rows: at every stored point of the interval (`_x[k+1, i]`) or at the state `_x[k, -1]`; then the rows of the last
+        # evaluated point once more (_mhe.py:1186-1188)
+        pts_nl = [xs[1 + b] for b in range(M)] if self.nl_colloc else [xs[0]]
+        for xv in pts_nl + [pts_nl[-1]]:
             for ncn in self.nl:
-                rows.append(at(ncn["expr"], xs[1 + b]))
+                rows.append(at(ncn["expr"], xv))
         lk = at(c["stage_cost"], xb)
         svars = [s for blk in xs for s in blk] + list(us) + list(ws) + list(vs) + list(pe)
         self.ns = len(svars)
@@ -153,8 +157,11 @@ class OracleMHE:
     def _build_bounds(self):
         c = self.case
         lb, ub = -np.inf * np.ones(self.n_opt_x), np.inf * np.ones(self.n_opt_x)
-        lb[:self.off_u].reshape(-1, self.nx)[:] = c["x_lb"]
-        ub[:self.off_u].reshape(-1, self.nx)[:] = c["x_ub"]
+        XL, XU = lb[:self.off_u].reshape(self.N + 1, self.M + 1, self.nx), ub[:self.off_u].reshape(self.N + 1, self.M + 1, self.nx)
+        if c.get("cons_check_colloc_points", True):
+            XL[:], XU[:] = c["x_lb"], c["x_ub"]
+        else:
+            XL[1:self.N, -1], XU[1:self.N, -1] = c["x_lb"], c["x_ub"]
         lb[self.off_u:self.off_w].reshape(-1, self.nu)[:] = c["u_lb"]
         ub[self.off_u:self.off_w].reshape(-1, self.nu)[:] = c["u_ub"]
         if self.npe:
@@ -164,9 +171,9 @@ class OracleMHE:
         ne = len(self.nl)
         if ne:
             G = lbg.reshape(self.N, self.rows_stage)
-            G[:, self.rows_stage - (self.M + 1) * ne:] = -np.inf
+            G[:, self.rows_stage - self.n_eval * ne:] = -np.inf
             U = ubg.reshape(self.N, self.rows_stage)
-            U[:, self.rows_stage - (self.M + 1) * ne:] = np.tile([q["ub"] for q in self.nl], self.M + 1)
+            U[:, self.rows_stage - self.n_eval * ne:] = np.tile([q["ub"] for q in self.nl], self.n_eval)
         self.lbg, self.ubg = lbg, ubg
 
     # ------------------------------------------------------------------ functions

@@ -299,6 +299,29 @@ def case_rotating_masses_mhe(**over):
     return dd
 
 
+def case_rotating_masses_mhe_w(**over):
+    """A second estimator on the same model, for the paths the shipped example leaves out (no stored run exists for it): process
+    noise on the three angular velocities (`set_rhs(..., process_noise=True)`), weights as numbers, the box of Theta_1 as bounds of
+    `_p_est`, one nl_cons row on a state checked at the states only (nl_cons_check_colloc_points = False), horizon 6."""
+    d = case_rotating_masses_mhe()
+    x, p = d["x"], d["p"]
+    w = sp.symbols("w_0:3")
+    rhs = list(d["rhs"])
+    for i in range(3):
+        rhs[3 + i] = rhs[3 + i] + w[i]
+    v = d["v"]
+    vv, ww = sp.Matrix(v), sp.Matrix(w)
+    stage = (vv.T * sp.diag(1, 1, 1, 20, 20) * vv)[0, 0] + 10.0 * (ww.T * ww)[0, 0]
+    dx = sp.Matrix([x[i] - d["x_prev"][i] for i in range(8)])
+    arrival = 1e-4 * (dx.T * dx)[0, 0] + 1.0 * (p[1] - d["p_est_prev"][0]) ** 2
+    dd = dict(d)
+    dd.update(name="rotating_masses_mhe_w", w=w, rhs=rhs, stage_cost=stage, arrival_cost=arrival, n_horizon=6,
+              nl_cons_check_colloc_points=False, nl_cons=[dict(name="phi_1_ub", expr=x[0] - 1.5, ub=0.0, soft=False)],
+              p_est_lb=1e-5, p_est_ub=1e-3)
+    dd.update(over)
+    return dd
+
+
 def case_oscillating_masses_dae(**over):
     """/root/reference/examples/oscillating_masses_discrete_dae/template_model.py:34-75, template_mpc.py:34-74: the discrete
     masses with the successor state as algebraic variable, x+ = z, 0 = z - A x - B u."""

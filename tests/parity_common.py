@@ -430,3 +430,28 @@ def check_mhe_batch(make_mhe):
         assert relerr(r["opt_x"][j], OX[k]) < 1e-8, (j, k, relerr(r["opt_x"][j], OX[k]))
         assert relerr(r["x"][j], OX[k][mhe._o_u - 8:mhe._o_u]) < 1e-8 and abs(r["p_est"][j, 0] - OX[k][-1]) < 1e-10
     return mhe
+
+
+def check_mhe_with_process_noise(make_mhe_w):
+    """An estimator with process noise `_w` (decision variables, weight P_w), `_p_est` bounds and an nl_cons row checked at the
+    states only - the paths the shipped example leaves out; no stored run exists: the product against the oracle's solve of the
+    restated reference NLP (oracle/mhe.py) from the same initial guess (different formulations, different iterates: 14 vs 29
+    iterations) - same solution (measured 5e-10) and multipliers (8e-13)"""
+    from oracle.mhe import OracleMHE
+    from oracle.models import case_rotating_masses_mhe_w
+    nlp = OracleMHE(case_rotating_masses_mhe_w())
+    mhe = make_mhe_w()
+    assert (nlp.n_opt_x, nlp.n_g, nlp.n_opt_p) == (mhe.n_opt_x, mhe.n_opt_lagr, mhe.n_opt_p)
+    OP = golden("rotating_masses")["estimator.opt_p_num"][4]
+    N = 6
+    P = np.concatenate([OP[:12], OP[12:12 + 26 * 10].reshape(10, 26)[:N].ravel(), OP[12 + 260:].reshape(10, 5)[-N:].ravel()])
+    init = nlp.initial_guess(np.zeros(8), np.zeros(2), 1e-4)
+    mhe.opt_p_num.master[:] = P
+    mhe.opt_x_num.master[:] = init
+    mhe.solve()
+    r = ipm.solve(nlp, init, P)
+    assert mhe.solver_stats["success"] and r["stats"]["success"]
+    assert relerr(mhe.opt_x_num.master, r["x"]) < 1e-7
+    assert np.max(np.abs(mhe.lam_g_num - r["lam_g"])) < 1e-7 * max(1.0, np.max(np.abs(r["lam_g"])))
+    assert np.max(np.abs(r["x"][nlp.off_w:nlp.off_v])) > 1e-5            # (the process noise is used)
+    return mhe

@@ -327,3 +327,8 @@ def test_mhe_golden_replay():
 def test_mhe_batch_of_estimation_problems():
     ex = CASES["rotating_masses"]
     pc.check_mhe_batch(lambda **kw: ex.build_mhe(ex.build_model(), **kw))
+
+
+def test_mhe_with_process_noise_against_the_oracle():
+    ex = CASES["rotating_masses"]
+    pc.check_mhe_with_process_noise(lambda: ex.build_mhe_w(ex.build_model(process_noise=True)))

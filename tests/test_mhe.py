@@ -99,3 +99,10 @@ def test_mpc_plant_mhe_closed_loop_reproduces_the_reference_run():
 
 def test_mhe_batch_of_estimation_problems():
     pc.check_mhe_batch(make_mhe)
+
+
+def test_mhe_with_process_noise_against_the_oracle():
+    def make():
+        with hostemu.patched():
+            return ex.build_mhe_w(ex.build_model(process_noise=True))
+    pc.check_mhe_with_process_noise(make)
