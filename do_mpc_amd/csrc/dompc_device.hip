@@ -67,8 +67,10 @@ extern "C" __global__ void __launch_bounds__(256, DOMPC_LB) dompc_solve_kernel(d
   Thr T = make_thr(A);
   T.kp = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
   if (wide && A.mode != 1) dompc::xcd_census(T);
-  if (A.mode == 1) {
-    if (blockIdx.x == 0) dompc::debug_newton(T, A);
+  if (A.mode == 1) {                     // Newton steps at one point for A.batch parameter vectors: one workgroup (= slot) each
+    const int bq = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    const int sq = slot_of_block(A);
+    if (bq < A.batch) dompc::debug_newton(T, A, bq, sq);
     return;
   }
   // (single call site of solve_problem: the compiler inlines the whole solver into the kernel; an
@@ -109,7 +111,10 @@ extern "C" void dompc_hostemu_run(const dompc::KArgs* A) {
     for (int i = 0; i < 2 * dompc::MAX_FILTER; ++i) filt[i] = v;
   }
   dompc::Thr T{0, 1, red, filt, flags, edge_lds, nullptr, 1, 0, 1, 0, 1, nullptr, nullptr, 0u, 0u, dompc::make_xctx(*A), 0u, nullptr};
-  if (A->mode == 1) { dompc::debug_newton(T, *A); return; }
+  if (A->mode == 1) {
+    for (int b = 0; b < A->batch; ++b) dompc::debug_newton(T, *A, b, 0);
+    return;
+  }
   for (int b = 0; b < A->batch; ++b) {
     if (A->mode == 2) dompc::sweep_problem(T, *A, b, 0);
     else dompc::solve_problem(T, *A, b, 0);

@@ -4661,9 +4661,10 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
 // ------------------------------------------------------------------------------------------------
 // mode 1: one Newton direction at a given primal-dual point (parity tests against the oracle's
 // sparse KKT solve).  Slacks: s = d(x) pushed inside, z_s = 1.
-DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A) {
+// (b: parameter vector / output row of a batched call - same point x, lam, z for every b; slot: workspace of the workgroup)
+DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A, int b = 0, int slot = 0) {
   const dompc_options& O = A.opt;
-  Prob Q = make_prob(A, 0, A.p);
+  Prob Q = make_prob(A, slot, A.p + (int64_t)b * A.n_opt_p);
   const int nX = A.n_opt_x;
   for (int g = T.tid; g < nX; g += T.nt) {
     Q.x[g] = A.x0[g]; Q.lb[g] = A.lbx[g]; Q.ub[g] = A.ubx[g];
@@ -4708,10 +4709,13 @@ DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A) {
   const int fail = run_backward(T, Q, 0, 0, A.dbg_mu, A.dbg_delta);
   run_forward(T, Q, 0, 0, A.dbg_mu, A.dbg_delta);
   for (int g = T.tid; g < nX; g += T.nt) {
-    A.dbg_dx[g] = fail ? NAN : Q.dx[g];
-    A.dbg_rd[g] = Q.rd[g];
+    A.dbg_dx[(int64_t)b * nX + g] = fail ? NAN : Q.dx[g];
+    A.dbg_rd[(int64_t)b * nX + g] = Q.rd[g];
   }
-  for (int r = T.tid; r < A.n_g; r += T.nt) { A.dbg_dlam[r] = Q.dlam[r]; A.dbg_c[r] = Q.c[r]; }
+  for (int r = T.tid; r < A.n_g; r += T.nt) {
+    A.dbg_dlam[(int64_t)b * A.n_g + r] = Q.dlam[r];
+    A.dbg_c[(int64_t)b * A.n_g + r] = Q.c[r];
+  }
   T.sync();
 }
 

@@ -807,6 +807,49 @@ extern "C" int dompc_newton_step_at_solution(dompc_handle* h, const double* x, c
   return newton_step_impl(h, x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p, mu, 0.0, dx, dlam, nullptr, nullptr, 1);
 }
 
+// B parameter vectors at ONE point (dompc_ipm.h): one launch per chunk of resident slots, one workgroup per vector
+extern "C" int dompc_newton_steps_at_solution(dompc_handle* h, int32_t B, const double* x, const double* lam_g, const double* zl,
+                                              const double* zu, const double* lbx, const double* ubx, const double* lbg,
+                                              const double* ubg, const double* p, double mu, double* dx, double* dlam) {
+  if (!h || B < 1) return 1;
+#ifndef DOMPC_HOST_EMU
+  HIPCHK(h, hipSetDevice(h->d.device));
+#endif
+  const dompc_problem_desc& d = h->d;
+  if (h->sharded) { h->error = "dompc_newton_steps_at_solution is not available on a sharded handle"; return 1; }
+  int chunk = h->n_slots < B ? h->n_slots : B;
+#ifdef DOMPC_HOST_EMU
+  chunk = B;
+#endif
+  if (chunk < 1) chunk = 1;
+  if (ensure_staging(h, chunk)) return 1;
+  int rc = 0;
+  rc |= h2d(h, h->s_x0, x, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_lbx, lbx, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_ubx, ubx, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_lbg, lbg, sizeof(double) * d.n_g);
+  rc |= h2d(h, h->s_ubg, ubg, sizeof(double) * d.n_g);
+  rc |= h2d(h, h->s_dbg[0], lam_g, sizeof(double) * d.n_g);
+  rc |= h2d(h, h->s_dbg[1], zl, sizeof(double) * d.n_opt_x);
+  rc |= h2d(h, h->s_dbg[2], zu, sizeof(double) * d.n_opt_x);
+  if (rc) return 1;
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = (B - b0 < chunk) ? B - b0 : chunk;
+    if (h2d(h, h->s_p, p + (size_t)b0 * d.n_opt_p, sizeof(double) * (size_t)nb * d.n_opt_p)) return 1;
+    dompc::KArgs A = h->base;
+    A.x0 = h->s_x0; A.lbx = h->s_lbx; A.ubx = h->s_ubx; A.lbg = h->s_lbg; A.ubg = h->s_ubg; A.p = h->s_p;
+    A.dbg_lam = h->s_dbg[0]; A.dbg_zl = h->s_dbg[1]; A.dbg_zu = h->s_dbg[2];
+    A.dbg_dx = h->s_x; A.dbg_dlam = h->s_lamg; A.dbg_rd = h->s_lamx; A.dbg_c = h->s_g;        // (batch staging buffers: nb rows each)
+    A.dbg_mu = mu; A.dbg_delta = 0.0;
+    A.batch = nb; A.mode = 1; A.dbg_at_solution = 1;
+    if (launch(h, A, nb, fit_block(h, 256), main_stream(h))) return 1;
+    rc |= d2h(h, dx + (size_t)b0 * d.n_opt_x, h->s_x, sizeof(double) * (size_t)nb * d.n_opt_x);
+    rc |= d2h(h, dlam + (size_t)b0 * d.n_g, h->s_lamg, sizeof(double) * (size_t)nb * d.n_g);
+    if (rc || dev_sync(h)) return 1;
+  }
+  return 0;
+}
+
 // Iteration trace of problem 0 of the last solve call: rows of 8 doubles
 // (it, mu, E0, inf_pr, inf_du, +-alpha (negative = line search failed), delta_w, obj).
 extern "C" int dompc_debug_get_trace(dompc_handle* h, double* out, int32_t max_rows) {

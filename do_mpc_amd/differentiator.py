@@ -16,7 +16,7 @@ and the Newton direction the kernels return at a point v is d(p) = -K(p)^-1 F(v;
     dv/dp_j = [d(p + h e_j) - d(p)] / h        exactly for every parameter that enters F linearly (x0, u_prev: any h),
             ~ [d(p + h e_j) - d(p - h e_j)] / 2h  for the others (_p, _tvp: O(h^2), the matrix changes by O(h |F|) ~ 0).
 
-One `dompc_newton_step_at_solution` call per column (+1), all at the solution point - no symbolic KKT matrix, no dense
+All columns (+1 residual direction) in one batched `dompc_newton_steps_at_solution` call, all at the solution point - no symbolic KKT matrix, no dense
 solve.  Models with nl_cons rows: the slack variables of the rows take their values at the solution (s = d(x), multipliers
 mu / distance) inside the call, the soft-constraint variables `_eps` are ordinary decision variables.
 Strict complementarity is assumed like in the reference (`check_SC`): a bound whose multiplier is not clearly separated
@@ -132,29 +132,30 @@ class DoMPCDifferentiator:
         lbg, ubg = mpc._nlp_cons_lb, mpc._nlp_cons_ub
         p0 = mpc.opt_p_num.master.copy()
 
-        def direction(p):
-            dx, dlam = mpc.S.newton_step_at_solution(x, lam, zl, zu, lb, ub, lbg, ubg, p, mu)
-            if not np.all(np.isfinite(dx)):
-                raise RuntimeError("DoMPCDifferentiator: the KKT matrix at the solution has the wrong inertia")
-            return dx, dlam
-
-        d0x, d0l = direction(p0)
-        dxdp = np.zeros((self.n_x, self.n_p))
-        dldp = np.zeros((self.n_g, self.n_p))
+        # every direction in ONE batched call (dompc_newton_steps_at_solution: one workgroup per parameter vector): the residual
+        # direction at p0, one forward step per parameter that enters linearly (exact), a central pair for the others
+        rows, plan = [p0.copy()], []
         for j in range(self.n_p):
-            p = p0.copy()
             if self._linear[j]:
                 h = max(1.0, abs(p0[j]))
-                p[j] = p0[j] + h
-                dx, dl = direction(p)
-                dxdp[:, j], dldp[:, j] = (dx - d0x) / h, (dl - d0l) / h
+                p = p0.copy(); p[j] = p0[j] + h
+                plan.append((j, h, len(rows), -1)); rows.append(p)
             else:
                 h = self.settings.fd_step * max(1.0, abs(p0[j]))
-                p[j] = p0[j] + h
-                dxp, dlp = direction(p)
-                p[j] = p0[j] - h
-                dxm, dlm = direction(p)
-                dxdp[:, j], dldp[:, j] = (dxp - dxm) / (2 * h), (dlp - dlm) / (2 * h)
+                pp, pm = p0.copy(), p0.copy()
+                pp[j], pm[j] = p0[j] + h, p0[j] - h
+                plan.append((j, h, len(rows), len(rows) + 1)); rows.extend([pp, pm])
+        DX, DL = mpc.S.newton_steps_at_solution(x, lam, zl, zu, lb, ub, lbg, ubg, np.array(rows), mu)
+        if not np.all(np.isfinite(DX)):
+            raise RuntimeError("DoMPCDifferentiator: the KKT matrix at the solution has the wrong inertia")
+        d0x, d0l = DX[0], DL[0]
+        dxdp = np.zeros((self.n_x, self.n_p))
+        dldp = np.zeros((self.n_g, self.n_p))
+        for j, h, ip, im in plan:
+            if im < 0:
+                dxdp[:, j], dldp[:, j] = (DX[ip] - d0x) / h, (DL[ip] - d0l) / h
+            else:
+                dxdp[:, j], dldp[:, j] = (DX[ip] - DX[im]) / (2 * h), (DL[ip] - DL[im]) / (2 * h)
         self.status = {"n_newton_solves": 1 + int(self._linear.sum()) + 2 * int((~self._linear).sum()),
                        "residual_step": float(np.max(np.abs(d0x)))}
         dxdp *= self.x_scaling_factors[:, None]                    # _nlpdifferentiator.py:851-853

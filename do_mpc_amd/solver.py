@@ -106,6 +106,8 @@ def _load(lib_path: str) -> C.CDLL:
     lib.dompc_debug_newton_step.restype = C.c_int
     lib.dompc_newton_step_at_solution.argtypes = [vp] + [vp] * 9 + [C.c_double] + [vp] * 2
     lib.dompc_newton_step_at_solution.restype = C.c_int
+    lib.dompc_newton_steps_at_solution.argtypes = [vp, C.c_int32] + [vp] * 9 + [C.c_double] + [vp] * 2
+    lib.dompc_newton_steps_at_solution.restype = C.c_int
     lib.dompc_debug_get_trace.argtypes = [vp, vp, C.c_int32]
     lib.dompc_debug_get_trace.restype = C.c_int
     lib.dompc_abort.argtypes = [vp, C.c_int32]
@@ -404,6 +406,17 @@ class HipIpmSolver:
         dx = np.empty(ps.n_opt_x)
         dlam = np.empty(ps.n_g)
         self._check(self._lib.dompc_newton_step_at_solution(self._h, *[_ptr(v) for v in a], float(mu), _ptr(dx), _ptr(dlam)))
+        return dx, dlam
+
+    def newton_steps_at_solution(self, x, lam_g, zl, zu, lbx, ubx, lbg, ubg, P, mu):
+        """`dompc_newton_steps_at_solution`: the Newton directions for B parameter vectors (rows of P) at one point, one launch"""
+        ps = self.structure
+        P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, ps.n_opt_p))
+        B = P.shape[0]
+        a = [_f64(v) for v in (x, lam_g, zl, zu, lbx, ubx, lbg, ubg)]
+        dx = np.empty((B, ps.n_opt_x))
+        dlam = np.empty((B, ps.n_g))
+        self._check(self._lib.dompc_newton_steps_at_solution(self._h, B, *[_ptr(v) for v in a], _ptr(P), float(mu), _ptr(dx), _ptr(dlam)))
         return dx, dlam
 
     def debug_newton_step(self, x, lam_g, zl, zu, lbx, ubx, lbg, ubg, p, mu, delta_w=0.0):

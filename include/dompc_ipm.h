@@ -175,6 +175,14 @@ int dompc_newton_step_at_solution(dompc_handle* h,
                                   const double* lbx, const double* ubx, const double* lbg, const double* ubg,
                                   const double* p, double mu, double* dx, double* dlam);
 
+/* The same for B parameter vectors p (row-major B x n_opt_p) at ONE point: one workgroup per vector, B directions in one launch
+ * (dx: B x n_opt_x, dlam: B x n_g) - all columns of a sensitivity matrix at once (do_mpc_amd/differentiator.py; the reference
+ * factorises the dense KKT matrix once and solves for all right-hand sides, _nlpdifferentiator.py:792-841). */
+int dompc_newton_steps_at_solution(dompc_handle* h, int32_t B,
+                                   const double* x, const double* lam_g, const double* zl, const double* zu,
+                                   const double* lbx, const double* ubx, const double* lbg, const double* ubg,
+                                   const double* p, double mu, double* dx, double* dlam);
+
 /* Iteration trace of problem 0 of the last solve: rows of 8 doubles (it, mu, E0, inf_pr, inf_du,
  * +-alpha (negative: line search failed), delta_w, obj). */
 int dompc_debug_get_trace(dompc_handle* h, double* out, int32_t max_rows);
