@@ -278,30 +278,41 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     return text + f"\n#define DOMPC_MODEL_HASH \"{digest}\"\n"
 
 
-def lower_plant(*, x_sym, u_sym, tvp_sym, p_sym, w_sym, v_sym, rhs, meas, discrete, name="plant") -> str:
+def lower_plant(*, x_sym, u_sym, tvp_sym, p_sym, w_sym, v_sym, rhs, meas, discrete, name="plant", z_sym=(), alg=()) -> str:
     """Header for the batched plant integrator (csrc/dompc_plant.hip): the model's right-hand side and measurement
     function in PHYSICAL units, as the reference's Simulator integrates them
-    (/root/reference/do_mpc/simulator.py:363-416: `_rhs_fun(x, u, z, tvp, p, w)`, `_meas_fun` at :822)."""
-    groups = [("x", x_sym), ("u", u_sym), ("tvp", tvp_sym), ("p", p_sym), ("w", w_sym), ("v", v_sym)]
+    (/root/reference/do_mpc/simulator.py:363-416: `_rhs_fun(x, u, z, tvp, p, w)`, `_meas_fun` at :822).
+    Models with algebraic states (semi-explicit index-1 DAE, simulator.py:381-416 IDAS / :363-378 the root-finding problem of a
+    discrete DAE): `plant_alg` returns the algebraic equations and their Jacobian w.r.t. z - the kernel solves them for z by
+    Newton's method inside every right-hand-side evaluation."""
+    nz = len(z_sym)
+    groups = [("x", x_sym), ("u", u_sym), ("tvp", tvp_sym), ("p", p_sym), ("w", w_sym), ("v", v_sym), ("z", z_sym)]
     binds: Dict[int, str] = {}
     for cname, syms in groups:
         for i, s in enumerate(syms):
             binds[s.idx] = f"{cname}[{i}]"
-    for what, nodes in (("rhs", rhs), ("meas", meas)):
+    for what, nodes in (("rhs", rhs), ("meas", meas), ("alg", alg)):
         free = [s for s in sym.free_symbols(list(nodes)) if s.idx not in binds]
         if free:
-            raise Exception(f"{what} depends on symbols outside (_x,_u,_tvp,_p,_w,_v): {free}")
+            raise Exception(f"{what} depends on symbols outside (_x,_u,_z,_tvp,_p,_w,_v): {free}")
     sig = "const double* x, const double* u, const double* tvp, const double* p"
+    zarg = ", const double* z" if nz else ""
     parts = []
     body = sym.emit_c([(f"f[{i}]", e) for i, e in enumerate(rhs)], binds, indent="  ")
-    parts.append(f"DOMPC_FN void plant_rhs({sig}, const double* w, double* f) {{\n{body}\n}}\n")
+    parts.append(f"DOMPC_FN void plant_rhs({sig}, const double* w{zarg}, double* f) {{\n{body}\n}}\n")
     body = sym.emit_c([(f"y[{i}]", e) for i, e in enumerate(meas)], binds, indent="  ")
-    parts.append(f"DOMPC_FN void plant_meas({sig}, const double* v, double* y) {{\n{body}\n}}\n")
+    parts.append(f"DOMPC_FN void plant_meas({sig}, const double* v{zarg}, double* y) {{\n{body}\n}}\n")
+    if nz:
+        Jz = sym.forward_jacobian(list(alg), list(z_sym))
+        outs = [(f"a[{i}]", e) for i, e in enumerate(alg)] + [(f"Jz[{i * nz + j}]", Jz[i][j]) for i in range(nz) for j in range(nz)]
+        body = sym.emit_c(outs, binds, indent="  ")
+        parts.append(f"DOMPC_FN void plant_alg({sig}, const double* w, const double* z, double* a, double* Jz) {{\n{body}\n}}\n")
     hdr = ["// GENERATED by do_mpc_amd/lowering.py:lower_plant - do not edit.", "#pragma once", "#include <math.h>",
            f"#define PLANT_MODEL_NAME \"{name}\"",
            f"#define PLANT_NX {len(x_sym)}", f"#define PLANT_NU {len(u_sym)}", f"#define PLANT_NP {len(p_sym)}",
            f"#define PLANT_NTVP {len(tvp_sym)}", f"#define PLANT_NW {len(w_sym)}", f"#define PLANT_NV {len(v_sym)}",
-           f"#define PLANT_NY {len(meas)}", f"#define PLANT_DISCRETE {1 if discrete else 0}", ""]
+           f"#define PLANT_NY {len(meas)}", f"#define PLANT_DISCRETE {1 if discrete else 0}",
+           *([f"#define PLANT_NZ {nz}"] if nz else []), ""]
     text = "\n".join(hdr) + "\n" + "\n".join(parts)
     digest = hashlib.sha256(text.encode()).hexdigest()[:16]
     return text + f"\n#define PLANT_MODEL_HASH \"{digest}\"\n"

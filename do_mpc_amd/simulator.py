@@ -91,6 +91,7 @@ class Simulator:
             self.settings.t_step = self.settings.t_step
         self._x0 = model._x(0.0)
         self._u0 = model._u(0.0)
+        self._z0 = model._z(0.0)
         self._t0 = np.array([0.0])
         from .controller import MPCData                 # per-step records like the reference's simulator.data (simulator.py:833-841)
         self.data = MPCData(model)
@@ -106,6 +107,7 @@ class Simulator:
         tgt.master[:] = a
 
     x0 = property(lambda self: self._x0, lambda self, v: self._set_iter("_x0", v))
+    z0 = property(lambda self: self._z0, lambda self, v: self._set_iter("_z0", v))
     u0 = property(lambda self: self._u0, lambda self, v: self._set_iter("_u0", v))
     t0 = property(lambda self: self._t0)
 
@@ -155,14 +157,13 @@ class Simulator:
         return lowering.lower_plant(
             x_sym=m._x.cat.nodes(), u_sym=m._u.cat.nodes(), tvp_sym=m._tvp.cat.nodes(), p_sym=m._p.cat.nodes(),
             w_sym=m._w.cat.nodes(), v_sym=m._v.cat.nodes(), rhs=m._rhs.nodes(), meas=m._y.cat.nodes(),
-            discrete=m.model_type == "discrete", name=type(m).__name__)
+            discrete=m.model_type == "discrete", name=type(m).__name__,
+            z_sym=m._z.cat.nodes(), alg=(m._alg.nodes() if m.n_z else []))
 
     def setup(self, _lib_path: Optional[str] = None, _code_object: Optional[str] = None) -> None:
         self.settings.check_for_mandatory_settings()
         self._check_validity()
         m = self.model
-        if m.n_z:
-            raise NotImplementedError("plant integrator: algebraic states (_z) are not supported")
         self.generated_header = self._lower()
         self.model_hash = self.generated_header.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0]
         if _lib_path is None:
@@ -200,9 +201,30 @@ class Simulator:
 
     # ------------------------------------------------------------------ runtime
     def set_initial_guess(self) -> None:
-        """Initial guess of the algebraic states for the DAE solver (simulator.py:603-620).  Models with algebraic states
-        are refused at setup, so there is nothing to initialise; kept because every main.py of the reference calls it."""
+        """Initial guess of the algebraic states for the DAE solver (simulator.py:603-620).  The kernel solves the
+        algebraic equations by Newton's method from z = 0 inside every right-hand-side evaluation; kept because every main.py of the
+        reference calls it."""
         assert self.flags["setup"], "Simulator was not setup yet. Please call Simulator.setup()."
+
+    def _host_z(self, x, u, tvp, p) -> np.ndarray:
+        """algebraic states at (x, u) for the data records (Newton's method on the model's own functions, from the last values)"""
+        m = self.model
+        if not m.n_z:
+            return np.zeros(0)
+        if getattr(self, "_algJ_fun", None) is None:
+            from . import sym
+            ins = [m._x.cat, m._u.cat, m._z.cat, m._tvp.cat, m._p.cat, m._w.cat]
+            self._algJ_fun = sym.Function("alg_jz", ins, [sym.jacobian(m._alg, m._z.cat)])
+        z, w = self._z0.master.copy(), np.zeros(m.n_w)
+        for _ in range(30):
+            a = np.asarray(m._alg_fun.eval(x, u, z, tvp, p, w)[0], float).ravel()
+            J = np.asarray(self._algJ_fun.eval(x, u, z, tvp, p, w)[0], float).reshape(m.n_z, m.n_z, order="F")
+            dz = np.linalg.solve(J, a)
+            z = z - dz
+            if np.max(np.abs(dz)) <= 1e-13 * max(1.0, np.max(np.abs(z))):
+                break
+        self._z0.master[:] = z
+        return z
 
     def make_step_batch(self, X, U=None, P=None, TVP=None, W=None, V=None) -> dict:
         """Advance B samples by one control interval.  X: [B][nx]; U, P, TVP, W, V: [B][n] or one row shared by all
@@ -256,8 +278,9 @@ class Simulator:
         if r["status"][0] != 0:
             raise RuntimeError("plant integration did not reach t_step (step limit or NaN right-hand side)")
         # records of the step: state BEFORE the step, the inputs and parameters it used, the new measurement (simulator.py:833-841)
-        aux0 = m._aux_expression_fun.eval(self._x0.master, u0.reshape(-1), np.zeros(0), tvp0, p0)[0]
-        self.data.update(_x=self._x0.master.copy(), _u=u0.reshape(-1), _z=np.zeros(0), _tvp=tvp0, _p=p0, _y=r["y"][0],
+        z0 = self._host_z(self._x0.master, u0.reshape(-1), tvp0, p0)      # (records only: the kernel solves for z itself)
+        aux0 = m._aux_expression_fun.eval(self._x0.master, u0.reshape(-1), z0, tvp0, p0)[0]
+        self.data.update(_x=self._x0.master.copy(), _u=u0.reshape(-1), _z=z0, _tvp=tvp0, _p=p0, _y=r["y"][0],
                          _aux=np.asarray(aux0, float).reshape(-1), _time=self._t0.copy())
         self._x0.master[:] = r["x"][0]
         self._u0.master[:] = u0.reshape(-1)

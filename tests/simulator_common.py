@@ -9,8 +9,10 @@ from do_mpc_amd.examples import CASES
 from do_mpc_amd.simulator import Simulator
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_hostemu")
-T_STEP = {"CSTR": 0.005, "batch_reactor": 1.0, "industrial_poly": 50.0 / 3600.0, "oscillating_masses": 0.5}
-U_TEST = {"CSTR": [20.0, -3000.0], "batch_reactor": [0.05], "industrial_poly": [20000.0, 350.0, 350.0], "oscillating_masses": [0.3]}
+T_STEP = {"CSTR": 0.005, "batch_reactor": 1.0, "industrial_poly": 50.0 / 3600.0, "oscillating_masses": 0.5,
+          "oscillating_masses_dae": 0.5, "dip": 0.04}
+U_TEST = {"CSTR": [20.0, -3000.0], "batch_reactor": [0.05], "industrial_poly": [20000.0, 350.0, 350.0], "oscillating_masses": [0.3],
+          "oscillating_masses_dae": [0.3], "dip": [1.5]}
 
 
 def make_simulator(name, hostemu=True, model=None, **params):

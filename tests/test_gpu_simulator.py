@@ -10,7 +10,7 @@ from test_closed_loop import CL_RTOL, run_closed_loop
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly", "oscillating_masses_dae", "dip"])
 def test_make_step_matches_scipy_radau(name):
     sc.check_against_scipy(name, hostemu=False)
 
@@ -20,12 +20,12 @@ def test_batch_semantics(name):
     sc.check_batch(name, hostemu=False, B=257)
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR", "industrial_poly", "oscillating_masses_dae", "dip"])
 def test_closed_loop_with_gpu_controller_and_gpu_plant_reproduces_the_reference_trajectory(name):
     def make_mpc(n):
         ex = CASES[n]
         return ex.build_mpc(ex.build_model())
-    wu, wx = run_closed_loop(make_mpc, name, make_plant=sc.closed_loop_plant(hostemu=False))
+    wu, wx = run_closed_loop(make_mpc, name, steps=5, make_plant=sc.closed_loop_plant(hostemu=False))
     assert wu < CL_RTOL and wx < CL_RTOL
 
 
