@@ -96,3 +96,121 @@ class BatchClosedLoop:
         torch.cuda.synchronize()
         st = np.frombuffer(self.stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
         return {"stats": st, "plant_status": (self.pstat.cpu().numpy() & 0xFF), "u0": self.U.cpu().numpy(), "x": self.X.cpu().numpy()}
+
+
+class BatchClosedLoopMHE:
+    """B closed loops controller -> plant -> moving horizon estimator -> controller advancing together, everything resident in HBM
+    (the loop of examples/rotating_oscillating_masses_mhe_mpc/main.py, one sample at a time on the host there): per control step
+    ONE batched solve of the controller (B problems), ONE batched plant step (states and measurements), ONE batched solve of the
+    estimator (B estimation problems), plus index arithmetic on device tensors - the estimator's parameter vectors (previous
+    estimates, sliding measurement window) and initial guesses are assembled from the previous device results.
+    The controller's and the estimator's problems live in their chain layouts (do_mpc_amd/estimator.py); torch is the allocator
+    and does the slicing."""
+
+    def __init__(self, mpc, simulator, mhe, X0_true, x0_est=None, p_est0=None, device: int = 0):
+        import torch
+        self.torch = torch
+        self.mpc, self.sim, self.mhe = mpc, simulator, mhe
+        m = simulator.model
+        ps, es = mpc.structure, mhe._ps                     # controller / estimator chain structures
+        self.ps, self.es = ps, es
+        X0_true = np.asarray(X0_true, dtype=float).reshape(-1, m.n_x)
+        self.B = B = X0_true.shape[0]
+        dev = self.dev = torch.device("cuda", device)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)      # noqa: E731
+        nx, nu, ny, npe = m.n_x, m.n_u, m.n_y, mhe.n_p_est
+        self.nx, self.nu, self.ny, self.npe = nx, nu, ny, npe
+        x_est = np.zeros((B, nx)) if x0_est is None else np.broadcast_to(np.asarray(x0_est, float).reshape(-1, nx), (B, nx)).copy()
+        p_est = np.zeros((B, npe)) if p_est0 is None else np.broadcast_to(np.asarray(p_est0, float).reshape(-1, npe), (B, npe)).copy()
+        # ---- controller: opt_p rows, initial guess (set_initial_guess semantics), bounds
+        t0 = float(mpc._t0[0])
+        Pc = np.tile(mpc.opt_p_num.master, (B, 1))
+        Pc[:, :nx] = x_est
+        Pc[:, ps.p_off_tvp:ps.p_off_p] = mpc.tvp_fun(t0).master
+        Pc[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(t0).master
+        Pc[:, ps.p_off_uprev:] = 0.0
+        Gc = np.zeros((B, ps.n_opt_x))
+        Gc[:, :ps.off_z].reshape(B, -1, ps.nx)[:] = (x_est / mpc._x_scaling.master)[:, None, :]
+        self.Pc, self.Gc = t(Pc), t(Gc)
+        self.c_lbx, self.c_ubx = t(mpc._lb_opt_x.master), t(mpc._ub_opt_x.master)
+        self.c_lbg, self.c_ubg = t(mpc._nlp_cons_lb), t(mpc._nlp_cons_ub)
+        self.c_sol = torch.empty((B, ps.n_opt_x), dtype=torch.float64, device=dev)
+        self.c_f = torch.empty(B, dtype=torch.float64, device=dev)
+        self.c_stats = torch.zeros(B * STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        self.xs, self.us = t(mpc._x_scaling.master), t(mpc._u_scaling.master)
+        # ---- plant
+        self.X = t(X0_true)
+        self.Xn = torch.empty_like(self.X)
+        self.U = torch.empty((B, nu), dtype=torch.float64, device=dev)
+        self.Y = torch.empty((B, ny), dtype=torch.float64, device=dev)
+        self.pstat = torch.zeros(B, dtype=torch.int32, device=dev)
+        ts = float(simulator._t0[0])
+        self.p_plant = t(simulator.p_fun(ts).master if m.n_p else np.zeros(1))
+        self.tvp_plant = t(simulator.tvp_fun(ts).master if m.n_tvp else np.zeros(1))
+        # ---- estimator: chain opt_p rows (previous estimate | (tvp_k, y_k) per stage | p_set | 0), initial guess, bounds
+        N = self.N = mhe.settings.n_horizon
+        te = float(mhe._t0[0])
+        op = np.zeros((B, mhe.n_opt_p))
+        op[:, :nx] = x_est
+        op[:, nx:nx + npe] = p_est
+        op[:, mhe._po_pset:mhe._po_tvp] = mhe.p_fun(te).master
+        op[:, mhe._po_tvp:mhe._po_y] = mhe.tvp_fun(te).master
+        ge = np.zeros((B, mhe.n_opt_x))
+        ge[:, :mhe._o_u].reshape(B, -1, nx)[:] = (x_est / mhe._x_scaling.master)[:, None, :]
+        ge[:, mhe._o_p:] = p_est
+        self.Pe, self.Ge = t(mhe._p_to_chain(op)), t(mhe._to_chain(ge))
+        em = mhe._mpc
+        self.e_lbx, self.e_ubx = t(em._lb_opt_x.master), t(em._ub_opt_x.master)
+        self.e_lbg, self.e_ubg = t(em._nlp_cons_lb), t(em._nlp_cons_ub)
+        self.e_sol = torch.empty((B, es.n_opt_x), dtype=torch.float64, device=dev)
+        self.e_f = torch.empty(B, dtype=torch.float64, device=dev)
+        self.e_stats = torch.zeros(B * STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        self.x_est, self.p_est = t(x_est), t(p_est)
+        self.exs = t(mhe._x_scaling.master)
+        self.t_mpc0, self.dt = t0, float(mpc.settings.t_step)
+        self.k = 0
+
+    def step(self) -> dict:
+        torch, ps, es, B, nx, nu, ny, npe, N = self.torch, self.ps, self.es, self.B, self.nx, self.nu, self.ny, self.npe, self.N
+        stream = torch.cuda.current_stream()
+        mt = self.mhe.model.n_tvp
+        if self.k > 0 and ps.ntvp:          # the controller's time-varying parameters at the current loop time (same for every sample)
+            row = np.ascontiguousarray(self.mpc.tvp_fun(self.t_mpc0 + self.k * self.dt).master, dtype=np.float64)
+            self.Pc[:, ps.p_off_tvp:ps.p_off_p] = torch.from_numpy(row).to(self.dev)
+        # 1. controller
+        self.mpc.S.solve_batch_device(B, self.Gc.data_ptr(), self.c_lbx.data_ptr(), self.c_ubx.data_ptr(), self.c_lbg.data_ptr(),
+                                      self.c_ubg.data_ptr(), self.Pc.data_ptr(), self.c_sol.data_ptr(), 0, 0, 0, self.c_f.data_ptr(),
+                                      self.c_stats.data_ptr(), stream=stream.cuda_stream)
+        iu = ps.iu(0, 0)
+        torch.mul(self.c_sol[:, iu:iu + nu], self.us, out=self.U)
+        # 2. plant: next true state and its measurement
+        self.sim.step_batch_device(B, self.X.data_ptr(), self.U.data_ptr(), self.tvp_plant.data_ptr(), self.p_plant.data_ptr(),
+                                   self.Xn.data_ptr(), self.Y.data_ptr(), self.pstat.data_ptr(), shared_mask=2 | 4 | 8 | 16,
+                                   stream=stream.cuda_stream)
+        self.X, self.Xn = self.Xn, self.X
+        # 3. estimator: previous estimates <- `_x[1, -1]`, `_p_est` of ITS previous solution (initial guess before the first solve,
+        #    _mhe.py:939-941), measurement window shifted by one stage, the new measurement last
+        i1 = es.ix(1, 0, es.M)
+        self.Pe[:, :nx] = self.Ge[:, i1:i1 + nx] * self.exs
+        self.Pe[:, nx:nx + npe] = self.p_est
+        TV = self.Pe[:, es.p_off_tvp:es.p_off_p].view(B, N + 1, es.ntvp)
+        TV[:, :N - 1, mt:] = TV[:, 1:N, mt:].clone()
+        TV[:, N - 1, mt:] = self.Y
+        self.mhe.S.solve_batch_device(B, self.Ge.data_ptr(), self.e_lbx.data_ptr(), self.e_ubx.data_ptr(), self.e_lbg.data_ptr(),
+                                      self.e_ubg.data_ptr(), self.Pe.data_ptr(), self.e_sol.data_ptr(), 0, 0, 0, self.e_f.data_ptr(),
+                                      self.e_stats.data_ptr(), stream=stream.cuda_stream)
+        iN = es.ix(N, 0, es.M)
+        self.x_est = self.e_sol[:, iN:iN + nx] * self.exs
+        i0 = es.ix(0, 0, es.M)
+        self.p_est = self.e_sol[:, i0 + nx:i0 + nx + npe].clone()
+        self.Ge.copy_(self.e_sol)                                  # warm start (unshifted, optimizer.py:754-768)
+        # 4. next controller problem: x0 <- estimate, u_prev <- applied input, initial guess <- previous solution
+        self.Pc[:, :nx] = self.x_est
+        self.Pc[:, ps.p_off_uprev:] = self.U
+        self.Gc.copy_(self.c_sol)
+        self.k += 1
+        torch.cuda.synchronize()
+        cs = np.frombuffer(self.c_stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
+        est = np.frombuffer(self.e_stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
+        return {"mpc_stats": cs, "mhe_stats": est, "plant_status": (self.pstat.cpu().numpy() & 0xFF), "u0": self.U.cpu().numpy(),
+                "x_true": self.X.cpu().numpy(), "y": self.Y.cpu().numpy(), "x_est": self.x_est.cpu().numpy(), "p_est": self.p_est.cpu().numpy()}

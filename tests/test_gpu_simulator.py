@@ -101,3 +101,49 @@ def test_closed_loop_sampling_equals_per_sample_loops():
             assert np.allclose(u0.ravel(), res["u"][i, k], rtol=1e-7, atol=1e-10)
             x0 = np.asarray(sim1.make_step(u0)).ravel()
             assert np.allclose(x0, res["x"][i, k + 1], rtol=1e-7, atol=1e-10)
+
+
+def test_device_resident_closed_loop_with_the_estimator_equals_the_per_sample_loops():
+    """controller -> plant -> moving horizon estimator -> controller for a batch of samples resident in HBM (BatchClosedLoopMHE:
+    three batched launches per control step) against the per-sample host loops of the reference's example
+    (examples/rotating_oscillating_masses_mhe_mpc/main.py), and sample 0 against the reference's stored run"""
+    from do_mpc_amd.closed_loop import BatchClosedLoopMHE
+    from do_mpc_amd.simulator import Simulator
+    ex = CASES["rotating_masses"]
+    model = ex.build_model()
+    B, steps = 3, 4
+    rng = np.random.RandomState(99)
+    X0 = np.array([rng.rand(8) - 0.5 for _ in range(B)])
+
+    def make_sim():
+        sim = Simulator(model)
+        sim.set_param(t_step=0.1, abstol=1e-10, reltol=1e-10)
+        pt = sim.get_p_template()
+        for k in ("Theta_1", "Theta_2", "Theta_3"):
+            pt[k] = 2.25e-4
+        sim.set_p_fun(lambda t: pt)
+        tv = sim.get_tvp_template()
+        sim.set_tvp_fun(lambda t: tv)
+        sim.setup()
+        return sim
+
+    loop = BatchClosedLoopMHE(ex.build_mpc(model, max_batch=B), make_sim(), ex.build_mhe(model, max_batch=B), X0, p_est0=1e-4)
+    out = [loop.step() for _ in range(steps)]
+    g = pc.golden("rotating_masses")
+    for k in range(steps):          # sample 0 starts like the reference's test (seed 99): its stored run
+        assert pc.relerr(out[k]["u0"][0], g["mpc._u"][k]) < 1e-6 and pc.relerr(out[k]["x_est"][0], g["estimator._x"][k + 1]) < 1e-6
+    for b in (1, 2):
+        mpc, sim, mhe = ex.build_mpc(model), make_sim(), ex.build_mhe(model)
+        x_est = np.zeros(8)
+        mpc.x0 = x_est
+        mhe.x0 = x_est
+        mhe.p_est0 = 1e-4
+        sim.x0 = X0[b]
+        mpc.set_initial_guess()
+        mhe.set_initial_guess()
+        for k in range(steps):
+            u0 = mpc.make_step(x_est)
+            y = sim.make_step(u0)
+            x_est = mhe.make_step(y).ravel()
+            assert pc.relerr(out[k]["u0"][b], u0.ravel()) < 1e-9 and pc.relerr(out[k]["y"][b], y.ravel()) < 1e-9
+            assert pc.relerr(out[k]["x_est"][b], x_est) < 1e-9
