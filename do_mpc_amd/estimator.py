@@ -84,9 +84,6 @@ class MHE:
         assert model.flags["setup"] is True, "Model for MHE was not setup. After the complete model creation call model.setup()."
         if model.n_z:
             raise NotImplementedError("structured HIP backend: MHE for models with algebraic states")
-        if model.model_type != "continuous":
-            raise NotImplementedError("structured HIP backend: MHE for discrete models (the stage cost of an interval reads its end state, "
-                                      "which is a node variable there)")
         self.model = m = model
         self.settings = self._settings = settings if settings is not None else MHESettings()
         pn = [n for n in m._p.names if m._p.vars[n].numel() > 0]
@@ -290,10 +287,17 @@ class MHE:
         if ny != nv or not dy_dv.is_constant() or not np.array_equal(dy_dv.to_numpy().reshape(ny, nv), np.eye(ny)):
             raise NotImplementedError("structured HIP backend: every measurement of the estimator model needs its own additive noise "
                                       "term (set_meas(..., meas_noise=True)): the measurement rows are solved for it")
+        discrete = self._discrete = m.model_type == "discrete"
+        if discrete:
+            # a discrete model has no stored points inside an interval: the NEXT state becomes an algebraic state of the interval,
+            # z = f(x, u, w, p) as its algebraic equation and x+ = z as its dynamics - the measurement residual (and with it the stage
+            # cost) then reads that algebraic state, which the dense edge path of the DAE models handles (`_z[k, s, -1]` in the cost)
+            z_next = sym.SX.sym("x_next", nx, 1)
+            h0 = sym.substitute(h0, m._x.cat, z_next)
         v_of = y_sym - h0                                            # v_k = y_k - h(x_{k+1}, u_k, tvp_k, p)
         stage = sym.substitute(self.stage_cost, m._v.cat, v_of) if nv else self.stage_cost
         # ---- the augmented model: states (x, p_est), inputs (u, w), tvp (tvp, y_meas), parameters p_set; symbols are shared
-        am = Model("continuous")
+        am = Model("discrete" if discrete else "continuous")
         for n in m._x.names:
             am._x.add(n, m._x.vars[n])
         for n in self._p_est.names:
@@ -310,10 +314,21 @@ class MHE:
         am._tvp.add("y_meas", y_sym)
         for n in self._p_set.names:
             am._p.add(n, self._p_set.vars[n])
-        for r in m.rhs_list:
-            am.rhs_list.append(dict(r))
-        for n in self._p_est.names:
-            am.rhs_list.append({"var_name": n, "expr": sym.SX(np.zeros(self._p_est.vars[n].shape))})
+        if discrete:
+            am._z.add("x_next", z_next)
+            am.alg_list.append({"expr_name": "x_next", "expr": z_next - m._rhs})
+            off = 0
+            for n in m._x.names:
+                k = m._x.vars[n].numel()
+                am.rhs_list.append({"var_name": n, "expr": z_next[off:off + k].reshape(m._x.vars[n].shape)})
+                off += k
+            for n in self._p_est.names:
+                am.rhs_list.append({"var_name": n, "expr": self._p_est.vars[n]})          # p+ = p
+        else:
+            for r in m.rhs_list:
+                am.rhs_list.append(dict(r))
+            for n in self._p_est.names:
+                am.rhs_list.append({"var_name": n, "expr": sym.SX(np.zeros(self._p_est.vars[n].shape))})
         for n in m._aux.names:
             if n != "default":
                 am._aux.add(n, m._aux.vars[n])
@@ -340,7 +355,7 @@ class MHE:
             mpc.set_p_fun(lambda t: mpc.get_p_template(1))
         mpc._estimator_opts = dict(arrival=self.arrival_cost.nodes()[0],
                                    xprev_sym=self._x_prev.cat.nodes() + self._p_est_prev.cat.nodes(),
-                                   lterm_end=True, nl_dup=True)
+                                   lterm_end=not discrete, nl_dup=True)
         mpc.setup()
         self._mpc = mpc
         self.S = mpc.S
@@ -374,7 +389,7 @@ class MHE:
         self.opt_x_scaling["_x"] = self._x_scaling.master
         self.opt_x_scaling["_u"] = self._u_scaling.master
         n_rows = ps.ne                                               # nl_cons rows of a stage (all evaluations)
-        self._rows_stage = M * nx + nx + ny + n_rows
+        self._rows_stage = M * nx + nx + ny + n_rows              # (discrete: M = 0 - the rows x+ = f of the reference, then measurement / nl_cons rows)
         self.n_opt_lagr = N * self._rows_stage
         self.lam_g_num = np.zeros(self.n_opt_lagr)
         # offsets inside the reference's opt_x
@@ -388,13 +403,18 @@ class MHE:
         self._po_y = self._po_tvp + N * m.n_tvp
         # numeric helpers: measurement noise and its cost gradient at the solution
         args = [am._x.cat, am._u.cat, am._tvp.cat, am._p.cat]
-        self._v_fun = sym.Function("v_of", args, [v_of])
+        if discrete:            # (h reads the next state through its algebraic copy: evaluate with the next NODE state in its place)
+            v_of_x = sym.substitute(v_of, z_next, m._x.cat)
+            h0_x = sym.substitute(h0, z_next, m._x.cat)
+        else:
+            v_of_x, h0_x = v_of, h0
+        self._v_fun = sym.Function("v_of", args, [v_of_x])
         dl_dv = sym.jacobian(self.stage_cost, m._v.cat).T if nv else sym.SX(np.zeros((0, 1)))
         self._dldv_fun = sym.Function("dldv", [m._w.cat, m._v.cat, m._tvp.cat, m._p.cat], [dl_dv])
         # (the reference's measurement rows read the NODE state x_{k+1}, here the stage cost reads the end slot of the interval:
         #  the multipliers of the continuity rows differ by (dh/dx)' lambda_meas)
         lam_y = sym.SX.sym("lam_y", ny, 1)
-        self._hx_fun = sym.Function("hx_lam", args + [lam_y], [sym.jacobian(h0, m._x.cat).T @ lam_y])
+        self._hx_fun = sym.Function("hx_lam", args + [lam_y], [sym.jacobian(h0_x, m._x.cat).T @ lam_y])
         self._update_bounds()
         meta = {k: getattr(s, k) for k in ("n_horizon", "t_step", "meas_from_data", "state_discretization", "collocation_type",
                                            "collocation_deg", "collocation_ni", "nl_cons_check_colloc_points", "store_full_solution",
@@ -442,6 +462,9 @@ class MHE:
         if nw:
             U[..., nu:] = ox[..., self._o_w:self._o_v].reshape(lead + (N, nw))
         out[..., ps.off_eps:] = ox[..., self._o_eps:self._o_p]
+        if self._discrete:      # (the algebraic copy of the next state starts at the guess of that state)
+            Z = out[..., ps.off_z:ps.off_u].reshape(lead + (N, nx))
+            Z[...] = X[..., 1:, -1, :nx]
         return out
 
     def _p_to_chain(self, op: np.ndarray) -> np.ndarray:
@@ -476,7 +499,7 @@ class MHE:
             Pm = np.broadcast_to(opt_p_chain[..., None, ps.p_off_p:ps.p_off_uprev], lead + (N, ps.np_))
             sx = np.concatenate([self._x_scaling.master, np.ones(ps.nx - nx)])
             su = np.concatenate([self._u_scaling.master, np.ones(ps.nu - nu)])
-            cols = lambda a: np.moveaxis(a, -1, 0).reshape(a.shape[-1], -1)        # noqa: E731   (numel, batch * N)
+            cols = lambda a: np.moveaxis(a, -1, 0).reshape(a.shape[-1], int(np.prod(a.shape[:-1])))        # noqa: E731   (numel, batch * N)
             V = np.asarray(self._v_fun.eval(cols(X[..., 1:, -1, :] * sx), cols(U * su), cols(TV), cols(Pm))[0])
             out[..., self._o_v:self._o_eps] = np.moveaxis(V.reshape((nv,) + lead + (N,)), 0, -1).reshape(lead + (-1,))
         out[..., self._o_eps:self._o_p] = cx[..., ps.off_eps:]
@@ -489,8 +512,14 @@ class MHE:
         nx, nw, nv, ny, M = m.n_x, m.n_w, m.n_v, m.n_y, ps.M
         out = np.zeros(self.n_opt_lagr).reshape(N, self._rows_stage)
         L = lam_chain[ps.nx:].reshape(N, -1)                         # (the chain problem keeps nx dummy initial rows)
-        blk = L[:, :(M + 1) * ps.nx].reshape(N, M + 1, ps.nx)        # collocation / end-of-element rows, then continuity
-        out[:, :(M + 1) * nx] = blk[:, :, :nx].reshape(N, -1)
+        if self._discrete:
+            # chain problem: rows z - f = 0 (multiplier la), then x+ - ... ; the reference's rows f - x+ = 0 carry -la
+            out[:, :nx] = -L[:, :nx]
+            n_dyn = nx + ps.nx
+        else:
+            blk = L[:, :(M + 1) * ps.nx].reshape(N, M + 1, ps.nx)    # collocation / end-of-element rows, then continuity
+            out[:, :(M + 1) * nx] = blk[:, :, :nx].reshape(N, -1)
+            n_dyn = (M + 1) * ps.nx
         if nv:
             W = ox[self._o_w:self._o_v].reshape(N, nw) if nw else np.zeros((N, 0))
             V = ox[self._o_v:self._o_eps].reshape(N, nv)
@@ -512,8 +541,9 @@ class MHE:
             U = cx[ps.off_u:ps.off_eps].reshape(N, ps.nu) * np.concatenate([self._u_scaling.master, np.ones(ps.nu - m.n_u)])
             TVc = Pc[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
             hx = self._hx_fun.eval(X.T, U.T, TVc.T, np.tile(Pc[ps.p_off_p:ps.p_off_uprev][:, None], (1, N)), lam_meas.T)[0]
-            out[:, M * nx:(M + 1) * nx] += np.asarray(hx).reshape(nx, N).T
-        out[:, (M + 1) * nx + ny:] = L[:, (M + 1) * ps.nx:]
+            if not self._discrete:
+                out[:, M * nx:(M + 1) * nx] += np.asarray(hx).reshape(nx, N).T
+        out[:, (M + 1) * nx + ny:] = L[:, n_dyn:]
         return out.reshape(-1)
 
     # ------------------------------------------------------------------ runtime

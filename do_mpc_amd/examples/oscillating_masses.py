@@ -15,12 +15,17 @@ A_D = np.array([[0.763, 0.460, 0.115, 0.020],
 B_D = np.array([[0.014], [0.063], [0.221], [0.367]])
 
 
-def build_model(symvar_type="SX"):
+def build_model(symvar_type="SX", estimation=False):
+    """estimation: the variant for the discrete-time estimator build_mhe (not in the reference's example): the two positions are
+    measured with noise, process noise on all four states"""
     mdl = Model("discrete", symvar_type)
     x = mdl.set_variable(var_type="_x", var_name="x", shape=(4, 1))
     u = mdl.set_variable(var_type="_u", var_name="u", shape=(1, 1))
     mdl.set_expression(expr_name="cost", expr=sum1(x ** 2))
-    mdl.set_rhs("x", A_D @ x + B_D @ u)
+    if estimation:
+        from ..sym import vertcat
+        mdl.set_meas("pos_meas", vertcat(x[0], x[2]))
+    mdl.set_rhs("x", A_D @ x + B_D @ u, process_noise=estimation)
     mdl.setup()
     return mdl
 
@@ -62,3 +67,25 @@ def _rterm_custom(model, mpc):
 
 
 RTERM_VARIANTS = {"custom": _rterm_custom}
+
+
+def build_mhe(model, silence_solver=True, **overrides):
+    """A discrete-time moving horizon estimator on build_model(estimation=True): horizon 8, weights as numbers, one nl_cons row.
+    No stored run exists for it: compared with the oracle's solve of the restated NLP (oracle/mhe.py)."""
+    from ..estimator import MHE
+    mhe = MHE(model, [])
+    st = mhe.settings
+    st.n_horizon, st.t_step, st.store_full_solution = 8, 0.5, True
+    for k, v in overrides.items():
+        setattr(st, k, v)
+    if silence_solver:
+        st.supress_ipopt_output()
+    mhe.set_default_objective(0.5 * np.eye(4), 10.0 * np.eye(2), None, 5.0 * np.eye(4))
+    limit = np.array([[4.0], [10.0], [4.0], [10.0]])
+    mhe.bounds["lower", "_x", "x"] = -limit
+    mhe.bounds["upper", "_x", "x"] = limit
+    mhe.bounds["lower", "_u", "u"] = -0.5
+    mhe.bounds["upper", "_u", "u"] = 0.5
+    mhe.set_nl_cons("x1_ub", model.x["x", 1] - 3.0, 0)
+    mhe.setup()
+    return mhe

@@ -33,12 +33,14 @@ class OracleMHE:
         npe, nps = len(self.p_est), len(self.p_set)
         self.npe, self.nps, self.ntvp = npe, nps, len(c["tvp"])
         self.N = N = c["n_horizon"]
-        self.deg = deg = c["collocation_deg"]
+        self.discrete = c.get("model_type") == "discrete"            # (optimizer.py:820-824: ifcn = [alg, rhs], no stored points)
+        self.deg = deg = 0 if self.discrete else c["collocation_deg"]
         assert c["collocation_ni"] == 1 and not c.get("z")
-        self.nl_colloc = bool(c["nl_cons_check_colloc_points"])
-        self.M = M = deg + 1
+        self.nl_colloc = bool(c["nl_cons_check_colloc_points"]) and not self.discrete
+        self.M = M = 0 if self.discrete else deg + 1
         self.h = c["t_step"]
-        self.tau, self.C, self.D = collocation_coeffs(deg, c["collocation_type"])
+        if not self.discrete:
+            self.tau, self.C, self.D = collocation_coeffs(deg, c["collocation_type"])
         self.nl = c["nl_cons"]
         ne = len(self.nl)
         # ---- layouts
@@ -84,16 +86,20 @@ class OracleMHE:
             return sp.sympify(expr).subs(sub)
 
         rows = []
-        pts = [xs[0]] + [xs[1 + r] for r in range(deg)]                 # point 0 = x_k, points 1..deg = the collocation slots
-        for j in range(1, deg + 1):                                     # collocation rows  h f(x_j) - sum_r C[r, j] x_r
-            for a in range(nx):
-                rows.append(self.h * at(c["rhs"][a], pts[j]) - sum(self.C[r, j] * pts[r][a] for r in range(deg + 1)))
-        xe = xs[M]                                                      # end-of-element slot
-        for a in range(nx):
-            rows.append(xe[a] - sum(self.D[r] * pts[r][a] for r in range(deg + 1)))
         xb = xs[M + 1]
-        for a in range(nx):                                             # continuity
-            rows.append(xe[a] - xb[a])
+        if self.discrete:
+            for a in range(nx):                                         # x+ = f(x, u, w, p)  (_mhe.py:1153-1155 with xf = rhs)
+                rows.append(at(c["rhs"][a], xs[0]) - xb[a])
+        else:
+            pts = [xs[0]] + [xs[1 + r] for r in range(deg)]             # point 0 = x_k, points 1..deg = the collocation slots
+            for j in range(1, deg + 1):                                 # collocation rows  h f(x_j) - sum_r C[r, j] x_r
+                for a in range(nx):
+                    rows.append(self.h * at(c["rhs"][a], pts[j]) - sum(self.C[r, j] * pts[r][a] for r in range(deg + 1)))
+            xe = xs[M]                                                  # end-of-element slot
+            for a in range(nx):
+                rows.append(xe[a] - sum(self.D[r] * pts[r][a] for r in range(deg + 1)))
+            for a in range(nx):                                         # continuity
+                rows.append(xe[a] - xb[a])
         for i in range(ny):                                             # measurement rows (meas_fun includes the noise v)
             rows.append(at(c["meas"][i], xb) - ym[i])
         # nl_cons rows: at every stored point of the interval (`_x[k+1, i]`) or at the state `_x[k, -1]`; then the rows of the last

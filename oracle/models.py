@@ -322,6 +322,27 @@ def case_rotating_masses_mhe_w(**over):
     return dd
 
 
+def case_oscillating_masses_mhe(**over):
+    """A discrete-time estimator (no stored run exists): the two oscillating masses of examples/oscillating_masses_discrete with a
+    measurement of the two positions (with noise), process noise on all four states, horizon 8, no estimated parameter."""
+    d = case_oscillating_masses()
+    x, u = d["x"], d["u"]
+    w = sp.symbols("w_0:4")
+    v = sp.symbols("v_0:2")
+    xp = sp.symbols("xprev_0:4")
+    rhs = [d["rhs"][i] + w[i] for i in range(4)]
+    meas = [x[0] + v[0], x[2] + v[1]]
+    vv, ww = sp.Matrix(v), sp.Matrix(w)
+    dx = sp.Matrix([x[i] - xp[i] for i in range(4)])
+    dd = dict(d)
+    dd.update(name="oscillating_masses_mhe", v=v, w=w, rhs=rhs, meas=meas, p_est=[], x_prev=xp, p_est_prev=(), tvp=(),
+              stage_cost=10.0 * (vv.T * vv)[0, 0] + 5.0 * (ww.T * ww)[0, 0], arrival_cost=0.5 * (dx.T * dx)[0, 0],
+              n_horizon=8, nl_cons_check_colloc_points=False, collocation_deg=0, collocation_ni=1,
+              nl_cons=[dict(name="x1_ub", expr=x[1] - 3.0, ub=0.0, soft=False)])
+    dd.update(over)
+    return dd
+
+
 def case_oscillating_masses_dae(**over):
     """/root/reference/examples/oscillating_masses_discrete_dae/template_model.py:34-75, template_mpc.py:34-74: the discrete
     masses with the successor state as algebraic variable, x+ = z, 0 = z - A x - B u."""

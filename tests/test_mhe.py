@@ -62,8 +62,11 @@ def test_mhe_surface_and_refusals():
         mhe.set_objective(m.x["phi_1"] ** 2, m.x["phi_1"] ** 2)          # stage cost: w, v, tvp, p only (_mhe.py:585-589)
     with pytest.raises(AssertionError):
         MHE(m, ["not_a_parameter"])
-    with pytest.raises(NotImplementedError, match="discrete"):
-        MHE(CASES["oscillating_masses"].build_model())
+    with pytest.raises(NotImplementedError, match="noise"):          # (a measurement without its own noise term)
+        e = MHE(CASES["oscillating_masses"].build_model())
+        e.settings.n_horizon, e.settings.t_step = 4, 0.5
+        e.set_default_objective(np.eye(4))
+        e.setup()
 
 
 def test_mpc_plant_mhe_closed_loop_reproduces_the_reference_run():
@@ -106,3 +109,12 @@ def test_mhe_with_process_noise_against_the_oracle():
         with hostemu.patched():
             return ex.build_mhe_w(ex.build_model(process_noise=True))
     pc.check_mhe_with_process_noise(make)
+
+
+def test_discrete_time_mhe_against_the_oracle():
+    from do_mpc_amd.examples import oscillating_masses as om
+
+    def make():
+        with hostemu.patched():
+            return om.build_mhe(om.build_model(estimation=True))
+    pc.check_discrete_mhe(make)
