@@ -839,7 +839,7 @@ constexpr bool TILE_CONDENSE = false;
 constexpr int EL_MX = 0;
 // (blocked elimination on the matrix cores, edge_factor_mfma: the W | w0 region doubles as its panel buffer - 4 columns of the
 //  padded collocation block - plus one row of 64 dual-residual products)
-constexpr int GJ_LDS = (NI == 1 && DEG >= 1) ? 4 * (((DEG * NX + 3) / 4) * 4) + 64 : 0;
+constexpr int GJ_LDS = (NI == 1 && DEG >= 1) ? 4 * (((DEG * NX + 3) / 4) * 4) + 256 : 0;
 constexpr int EL_T1 = EL_MX + (NW * MX_LD > GJ_LDS ? NW * MX_LD : GJ_LDS);   // Hww W  (NW x NA); first NW entries: the residual rows
 constexpr int EL_T0 = EL_T1 + (TILE_CONDENSE ? NW : NW * NA);          // Hww w0 (NW)
 constexpr int EL_RW = EL_T0 + NW;                                      // Newton-form gradient of w (NW)
@@ -1067,6 +1067,12 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #ifndef DOMPC_MFMA_GJ
 #define DOMPC_MFMA_GJ 1
 #endif
+#ifndef DOMPC_GJ_SKIP
+#define DOMPC_GJ_SKIP 1             // blocked elimination: skip the updates of tile columns whose unit columns are still untouched (0: update everything)
+#endif
+#ifndef DOMPC_DUAL_VALU
+#define DOMPC_DUAL_VALU 1           // dual-residual products of the factorisation on the vector ALU (0: on the matrix cores, multipliers in one row of the A operand)
+#endif
 #ifndef DOMPC_GJ_SB
 #define DOMPC_GJ_SB 0               // 1: scheduling barriers at the step boundaries of the blocked elimination (measurement aid)
 #endif
@@ -1079,7 +1085,7 @@ constexpr int GJ_R = DEG * NX, GJ_RP = ((GJ_R + 3) / 4) * 4, GJ_NRHS = NA + 1;
 constexpr int GJ_NC = GJ_RP + GJ_NRHS + GJ_R;                      // columns: [G_cc padded | G_y r | I]
 constexpr bool MFMA_GJ = (NI == 1) && (DEG >= 1) && !DENSE_EDGE && (GJ_RP <= 32) && (GJ_NC <= 64) && (DOMPC_MFMA_GJ != 0);
 constexpr int GJ_MT = (GJ_RP + 15) / 16, GJ_NT = (GJ_NC + 15) / 16;
-static_assert(!MFMA_GJ || GJ_RP * 4 + 64 <= EL_T1 - EL_MX, "the panel buffer and the dual-residual row share the W | w0 region of the edge working set");
+static_assert(!MFMA_GJ || GJ_RP * 4 + 256 <= EL_T1 - EL_MX, "the panel buffer and the dual-residual row share the W | w0 region of the edge working set");
 
 // Register budget: the function is called per edge from the sweep; it must stay within the ~148 caller-saved VGPRs (every
 // other register it touches costs a scratch round trip per call).  When the padded block has 16 + 4 rows (industrial_poly)
@@ -1169,6 +1175,33 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
     // in row 0 of a 16 x 4 block per k-block; B operand: the tile registers themselves (register r of tile row mi = rows
     // 16 mi + 4 r ...).  Row 0 of the result tiles goes through LDS to the lanes that own the columns (dual_from).
     constexpr int NDT = (RP + NA + 15) / 16 < NT ? (RP + NA + 15) / 16 : NT;
+    ldsd* du = Ld + EL_MX + 4 * RP;                 // (behind the panel buffer; the W | w0 region is written after the last step)
+#if DOMPC_DUAL_VALU
+    // on the vector ALU: this lane's rows of its columns (4 per full tile row + 1 packed) times their multipliers; the four lane
+    // groups of a column leave their partial sums in four rows of the buffer, the reader adds them (an MFMA with the multipliers
+    // in one row of the A operand does the same at 1/16 of its throughput: 15 instructions of 64 cycles)
+    {
+      double lamr[MT][4], lamx = 0.0;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mi + 4 * r + lr;
+          lamr[mi][r] = (row < R) ? (double)Ld[EL_T0 + row] : 0.0;
+        }
+      if constexpr (GJ_PACK) lamx = (16 + lr < R) ? (double)Ld[EL_T0 + 16 + lr] : 0.0;
+#pragma unroll
+      for (int ni = 0; ni < NDT; ++ni) {
+        double t = 0.0;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t = fma(lamr[mi][r], T[mi][ni][r], t);
+        if constexpr (GJ_PACK) t = fma(lamx, X[ni], t);
+        du[64 * lr + 16 * ni + lc] = t;
+      }
+    }
+#else
     d4 acc[NDT];
 #pragma unroll
     for (int ni = 0; ni < NDT; ++ni) acc[ni] = d4{0.0, 0.0, 0.0, 0.0};
@@ -1183,11 +1216,11 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
         acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[ni], 0, 0, 0);
       }
     }
-    ldsd* du = Ld + EL_MX + 4 * RP;                 // (behind the panel buffer; the W | w0 region is written after the last step)
-    if (lr == 0) {
 #pragma unroll
-      for (int ni = 0; ni < NDT; ++ni) du[16 * ni + lc] = acc[ni][0];
+    for (int ni = 0; ni < NDT; ++ni) {              // (same buffer layout as the vector-ALU variant: row 0 holds the sums)
+      du[64 * lr + 16 * ni + lc] = (lr == 0) ? acc[ni][0] : 0.0;
     }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     dual_from((const ldsd*)du);
@@ -1281,6 +1314,9 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
       const int nxt = (p + 1) / 4 < NT ? (p + 1) / 4 : 0;
       const int ni = (o == 0) ? nxt : (o <= nxt ? o - 1 : o);
       if (16 * (ni + 1) <= 4 * (p + 1)) continue;
+      // a tile column that holds only unit columns e_b (and padding) with b >= 4 (p + 1): their entries in the panel rows are still
+      // zero - the update would add nothing (industrial_poly: tile column 3 during the first three steps, 6 of 36 MFMAs)
+      if (DOMPC_GJ_SKIP && 16 * ni >= RP + GJ_NRHS && 16 * ni - (RP + GJ_NRHS) >= 4 * (p + 1)) continue;
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) T[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(cp[mi], Rb[ni], T[mi][ni], 0, 0, 0);
       if constexpr (GJ_PACK) X = __builtin_amdgcn_mfma_f64_16x16x4f64(((lc >> 2) == ni) ? cpx : 0.0, Rb[ni], X, 0, 0, 0);
@@ -1521,7 +1557,10 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (edge_factor_mfma(Q, e, lane, Ld, [&](const ldsd* du) {
-          dual_pieces([&](int, int cx) { return (double)du[cx < R ? cx : (cx < R + NA ? GJ_RP + (cx - R) : 0)]; });
+          dual_pieces([&](int, int cx) {
+            const int c_ = cx < R ? cx : (cx < R + NA ? GJ_RP + (cx - R) : 0);
+            return (double)du[c_] + (double)du[64 + c_] + (double)du[128 + c_] + (double)du[192 + c_];
+          });
         })) return 2;
     {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
