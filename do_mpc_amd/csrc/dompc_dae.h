@@ -9,8 +9,8 @@
 //
 // The algebraic states of an interval are edge unknowns like its collocation states: w = [x slots (M nx) | z slots (MZ nz)],
 // eliminated through the edge's own square constraint block G_w (NW x NW, rows in the reference's order).  Everything is
-// assembled DENSE in the wavefront's LDS region - the extended matrix [G_w | G_y | r | I], the edge Hessian over [w | y] -
-// by scatter through index functions, inverted by Gauss-Jordan with partial pivoting and condensed by plain triple loops:
+// assembled DENSE in the wavefront's LDS region - the extended matrix [G_w | G_y | r], the edge Hessian over [w | y] -
+// by scatter through index functions, inverted in place by Gauss-Jordan with partial pivoting and condensed by plain triple loops:
 // this path is about coverage of the reference's DAE models (double inverted pendulum: 36 unknowns per edge), not about the
 // benchmark; the node level (tree Riccati recursion) is unchanged, z never reaches it.
 #pragma once
@@ -31,7 +31,7 @@ constexpr int DELR = NZ + DEG * (NX + NZ) + NX;               // rows of one fin
 constexpr int ELR1 = DELR > 0 ? DELR : 1;
 constexpr int NXZ1 = NX + NZ > 0 ? NX + NZ : 1;
 // LDS working set of one edge (doubles)
-constexpr int DG_NC = NW + NA + 1 + NW;                       // [G_w | G_y | r | I]  ->  [I | -W | -w0 | G_w^-1]
+constexpr int DG_NC = NW + NA + 1;                            // [G_w | G_y | r]  ->  [G_w^-1 | -W | -w0]  (inverted in place)
 constexpr int DG_G = 0;
 constexpr int DG_H = DG_G + NW * DG_NC;                       // NWY x NWY edge Hessian
 constexpr int DG_T = DG_H + NWY * NWY;                        // NWY x (NA + 2):  Hfull [Z | z0 | 0] + [0 | r_w | b]
@@ -46,7 +46,8 @@ constexpr int DG_RE = DG_EY + NX * NA;                        // NX: end-point r
 constexpr int DG_JDW = DG_RE + NX;                            // NE x NW
 constexpr int DG_JDY = DG_JDW + NE * NW;                      // NE x NA
 constexpr int DG_CK = DG_JDY + NE * NA;                       // NW: pivot column copy
-constexpr int DG_RT = DG_CK + NW;                             // user-defined rterm of the edge (RT_LEN)
+constexpr int DG_PV = DG_CK + NW;                             // NW: pivot rows of the elimination (the column interchanges that undo them)
+constexpr int DG_RT = DG_PV + NW;                             // user-defined rterm of the edge (RT_LEN)
 constexpr int DG_SIZE = DG_RT + RT_LEN;
 // forward pass
 constexpr int DF_DY = 0, DF_DNU = DF_DY + NA, DF_DW = DF_DNU + NX, DF_RHS = DF_DW + NW, DF_DYD = DF_RHS + NW, DF_SIZE = DF_DYD + NE1;
@@ -222,12 +223,11 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
   // ---- A: clear
   for (int i = lane; i < DG_SIZE; i += GS) Ld[i] = 0.0;
   T.gsync();
-  // ---- B: rows of the block [G_w | G_y | r | I]: residual, collocation / continuity coefficients, point Jacobians
+  // ---- B: rows of the block [G_w | G_y | r]: residual, collocation / continuity coefficients, point Jacobians
   for (int r = lane; r < NW; r += GS) {
     const Row R = decode_row(r);
     const double* pt = mo + MO_PT + point_of(R.el, R.j) * PT_STRIDE;
     double res;
-    Gm(r, NW + NA + 1 + r) = 1.0;
     if (R.kind == 2) {
       const double* x0 = (R.el == 0) ? xn : w + slot_of(R.el, 0) * NX;
       double xf = DOMPC_D[0] * x0[R.comp];
@@ -343,7 +343,10 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     Ld[DG_SG + c] = sigma_of(xv, l, u, zl_, zu_) + Q.dsw;
   }
   T.gsync();
-  // ---- Gauss-Jordan with partial pivoting on the extended matrix (row interchanges carry the appended identity along)
+  // ---- Gauss-Jordan with partial pivoting, IN PLACE: the eliminated column kk takes the column of the inverse that an appended
+  // identity would hold (row kk scaled by 1 / pivot, entry (kk, kk) = 1 / pivot, the other rows -a_rk / pivot), so every step
+  // touches NW + NA + 1 columns instead of 2 NW + NA + 1; the row interchanges are undone at the end by interchanging the
+  // COLUMNS of the inverse in reverse order ((P A)^-1 = A^-1 P')
   for (int kk = 0; kk < NW; ++kk) {
     int pr = kk;
     double best = fabs((double)Gm(kk, kk));
@@ -353,6 +356,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     }
     if (!(best > 1e-300)) fail = 1;
     T.gsync();
+    if (lane == 0) Ld[DG_PV + kk] = (double)pr;
     if (pr != kk)
       for (int c = lane; c < DG_NC; c += GS) { const double t = Gm(kk, c); Gm(kk, c) = Gm(pr, c); Gm(pr, c) = t; }
     T.gsync();
@@ -361,16 +365,23 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     for (int r = lane; r < NW; r += GS) Ld[DG_CK + r] = Gm(r, kk);
     T.gsync();
     for (int c = lane; c < DG_NC; c += GS) {
-      const double prow = Gm(kk, c) * pinv;
+      const bool own = (c == kk);
+      const double prow = (own ? 1.0 : (double)Gm(kk, c)) * pinv;
       for (int r = 0; r < NW; ++r)
-        if (r != kk) Gm(r, c) = fma(-(double)Ld[DG_CK + r], prow, (double)Gm(r, c));
+        if (r != kk) Gm(r, c) = fma(-(double)Ld[DG_CK + r], prow, own ? 0.0 : (double)Gm(r, c));
       Gm(kk, c) = prow;
     }
     T.gsync();
   }
-  // now: columns NW .. NW+NA = G_w^-1 G_y = -W, column NW+NA = G_w^-1 r = -w0, columns NW+NA+1 .. = G_w^-1
+  for (int r = lane; r < NW; r += GS)                    // (row r of the inverse: its own sequence of interchanges, no barrier in between)
+    for (int kk = NW - 1; kk >= 0; --kk) {
+      const int pr = (int)(double)Ld[DG_PV + kk];
+      if (pr != kk) { const double t = Gm(r, kk); Gm(r, kk) = Gm(r, pr); Gm(r, pr) = t; }
+    }
+  T.gsync();
+  // now: columns 0 .. NW-1 = G_w^-1, columns NW .. NW+NA-1 = G_w^-1 G_y = -W, column NW+NA = G_w^-1 r = -w0
   auto Wm = [&](int r, int c) -> double { return -(double)Gm(r, NW + c); };        // c == NA: w0
-  auto Gi = [&](int r, int c) -> double { return (double)Gm(r, NW + NA + 1 + c); };
+  auto Gi = [&](int r, int c) -> double { return (double)Gm(r, c); };
   // ---- linearised dynamics of the interval: [A B] = E_y + E_w W, c~ = r_end + E_w w0; effective nl_cons rows
   for (int it = lane; it < NX * (NA + 1); it += GS) {
     const int a = it / (NA + 1), b = it % (NA + 1);
