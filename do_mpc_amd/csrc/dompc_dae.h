@@ -33,7 +33,8 @@ constexpr int NXZ1 = NX + NZ > 0 ? NX + NZ : 1;
 // LDS working set of one edge (doubles)
 constexpr int DG_NC = NW + NA + 1;                            // [G_w | G_y | r]  ->  [G_w^-1 | -W | -w0]  (inverted in place)
 constexpr int DG_G = 0;
-constexpr int DG_H = DG_G + NW * DG_NC;                       // NWY x NWY edge Hessian
+constexpr int DG_LD = DG_NC + 1;                               // row stride: one more column that stays zero
+constexpr int DG_H = DG_G + NW * DG_LD;                       // NWY x NWY edge Hessian
 constexpr int DG_T = DG_H + NWY * NWY;                        // NWY x (NA + 2):  Hfull [Z | z0 | 0] + [0 | r_w | b]
 constexpr int DG_GL = DG_T + NWY * (NA + 2);                  // constraint part of the Lagrangian gradient w.r.t. [w | y]
 constexpr int DG_GF = DG_GL + NWY;                            // objective gradient w.r.t. [w | y]
@@ -196,6 +197,24 @@ DOMPC_DEV inline double dae_edge_f(const Prob& Q, int e, const double* xv, const
   return obj;
 }
 
+#ifndef DOMPC_HOST_EMU
+// maximum over the 64 lanes of a wavefront of NON-NEGATIVE values (identity 0), in every lane: row shifts, row broadcasts (DPP), lane 63
+__device__ inline double wave_max_nonneg(double v) {
+#define DOMPC_DPP_MAX(ctrl, rmask) {                                                                   \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false);        \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false);        \
+    v = fmax(v, __hiloint2double(hi_, lo_)); }
+  DOMPC_DPP_MAX(0x111, 0xf)      // row_shr:1
+  DOMPC_DPP_MAX(0x112, 0xf)      // row_shr:2
+  DOMPC_DPP_MAX(0x114, 0xf)      // row_shr:4
+  DOMPC_DPP_MAX(0x118, 0xf)      // row_shr:8   -> lane 15 of every row: maximum of the row
+  DOMPC_DPP_MAX(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+  DOMPC_DPP_MAX(0x143, 0xc)      // row_bcast:31 into rows 2 and 3 -> lane 63: maximum of the wavefront
+#undef DOMPC_DPP_MAX
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+#endif
+
 // ================================================================================================
 // Derivative evaluation + condensing of one edge of a DAE model (dense twin of eval_edge_coop; same outputs: the shared
 // record ES, the forward record EW, c / gf / rd of the edge's rows and unknowns).  Returns 1 if G_w is singular.
@@ -218,8 +237,16 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
   const double* mo = Q.MO(e);
   const bool last_stage = (k == A.N - 1);
   int fail = 0;
-  auto Gm = [&](int r, int c) -> ldsd& { return Ld[DG_G + r * DG_NC + c]; };
+  auto Gm = [&](int r, int c) -> ldsd& { return Ld[DG_G + r * DG_LD + c]; };
   auto Hm = [&](int a, int b) -> ldsd& { return Ld[DG_H + a * NWY + b]; };
+#if DOMPC_PROFILE && !defined(DOMPC_HOST_EMU)
+  // sub-phase cycle counters of the dense path (slots of the edge counters of the optimised path, tools/gpu_profile.py):
+  // 0 clear + rows, 4 Hessian scatter, 5 gradient + per-variable terms, 6 elimination, 1 dynamics + T, 2 condensing, 7 record, 3 tail
+  long long pc0_ = clock64();
+#define DAE_PH(i) if (threadIdx.x == 0) { const long long pc1_ = clock64(); lds_prof[i] += pc1_ - pc0_; pc0_ = pc1_; }
+#else
+#define DAE_PH(i)
+#endif
   // ---- A: clear
   for (int i = lane; i < DG_SIZE; i += GS) Ld[i] = 0.0;
   T.gsync();
@@ -298,6 +325,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     edge_rterm_store(Ld + DG_RT, S_, lane, GS);
     T.gsync();
   }
+  DAE_PH(0)
   // ---- Hessian of the edge's Lagrangian terms over [w | y]: one function after the other (their supports overlap)
   for (int p = 0; p < NPT_E; ++p) {
     const int el = (M == 0) ? 0 : p / (DEG + 1), jj = (M == 0) ? 0 : p % (DEG + 1);
@@ -322,6 +350,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
       T.gsync();
     }
   }
+  DAE_PH(4)
   // ---- constraint part of the Lagrangian gradient: [G_w G_y]' lambda + [E_w E_y]' nu + [Jd_w Jd_y]' y_d
   for (int v = lane; v < NWY; v += GS) {
     double t = 0.0;
@@ -343,35 +372,101 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     Ld[DG_SG + c] = sigma_of(xv, l, u, zl_, zu_) + Q.dsw;
   }
   T.gsync();
+  DAE_PH(5)
   // ---- Gauss-Jordan with partial pivoting, IN PLACE: the eliminated column kk takes the column of the inverse that an appended
   // identity would hold (row kk scaled by 1 / pivot, entry (kk, kk) = 1 / pivot, the other rows -a_rk / pivot), so every step
   // touches NW + NA + 1 columns instead of 2 NW + NA + 1; the row interchanges are undone at the end by interchanging the
   // COLUMNS of the inverse in reverse order ((P A)^-1 = A^-1 P')
+  // Per step ONE batch of LDS reads - the pivot column (every lane, broadcast reads) and the lane's own column -, the pivot search, the
+  // row interchange and the rank-1 update in registers, one batch of writes: the first version walked the rows in loops whose every
+  // trip waited for its LDS round trip (pivot search, column copy, interchange pass, update: ~10 k cycles per step at 36 unknowns).
+  constexpr bool GJ_REGS = NW <= 48;                     // (2 NW doubles in registers; larger blocks keep the row loops)
+  constexpr int NW1_ = NW > 0 ? NW : 1;
   for (int kk = 0; kk < NW; ++kk) {
-    int pr = kk;
-    double best = fabs((double)Gm(kk, kk));
-    for (int r = kk + 1; r < NW; ++r) {
-      const double a = fabs((double)Gm(r, kk));
-      if (a > best) { best = a; pr = r; }
+    if constexpr (GJ_REGS) {
+      // reads of the step in one batch: the pivot column (every lane, broadcast reads), this lane's own column (the owner of the pivot
+      // column reads the zero column behind the block instead: its column starts from the unit column of the appended identity)
+      double ck[NW1_], g[NW1_];
+#pragma unroll
+      for (int r = 0; r < NW; ++r) ck[r] = Gm(r, kk);
+      int c = lane;
+      bool own = (c == kk);
+      if (c < DG_NC) {
+#pragma unroll
+        for (int r = 0; r < NW; ++r) g[r] = Gm(r, own ? DG_NC : c);
+      }
+      double g_k = (c < DG_NC) ? (double)Gm(kk, own ? DG_NC : c) : 0.0;
+      // pivot row: the first row >= kk that attains the largest magnitude
+      int pr = NW;
+      double best;
+#ifndef DOMPC_HOST_EMU
+      {
+        // lane r holds |a_rk| (0 outside kk <= r < NW), maximum over the wavefront by DPP shifts, first lane that attains it by ballot:
+        // ~30 instructions instead of a chain over the NW rows in every lane
+        const bool valid = lane >= kk && lane < NW;
+        const double a = valid ? fabs((double)Gm(valid ? lane : kk, kk)) : 0.0;
+        best = wave_max_nonneg(a);
+        const unsigned long long m = __ballot(valid && a == best);
+        if (m) pr = (int)__builtin_ctzll(m);
+      }
+#else
+      best = -1.0;
+      for (int r = kk; r < NW; ++r) best = fmax(best, fabs(ck[r]));
+      for (int r = NW - 1; r >= kk; --r) pr = (fabs(ck[r]) == best) ? r : pr;
+#endif
+      if (!(best > 1e-300) || pr >= NW) { fail = 1; pr = kk; }      // (NaN in the column: no row attains the "maximum")
+      DAE_PH(24)
+      const double ck_k = Gm(kk, kk), piv = Gm(pr, kk);            // (entries kk and pr of the pivot column: dynamic rows)
+      double g_p = (c < DG_NC) ? (double)Gm(pr, own ? DG_NC : c) : 0.0;
+      const double pinv = (fabs(piv) > 1e-300) ? 1.0 / piv : 1.0;
+      T.gsync();                                                   // (the owner of column kk overwrites it below)
+      if (lane == 0) Ld[DG_PV + kk] = (double)pr;
+      DAE_PH(25)
+      while (c < DG_NC) {
+        const double prow = (own ? 1.0 : g_p) * pinv;               // (row kk after the interchange = the old row pr)
+        // every row by the plain formula, then the two rows of the interchange once more (LDS writes of a wavefront land in order):
+        // no select per entry
+#pragma unroll
+        for (int r = 0; r < NW; ++r) Gm(r, c) = fma(-ck[r], prow, g[r]);
+        if (pr != kk) Gm(pr, c) = fma(-ck_k, prow, g_k);             // (row pr after the interchange = the old row kk)
+        Gm(kk, c) = prow;
+        c += GS;
+        if (c < DG_NC) {                                             // (blocks wider than the wavefront, host emulation: the next column)
+          own = (c == kk);
+#pragma unroll
+          for (int r = 0; r < NW; ++r) g[r] = Gm(r, own ? DG_NC : c);
+          g_k = Gm(kk, own ? DG_NC : c);
+          g_p = Gm(pr, own ? DG_NC : c);
+        }
+      }
+      T.gsync();
+      DAE_PH(26)
+    } else {
+      int pr = kk;
+      double best = fabs((double)Gm(kk, kk));
+      for (int r = kk + 1; r < NW; ++r) {
+        const double a = fabs((double)Gm(r, kk));
+        if (a > best) { best = a; pr = r; }
+      }
+      if (!(best > 1e-300)) fail = 1;
+      T.gsync();
+      if (lane == 0) Ld[DG_PV + kk] = (double)pr;
+      if (pr != kk)
+        for (int c = lane; c < DG_NC; c += GS) { const double t = Gm(kk, c); Gm(kk, c) = Gm(pr, c); Gm(pr, c) = t; }
+      T.gsync();
+      const double piv = Gm(kk, kk);
+      const double pinv = (fabs(piv) > 1e-300) ? 1.0 / piv : 1.0;
+      for (int r = lane; r < NW; r += GS) Ld[DG_CK + r] = Gm(r, kk);
+      T.gsync();
+      for (int c = lane; c < DG_NC; c += GS) {
+        const bool own = (c == kk);
+        const double prow = (own ? 1.0 : (double)Gm(kk, c)) * pinv;
+        for (int r = 0; r < NW; ++r)
+          if (r != kk) Gm(r, c) = fma(-(double)Ld[DG_CK + r], prow, own ? 0.0 : (double)Gm(r, c));
+        Gm(kk, c) = prow;
+      }
+      T.gsync();
     }
-    if (!(best > 1e-300)) fail = 1;
-    T.gsync();
-    if (lane == 0) Ld[DG_PV + kk] = (double)pr;
-    if (pr != kk)
-      for (int c = lane; c < DG_NC; c += GS) { const double t = Gm(kk, c); Gm(kk, c) = Gm(pr, c); Gm(pr, c) = t; }
-    T.gsync();
-    const double piv = Gm(kk, kk);
-    const double pinv = (fabs(piv) > 1e-300) ? 1.0 / piv : 1.0;
-    for (int r = lane; r < NW; r += GS) Ld[DG_CK + r] = Gm(r, kk);
-    T.gsync();
-    for (int c = lane; c < DG_NC; c += GS) {
-      const bool own = (c == kk);
-      const double prow = (own ? 1.0 : (double)Gm(kk, c)) * pinv;
-      for (int r = 0; r < NW; ++r)
-        if (r != kk) Gm(r, c) = fma(-(double)Ld[DG_CK + r], prow, own ? 0.0 : (double)Gm(r, c));
-      Gm(kk, c) = prow;
-    }
-    T.gsync();
   }
   for (int r = lane; r < NW; r += GS)                    // (row r of the inverse: its own sequence of interchanges, no barrier in between)
     for (int kk = NW - 1; kk >= 0; --kk) {
@@ -379,6 +474,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
       if (pr != kk) { const double t = Gm(r, kk); Gm(r, kk) = Gm(r, pr); Gm(r, pr) = t; }
     }
   T.gsync();
+  DAE_PH(27)
   // now: columns 0 .. NW-1 = G_w^-1, columns NW .. NW+NA-1 = G_w^-1 G_y = -W, column NW+NA = G_w^-1 r = -w0
   auto Wm = [&](int r, int c) -> double { return -(double)Gm(r, NW + c); };        // c == NA: w0
   auto Gi = [&](int r, int c) -> double { return (double)Gm(r, c); };
@@ -411,6 +507,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     Ld[DG_T + v * (NA + 2) + c] = t;
   }
   T.gsync();
+  DAE_PH(1)
   // ---- Q~ = Z' T, q~ and W'b
   for (int it = lane; it < NA * (NA + 2); it += GS) {
     const int a = it / (NA + 2), c = it % (NA + 2);
@@ -424,6 +521,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     S_[ES_RY + a] = (double)Ld[DG_GL + NW + a] + (double)Ld[DG_GF + NW + a];
     S_[ES_GFY + a] = Ld[DG_GF + NW + a];
   }
+  DAE_PH(2)
   // ---- forward record
   for (int it = lane; it < NW * NW; it += GS) Q.EW(e, EW_LU + it) = Gi(it / NW, it % NW);
   for (int it = lane; it < NW * NA; it += GS) Q.EW(e, EW_W + it) = Wm(it / NA, it % NA);
@@ -438,6 +536,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
   }
   for (int it = lane; it < NX * NW; it += GS) Q.EW(e, EW_EWJ + it) = Ld[DG_EW + it];
   for (int it = lane; it < NE * NW; it += GS) Q.EW(e, EW_JDW + it) = Ld[DG_JDW + it];
+  DAE_PH(7)
   // ---- terminal cost, objective share, nl_cons rows (as in eval_edge_coop, phase 7)
   if (last_stage) {
     for (int a = lane; a < NX; a += GS) S_[ES_MG + a] = om * mo[MO_MT + 1 + a];
@@ -466,6 +565,8 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     S_[ES_OBJ] = obj;
   }
   T.gsync();
+  DAE_PH(3)
+#undef DAE_PH
   return fail;
 }
 

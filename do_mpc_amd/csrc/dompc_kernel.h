@@ -891,7 +891,7 @@ constexpr int RF_MOC = RF_EW + EW_STAGE;
 constexpr int RF_IMG = RF_MOC + MOC_STAGE;
 constexpr int MOH_H0 = NX + NX * NA;                                    // offset of the packed Hessian inside a point record
 // DAE models: dense edge working set of eval_edge_dae (= dae::DG_SIZE, asserted in sweep())
-constexpr int DAE_NEED = DENSE_EDGE ? NW * (NW + NA + 1) + (NW + NA) * (NW + NA) + (NW + NA) * (NA + 2) + 2 * (NW + NA) + 3 * NW
+constexpr int DAE_NEED = DENSE_EDGE ? NW * (NW + NA + 2) + (NW + NA) * (NW + NA) + (NW + NA) * (NA + 2) + 2 * (NW + NA) + 3 * NW
                                       + NX * NW + NX * NA + NX + NE * NW + NE * NA + 2 * NW + RT_LEN : 0;
 constexpr int EL_SIZE = ((el_max(el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)), DAE_NEED) + 7) / 8) * 8;
 

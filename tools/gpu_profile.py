@@ -17,14 +17,27 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "industrial_poly"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     kw = json.loads(sys.argv[3]) if len(sys.argv) > 3 else {}
+    mhe = name.endswith(":mhe")            # the estimator of an example (rotating_masses:mhe): window 3 of the reference's stored run
+    name = name.split(":")[0]
     ex = CASES[name]
-    mpc = ex.build_mpc(ex.build_model(), max_batch=max(B, 1), **kw)
-    X0 = bench.synthetic_x0_batch(B) if name == "industrial_poly" else np.tile(ex.X0, (B, 1))
     import time
-    for rep in range(2):
-        t = time.time()
-        r = mpc.make_step_batch(X0)
-        dt = time.time() - t
+    if mhe:
+        est = ex.build_mhe(ex.build_model(), max_batch=max(B, 1), **kw)
+        mpc = est._mpc
+        g = np.load(os.path.join(ROOT, "tests", "golden", "rotating_masses.npz"))
+        P = np.tile(np.asarray(g["estimator.opt_p_num"], float)[3][None, :], (B, 1))
+        init = np.tile(np.asarray(g["estimator._opt_x_num"], float)[2][None, :], (B, 1))
+        for rep in range(2):
+            t = time.time()
+            r = est.solve_batch(P, init)
+            dt = time.time() - t
+    else:
+        mpc = ex.build_mpc(ex.build_model(), max_batch=max(B, 1), **kw)
+        X0 = bench.synthetic_x0_batch(B) if name == "industrial_poly" else np.tile(ex.X0, (B, 1))
+        for rep in range(2):
+            t = time.time()
+            r = mpc.make_step_batch(X0)
+            dt = time.time() - t
     st = r["stats"]
     tr = mpc.S.trace(4096)[-1]
     tot = tr[5]
