@@ -143,7 +143,9 @@ def main():
     bmax = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
     Bs = [b for b in (1, 64, 1024, 4096, 16384) if b <= bmax]
     rows = []
+    only = os.environ.get("DOMPC_TABLE_ONLY", "")                  # "mhe": the estimator rows only
     for label, name, kw in CONFIGS:
+        if only and only not in label: continue
         run(label, name, kw, Bs, rows)
     run_mhe([b for b in Bs if b <= 4096], rows)
     lines = ["| config | B | cold ms | cold steps/s | cold conv. | cold iters | warm ms | warm steps/s | warm conv. | warm iters |",
