@@ -1073,6 +1073,9 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #ifndef DOMPC_DUAL_VALU
 #define DOMPC_DUAL_VALU 1           // dual-residual products of the factorisation on the vector ALU (0: on the matrix cores, multipliers in one row of the A operand)
 #endif
+#ifndef DOMPC_GJ_ADJ
+#define DOMPC_GJ_ADJ 0                // 1: inverse of the 4 x 4 pivot block from its adjugate instead of LU in uniform arithmetic + two triangular solves (measured: +-0)
+#endif
 #ifndef DOMPC_GJ_SB
 #define DOMPC_GJ_SB 0               // 1: scheduling barriers at the step boundaries of the blocked elimination (measurement aid)
 #endif
@@ -1250,12 +1253,46 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
     double Rb[NT];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) Rb[ni] = prow_x ? X[ni] : T[prow_x ? 0 : mip][ni][rp];
-    // P, LU in uniform arithmetic
-    double a_[4][4], iu[4];
+    double a_[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) a_[i][j] = pan[(4 * p + i) * 4 + j];
+    double x_[4];
+#if DOMPC_GJ_ADJ
+    // column lr of P^-1 from the adjugate (2 x 2 minors of the row pairs (0,1) and (2,3), Laplace expansion): a dependent chain of
+    // ~12 instructions instead of ~43 through the LU factors and the two triangular solves - a dependent FP64 instruction costs
+    // ~16 cycles here, and this chain sits in front of the matrix-core instructions of every step.  Accepted if the determinant
+    // lost less than four digits to cancellation (|det| >= 1e-4 sum |terms|); otherwise the caller repeats the factorisation with
+    // partial pivoting like after a failed threshold test of the LU variant.
+    {
+      const int rho = 4 * p + (lr ^ 1);                         // column j of the adjugate is built from row j ^ 1 and the minors of the OTHER row pair
+      const double r0 = pan[rho * 4 + 0], r1 = pan[rho * 4 + 1], r2 = pan[rho * 4 + 2], r3 = pan[rho * 4 + 3];
+      double sm[6], cm[6];
+      constexpr int MA[6] = {0, 0, 0, 1, 1, 2}, MB[6] = {1, 2, 3, 2, 3, 3};      // column pairs of the minors
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        sm[k] = fma(a_[0][MA[k]], a_[1][MB[k]], -(a_[1][MA[k]] * a_[0][MB[k]]));
+        cm[k] = fma(a_[2][MA[k]], a_[3][MB[k]], -(a_[3][MA[k]] * a_[2][MB[k]]));
+      }
+      const double t0 = sm[0] * cm[5], t1 = sm[1] * cm[4], t2 = sm[2] * cm[3], t3 = sm[3] * cm[2], t4 = sm[4] * cm[1], t5 = sm[5] * cm[0];
+      const double det = ((t0 - t1) + (t2 + t3)) + (t5 - t4);
+      const double mag = ((fabs(t0) + fabs(t1)) + (fabs(t2) + fabs(t3))) + (fabs(t5) + fabs(t4));
+      viol = fmax(viol, fma(1e-4, mag, -fabs(det)));            // > 0: cancellation
+      pmin = fmin(pmin, fabs(det));
+      double m_[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) m_[k] = (lr < 2) ? cm[k] : sm[k];
+      const double idet = fast_rcp((fabs(det) > 1e-300) ? det : 1.0);
+      const double sg = (lr & 1) ? -idet : idet;
+      x_[0] = sg * fma(r1, m_[5], fma(-r2, m_[4], r3 * m_[3]));
+      x_[1] = sg * fma(-r0, m_[5], fma(r2, m_[2], -(r3 * m_[1])));
+      x_[2] = sg * fma(r0, m_[4], fma(-r1, m_[2], r3 * m_[0]));
+      x_[3] = sg * fma(-r0, m_[3], fma(r1, m_[1], -(r2 * m_[0])));
+    }
+#else
+    // P, LU in uniform arithmetic
+    double iu[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       double m = 0.0;
@@ -1272,7 +1309,6 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
       }
     }
     // column k = lr of P^-1:  L y = e_k, U x = y
-    double x_[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       double t = (lr == i) ? 1.0 : 0.0;
@@ -1287,6 +1323,7 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
       for (int j = i + 1; j < 4; ++j) t = fma(-a_[i][j], x_[j], t);
       x_[i] = t * iu[i];
     }
+#endif
     GJ_SB();             // (the LU factors are dead: do not hoist the loads below above them)
     // this lane's entries of -(C~ P^-1): row lc of every full tile row (packed rows: row 16 + (lc & 3)), column lr
     auto cprime = [&](int row) {
