@@ -429,6 +429,14 @@ class MPC:
                                           "is supported for scenario chains (n_robust = 0) only")
         if s.state_discretization != "collocation" and m.model_type == "continuous":
             raise Exception("Unknown state_discretization: {}".format(s.state_discretization))
+        # size limit of an edge (kernel: the collocation / algebraic unknowns of an interval are eliminated inside one wavefront's
+        # registers / LDS region; csrc/dompc_kernel.h asserts the same bound at compile time)
+        pts = (s.collocation_deg + 1) * s.collocation_ni if m.model_type == "continuous" else 0
+        n_w = pts * m.n_x + max(pts, 1) * m.n_z
+        if n_w > 64:
+            raise NotImplementedError("structured HIP backend: {} collocation / algebraic unknowns per control interval "
+                                      "((deg + 1) * ni * n_x + points * n_z); the kernels eliminate at most 64 per interval - "
+                                      "lower collocation_deg / collocation_ni".format(n_w))
         self._check_validity()
         # slack / nl_cons bookkeeping (optimizer.py:543-585)
         eps_entries = [Entry(sl["slack_name"], sl["shape"]) for sl in self.slack_vars_list]

@@ -136,3 +136,24 @@ def test_stop_request_returns_user_requested_stop():
     mpc.set_initial_guess()
     mpc.make_step(ex.X0)
     assert mpc.solver_stats["success"], mpc.solver_stats
+
+
+def test_too_many_unknowns_per_interval_is_refused_by_name():
+    """The kernels eliminate at most 64 collocation / algebraic unknowns per control interval (static_assert in
+    csrc/dompc_kernel.h): the setup says so instead of leaving the user with a failed hipcc run."""
+    from do_mpc_amd.controller import MPC
+    from do_mpc_amd.model import Model
+    model = Model("continuous")
+    xs = [model.set_variable("_x", f"x{i}") for i in range(17)]
+    u = model.set_variable("_u", "u")
+    for i in range(17):
+        model.set_rhs(f"x{i}", -xs[i] + u)
+    model.setup()
+    mpc = MPC(model)
+    st = mpc.settings
+    st.n_horizon, st.n_robust, st.t_step = 3, 0, 0.1
+    st.collocation_deg, st.collocation_ni = 3, 1               # 4 * 17 = 68 unknowns per interval
+    mpc.set_objective(mterm=xs[0] ** 2, lterm=xs[0] ** 2)
+    mpc.set_rterm(u=0.1)
+    with pytest.raises(NotImplementedError, match="68 collocation"):
+        mpc.setup()
