@@ -277,8 +277,8 @@ class MHE:
             raise NotImplementedError("structured HIP backend: nl_cons_single_slack couples all stages")
         nx, nu, nw, nv, ny, npe = m.n_x, m.n_u, m.n_w, m.n_v, m.n_y, self.n_p_est
         N = s.n_horizon
-        if any(float(q) != 1.0 for q in np.concatenate([self._p_est_scaling.master, self._p_set_scaling.master])):
-            raise NotImplementedError("structured HIP backend: parameter scaling in the estimator")
+        # (scaling of the estimated parameters: they ride as states of the augmented model, below; a scaling of the FIXED parameters
+        #  cancels in the reference's NLP - `_p_set / _p_set_scaling` times the model's `_p_scaling`, _mhe.py:1127, 1040 - and is ignored)
         # ---- measurement noise as a function of (x, u, tvp, p, y_meas): every measurement must carry its own noise term
         y_sym = sym.SX.sym("y_meas", ny, 1)
         zero_v = sym.SX(np.zeros((nv, 1)))
@@ -349,6 +349,8 @@ class MHE:
             mpc.set_nl_cons(c["expr_name"], c["expr"], ub=c["ub"], soft_constraint=c["soft_constraint"],
                             penalty_term_cons=c["penalty_term_cons"], maximum_violation=c["maximum_violation"])
         mpc._x_scaling.master[:nx] = self._x_scaling.master
+        mpc._x_scaling.master[nx:nx + npe] = self._p_est_scaling.master          # (_mhe.py:1083)
+        self._sx_aug = mpc._x_scaling.master.copy()                               # scaling of the augmented state (x, p_est)
         mpc._u_scaling.master[:nu] = self._u_scaling.master
         mpc.set_tvp_fun(lambda t: mpc.get_tvp_template())
         if am.n_p:
@@ -388,6 +390,8 @@ class MHE:
         self.opt_x_scaling = NumStruct(self._opt_x_layout, 1.0)
         self.opt_x_scaling["_x"] = self._x_scaling.master
         self.opt_x_scaling["_u"] = self._u_scaling.master
+        if npe:
+            self.opt_x_scaling["_p_est"] = self._p_est_scaling.master
         n_rows = ps.ne                                               # nl_cons rows of a stage (all evaluations)
         self._rows_stage = M * nx + nx + ny + n_rows              # (discrete: M = 0 - the rows x+ = f of the reference, then measurement / nl_cons rows)
         self.n_opt_lagr = N * self._rows_stage
@@ -439,7 +443,7 @@ class MHE:
             XL[:, :, :nx], XU[:, :, :nx] = xl, xu
         else:
             XL[1:N, -1, :nx], XU[1:N, -1, :nx] = xl, xu
-        XL[0, -1, nx:], XU[0, -1, nx:] = self._p_est_lb.master, self._p_est_ub.master
+        XL[0, -1, nx:], XU[0, -1, nx:] = self._p_est_lb.master / self._p_est_scaling.master, self._p_est_ub.master / self._p_est_scaling.master
         UL, UU = lb[ps.off_u:ps.off_eps].reshape(N, NUA), ub[ps.off_u:ps.off_eps].reshape(N, NUA)
         UL[:, :nu], UU[:, :nu] = self._u_lb.master / self._u_scaling.master, self._u_ub.master / self._u_scaling.master
         if mpc.n_eps:
@@ -497,7 +501,7 @@ class MHE:
         if nv:      # measurement noise of stage k from the end state of its interval
             TV = opt_p_chain[..., ps.p_off_tvp:ps.p_off_p].reshape(lead + (N + 1, ps.ntvp))[..., :N, :]
             Pm = np.broadcast_to(opt_p_chain[..., None, ps.p_off_p:ps.p_off_uprev], lead + (N, ps.np_))
-            sx = np.concatenate([self._x_scaling.master, np.ones(ps.nx - nx)])
+            sx = self._sx_aug
             su = np.concatenate([self._u_scaling.master, np.ones(ps.nu - nu)])
             cols = lambda a: np.moveaxis(a, -1, 0).reshape(a.shape[-1], int(np.prod(a.shape[:-1])))        # noqa: E731   (numel, batch * N)
             V = np.asarray(self._v_fun.eval(cols(X[..., 1:, -1, :] * sx), cols(U * su), cols(TV), cols(Pm))[0])
@@ -529,7 +533,7 @@ class MHE:
             for n in m._p.names:
                 k = m._p.vars[n].numel()
                 if k:
-                    src = ox[self._o_p:] if n in self._p_est.names else opt_p.master[self._po_pset:self._po_tvp]
+                    src = ox[self._o_p:] * self._p_est_scaling.master if n in self._p_est.names else opt_p.master[self._po_pset:self._po_tvp]
                     grp = self._p_est if n in self._p_est.names else self._p_set
                     pm[off:off + k] = src[grp.offset(n):grp.offset(n) + k]
                 off += k
@@ -537,7 +541,7 @@ class MHE:
             lam_meas = -np.asarray(g).reshape(nv, N).T
             out[:, (M + 1) * nx:(M + 1) * nx + ny] = lam_meas
             cx, Pc = self._mpc.opt_x_num.master, self._mpc.opt_p_num.master
-            X = cx[:ps.off_z].reshape(N + 1, M + 1, ps.nx)[1:, -1, :] * np.concatenate([self._x_scaling.master, np.ones(ps.nx - nx)])
+            X = cx[:ps.off_z].reshape(N + 1, M + 1, ps.nx)[1:, -1, :] * self._sx_aug
             U = cx[ps.off_u:ps.off_eps].reshape(N, ps.nu) * np.concatenate([self._u_scaling.master, np.ones(ps.nu - m.n_u)])
             TVc = Pc[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
             hx = self._hx_fun.eval(X.T, U.T, TVc.T, np.tile(Pc[ps.p_off_p:ps.p_off_uprev][:, None], (1, N)), lam_meas.T)[0]
@@ -552,7 +556,7 @@ class MHE:
         self._opt_x_num["_x"] = self._x0.master / self._x_scaling.master
         self._opt_x_num["_u"] = self._u0.master / self._u_scaling.master
         if self.n_p_est:
-            self._opt_x_num["_p_est"] = self._p_est0.master
+            self._opt_x_num["_p_est"] = self._p_est0.master / self._p_est_scaling.master
         self.flags["set_initial_guess"] = True
 
     def solve(self) -> None:
@@ -581,7 +585,7 @@ class MHE:
         r = self.S.solve_batch(Xi, mpc._lb_opt_x.master, mpc._ub_opt_x.master, mpc._nlp_cons_lb, mpc._nlp_cons_ub, P)
         ox = self._from_chain(r["x"], P)
         xN = ox[:, self._o_u - m.n_x:self._o_u] * self._x_scaling.master
-        return {"opt_x": ox, "x": xN, "p_est": ox[:, self._o_p:], "stats": r["stats"]}
+        return {"opt_x": ox, "x": xN, "p_est": ox[:, self._o_p:] * self._p_est_scaling.master, "stats": r["stats"]}
 
     def make_step(self, y0: np.ndarray) -> np.ndarray:
         """_mhe.py:896-993: the current measurement in, the state estimate at the end of the horizon out"""
@@ -601,7 +605,7 @@ class MHE:
         Pm[self._po_y:] = y_traj.master
         self.solve()
         x_next = _arr(self._opt_x_num["_x", -1, -1]) * self._x_scaling.master
-        p_est_next = _arr(self._opt_x_num["_p_est"]) if self.n_p_est else np.zeros(0)
+        p_est_next = _arr(self._opt_x_num["_p_est"]) * self._p_est_scaling.master if self.n_p_est else np.zeros(0)
         u0 = _arr(self._opt_x_num["_u", -1]) * self._u_scaling.master
         p0 = np.zeros(self.model.n_p)
         off = 0

@@ -126,7 +126,7 @@ def build_mhe(model, silence_solver=True, **overrides):
     return mhe
 
 
-def build_mhe_w(model, silence_solver=True, **overrides):
+def build_mhe_w(model, silence_solver=True, scaling=None, **overrides):
     """A second estimator on the model with process noise (build_model(process_noise=True)) for the paths the shipped example leaves
     out: `_w` as decision variables with weight P_w, numeric weights, the box of Theta_1 as bounds of `_p_est`, an nl_cons row on a
     state checked at the states only.  No stored run exists for it: compared with the oracle's solve of the restated NLP."""
@@ -153,5 +153,7 @@ def build_mhe_w(model, silence_solver=True, **overrides):
     mhe.bounds["lower", "_p_est", "Theta_1"] = 1e-5
     mhe.bounds["upper", "_p_est", "Theta_1"] = 1e-3
     mhe.set_nl_cons("phi_1_ub", model.x["phi_1"] - 1.5, 0)
+    for (group, name), v in (scaling or {}).items():       # e.g. {("_x", "dphi"): 5.0, ("_p_est", "Theta_1"): 1e-4}
+        mhe.scaling[group, name] = v
     mhe.setup()
     return mhe

@@ -457,6 +457,31 @@ def check_mhe_with_process_noise(make_mhe_w):
     return mhe
 
 
+def check_mhe_scaling_invariance(make_mhe_w):
+    """Scaling of states, inputs and ESTIMATED parameters (_mhe.py:1077-1085: `opt_x_scaling`; the parameter rides as a state of
+    the augmented model here) changes the variables of the NLP, not its solution: the scaled estimator's solution times its scaling
+    equals the unscaled estimator's (measured 2e-9), and so do the estimates returned by the batch entry point"""
+    scal = {("_x", "phi_1"): 2.0, ("_x", "phi_m"): 0.5, ("_x", "dphi"): 5.0, ("_u", "phi_m_set"): 3.0, ("_p_est", "Theta_1"): 1e-4}
+    ref, sc = make_mhe_w(), make_mhe_w(scaling=scal)
+    assert np.max(sc.opt_x_scaling.master) == 5.0 and np.min(sc.opt_x_scaling.master) == 1e-4
+    OP = golden("rotating_masses")["estimator.opt_p_num"][4]
+    N = 6
+    P = np.concatenate([OP[:12], OP[12:12 + 26 * 10].reshape(10, 26)[:N].ravel(), OP[12 + 260:].reshape(10, 5)[-N:].ravel()])
+    init = np.zeros(ref.n_opt_x)
+    init[ref._o_p:] = 1e-4
+    out = []
+    for m in (ref, sc):
+        m.opt_p_num.master[:] = P
+        m.opt_x_num.master[:] = init / m.opt_x_scaling.master
+        m.solve()
+        assert m.solver_stats["success"]
+        out.append(m.opt_x_num.master * m.opt_x_scaling.master)
+    assert relerr(out[1], out[0]) < 1e-7, relerr(out[1], out[0])
+    assert 1e-5 - 1e-9 <= out[1][ref._o_p] <= 1e-3 + 1e-9                # (the parameter's box holds in physical units)
+    rb = sc.solve_batch(P[None, :], (init / sc.opt_x_scaling.master)[None, :])
+    assert abs(rb["p_est"][0, 0] - out[0][ref._o_p]) < 1e-9 and np.max(np.abs(rb["x"][0] - out[0][ref._o_u - 8:ref._o_u])) < 1e-7
+
+
 def check_discrete_mhe(make_mhe):
     """A discrete-time estimator (process and measurement noise, arrival cost, an nl_cons row): the next state rides as an algebraic
     state of the interval in the product; against the oracle's solve of the restated reference NLP on synthetic measurements -

@@ -111,6 +111,13 @@ def test_mhe_with_process_noise_against_the_oracle():
     pc.check_mhe_with_process_noise(make)
 
 
+def test_mhe_scaling_of_states_inputs_and_estimated_parameters():
+    def make(**kw):
+        with hostemu.patched():
+            return ex.build_mhe_w(ex.build_model(process_noise=True), max_batch=1, **kw)
+    pc.check_mhe_scaling_invariance(make)
+
+
 def test_discrete_time_mhe_against_the_oracle():
     from do_mpc_amd.examples import oscillating_masses as om
 
