@@ -126,6 +126,10 @@ def build_mhe(model, silence_solver=True, **overrides):
     return mhe
 
 
+# a scaling of states, inputs and the estimated parameter for build_mhe_w (scaling-invariance tests)
+MHE_W_SCALING = {("_x", "phi_1"): 2.0, ("_x", "phi_m"): 0.5, ("_x", "dphi"): 5.0, ("_u", "phi_m_set"): 3.0, ("_p_est", "Theta_1"): 1e-4}
+
+
 def build_mhe_w(model, silence_solver=True, scaling=None, **overrides):
     """A second estimator on the model with process noise (build_model(process_noise=True)) for the paths the shipped example leaves
     out: `_w` as decision variables with weight P_w, numeric weights, the box of Theta_1 as bounds of `_p_est`, an nl_cons row on a

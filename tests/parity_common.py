@@ -461,8 +461,8 @@ def check_mhe_scaling_invariance(make_mhe_w):
     """Scaling of states, inputs and ESTIMATED parameters (_mhe.py:1077-1085: `opt_x_scaling`; the parameter rides as a state of
     the augmented model here) changes the variables of the NLP, not its solution: the scaled estimator's solution times its scaling
     equals the unscaled estimator's (measured 2e-9), and so do the estimates returned by the batch entry point"""
-    scal = {("_x", "phi_1"): 2.0, ("_x", "phi_m"): 0.5, ("_x", "dphi"): 5.0, ("_u", "phi_m_set"): 3.0, ("_p_est", "Theta_1"): 1e-4}
-    ref, sc = make_mhe_w(), make_mhe_w(scaling=scal)
+    from do_mpc_amd.examples.rotating_masses import MHE_W_SCALING
+    ref, sc = make_mhe_w(), make_mhe_w(scaling=MHE_W_SCALING)
     assert np.max(sc.opt_x_scaling.master) == 5.0 and np.min(sc.opt_x_scaling.master) == 1e-4
     OP = golden("rotating_masses")["estimator.opt_p_num"][4]
     N = 6

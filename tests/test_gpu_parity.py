@@ -334,6 +334,11 @@ def test_mhe_with_process_noise_against_the_oracle():
     pc.check_mhe_with_process_noise(lambda: ex.build_mhe_w(ex.build_model(process_noise=True)))
 
 
+def test_mhe_scaling_of_states_inputs_and_estimated_parameters():
+    ex = CASES["rotating_masses"]
+    pc.check_mhe_scaling_invariance(lambda **kw: ex.build_mhe_w(ex.build_model(process_noise=True), max_batch=1, **kw))
+
+
 def test_discrete_time_mhe_against_the_oracle():
     from do_mpc_amd.examples import oscillating_masses as om
     pc.check_discrete_mhe(lambda: om.build_mhe(om.build_model(estimation=True)))
