@@ -1073,6 +1073,9 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #ifndef DOMPC_DUAL_VALU
 #define DOMPC_DUAL_VALU 1           // dual-residual products of the factorisation on the vector ALU (0: on the matrix cores, multipliers in one row of the A operand)
 #endif
+#ifndef DOMPC_GJ_U
+#define DOMPC_GJ_U 0.01              // threshold of the pivot test of the blocked elimination (|a_kk| >= u max|a_ik|); a huge value sends every
+#endif                               // edge through the out-of-line factorisation with partial pivoting (test of that fallback)
 #ifndef DOMPC_GJ_ADJ
 #define DOMPC_GJ_ADJ 0                // 1: inverse of the 4 x 4 pivot block from its adjugate instead of LU in uniform arithmetic + two triangular solves (measured: +-0)
 #endif
@@ -1148,7 +1151,7 @@ __device__ inline double gj_element(const ldsd* mol, const ldsd* Ld, int row, in
 template <class DUAL>
 __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld, DUAL&& dual_from) {
   constexpr int R = GJ_R, RP = GJ_RP, MT = GJ_MTF > 0 ? GJ_MTF : 1, NT = GJ_NT > 0 ? GJ_NT : 1;      // (at least one tile: the function is compiled for every model)
-  constexpr double GJ_U = 0.01;
+  constexpr double GJ_U = DOMPC_GJ_U;
   const ldsd* mol = Ld + EL_MOS;                  // dense image of the model-output record
   ldsd* pan = Ld + EL_MX;                         // panel columns of the current step, RP x 4 row-major
 #if DOMPC_PROFILE

@@ -295,6 +295,27 @@ def test_user_defined_rterm_vs_oracle(name):
     pc.check_custom_rterm_vs_oracle(make_mpc, name)
 
 
+@pytest.mark.parametrize("name", ["CSTR", "industrial_poly"])
+def test_pivoting_fallback_of_the_factorisation(name, monkeypatch):
+    """The blocked elimination on the matrix cores runs in natural pivot order and hands an edge whose threshold test fails to the
+    out-of-line factorisation with partial pivoting (phase_edge_factor_pivot) - never taken on the shipped workloads.  A code object
+    whose threshold cannot be met (-DDOMPC_GJ_U=1e9) sends EVERY edge of every iteration through it: same iterations, same solution
+    (different elimination order: rounding level)"""
+    ex = CASES[name]
+    sol = []
+    for defs in ("", "DOMPC_GJ_U=1e9"):
+        monkeypatch.setenv("DOMPC_DEFS", defs)
+        mpc = make_mpc(name)
+        mpc.x0 = ex.X0
+        mpc.set_initial_guess()
+        mpc.make_step(ex.X0)
+        assert mpc.solver_stats["success"]
+        sol.append((mpc.solver_stats["iter_count"], mpc.opt_x_num.master.copy(), mpc.lam_g_num.copy()))
+    assert sol[0][0] == sol[1][0]
+    assert pc.relerr(sol[0][1], sol[1][1]) < 1e-9 and pc.relerr(sol[0][2], sol[1][2]) < 1e-7
+    assert not np.array_equal(sol[0][1], sol[1][1])          # (a different elimination did the work: not the same bits)
+
+
 @pytest.mark.parametrize("name,over,x0", pc.NL_COLLOC_CASES, ids=[c[0] for c in pc.NL_COLLOC_CASES])
 def test_nl_cons_at_collocation_points(name, over, x0):
     pc.check_nl_cons_at_collocation_points(make_mpc, name, over, x0)
