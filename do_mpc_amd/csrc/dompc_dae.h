@@ -380,7 +380,10 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
   // Per step ONE batch of LDS reads - the pivot column (every lane, broadcast reads) and the lane's own column -, the pivot search, the
   // row interchange and the rank-1 update in registers, one batch of writes: the first version walked the rows in loops whose every
   // trip waited for its LDS round trip (pivot search, column copy, interchange pass, update: ~10 k cycles per step at 36 unknowns).
-  constexpr bool GJ_REGS = NW <= 48;                     // (2 NW doubles in registers; larger blocks keep the row loops)
+#ifndef DOMPC_GJ_REGS_MAX
+#define DOMPC_GJ_REGS_MAX 48        // largest block whose pivot steps run in registers (tests: 0 = the row loops for every block)
+#endif
+  constexpr bool GJ_REGS = NW <= DOMPC_GJ_REGS_MAX;      // (2 NW doubles in registers; larger blocks keep the row loops)
   constexpr int NW1_ = NW > 0 ? NW : 1;
   for (int kk = 0; kk < NW; ++kk) {
     if constexpr (GJ_REGS) {

@@ -218,3 +218,21 @@ def test_dense_edge_path_reproduces_the_fast_path(name, monkeypatch):
         sol.append((mpc.solver_stats["iter_count"], mpc.opt_x_num.master.copy(), mpc.lam_g_num.copy()))
     assert sol[0][0] == sol[1][0]
     assert pc.relerr(sol[0][1], sol[1][1]) < 1e-11 and pc.relerr(sol[0][2], sol[1][2]) < 1e-9      # (measured 7e-14 / 1e-12)
+
+
+def test_dense_elimination_with_row_loops_equals_the_register_variant(monkeypatch):
+    """blocks of more than 48 unknowns keep the pivot steps of the dense path as loops over the rows (no example is that large):
+    -DDOMPC_GJ_REGS_MAX=0 compiles that variant for the double inverted pendulum (36 unknowns, row interchanges at several
+    pivots) - same iterations and solution as the in-register variant"""
+    ex = CASES["dip"]
+    sol = []
+    for defs in ("", "DOMPC_GJ_REGS_MAX=0"):
+        monkeypatch.setenv("DOMPC_DEFS", defs)
+        mpc = make_mpc("dip", n_horizon=12)
+        mpc.x0 = ex.X0
+        mpc.set_initial_guess()
+        mpc.make_step(ex.X0)
+        assert mpc.solver_stats["success"]
+        sol.append((mpc.solver_stats["iter_count"], mpc.opt_x_num.master.copy(), mpc.lam_g_num.copy()))
+    assert sol[0][0] == sol[1][0] and sol[0][0] > 10
+    assert pc.relerr(sol[0][1], sol[1][1]) < 1e-11 and pc.relerr(sol[0][2], sol[1][2]) < 1e-9
