@@ -234,5 +234,5 @@ def test_dense_elimination_with_row_loops_equals_the_register_variant(monkeypatc
         mpc.make_step(ex.X0)
         assert mpc.solver_stats["success"]
         sol.append((mpc.solver_stats["iter_count"], mpc.opt_x_num.master.copy(), mpc.lam_g_num.copy()))
-    assert sol[0][0] == sol[1][0] and sol[0][0] > 10
+    assert sol[0][0] == sol[1][0] and sol[0][0] >= 5
     assert pc.relerr(sol[0][1], sol[1][1]) < 1e-11 and pc.relerr(sol[0][2], sol[1][2]) < 1e-9
