@@ -156,7 +156,7 @@ class BatchClosedLoopMHE:
         op[:, mhe._po_pset:mhe._po_tvp] = mhe.p_fun(te).master
         op[:, mhe._po_tvp:mhe._po_y] = mhe.tvp_fun(te).master
         ge = np.zeros((B, mhe.n_opt_x))
-        ge[:, :mhe._o_u].reshape(B, -1, nx)[:] = (x_est / mhe._x_scaling.master)[:, None, :]
+        ge[:, :mhe._o_z].reshape(B, -1, nx)[:] = (x_est / mhe._x_scaling.master)[:, None, :]
         ge[:, mhe._o_p:] = p_est
         self.Pe, self.Ge = t(mhe._p_to_chain(op)), t(mhe._to_chain(ge))
         em = mhe._mpc

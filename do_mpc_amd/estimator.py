@@ -19,7 +19,10 @@ four differences, each a switch of the generated header (csrc/dompc_kernel.h: DO
   * the measurement rows  h(x_{k+1}, u_k, tvp_k, p) + v_k = y_k  are solved for the measurement noise v_k, which only
     appears in the stage cost: the cost of stage k becomes a function of the END state of the interval (every measurement
     must carry its noise term - `set_meas(..., meas_noise=True)`, the default);
-  * process noise `_w` is one more input of the interval.
+  * process noise `_w` is one more input of the interval;
+  * algebraic states `_z` of the model (and its algebraic equations) are edge unknowns of the chain problem exactly as in the
+    controller; the measurement function reads `_z[k, -1]` (:1158) - what a stage cost reads there.  Discrete-time models: the
+    next state itself rides as an algebraic state of the interval (no stored points inside an interval otherwise).
 `opt_x_num`, `opt_p_num`, `lam_g_num` are handed out in the reference's layout.
 """
 from __future__ import annotations
@@ -82,8 +85,6 @@ def _group(kind: str, items) -> VarGroup:
 class MHE:
     def __init__(self, model: Model, p_est_list: list = [], settings: Optional[MHESettings] = None):
         assert model.flags["setup"] is True, "Model for MHE was not setup. After the complete model creation call model.setup()."
-        if model.n_z:
-            raise NotImplementedError("structured HIP backend: MHE for models with algebraic states")
         self.model = m = model
         self.settings = self._settings = settings if settings is not None else MHESettings()
         pn = [n for n in m._p.names if m._p.vars[n].numel() > 0]
@@ -288,6 +289,9 @@ class MHE:
             raise NotImplementedError("structured HIP backend: every measurement of the estimator model needs its own additive noise "
                                       "term (set_meas(..., meas_noise=True)): the measurement rows are solved for it")
         discrete = self._discrete = m.model_type == "discrete"
+        nz = m.n_z
+        if discrete and nz:
+            raise NotImplementedError("structured HIP backend: MHE for discrete-time models with algebraic states")
         if discrete:
             # a discrete model has no stored points inside an interval: the NEXT state becomes an algebraic state of the interval,
             # z = f(x, u, w, p) as its algebraic equation and x+ = z as its dynamics - the measurement residual (and with it the stage
@@ -329,6 +333,13 @@ class MHE:
                 am.rhs_list.append(dict(r))
             for n in self._p_est.names:
                 am.rhs_list.append({"var_name": n, "expr": sym.SX(np.zeros(self._p_est.vars[n].shape))})
+            # algebraic states of the model (_mhe.py:1056, 1136-1141): edge unknowns of the chain problem like in the controller; the
+            # measurement function reads `_z[k, -1]` (:1158), which is what a stage cost reads there (dense edge path)
+            for n in m._z.names:
+                if m._z.vars[n].numel():
+                    am._z.add(n, m._z.vars[n])
+            for a in m.alg_list:
+                am.alg_list.append(dict(a))
         for n in m._aux.names:
             if n != "default":
                 am._aux.add(n, m._aux.vars[n])
@@ -352,6 +363,8 @@ class MHE:
         mpc._x_scaling.master[nx:nx + npe] = self._p_est_scaling.master          # (_mhe.py:1083)
         self._sx_aug = mpc._x_scaling.master.copy()                               # scaling of the augmented state (x, p_est)
         mpc._u_scaling.master[:nu] = self._u_scaling.master
+        if nz:
+            mpc._z_scaling.master[:] = self._z_scaling.master
         mpc.set_tvp_fun(lambda t: mpc.get_tvp_template())
         if am.n_p:
             mpc.set_p_fun(lambda t: mpc.get_p_template(1))
@@ -390,14 +403,25 @@ class MHE:
         self.opt_x_scaling = NumStruct(self._opt_x_layout, 1.0)
         self.opt_x_scaling["_x"] = self._x_scaling.master
         self.opt_x_scaling["_u"] = self._u_scaling.master
+        if nz:
+            self.opt_x_scaling["_z"] = self._z_scaling.master
         if npe:
             self.opt_x_scaling["_p_est"] = self._p_est_scaling.master
         n_rows = ps.ne                                               # nl_cons rows of a stage (all evaluations)
-        self._rows_stage = M * nx + nx + ny + n_rows              # (discrete: M = 0 - the rows x+ = f of the reference, then measurement / nl_cons rows)
+        self._rows_stage = M * (nx + nz) + nx + ny + n_rows       # (discrete: M = 0 - the rows x+ = f of the reference, then measurement / nl_cons rows)
         self.n_opt_lagr = N * self._rows_stage
         self.lam_g_num = np.zeros(self.n_opt_lagr)
+        if not discrete:
+            # chain rows of a stage that exist in the reference (the riding parameters' rows do not): interval function per finite
+            # element [alg rows of point 0 | per collocation point: collocation rows, alg rows | end-of-element rows], continuity rows
+            deg, ni, nxa = s.collocation_deg, s.collocation_ni, ps.nx
+            st_rows = np.arange(nxa) < nx
+            el = np.concatenate([np.ones(nz, bool)] + [np.concatenate([st_rows, np.ones(nz, bool)])] * deg + [st_rows])
+            self._dyn_keep = np.concatenate([el] * ni + [st_rows])
+            assert int(self._dyn_keep.sum()) == M * (nx + nz) + nx and self._dyn_keep.size == M * (nxa + nz) + nxa
         # offsets inside the reference's opt_x
-        self._o_u = (N + 1) * (M + 1) * nx
+        self._o_z = (N + 1) * (M + 1) * nx                          # end of `_x` = start of `_z` (N x max(M, 1) slots)
+        self._o_u = self._o_z + N * max(M, 1) * nz
         self._o_w = self._o_u + N * nu
         self._o_v = self._o_w + N * nw
         self._o_eps = self._o_v + N * nv
@@ -406,7 +430,7 @@ class MHE:
         self._po_tvp = self._po_pset + self.n_p_set
         self._po_y = self._po_tvp + N * m.n_tvp
         # numeric helpers: measurement noise and its cost gradient at the solution
-        args = [am._x.cat, am._u.cat, am._tvp.cat, am._p.cat]
+        args = [am._x.cat, am._u.cat, m._z.cat, am._tvp.cat, am._p.cat]      # (z: the model's algebraic states of the LAST point of the interval)
         if discrete:            # (h reads the next state through its algebraic copy: evaluate with the next NODE state in its place)
             v_of_x = sym.substitute(v_of, z_next, m._x.cat)
             h0_x = sym.substitute(h0, z_next, m._x.cat)
@@ -446,6 +470,11 @@ class MHE:
         XL[0, -1, nx:], XU[0, -1, nx:] = self._p_est_lb.master / self._p_est_scaling.master, self._p_est_ub.master / self._p_est_scaling.master
         UL, UU = lb[ps.off_u:ps.off_eps].reshape(N, NUA), ub[ps.off_u:ps.off_eps].reshape(N, NUA)
         UL[:, :nu], UU[:, :nu] = self._u_lb.master / self._u_scaling.master, self._u_ub.master / self._u_scaling.master
+        if self.model.n_z and not self._discrete:        # (_mhe.py:1006-1007 every `_z` slot, :1015-1016 the first slot of every interval)
+            nz = self.model.n_z
+            ZL, ZU = lb[ps.off_z:ps.off_u].reshape(N, -1, nz), ub[ps.off_z:ps.off_u].reshape(N, -1, nz)
+            sl = slice(None) if s.cons_check_colloc_points else slice(0, 1)
+            ZL[:, sl, :], ZU[:, sl, :] = self._z_lb.master / self._z_scaling.master, self._z_ub.master / self._z_scaling.master
         if mpc.n_eps:
             lb[ps.off_eps:].reshape(-1, mpc.n_eps)[:] = mpc._eps_lb
             ub[ps.off_eps:].reshape(-1, mpc.n_eps)[:] = mpc._eps_ub
@@ -459,7 +488,7 @@ class MHE:
         lead = ox.shape[:-1]
         out = np.zeros(lead + (ps.n_opt_x,))
         X = out[..., :ps.off_z].reshape(lead + (N + 1, M + 1, ps.nx))
-        X[..., :nx] = ox[..., :self._o_u].reshape(lead + (N + 1, M + 1, nx))
+        X[..., :nx] = ox[..., :self._o_z].reshape(lead + (N + 1, M + 1, nx))
         X[..., nx:] = ox[..., None, None, self._o_p:]
         U = out[..., ps.off_u:ps.off_eps].reshape(lead + (N, ps.nu))
         U[..., :nu] = ox[..., self._o_u:self._o_w].reshape(lead + (N, nu))
@@ -469,7 +498,17 @@ class MHE:
         if self._discrete:      # (the algebraic copy of the next state starts at the guess of that state)
             Z = out[..., ps.off_z:ps.off_u].reshape(lead + (N, nx))
             Z[...] = X[..., 1:, -1, :nx]
+        elif m.n_z:             # (same block in both layouts: N x M slots, _mhe.py:1056 / _mpc.py:1130 with one scenario)
+            out[..., ps.off_z:ps.off_u] = ox[..., self._o_z:self._o_u]
         return out
+
+    def _z_last(self, cx: np.ndarray, lead: tuple) -> np.ndarray:
+        """(unscaled) algebraic states of the last point of every interval, shape lead + (N, n_z) - what the measurement function reads"""
+        ps, m, N = self._ps, self.model, self.settings.n_horizon
+        if not m.n_z or self._discrete:
+            return np.zeros(lead + (N, 0))
+        Z = cx[..., ps.off_z:ps.off_u].reshape(lead + (N, max(ps.M, 1), m.n_z))
+        return Z[..., -1, :] * self._z_scaling.master
 
     def _p_to_chain(self, op: np.ndarray) -> np.ndarray:
         """opt_p: [_x_prev | _p_est_prev | _p_set | _tvp (N) | _y_meas (N)] -> [_x0 = previous estimate of (x, p_est) |
@@ -493,7 +532,9 @@ class MHE:
         lead = cx.shape[:-1]
         out = np.zeros(lead + (self.n_opt_x,))
         X = cx[..., :ps.off_z].reshape(lead + (N + 1, M + 1, ps.nx))
-        out[..., :self._o_u] = X[..., :nx].reshape(lead + (-1,))
+        out[..., :self._o_z] = X[..., :nx].reshape(lead + (-1,))
+        if m.n_z and not self._discrete:
+            out[..., self._o_z:self._o_u] = cx[..., ps.off_z:ps.off_u]
         U = cx[..., ps.off_u:ps.off_eps].reshape(lead + (N, ps.nu))
         out[..., self._o_u:self._o_w] = U[..., :nu].reshape(lead + (-1,))
         if nw:
@@ -504,7 +545,7 @@ class MHE:
             sx = self._sx_aug
             su = np.concatenate([self._u_scaling.master, np.ones(ps.nu - nu)])
             cols = lambda a: np.moveaxis(a, -1, 0).reshape(a.shape[-1], int(np.prod(a.shape[:-1])))        # noqa: E731   (numel, batch * N)
-            V = np.asarray(self._v_fun.eval(cols(X[..., 1:, -1, :] * sx), cols(U * su), cols(TV), cols(Pm))[0])
+            V = np.asarray(self._v_fun.eval(cols(X[..., 1:, -1, :] * sx), cols(U * su), cols(self._z_last(cx, lead)), cols(TV), cols(Pm))[0])
             out[..., self._o_v:self._o_eps] = np.moveaxis(V.reshape((nv,) + lead + (N,)), 0, -1).reshape(lead + (-1,))
         out[..., self._o_eps:self._o_p] = cx[..., ps.off_eps:]
         out[..., self._o_p:] = X[..., 0, -1, nx:]
@@ -521,9 +562,11 @@ class MHE:
             out[:, :nx] = -L[:, :nx]
             n_dyn = nx + ps.nx
         else:
-            blk = L[:, :(M + 1) * ps.nx].reshape(N, M + 1, ps.nx)    # collocation / end-of-element rows, then continuity
-            out[:, :(M + 1) * nx] = blk[:, :, :nx].reshape(N, -1)
-            n_dyn = (M + 1) * ps.nx
+            # rows of the interval function (optimizer.py:905-983: algebraic rows of point 0, per collocation point the collocation rows of
+            # the states and the algebraic rows, the end-of-element rows), then the continuity rows: the rows of the riding parameters drop out
+            keep = self._dyn_keep
+            n_dyn = keep.size
+            out[:, :int(keep.sum())] = L[:, :n_dyn][:, keep]
         if nv:
             W = ox[self._o_w:self._o_v].reshape(N, nw) if nw else np.zeros((N, 0))
             V = ox[self._o_v:self._o_eps].reshape(N, nv)
@@ -539,15 +582,19 @@ class MHE:
                 off += k
             g = self._dldv_fun.eval(W.T, V.T, TV.T, np.tile(pm[:, None], (1, N)))[0]
             lam_meas = -np.asarray(g).reshape(nv, N).T
-            out[:, (M + 1) * nx:(M + 1) * nx + ny] = lam_meas
+            r_meas = self._rows_stage - ny - (L.shape[1] - n_dyn)       # (first measurement row of a stage)
+            out[:, r_meas:r_meas + ny] = lam_meas
             cx, Pc = self._mpc.opt_x_num.master, self._mpc.opt_p_num.master
             X = cx[:ps.off_z].reshape(N + 1, M + 1, ps.nx)[1:, -1, :] * self._sx_aug
             U = cx[ps.off_u:ps.off_eps].reshape(N, ps.nu) * np.concatenate([self._u_scaling.master, np.ones(ps.nu - m.n_u)])
             TVc = Pc[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
-            hx = self._hx_fun.eval(X.T, U.T, TVc.T, np.tile(Pc[ps.p_off_p:ps.p_off_uprev][:, None], (1, N)), lam_meas.T)[0]
+            Zl = self._z_last(cx, ())
+            hx = self._hx_fun.eval(X.T, U.T, Zl.T, TVc.T, np.tile(Pc[ps.p_off_p:ps.p_off_uprev][:, None], (1, N)), lam_meas.T)[0]
             if not self._discrete:
-                out[:, M * nx:(M + 1) * nx] += np.asarray(hx).reshape(nx, N).T
-        out[:, (M + 1) * nx + ny:] = L[:, n_dyn:]
+                out[:, r_meas - nx:r_meas] += np.asarray(hx).reshape(nx, N).T
+        else:
+            r_meas = self._rows_stage - ny - (L.shape[1] - n_dyn)
+        out[:, r_meas + ny:] = L[:, n_dyn:]
         return out.reshape(-1)
 
     # ------------------------------------------------------------------ runtime
@@ -555,6 +602,8 @@ class MHE:
         assert self.flags["setup"] is True, "mhe was not setup yet. Please call mhe.setup()."
         self._opt_x_num["_x"] = self._x0.master / self._x_scaling.master
         self._opt_x_num["_u"] = self._u0.master / self._u_scaling.master
+        if self.model.n_z:
+            self._opt_x_num["_z"] = self._z0.master / self._z_scaling.master
         if self.n_p_est:
             self._opt_x_num["_p_est"] = self._p_est0.master / self._p_est_scaling.master
         self.flags["set_initial_guess"] = True
@@ -584,7 +633,7 @@ class MHE:
         Xi = self._to_chain(np.asarray(OPT_X_INIT, dtype=float).reshape(B, self.n_opt_x))
         r = self.S.solve_batch(Xi, mpc._lb_opt_x.master, mpc._ub_opt_x.master, mpc._nlp_cons_lb, mpc._nlp_cons_ub, P)
         ox = self._from_chain(r["x"], P)
-        xN = ox[:, self._o_u - m.n_x:self._o_u] * self._x_scaling.master
+        xN = ox[:, self._o_z - m.n_x:self._o_z] * self._x_scaling.master
         return {"opt_x": ox, "x": xN, "p_est": ox[:, self._o_p:] * self._p_est_scaling.master, "stats": r["stats"]}
 
     def make_step(self, y0: np.ndarray) -> np.ndarray:
@@ -607,6 +656,7 @@ class MHE:
         x_next = _arr(self._opt_x_num["_x", -1, -1]) * self._x_scaling.master
         p_est_next = _arr(self._opt_x_num["_p_est"]) * self._p_est_scaling.master if self.n_p_est else np.zeros(0)
         u0 = _arr(self._opt_x_num["_u", -1]) * self._u_scaling.master
+        z0 = _arr(self._opt_x_num["_z", -1, -1]) * self._z_scaling.master if self.model.n_z else np.zeros(0)
         p0 = np.zeros(self.model.n_p)
         off = 0
         for n in self.model._p.names:
@@ -616,6 +666,8 @@ class MHE:
                 p0[off:off + k] = src[grp.offset(n):grp.offset(n) + k]
             off += k
         self.data.update(_x=x0, _u=u0, _p=p0, _time=self._t0)
+        if self.model.n_z:
+            self.data.update(_z=z0)
         if self.model.n_tvp:
             self.data.update(_tvp=_arr(tvp0["_tvp", -1]))
         self.data.update(opt_p_num=self._opt_p_num.master.copy())
@@ -631,4 +683,6 @@ class MHE:
         if self.n_p_est:
             self._p_est0.master[:] = p_est_next
         self._u0.master[:] = u0
+        if self.model.n_z:
+            self._z0.master[:] = z0
         return x_next.reshape(-1, 1)

@@ -27,9 +27,12 @@ def setpoint_trajectory():
     return np.array(traj)
 
 
-def build_model(symvar_type="SX", process_noise=False):
+def build_model(symvar_type="SX", process_noise=False, dae=False):
     """process_noise: additive noise on the three angular accelerations (`set_rhs(..., process_noise=True)`; not in the reference's
-    example - the estimator variant build_mhe_w uses it)"""
+    example - the estimator variant build_mhe_w uses it).
+    dae: the same plant written with algebraic states - the twist `tw_i = phi_i - left_i` of the spring on the left of every disc
+    as `_z` with its algebraic equation, read by the accelerations AND by the first measurement (`phi_1 = tw_1 + phi_m_1`): an
+    equivalent model for the estimator's DAE path (same estimates as the ODE model; no stored run exists for it)"""
     mdl = Model("continuous", symvar_type)
     phi = vertcat(*[mdl.set_variable("_x", "phi_%d" % i) for i in (1, 2, 3)])
     dphi = mdl.set_variable("_x", "dphi", shape=(3, 1))
@@ -38,16 +41,23 @@ def build_model(symvar_type="SX", process_noise=False):
     mdl.set_variable("_tvp", "phi_2_set")
     mdl.set_variable("_p", "P_p")
     mdl.set_variable("_tvp", "P_v", shape=(5, 5))
-    mdl.set_meas("phi_1_meas", phi)
+    left = [phi_m[0], phi[0], phi[1]]
+    right = [phi[1], phi[2], phi_m[1]]
+    if dae:
+        tw = mdl.set_variable("_z", "tw", shape=(3, 1))
+        mdl.set_alg("twist", vertcat(*[tw[i] - (phi[i] - left[i]) for i in range(3)]))
+        twist = [tw[i] for i in range(3)]
+        mdl.set_meas("phi_1_meas", vertcat(tw[0] + phi_m[0], phi[1], phi[2]))
+    else:
+        twist = [phi[i] - left[i] for i in range(3)]
+        mdl.set_meas("phi_1_meas", phi)
     mdl.set_meas("phi_m_set_meas", phi_m_set)
     th = [mdl.set_variable("_p", "Theta_%d" % i) for i in (1, 2, 3)]
     c = np.array([2.697, 2.66, 3.05, 2.86]) * 1e-3       # spring constants
     d = np.array([6.78, 8.01, 8.82]) * 1e-5              # friction
     for i in range(3):
         mdl.set_rhs("phi_%d" % (i + 1), dphi[i])
-    left = [phi_m[0], phi[0], phi[1]]
-    right = [phi[1], phi[2], phi_m[1]]
-    mdl.set_rhs("dphi", vertcat(*[-c[i] / th[i] * (phi[i] - left[i]) - c[i + 1] / th[i] * (phi[i] - right[i])
+    mdl.set_rhs("dphi", vertcat(*[-c[i] / th[i] * twist[i] - c[i + 1] / th[i] * (phi[i] - right[i])
                                   - d[i] / th[i] * dphi[i] for i in range(3)]), process_noise=process_noise)
     mdl.set_rhs("phi_m", 1 / 1e-2 * (phi_m_set - phi_m))
     mdl.setup()

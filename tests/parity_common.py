@@ -401,7 +401,7 @@ def check_mhe_golden_replay(make_mhe, steps=5):
         assert np.max(np.abs(mhe.opt_p_num.master - OP[k])) < 1e-8, k
         assert relerr(mhe.opt_x_num.master, OX[k]) < 1e-8, (k, relerr(mhe.opt_x_num.master, OX[k]))
         assert np.max(np.abs(mhe.lam_g_num - LG[k])) < 1e-8 * max(1.0, np.max(np.abs(LG[k]))), k
-        assert relerr(x_est, OX[k][mhe._o_u - 8:mhe._o_u]) < 1e-8
+        assert relerr(x_est, OX[k][mhe._o_z - 8:mhe._o_z]) < 1e-8
     assert relerr(mhe.data["_x"], XE[:steps]) < 1e-8            # (the reference's own assertion: estimator states of the run, 1e-8)
     # the solution is a KKT point of the restated reference NLP (oracle/mhe.py) with the mapped multipliers
     nlp = oracle_mhe()
@@ -428,7 +428,7 @@ def check_mhe_batch(make_mhe):
     assert np.all(r["stats"]["success"] == 1)
     for j, k in enumerate(idx):
         assert relerr(r["opt_x"][j], OX[k]) < 1e-8, (j, k, relerr(r["opt_x"][j], OX[k]))
-        assert relerr(r["x"][j], OX[k][mhe._o_u - 8:mhe._o_u]) < 1e-8 and abs(r["p_est"][j, 0] - OX[k][-1]) < 1e-10
+        assert relerr(r["x"][j], OX[k][mhe._o_z - 8:mhe._o_z]) < 1e-8 and abs(r["p_est"][j, 0] - OX[k][-1]) < 1e-10
     return mhe
 
 
@@ -479,7 +479,67 @@ def check_mhe_scaling_invariance(make_mhe_w):
     assert relerr(out[1], out[0]) < 1e-7, relerr(out[1], out[0])
     assert 1e-5 - 1e-9 <= out[1][ref._o_p] <= 1e-3 + 1e-9                # (the parameter's box holds in physical units)
     rb = sc.solve_batch(P[None, :], (init / sc.opt_x_scaling.master)[None, :])
-    assert abs(rb["p_est"][0, 0] - out[0][ref._o_p]) < 1e-9 and np.max(np.abs(rb["x"][0] - out[0][ref._o_u - 8:ref._o_u])) < 1e-7
+    assert abs(rb["p_est"][0, 0] - out[0][ref._o_p]) < 1e-9 and np.max(np.abs(rb["x"][0] - out[0][ref._o_z - 8:ref._o_z])) < 1e-7
+
+
+def check_mhe_dae_equals_ode(make_mhe_w):
+    """The estimator for a model with algebraic states (_mhe.py:1056, 1136-1141, 1158: `_z[k, :]` in the interval function, `_z[k, -1]`
+    in the measurement function).  No stored run of the reference exists for one: the rotating masses written with the spring twists
+    as algebraic states - read by the accelerations and by the first measurement - is the SAME estimation problem as the ODE model,
+    so states, inputs, noise, estimated parameter and the measurement rows' multipliers must agree (measured 3e-10 / 1e-9), the
+    algebraic states must satisfy their equations and the dense edge path must have been the one that ran"""
+    ode, dae = make_mhe_w(dae=False), make_mhe_w(dae=True)
+    assert dae.model.n_z == 3 and dae.n_opt_x == ode.n_opt_x + dae.settings.n_horizon * dae._ps.M * 3
+    assert dae.n_opt_lagr == ode.n_opt_lagr + dae.settings.n_horizon * dae._ps.M * 3
+    OP = golden("rotating_masses")["estimator.opt_p_num"][4]
+    N = 6
+    P = np.concatenate([OP[:12], OP[12:12 + 26 * 10].reshape(10, 26)[:N].ravel(), OP[12 + 260:].reshape(10, 5)[-N:].ravel()])
+    out = []
+    for m in (ode, dae):
+        init = np.zeros(m.n_opt_x)
+        init[m._o_p:] = 1e-4
+        m.opt_p_num.master[:] = P
+        m.opt_x_num.master[:] = init
+        m.solve()
+        assert m.solver_stats["success"]
+        out.append((m.opt_x_num.master.copy(), m.lam_g_num.copy()))
+    xo, xd = out[0][0], out[1][0]
+    assert relerr(xd[:dae._o_z], xo[:ode._o_z]) < 1e-7                                  # states
+    assert relerr(xd[dae._o_u:], xo[ode._o_u:]) < 1e-7                                  # inputs, noise, slack, parameter
+    M, nx = dae._ps.M, 8
+    X = xd[:dae._o_z].reshape(N + 1, M + 1, nx)
+    Z = xd[dae._o_z:dae._o_u].reshape(N, M, 3)
+    for k in range(N):                    # twist of point i of interval k (optimizer.py:905-969: point 0 = the state `_x[k, -1]`, point j = `_x[k+1, j-1]`)
+        for i in range(M):
+            x = X[k, -1] if i == 0 else X[k + 1, i - 1]
+            tw = np.array([x[0] - x[6], x[1] - x[0], x[2] - x[1]])
+            assert np.max(np.abs(Z[k, i] - tw)) < 1e-9, (k, i)
+    ro, rd = ode._rows_stage, dae._rows_stage
+    lo, ld = out[0][1].reshape(N, ro), out[1][1].reshape(N, rd)
+    mo, md = ro - 5 - (ode._ps.ne), rd - 5 - (dae._ps.ne)                               # measurement rows (5 per stage)
+    assert np.max(np.abs(ld[:, md:md + 5] - lo[:, mo:mo + 5])) < 1e-7 * max(1.0, np.max(np.abs(lo)))
+    return dae
+
+
+def check_mhe_dae_make_step(make_mhe):
+    """`make_step` of the estimator for the model with algebraic states (the shipped example's estimator - nl_cons rows at every
+    collocation point - on the equivalent DAE model): the same estimates as the ODE model over the first measurements of the
+    reference's stored run, `_z` recorded and carried as the next initial guess (_mhe.py:957, 966, 990)"""
+    g = golden("rotating_masses")
+    Y = g["estimator._y"]
+    ode, dae = make_mhe(dae=False), make_mhe(dae=True)
+    for m in (ode, dae):
+        m.x0 = np.zeros(8)
+        m.p_est0 = 1e-4
+        m.set_initial_guess()
+    for k in range(3):
+        xo, xd = ode.make_step(Y[k]).ravel(), dae.make_step(Y[k]).ravel()
+        assert ode.solver_stats["success"] and dae.solver_stats["success"]
+        assert relerr(xd, xo) < 1e-6, (k, relerr(xd, xo))
+        z = dae.data["_z"][-1]
+        tw = np.array([xd[0] - xd[6], xd[1] - xd[0], xd[2] - xd[1]])
+        assert np.max(np.abs(z - tw)) < 1e-8 and np.array_equal(dae._z0.master, z)
+    assert dae.data["_z"].shape == (3, 3)
 
 
 def check_discrete_mhe(make_mhe):

@@ -360,6 +360,12 @@ def test_mhe_scaling_of_states_inputs_and_estimated_parameters():
     pc.check_mhe_scaling_invariance(lambda **kw: ex.build_mhe_w(ex.build_model(process_noise=True), max_batch=1, **kw))
 
 
+def test_mhe_for_a_model_with_algebraic_states():
+    ex = CASES["rotating_masses"]
+    pc.check_mhe_dae_equals_ode(lambda dae: ex.build_mhe_w(ex.build_model(process_noise=True, dae=dae)))
+    pc.check_mhe_dae_make_step(lambda dae: ex.build_mhe(ex.build_model(dae=dae)))
+
+
 def test_discrete_time_mhe_against_the_oracle():
     from do_mpc_amd.examples import oscillating_masses as om
     pc.check_discrete_mhe(lambda: om.build_mhe(om.build_model(estimation=True)))

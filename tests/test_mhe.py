@@ -118,6 +118,20 @@ def test_mhe_scaling_of_states_inputs_and_estimated_parameters():
     pc.check_mhe_scaling_invariance(make)
 
 
+def test_mhe_for_a_model_with_algebraic_states():
+    def make(dae):
+        with hostemu.patched():
+            return ex.build_mhe_w(ex.build_model(process_noise=True, dae=dae))
+    pc.check_mhe_dae_equals_ode(make)
+
+
+def test_mhe_make_step_for_a_model_with_algebraic_states():
+    def make(dae):
+        with hostemu.patched():
+            return ex.build_mhe(ex.build_model(dae=dae))
+    pc.check_mhe_dae_make_step(make)
+
+
 def test_discrete_time_mhe_against_the_oracle():
     from do_mpc_amd.examples import oscillating_masses as om
 
