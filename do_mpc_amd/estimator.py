@@ -290,8 +290,6 @@ class MHE:
                                       "term (set_meas(..., meas_noise=True)): the measurement rows are solved for it")
         discrete = self._discrete = m.model_type == "discrete"
         nz = m.n_z
-        if discrete and nz:
-            raise NotImplementedError("structured HIP backend: MHE for discrete-time models with algebraic states")
         if discrete:
             # a discrete model has no stored points inside an interval: the NEXT state becomes an algebraic state of the interval,
             # z = f(x, u, w, p) as its algebraic equation and x+ = z as its dynamics - the measurement residual (and with it the stage
@@ -319,6 +317,13 @@ class MHE:
         for n in self._p_set.names:
             am._p.add(n, self._p_set.vars[n])
         if discrete:
+            # (the model's own algebraic states and equations first - the reference's rows of a discrete interval are [alg ; rhs - x+],
+            #  optimizer.py:820-824 - then the copy of the next state)
+            for n in m._z.names:
+                if m._z.vars[n].numel():
+                    am._z.add(n, m._z.vars[n])
+            for a in m.alg_list:
+                am.alg_list.append(dict(a))
             am._z.add("x_next", z_next)
             am.alg_list.append({"expr_name": "x_next", "expr": z_next - m._rhs})
             off = 0
@@ -364,7 +369,7 @@ class MHE:
         self._sx_aug = mpc._x_scaling.master.copy()                               # scaling of the augmented state (x, p_est)
         mpc._u_scaling.master[:nu] = self._u_scaling.master
         if nz:
-            mpc._z_scaling.master[:] = self._z_scaling.master
+            mpc._z_scaling.master[:nz] = self._z_scaling.master
         mpc.set_tvp_fun(lambda t: mpc.get_tvp_template())
         if am.n_p:
             mpc.set_p_fun(lambda t: mpc.get_p_template(1))
@@ -408,7 +413,7 @@ class MHE:
         if npe:
             self.opt_x_scaling["_p_est"] = self._p_est_scaling.master
         n_rows = ps.ne                                               # nl_cons rows of a stage (all evaluations)
-        self._rows_stage = M * (nx + nz) + nx + ny + n_rows       # (discrete: M = 0 - the rows x+ = f of the reference, then measurement / nl_cons rows)
+        self._rows_stage = M * nx + max(M, 1) * nz + nx + ny + n_rows       # (discrete: M = 0 - algebraic rows, the rows x+ = f of the reference, then measurement / nl_cons rows)
         self.n_opt_lagr = N * self._rows_stage
         self.lam_g_num = np.zeros(self.n_opt_lagr)
         if not discrete:
@@ -470,9 +475,12 @@ class MHE:
         XL[0, -1, nx:], XU[0, -1, nx:] = self._p_est_lb.master / self._p_est_scaling.master, self._p_est_ub.master / self._p_est_scaling.master
         UL, UU = lb[ps.off_u:ps.off_eps].reshape(N, NUA), ub[ps.off_u:ps.off_eps].reshape(N, NUA)
         UL[:, :nu], UU[:, :nu] = self._u_lb.master / self._u_scaling.master, self._u_ub.master / self._u_scaling.master
-        if self.model.n_z and not self._discrete:        # (_mhe.py:1006-1007 every `_z` slot, :1015-1016 the first slot of every interval)
+        if self.model.n_z:        # (_mhe.py:1006-1007 every `_z` slot, :1015-1016 the first slot of every interval)
             nz = self.model.n_z
-            ZL, ZU = lb[ps.off_z:ps.off_u].reshape(N, -1, nz), ub[ps.off_z:ps.off_u].reshape(N, -1, nz)
+            if self._discrete:    # (one slot per interval: the model's algebraic states, then the copy of the next state)
+                ZL, ZU = lb[ps.off_z:ps.off_u].reshape(N, 1, nz + nx)[:, :, :nz], ub[ps.off_z:ps.off_u].reshape(N, 1, nz + nx)[:, :, :nz]
+            else:
+                ZL, ZU = lb[ps.off_z:ps.off_u].reshape(N, -1, nz), ub[ps.off_z:ps.off_u].reshape(N, -1, nz)
             sl = slice(None) if s.cons_check_colloc_points else slice(0, 1)
             ZL[:, sl, :], ZU[:, sl, :] = self._z_lb.master / self._z_scaling.master, self._z_ub.master / self._z_scaling.master
         if mpc.n_eps:
@@ -496,8 +504,10 @@ class MHE:
             U[..., nu:] = ox[..., self._o_w:self._o_v].reshape(lead + (N, nw))
         out[..., ps.off_eps:] = ox[..., self._o_eps:self._o_p]
         if self._discrete:      # (the algebraic copy of the next state starts at the guess of that state)
-            Z = out[..., ps.off_z:ps.off_u].reshape(lead + (N, nx))
-            Z[...] = X[..., 1:, -1, :nx]
+            Z = out[..., ps.off_z:ps.off_u].reshape(lead + (N, m.n_z + nx))
+            Z[..., m.n_z:] = X[..., 1:, -1, :nx]
+            if m.n_z:
+                Z[..., :m.n_z] = ox[..., self._o_z:self._o_u].reshape(lead + (N, m.n_z))
         elif m.n_z:             # (same block in both layouts: N x M slots, _mhe.py:1056 / _mpc.py:1130 with one scenario)
             out[..., ps.off_z:ps.off_u] = ox[..., self._o_z:self._o_u]
         return out
@@ -505,8 +515,10 @@ class MHE:
     def _z_last(self, cx: np.ndarray, lead: tuple) -> np.ndarray:
         """(unscaled) algebraic states of the last point of every interval, shape lead + (N, n_z) - what the measurement function reads"""
         ps, m, N = self._ps, self.model, self.settings.n_horizon
-        if not m.n_z or self._discrete:
+        if not m.n_z:
             return np.zeros(lead + (N, 0))
+        if self._discrete:
+            return cx[..., ps.off_z:ps.off_u].reshape(lead + (N, m.n_z + m.n_x))[..., :m.n_z] * self._z_scaling.master
         Z = cx[..., ps.off_z:ps.off_u].reshape(lead + (N, max(ps.M, 1), m.n_z))
         return Z[..., -1, :] * self._z_scaling.master
 
@@ -535,6 +547,8 @@ class MHE:
         out[..., :self._o_z] = X[..., :nx].reshape(lead + (-1,))
         if m.n_z and not self._discrete:
             out[..., self._o_z:self._o_u] = cx[..., ps.off_z:ps.off_u]
+        elif m.n_z:
+            out[..., self._o_z:self._o_u] = cx[..., ps.off_z:ps.off_u].reshape(lead + (N, m.n_z + nx))[..., :m.n_z].reshape(lead + (-1,))
         U = cx[..., ps.off_u:ps.off_eps].reshape(lead + (N, ps.nu))
         out[..., self._o_u:self._o_w] = U[..., :nu].reshape(lead + (-1,))
         if nw:
@@ -559,8 +573,10 @@ class MHE:
         L = lam_chain[ps.nx:].reshape(N, -1)                         # (the chain problem keeps nx dummy initial rows)
         if self._discrete:
             # chain problem: rows z - f = 0 (multiplier la), then x+ - ... ; the reference's rows f - x+ = 0 carry -la
-            out[:, :nx] = -L[:, :nx]
-            n_dyn = nx + ps.nx
+            nz = m.n_z
+            out[:, :nz] = L[:, :nz]                                  # (the model's own algebraic rows: the same rows)
+            out[:, nz:nz + nx] = -L[:, nz:nz + nx]
+            n_dyn = nz + nx + ps.nx
         else:
             # rows of the interval function (optimizer.py:905-983: algebraic rows of point 0, per collocation point the collocation rows of
             # the states and the algebraic rows, the end-of-element rows), then the continuity rows: the rows of the riding parameters drop out

@@ -15,9 +15,11 @@ A_D = np.array([[0.763, 0.460, 0.115, 0.020],
 B_D = np.array([[0.014], [0.063], [0.221], [0.367]])
 
 
-def build_model(symvar_type="SX", estimation=False):
+def build_model(symvar_type="SX", estimation=False, dae=False):
     """estimation: the variant for the discrete-time estimator build_mhe (not in the reference's example): the two positions are
-    measured with noise, process noise on all four states"""
+    measured with noise, process noise on all four states.
+    dae (with estimation): the same plant with the free response `ax = A x` as algebraic states - an equivalent model for the
+    estimator's discrete-time DAE path"""
     mdl = Model("discrete", symvar_type)
     x = mdl.set_variable(var_type="_x", var_name="x", shape=(4, 1))
     u = mdl.set_variable(var_type="_u", var_name="u", shape=(1, 1))
@@ -25,7 +27,12 @@ def build_model(symvar_type="SX", estimation=False):
     if estimation:
         from ..sym import vertcat
         mdl.set_meas("pos_meas", vertcat(x[0], x[2]))
-    mdl.set_rhs("x", A_D @ x + B_D @ u, process_noise=estimation)
+    if dae:
+        ax = mdl.set_variable(var_type="_z", var_name="ax", shape=(4, 1))
+        mdl.set_alg("ax", ax - A_D @ x)
+        mdl.set_rhs("x", ax + B_D @ u, process_noise=estimation)
+    else:
+        mdl.set_rhs("x", A_D @ x + B_D @ u, process_noise=estimation)
     mdl.setup()
     return mdl
 

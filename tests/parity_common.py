@@ -567,3 +567,36 @@ def check_discrete_mhe(make_mhe):
     assert relerr(mhe.opt_x_num.master, r["x"]) < 1e-10
     assert np.max(np.abs(mhe.lam_g_num - r["lam_g"])) < 1e-10 * max(1.0, np.max(np.abs(r["lam_g"])))
     return mhe
+
+
+def check_discrete_mhe_dae_equals_ode(make_mhe):
+    """discrete-time estimator for a model with algebraic states (rows of an interval [alg ; f - x+], optimizer.py:820-824): the
+    oscillating masses with the free response `ax = A x` as algebraic states is the same estimation problem as the plain model -
+    states, inputs, noise and the multipliers of the rows `f - x+`, measurement and nl_cons rows agree (measured 1e-13), the
+    algebraic states satisfy their equation"""
+    from do_mpc_amd.examples import oscillating_masses as om
+    ode, dae = make_mhe(dae=False), make_mhe(dae=True)
+    N = 8
+    assert dae.n_opt_x == ode.n_opt_x + N * 4 and dae.n_opt_lagr == ode.n_opt_lagr + N * 4
+    rng = np.random.default_rng(3)
+    x, ys = np.array([0.5, -0.3, 0.2, 0.1]), []
+    for k in range(N):
+        x = om.A_D @ x + om.B_D.ravel() * 0.3 * np.sin(k) + 0.01 * rng.standard_normal(4)
+        ys.append([x[0] + 0.02 * rng.standard_normal(), x[2] + 0.02 * rng.standard_normal()])
+    P = np.concatenate([np.array([0.4, -0.2, 0.1, 0.0]), np.array(ys).ravel()])
+    out = []
+    for m in (ode, dae):
+        m.opt_p_num.master[:] = P
+        m.opt_x_num.master[:] = 0.0
+        m.solve()
+        assert m.solver_stats["success"]
+        out.append((m.opt_x_num.master.copy(), m.lam_g_num.copy()))
+    xo, xd = out[0][0], out[1][0]
+    assert relerr(xd[:dae._o_z], xo[:ode._o_z]) < 1e-9 and relerr(xd[dae._o_u:], xo[ode._o_u:]) < 1e-9
+    X = xd[:dae._o_z].reshape(N + 1, 4)
+    Z = xd[dae._o_z:dae._o_u].reshape(N, 4)
+    assert np.max(np.abs(Z - X[:N] @ om.A_D.T)) < 1e-10
+    lo, ld = out[0][1].reshape(N, ode._rows_stage), out[1][1].reshape(N, dae._rows_stage)
+    assert np.max(np.abs(ld[:, 4:] - lo)) < 1e-8 * max(1.0, np.max(np.abs(lo)))
+    return dae
+

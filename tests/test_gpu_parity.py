@@ -369,3 +369,4 @@ def test_mhe_for_a_model_with_algebraic_states():
 def test_discrete_time_mhe_against_the_oracle():
     from do_mpc_amd.examples import oscillating_masses as om
     pc.check_discrete_mhe(lambda: om.build_mhe(om.build_model(estimation=True)))
+    pc.check_discrete_mhe_dae_equals_ode(lambda dae: om.build_mhe(om.build_model(estimation=True, dae=dae)))

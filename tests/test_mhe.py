@@ -139,3 +139,13 @@ def test_discrete_time_mhe_against_the_oracle():
         with hostemu.patched():
             return om.build_mhe(om.build_model(estimation=True))
     pc.check_discrete_mhe(make)
+
+
+def test_discrete_time_mhe_for_a_model_with_algebraic_states():
+    from do_mpc_amd.examples import oscillating_masses as om
+
+    def make(dae):
+        with hostemu.patched():
+            return om.build_mhe(om.build_model(estimation=True, dae=dae))
+    pc.check_discrete_mhe_dae_equals_ode(make)
+
