@@ -218,6 +218,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   d4 qt_s, F, cvr;
   double fu, qv_s;
   staged_tiles(Ls, lane, qt_s, F, cvr, fu, qv_s);
+  DOMPC_PRIO_UP();
   R16_PN(12)
   // ---- own quadratic: per-variable terms in column layout (lane: z-entry j)
   double dg = 0.0, gv = 0.0;
@@ -413,6 +414,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   // node (LDS-DMA copy, register prefetch): on gfx9 stores count in vmcnt like loads, so a wait for data issued after
   // a store also waits for the store's ~2 us round trip - waiting first and storing afterwards keeps the stores of
   // this node in flight during the whole update of the next one.
+  DOMPC_PRIO_DOWN();
   staged_ready();
   double* Nd = Q.ND(n);
   if (g == 0 && j < NA)
