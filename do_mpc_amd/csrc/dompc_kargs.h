@@ -75,6 +75,11 @@ struct KArgs {
   // debugging aid: value the LDS pool is filled with when the kernel starts (0 in production), words [lo, hi)
   double lds_fill;
   int32_t lds_fill_lo, lds_fill_hi;
+  // bounds of opt_x as the solver uses them (relaxed; unused variables taken out): ONE copy for all problems of a launch - lbx / ubx
+  // are inputs of the launch, not of a problem - instead of one per slot: the passes that read them (sweep, step rules, accept,
+  // error measures) then hit the L2 instead of streaming 2 x n_opt_x doubles per slot from HBM.  Every problem writes the same
+  // values at its start; null = per-slot copies (DOMPC_SHARED_BOUNDS=0)
+  double *lb_sh, *ub_sh;
 };
 
 

@@ -570,6 +570,7 @@ struct Prob {
   const KArgs* A;
   const double* P;                                   // opt_p of this problem
   double *x, *zl, *zu, *lb, *ub, *dx, *gf, *rd, *xt, *dx_sv;
+  double *lb_own, *ub_own;                           // this slot's copies of the bounds (lb / ub: the ones the phases read, prob_bounds)
   double *lam, *dlam, *c, *ct, *dlam_sv;
   double *s, *zsl, *zsu, *sl, *su, *ds, *st, *ds_sv;
   double *ew, *es, *nd, *mo;
@@ -595,7 +596,8 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   double* w = A.ws + (int64_t)slot * A.ws_stride;
   Prob p;
   p.A = &A; p.P = P;
-  p.x = w + L.x; p.zl = w + L.zl; p.zu = w + L.zu; p.lb = w + L.lb; p.ub = w + L.ub; p.dx = w + L.dx;
+  p.x = w + L.x; p.zl = w + L.zl; p.zu = w + L.zu; p.lb_own = w + L.lb; p.ub_own = w + L.ub; p.dx = w + L.dx;
+  p.lb = A.lb_sh ? A.lb_sh : p.lb_own; p.ub = A.ub_sh ? A.ub_sh : p.ub_own;
   p.gf = w + L.gf; p.rd = w + L.rd; p.xt = w + L.xt; p.dx_sv = w + L.dx_sv;
   p.lam = w + L.lam; p.dlam = w + L.dlam; p.c = w + L.c; p.ct = w + L.ct; p.dlam_sv = w + L.dlam_sv;
   p.s = w + L.s; p.zsl = w + L.zsl; p.zsu = w + L.zsu; p.sl = w + L.sl; p.su = w + L.su;
@@ -603,6 +605,15 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo;
   p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0; p.dsw = 0.0; p.slot = slot;
   return p;
+}
+// Bounds the phases read: ONE copy for all problems of the launch (KArgs::lb_sh / ub_sh) - except while the least-squares multiplier
+// estimate of a problem runs (Prob::soc bit 1): its sweep works on bounds one unit away from the problem's own starting point, kept
+// in the slot's copies.
+DOMPC_DEV inline void prob_bounds(Prob& Q) {
+  const KArgs& A = *Q.A;
+  const bool own = (Q.soc & 2) != 0 || !A.lb_sh;
+  Q.lb = own ? Q.lb_own : A.lb_sh;
+  Q.ub = own ? Q.ub_own : A.ub_sh;
 }
 
 // slot of collocation point r of finite element i inside the edge's w block (optimizer.py:905-935)
@@ -1684,6 +1695,7 @@ __device__ inline KArgs kernel_args(const void* kp);
   Prob Q = make_prob(A, __builtin_amdgcn_readfirstlane(slot), nullptr);                                          \
   Q.sf = ufl(sf);                                                                                                \
   Q.soc = __builtin_amdgcn_readfirstlane(soc);                                                                   \
+  prob_bounds(Q);                                                                                                \
   const int lane = (int)(threadIdx.x & 63u);                                                                     \
   ldsd* Ld = (ldsd*)lds_pool + (int64_t)(threadIdx.x >> 6) * EL_SIZE;                                            \
   const double vx[EF_CPX][5] = {{v0, v1, v2, v3, v4}};                                                           \
@@ -4216,6 +4228,7 @@ struct PhaseRet3 { unsigned gen, nred, xseq; double v0, v1, v2; };
 __device__ __attribute__((noinline)) PhaseRet phase_sweep(const void* kp, int b, int slot, double sf, double mu, double dsw, int soc, unsigned gen, unsigned nred, unsigned xseq) {
   DOMPC_PHASE_PROLOGUE
   Q.soc = ufl(soc);
+  prob_bounds(Q);
   Q.dsw = ufl(dsw);
   const int rc = sweep(T, Q, ufl(mu));
   return PhaseRet{T.gen, T.nred, T.xseq, rc};
@@ -4224,6 +4237,7 @@ __device__ __attribute__((noinline)) PhaseRet phase_backward(const void* kp, int
   DOMPC_PHASE_PROLOGUE
   Q.dsw = ufl(dsw);
   Q.soc = ufl(mode);
+  prob_bounds(Q);
   const int rc = riccati_backward(T, Q, ufl(mu), ufl(delta));
   return PhaseRet{T.gen, T.nred, T.xseq, rc};
 }
@@ -4264,8 +4278,10 @@ DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu
 #else
   (void)b; (void)slot;
   Q.soc = soc;
+  prob_bounds(Q);
   const int rc = sweep(T, Q, mu);
   Q.soc = 0;
+  prob_bounds(Q);
   return rc;
 #endif
 }
@@ -4278,6 +4294,7 @@ DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, 
   (void)b; (void)slot;
   Prob Qm = Q;
   Qm.soc = mode;
+  prob_bounds(Qm);
   return riccati_backward(T, Qm, mu, delta);
 #endif
 }
@@ -4355,7 +4372,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (hl && hu) { pl = fmin(pl, O.bound_frac * (u - l)); pu = fmin(pu, O.bound_frac * (u - l)); }
     if (hl) xv = fmax(xv, l + pl);
     if (hu) xv = fmin(xv, u - pu);
-    Q.lb[g] = l; Q.ub[g] = u; Q.x[g] = xv;
+    Q.lb_own[g] = l; Q.ub_own[g] = u; Q.x[g] = xv;
     Q.zl[g] = hl ? 1.0 : 0.0; Q.zu[g] = hu ? 1.0 : 0.0;
     if (sh_cnt(A, mk_x(A, g))) cnt[0] += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
   }
@@ -4371,11 +4388,16 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
     const int g = A.dummy_idx[d];
     if (singular0) continue;
-    if (sh_cnt(A, mk_x(A, g))) cnt[0] -= (Q.lb[g] > -INFINITY ? 1.0 : 0.0) + (Q.ub[g] < INFINITY ? 1.0 : 0.0);
+    if (sh_cnt(A, mk_x(A, g))) cnt[0] -= (Q.lb_own[g] > -INFINITY ? 1.0 : 0.0) + (Q.ub_own[g] < INFINITY ? 1.0 : 0.0);
     Q.x[g] = fmin(fmax(x0[g], A.lbx[g]), A.ubx[g]);           // the caller's value, projected onto its box
-    Q.lb[g] = -INFINITY; Q.ub[g] = INFINITY; Q.zl[g] = 0.0; Q.zu[g] = 0.0;
+    Q.lb_own[g] = -INFINITY; Q.ub_own[g] = INFINITY; Q.zl[g] = 0.0; Q.zu[g] = 0.0;
   }
   T.sync();
+  if (A.lb_sh) {
+    // the shared copy: final values only (every problem of the launch writes the same bits; another problem may be reading them)
+    for (int g = T.tid; g < nX; g += T.nt) { A.lb_sh[g] = Q.lb_own[g]; A.ub_sh[g] = Q.ub_own[g]; }
+    T.sync();
+  }
   // slacks of the nl_cons rows: s = d(x) pushed into [lbg,ubg]
   if (NE > 0) {
     for (int e = T.tid; e < A.n_edges; e += T.nt) {
@@ -4427,8 +4449,8 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   const bool ls_init = NE == 0 && O.constr_mult_init_max > 0.0;
   if (ls_init) {
     for (int g = T.tid; g < nX; g += T.nt) {
-      if (Q.lb[g] > -INFINITY) Q.lb[g] = Q.x[g] - 1.0;
-      if (Q.ub[g] < INFINITY) Q.ub[g] = Q.x[g] + 1.0;
+      if (Q.lb_own[g] > -INFINITY) Q.lb_own[g] = Q.x[g] - 1.0;
+      if (Q.ub_own[g] < INFINITY) Q.ub_own[g] = Q.x[g] + 1.0;
       Q.zl[g] = 0.0; Q.zu[g] = 0.0;
     }
     for (int r = T.tid; r < A.n_g; r += T.nt) Q.c[r] = 0.0;
@@ -4468,9 +4490,9 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     for (int r = T.tid; r < A.n_g; r += T.nt) Q.lam[r] = keep ? Q.dlam[r] : 0.0;
     for (int g = T.tid; g < nX; g += T.nt) {             // bounds and bound multipliers back to their starting values
       double l = A.lbx[g], u = A.ubx[g];
-      const bool hl = Q.lb[g] > -INFINITY, hu = Q.ub[g] < INFINITY;   // (unused variables that were taken out stay out)
-      if (hl) Q.lb[g] = l - fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(l)));
-      if (hu) Q.ub[g] = u + fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(u)));
+      const bool hl = Q.lb_own[g] > -INFINITY, hu = Q.ub_own[g] < INFINITY;   // (unused variables that were taken out stay out)
+      if (hl) Q.lb_own[g] = l - fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(l)));
+      if (hu) Q.ub_own[g] = u + fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(u)));
       Q.zl[g] = hl ? 1.0 : 0.0; Q.zu[g] = hu ? 1.0 : 0.0;
     }
     T.sync();

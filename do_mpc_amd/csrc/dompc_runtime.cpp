@@ -464,6 +464,14 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   }
 #endif
   if (dev_alloc(h, (void**)&A.work_counter, 64)) return fail(1);
+  A.lb_sh = A.ub_sh = nullptr;
+  {
+    const char* sb = getenv("DOMPC_SHARED_BOUNDS");      // (measurement aid: 0 = per-slot copies of the bounds)
+    if (!sb || atoi(sb) != 0) {
+      if (dev_alloc(h, (void**)&A.lb_sh, sizeof(double) * (size_t)d.n_opt_x)) return fail(1);
+      if (dev_alloc(h, (void**)&A.ub_sh, sizeof(double) * (size_t)d.n_opt_x)) return fail(1);
+    }
+  }
   // wide mode (small batches): up to 64 slots x 32 workgroups
   if (dev_alloc(h, (void**)&A.wide_bar, sizeof(uint32_t) * 16 * 64)) return fail(1);
   if (dev_alloc(h, (void**)&A.wide_flags, sizeof(int32_t) * 8 * 64)) return fail(1);
