@@ -33,6 +33,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
+# TEST-ONLY switch (tests/test_distributed.py): DOMPC_BENCH_BACKEND=hostemu runs the same script on the g++ host emulation of
+# the kernels (tests/hostemu.py) with gloo instead of RCCL, so that the N-rank launch path, the batch partition and the one
+# JSON line can be checked in the GPU-less CI container.  Such a line says so in `data`; it is not a measurement.
+BACKEND = os.environ.get("DOMPC_BENCH_BACKEND", "hip")
+
 
 def synthetic_x0_batch(B: int, seed: int = 99) -> np.ndarray:
     """x0_i around the example's initial state (seed 99): masses x (1 + 2% U(-1,1)),
@@ -126,7 +131,9 @@ def live_traffic(args, B: int):
     """HBM bytes of ONE launch of dompc_solve_kernel at this batch size, measured NOW: two extra passes of this script (one
     step each) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, MI355X_MICROARCH.md
     section HBM; counter unit KB; FETCH_SIZE counts half of the bytes of coalesced reads on gfx950 - calibrated on this
-    project's 8 B/lane pattern in profiles/pmc_calibration.json: x2.0 / x1.0).  Returns (bytes or None, note)."""
+    project's 8 B/lane pattern in profiles/pmc_calibration.json: x2.0 / x1.0).  The child runs one solve launch and then one
+    sweep-only launch (dompc_sweep_batch_device, same kernel symbol, mode 2): the dispatch rows are told apart by their order.
+    Returns (bytes of the solve launch or None, bytes of the sweep-only launch or None, note)."""
     import csv
     import glob
     import shutil
@@ -134,33 +141,37 @@ def live_traffic(args, B: int):
     import tempfile
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rp):
-        return None, "rocprofv3 not found"
+        return None, None, "rocprofv3 not found"
     tot = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="dompc_pmc_", dir="/tmp")
         cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--batch", str(B), "--variant", args.variant,
-               "--no-cpu-baseline", "--no-traffic", "--no-b1"]
+               "--no-cpu-baseline", "--no-traffic", "--no-b1", "--no-variant-b", "--sweep-steps", "1", "--sweep-warmup", "0"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                                timeout=float(os.environ.get("DOMPC_PMC_TIMEOUT", "300")))
         except Exception as e:      # noqa: BLE001
             shutil.rmtree(d, ignore_errors=True)
-            return None, f"{counter} pass failed: {type(e).__name__}"
-        val, rows = 0.0, 0
+            return None, None, f"{counter} pass failed: {type(e).__name__}"
+        per = {}                  # dispatch id -> counter value (the child launches the solve first, then the sweep-only launch)
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 if "dompc_solve" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-                    val += float(row["Counter_Value"])
-                    rows += 1
+                    k = int(float(row.get("Dispatch_Id", 0) or 0))
+                    per[k] = per.get(k, 0.0) + float(row["Counter_Value"])
         shutil.rmtree(d, ignore_errors=True)
-        if rows == 0:
-            return None, f"{counter} pass produced no rows (rc {r.returncode}): {r.stdout[-200:]}"
-        tot[counter] = val
-    byt = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
-    return byt, (f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one launch each at this batch size "
-                 f"(FETCH_SIZE {tot['FETCH_SIZE']:.6g} KB x2.0, WRITE_SIZE {tot['WRITE_SIZE']:.6g} KB x1.0)")
+        if not per:
+            return None, None, f"{counter} pass produced no rows (rc {r.returncode}): {r.stdout[-200:]}"
+        vals = [per[k] for k in sorted(per)]
+        tot[counter] = (vals[0], vals[1] if len(vals) > 1 else None)
+    byt = (2.0 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]) * 1024.0
+    sw = None
+    if tot["FETCH_SIZE"][1] is not None and tot["WRITE_SIZE"][1] is not None:
+        sw = (2.0 * tot["FETCH_SIZE"][1] + tot["WRITE_SIZE"][1]) * 1024.0
+    return byt, sw, (f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one launch each at this batch size "
+                     f"(FETCH_SIZE {tot['FETCH_SIZE'][0]:.6g} KB x2.0, WRITE_SIZE {tot['WRITE_SIZE'][0]:.6g} KB x1.0)")
 
 
 def make_step_b1(mpc, ex, n_warm: int = 4) -> dict:
@@ -196,9 +207,11 @@ def make_step_b1(mpc, ex, n_warm: int = 4) -> dict:
                     "barriers between the workgroups of the problem)"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node.  Under torchrun (WORLD_SIZE in the environment) the launcher decides; "
+                         "started plainly with N > 1 the script launches N ranks of itself, one per GPU")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("DOMPC_BENCH_BATCH", "16384")),
@@ -214,22 +227,93 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--no-b1", action="store_true", help="skip the single-problem make_step latency")
+    ap.add_argument("--no-variant-b", action="store_true", help="skip the extra `variant_b` key (SURVEY App. D's second reading of configs[3])")
+    ap.add_argument("--sweep-steps", type=int, default=3, help="launches of the sweep-only kernel for roofline.sweep_only (0: skip)")
+    ap.add_argument("--sweep-warmup", type=int, default=1)
     ap.add_argument("--max-soc", type=int, default=None,
                     help="measurement aid: ipopt.max_soc (default: IPOPT's 4; 0 switches the second-order correction off)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def visible_devices() -> int:
+    if BACKEND == "hostemu":
+        return 1 << 30
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one process per GPU (RANK = LOCAL_RANK =
+    device index, rendezvous on 127.0.0.1), the way the reference fans make_step out over processes
+    (examples/tools/sampling/multiprocessing/closed_loop/mp_sampling_closed_loop_02.py:32-70).  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = visible_devices()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n} needs {n} devices on this node, {have} visible: one rank per GPU, nothing is "
+                         f"time-shared (run it with --gpus {max(have, 1)} or under torchrun on a node that has them)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc, alive = 0, list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in alive:             # a rank died: the others would wait at the next barrier forever
+                    q.terminate()
+    return rc
+
+
+class _HostTimer:
+    """stand-in for a pair of HIP events on the host emulation (test plumbing)"""
+    def __init__(self):
+        self.t = 0.0
+
+    def record(self, _stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the dompc IPM backend has no CPU path")
-    torch.cuda.set_device(local_rank)
+    hip = BACKEND != "hostemu"
+    if hip:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the dompc IPM backend has no CPU path")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, this node has {torch.cuda.device_count()}")
+        torch.cuda.set_device(local_rank)
+    elif args.variant not in ("A", "B"):
+        raise SystemExit("the host-emulation backend (tests) covers variants A and B only")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl" if hip else "gloo", rank=rank, world_size=world)
 
     from do_mpc_amd.examples import industrial_poly as ex
     from do_mpc_amd.solver import STATS_DTYPE
@@ -237,86 +321,144 @@ def main():
         return bench_tree(args, ex, rank, world, local_rank, dist)
     if args.variant == "closed_loop":
         return bench_closed_loop(args, ex, rank, world, local_rank, dist)
-    kw = {} if args.variant == "A" else {"n_robust": 2, "uncertainty": "paired"}
-    if args.max_soc is not None:
-        kw["nlpsol_opts"] = {"ipopt.max_soc": args.max_soc}
+    dev = torch.device("cuda", local_rank) if hip else torch.device("cpu")
+    sync = torch.cuda.synchronize if hip else (lambda: None)
+    stream = torch.cuda.current_stream() if hip else None
+    stream_ptr = stream.cuda_stream if hip else 0
+
+    def build(variant, B):
+        kw = {} if variant == "A" else {"n_robust": 2, "uncertainty": "paired"}
+        if args.max_soc is not None:
+            kw["nlpsol_opts"] = {"ipopt.max_soc": args.max_soc}
+        if hip:
+            return ex.build_mpc(ex.build_model(), gpu_index=local_rank, max_batch=B, **kw)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hostemu                                       # TEST-ONLY (see BACKEND above)
+        with hostemu.patched():
+            return ex.build_mpc(ex.build_model(), max_batch=B, **kw)
+
+    def resident_inputs(mpc, B):
+        """synthetic inputs of this rank's shard, resident in device memory before any timed region"""
+        ps = mpc.structure
+        lo, hi = shard(B * world, rank, world)
+        X0 = synthetic_x0_batch(B * world)[lo:hi]
+        P = np.tile(mpc.opt_p_num.master, (B, 1))
+        P[:, :ps.nx] = X0
+        P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(0.0).master
+        Xi = np.zeros((B, ps.n_opt_x))
+        Xi[:, :ps.off_z].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
+        t = {"X0": torch.from_numpy(Xi).to(dev), "P": torch.from_numpy(P).to(dev),
+             "lbx": torch.from_numpy(mpc._lb_opt_x.master).to(dev), "ubx": torch.from_numpy(mpc._ub_opt_x.master).to(dev),
+             "lbg": torch.from_numpy(mpc._nlp_cons_lb).to(dev), "ubg": torch.from_numpy(mpc._nlp_cons_ub).to(dev),
+             "X": torch.empty((B, ps.n_opt_x), dtype=torch.float64, device=dev),
+             "LG": torch.empty((B, ps.n_g), dtype=torch.float64, device=dev),
+             "F": torch.empty(B, dtype=torch.float64, device=dev),
+             "Stats": torch.zeros(B * STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev), "lo": lo, "hi": hi}
+        return t
+
+    def timed_steps(mpc, t, B, warmup, steps):
+        """`warmup` untimed launches, then `steps` launches between barrier + synchronize on both sides; max over the ranks"""
+        S = mpc.S
+
+        def step():
+            S.solve_batch_device(B, t["X0"].data_ptr(), t["lbx"].data_ptr(), t["ubx"].data_ptr(), t["lbg"].data_ptr(),
+                                 t["ubg"].data_ptr(), t["P"].data_ptr(), t["X"].data_ptr(), 0, 0, t["LG"].data_ptr(),
+                                 t["F"].data_ptr(), t["Stats"].data_ptr(), stream=stream_ptr)
+
+        for _ in range(warmup):
+            step()
+        sync()
+        if dist is not None:
+            dist.barrier()
+        mk = (lambda: torch.cuda.Event(enable_timing=True)) if hip else _HostTimer
+        ev = [(mk(), mk()) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record(stream)
+            step()
+            ev[k][1].record(stream)
+        sync()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        stats = np.frombuffer(t["Stats"].cpu().numpy().tobytes(), dtype=STATS_DTYPE)
+        return dt, kern_ms, stats
+
     B = args.batch
-    mpc = ex.build_mpc(ex.build_model(), gpu_index=local_rank, max_batch=B, **kw)
+    mpc = build(args.variant, B)
     ps = mpc.structure
     S = mpc.S
-
-    # ---- synthetic inputs, resident in HBM before the timed region
-    lo, hi = shard(B * world, rank, world)
-    X0 = synthetic_x0_batch(B * world)[lo:hi]
-    P = np.tile(mpc.opt_p_num.master, (B, 1))
-    P[:, :ps.nx] = X0
-    P[:, ps.p_off_p:ps.p_off_uprev] = mpc.p_fun(0.0).master
-    Xi = np.zeros((B, ps.n_opt_x))
-    Xi[:, :ps.off_z].reshape(B, -1, ps.nx)[:] = (X0 / mpc._x_scaling.master)[:, None, :]
-    dev = torch.device("cuda", local_rank)
-    tX0 = torch.from_numpy(Xi).to(dev)
-    tP = torch.from_numpy(P).to(dev)
-    tlbx = torch.from_numpy(mpc._lb_opt_x.master).to(dev)
-    tubx = torch.from_numpy(mpc._ub_opt_x.master).to(dev)
-    tlbg = torch.from_numpy(mpc._nlp_cons_lb).to(dev)
-    tubg = torch.from_numpy(mpc._nlp_cons_ub).to(dev)
-    tX = torch.empty((B, ps.n_opt_x), dtype=torch.float64, device=dev)
-    tLG = torch.empty((B, ps.n_g), dtype=torch.float64, device=dev)
-    tF = torch.empty(B, dtype=torch.float64, device=dev)
-    tStats = torch.zeros(B * STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream()
-
-    def step():
-        S.solve_batch_device(B, tX0.data_ptr(), tlbx.data_ptr(), tubx.data_ptr(), tlbg.data_ptr(), tubg.data_ptr(),
-                             tP.data_ptr(), tX.data_ptr(), 0, 0, tLG.data_ptr(), tF.data_ptr(), tStats.data_ptr(),
-                             stream=stream.cuda_stream)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    t = resident_inputs(mpc, B)
+    dt, kern_ms, stats = timed_steps(mpc, t, B, args.warmup, args.steps)
+    u0 = (t["X"][:, ps.iu(0, 0):ps.iu(0, 0) + ps.nu].cpu().numpy() * mpc._u_scaling.master)
+    n_ok_all = int(stats["success"].sum())
     if dist is not None:
-        dist.barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record(stream)
-        step()
-        ev[k][1].record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    stats = np.frombuffer(tStats.cpu().numpy().tobytes(), dtype=STATS_DTYPE)
-    u0 = (tX[:, ps.iu(0, 0):ps.iu(0, 0) + ps.nu].cpu().numpy() * mpc._u_scaling.master)
+        tt = torch.tensor([float(n_ok_all), float(t["hi"] - t["lo"])], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        n_ok_all, n_all = int(tt[0].item()), int(tt[1].item())
+    else:
+        n_all = B
 
     if rank == 0:
         n_ok = int(stats["success"].sum())
         sweep_b = sweep_bytes_per_problem(ps)
         alg_bytes = float(stats["n_sweeps"].astype(np.float64).sum()) * sweep_b
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        # ---- the roofline north_star names literally: the Jacobian (model-evaluation) sweep ALONE.  One launch of
+        # dompc_sweep_batch_device (same kernel symbol, mode 2) evaluates g, the per-edge Jacobian / Hessian blocks and their
+        # condensed form at B iterates - here the B solutions of the timed batch with their multipliers; residuals out only.
+        sweep_only = None
+        if args.sweep_steps > 0:
+            tG = torch.empty((B, ps.n_g), dtype=torch.float64, device=dev)
+            mk = (lambda: torch.cuda.Event(enable_timing=True)) if hip else _HostTimer
+
+            def sweep_launch():
+                S.sweep_batch_device(B, t["X"].data_ptr(), t["LG"].data_ptr(), t["P"].data_ptr(), tG.data_ptr(), 0, stream=stream_ptr)
+
+            for _ in range(args.sweep_warmup):
+                sweep_launch()
+            sync()
+            evs = [(mk(), mk()) for _ in range(args.sweep_steps)]
+            for a, b_ in evs:
+                a.record(stream)
+                sweep_launch()
+                b_.record(stream)
+            sync()
+            sw_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in evs]))
+            sw_ach = B * sweep_b / (sw_ms * 1e-3) / 1e9
+            sweep_only = {"achieved": sw_ach, "frac": sw_ach / HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                          "kernel_ms": sw_ms, "algorithmic_bytes_per_launch": float(B * sweep_b),
+                          "what": "dompc_sweep_batch_device: one model-evaluation sweep (g, per-edge Jacobian and Lagrangian-Hessian "
+                                  "blocks, condensing records) of each of the B solutions, residuals copied out; dompc_solve_kernel mode 2"}
         traffic, traffic_note = None, "not measured (--no-traffic or N > 1)"
-        if not args.no_traffic and world == 1:
-            traffic, traffic_note = live_traffic(args, B)
+        if not args.no_traffic and world == 1 and hip:
+            traffic, sw_traffic, traffic_note = live_traffic(args, B)
+            if sweep_only is not None and sw_traffic:
+                sweep_only["traffic"] = sw_traffic
+                sweep_only["traffic_over_algorithmic"] = sw_traffic / (B * sweep_b)
         out = {
             "metric": "MPC steps/sec (make_step wall-time), industrial_poly robust multi-stage",
-            "value": B * world * args.steps / dt, "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps,
+            "value": n_all * args.steps / dt, "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if hip else "synthetic; HOST EMULATION of the kernels (test plumbing, not a measurement)",
             "config": {"workload": f"industrial_poly robust multi-stage NMPC, variant {args.variant} "
                                    f"({'9 combos x n_robust=1' if args.variant == 'A' else '3 combos x n_robust=2'}, "
                                    f"9 scenarios, N=20, Radau deg 2)",
                        "batch_per_gpu": B, "n_opt_x": ps.n_opt_x, "n_g": ps.n_g, "edges": ps.n_edges,
                        "start": "cold (set_initial_guess semantics)", "parallelism": f"x0-batch shards x{world}",
+                       "shard_of_rank0": [int(t["lo"]), int(t["hi"])], "global_batch": n_all,
                        "problem_slots": S.num_slots,
                        "x0_batch": "seed 99: masses x(1 + 2 % U(-1,1)), temperatures +- 1 K U(-1,1), T_adiab recomputed "
                                    "(SURVEY 8(d) asks for 2 % relative on every state: on Kelvin temperatures that leaves the "
                                    "+-2 K reactor band and makes the robust problem infeasible, also for IPOPT)"},
-            "solve": {"converged": n_ok, "of": B, "iters_mean": float(stats["iter_count"].mean()),
+            "solve": {"converged": n_ok, "of": B, "converged_all_ranks": n_ok_all, "of_all_ranks": n_all,
+                      "iters_mean": float(stats["iter_count"].mean()),
                       "iters_max": int(stats["iter_count"].max()),
                       "sweeps_per_solve": float(stats["n_sweeps"].mean()), "trials_per_solve": float(stats["n_trials"].mean()),
                       "u0_first": [float(v) for v in u0[0]]},
@@ -325,9 +467,22 @@ def main():
                          "traffic_over_algorithmic": (traffic / alg_bytes if traffic else None),
                          "kernel": "dompc_solve_kernel",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "sweep_bytes_per_problem": sweep_b},
+                         "sweep_bytes_per_problem": sweep_b, "sweep_only": sweep_only},
         }
-        if not args.no_b1 and world == 1:
+        if not args.no_variant_b and world == 1 and args.variant == "A":
+            # SURVEY App. D's second reading of BASELINE configs[3] (3 combinations, n_robust = 2: the docs' figure), same batch
+            try:
+                mpc_b = build("B", B)
+                tb = resident_inputs(mpc_b, B)
+                dtb, kb_ms, sb = timed_steps(mpc_b, tb, B, 1, 2)
+                out["variant_b"] = {"value": B * 2 / dtb, "unit": "MPC steps/s", "ms_per_step": dtb / 2 * 1e3, "steps": 2, "warmup": 1,
+                                    "kernel_ms": kb_ms, "converged": int(sb["success"].sum()), "of": B,
+                                    "iters_mean": float(sb["iter_count"].mean()), "edges": mpc_b.structure.n_edges, "n_g": mpc_b.structure.n_g,
+                                    "workload": "industrial_poly robust multi-stage NMPC, variant B (3 combos x n_robust=2, 9 scenarios, N=20, Radau deg 2)"}
+                del mpc_b, tb
+            except Exception as e:      # noqa: BLE001
+                out["variant_b"] = {"error": repr(e)}
+        if not args.no_b1 and world == 1 and hip:
             try:
                 out["make_step_ms_b1"] = make_step_b1(mpc, ex)
             except Exception as e:      # noqa: BLE001
@@ -338,7 +493,9 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 def bench_closed_loop(args, ex, rank, world, local_rank, dist):
@@ -458,4 +615,4 @@ def bench_tree(args, ex, rank, world, local_rank, dist):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

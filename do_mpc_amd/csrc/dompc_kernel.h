@@ -4828,9 +4828,11 @@ DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A, int b = 0, int 
     T.sync();
   }
   Q.sf = 1.0;
-  run_sweep(T, Q, 0, 0, A.dbg_mu, 0, A.dbg_delta);
-  const int fail = run_backward(T, Q, 0, 0, A.dbg_mu, A.dbg_delta);
-  run_forward(T, Q, 0, 0, A.dbg_mu, A.dbg_delta);
+  // (b, slot: the outlined phases rebuild their view of the problem from exactly these two - ADVICE r3: with the literal
+  //  (0, 0) every workgroup of a batched call swept and factorised slot 0 with parameter row 0)
+  run_sweep(T, Q, b, slot, A.dbg_mu, 0, A.dbg_delta);
+  const int fail = run_backward(T, Q, b, slot, A.dbg_mu, A.dbg_delta);
+  run_forward(T, Q, b, slot, A.dbg_mu, A.dbg_delta);
   for (int g = T.tid; g < nX; g += T.nt) {
     A.dbg_dx[(int64_t)b * nX + g] = fail ? NAN : Q.dx[g];
     A.dbg_rd[(int64_t)b * nX + g] = Q.rd[g];
@@ -4865,7 +4867,7 @@ DOMPC_DEV inline void sweep_problem(const Thr& T, const KArgs& A, int b, int slo
   double* gout = A.sw_g + (int64_t)b * A.n_g;
   for (int r = T.tid; r < A.n_g; r += T.nt) gout[r] = Q.c[r];
   double* bl = A.sw_blocks + (int64_t)b * A.n_edges * SWEEP_BLOCK;
-  for (int it = T.tid; it < A.n_edges * SWEEP_BLOCK; it += T.nt) {
+  for (int it = T.tid; A.sw_blocks && it < A.n_edges * SWEEP_BLOCK; it += T.nt) {
     const int e = it / SWEEP_BLOCK, i = it % SWEEP_BLOCK;
     const double* S_ = Q.ES(e);
     double v;

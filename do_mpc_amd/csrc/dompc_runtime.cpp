@@ -755,7 +755,7 @@ extern "C" int dompc_sweep_batch_device(dompc_handle* h, int32_t B, const double
                                         double* g, double* blocks, void* stream) {
   if (!h) return 1;
   if (B <= 0) return 0;
-  if (!x || !lam || !p || !g || !blocks) { h->error = "null pointer"; return 1; }
+  if (!x || !lam || !p || !g) { h->error = "null pointer"; return 1; }      // (blocks may be null: residuals only - the timing of the sweep itself, bench.py)
 #ifndef DOMPC_HOST_EMU
   HIPCHK(h, hipSetDevice(h->d.device));
 #endif

@@ -98,3 +98,42 @@ def check_against_resolves(make_mpc, name, p_keys, rtol=2e-3, **over):
         fd = (us[0] - us[1]) / (2 * h)
         scale = max(np.max(np.abs(fd)), 1e-8)
         assert np.max(np.abs(fd - du0)) < rtol * scale + 1e-7, (key, fd, du0)
+
+
+def check_batched_directions_equal_single_rows(make_mpc, name, max_batch=8, **over):
+    """`dompc_newton_steps_at_solution` with SEVERAL workspace slots (max_batch > 1: one workgroup and one slot per parameter
+    vector) against the single-row entry point `dompc_newton_step_at_solution`, row by row (the batched call used to
+    factorise slot 0 with parameter row 0 in every workgroup; with max_batch = 1 the batch degenerates to a loop and hides it)."""
+    mpc = solved(make_mpc, name, max_batch=max_batch, **over)
+    assert mpc.S.num_slots > 1 or mpc.S._host_emulation      # (the host emulation runs the rows one after the other in one slot)
+    nd = DoMPCDifferentiator(mpc)
+    x, lam, zl, zu, lb, ub, mu = nd._point()
+    lbg, ubg = mpc._nlp_cons_lb, mpc._nlp_cons_ub
+    p0 = mpc.opt_p_num.master.copy()
+    lay = mpc._opt_p_layout
+    cols = np.concatenate([lay.resolve(("_x0",)).ravel(), lay.resolve(("_u_prev",)).ravel()])
+    rows = [p0.copy()]
+    for j in cols:
+        p = p0.copy()
+        p[j] += max(1.0, abs(p0[j]))
+        rows.append(p)
+    rows = np.array(rows)
+    assert len(rows) > 2
+    DX, DL = mpc.S.newton_steps_at_solution(x, lam, zl, zu, lb, ub, lbg, ubg, rows, mu)
+    differ = 0.0
+    for i, p in enumerate(rows):
+        dx, dl = mpc.S.newton_step_at_solution(x, lam, zl, zu, lb, ub, lbg, ubg, p, mu)
+        sc = max(1.0, np.max(np.abs(dx)))
+        assert np.max(np.abs(DX[i] - dx)) <= 1e-12 * sc, (i, np.max(np.abs(DX[i] - dx)))
+        assert np.max(np.abs(DL[i] - dl)) <= 1e-12 * max(1.0, np.max(np.abs(dl))), i
+        if i:
+            differ = max(differ, np.max(np.abs(DX[i] - DX[0])))
+    assert differ > 1e-6            # (the rows are not all the direction of parameter row 0)
+    # ... and the sensitivities of the batched differentiator equal those of a controller with a single slot
+    dxdp, _ = nd.differentiate()
+    mpc1 = solved(make_mpc, name, **over)
+    dxdp1, _ = DoMPCDifferentiator(mpc1).differentiate()
+    used = np.ones(mpc.structure.n_opt_x, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    ref = np.asarray(dxdp1)[used][:, cols]
+    assert np.max(np.abs(np.asarray(dxdp)[used][:, cols] - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref)))

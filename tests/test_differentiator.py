@@ -36,3 +36,7 @@ def test_reference_surface():
     # the rterm pulls u0 towards u_prev: 0 < du0/du_prev < 1
     assert 0.0 < du0dup[0, 0] < 1.0
 
+
+
+def test_batched_newton_directions_with_several_workspace_slots():
+    dc.check_batched_directions_equal_single_rows(make_mpc, "batch_reactor", max_batch=8)

@@ -18,3 +18,8 @@ def test_sensitivities_match_finite_differences_of_complete_resolves():
 
 def test_sensitivities_of_a_model_with_nl_cons_rows_and_soft_constraints():
     dc.check_against_resolves(make_mpc, "CSTR", [("_x0", "C_b"), ("_u_prev", "Q_dot")])
+
+
+@pytest.mark.parametrize("name", ["batch_reactor", "CSTR"])
+def test_batched_newton_directions_with_several_workspace_slots(name):
+    dc.check_batched_directions_equal_single_rows(make_mpc, name, max_batch=8)

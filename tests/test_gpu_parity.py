@@ -370,3 +370,81 @@ def test_discrete_time_mhe_against_the_oracle():
     from do_mpc_amd.examples import oscillating_masses as om
     pc.check_discrete_mhe(lambda: om.build_mhe(om.build_model(estimation=True)))
     pc.check_discrete_mhe_dae_equals_ode(lambda dae: om.build_mhe(om.build_model(estimation=True, dae=dae)))
+
+
+def _rccl_world_worker(rank, world, port, name, kw, cut, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        ex = CASES[name]
+        mpc = ex.build_mpc(ex.build_model(), gpu_index=rank, **kw)
+        mpc.x0 = ex.X0
+        mpc.set_initial_guess()
+        info = mpc.shard_tree(rank, world, cut_level=cut, native_rccl=True)       # dompc_rccl_unique_id / dompc_rccl_init, world > 1
+        u0 = mpc.make_step(ex.X0).ravel().copy()
+        q.put((rank, u0, mpc.opt_x_num.master.copy(), dict(mpc.solver_stats), int((info["edge_mask"] == 1).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_native_rccl_exchange_with_two_ranks():
+    """The runtime's own RCCL communicator with world = 2 (one process per GPU; unique id from rank 0 broadcast over the
+    caller's group, ncclAllReduce called by the host service loop): the two-rank solve of the 9-leaf tree equals the plain
+    one.  Needs two devices - skipped on the 1-GPU boxes of the pool."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (dompc_rccl_init with world = 2)")
+    name, kw, cut = "industrial_poly", {"n_robust": 2, "uncertainty": "paired"}, 1
+    ex = CASES[name]
+    ref = ex.build_mpc(ex.build_model(), **kw)
+    ref.x0 = ex.X0
+    ref.set_initial_guess()
+    u_ref = ref.make_step(ex.X0).ravel().copy()
+    x_ref, it_ref = ref.opt_x_num.master.copy(), ref.solver_stats["iter_count"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_world_worker, args=(r, 2, port, name, kw, cut, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    keep = np.ones(x_ref.size, bool)
+    keep[ref.structure.tables["dummy_idx"]] = False
+    for rank, u, x, st, n_own in res:
+        assert st["success"] and abs(st["iter_count"] - it_ref) <= 2 and n_own > 0
+        assert np.allclose(u, u_ref, rtol=1e-7, atol=0)
+        assert pc.relerr(x[keep], x_ref[keep]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_on_this_box():
+    """`python bench.py --gpus 2` on a 1-GPU box refuses by name; with two devices it reports n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-b1", "--no-variant-b", "--no-traffic"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "needs 2 devices" in (r.stderr + r.stdout)
+        return
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["solve"]["converged_all_ranks"] == 128
