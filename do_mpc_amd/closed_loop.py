@@ -157,7 +157,8 @@ class BatchClosedLoopMHE:
         op[:, mhe._po_tvp:mhe._po_y] = mhe.tvp_fun(te).master
         ge = np.zeros((B, mhe.n_opt_x))
         ge[:, :mhe._o_z].reshape(B, -1, nx)[:] = (x_est / mhe._x_scaling.master)[:, None, :]
-        ge[:, mhe._o_p:] = p_est
+        pes = mhe._p_est_scaling.master if npe else np.zeros(0)
+        ge[:, mhe._o_p:] = p_est / pes if npe else p_est      # (opt_x holds the SCALED parameter, _mhe.py:939-941 / set_initial_guess)
         self.Pe, self.Ge = t(mhe._p_to_chain(op)), t(mhe._to_chain(ge))
         em = mhe._mpc
         self.e_lbx, self.e_ubx = t(em._lb_opt_x.master), t(em._ub_opt_x.master)
@@ -167,16 +168,47 @@ class BatchClosedLoopMHE:
         self.e_stats = torch.zeros(B * STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         self.x_est, self.p_est = t(x_est), t(p_est)
         self.exs = t(mhe._x_scaling.master)
+        self.eps_ = t(pes if npe else np.zeros(1))              # scaling of the estimated parameters (they ride as scaled states of the chain problem)
         self.t_mpc0, self.dt = t0, float(mpc.settings.t_step)
+        self.t_sim0, self.dt_sim = ts, float(simulator.settings.t_step)
+        self.t_mhe0, self.dt_mhe = te, float(mhe.settings.t_step)
+        self._pc_row = Pc[0].copy()
         self.k = 0
+
+    def _refresh_time_varying(self):
+        """_tvp / _p of controller, plant AND estimator at the current loop time -> device (same values for every sample).  The
+        reference's per-sample loop re-evaluates all of them in every make_step (_mpc.py:1009-1019, simulator.py:790-800,
+        _mhe.py:940-950); only the measurement columns of the estimator's window are data of the loop."""
+        torch, ps, es, m, mhe = self.torch, self.ps, self.es, self.sim.model, self.mhe
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.dev)      # noqa: E731
+        tm, ts, te = self.t_mpc0 + self.k * self.dt, self.t_sim0 + self.k * self.dt_sim, self.t_mhe0 + self.k * self.dt_mhe
+        if ps.ntvp or ps.np_:
+            row = self._pc_row
+            row[ps.p_off_tvp:ps.p_off_p] = self.mpc.tvp_fun(tm).master
+            row[ps.p_off_p:ps.p_off_uprev] = self.mpc.p_fun(tm).master
+            self.Pc[:, ps.p_off_tvp:ps.p_off_uprev] = up(row[ps.p_off_tvp:ps.p_off_uprev].copy())
+        if m.n_p:
+            self.p_plant.copy_(up(self.sim.p_fun(ts).master))
+        if m.n_tvp:
+            self.tvp_plant.copy_(up(self.sim.tvp_fun(ts).master))
+        mt = mhe.model.n_tvp
+        if mt or mhe.n_p_set:
+            op = np.zeros((1, mhe.n_opt_p))
+            op[:, mhe._po_pset:mhe._po_tvp] = mhe.p_fun(te).master
+            op[:, mhe._po_tvp:mhe._po_y] = mhe.tvp_fun(te).master
+            pc = mhe._p_to_chain(op)[0]
+            if mt:
+                tv = pc[es.p_off_tvp:es.p_off_p].reshape(self.N + 1, es.ntvp)[:, :mt]
+                self.Pe[:, es.p_off_tvp:es.p_off_p].view(self.B, self.N + 1, es.ntvp)[:, :, :mt] = up(tv.copy())
+            if es.p_off_uprev > es.p_off_p:
+                self.Pe[:, es.p_off_p:es.p_off_uprev] = up(pc[es.p_off_p:es.p_off_uprev].copy())
 
     def step(self) -> dict:
         torch, ps, es, B, nx, nu, ny, npe, N = self.torch, self.ps, self.es, self.B, self.nx, self.nu, self.ny, self.npe, self.N
         stream = torch.cuda.current_stream()
         mt = self.mhe.model.n_tvp
-        if self.k > 0 and ps.ntvp:          # the controller's time-varying parameters at the current loop time (same for every sample)
-            row = np.ascontiguousarray(self.mpc.tvp_fun(self.t_mpc0 + self.k * self.dt).master, dtype=np.float64)
-            self.Pc[:, ps.p_off_tvp:ps.p_off_p] = torch.from_numpy(row).to(self.dev)
+        if self.k > 0:
+            self._refresh_time_varying()
         # 1. controller
         self.mpc.S.solve_batch_device(B, self.Gc.data_ptr(), self.c_lbx.data_ptr(), self.c_ubx.data_ptr(), self.c_lbg.data_ptr(),
                                       self.c_ubg.data_ptr(), self.Pc.data_ptr(), self.c_sol.data_ptr(), 0, 0, 0, self.c_f.data_ptr(),
@@ -202,7 +234,9 @@ class BatchClosedLoopMHE:
         iN = es.ix(N, 0, es.M)
         self.x_est = self.e_sol[:, iN:iN + nx] * self.exs
         i0 = es.ix(0, 0, es.M)
-        self.p_est = self.e_sol[:, i0 + nx:i0 + nx + npe].clone()
+        # (physical units: the chain problem carries the parameter as a SCALED state; `_p_est_prev` of the arrival cost and the
+        #  returned estimate are physical, _mhe.py: opt_x_num['_p_est'] * _p_est_scaling - ADVICE r3)
+        self.p_est = self.e_sol[:, i0 + nx:i0 + nx + npe] * self.eps_[:npe] if npe else self.e_sol[:, i0 + nx:i0 + nx].clone()
         self.Ge.copy_(self.e_sol)                                  # warm start (unshifted, optimizer.py:754-768)
         # 4. next controller problem: x0 <- estimate, u_prev <- applied input, initial guess <- previous solution
         self.Pc[:, :nx] = self.x_est

@@ -170,6 +170,51 @@ def check_same_iterates_as_oracle(make_mpc, name, oracle_opts=None, tol=1e-8, **
     return mpc
 
 
+TREE27 = dict(n_robust=3, uncertainty="paired")          # industrial_poly, 3 combinations x n_robust = 3: 27 leaves, 24 300 variables, 19 930 rows
+
+
+def oracle_tree27():
+    """cold oracle solve of the 27-leaf industrial_poly tree from golden x0 (cached: ~30 s of scipy SuperLU)"""
+    key = "tree27"
+    if key not in _oracle_solves:
+        nlp = oracle_nlp("industrial_poly", n_robust=3, p_values=PAIRED_P)
+        x0 = golden("industrial_poly")["mpc._x"][0]
+        _oracle_solves[key] = (nlp, x0, ipm.solve(nlp, nlp.initial_guess(x0), nlp.opt_p(x0, np.zeros(nlp.nu))))
+    return _oracle_solves[key]
+
+
+_oracle_solves = {}
+
+
+def check_tree27_same_iterates_as_oracle(make_mpc, shard=None):
+    """an oracle SOLVE between the 9-leaf fixture and the 243-leaf tree of BASELINE configs[4] - the mid-size tree
+    (27 leaves) cold from golden x0: same iteration count and regularisation count as the oracle, final iterate and multipliers
+    equal.  `shard`: kwargs of MPC.shard_tree (the tree-sharded kernel variant; sums formed in another order: count +-1)."""
+    nlp, x0, r = oracle_tree27()
+    mpc = make_mpc("industrial_poly", **TREE27)
+    assert (mpc.structure.S, mpc.structure.n_opt_x, mpc.structure.n_g) == (27, nlp.n_opt_x, nlp.n_g)
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    if shard is not None:
+        mpc.shard_tree(**shard)
+    u0 = mpc.make_step(x0).ravel()
+    st = mpc.solver_stats
+    assert st["success"] and r["stats"]["success"]
+    if shard is None:
+        assert st["iter_count"] == r["stats"]["iter_count"] and st["n_reg"] == r["stats"]["n_reg"]
+    else:
+        assert abs(st["iter_count"] - r["stats"]["iter_count"]) <= 1
+    used = np.ones(nlp.n_opt_x, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    tol = 1e-8 if shard is None else 1e-6
+    assert relerr(u0, nlp.u0_of(r["x"])) < tol
+    assert relerr(mpc.opt_x_num.master[used], r["x"][used]) < tol
+    # (measured: primal 4e-13, multipliers 2.2e-5 of the largest - 0.017 on entries of size 100 next to active state bounds, where
+    #  the multiplier is the small difference of Sigma-sized terms; the 9-leaf case measures 9e-7)
+    assert np.max(np.abs(mpc.lam_g_num - r["lam_g"])) < (5e-5 if shard is None else 2e-4) * max(1.0, np.max(np.abs(r["lam_g"])))
+    return mpc
+
+
 def check_newton_step(make_mpc, name, oracle_iters=6, delta=0.0):
     """One Newton direction of the structured solve (condensing + tree Riccati) against a general sparse
     LU of the same KKT system, at an interior iterate produced by the oracle.  delta > 0: the inertia-correction

@@ -448,3 +448,51 @@ def test_bench_gpus_flag_on_this_box():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["solve"]["converged_all_ranks"] == 128
+
+
+@pytest.mark.gpu
+def test_mid_size_tree_same_iterates_as_the_oracle():
+    """27-leaf industrial_poly tree (n_robust = 3, 24 300 variables) on the GPU against an oracle SOLVE: same iteration and
+    regularisation counts, final iterate 1e-8 - the step between the 9-leaf fixture and the 243-leaf tree (KKT properties only)."""
+    pc.check_tree27_same_iterates_as_oracle(make_mpc)
+
+
+@pytest.mark.gpu
+def test_mid_size_tree_sharded_kernel_variant_against_the_oracle():
+    """... and the tree-sharded kernel variant on it (cut level 2: 3 cut parents, 9 sub-trees; world = 1, native RCCL exchanges)."""
+    pc.check_tree27_same_iterates_as_oracle(make_mpc, shard=dict(rank=0, world=1, cut_level=2, native_rccl=True))
+
+
+def _oracle_member(args):
+    import warnings
+    warnings.filterwarnings("ignore")
+    i, x0 = args
+    from oracle import ipm as oipm
+    nlp = pc.oracle_nlp("industrial_poly")
+    r = oipm.solve(nlp, nlp.initial_guess(x0), nlp.opt_p(x0, np.zeros(nlp.nu)))
+    return i, nlp.u0_of(r["x"]), int(r["stats"]["iter_count"]), bool(r["stats"]["success"]), r["x"]
+
+
+@pytest.mark.gpu
+def test_members_of_the_timed_batch_equal_oracle_solves():
+    """The TIMED launch shape of bench.py (B >= 4096: one 64-lane wavefront per problem, 2048 resident slots, problems pulled from
+    a device-wide counter, perturbed x0 of bench.synthetic_x0_batch) tied to the oracle directly: eight members of a B = 4096
+    batch-mode launch against oracle/ipm.solve of the same x0 - same iteration count, u0 and the full primal solution."""
+    import multiprocessing as mp
+    import bench
+    B = 4096
+    X0 = bench.synthetic_x0_batch(B)
+    mpc = make_mpc("industrial_poly", max_batch=B)
+    assert mpc.S.num_slots >= 1024                     # (one wavefront per problem: 8 slots per CU)
+    r = mpc.make_step_batch(X0)
+    assert r["stats"]["success"].all()
+    members = [0, 1, 511, 1024, 2047, 2048, 3333, 4095]
+    with mp.get_context("spawn").Pool(len(members)) as pool:
+        res = pool.map(_oracle_member, [(i, X0[i]) for i in members])
+    used = np.ones(mpc.structure.n_opt_x, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    for i, u_ref, it_ref, ok, x_ref in res:
+        assert ok
+        assert int(r["stats"]["iter_count"][i]) == it_ref, (i, r["stats"]["iter_count"][i], it_ref)
+        assert pc.relerr(r["u0"][i], u_ref) < 1e-8, (i, r["u0"][i], u_ref)
+        assert pc.relerr(r["x"][i][used], x_ref[used]) < 1e-7, i

@@ -147,3 +147,56 @@ def test_device_resident_closed_loop_with_the_estimator_equals_the_per_sample_lo
             x_est = mhe.make_step(y).ravel()
             assert pc.relerr(out[k]["u0"][b], u0.ravel()) < 1e-9 and pc.relerr(out[k]["y"][b], y.ravel()) < 1e-9
             assert pc.relerr(out[k]["x_est"][b], x_est) < 1e-9
+
+
+def test_device_resident_estimator_loop_with_a_scaled_estimated_parameter():
+    """the chain problem carries `_p_est` as a SCALED state; the arrival-cost anchor `_p_est_prev`, the initial guess and
+    the returned estimate must be converted (`_mhe.py`: opt_x_num['_p_est'] * _p_est_scaling).  The estimator with process noise and
+    the scaling MHE_W_SCALING (Theta_1 scaled by 1e-4) in the device loop against (1) the same loop with the unscaled estimator -
+    the estimates are scaling-invariant - and (2) the per-sample host loop with MHE.make_step.  No stored run of the reference
+    exists for this estimator: equivalence checks, not a reproduction of the reference."""
+    from do_mpc_amd.closed_loop import BatchClosedLoopMHE
+    from do_mpc_amd.simulator import Simulator
+    ex = CASES["rotating_masses"]
+    model, model_w = ex.build_model(), ex.build_model(process_noise=True)
+    B, steps = 3, 3
+    rng = np.random.RandomState(7)
+    X0 = np.array([rng.rand(8) - 0.5 for _ in range(B)])
+
+    def make_sim():
+        sim = Simulator(model)
+        sim.set_param(t_step=0.1, abstol=1e-10, reltol=1e-10)
+        pt = sim.get_p_template()
+        for k in ("Theta_1", "Theta_2", "Theta_3"):
+            pt[k] = 2.25e-4
+        sim.set_p_fun(lambda t: pt)
+        tv = sim.get_tvp_template()
+        sim.set_tvp_fun(lambda t: tv)
+        sim.setup()
+        return sim
+
+    outs = {}
+    for key, scaling in (("plain", None), ("scaled", ex.MHE_W_SCALING)):
+        loop = BatchClosedLoopMHE(ex.build_mpc(model, max_batch=B), make_sim(), ex.build_mhe_w(model_w, scaling=scaling, max_batch=B), X0, p_est0=1e-4)
+        outs[key] = [loop.step() for _ in range(steps)]
+        assert all(o["mhe_stats"]["success"].all() and o["mpc_stats"]["success"].all() for o in outs[key])
+    for k in range(steps):
+        assert pc.relerr(outs["scaled"][k]["p_est"], outs["plain"][k]["p_est"]) < 1e-5
+        assert pc.relerr(outs["scaled"][k]["x_est"], outs["plain"][k]["x_est"]) < 1e-5
+        assert np.all(outs["scaled"][k]["p_est"] > 5e-6) and np.all(outs["scaled"][k]["p_est"] < 2e-3)      # physical units (box 1e-5 .. 1e-3)
+    b = 1
+    mpc, sim, mhe = ex.build_mpc(model), make_sim(), ex.build_mhe_w(model_w, scaling=ex.MHE_W_SCALING)
+    x_est = np.zeros(8)
+    mpc.x0 = x_est
+    mhe.x0 = x_est
+    mhe.p_est0 = 1e-4
+    sim.x0 = X0[b]
+    mpc.set_initial_guess()
+    mhe.set_initial_guess()
+    for k in range(steps):
+        u0 = mpc.make_step(x_est)
+        y = sim.make_step(u0)
+        x_est = mhe.make_step(y).ravel()
+        assert pc.relerr(outs["scaled"][k]["u0"][b], u0.ravel()) < 1e-8
+        assert pc.relerr(outs["scaled"][k]["x_est"][b], x_est) < 1e-8
+        assert pc.relerr(outs["scaled"][k]["p_est"][b], mhe._p_est0.master) < 1e-7

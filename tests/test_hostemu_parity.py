@@ -236,3 +236,8 @@ def test_dense_elimination_with_row_loops_equals_the_register_variant(monkeypatc
         sol.append((mpc.solver_stats["iter_count"], mpc.opt_x_num.master.copy(), mpc.lam_g_num.copy()))
     assert sol[0][0] == sol[1][0] and sol[0][0] >= 5
     assert pc.relerr(sol[0][1], sol[1][1]) < 1e-11 and pc.relerr(sol[0][2], sol[1][2]) < 1e-9
+
+
+def test_mid_size_tree_same_iterates_as_the_oracle():
+    """27-leaf industrial_poly tree (n_robust = 3): oracle solve vs the kernels, same iterates"""
+    pc.check_tree27_same_iterates_as_oracle(make_mpc)

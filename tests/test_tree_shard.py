@@ -175,3 +175,52 @@ def test_random_trees_and_worlds_partition(seed):
         assert np.array_equal(t["node_mask"][below], t["node_mask"][par[below]])
     for acc, rep in zip(own, reps):
         assert np.all(acc + rep == 1)
+
+
+def _worker27(rank, world, port, q):
+    import parity_common as pc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = CASES["industrial_poly"]
+        x0 = pc.golden("industrial_poly")["mpc._x"][0]
+        with hostemu.patched():
+            mpc = ex.build_mpc(ex.build_model(), **pc.TREE27)
+            mpc.x0 = x0
+            mpc.set_initial_guess()
+            mpc.shard_tree(rank=rank, world=world, cut_level=2)
+            u0 = mpc.make_step(x0).ravel().copy()
+        q.put((rank, u0, mpc.opt_x_num.master.copy(), np.array(mpc.lam_g_num).copy(), dict(mpc.solver_stats)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mid_size_tree_on_three_gloo_ranks_against_the_oracle_solve():
+    """27-leaf industrial_poly tree, cut level 2 (3 cut parents, 9 sub-trees) on three gloo ranks against the ORACLE's solve of
+    the same problem (not only against the single-rank product): iteration count +-1, final iterate, multipliers."""
+    import parity_common as pc
+    nlp, x0, r = pc.oracle_tree27()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker27, args=(rk, 3, port, q)) for rk in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(3)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ex = CASES["industrial_poly"]
+    with hostemu.patched():
+        dummy = ex.build_mpc(ex.build_model(), **pc.TREE27).structure.tables["dummy_idx"]
+    used = np.ones(nlp.n_opt_x, bool)
+    used[dummy] = False
+    for rank, u, x, lg, st in res:
+        assert st["success"] and abs(st["iter_count"] - r["stats"]["iter_count"]) <= 1
+        assert pc.relerr(u, nlp.u0_of(r["x"])) < 1e-6
+        assert pc.relerr(x[used], r["x"][used]) < 1e-6
+        assert np.max(np.abs(lg - r["lam_g"])) < 2e-4 * max(1.0, np.max(np.abs(r["lam_g"])))
