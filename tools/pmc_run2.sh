@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${DOMPC_PMC_DIR:-pmc2}
 mkdir -p $OUT
-CMD="python $R/bench.py --steps 1 --warmup 0 --batch ${DOMPC_PMC_BATCH:-16384} --no-cpu-baseline --no-traffic --no-b1"
+CMD="python $R/bench.py --steps 1 --warmup 0 --batch ${DOMPC_PMC_BATCH:-16384} --no-cpu-baseline --no-traffic --no-b1 --no-variant-b --sweep-steps 0"
 i=0
 while read -r line; do
   [ -z "$line" ] && continue

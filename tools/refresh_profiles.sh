@@ -6,7 +6,7 @@ O=gpurun_out/$R
 mkdir -p $O
 timeout 300 python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
 cut -c1-400 $O/bench.json
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --no-b1 > $GRAFT_REPO_ROOT/$O/stats.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-traffic --no-b1 --no-variant-b --sweep-steps 0 > $GRAFT_REPO_ROOT/$O/stats.log 2>&1)
 ls -t $O/stats/*/*kernel_stats.csv | head -1 | xargs cat | head -5
 # QUICK=1: the phase profile at the bench batch size only and the two traffic passes of the counters (FETCH_SIZE, WRITE_SIZE)
 if [ -n "${QUICK:-}" ]; then
