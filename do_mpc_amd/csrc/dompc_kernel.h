@@ -103,6 +103,10 @@ constexpr int MAX_FILTER = 48;
 #ifndef DOMPC_SHARD
 #define DOMPC_SHARD 0
 #endif
+#ifndef DOMPC_KO
+#define DOMPC_KO 0                  // measurement aid (tools/gpu_sweep_ko.py; WRONG RESULTS): pieces of the edge sweep left out, to see what each one
+#endif                              // costs in THROUGHPUT under real concurrency: 1 factorisation, 2 condensing, 4 record stores, 8 model evaluation,
+                                    // 16 per-variable loads of the edge, 32 staging + expansion of the model-output record
 constexpr int RED_MAX = 12;          // values reduced per pass
 #ifndef DOMPC_HOST_EMU
 constexpr int GS_C = 64;             // lanes per edge group: one wavefront
@@ -371,10 +375,6 @@ __shared__ int lds_b;
 #ifndef DOMPC_PROFILE
 #define DOMPC_PROFILE 0             // 1: sub-phase shader-clock counters of the edge sweep / node update (tools/gpu_profile.py)
 #endif
-#ifndef DOMPC_KO
-#define DOMPC_KO 0                  // measurement aid (tools/gpu_sweep_ko.py; WRONG RESULTS): pieces of the edge sweep left out, to see what each one
-#endif                              // costs in THROUGHPUT under real concurrency: 1 factorisation, 2 condensing, 4 record stores, 8 model evaluation,
-                                    // 16 per-variable loads of the edge, 32 staging + expansion of the model-output record
 __shared__ long long lds_prof[32];
 
 // slot of the calling workgroup: normal mode one workgroup per problem slot; wide mode (small batches) K = A.wide
