@@ -113,16 +113,20 @@ static int dev_sync(dompc_handle* h) {
 }
 // Wait for `st` with the watchdog: after watchdog_s the stop request is raised (the kernel leaves its IPM loops with
 // status 6); if the stream still has not drained after a grace period the call fails instead of blocking forever.
-static int dev_sync_watchdog(dompc_handle* h, hipStream_t st) {
+// The limit is per ROUND over the resident problem slots (a batch of B problems on n_slots slots takes ceil(B / n_slots) rounds): a
+// legitimately long batch is not cut short by a limit that was sized for one problem.  A watchdog that fired leaves a message in
+// dompc_last_error even though the call succeeds (the problems it stopped carry status 6, `User_Requested_Stop`).
+static int dev_sync_watchdog(dompc_handle* h, hipStream_t st, int rounds = 1) {
   const auto t0 = std::chrono::steady_clock::now();
   bool raised = false;
+  const double limit = h->watchdog_s * (rounds > 1 ? rounds : 1);
   while (true) {
     const hipError_t q = hipStreamQuery(st);
     if (q == hipSuccess) break;
     if (q != hipErrorNotReady) { h->error = std::string("hipStreamQuery: ") + hipGetErrorString(q); return 1; }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (!raised && dt > h->watchdog_s) { int32_t z_ = 0; __atomic_compare_exchange_n(h->abort_word, &z_, 1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); raised = true; }   // (0 -> 1: a user's request, 2, is left alone)
-    if (raised && dt > h->watchdog_s + 30.0) {
+    if (!raised && dt > limit) { int32_t z_ = 0; __atomic_compare_exchange_n(h->abort_word, &z_, 1, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); raised = true; }   // (0 -> 1: a user's request, 2, is left alone)
+    if (raised && dt > limit + 30.0) {
       h->error = "watchdog: the solver kernel did not finish and did not react to the stop request";
       return 1;
     }
@@ -133,6 +137,10 @@ static int dev_sync_watchdog(dompc_handle* h, hipStream_t st) {
     // it is documented as sticky until dompc_abort(h, 0)); the caller learns about it through the error string and status 6
     int32_t expect = 1;
     __atomic_compare_exchange_n(h->abort_word, &expect, 0, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+    char msg[200];
+    snprintf(msg, sizeof msg, "watchdog: stop request raised after %.0f s (DOMPC_WATCHDOG_S = %.0f s per round over the problem slots, %d round(s)); "
+             "unfinished problems return status 6", limit, h->watchdog_s, rounds > 1 ? rounds : 1);
+    h->error = msg;
   }
   return 0;
 }
@@ -729,7 +737,7 @@ extern "C" int dompc_solve_batch(dompc_handle* h, int32_t B, const double* x0, c
     return 1;
 #ifndef DOMPC_HOST_EMU
   // wait here (bounded by the watchdog) before the result copies are queued behind the kernel
-  if (!h->sharded && dev_sync_watchdog(h, h->stream)) return 1;
+  if (!h->sharded && dev_sync_watchdog(h, h->stream, (B + h->n_slots - 1) / (h->n_slots > 0 ? h->n_slots : 1))) return 1;
 #endif
   if (x) rc |= d2h(h, x, h->s_x, sizeof(double) * (size_t)B * d.n_opt_x);
   if (g) rc |= d2h(h, g, h->s_g, sizeof(double) * (size_t)B * d.n_g);

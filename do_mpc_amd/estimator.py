@@ -682,6 +682,23 @@ class MHE:
                 p0[off:off + k] = src[grp.offset(n):grp.offset(n) + k]
             off += k
         self.data.update(_x=x0, _u=u0, _p=p0, _time=self._t0)
+        # auxiliary expressions of the LAST stage of the window (_mhe.py:959, 969, 1193-1195: aux(x[k, -1], u[k], z[k, -1], tvp[k], p)
+        # with the parameters of the current solution) - ADVICE r3
+        if self.model.n_aux:
+            mdl = self.model
+            xk = _arr(self._opt_x_num["_x", -2, -1]) * self._x_scaling.master
+            pk = np.zeros(mdl.n_p)
+            off = 0
+            for n in mdl._p.names:
+                k = mdl._p.vars[n].numel()
+                if k:
+                    grp, src = (self._p_est, p_est_next) if n in self._p_est.names else (self._p_set, p_set0.master)
+                    pk[off:off + k] = src[grp.offset(n):grp.offset(n) + k]
+                off += k
+            tvk = _arr(tvp0["_tvp", -1]) if mdl.n_tvp else np.zeros(0)
+            aux0 = mdl._aux_expression_fun.eval(xk.reshape(-1, 1), u0.reshape(-1, 1), z0.reshape(-1, 1), np.asarray(tvk, float).reshape(-1, 1),
+                                                pk.reshape(-1, 1))[0]
+            self.data.update(_aux=np.asarray(aux0, float).reshape(-1))
         if self.model.n_z:
             self.data.update(_z=z0)
         if self.model.n_tvp:
