@@ -27,6 +27,11 @@ struct dompc_plant {
   double *s_x = nullptr, *s_u = nullptr, *s_tvp = nullptr, *s_p = nullptr, *s_w = nullptr, *s_v = nullptr, *s_xn = nullptr, *s_y = nullptr;
   int32_t* s_st = nullptr;
   std::vector<void*> allocs;
+  int32_t nz = 0;                       // algebraic states of the model (from the code object)
+  int32_t method = 0, explicit_limit = 4000;
+  std::vector<double> z0;               // Newton start of the algebraic states (dompc_plant_set_z0; zeros by default)
+  double* z_dev = nullptr;              // [z_cap][nz]: per-sample start values, carried from call to call
+  int32_t z_cap = 0;
 #ifndef DOMPC_HOST_EMU
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr, fn_info = nullptr;
@@ -124,7 +129,48 @@ extern "C" int dompc_plant_create(const dompc_plant_desc* desc, dompc_plant** ou
   if (info[8] != (int64_t)sizeof(dompc_plantk::Args)) { h->error = "plant argument layout mismatch between runtime and code object"; return fail(); }
   if (desc->model_hash && strncmp(desc->model_hash, hash, 63) != 0) { h->error = "plant model hash mismatch"; return fail(); }
   h->d.code_object_path = nullptr; h->d.model_hash = nullptr;
+  h->nz = (int32_t)info[9];
+  h->z0.assign((size_t)(h->nz > 0 ? h->nz : 0), 0.0);
   *out = h;
+  return 0;
+}
+
+extern "C" int dompc_plant_set_method(dompc_plant* h, int32_t method, int32_t explicit_limit) {
+  if (!h) return 1;
+  if (method < 0 || method > 2) { h->error = "method must be 0 (explicit, implicit for stiff samples), 1 (explicit) or 2 (implicit)"; return 1; }
+  h->method = method;
+  if (explicit_limit > 0) h->explicit_limit = explicit_limit;
+  return 0;
+}
+
+extern "C" int32_t dompc_plant_num_alg_states(const dompc_plant* h) { return h ? h->nz : 0; }
+
+extern "C" int dompc_plant_set_z0(dompc_plant* h, const double* z0) {
+  if (!h) return 1;
+  for (int i = 0; i < h->nz; ++i) h->z0[(size_t)i] = z0 ? z0[i] : 0.0;
+  h->z_cap = 0;                          // (the per-sample values are re-seeded by the next call)
+  return 0;
+}
+
+// per-sample start values of the algebraic states for B samples: seeded with z0 when the buffer is (re)created
+static int ensure_z(dompc_plant* h, int32_t B) {
+  if (h->nz <= 0 || B <= h->z_cap) return 0;
+  if (h->z_dev) {
+    for (size_t i = 0; i < h->allocs.size(); ++i)
+      if (h->allocs[i] == h->z_dev) { h->allocs.erase(h->allocs.begin() + i); pfree(h->z_dev); break; }
+    h->z_dev = nullptr;
+  }
+  h->z_cap = 0;
+  if (palloc(h, (void**)&h->z_dev, sizeof(double) * (size_t)B * h->nz)) return 1;
+  std::vector<double> seed((size_t)B * h->nz);
+  for (int32_t b = 0; b < B; ++b)
+    for (int i = 0; i < h->nz; ++i) seed[(size_t)b * h->nz + i] = h->z0[(size_t)i];
+#ifndef DOMPC_HOST_EMU
+  PHIP(h, hipMemcpy(h->z_dev, seed.data(), seed.size() * sizeof(double), hipMemcpyHostToDevice));
+#else
+  memcpy(h->z_dev, seed.data(), seed.size() * sizeof(double));
+#endif
+  h->z_cap = B;
   return 0;
 }
 
@@ -146,6 +192,8 @@ static void fill_args(const dompc_plant* h, dompc_plantk::Args& A, int32_t B, in
   A.stride_u = (shared_mask & 1) ? 0 : d.nu; A.stride_tvp = (shared_mask & 2) ? 0 : d.ntvp; A.stride_p = (shared_mask & 4) ? 0 : d.np;
   A.stride_w = (shared_mask & 8) ? 0 : d.nw; A.stride_v = (shared_mask & 16) ? 0 : d.nv;
   A.max_steps = d.max_steps > 0 ? d.max_steps : 200000; A.pad = 0;
+  A.method = h->method; A.explicit_limit = h->explicit_limit;
+  A.z_guess = (h->nz > 0 && B <= h->z_cap) ? h->z_dev : nullptr;
   A.t_step = d.t_step; A.rtol = d.reltol > 0 ? d.reltol : 1e-10; A.atol = d.abstol > 0 ? d.abstol : 1e-10;
 }
 
@@ -159,6 +207,7 @@ extern "C" int dompc_plant_step_batch_device(dompc_plant* h, int32_t B, const do
 #ifndef DOMPC_HOST_EMU
   PHIP(h, hipSetDevice(d.device));
 #endif
+  if (ensure_z(h, B)) return 1;
   dompc_plantk::Args A;
   memset(&A, 0, sizeof(A));
   A.x = x; A.u = u; A.tvp = tvp; A.p = p; A.w = w; A.v = v; A.x_next = x_next; A.y = y; A.status = status;

@@ -4,13 +4,13 @@ Mirror of the reference's `do_mpc.simulator.Simulator` surface (/root/reference/
 `Simulator(model)`, `settings.t_step / abstol / reltol / integration_tool` (`set_param(**kw)` forwards to it),
 `get_p_template / set_p_fun`, `get_tvp_template / set_tvp_fun`, `setup()`, the iterated variables `x0`, `u0`, `t0`,
 `make_step(u0, v0=None, w0=None) -> y_next`.  Underneath, the CVODES integrator object of simulator.py:381-416 is
-replaced by the batched explicit Runge-Kutta integrator of csrc/dompc_plant.hip behind the C ABI `dompc_plant_*`
+replaced by the batched Runge-Kutta integrator of csrc/dompc_plant.hip (explicit pair + implicit SDIRK) behind the C ABI `dompc_plant_*`
 (include/dompc_ipm.h); `make_step_batch(X, U, ...)` advances B samples with one launch, and
 `step_batch_device(...)` does the same on device pointers so that an x0 batch never leaves HBM between the
 controller's `make_step_batch` calls.
 
-There is no CPU fallback: without a HIP device `setup()` raises.  Algebraic states (`_z`, IDAS in the reference) are
-not supported.
+There is no CPU fallback: without a HIP device `setup()` raises.  Stiff plants: `settings.integration_tool` ('cvodes' / 'idas':
+explicit pair with an implicit repeat for stiff samples; 'sdirk4': implicit only; 'dopri5': explicit only).
 """
 from __future__ import annotations
 
@@ -31,7 +31,9 @@ class SimulatorSettings:
     t_step: float = None
     abstol: float = 1e-10
     reltol: float = 1e-10
-    integration_tool: str = "cvodes"      # accepted for source compatibility; the integrator is dompc_plant.hip
+    # 'cvodes' / 'idas' (the reference's implicit integrators): explicit pair, stiff samples repeat their interval with the
+    # implicit SDIRK method; 'dopri5': explicit only; 'sdirk4': implicit only (csrc/dompc_plant.hip)
+    integration_tool: str = "cvodes"
     integration_opts: Dict = field(default_factory=dict)
     gpu_index: int = 0
     max_steps: int = 0                    # integration steps per sample and control interval (0 = 200000)
@@ -59,6 +61,12 @@ def _bind(lib_path: str) -> C.CDLL:
     lib.dompc_plant_step_batch.restype = C.c_int
     lib.dompc_plant_step_batch_device.argtypes = [vp, C.c_int32] + [vp] * 6 + [C.c_int32] + [vp] * 3 + [vp]
     lib.dompc_plant_step_batch_device.restype = C.c_int
+    lib.dompc_plant_set_method.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.dompc_plant_set_method.restype = C.c_int
+    lib.dompc_plant_set_z0.argtypes = [vp, vp]
+    lib.dompc_plant_set_z0.restype = C.c_int
+    lib.dompc_plant_num_alg_states.argtypes = [vp]
+    lib.dompc_plant_num_alg_states.restype = C.c_int32
     return lib
 
 
@@ -186,7 +194,20 @@ class Simulator:
         if self._lib.dompc_plant_create(C.byref(d), C.byref(h)) != 0:
             raise RuntimeError("dompc_plant_create failed: " + (self._lib.dompc_plant_last_error(None) or b"?").decode())
         self._h = h
+        tool = str(self.settings.integration_tool).lower()
+        methods = {"cvodes": 0, "idas": 0, "auto": 0, "dopri5": 1, "rk45": 1, "sdirk4": 2, "implicit": 2}
+        if tool not in methods:
+            raise ValueError(f"integration_tool {self.settings.integration_tool!r}: expected one of {sorted(methods)}")
+        if self._lib.dompc_plant_set_method(h, methods[tool], int(self.settings.integration_opts.get("explicit_limit", 0))) != 0:
+            raise RuntimeError("dompc_plant: " + (self._lib.dompc_plant_last_error(h) or b"?").decode())
+        self._seed_z()
         self.flags["setup"] = True
+
+    def _seed_z(self):
+        """Newton start of the algebraic states on the device = simulator.z0 (simulator.py:603-620: sim_z_num)"""
+        if self.model.n_z and self._h:
+            z = np.ascontiguousarray(self._z0.master, dtype=np.float64)
+            self._lib.dompc_plant_set_z0(self._h, z.ctypes.data_as(C.c_void_p))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -201,10 +222,11 @@ class Simulator:
 
     # ------------------------------------------------------------------ runtime
     def set_initial_guess(self) -> None:
-        """Initial guess of the algebraic states for the DAE solver (simulator.py:603-620).  The kernel solves the
-        algebraic equations by Newton's method from z = 0 inside every right-hand-side evaluation; kept because every main.py of the
-        reference calls it."""
+        """Initial guess of the algebraic states for the DAE solver (simulator.py:603-620): `simulator.z0` becomes the Newton start of
+        the algebraic equations for every sample (the kernel then continues from the values it found at the end of the previous
+        step, like IDAS from sim_z_num); the records' z (`_host_z`) starts from the same values."""
         assert self.flags["setup"], "Simulator was not setup yet. Please call Simulator.setup()."
+        self._seed_z()
 
     def _host_z(self, x, u, tvp, p) -> np.ndarray:
         """algebraic states at (x, u) for the data records (Newton's method on the model's own functions, from the last values)"""

@@ -243,9 +243,14 @@ int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* desc);
  * x_next and y = meas(x_next, u, tvp, p) + v out, in physical units - for B samples at once, one GPU thread per sample,
  * so that an x0 batch stays resident in HBM between the controller's make_step calls.  The model's right-hand side and
  * measurement function come from a per-model gfx950 code object (do_mpc_amd/lowering.py:lower_plant).
- * Explicit Dormand-Prince 5(4) with per-sample step-size control (local error at 1/100 of abstol / reltol);
- * algebraic states are not supported.  status[b]: bit 0 = step limit reached or NaN right-hand side (x_next is the
- * state reached so far), steps taken = status[b] >> 8.
+ * Methods (dompc_plant_set_method): explicit Dormand-Prince 5(4) and the implicit SDIRK 4(3) of Hairer & Wanner, both with
+ * per-sample step-size control (local error at 1/100 of abstol / reltol); default 0 = explicit, a sample that needs more than
+ * `explicit_limit` explicit steps (stiff) repeats its interval with the implicit method - CVODES / IDAS of the reference are
+ * implicit.  Algebraic states (semi-explicit index-1 DAE): solved for by Newton's method inside every right-hand-side
+ * evaluation, per-sample start values carried from call to call (seed: dompc_plant_set_z0, the reference's
+ * simulator.set_initial_guess / sim_z_num, simulator.py:603-620).  status[b]: bit 0 = step limit reached, NaN right-hand
+ * side or a failed algebraic / stage solve (x_next is the state reached so far), bit 1 = the implicit method produced the
+ * result, steps taken = status[b] >> 8.
  * shared_mask: bit 0/1/2/3/4 set = u/tvp/p/w/v is ONE row shared by all samples instead of [B][n]. */
 typedef struct dompc_plant dompc_plant;
 typedef struct dompc_plant_desc {
@@ -259,6 +264,13 @@ typedef struct dompc_plant_desc {
 } dompc_plant_desc;
 int  dompc_plant_create(const dompc_plant_desc* desc, dompc_plant** out);
 void dompc_plant_destroy(dompc_plant* h);
+/* method: 0 explicit with implicit repeat for stiff samples (default), 1 explicit only, 2 implicit only;
+ * explicit_limit: explicit steps per interval after which a sample counts as stiff (0 = keep, default 4000) */
+int  dompc_plant_set_method(dompc_plant* h, int32_t method, int32_t explicit_limit);
+/* algebraic states: their number, and the Newton start for every sample (host array of that many values, NULL = zeros);
+ * afterwards every sample continues from the values it found at the end of the previous call */
+int32_t dompc_plant_num_alg_states(const dompc_plant* h);
+int  dompc_plant_set_z0(dompc_plant* h, const double* z0);
 const char* dompc_plant_last_error(const dompc_plant* h);     /* h may be NULL: error of the last failed create */
 /* host buffers; w, v, y, status may be NULL */
 int dompc_plant_step_batch(dompc_plant* h, int32_t B, const double* x, const double* u, const double* tvp, const double* p,

@@ -88,3 +88,70 @@ def closed_loop_plant(hostemu):
             return sim.make_step(np.asarray(u, float).reshape(-1, 1)).ravel()
         return step
     return make_plant
+
+
+def check_implicit_against_scipy(name, hostemu, tol=2e-9):
+    """the implicit method (SDIRK 4(3), settings.integration_tool = 'sdirk4') on a shipped plant against scipy's Radau at 1e-11"""
+    ex = CASES[name]
+    sim = make_simulator(name, hostemu, integration_tool="sdirk4")
+    m = sim.model
+    p = plant.p_vector(m, plant.PLANT_P[name])
+    x = ex.X0.copy()
+    for k in range(2):
+        u = np.array(U_TEST[name]) * (1.0 + 0.1 * k)
+        r = sim.make_step_batch(x[None, :], u)
+        assert r["status"][0] == 2, r["status"]                     # bit 1: implicit method, bit 0 clear
+        ref = plant.plant_step(m, x, u, p, T_STEP[name])
+        assert np.max(np.abs(r["x"][0] - ref) / np.maximum(1.0, np.abs(ref))) < tol, (name, k, r["x"][0], ref)
+        x = ref
+
+
+def stiff_model(mu=1e4):
+    """Van der Pol oscillator in Lienard coordinates with stiffness parameter mu - no shipped example is stiff"""
+    from do_mpc_amd import Model
+    m = Model("continuous")
+    x = m.set_variable("_x", "x", (2, 1))
+    u = m.set_variable("_u", "u")
+    m.set_rhs("x", np.array([[0.0], [0.0]]) + _vdp(x, u, mu))
+    m.setup()
+    return m
+
+
+def _vdp(x, u, mu):
+    from do_mpc_amd.sym import vertcat
+    return vertcat(x[1], mu * ((1.0 - x[0] * x[0]) * x[1]) - x[0] + u)
+
+
+def check_stiff_plant(hostemu):
+    """A stiff plant (Van der Pol, mu = 1e4, two time units: the explicit pair would need ~2e4 steps): the explicit pair alone runs into its step limit (status 1, as
+    before); the default ('cvodes': explicit first) notices that, repeats the interval with the implicit method and agrees with
+    scipy's Radau; 'sdirk4' gives the same result directly.  The reference integrates every plant with CVODES / IDAS."""
+    from scipy.integrate import solve_ivp
+    m = stiff_model()
+    x0, u0, T = np.array([2.0, 0.0]), np.array([0.1]), 2.0
+
+    def make(tool, **kw):
+        sim = Simulator(m)
+        sim.set_param(t_step=T, abstol=1e-10, reltol=1e-10, integration_tool=tool, **kw)
+        if hostemu:
+            hdr = sim._lower()
+            h = hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0]
+            sim.setup(_lib_path=build.plant_hostemu_library(hdr, h, OUT), _code_object="")
+        else:
+            sim.setup()
+        return sim
+
+    f = lambda t, y: np.array([y[1], 1e4 * (1.0 - y[0] ** 2) * y[1] - y[0] + u0[0]])      # noqa: E731
+    ref = solve_ivp(f, (0.0, T), x0, method="Radau", rtol=1e-12, atol=1e-13).y[:, -1]
+    r = make("dopri5", max_steps=3000).make_step_batch(x0[None, :], u0)
+    assert r["status"][0] == 1 and r["n_steps"][0] == 3000                 # explicit only: stiff -> step limit
+    r = make("cvodes", integration_opts={"explicit_limit": 1500}).make_step_batch(x0[None, :], u0)
+    assert r["status"][0] == 2                                             # implicit repeat, finished
+    assert np.max(np.abs(r["x"][0] - ref) / np.maximum(1e-3, np.abs(ref))) < 1e-6, (r["x"][0], ref)
+    assert r["n_steps"][0] < 1500 + 1200                                   # (the implicit method needs a few hundred steps)
+    r2 = make("sdirk4").make_step_batch(x0[None, :], u0)
+    assert r2["status"][0] == 2 and np.max(np.abs(r2["x"][0] - r["x"][0])) < 1e-12
+    # a batch in which only some samples are stiff: every sample picks its own method
+    X = np.array([[2.0, 0.0], [0.0, 0.0]])
+    rb = make("cvodes", integration_opts={"explicit_limit": 1500}).make_step_batch(X, np.array([0.1]))
+    assert rb["status"][0] == 2 and rb["status"][1] in (0, 2)

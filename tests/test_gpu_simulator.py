@@ -202,3 +202,12 @@ def test_device_resident_estimator_loop_with_a_scaled_estimated_parameter():
         assert pc.relerr(outs["scaled"][k]["u0"][b], u0.ravel()) < 1e-8
         assert pc.relerr(outs["scaled"][k]["x_est"][b], x_est) < 1e-8
         assert pc.relerr(outs["scaled"][k]["p_est"][b], mhe._p_est0.master) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["industrial_poly", "dip"])
+def test_implicit_method_matches_scipy_radau(name):
+    sc.check_implicit_against_scipy(name, hostemu=False)
+
+
+def test_stiff_plant_switches_to_the_implicit_method():
+    sc.check_stiff_plant(hostemu=False)

@@ -88,3 +88,12 @@ def test_closed_loop_with_this_plant_reproduces_the_reference_trajectory(name):
             return ex.build_mpc(ex.build_model())
     wu, wx = run_closed_loop(make_mpc, name, steps=CL_STEPS.get(name, 5), make_plant=sc.closed_loop_plant(hostemu=True))
     assert wu < CL_RTOL and wx < CL_RTOL
+
+
+@pytest.mark.parametrize("name", ["batch_reactor", "CSTR", "industrial_poly", "dip"])
+def test_implicit_method_matches_scipy_radau(name):
+    sc.check_implicit_against_scipy(name, hostemu=True)
+
+
+def test_stiff_plant_switches_to_the_implicit_method():
+    sc.check_stiff_plant(hostemu=True)
