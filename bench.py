@@ -193,22 +193,41 @@ def cpu_baseline(per_core: int = 1, max_cores: int = 0) -> dict:
         host by g++ -O2 (the TEST-ONLY host emulation of the kernel text, tests/_hostemu) - not the reference's path, reported
         because it is the stronger CPU number: what these cores do with the algorithm the GPU runs."""
     try:
-        cores = len(os.sched_getaffinity(0))
+        logical = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        logical = os.cpu_count() or 1
+    # CPU time this process tree may actually use: the cgroup quota (cpu.max = "quota period"; the GPU boxes of the pool show 256
+    # logical CPUs under a quota of 16 - more runnable workers than that are throttled: measured 78 tasks/s with 16 busy
+    # processes, 57 with 256)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:           # noqa: BLE001
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:       # noqa: BLE001
+            pass
+    cores = logical if quota is None else max(1, min(logical, int(quota + 0.5)))
     host_cores = cores
     cap = max_cores or int(os.environ.get("DOMPC_CPU_BASELINE_CORES", "0"))
     if cap > 0:
         cores = min(cores, cap)
     t0 = time.perf_counter()
+    per_core = max(per_core, 3 if cores <= 32 else 1)
     o, err = _run_fanout("oracle", cores, per_core, timeout=240.0)
-    out = {"value": None, "unit": "MPC steps/s", "cores": cores, "host_cores": host_cores, "kind": "port"}
+    out = {"value": None, "unit": "MPC steps/s", "cores": cores, "host_cores": host_cores, "kind": "port",
+           "host_logical_cpus": logical, "cpu_quota": quota}
     if o is None:
         out["sample"] = f"oracle fan-out failed: {err}"
     else:
         out.update({"value": o["value"], "per_core": o["per_core"], "ms_per_iteration": o["ms_per_iteration"],
                     "sample": f"{o['n']} cold make_step solves of the same workload ({per_core} per core, one single-threaded process per core, "
-                              f"{cores} of {host_cores} cores; oracle/ipm.py with opts fast: Python driver, numpy-vectorised NLP functions, scipy "
+                              f"{cores} of the {host_cores} cores this box grants (cgroup CPU quota; {logical} logical CPUs visible); oracle/ipm.py with opts fast: Python driver, numpy-vectorised NLP functions, scipy "
                               f"SuperLU on an RCM-ordered KKT matrix, one factorisation per iteration), {o['n_ok']}/{o['n']} converged, "
                               f"{o['iters_mean']:.1f} iterations and {o['s_per_solve']:.2f} s per solve = {o['ms_per_iteration']:.1f} ms per "
                               f"iteration and core under this load (the reference's own logged datum: IPOPT + MUMPS 23 ms per iteration "
@@ -216,13 +235,14 @@ def cpu_baseline(per_core: int = 1, max_cores: int = 0) -> dict:
                               f"{o['t_par']:.1f} s, {time.perf_counter() - t0:.1f} s incl. start-up and the {o['t_build']:.1f} s model build"})
     if os.environ.get("DOMPC_CPU_SAME_ALGORITHM", "1") != "0":
         t1 = time.perf_counter()
-        h, err = _run_fanout("hostemu", cores, 2, timeout=300.0)
+        n_he = 8 if cores <= 32 else 2
+        h, err = _run_fanout("hostemu", cores, n_he, timeout=300.0)
         if h is None:
             out["same_algorithm_on_cpu"] = {"error": err}
         else:
             out["same_algorithm_on_cpu"] = {
                 "value": h["value"], "unit": "MPC steps/s", "per_core": h["per_core"], "cores": cores, "ms_per_iteration": h["ms_per_iteration"],
-                "sample": f"{h['n']} cold solves (2 per core, {cores} single-threaded processes): the kernel text of the product compiled by "
+                "sample": f"{h['n']} cold solves ({n_he} per core, {cores} single-threaded processes): the kernel text of the product compiled by "
                           f"g++ -O2 for the host (tests/_hostemu, test infrastructure), {h['n_ok']}/{h['n']} converged, {h['s_per_solve']:.2f} s per "
                           f"solve, parallel region {h['t_par']:.1f} s, {time.perf_counter() - t1:.1f} s incl. start-up",
                 "note": "NOT the reference's CPU path (that is IPOPT + a general sparse LDL'); the product's structured algorithm on the host cores"}
