@@ -695,6 +695,7 @@ def bench_tree(args, ex, rank, world, local_rank, dist):
     info = mpc.shard_tree(rank, world, cut_level=cut)
     t_step = []
     iters = []
+    n_xchg = []
     ok = True
     for k in range(args.warmup + args.steps):
         mpc.x0 = ex.X0
@@ -711,6 +712,7 @@ def bench_tree(args, ex, rank, world, local_rank, dist):
         if k >= args.warmup:
             t_step.append(dt)
             iters.append(mpc.solver_stats["iter_count"])
+            n_xchg.append(mpc.solver_stats.get("n_exchanges", 0))
             ok = ok and bool(mpc.solver_stats["success"])
     t = torch.tensor([sum(t_step)], dtype=torch.float64, device=torch.device("cuda", local_rank))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -727,7 +729,8 @@ def bench_tree(args, ex, rank, world, local_rank, dist):
                                    f"(3 combos x n_robust={args.n_robust}, N=20, Radau deg 2), tree sharded over the ranks",
                        "n_opt_x": ps.n_opt_x, "n_g": ps.n_g, "edges": ps.n_edges, "cut_level": info["cut_level"],
                        "cut_parents": info["n_cut"], "start": "cold", "parallelism": f"scenario sub-trees x{world}, RCCL all-reduce"},
-            "solve": {"converged": bool(ok), "iters_mean": float(np.mean(iters)), "u0": [float(v) for v in np.ravel(u0)]},
+            "solve": {"converged": bool(ok), "iters_mean": float(np.mean(iters)), "u0": [float(v) for v in np.ravel(u0)],
+                      "exchanges_per_solve": float(np.mean(n_xchg)), "exchanges_per_iteration": float(np.mean(n_xchg) / max(np.mean(iters), 1.0))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None, "kernel": "dompc_solve_kernel",
                          "kernel_ms": dt / args.steps * 1e3, "sweep_bytes_per_problem": sweep_b,

@@ -55,6 +55,7 @@ struct dompc_handle {
   uint32_t* x_words = nullptr;           // pinned host memory: [req, ack, count, off] (device build)
   int32_t* abort_word = nullptr;         // pinned host memory (device build) / plain word: stop request read by the kernel
   double watchdog_s = 600.0;
+  int64_t n_exchanges = 0;                      // cross-rank exchanges served during the last sharded solve
 #ifndef DOMPC_HOST_EMU
   // native RCCL collective (dlopen'ed): communicator of the sharded problem and its stream
   struct RcclUid { char internal[128]; };
@@ -659,9 +660,12 @@ static int serve_exchanges(dompc_handle* h, hipStream_t st) {
   }
   hipEventDestroy(done);
   if (raised) { int32_t expect = 1; __atomic_compare_exchange_n(h->abort_word, &expect, 0, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); }
+  h->n_exchanges = (int64_t)served;             // (the kernel numbers its requests 1, 2, ...: the last one served = their count)
   return rc;
 }
 #endif
+
+extern "C" int64_t dompc_last_exchange_count(const dompc_handle* h) { return h ? h->n_exchanges : 0; }
 
 extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double* x0, const double* lbx, const double* ubx,
                                         const double* lbg, const double* ubg, const double* p, double* x, double* g,

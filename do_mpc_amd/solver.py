@@ -120,6 +120,8 @@ def _load(lib_path: str) -> C.CDLL:
     lib.dompc_exchange_doubles.restype = C.c_int64
     lib.dompc_set_sharding.argtypes = [vp, C.POINTER(ShardDesc)]
     lib.dompc_set_sharding.restype = C.c_int
+    lib.dompc_last_exchange_count.argtypes = [vp]
+    lib.dompc_last_exchange_count.restype = C.c_int64
     lib.dompc_rccl_unique_id.argtypes = [vp, C.c_char_p, vp]
     lib.dompc_rccl_unique_id.restype = C.c_int
     lib.dompc_rccl_init.argtypes = [vp, C.c_char_p, vp, C.c_int32, C.c_int32]
@@ -244,6 +246,7 @@ class HipIpmSolver:
                                           None, None, _ptr(x), _ptr(g), _ptr(lam_x), _ptr(lam_g), _ptr(f), _ptr(st)))
         self._stats = self._stats_dict(st[0])
         if self._shard is not None:
+            self._stats["n_exchanges"] = int(self._lib.dompc_last_exchange_count(self._h))      # (host emulation: direct callbacks, 0)
             # every entry was written by exactly one rank (zeros elsewhere): the sum is the full vector
             x, g, lam_x, lam_g = (self._sum_over_ranks(a) for a in (x, g, lam_x, lam_g))
         return {"x": x, "f": float(f[0]), "g": g, "lam_x": lam_x, "lam_g": lam_g, "lam_p": np.zeros(ps.n_opt_p)}

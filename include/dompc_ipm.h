@@ -235,6 +235,9 @@ int dompc_rccl_init(dompc_handle* h, const char* librccl_path, const uint8_t id[
 int64_t dompc_exchange_doubles(const dompc_handle* h, int32_t world, int32_t n_cut);
 /* desc == NULL switches sharding off again */
 int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* desc);
+/* exchanges (element-wise SUMs over the exchange buffer) the last sharded solve asked for; divided by its iteration count:
+ * the collectives per interior-point iteration */
+int64_t dompc_last_exchange_count(const dompc_handle* h);
 
 /* ---- batched plant integration ---------------------------------------------------------
  * Replaces the integrator object of do_mpc.simulator.Simulator (do_mpc/simulator.py:381-416:
