@@ -3959,14 +3959,32 @@ DOMPC_DEV inline double comp_err(const Comp& C, double mu) { return C.smax >= C.
 #ifndef DOMPC_FW
 #define DOMPC_FW 8                     // elements per thread and trip (measured on MI355X, industrial_poly B = 4096: 4 -> 8 -2 % total time, 16 another -1.5 %)
 #endif
-#define DOMPC_FOR4(n, LOAD, BODY)                                              \
-  for (int g0_ = T.tid; g0_ < (n); g0_ += DOMPC_FW * T.nt) {                   \
-    _Pragma("unroll") for (int u_ = 0; u_ < DOMPC_FW; ++u_) {                  \
+// Round 4 experiment: the width per LOOP (DOMPC_FORN, -DDOMPC_FW_TUNED=1).  A trip is one dependent memory round trip of the wavefront,
+// and with one wavefront per problem a pass over an iterate-sized vector is 14 - 16 of them at 8 elements per thread; loops that read
+// one or two arrays afford 32 elements per thread in the same registers (4 trips), four arrays 16 - 60 instead of 106 trips per
+// iteration over the four vector phases.  Every thread still visits its elements (g = tid mod nt) in increasing order: results bit
+// for bit the same.  Measured (same box, interleaved): 6 176 / 6 179 vs 6 205 / 6 173 steps/s at B = 4096, 6 592 vs 6 602 at 16 384 -
+// nothing: these passes are not bound by their round trips but by the bytes (the memory system as a whole moves ~2.8 TB/s with this
+// access mix), so only fewer bytes would shorten them.  Off by default.
+#ifndef DOMPC_FW_TUNED
+#define DOMPC_FW_TUNED 0
+#endif
+#if DOMPC_FW_TUNED && !defined(DOMPC_HOST_EMU)
+#define DOMPC_FW1 32                   // loops over one or two arrays
+#define DOMPC_FW3 16                   // three or four arrays
+#else
+#define DOMPC_FW1 DOMPC_FW
+#define DOMPC_FW3 DOMPC_FW
+#endif
+#define DOMPC_FOR4(n, LOAD, BODY) DOMPC_FORN(DOMPC_FW, n, LOAD, BODY)
+#define DOMPC_FORN(FW_, n, LOAD, BODY)                                         \
+  for (int g0_ = T.tid; g0_ < (n); g0_ += (FW_) * T.nt) {                      \
+    _Pragma("unroll") for (int u_ = 0; u_ < (FW_); ++u_) {                     \
       const int g_ = g0_ + u_ * T.nt;                                          \
       const int gc_ = g_ < (n) ? g_ : g0_;                                     \
       LOAD(u_, gc_)                                                            \
     }                                                                          \
-    _Pragma("unroll") for (int u_ = 0; u_ < DOMPC_FW; ++u_) {                  \
+    _Pragma("unroll") for (int u_ = 0; u_ < (FW_); ++u_) {                     \
       const int g_ = g0_ + u_ * T.nt;                                          \
       if (g_ < (n)) { BODY(u_, g_) }                                           \
     }                                                                          \
@@ -3980,10 +3998,10 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, const Comp* pre) {
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // e_d, e_p, sum|y|, obj, theta, smax, -smin, sum z
   Comp C = pre ? *pre : Comp{-INFINITY, INFINITY, 0.0};
   if (pre) {
-    double rd_[DOMPC_FW];
+    double rd_[DOMPC_FW3];
 #define L_(u, g) rd_[u] = Q.rd[g]; if (KAPPA_D != 0.0) rd_[u] += KAPPA_D * Q.mu * one_sided(Q.lb[g], Q.ub[g]);
 #define B_(u, g) if (sh_cnt(A, mk_x(A, g))) v[0] = fmax(v[0], fabs(rd_[u]));
-    DOMPC_FOR4(A.n_opt_x, L_, B_)
+    DOMPC_FORN(DOMPC_FW3, A.n_opt_x, L_, B_)
 #undef L_
 #undef B_
   } else {
@@ -4012,10 +4030,10 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, const Comp* pre) {
     }
   }
   {
-    double c_[DOMPC_FW], y_[DOMPC_FW];
+    double c_[DOMPC_FW1], y_[DOMPC_FW1];
 #define L_(u, g) c_[u] = Q.c[g]; y_[u] = Q.lam[g];
 #define B_(u, g) if (sh_cnt(A, mk_g(A, g))) { v[1] = fmax(v[1], fabs(c_[u])); v[2] += fabs(y_[u]); v[4] += fabs(c_[u]); }
-    DOMPC_FOR4(A.n_g, L_, B_)
+    DOMPC_FORN(DOMPC_FW1, A.n_g, L_, B_)
 #undef L_
 #undef B_
   }
@@ -4122,7 +4140,7 @@ DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, do
   LogAcc La{1.0, 0, 0};
   double lin = 0.0;                  // distances to the single bound of the one-sided variables (damping term, KAPPA_D)
   {                                  // trial point and its barrier terms in one pass
-    double x_[DOMPC_FW], d_[DOMPC_FW], l_[DOMPC_FW], u2_[DOMPC_FW];
+    double x_[DOMPC_FW3], d_[DOMPC_FW3], l_[DOMPC_FW3], u2_[DOMPC_FW3];
 #define L_(u, g) x_[u] = Q.x[g]; d_[u] = Q.dx[g]; l_[u] = Q.lb[g]; u2_[u] = Q.ub[g];
 #define B_(u, g)                                                                               \
     if (mk_x(A, g)) {                                                                      \
@@ -4134,7 +4152,7 @@ DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, do
         if (KAPPA_D != 0.0) { const double os_ = one_sided(l_[u], u2_[u]); lin += os_ > 0.0 ? xt_ - l_[u] : (os_ < 0.0 ? u2_[u] - xt_ : 0.0); } \
       }                                                                                    \
     }
-    DOMPC_FOR4(nX, L_, B_)
+    DOMPC_FORN(DOMPC_FW3, nX, L_, B_)
 #undef L_
 #undef B_
   }
@@ -4149,10 +4167,10 @@ DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, do
   r3[0] += trial_edges(T, Q);
   T.sync();
   {
-    double c_[DOMPC_FW];
+    double c_[DOMPC_FW1];
 #define L_(u, g) c_[u] = Q.ct[g];
 #define B_(u, g) if (sh_cnt(A, mk_g(A, g))) r3[1] += fabs(c_[u]);
-    DOMPC_FOR4(A.n_g, L_, B_)
+    DOMPC_FORN(DOMPC_FW1, A.n_g, L_, B_)
 #undef L_
 #undef B_
   }
@@ -4226,10 +4244,10 @@ DOMPC_DEV inline Comp accept_pass(const Thr& T, const Prob& Q, double alpha, dou
     }
   }
   {
-    double y_[DOMPC_FW], dy_[DOMPC_FW];
+    double y_[DOMPC_FW1], dy_[DOMPC_FW1];
 #define L_(u, g) y_[u] = Q.lam[g]; dy_[u] = Q.dlam[g];
 #define B_(u, g) if (mk_g(A, g)) Q.lam[g] = y_[u] + alpha * dy_[u];
-    DOMPC_FOR4(A.n_g, L_, B_)
+    DOMPC_FORN(DOMPC_FW1, A.n_g, L_, B_)
 #undef L_
 #undef B_
   }
