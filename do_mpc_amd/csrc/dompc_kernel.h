@@ -103,6 +103,9 @@ constexpr int MAX_FILTER = 48;
 #ifndef DOMPC_SHARD
 #define DOMPC_SHARD 0
 #endif
+#ifndef DOMPC_GJ_U
+#define DOMPC_GJ_U 0.01              // threshold of the pivot test of the collocation-block elimination in its natural order (|a_kk| >= u max|a_ik|); a huge
+#endif                               // value sends every edge through the elimination with partial pivoting (test of that fallback)
 #ifndef DOMPC_KO
 #define DOMPC_KO 0                  // measurement aid (tools/gpu_sweep_ko.py; WRONG RESULTS): pieces of the edge sweep left out, to see what each one
 #endif                              // costs in THROUGHPUT under real concurrency: 1 factorisation, 2 condensing, 4 record stores, 8 model evaluation,
@@ -1458,7 +1461,7 @@ DOMPC_DEV inline int edge_factor_body(const Prob& Q, int e, double mu, int lane,
   constexpr int NRHS = NA + 1;
   constexpr int NCX = 2 * R + NRHS;                      // extended columns: G_cc | G_y r | I
   constexpr int CPX = (NCX + GS_C - 1) / GS_C;
-  constexpr double GJ_U = 0.01;
+  constexpr double GJ_U = DOMPC_GJ_U;        // (threshold of the natural pivot order, as in the blocked variant)
   double bc[CPX][RA];
   // column cx of the collocation rows (row r = (jj, a): point j = jj + 1, state a), straight from the model-output
   // record (optimizer.py:951-963):  G_cc (slot sl, state b): [sl == jj] J_jj[a][b] - [a == b] C[sl+1][j];
