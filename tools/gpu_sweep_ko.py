@@ -14,6 +14,10 @@ VARIANTS = [("full", ""), ("no factorisation", "DOMPC_KO=1"), ("no condensing", 
             ("no factor+condense", "DOMPC_KO=3"), ("loads+stores only", "DOMPC_KO=11"), ("nothing but the loop", "DOMPC_KO=63")]
 
 
+if os.environ.get("DOMPC_KO_VARIANTS"):      # "label:defs;label:defs" - other build switches timed the same way
+    VARIANTS = [tuple(v.split(":", 1)) for v in os.environ["DOMPC_KO_VARIANTS"].split(";")]
+
+
 def build_all():
     import __graft_entry__ as g
     from do_mpc_amd import build as nb
