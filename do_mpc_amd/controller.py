@@ -582,7 +582,7 @@ class MPC:
             name=type(m).__name__, nz=m.n_z, z_sym=m._z.cat.nodes(), alg=alg, sz=self._z_scaling.master,
             sp=self._p_scaling.master,
             rterm_expr=(self.rterm_expr.nodes()[0] if self.rterm_expr is not None else None),
-            uprev_sym=self.u_prev.cat.nodes(), nl_colloc=self._nl_colloc,
+            uprev_sym=self.u_prev.cat.nodes(), nl_colloc=self._nl_colloc, eps_global=ps.eps_global,
             **{k: v for k, v in (getattr(self, "_estimator_opts", None) or {}).items()
                if k in ("arrival", "xprev_sym", "lterm_end", "nl_dup")})
 
@@ -615,6 +615,8 @@ class MPC:
         assert self.flags["setup"] is True, "MPC was not setup yet. Please call MPC.setup()."
         if self.rterm_expr is not None:
             raise NotImplementedError("structured HIP backend: tree sharding with a user-defined rterm expression")
+        if self.structure.eps_global:
+            raise NotImplementedError("structured HIP backend: tree sharding with nl_cons_single_slack")
         if not getattr(self.S, "shard_capable", False):
             # the sharding-aware kernel is a second code object of the same model (build.py): swap the solver
             ctor = dict(self.S._ctor)

@@ -187,12 +187,12 @@ DOMPC_DEV inline double dae_edge_f(const Prob& Q, int e, const double* xv, const
     double d[NE1];
     for (int blk = 0; blk < NLB; ++blk)
       dompc_nlcons_f(NL_COLLOC ? w + nl_pt(blk) * NX : xn, un, zb + (NL_COLLOC ? nl_pt(blk) * NZ : 0), tvp, pp, d + blk * NEB);
-    const double* eps = (NS > 0) ? xv + A.node_eps_off[n] : nullptr;
+    const double* eps = (NSE > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
       if (nl_slack(i) >= 0) d[i] -= eps[nl_slack(i)];
       cv[row0 + NW + NX + i] = d[i] - sv[e * NE1 + i];
     }
-    for (int q = 0; q < NS; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
+    for (int q = 0; q < NSE; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
   }
   return obj;
 }
@@ -550,7 +550,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     if (last_stage) obj += om * mo[MO_MT];
     if (RT_CUSTOM) obj += Ld[DG_RT];
     if (NE > 0) {
-      const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
+      const double* eps = (NSE > 0) ? Q.x + A.node_eps_off[n] : nullptr;
       for (int i = 0; i < NE; ++i) {
         double d = mo[MO_NL + (i / NEB1) * NL_STRIDE + i % NEB1];
         if (nl_slack(i) >= 0) d -= eps[nl_slack(i)];
@@ -563,7 +563,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
         S_[ES_SIGS + i] = sigma_of(sv, l, u, Q.zsl[si], Q.zsu[si]);
         S_[ES_RSN + i] = -yd[i] + bar_grad(sv, l, u, mu);
       }
-      for (int q = 0; q < NS; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
+      for (int q = 0; q < NSE; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
     }
     S_[ES_OBJ] = obj;
   }
@@ -592,7 +592,7 @@ DOMPC_DEV inline void forward_edge_dae(const Thr& T, const Prob& Q, int e, doubl
   for (int i = lane; i < NE; i += GS) {
     double t = S_[ES_RDN + i];
     for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_JD + i * NA + b) * Ld[DF_DY + b];
-    if (nl_slack(i) >= 0) t -= Q.dx[A.node_eps_off[n] + nl_slack(i)];
+    if (!EPS_GLOBAL && nl_slack(i) >= 0) t -= Q.dx[A.node_eps_off[n] + nl_slack(i)];
     Q.ds[e * NE1 + i] = t;
     const double dyd = (S_[ES_SIGS + i] + delta) * t + S_[ES_RSN + i];
     Q.dlam[row0 + NW + NX + i] = dyd;

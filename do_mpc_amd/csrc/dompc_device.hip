@@ -30,7 +30,7 @@ namespace dompc {
 DOMPC_HD inline void model_info(const int32_t* in, int64_t* out) {
   // in: n_opt_x, n_g, n_edges, e_pad, n_nodes
   WsLayout L = ws_layout(in[0], in[1], in[2], in[3], in[4]);
-  out[0] = NX; out[1] = NU; out[2] = NP; out[3] = NTVP; out[4] = NE; out[5] = NS;
+  out[0] = NX; out[1] = NU; out[2] = NP; out[3] = NTVP; out[4] = NE; out[5] = NSE;
   out[6] = DEG; out[7] = NI; out[8] = M;
   out[9] = L.total;
   out[10] = SWEEP_BLOCK;

@@ -38,7 +38,18 @@ namespace dompc {
 #endif
 
 constexpr int NX = DOMPC_NX, NU = DOMPC_NU, NP = DOMPC_NP, NTVP = DOMPC_NTVP;
-constexpr int NS = DOMPC_NS, NZ = DOMPC_NZ;
+// nl_cons_single_slack (_mpc.py:1120-1123, 1228: ONE `_eps` entry per scenario slot for all stages, `eps[min(k, n_eps - 1), s]`): the slack
+// variables are then shared by nodes of several stages (and, with n_robust >= 2, of several sub-trees) - no longer decision variables of a
+// node.  Generated header: DOMPC_EPS_GLOBAL 1.  They leave the structured part (NS = 0: a node decides on u only; the rows and the cost
+// terms still READ them, NSE) and are solved for by a Schur complement on top of the structured solve, solve_problem: eps_schur_*.
+#ifndef DOMPC_EPS_GLOBAL
+#define DOMPC_EPS_GLOBAL 0
+#endif
+constexpr bool EPS_GLOBAL = DOMPC_EPS_GLOBAL != 0 && DOMPC_NS > 0 && DOMPC_NE > 0;
+constexpr int NS = EPS_GLOBAL ? 0 : DOMPC_NS;       // slack entries that are decision variables of a node
+constexpr int NSE = DOMPC_NS;                       // slack entries an edge's rows / cost terms read (at node_eps_off of its parent node)
+constexpr int NVG_MAX = 32;                         // EPS_GLOBAL: at most this many shared slack variables (n_eps * S * ns)
+constexpr int NZ = DOMPC_NZ;
 constexpr int DEG = DOMPC_DEG, NI = DOMPC_NI, M = DOMPC_M;
 // nl_cons rows of an edge: ONE evaluation of the user's expressions at (x_n, u, z of the first point) (_mpc.py:1239-1246) or,
 // with nl_cons_check_colloc_points, one evaluation per stored point i of the interval at (_x[k+1,s,i], u, _z[k,s,i])
@@ -198,7 +209,7 @@ struct WsLayout {
   int64_t x, zl, zu, lb, ub, dx, gf, rd, xt, dx_sv;
   int64_t lam, dlam, c, ct, dlam_sv;
   int64_t s, zsl, zsu, sl, su, ds, st, ds_sv;
-  int64_t ew, es, nd, mo, total;
+  int64_t ew, es, nd, mo, gsc, total;
 };
 
 DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad, int n_nodes) {
@@ -216,6 +227,7 @@ DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad,
   L.es = take((int64_t)ES_SIZE * n_edges);
   L.nd = take((int64_t)ND_SIZE * n_nodes);
   L.mo = take((int64_t)MO_REC * n_edges);
+  L.gsc = take(EPS_GLOBAL ? NVG_MAX * (NVG_MAX + 4) : 0);      // shared slack variables: Schur complement, its Cholesky factor, right-hand side / step
   o += 256;                       // slack: block-granular staging reads of the last records may run past their end
   L.total = o;
   return L;
@@ -580,7 +592,7 @@ struct Prob {
   double *lb_own, *ub_own;                           // this slot's copies of the bounds (lb / ub: the ones the phases read, prob_bounds)
   double *lam, *dlam, *c, *ct, *dlam_sv;
   double *s, *zsl, *zsu, *sl, *su, *ds, *st, *ds_sv;
-  double *ew, *es, *nd, *mo;
+  double *ew, *es, *nd, *mo, *gsc;
   int e_pad;
   double sf;                                         // objective scaling
   double mu;
@@ -609,7 +621,7 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   p.lam = w + L.lam; p.dlam = w + L.dlam; p.c = w + L.c; p.ct = w + L.ct; p.dlam_sv = w + L.dlam_sv;
   p.s = w + L.s; p.zsl = w + L.zsl; p.zsu = w + L.zsu; p.sl = w + L.sl; p.su = w + L.su;
   p.ds = w + L.ds; p.st = w + L.st; p.ds_sv = w + L.ds_sv;
-  p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo;
+  p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo; p.gsc = w + L.gsc;
   p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0; p.dsw = 0.0; p.slot = slot;
   return p;
 }
@@ -768,12 +780,12 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
   if (NE > 0) {
     double d[NE1];
     dompc_nlcons_f(xn, un, nullptr, tvp, pp, d);
-    const double* eps = (NS > 0) ? xv + A.node_eps_off[n] : nullptr;
+    const double* eps = (NSE > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
       if (nl_slack(i) >= 0) d[i] -= eps[nl_slack(i)];
       cv[row0 + NW + NX + i] = d[i] - sv[e * NE1 + i];
     }
-    for (int q = 0; q < NS; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
+    for (int q = 0; q < NSE; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
   }
   return obj;
 }
@@ -2429,7 +2441,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       if (k == A.N - 1) obj += PF ? om * pf_mt0 : om * mo[MO_MT];
       if (RT_CUSTOM) obj += Ld[EL_RT];
       if (NE > 0) {
-        const double* eps = (NS > 0) ? Q.x + A.node_eps_off[n] : nullptr;
+        const double* eps = (NSE > 0) ? Q.x + A.node_eps_off[n] : nullptr;
         for (int i = 0; i < NE; ++i) {
           double d = MOV(MO_NL + i);
           if (nl_slack(i) >= 0) d -= eps[nl_slack(i)];
@@ -2441,7 +2453,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           S_[ES_SIGS + i] = sigma_of(sv, l, u, Q.zsl[si], Q.zsu[si]);
           S_[ES_RSN + i] = -yd[i] + bar_grad(sv, l, u, mu);
         }
-        for (int q = 0; q < NS; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
+        for (int q = 0; q < NSE; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
       }
       S_[ES_OBJ] = obj;
     }
@@ -3795,7 +3807,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       for (int i = lane; i < NE; i += GS) {
         double t = S_[ES_RDN + i];
         for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_JD + i * NA + b) * Ld[RF_DY + b];
-        if (nl_slack(i) >= 0) t -= Q.dx[A.node_eps_off[n] + nl_slack(i)];
+        if (!EPS_GLOBAL && nl_slack(i) >= 0) t -= Q.dx[A.node_eps_off[n] + nl_slack(i)];      // (shared slacks: their step is part of the residual, eps_schur_apply)
         Q.ds[e * NE1 + i] = t;
         Q.dlam[row0 + NW + NX + i] = (S_[ES_SIGS + i] + delta) * t + S_[ES_RSN + i];
       }
@@ -4375,6 +4387,72 @@ DOMPC_DEV inline void run_forward(const Thr& T, const Prob& Q, int b, int slot, 
 #endif
 }
 
+
+// ================================================================================================
+// Shared slack variables (nl_cons_single_slack, EPS_GLOBAL).  The slack entries e (n_v = n_opt_x - off_eps of them, e_j is read by the
+// nl_cons rows I_j of every edge whose parent node carries node_eps_off = off_eps + j - q) border the structured primal-dual system
+//     [ K   B ] [ d  ]   [ -r   ]        K: the tree-structured system (x, u, w, s, lambda) the sweep + Riccati passes factorise,
+//     [ B'  D ] [ de ] = [ -r_e ]        B = [0; E] with E = d c / d e (-1 in the rows I_j), D = Sigma_e + delta_w,
+// r_e = grad_e f + E' lambda + barrier gradient.  The rows are LINEAR in e and B has entries in constraint rows only, so a structured
+// solve with the constraint residual as an INPUT (the mode of the second-order correction, Prob::soc bit 0) delivers every product that is
+// needed:  d(c + E v) - d(c) = -K^-1 [0; E] v  exactly.  Per iteration: the structured step d(c), one solve per slack for the columns
+// of the Schur complement  S = D + E' (dlam(c + E_j) - dlam(c))_j  (symmetric positive definite iff the inertia of the bordered matrix is
+// the right one: a failed Cholesky factorisation of S escalates delta_w like a failed factorisation inside the Riccati pass), the slack
+// step  S de = -r_e - E' dlam(c),  and the final structured solve at the residual c + E de, which IS the structured part of the full
+// Newton direction - nothing is accumulated from differences.  (n_v + 1 extra linear solves per iteration: the option is a convenience of
+// the reference for small problems, not a throughput path.)  Same NLP, same variables as the reference: the iterates are IPOPT's.
+DOMPC_DEV inline int epsg_off(const KArgs& A) { return A.node_eps_off[0]; }          // (the root reads eps[0, 0]: first entry of the block)
+DOMPC_DEV inline int epsg_n(const KArgs& A) { return A.n_opt_x - A.node_eps_off[0]; }
+// objective gradient and dual residual of the shared slacks at the current iterate (after every sweep of an iterate)
+DOMPC_DEV inline void epsg_grad(const Thr& T, const Prob& Q) {
+  const KArgs& A = *Q.A;
+  const int o = epsg_off(A), nv = epsg_n(A);
+  for (int j = T.tid; j < nv; j += T.nt) {
+    double g = 0.0, r = 0.0;
+    for (int e = 0; e < A.n_edges; ++e) {
+      const int q = j - (A.node_eps_off[A.edge_parent[e]] - o);
+      if (q < 0 || q >= NSE) continue;
+      g += Q.sf * DOMPC_EPS_PEN[q];                                   // (the slack cost is added once per edge, _mpc.py:1254)
+      const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
+      for (int i = 0; i < NE; ++i)
+        if (nl_slack(i) == q) r -= yd[i];
+    }
+    Q.gf[o + j] = g;
+    Q.rd[o + j] = g + r - Q.zl[o + j] + Q.zu[o + j];
+  }
+  T.sync();
+}
+// -(E' v)_j = sum of v over the rows that read slack j
+DOMPC_DEV inline double epsg_rowsum(const Prob& Q, int j, const double* v, const double* v0) {
+  const KArgs& A = *Q.A;
+  const int o = epsg_off(A);
+  double t = 0.0;
+  for (int e = 0; e < A.n_edges; ++e) {
+    const int q = j - (A.node_eps_off[A.edge_parent[e]] - o);
+    if (q < 0 || q >= NSE) continue;
+    const int r0 = A.edge_row0[e] + NW + NX;
+    for (int i = 0; i < NE; ++i)
+      if (nl_slack(i) == q) t += v[r0 + i] - (v0 ? v0[r0 + i] : 0.0);
+  }
+  return t;
+}
+// Q.c = Q.ct + E v on the rows that read a shared slack (v == nullptr: unit vector j1; j1 < 0 and v == nullptr: Q.c = Q.ct there)
+DOMPC_DEV inline void epsg_residual(const Thr& T, const Prob& Q, const double* v, int j1) {
+  const KArgs& A = *Q.A;
+  const int o = epsg_off(A);
+  for (int e = T.tid; e < A.n_edges; e += T.nt) {
+    const int jo = A.node_eps_off[A.edge_parent[e]] - o;
+    const int r0 = A.edge_row0[e] + NW + NX;
+    for (int i = 0; i < NE; ++i) {
+      const int q = nl_slack(i);
+      if (q < 0) continue;
+      const double ve = v ? v[jo + q] : ((jo + q == j1) ? 1.0 : 0.0);
+      Q.c[r0 + i] = Q.ct[r0 + i] - ve;
+    }
+  }
+  T.sync();
+}
+
 // ================================================================================================
 DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slot) {
   const dompc_options& O = A.opt;
@@ -4499,7 +4577,88 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   }
   auto first_sweep = [&]() {
     ++n_sweeps;
-    return ls_init ? run_sweep(T, Q, b, slot, 1.0, 3, 1.0) : run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(0.0) : 0.0);
+    const int rc = ls_init ? run_sweep(T, Q, b, slot, 1.0, 3, 1.0) : run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(0.0) : 0.0);
+    if (EPS_GLOBAL) epsg_grad(T, Q);
+    return rc;
+  };
+  // ---- shared slack variables (EPS_GLOBAL): Schur complement on top of the structured solve, see epsg_* above.
+  // workspace Q.gsc: S / its Cholesky factor (n_v x n_v, leading dimension NVG_MAX), then [flag | rhs / step (NVG_MAX)]
+  // columns of the Schur complement after the structured step of this iterate (Q.dlam = dlam(c)); returns 1 = wrong inertia
+  auto epsg_build = [&](double delta) -> int {
+    const int o = epsg_off(A), nv = epsg_n(A);
+    double* G = Q.gsc;
+    for (int g = T.tid; g < A.n_g; g += T.nt) { Q.dlam_sv[g] = Q.dlam[g]; Q.ct[g] = Q.c[g]; }
+    T.sync();
+    int rc = 0;
+    for (int j = 0; j < nv && !rc; ++j) {
+      epsg_residual(T, Q, nullptr, j);
+      ++n_sweeps;
+      rc = run_sweep(T, Q, b, slot, mu, 1, delta);
+      if (!rc) rc = run_backward(T, Q, b, slot, mu, delta);
+      if (!rc) {
+        run_forward(T, Q, b, slot, mu, delta);
+        for (int jp = T.tid; jp < nv; jp += T.nt) G[jp * NVG_MAX + j] = -epsg_rowsum(Q, jp, Q.dlam, Q.dlam_sv);
+      }
+    }
+    epsg_residual(T, Q, nullptr, -1);                    // Q.c back to c(x)
+    if (T.tid == 0) {
+      int ok = rc ? 0 : 1;
+      for (int j = 0; j < nv && ok; ++j) {
+        const int g = o + j;
+        G[j * NVG_MAX + j] += sigma_of(Q.x[g], Q.lb[g], Q.ub[g], Q.zl[g], Q.zu[g]) + delta;
+      }
+      for (int j = 0; j < nv && ok; ++j) {               // Cholesky, lower triangle in place
+        double dj = G[j * NVG_MAX + j];
+        for (int k = 0; k < j; ++k) dj -= G[j * NVG_MAX + k] * G[j * NVG_MAX + k];
+        if (!(dj > 0.0)) { ok = 0; break; }
+        dj = sqrt(dj);
+        G[j * NVG_MAX + j] = dj;
+        for (int i = j + 1; i < nv; ++i) {
+          double t = 0.5 * (G[i * NVG_MAX + j] + G[j * NVG_MAX + i]);      // (S is symmetric up to rounding)
+          for (int k = 0; k < j; ++k) t -= G[i * NVG_MAX + k] * G[j * NVG_MAX + k];
+          G[i * NVG_MAX + j] = t / dj;
+        }
+      }
+      G[NVG_MAX * NVG_MAX] = ok ? 0.0 : 1.0;
+    }
+    T.sync();
+    return G[NVG_MAX * NVG_MAX] != 0.0;
+  };
+  // slack step and the structured part of the full direction, given the structured step at the CURRENT residual Q.c (its
+  // multiplier steps in `dl`) and the factor of S; Q.ct is free at both call sites (the trial values have been consumed)
+  auto epsg_apply = [&](double delta, const double* dl) -> int {
+    const int o = epsg_off(A), nv = epsg_n(A);
+    double* G = Q.gsc;
+    double* de = G + NVG_MAX * NVG_MAX + 1;
+    for (int j = T.tid; j < nv; j += T.nt) {
+      const int g = o + j;
+      const double re = Q.rd[g] + Q.zl[g] - Q.zu[g] + bar_grad(Q.x[g], Q.lb[g], Q.ub[g], mu);
+      de[j] = -re + epsg_rowsum(Q, j, dl, nullptr);       // -r_e - E' dlam(c)
+    }
+    for (int g = T.tid; g < A.n_g; g += T.nt) Q.ct[g] = Q.c[g];
+    T.sync();
+    if (T.tid == 0) {
+      for (int i = 0; i < nv; ++i) {
+        double t = de[i];
+        for (int k = 0; k < i; ++k) t -= G[i * NVG_MAX + k] * de[k];
+        de[i] = t / G[i * NVG_MAX + i];
+      }
+      for (int i = nv - 1; i >= 0; --i) {
+        double t = de[i];
+        for (int k = i + 1; k < nv; ++k) t -= G[k * NVG_MAX + i] * de[k];
+        de[i] = t / G[i * NVG_MAX + i];
+      }
+    }
+    T.sync();
+    epsg_residual(T, Q, de, -1);
+    ++n_sweeps;
+    int rc = run_sweep(T, Q, b, slot, mu, 1, delta);
+    if (!rc) rc = run_backward(T, Q, b, slot, mu, delta);
+    if (!rc) run_forward(T, Q, b, slot, mu, delta);
+    epsg_residual(T, Q, nullptr, -1);
+    for (int j = T.tid; j < nv; j += T.nt) Q.dx[o + j] = de[j];
+    T.sync();
+    return rc;
   };
   int bad = first_sweep();
   if (O.obj_scaling) {
@@ -4613,10 +4772,15 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
 
     // ---- search direction with inertia correction (delta_w on all primal variables)
     double delta = 0.0;
-    bool first_try = true, dir_ok = true;
+    bool first_try = true, dir_ok = true, recs_dirty = false;
     while (true) {
       c_t = prof_clock();
-      const int fail = (singular0 && delta == 0.0) ? 1 : run_backward(T, Q, b, slot, mu, delta);
+      int fail = (singular0 && delta == 0.0) ? 1 : run_backward(T, Q, b, slot, mu, delta);
+      if (EPS_GLOBAL && !fail) {
+        run_forward(T, Q, b, slot, mu, delta);            // structured step at c(x), then the Schur complement of the shared slacks
+        fail = epsg_build(delta);
+        recs_dirty = true;                                // (the vector parts of the records now belong to the last column's residual)
+      }
       c_bwd += prof_clock() - c_t;
       if (!fail) break;
       if (delta == 0.0) {
@@ -4626,17 +4790,21 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         first_try = false;   // (IPOPT: the larger factor only on the very first increase)
         if (delta > O.delta_w_max) { dir_ok = false; break; }
       }
-      if (NW > 0 && delta != Q.dsw) {
+      if ((NW > 0 && delta != Q.dsw) || (EPS_GLOBAL && recs_dirty)) {
         // the condensed blocks hold another inertia correction (Q~(delta) = Q~ + delta W'W, q~ likewise): the sweep is
         // repeated with this one folded in - W is not kept beyond the sweep, so the Riccati pass cannot add the
         // difference itself.  Rare: under `singular0` the first delta of an iteration is known before its sweep.
         ++n_sweeps;
         if (run_sweep(T, Q, b, slot, mu, 0, delta)) { dir_ok = false; break; }
+        recs_dirty = false;
       }
     }
     if (!dir_ok) { status = 3; break; }
     if (delta > 0.0) { delta_last = delta; ++n_reg; }
-    c_t = prof_clock(); run_forward(T, Q, b, slot, mu, delta); c_fwd += prof_clock() - c_t;
+    c_t = prof_clock();
+    if (EPS_GLOBAL) { if (epsg_apply(delta, Q.dlam_sv)) { status = 3; break; } }
+    else run_forward(T, Q, b, slot, mu, delta);
+    c_fwd += prof_clock() - c_t;
 
     // ---- fraction to the boundary, directional derivative of the barrier function
     c_t = prof_clock();
@@ -4731,6 +4899,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
           if (run_sweep(T, Q, b, slot, mu, 1, delta)) break;
           if (run_backward(T, Q, b, slot, mu, delta)) break;
           run_forward(T, Q, b, slot, mu, delta);
+          if (EPS_GLOBAL && epsg_apply(delta, Q.dlam)) break;
           double q5[5];
           step_rules(q5);
           const double a_s = (q5[0] > tau) ? tau / q5[0] : 1.0;
@@ -4787,6 +4956,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     ++it;
     c_t = prof_clock(); bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(delta_last) : 0.0); c_sweep += prof_clock() - c_t;
     ++n_sweeps;
+    if (EPS_GLOBAL) epsg_grad(T, Q);
     if (KAPPA_D != 0.0) Q.mu = mu;
     c_t = prof_clock(); E = measure(T, Q, &Cp); c_meas += prof_clock() - c_t;
   }

@@ -47,7 +47,7 @@ def _sym_hessian_upper(L: sym.Node, v: List[sym.Node]):
 def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, mterm, nl_exprs,
                 nl_slack_index, eps_penalty, sx, su, rterm, h_scale, deg, ni, discrete, C, D,
                 name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None, rterm_expr=None, uprev_sym=(), nl_colloc=False,
-                arrival=None, xprev_sym=(), lterm_end=False, nl_dup=False) -> str:
+                arrival=None, xprev_sym=(), lterm_end=False, nl_dup=False, eps_global=False) -> str:
     """Return the text of the generated header.
 
     x_sym/u_sym/z_sym/tvp_sym/p_sym: lists of sym.Node (the model's own symbols, unscaled).
@@ -262,6 +262,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         *(["#define DOMPC_FREE_ROOT 1      // estimator: free initial state with the arrival cost dompc_aterm (no initial-condition rows)"] if arrival is not None else []),
         *(["#define DOMPC_LT_END 1         // estimator: the stage cost reads the END state of the interval"] if lterm_end else []),
         *(["#define DOMPC_NL_DUP 1         // estimator: the nl_cons rows of the last evaluated point once more"] if nl_dup and ne else []),
+        *(["#define DOMPC_EPS_GLOBAL 1     // nl_cons_single_slack: the slack variables are shared by all stages (Schur complement in the solver)"] if eps_global and ne and ns else []),
         f"#define DOMPC_DEG {deg if not discrete else 0}", f"#define DOMPC_NI {ni if not discrete else 1}",
         f"#define DOMPC_M {M}", f"#define DOMPC_DISCRETE {1 if discrete else 0}",
         _fmt_array("DOMPC_C", np.asarray(C).reshape(-1) if not discrete else [0.0]),

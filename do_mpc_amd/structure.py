@@ -79,6 +79,7 @@ class ProblemStructure:
     n_eps: int
     discrete: bool
     tables: Dict[str, np.ndarray] = field(default_factory=dict)
+    eps_global: bool = False     # nl_cons_single_slack: the slack variables are shared by all stages
 
     # -- sizes
     @property
@@ -173,8 +174,17 @@ def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust,
     if open_loop and S > 1:
         raise NotImplementedError("structured HIP backend: open_loop=True couples all scenarios of a stage "
                                   "(shared input) and is not tree-structured")
-    if single_slack and ns > 0 and N > 1:
-        raise NotImplementedError("structured HIP backend: nl_cons_single_slack couples all stages")
+    # nl_cons_single_slack (_mpc.py:1120-1123, 1228): one `_eps` entry per scenario slot for ALL stages.  The slacks then are no
+    # decision variables of a node; the kernels take them out of the tree-structured part and solve for them by a Schur
+    # complement (csrc/dompc_kernel.h: EPS_GLOBAL) - one extra linear solve per slack variable and iteration.
+    ps.eps_global = bool(single_slack and ns > 0 and N > 1)
+    if ps.eps_global:
+        if S * ns > 32:
+            raise NotImplementedError("structured HIP backend: nl_cons_single_slack with {} shared slack variables "
+                                      "(scenarios x slack entries); the kernels handle at most 32".format(S * ns))
+        if n_robust >= N:
+            raise NotImplementedError("structured HIP backend: nl_cons_single_slack with n_robust = n_horizon "
+                                      "(slack entries of scenario slots that no node reads)")
 
     n_branches = [n_comb if k < n_robust else 1 for k in range(N)]
     n_scen = [n_comb ** min(k, n_robust) for k in range(N + 1)]

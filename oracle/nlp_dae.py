@@ -37,7 +37,7 @@ class OracleNLPDae:
         self.n_comb = n_comb = self.p_values.shape[0]
         n_robust = c["n_robust"]
         self.S = S = n_comb ** n_robust
-        assert not c["open_loop"] and not c["nl_cons_single_slack"]
+        assert not c["open_loop"]
         self.nl = c["nl_cons"]
         # nl_cons rows per edge: one evaluation at (x_n, u, z first point), or with nl_cons_check_colloc_points one per stored
         # point i of the interval at (`_x[k+1, s, i]`, u, `_z[k, s, i]`), s = the PARENT's scenario index (_mpc.py:1229-1246)
@@ -47,7 +47,7 @@ class OracleNLPDae:
         self.ne = self.neb * self.nlb
         self.soft = [i for i, nc in enumerate(self.nl) if nc["soft"]]
         self.n_slack = len(self.soft)
-        self.n_eps = N
+        self.n_eps = 1 if c["nl_cons_single_slack"] else N       # (_mpc.py:1120-1123)
         self.sx, self.su = np.asarray(c["x_scaling"], float), np.asarray(c["u_scaling"], float)
         self.sz = np.asarray(c.get("z_scaling", np.ones(nz)), float)
         self.h = c["t_step"] / self.ni
@@ -184,7 +184,7 @@ class OracleNLPDae:
         self.col_zl = np.array([self.iz(kk, ss, self.MZ - 1) for kk, ss in zip(k, s)])    # `_z[k, s, -1]` (stage cost)
         self.col_zn = np.array([self.iz(kk, ss, 0) for kk, ss in zip(k, s)])              # `_z[k, s, 0]` (nl_cons)
         self.row0 = nx + np.arange(self.E) * self.rows_per_edge
-        self.col_eps = np.array([self.ieps(kk, ss) for kk, ss in zip(k, s)]) if self.n_slack else None
+        self.col_eps = np.array([self.ieps(min(kk, self.n_eps - 1), ss) for kk, ss in zip(k, s)]) if self.n_slack else None     # (_mpc.py:1228)
         self.col_uprev = np.array([self.iu(kk - 1, self.parent[kk, ss]) if kk > 0 else -1 for kk, ss in zip(k, s)])
 
     def _nl_cols(self, blk):

@@ -425,6 +425,46 @@ def check_nl_cons_at_collocation_points(make_mpc, name, over, x0):
     return mpc
 
 
+# nl_cons_single_slack (_mpc.py:1120-1123, 1228): one `_eps` entry per scenario slot for ALL stages - shared variables, a Schur complement on
+# top of the structured solve (csrc/dompc_kernel.h: EPS_GLOBAL).  Starts with T_R above the soft limit of 140: the shared slacks end active.
+SINGLE_SLACK_CASES = [
+    ("tree9", dict(), np.array([0.8, 0.5, 141.5, 138.0])),                                   # the shipped tree: 9 slacks, one per scenario chain (the root reads slack 0)
+    ("tree9_nrobust2", dict(n_robust=2, n_horizon=8, uncertainty=dict(alpha=[1.0, 1.05, 0.95], beta=[1.0])),
+     np.array([0.8, 0.5, 141.5, 138.0])),                                                    # slack s shared by nodes (1, s) and (k >= 2, s): not on one root-to-leaf path
+    ("chain_colloc_rows", dict(n_robust=0, nl_cons_check_colloc_points=True), np.array([0.8, 0.5, 146.0, 138.0])),    # dense edge path: rows on the edge unknowns
+]
+
+
+def check_single_slack(make_mpc, over, x0):
+    """`nl_cons_single_slack=True` on the CSTR example against the oracle's solve of the restated NLP (the flat sparse NLP has no
+    trouble with shared variables): same iteration and regularisation counts, final iterate and multipliers, the layout of `_eps`
+    (one repeat), and the slacks are in use.  Measured: 45 = 45 / 37 = 37 / 35 = 35 iterations, primal 8e-14 / 3e-14 / 1e-14.
+    [NO REFERENCE FIXTURE: oracle-or-equivalence check, not a reproduction of a stored reference run]"""
+    over = dict(over, nl_cons_single_slack=True)
+    mpc = make_mpc("CSTR", **over)
+    nlp = oracle_nlp("CSTR", **over)
+    ps = mpc.structure
+    assert (nlp.n_opt_x, nlp.n_g) == (ps.n_opt_x, ps.n_g) and ps.n_eps == 1 and ps.eps_global
+    assert mpc.opt_x_num.layout.resolve(("_eps",)).size == ps.S * ps.ns == ps.n_opt_x - ps.off_eps
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    mpc.make_step(x0)
+    st = mpc.solver_stats
+    r = ipm.solve(nlp, nlp.initial_guess(x0), mpc.opt_p_num.master.copy())
+    assert st["success"] and r["stats"]["success"]
+    assert st["iter_count"] == r["stats"]["iter_count"] and st["n_reg"] == r["stats"]["n_reg"]
+    used = np.ones(nlp.n_opt_x, bool)
+    used[ps.tables["dummy_idx"]] = False
+    assert used[ps.off_eps:].all()
+    assert relerr(mpc.opt_x_num.master[used], r["x"][used]) < 1e-9
+    assert np.max(np.abs(mpc.lam_g_num - r["lam_g"])) < 1e-5 * max(1.0, np.max(np.abs(r["lam_g"])))
+    assert np.max(mpc.opt_x_num.master[ps.off_eps:]) > 0.5                                   # (a shared slack is active)
+    # stationarity w.r.t. the shared slacks with OUR multipliers: (edges reading it) x penalty - sum of its rows' multipliers + lam_x = 0
+    rd = nlp.grad(mpc.opt_x_num.master, mpc.opt_p_num.master) + nlp.jac(mpc.opt_x_num.master, mpc.opt_p_num.master).T @ mpc.lam_g_num + mpc.lam_x_num
+    assert np.max(np.abs(rd[ps.off_eps:])) < 1e-6
+    return mpc
+
+
 # ---------------------------------------------------------------------------------------------- moving horizon estimation
 def oracle_mhe():
     from oracle.mhe import OracleMHE

@@ -201,6 +201,11 @@ def test_nl_cons_at_collocation_points(name, over, x0):
     pc.check_nl_cons_at_collocation_points(make_mpc, name, over, x0)
 
 
+@pytest.mark.parametrize("over,x0", [c[1:] for c in pc.SINGLE_SLACK_CASES], ids=[c[0] for c in pc.SINGLE_SLACK_CASES])
+def test_single_slack_shared_by_all_stages(over, x0):
+    pc.check_single_slack(make_mpc, over, x0)
+
+
 @pytest.mark.parametrize("name", ["CSTR", "batch_reactor", "industrial_poly"])
 def test_dense_edge_path_reproduces_the_fast_path(name, monkeypatch):
     """-DDOMPC_FORCE_DENSE=1 sends a model without algebraic states through the dense edge path of the DAE models
