@@ -274,8 +274,6 @@ class MHE:
         s, m = self.settings, self.model
         s.check_for_mandatory_settings()
         self._check_validity()
-        if s.nl_cons_single_slack:
-            raise NotImplementedError("structured HIP backend: nl_cons_single_slack couples all stages")
         nx, nu, nw, nv, ny, npe = m.n_x, m.n_u, m.n_w, m.n_v, m.n_y, self.n_p_est
         N = s.n_horizon
         # (scaling of the estimated parameters: they ride as states of the augmented model, below; a scaling of the FIXED parameters
@@ -357,6 +355,7 @@ class MHE:
         st.state_discretization, st.collocation_type = s.state_discretization, s.collocation_type
         st.collocation_deg, st.collocation_ni = s.collocation_deg, s.collocation_ni
         st.nl_cons_check_colloc_points, st.cons_check_colloc_points = s.nl_cons_check_colloc_points, s.cons_check_colloc_points
+        st.nl_cons_single_slack = bool(s.nl_cons_single_slack)      # (_mhe.py:1046-1049, 1161: one `_eps` entry for all stages - shared variables, csrc: EPS_GLOBAL)
         st.store_full_solution, st.nlpsol_opts = False, dict(s.nlpsol_opts)
         st.gpu_index, st.max_batch, st.block_threads = s.gpu_index, s.max_batch, s.block_threads
         mpc.set_objective(mterm=sym.SX(0.0), lterm=stage)
@@ -384,7 +383,7 @@ class MHE:
         # ---- the reference's layouts
         xs_l, zs_l, us_l = m._x.layout(), m._z.layout(), m._u.layout()
         self._eps_layout = mpc._eps_layout
-        self.n_eps = N
+        self.n_eps = ps.n_eps                                        # (N, or 1 with nl_cons_single_slack)
         self._opt_x_layout = Layout([
             Entry("_x", struct=xs_l, repeat=[N + 1, 1 + M]),
             Entry("_z", struct=zs_l, repeat=[N, max(M, 1)]),

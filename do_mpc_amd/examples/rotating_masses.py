@@ -140,7 +140,7 @@ def build_mhe(model, silence_solver=True, **overrides):
 MHE_W_SCALING = {("_x", "phi_1"): 2.0, ("_x", "phi_m"): 0.5, ("_x", "dphi"): 5.0, ("_u", "phi_m_set"): 3.0, ("_p_est", "Theta_1"): 1e-4}
 
 
-def build_mhe_w(model, silence_solver=True, scaling=None, **overrides):
+def build_mhe_w(model, silence_solver=True, scaling=None, soft_limit=None, **overrides):
     """A second estimator on the model with process noise (build_model(process_noise=True)) for the paths the shipped example leaves
     out: `_w` as decision variables with weight P_w, numeric weights, the box of Theta_1 as bounds of `_p_est`, an nl_cons row on a
     state checked at the states only.  No stored run exists for it: compared with the oracle's solve of the restated NLP."""
@@ -166,7 +166,10 @@ def build_mhe_w(model, silence_solver=True, scaling=None, **overrides):
     mhe.bounds["upper", "_x", "dphi"] = 6
     mhe.bounds["lower", "_p_est", "Theta_1"] = 1e-5
     mhe.bounds["upper", "_p_est", "Theta_1"] = 1e-3
-    mhe.set_nl_cons("phi_1_ub", model.x["phi_1"] - 1.5, 0)
+    if soft_limit is None:
+        mhe.set_nl_cons("phi_1_ub", model.x["phi_1"] - 1.5, 0)
+    else:             # (limit, penalty): the row as a soft constraint (slack variables `_eps`: one per stage, or one with nl_cons_single_slack)
+        mhe.set_nl_cons("phi_1_ub", model.x["phi_1"] - soft_limit[0], 0, soft_constraint=True, penalty_term_cons=soft_limit[1])
     for (group, name), v in (scaling or {}).items():       # e.g. {("_x", "dphi"): 5.0, ("_p_est", "Theta_1"): 1e-4}
         mhe.scaling[group, name] = v
     mhe.setup()

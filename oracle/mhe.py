@@ -47,7 +47,13 @@ class OracleMHE:
         self.off_u = (N + 1) * (M + 1) * nx
         self.off_w = self.off_u + N * nu
         self.off_v = self.off_w + N * nw
-        self.off_p = self.off_v + N * nv
+        # soft constraints (optimizer.py:543-585): one slack entry per soft row, `_eps` repeated n_eps times (_mhe.py:1046-1049:
+        # N, or 1 with nl_cons_single_slack), stage k reads `_eps[min(k, n_eps - 1)]` (:1161); cost penalty * eps once per stage (:1196)
+        self.soft = [i for i, q in enumerate(self.nl) if q.get("soft")]
+        self.n_slack = len(self.soft)
+        self.n_eps = 1 if c.get("nl_cons_single_slack") else N
+        self.off_eps = self.off_v + N * nv
+        self.off_p = self.off_eps + self.n_eps * self.n_slack
         self.n_opt_x = self.off_p + npe
         self.po_pprev = nx
         self.po_pset = nx + npe
@@ -70,6 +76,7 @@ class OracleMHE:
         xs = [sp.symbols(f"xa0:{nx}")] + [sp.symbols(f"xs{i}_0:{nx}") for i in range(M)] + [sp.symbols(f"xb0:{nx}")]
         us, ws, vs = sp.symbols(f"uu0:{nu}"), sp.symbols(f"ww0:{nw}") if nw else (), sp.symbols(f"vv0:{nv}")
         pe = sp.symbols(f"pe0:{npe}") if npe else ()
+        es = sp.symbols(f"ee0:{self.n_slack}") if self.n_slack else ()
         pset = sp.symbols(f"ps0:{self.nps}") if self.nps else ()
         tv = sp.symbols(f"tv0:{self.ntvp}") if self.ntvp else ()
         ym = sp.symbols(f"ym0:{ny}")
@@ -106,10 +113,10 @@ class OracleMHE:
         # evaluated point once more (_mhe.py:1186-1188)
         pts_nl = [xs[1 + b] for b in range(M)] if self.nl_colloc else [xs[0]]
         for xv in pts_nl + [pts_nl[-1]]:
-            for ncn in self.nl:
-                rows.append(at(ncn["expr"], xv))
-        lk = at(c["stage_cost"], xb)
-        svars = [s for blk in xs for s in blk] + list(us) + list(ws) + list(vs) + list(pe)
+            for i, ncn in enumerate(self.nl):
+                rows.append(at(ncn["expr"], xv) - (es[self.soft.index(i)] if i in self.soft else 0))
+        lk = at(c["stage_cost"], xb) + sum(self.nl[i]["penalty"] * es[q] for q, i in enumerate(self.soft))
+        svars = [s for blk in xs for s in blk] + list(us) + list(ws) + list(vs) + list(es) + list(pe)
         self.ns = len(svars)
         lam = sp.symbols(f"lm0:{len(rows)}")
         sig = sp.Symbol("sg")
@@ -147,7 +154,8 @@ class OracleMHE:
         idx += [self.ix(k + 1, s) + np.arange(nx) for s in range(M)]
         idx += [self.ix(k + 1, M) + np.arange(nx)]
         idx += [self.off_u + k * self.nu + np.arange(self.nu), self.off_w + k * self.nw + np.arange(self.nw),
-                self.off_v + k * self.nv + np.arange(self.nv), self.off_p + np.arange(self.npe)]
+                self.off_v + k * self.nv + np.arange(self.nv),
+                self.off_eps + min(k, self.n_eps - 1) * self.n_slack + np.arange(self.n_slack), self.off_p + np.arange(self.npe)]
         return np.concatenate(idx).astype(int)
 
     def _args(self, x, p, k):
@@ -170,6 +178,9 @@ class OracleMHE:
             XL[1:self.N, -1], XU[1:self.N, -1] = c["x_lb"], c["x_ub"]
         lb[self.off_u:self.off_w].reshape(-1, self.nu)[:] = c["u_lb"]
         ub[self.off_u:self.off_w].reshape(-1, self.nu)[:] = c["u_ub"]
+        if self.n_slack:
+            lb[self.off_eps:self.off_p] = 0.0
+            ub[self.off_eps:self.off_p].reshape(-1, self.n_slack)[:] = [self.nl[i].get("max_violation", np.inf) for i in self.soft]
         if self.npe:
             lb[self.off_p:], ub[self.off_p:] = c.get("p_est_lb", -np.inf), c.get("p_est_ub", np.inf)
         self.lbx, self.ubx = lb, ub

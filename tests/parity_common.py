@@ -550,6 +550,38 @@ def check_mhe_with_process_noise(make_mhe_w):
     return mhe
 
 
+def check_mhe_soft_constraint(make_mhe_w, single_slack):
+    """The estimator with its nl_cons row as a SOFT constraint (optimizer.py:543-585; limit -0.1 on phi_1, penalty 0.01: the slack is in
+    use) - one slack per stage, or ONE for all stages with `nl_cons_single_slack` (_mhe.py:1046-1049, 1161: a shared variable, Schur
+    complement in the solver) - against the oracle's solve of the restated reference NLP (oracle/mhe.py with `_eps`) from the same
+    initial guess: same solution (measured 3e-13) and multipliers (1e-11).
+    [NO REFERENCE FIXTURE: oracle-or-equivalence check, not a reproduction of a stored reference run]"""
+    from oracle.mhe import OracleMHE
+    from oracle.models import case_rotating_masses_mhe_w
+    lim, pen = -0.1, 0.01
+    x_sym = case_rotating_masses_mhe_w()["x"]
+    nlp = OracleMHE(case_rotating_masses_mhe_w(nl_cons=[dict(name="phi_1_ub", expr=x_sym[0] - lim, ub=0.0, soft=True, penalty=pen)],
+                                               nl_cons_single_slack=bool(single_slack)))
+    mhe = make_mhe_w(soft_limit=(lim, pen), nl_cons_single_slack=bool(single_slack))
+    assert (nlp.n_opt_x, nlp.n_g, nlp.n_opt_p) == (mhe.n_opt_x, mhe.n_opt_lagr, mhe.n_opt_p)
+    assert nlp.off_p - nlp.off_eps == (1 if single_slack else 6)
+    OP = golden("rotating_masses")["estimator.opt_p_num"][4]
+    N = 6
+    P = np.concatenate([OP[:12], OP[12:12 + 26 * 10].reshape(10, 26)[:N].ravel(), OP[12 + 260:].reshape(10, 5)[-N:].ravel()])
+    init = nlp.initial_guess(np.zeros(8), np.zeros(2), 1e-4)
+    mhe.opt_p_num.master[:] = P
+    mhe.opt_x_num.master[:] = init
+    mhe.solve()
+    r = ipm.solve(nlp, init, P)
+    assert mhe.solver_stats["success"] and r["stats"]["success"]
+    assert relerr(mhe.opt_x_num.master, r["x"]) < 1e-8
+    assert np.max(np.abs(mhe.lam_g_num - r["lam_g"])) < 1e-7 * max(1.0, np.max(np.abs(r["lam_g"])))
+    assert np.max(r["x"][nlp.off_eps:nlp.off_p]) > 0.1                      # (the slack is in use)
+    assert np.array_equal(mhe.opt_x_num["_eps"].ravel() if hasattr(mhe.opt_x_num["_eps"], "ravel") else np.ravel(mhe.opt_x_num["_eps"]),
+                          mhe.opt_x_num.master[nlp.off_eps:nlp.off_p])
+    return mhe
+
+
 def check_mhe_scaling_invariance(make_mhe_w):
     """Scaling of states, inputs and ESTIMATED parameters (_mhe.py:1077-1085: `opt_x_scaling`; the parameter rides as a state of
     the augmented model here) changes the variables of the NLP, not its solution: the scaled estimator's solution times its scaling

@@ -361,6 +361,12 @@ def test_mhe_with_process_noise_against_the_oracle():
     pc.check_mhe_with_process_noise(lambda: ex.build_mhe_w(ex.build_model(process_noise=True)))
 
 
+@pytest.mark.parametrize("single_slack", [False, True], ids=["slack_per_stage", "single_slack"])
+def test_mhe_soft_constraint_against_the_oracle(single_slack):
+    ex = CASES["rotating_masses"]
+    pc.check_mhe_soft_constraint(lambda **kw: ex.build_mhe_w(ex.build_model(process_noise=True), **kw), single_slack)
+
+
 def test_mhe_scaling_of_states_inputs_and_estimated_parameters():
     ex = CASES["rotating_masses"]
     pc.check_mhe_scaling_invariance(lambda **kw: ex.build_mhe_w(ex.build_model(process_noise=True), max_batch=1, **kw))

@@ -111,6 +111,14 @@ def test_mhe_with_process_noise_against_the_oracle():
     pc.check_mhe_with_process_noise(make)
 
 
+@pytest.mark.parametrize("single_slack", [False, True], ids=["slack_per_stage", "single_slack"])
+def test_mhe_soft_constraint_against_the_oracle(single_slack):
+    def make(**kw):
+        with hostemu.patched():
+            return ex.build_mhe_w(ex.build_model(process_noise=True), **kw)
+    pc.check_mhe_soft_constraint(make, single_slack)
+
+
 def test_mhe_scaling_of_states_inputs_and_estimated_parameters():
     def make(**kw):
         with hostemu.patched():
