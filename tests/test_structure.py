@@ -56,8 +56,23 @@ def test_tree_tables_are_consistent_for_deeper_trees():
 def test_unsupported_couplings_are_refused_loudly():
     with pytest.raises(NotImplementedError):
         build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=5, n_comb=3, n_robust=1, discrete=False, open_loop=True)
-    with pytest.raises(NotImplementedError):
-        build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=1, ns=1, deg=2, ni=1, N=5, n_comb=1, n_robust=0, discrete=False, single_slack=True)
+    with pytest.raises(NotImplementedError):      # nl_cons_single_slack: more shared slack variables than the kernels' Schur complement holds
+        build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=1, ns=1, deg=2, ni=1, N=5, n_comb=7, n_robust=2, discrete=False, single_slack=True)
+    with pytest.raises(NotImplementedError):      # ... slack entries of scenario slots that no node reads
+        build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=1, ns=1, deg=2, ni=1, N=2, n_comb=3, n_robust=2, discrete=False, single_slack=True)
+
+
+def test_single_slack_structure():
+    """nl_cons_single_slack (_mpc.py:1120-1123, 1228): one `_eps` repeat, every node of scenario slot s reads entry s"""
+    ps = build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=1, ns=1, deg=2, ni=1, N=5, n_comb=3, n_robust=1, discrete=False, single_slack=True)
+    assert ps.eps_global and ps.n_eps == 1 and ps.n_opt_x == ps.off_eps + 3
+    T = ps.tables
+    for n in range(ps.n_nodes):
+        k = T["node_level"][n]
+        s_ = n - T["level_node_start"][k]
+        assert T["node_eps_off"][n] == (ps.off_eps + s_ if k < 5 else -1)
+    assert not set(range(ps.off_eps, ps.n_opt_x)) & set(T["dummy_idx"])
+    assert not build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=1, ns=1, deg=2, ni=1, N=5, n_comb=3, n_robust=1, discrete=False).eps_global
 
 
 def test_nl_cons_at_collocation_points_rows_and_refusals():
