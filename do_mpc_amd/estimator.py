@@ -17,8 +17,11 @@ four differences, each a switch of the generated header (csrc/dompc_kernel.h: DO
     rows of those states - the same feasible set, objective and barrier terms in the reduced space, hence the same solution
     (the interior-point iterates differ from IPOPT's on the reference's formulation; solutions agree to the solver tolerance);
   * the measurement rows  h(x_{k+1}, u_k, tvp_k, p) + v_k = y_k  are solved for the measurement noise v_k, which only
-    appears in the stage cost: the cost of stage k becomes a function of the END state of the interval (every measurement
-    must carry its noise term - `set_meas(..., meas_noise=True)`, the default);
+    appears in the stage cost: the cost of stage k becomes a function of the END state of the interval.  A measurement
+    WITHOUT noise (`set_meas(..., meas_noise=False)`) is supported where it measures an input variable as it is - the use the
+    reference's documentation suggests (_model.py:693-695): the rows  u - y = 0  fix that input, which leaves the chain problem
+    (it becomes an entry of the stage's time-varying parameters); `opt_x['_u']` hands it back and the multipliers of those rows
+    are the derivatives of the chain problem's Lagrangian w.r.t. it (other noise-free measurements are refused by name);
   * process noise `_w` is one more input of the interval;
   * algebraic states `_z` of the model (and its algebraic equations) are edge unknowns of the chain problem exactly as in the
     controller; the measurement function reads `_z[k, -1]` (:1158) - what a stage cost reads there.  Discrete-time models: the
@@ -278,14 +281,61 @@ class MHE:
         N = s.n_horizon
         # (scaling of the estimated parameters: they ride as states of the augmented model, below; a scaling of the FIXED parameters
         #  cancels in the reference's NLP - `_p_set / _p_set_scaling` times the model's `_p_scaling`, _mhe.py:1127, 1040 - and is ignored)
-        # ---- measurement noise as a function of (x, u, tvp, p, y_meas): every measurement must carry its own noise term
+        # ---- measurement noise as a function of (x, u, tvp, p, y_meas).  A measurement WITH its noise term (the default) is solved for
+        # it: v_k = y_k - h(x_{k+1}, u_k, ...).  A measurement WITHOUT noise (`set_meas(..., meas_noise=False)`, _model.py:670-735) is an
+        # equality row  h - y = 0  (_mhe.py:1144-1158).  Supported where the reference's documentation suggests it ("deactivate
+        # measurement noise for measured inputs: certain variables", _model.py:693-695; the MHE example notebook): the measurement of an
+        # INPUT variable as it is.  That input then is no variable of the chain problem - it is replaced by its measurement (one entry of
+        # the time-varying parameters) everywhere; opt_x['_u'] hands it back, the multiplier of its row is the derivative of the chain
+        # problem's Lagrangian w.r.t. that parameter (_fixed_input_multipliers).
         y_sym = sym.SX.sym("y_meas", ny, 1)
         zero_v = sym.SX(np.zeros((nv, 1)))
         h0 = sym.substitute(m._y.cat, m._v.cat, zero_v) if nv else m._y.cat
         dy_dv = sym.jacobian(m._y.cat, m._v.cat) if nv else None
-        if ny != nv or not dy_dv.is_constant() or not np.array_equal(dy_dv.to_numpy().reshape(ny, nv), np.eye(ny)):
-            raise NotImplementedError("structured HIP backend: every measurement of the estimator model needs its own additive noise "
-                                      "term (set_meas(..., meas_noise=True)): the measurement rows are solved for it")
+        D = dy_dv.to_numpy().reshape(ny, nv) if (nv and dy_dv.is_constant()) else None
+        if nv and D is None:
+            raise NotImplementedError("structured HIP backend: the measurement noise must enter the measurement equations additively")
+        noisy = [i for i in range(ny) if nv and np.any(D[i] != 0.0)]
+        if len(noisy) != nv or (nv and not np.array_equal(D[noisy], np.eye(nv))):
+            raise NotImplementedError("structured HIP backend: every noisy measurement of the estimator model needs its own additive "
+                                      "noise term: the measurement rows are solved for it")
+        self._y_noisy = np.array(noisy, dtype=int)
+        self._y_free = np.array([i for i in range(ny) if i not in noisy], dtype=int)
+        u_nodes = m._u.cat.nodes()
+        u_of_row = {}
+        for i in self._y_free:
+            j = next((j for j, un in enumerate(u_nodes) if un.idx == h0.nodes()[i].idx), None)
+            if j is None or j in u_of_row.values():
+                raise NotImplementedError("structured HIP backend: a measurement without noise (set_meas(..., meas_noise=False)) is "
+                                          "supported where it measures an input variable as it is (each input once)")
+            u_of_row[int(i)] = j
+        fixed_el = set(u_of_row.values())
+        off, self._u_fixed_names = 0, []
+        for n in m._u.names:
+            k = m._u.vars[n].numel()
+            hit = [j in fixed_el for j in range(off, off + k)]
+            if k and any(hit):
+                if not all(hit):
+                    raise NotImplementedError("structured HIP backend: input '{}' is measured without noise in some of its elements "
+                                              "only".format(n))
+                self._u_fixed_names.append(n)
+            off += k
+        self._u_keep = np.array([j for j in range(nu) if j not in fixed_el], dtype=int)
+        self._u_fixed = np.array([u_of_row[int(i)] for i in self._y_free], dtype=int)       # input element of the free measurement rows, in row order
+        nuk = self._nuk = self._u_keep.size
+        if self._u_fixed.size:
+            if nv == 0:
+                raise NotImplementedError("structured HIP backend: an estimator whose measurements are ALL without noise")
+            if m.model_type == "discrete" or m.n_z:
+                raise NotImplementedError("structured HIP backend: measurements without noise for discrete-time models / models with "
+                                          "algebraic states")
+            u_repl = sym.vertcat(*[(y_sym[int(self._y_free[list(self._u_fixed).index(j)])] if j in fixed_el else m._u.cat[j]) for j in range(nu)])
+            fix = lambda e: sym.substitute(sym.SX(e), m._u.cat, u_repl)      # noqa: E731
+            h0 = fix(h0)
+            if any(sym.depends_on(sym.SX(c["expr"]).nodes(), [u_nodes[j] for j in fixed_el]) for c in self.nl_cons_list):
+                raise NotImplementedError("structured HIP backend: nl_cons rows that depend on an input measured without noise")
+        else:
+            fix = lambda e: e                                                  # noqa: E731
         discrete = self._discrete = m.model_type == "discrete"
         nz = m.n_z
         if discrete:
@@ -294,7 +344,7 @@ class MHE:
             # cost) then reads that algebraic state, which the dense edge path of the DAE models handles (`_z[k, s, -1]` in the cost)
             z_next = sym.SX.sym("x_next", nx, 1)
             h0 = sym.substitute(h0, m._x.cat, z_next)
-        v_of = y_sym - h0                                            # v_k = y_k - h(x_{k+1}, u_k, tvp_k, p)
+        v_of = (y_sym - h0)[[int(i) for i in self._y_noisy]] if self._y_free.size else y_sym - h0       # v_k = y_k - h(x_{k+1}, u_k, tvp_k, p): the noisy rows
         stage = sym.substitute(self.stage_cost, m._v.cat, v_of) if nv else self.stage_cost
         # ---- the augmented model: states (x, p_est), inputs (u, w), tvp (tvp, y_meas), parameters p_set; symbols are shared
         am = Model("discrete" if discrete else "continuous")
@@ -303,7 +353,7 @@ class MHE:
         for n in self._p_est.names:
             am._x.add(n, self._p_est.vars[n])
         for n in m._u.names:
-            if m._u.vars[n].numel():
+            if m._u.vars[n].numel() and n not in self._u_fixed_names:
                 am._u.add(n, m._u.vars[n])
         for n in m._w.names:
             if m._w.vars[n].numel():
@@ -333,7 +383,7 @@ class MHE:
                 am.rhs_list.append({"var_name": n, "expr": self._p_est.vars[n]})          # p+ = p
         else:
             for r in m.rhs_list:
-                am.rhs_list.append(dict(r))
+                am.rhs_list.append(dict(r, expr=fix(r["expr"])))
             for n in self._p_est.names:
                 am.rhs_list.append({"var_name": n, "expr": sym.SX(np.zeros(self._p_est.vars[n].shape))})
             # algebraic states of the model (_mhe.py:1056, 1136-1141): edge unknowns of the chain problem like in the controller; the
@@ -345,7 +395,7 @@ class MHE:
                 am.alg_list.append(dict(a))
         for n in m._aux.names:
             if n != "default":
-                am._aux.add(n, m._aux.vars[n])
+                am._aux.add(n, fix(m._aux.vars[n]))
         am.setup()
         self._aug_model = am
         # ---- the chain problem on the controller's machinery
@@ -366,7 +416,7 @@ class MHE:
         mpc._x_scaling.master[:nx] = self._x_scaling.master
         mpc._x_scaling.master[nx:nx + npe] = self._p_est_scaling.master          # (_mhe.py:1083)
         self._sx_aug = mpc._x_scaling.master.copy()                               # scaling of the augmented state (x, p_est)
-        mpc._u_scaling.master[:nu] = self._u_scaling.master
+        mpc._u_scaling.master[:nuk] = self._u_scaling.master[self._u_keep]
         if nz:
             mpc._z_scaling.master[:nz] = self._z_scaling.master
         mpc.set_tvp_fun(lambda t: mpc.get_tvp_template())
@@ -447,6 +497,13 @@ class MHE:
         #  the multipliers of the continuity rows differ by (dh/dx)' lambda_meas)
         lam_y = sym.SX.sym("lam_y", ny, 1)
         self._hx_fun = sym.Function("hx_lam", args + [lam_y], [sym.jacobian(h0_x, m._x.cat).T @ lam_y])
+        if self._y_free.size:
+            # d/d(y of the free rows) of the chain problem's stage terms: collocation rows  h f(x_j, u, tvp, p) / s_x  (weighted by their
+            # multipliers) and the stage cost at the end state - what the multipliers of the rows  u - y = 0  balance
+            y_free = y_sym[[int(i) for i in self._y_free]]
+            lam_c = sym.SX.sym("lam_c", ps.nx, 1)
+            self._dfdy_fun = sym.Function("dfdy_lam", args + [lam_c], [sym.jacobian(am._rhs, y_free).T @ lam_c])
+            self._dldy_fun = sym.Function("dldy", args, [sym.jacobian(stage, y_free).T])
         self._update_bounds()
         meta = {k: getattr(s, k) for k in ("n_horizon", "t_step", "meas_from_data", "state_discretization", "collocation_type",
                                            "collocation_deg", "collocation_ni", "nl_cons_check_colloc_points", "store_full_solution",
@@ -473,7 +530,8 @@ class MHE:
             XL[1:N, -1, :nx], XU[1:N, -1, :nx] = xl, xu
         XL[0, -1, nx:], XU[0, -1, nx:] = self._p_est_lb.master / self._p_est_scaling.master, self._p_est_ub.master / self._p_est_scaling.master
         UL, UU = lb[ps.off_u:ps.off_eps].reshape(N, NUA), ub[ps.off_u:ps.off_eps].reshape(N, NUA)
-        UL[:, :nu], UU[:, :nu] = self._u_lb.master / self._u_scaling.master, self._u_ub.master / self._u_scaling.master
+        kp = self._u_keep
+        UL[:, :kp.size], UU[:, :kp.size] = (self._u_lb.master / self._u_scaling.master)[kp], (self._u_ub.master / self._u_scaling.master)[kp]
         if self.model.n_z:        # (_mhe.py:1006-1007 every `_z` slot, :1015-1016 the first slot of every interval)
             nz = self.model.n_z
             if self._discrete:    # (one slot per interval: the model's algebraic states, then the copy of the next state)
@@ -498,9 +556,10 @@ class MHE:
         X[..., :nx] = ox[..., :self._o_z].reshape(lead + (N + 1, M + 1, nx))
         X[..., nx:] = ox[..., None, None, self._o_p:]
         U = out[..., ps.off_u:ps.off_eps].reshape(lead + (N, ps.nu))
-        U[..., :nu] = ox[..., self._o_u:self._o_w].reshape(lead + (N, nu))
+        nuk = self._nuk                                             # (inputs measured without noise are no variables of the chain problem)
+        U[..., :nuk] = ox[..., self._o_u:self._o_w].reshape(lead + (N, nu))[..., self._u_keep]
         if nw:
-            U[..., nu:] = ox[..., self._o_w:self._o_v].reshape(lead + (N, nw))
+            U[..., nuk:] = ox[..., self._o_w:self._o_v].reshape(lead + (N, nw))
         out[..., ps.off_eps:] = ox[..., self._o_eps:self._o_p]
         if self._discrete:      # (the algebraic copy of the next state starts at the guess of that state)
             Z = out[..., ps.off_z:ps.off_u].reshape(lead + (N, m.n_z + nx))
@@ -549,14 +608,19 @@ class MHE:
         elif m.n_z:
             out[..., self._o_z:self._o_u] = cx[..., ps.off_z:ps.off_u].reshape(lead + (N, m.n_z + nx))[..., :m.n_z].reshape(lead + (-1,))
         U = cx[..., ps.off_u:ps.off_eps].reshape(lead + (N, ps.nu))
-        out[..., self._o_u:self._o_w] = U[..., :nu].reshape(lead + (-1,))
+        nuk = self._nuk
+        Uo = np.zeros(lead + (N, nu))
+        Uo[..., self._u_keep] = U[..., :nuk]
+        TV = opt_p_chain[..., ps.p_off_tvp:ps.p_off_p].reshape(lead + (N + 1, ps.ntvp))[..., :N, :]
+        if self._u_fixed.size:      # an input measured without noise IS its measurement (scaled like every entry of opt_x)
+            Uo[..., self._u_fixed] = TV[..., m.n_tvp + self._y_free] / self._u_scaling.master[self._u_fixed]
+        out[..., self._o_u:self._o_w] = Uo.reshape(lead + (-1,))
         if nw:
-            out[..., self._o_w:self._o_v] = U[..., nu:].reshape(lead + (-1,))
+            out[..., self._o_w:self._o_v] = U[..., nuk:].reshape(lead + (-1,))
         if nv:      # measurement noise of stage k from the end state of its interval
-            TV = opt_p_chain[..., ps.p_off_tvp:ps.p_off_p].reshape(lead + (N + 1, ps.ntvp))[..., :N, :]
             Pm = np.broadcast_to(opt_p_chain[..., None, ps.p_off_p:ps.p_off_uprev], lead + (N, ps.np_))
             sx = self._sx_aug
-            su = np.concatenate([self._u_scaling.master, np.ones(ps.nu - nu)])
+            su = np.concatenate([self._u_scaling.master[self._u_keep], np.ones(ps.nu - nuk)])
             cols = lambda a: np.moveaxis(a, -1, 0).reshape(a.shape[-1], int(np.prod(a.shape[:-1])))        # noqa: E731   (numel, batch * N)
             V = np.asarray(self._v_fun.eval(cols(X[..., 1:, -1, :] * sx), cols(U * su), cols(self._z_last(cx, lead)), cols(TV), cols(Pm))[0])
             out[..., self._o_v:self._o_eps] = np.moveaxis(V.reshape((nv,) + lead + (N,)), 0, -1).reshape(lead + (-1,))
@@ -598,19 +662,47 @@ class MHE:
             g = self._dldv_fun.eval(W.T, V.T, TV.T, np.tile(pm[:, None], (1, N)))[0]
             lam_meas = -np.asarray(g).reshape(nv, N).T
             r_meas = self._rows_stage - ny - (L.shape[1] - n_dyn)       # (first measurement row of a stage)
-            out[:, r_meas:r_meas + ny] = lam_meas
+            lam_all = np.zeros((N, ny))
+            lam_all[:, self._y_noisy] = lam_meas
             cx, Pc = self._mpc.opt_x_num.master, self._mpc.opt_p_num.master
+            if self._y_free.size:
+                lam_all[:, self._y_free] = self._fixed_input_multipliers(L, cx, Pc)
+            out[:, r_meas:r_meas + ny] = lam_all
             X = cx[:ps.off_z].reshape(N + 1, M + 1, ps.nx)[1:, -1, :] * self._sx_aug
-            U = cx[ps.off_u:ps.off_eps].reshape(N, ps.nu) * np.concatenate([self._u_scaling.master, np.ones(ps.nu - m.n_u)])
+            U = cx[ps.off_u:ps.off_eps].reshape(N, ps.nu) * np.concatenate([self._u_scaling.master[self._u_keep], np.ones(ps.nu - self._nuk)])
             TVc = Pc[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
             Zl = self._z_last(cx, ())
-            hx = self._hx_fun.eval(X.T, U.T, Zl.T, TVc.T, np.tile(Pc[ps.p_off_p:ps.p_off_uprev][:, None], (1, N)), lam_meas.T)[0]
+            hx = self._hx_fun.eval(X.T, U.T, Zl.T, TVc.T, np.tile(Pc[ps.p_off_p:ps.p_off_uprev][:, None], (1, N)), lam_all.T)[0]
             if not self._discrete:
                 out[:, r_meas - nx:r_meas] += np.asarray(hx).reshape(nx, N).T
         else:
             r_meas = self._rows_stage - ny - (L.shape[1] - n_dyn)
         out[:, r_meas + ny:] = L[:, n_dyn:]
         return out.reshape(-1)
+
+    def _fixed_input_multipliers(self, L: np.ndarray, cx: np.ndarray, Pc: np.ndarray) -> np.ndarray:
+        """Multipliers of the rows  u_j - y = 0  of the inputs measured without noise (reference rows `yk_calc - y_meas`,
+        _mhe.py:1144-1158), shape (N, n_free).  In the chain problem such an input is the parameter y of its stage; stationarity of the
+        reference's NLP w.r.t. the (scaled) input reads  s_u dL'/du + s_u nu = 0  with L' = every other term of the Lagrangian, and
+        L' as a function of the physical input is the chain problem's Lagrangian as a function of that parameter:  nu = -dL_c/dy.
+        The terms that depend on it: the collocation rows  h f(x_j, u, ..) / s_x - sum_r C[r, j] x_r  (multipliers L) and the stage
+        cost (through the noise of measurements that read the input, if any).  Continuous models without algebraic states."""
+        ps, m, s = self._ps, self.model, self.settings
+        N, M, deg, ni = s.n_horizon, ps.M, s.collocation_deg, s.collocation_ni
+        h = s.t_step / ni
+        Xs = cx[:ps.off_z].reshape(N + 1, M + 1, ps.nx) * self._sx_aug
+        U = cx[ps.off_u:ps.off_eps].reshape(N, ps.nu) * np.concatenate([self._u_scaling.master[self._u_keep], np.ones(ps.nu - self._nuk)])
+        TVc = Pc[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
+        Pm = np.tile(Pc[ps.p_off_p:ps.p_off_uprev][:, None], (1, N))
+        Z0 = np.zeros((0, N))
+        dL = np.asarray(self._dldy_fun.eval(Xs[1:, -1, :].T, U.T, Z0, TVc.T, Pm)[0], float).reshape(self._y_free.size, N)
+        for i in range(ni):                       # rows of a stage: per finite element deg collocation blocks, then its end-of-element rows
+            for j in range(1, deg + 1):
+                slot = i * (deg + 1) + j - 1      # stored slot of collocation point j of element i (optimizer.py:905-935)
+                r0 = (i * (deg + 1) + (j - 1)) * ps.nx
+                lam = L[:, r0:r0 + ps.nx] * (h / self._sx_aug)
+                dL = dL + np.asarray(self._dfdy_fun.eval(Xs[1:, slot, :].T, U.T, Z0, TVc.T, Pm, lam.T)[0], float).reshape(self._y_free.size, N)
+        return -dL.T
 
     # ------------------------------------------------------------------ runtime
     def set_initial_guess(self) -> None:

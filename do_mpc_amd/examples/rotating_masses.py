@@ -27,12 +27,14 @@ def setpoint_trajectory():
     return np.array(traj)
 
 
-def build_model(symvar_type="SX", process_noise=False, dae=False):
+def build_model(symvar_type="SX", process_noise=False, dae=False, input_meas_noise=True):
     """process_noise: additive noise on the three angular accelerations (`set_rhs(..., process_noise=True)`; not in the reference's
     example - the estimator variant build_mhe_w uses it).
     dae: the same plant written with algebraic states - the twist `tw_i = phi_i - left_i` of the spring on the left of every disc
     as `_z` with its algebraic equation, read by the accelerations AND by the first measurement (`phi_1 = tw_1 + phi_m_1`): an
-    equivalent model for the estimator's DAE path (same estimates as the ODE model; no stored run exists for it)"""
+    equivalent model for the estimator's DAE path (same estimates as the ODE model; no stored run exists for it)
+    input_meas_noise=False: the motor set-points are measured WITHOUT noise (`set_meas(..., meas_noise=False)`, what the reference's
+    documentation suggests for measured inputs, _model.py:693-695, and its MHE example notebook does)"""
     mdl = Model("continuous", symvar_type)
     phi = vertcat(*[mdl.set_variable("_x", "phi_%d" % i) for i in (1, 2, 3)])
     dphi = mdl.set_variable("_x", "dphi", shape=(3, 1))
@@ -51,7 +53,7 @@ def build_model(symvar_type="SX", process_noise=False, dae=False):
     else:
         twist = [phi[i] - left[i] for i in range(3)]
         mdl.set_meas("phi_1_meas", phi)
-    mdl.set_meas("phi_m_set_meas", phi_m_set)
+    mdl.set_meas("phi_m_set_meas", phi_m_set, meas_noise=input_meas_noise)
     th = [mdl.set_variable("_p", "Theta_%d" % i) for i in (1, 2, 3)]
     c = np.array([2.697, 2.66, 3.05, 2.86]) * 1e-3       # spring constants
     d = np.array([6.78, 8.01, 8.82]) * 1e-5              # friction
@@ -152,7 +154,7 @@ def build_mhe_w(model, silence_solver=True, scaling=None, soft_limit=None, **ove
         setattr(st, k, v)
     if silence_solver:
         st.supress_ipopt_output()
-    mhe.set_default_objective(1e-4 * np.eye(8), np.diag([1.0, 1.0, 1.0, 20.0, 20.0]), np.eye(1), 10.0 * np.eye(3))
+    mhe.set_default_objective(1e-4 * np.eye(8), np.diag([1.0, 1.0, 1.0, 20.0, 20.0][:model.n_v]), np.eye(1), 10.0 * np.eye(3))
     tvp_template = mhe.get_tvp_template()
     mhe.set_tvp_fun(lambda t_now: tvp_template)
     p_template = mhe.get_p_template()

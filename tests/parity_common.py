@@ -582,6 +582,48 @@ def check_mhe_soft_constraint(make_mhe_w, single_slack):
     return mhe
 
 
+def check_mhe_inputs_measured_without_noise(make_mhe_nf):
+    """`set_meas('phi_m_set_meas', phi_m_set, meas_noise=False)` - what the reference's documentation suggests for measured inputs
+    (_model.py:693-695) and its MHE example notebook does: the rows `u - y_meas = 0` of the reference's NLP (_mhe.py:1144-1158) fix the
+    inputs; the product takes them out of the chain problem (they become parameters of their stage).  Against the oracle's solve of the
+    reference's NLP WITH those rows and variables: solution incl. `_u` (measured 2e-15) and multipliers incl. the ones of the
+    measurement rows without noise (1e-10).
+    [NO REFERENCE FIXTURE: oracle-or-equivalence check, not a reproduction of a stored reference run]"""
+    import sympy as sp
+    from oracle.mhe import OracleMHE
+    from oracle.models import case_rotating_masses_mhe_w
+    c0 = case_rotating_masses_mhe_w()
+    x, u, w = c0["x"], c0["u"], c0["w"]
+    v = sp.symbols("v_0:3")
+    vv, ww = sp.Matrix(v), sp.Matrix(w)
+    stage = (vv.T * sp.diag(1, 1, 1) * vv)[0, 0] + 10.0 * (ww.T * ww)[0, 0]
+    nlp = OracleMHE(case_rotating_masses_mhe_w(v=v, meas=[x[0] + v[0], x[1] + v[1], x[2] + v[2], u[0], u[1]], stage_cost=stage))
+    mhe = make_mhe_nf()
+    assert (nlp.n_opt_x, nlp.n_g, nlp.n_opt_p) == (mhe.n_opt_x, mhe.n_opt_lagr, mhe.n_opt_p)
+    assert mhe._ps.nu == 3 and mhe.model.n_v == 3 and mhe.model.n_y == 5          # (chain problem: the process noise only; 3 noisy of 5 measurements)
+    OP = golden("rotating_masses")["estimator.opt_p_num"][4]
+    N = 6
+    P = np.concatenate([OP[:12], OP[12:12 + 26 * 10].reshape(10, 26)[:N].ravel(), OP[12 + 260:].reshape(10, 5)[-N:].ravel()])
+    init = nlp.initial_guess(np.zeros(8), np.zeros(2), 1e-4)
+    mhe.opt_p_num.master[:] = P
+    mhe.opt_x_num.master[:] = init
+    mhe.solve()
+    r = ipm.solve(nlp, init, P)
+    assert mhe.solver_stats["success"] and r["stats"]["success"]
+    assert relerr(mhe.opt_x_num.master, r["x"]) < 1e-8
+    y = P[nlp.po_y:].reshape(N, 5)
+    assert np.array_equal(mhe.opt_x_num.master[nlp.off_u:nlp.off_w].reshape(N, 2), y[:, 3:])      # the inputs ARE their measurements
+    assert np.max(np.abs(mhe.lam_g_num - r["lam_g"])) < 1e-7 * max(1.0, np.max(np.abs(r["lam_g"])))
+    rows = (np.arange(N)[:, None] * nlp.rows_stage + nlp.rows_stage - nlp.n_eval * len(nlp.nl) - 5 + np.array([3, 4])[None, :]).ravel()
+    assert np.max(np.abs(r["lam_g"][rows])) > 1e-4                                # (the multipliers of the rows without noise are not zero)
+    # two measurement windows of a batch in one launch, in the reference's layout
+    P2 = np.stack([P, P])
+    P2[1, nlp.po_y:] += 1e-3 * np.sin(np.arange(P.size - nlp.po_y))
+    rb = mhe.solve_batch(P2, np.stack([init, init]))
+    assert relerr(rb["opt_x"][0], r["x"]) < 1e-8 and np.array_equal(rb["opt_x"][1][nlp.off_u:nlp.off_w].reshape(N, 2), P2[1, nlp.po_y:].reshape(N, 5)[:, 3:])
+    return mhe
+
+
 def check_mhe_scaling_invariance(make_mhe_w):
     """Scaling of states, inputs and ESTIMATED parameters (_mhe.py:1077-1085: `opt_x_scaling`; the parameter rides as a state of
     the augmented model here) changes the variables of the NLP, not its solution: the scaled estimator's solution times its scaling

@@ -361,6 +361,11 @@ def test_mhe_with_process_noise_against_the_oracle():
     pc.check_mhe_with_process_noise(lambda: ex.build_mhe_w(ex.build_model(process_noise=True)))
 
 
+def test_mhe_inputs_measured_without_noise_against_the_oracle():
+    ex = CASES["rotating_masses"]
+    pc.check_mhe_inputs_measured_without_noise(lambda: ex.build_mhe_w(ex.build_model(process_noise=True, input_meas_noise=False), max_batch=2))
+
+
 @pytest.mark.parametrize("single_slack", [False, True], ids=["slack_per_stage", "single_slack"])
 def test_mhe_soft_constraint_against_the_oracle(single_slack):
     ex = CASES["rotating_masses"]

@@ -111,6 +111,13 @@ def test_mhe_with_process_noise_against_the_oracle():
     pc.check_mhe_with_process_noise(make)
 
 
+def test_mhe_inputs_measured_without_noise_against_the_oracle():
+    def make():
+        with hostemu.patched():
+            return ex.build_mhe_w(ex.build_model(process_noise=True, input_meas_noise=False), max_batch=2)
+    pc.check_mhe_inputs_measured_without_noise(make)
+
+
 @pytest.mark.parametrize("single_slack", [False, True], ids=["slack_per_stage", "single_slack"])
 def test_mhe_soft_constraint_against_the_oracle(single_slack):
     def make(**kw):
