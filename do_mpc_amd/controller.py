@@ -484,11 +484,14 @@ class MPC:
                              open_loop=bool(s.open_loop), single_slack=bool(s.nl_cons_single_slack))
         self.structure = ps
         self.scenario_tree = ps.scenario_tree
+        if ps.open_loop_stack:
+            from . import open_loop
+            open_loop.check_supported(self)
         xs_l, zs_l, us_l = m._x.layout(), m._z.layout(), m._u.layout()
         self._opt_x_layout = Layout([
             Entry("_x", struct=xs_l, repeat=[s.n_horizon + 1, ps.S, 1 + ps.M]),
             Entry("_z", struct=zs_l, repeat=[s.n_horizon, ps.S, max(ps.M, 1)]),
-            Entry("_u", struct=us_l, repeat=[s.n_horizon, ps.S]),
+            Entry("_u", struct=us_l, repeat=[s.n_horizon, ps.SU]),
             Entry("_eps", struct=self._eps_layout, repeat=[ps.n_eps, ps.S]),
         ])
         self._opt_p_layout = Layout([
@@ -588,12 +591,18 @@ class MPC:
 
     def create_nlp(self, _solver_factory=None) -> None:
         assert self.flags["prepare_nlp"], "call prepare_nlp() first"
-        self.generated_header = self._lower()
-        self.model_hash = self.generated_header.rsplit('DOMPC_MODEL_HASH "', 1)[1].split('"')[0]
-        factory = _solver_factory or HipIpmSolver
-        self.S = factory(self.structure, self.generated_header, self.model_hash, nlpsol_opts=self.settings.nlpsol_opts,
-                         device=self.settings.gpu_index, max_batch=self.settings.max_batch,
-                         block_threads=self.settings.block_threads)
+        if self.structure.open_loop_stack:
+            # open_loop with several scenarios: not tree-structured - a chain over the stacked scenario states, behind the same callable
+            from . import open_loop
+            self.S = open_loop.OpenLoopStack(self, _solver_factory)
+            self.generated_header, self.model_hash = self.S.inner.generated_header, self.S.inner.model_hash
+        else:
+            self.generated_header = self._lower()
+            self.model_hash = self.generated_header.rsplit('DOMPC_MODEL_HASH "', 1)[1].split('"')[0]
+            factory = _solver_factory or HipIpmSolver
+            self.S = factory(self.structure, self.generated_header, self.model_hash, nlpsol_opts=self.settings.nlpsol_opts,
+                             device=self.settings.gpu_index, max_batch=self.settings.max_batch,
+                             block_threads=self.settings.block_threads)
         meta = {k: v for k, v in asdict(self.settings).items()}
         meta["structure_scenario"] = self.scenario_tree["structure_scenario"]
         self.data.set_meta(**meta)
@@ -617,6 +626,8 @@ class MPC:
             raise NotImplementedError("structured HIP backend: tree sharding with a user-defined rterm expression")
         if self.structure.eps_global:
             raise NotImplementedError("structured HIP backend: tree sharding with nl_cons_single_slack")
+        if self.structure.open_loop_stack:
+            raise NotImplementedError("structured HIP backend: tree sharding with open_loop")
         if not getattr(self.S, "shard_capable", False):
             # the sharding-aware kernel is a second code object of the same model (build.py): swap the solver
             ctor = dict(self.S._ctor)
@@ -642,7 +653,7 @@ class MPC:
         """opt_aux_expression_fun (_mpc.py:1277-1284, 1331): aux at every (k, s)."""
         m, ps, N = self.model, self.structure, self.settings.n_horizon
         X = opt_x_unscaled.master[:ps.off_z].reshape(N + 1, ps.S, ps.M + 1, ps.nx)[:N, :, -1, :]
-        U = opt_x_unscaled.master[ps.off_u:ps.off_eps].reshape(N, ps.S, ps.nu)
+        U = opt_x_unscaled.master[ps.off_u:ps.off_eps].reshape(N, ps.SU, ps.nu)
         TV = opt_p.master[ps.p_off_tvp:ps.p_off_p].reshape(N + 1, ps.ntvp)[:N]
         Pm = opt_p.master[ps.p_off_p:ps.p_off_uprev].reshape(ps.n_comb, ps.np_)
         cache = getattr(self, "_aux_index_cache", None)
@@ -660,7 +671,7 @@ class MPC:
         src_s, pidx = cache
         kk = np.repeat(np.arange(N), ps.S)
         Xf = X[kk, src_s.reshape(-1)].T
-        Uf = U[kk, src_s.reshape(-1)].T
+        Uf = U[kk, src_s.reshape(-1) if ps.SU == ps.S else 0].T        # (open_loop: `_u[k, 0]` for every scenario)
         Tf = TV[kk].T
         Pf = Pm[pidx.reshape(-1)].T
         if ps.nz:      # (_mpc.py:1277-1284: `_z[k, s, -1]`)

@@ -93,6 +93,8 @@ class DoMPCDifferentiator:
         if getattr(ps, "eps_global", False):
             raise NotImplementedError("structured HIP backend: DoMPCDifferentiator with nl_cons_single_slack (the Newton steps at the "
                                       "solution do not carry the Schur complement of the shared slack variables)")
+        if getattr(ps, "open_loop_stack", False):
+            raise NotImplementedError("structured HIP backend: DoMPCDifferentiator with open_loop and several scenarios")
         self.x_scaling_factors = optimizer.opt_x_scaling.master.copy()
         self.sens_num = _SensNum(self)
         self.n_x, self.n_p, self.n_g = ps.n_opt_x, ps.n_opt_p, ps.n_g

@@ -40,7 +40,7 @@ def build_model(symvar_type="SX"):
     return mdl
 
 
-def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_deg=2, track_sign=1.0, custom_rterm=None, uncertainty=None, **overrides):
+def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_deg=2, track_sign=1.0, custom_rterm=None, uncertainty=None, soft_T_R=True, **overrides):
     """track_sign=-1 turns the tracking cost into a concave one (C_b is pushed AWAY from 0.6, bounded only by the
     box): a non-convex test problem whose reduced Hessian needs inertia correction in most iterations."""
     mpc = MPC(model)
@@ -72,7 +72,7 @@ def build_mpc(model, silence_solver=True, n_horizon=20, n_robust=1, collocation_
     mpc.bounds["lower", "_u", "Q_dot"] = -8500
     mpc.bounds["upper", "_u", "F"] = 100
     mpc.bounds["upper", "_u", "Q_dot"] = 0.0
-    mpc.set_nl_cons("T_R", model.x["T_R"], ub=140, soft_constraint=True, penalty_term_cons=1e2)
+    mpc.set_nl_cons("T_R", model.x["T_R"], ub=140, soft_constraint=bool(soft_T_R), penalty_term_cons=1e2)
     if uncertainty is None:
         uncertainty = dict(alpha=[1.0, 1.05, 0.95], beta=[1.0, 1.1, 0.9])
     mpc.set_uncertainty_values(**{k: np.asarray(v, float) for k, v in uncertainty.items()})

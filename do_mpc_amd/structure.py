@@ -80,6 +80,8 @@ class ProblemStructure:
     discrete: bool
     tables: Dict[str, np.ndarray] = field(default_factory=dict)
     eps_global: bool = False     # nl_cons_single_slack: the slack variables are shared by all stages
+    S_u: int = 0                 # scenario slots of `_u` (_mpc.py:1112-1117: 1 with open_loop, else S); 0 = S
+    open_loop_stack: bool = False   # open_loop with several scenarios: solved as a chain over the stacked scenario states (open_loop.py)
 
     # -- sizes
     @property
@@ -99,8 +101,12 @@ class ProblemStructure:
         return self.off_z + self.n_z_block
 
     @property
+    def SU(self):
+        return self.S_u or self.S
+
+    @property
     def off_eps(self):
-        return self.off_u + self.N * self.S * self.nu
+        return self.off_u + self.N * self.SU * self.nu
 
     @property
     def n_opt_x(self):
@@ -156,7 +162,7 @@ class ProblemStructure:
         return ((k * self.S + s) * (self.M + 1) + c) * self.nx
 
     def iu(self, k, s):
-        return self.off_u + (k * self.S + s) * self.nu
+        return self.off_u + (k * self.SU + (s if self.SU == self.S else 0)) * self.nu       # (open_loop: one input for all scenarios of a stage)
 
     def ieps(self, e, s):
         return self.off_eps + (e * self.S + s) * self.ns
@@ -171,9 +177,11 @@ def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust,
     n_eps = 1 if single_slack else N
     ps = ProblemStructure(nx=nx, nu=nu, nz=nz, np_=np_, ntvp=ntvp, ne=ne, ns=ns, deg=deg, ni=ni, M=M, N=N, S=S,
                           n_comb=n_comb, n_robust=n_robust, n_eps=n_eps, discrete=discrete)
-    if open_loop and S > 1:
-        raise NotImplementedError("structured HIP backend: open_loop=True couples all scenarios of a stage "
-                                  "(shared input) and is not tree-structured")
+    # open_loop with several scenarios (_mpc.py:1112-1117, 1205-1206): `_u` has ONE scenario slot, every scenario of a stage applies the
+    # same input.  The layout below is the reference's; the problem is not tree-structured and is solved as a chain over the stacked
+    # scenario states (do_mpc_amd/open_loop.py) - these tables then describe the reference's variables / rows for the mapping only.
+    ps.S_u = 1 if open_loop else S
+    ps.open_loop_stack = bool(open_loop and S > 1)
     # nl_cons_single_slack (_mpc.py:1120-1123, 1228): one `_eps` entry per scenario slot for ALL stages.  The slacks then are no
     # decision variables of a node; the kernels take them out of the tree-structured part and solve for them by a Schur
     # complement (csrc/dompc_kernel.h: EPS_GLOBAL) - one extra linear solve per slack variable and iteration.

@@ -465,6 +465,61 @@ def check_single_slack(make_mpc, over, x0):
     return mpc
 
 
+# open_loop = True with several scenarios (_mpc.py:1112-1117, 1205-1206: one input for all scenarios of a stage) - solved as a chain over the
+# stacked scenario states (do_mpc_amd/open_loop.py), handed out in the reference's layout
+OPEN_LOOP_CASES = [
+    ("3_scenarios_soft", dict(uncertainty=dict(alpha=[1.0, 1.05, 0.95], beta=[1.0])), {}, np.array([0.8, 0.5, 141.5, 138.0])),
+    ("4_leaves_nrobust2", dict(n_robust=2, n_horizon=6, uncertainty=dict(alpha=[1.0, 1.05], beta=[1.0]), soft_T_R=False), None,
+     np.array([0.8, 0.5, 134.14, 130.0])),
+]
+
+
+def check_open_loop(make_mpc, over, o_over, x0):
+    """CSTR with `open_loop=True` against the oracle's solve of the restated NLP (shared `_u[k, 0]`, oracle/nlp.py): first input, every
+    variable that a node reads, multipliers, iteration count within two (the stacked chain carries a copy of a shared tree node per leaf
+    scenario: more rows and multipliers in the scaled error measures), the solution is a KKT point of the ORACLE's NLP with OUR multipliers,
+    `_u` has one scenario slot.  3 scenarios, soft constraint in use: u0 5e-9; n_robust = 2 with 4 leaves (tree nodes shared by two leaf scenarios).
+    [NO REFERENCE FIXTURE: oracle-or-equivalence check, not a reproduction of a stored reference run]"""
+    over = dict(over, open_loop=True)
+    mpc = make_mpc("CSTR", **over)
+    oo = {k: v for k, v in over.items() if k != "soft_T_R"}
+    if o_over is None:      # the row as a hard constraint
+        import sympy as sp
+        oo["nl_cons"] = [dict(name="T_R", expr=sp.Symbol("T_R"), ub=140.0, soft=False)]
+    nlp = oracle_nlp("CSTR", **oo)
+    ps = mpc.structure
+    assert (nlp.n_opt_x, nlp.n_g) == (ps.n_opt_x, ps.n_g) and ps.SU == 1 and ps.open_loop_stack
+    assert mpc.opt_x_num.layout.resolve(("_u",)).size == ps.N * ps.nu
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    u0 = mpc.make_step(x0).ravel()
+    st = mpc.solver_stats
+    p_in = mpc.opt_p_num.master.copy()
+    r = ipm.solve(nlp, nlp.initial_guess(x0), p_in)
+    assert st["success"] and r["stats"]["success"]
+    assert abs(st["iter_count"] - r["stats"]["iter_count"]) <= 2
+    # (scaled variables.  The cooling input Q_dot is weakly determined - penalty 1e-3 on its scaled change - and with n_robust = 2 a tree node
+    #  shared by two leaf scenarios has two copies, i.e. twice the barrier weight on its bounds: another central path to the same limit;
+    #  at tol = 1e-8 the stop points differ by 7e-5 in that input, 2e-9 in the objective - ours is the lower one)
+    u_tol, x_tol = (1e-7, 1e-4) if o_over is not None else (2e-4, 2e-3)
+    us = mpc._u_scaling.master
+    assert np.max(np.abs(u0 - nlp.u0_of(r["x"])) / us) < u_tol
+    used = np.ones(nlp.n_opt_x, bool)
+    used[ps.tables["dummy_idx"]] = False
+    assert relerr(mpc.opt_x_num.master[used], r["x"][used]) < x_tol                    # (flat directions at tol = 1e-8, as on the golden cases)
+    assert abs(nlp.f(mpc.opt_x_num.master, p_in) - nlp.f(r["x"], p_in)) < 1e-6 * max(1.0, abs(nlp.f(r["x"], p_in)))
+    assert np.max(np.abs(mpc.lam_g_num - r["lam_g"])) < (1e-6 if o_over is not None else 1e-3) * max(1.0, np.max(np.abs(r["lam_g"])))
+    x = mpc.opt_x_num.master
+    gv = nlp.g(x, p_in)
+    eq = nlp.lbg == nlp.ubg
+    assert np.max(np.abs(gv[eq])) < 1e-7 and np.allclose(gv, mpc.opt_g_num, atol=1e-9)
+    rd = nlp.grad(x, p_in) + nlp.jac(x, p_in).T @ mpc.lam_g_num + mpc.lam_x_num
+    assert np.max(np.abs(rd[used])) < 1e-6 * max(1.0, np.max(np.abs(mpc.lam_g_num)))
+    if o_over is not None:
+        assert np.max(x[ps.off_eps:]) > 0.5                                             # (the soft constraint is in use)
+    return mpc
+
+
 # ---------------------------------------------------------------------------------------------- moving horizon estimation
 def oracle_mhe():
     from oracle.mhe import OracleMHE

@@ -54,8 +54,25 @@ def test_tree_tables_are_consistent_for_deeper_trees():
 
 
 def test_unsupported_couplings_are_refused_loudly():
-    with pytest.raises(NotImplementedError):
-        build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=5, n_comb=3, n_robust=1, discrete=False, open_loop=True)
+    # open_loop with several scenarios: the reference's layout (`_u` with ONE scenario slot, _mpc.py:1112-1117); the problem itself runs as
+    # a chain over the stacked scenario states (do_mpc_amd/open_loop.py) - refused by name where that chain is too large for the kernels
+    ps = build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=5, n_comb=3, n_robust=1, discrete=False, open_loop=True)
+    ref = build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=0, ns=0, deg=2, ni=1, N=5, n_comb=3, n_robust=1, discrete=False)
+    assert ps.open_loop_stack and ps.SU == 1 and ps.n_opt_x == ref.n_opt_x - 5 * 2 * 1 and ps.n_g == ref.n_g
+    assert all(ps.tables["node_u_off"][n] == ps.iu(int(ps.tables["node_level"][n]), 0) for n in range(ps.n_nodes) if ps.tables["node_level"][n] < 5)
+    from do_mpc_amd import controller
+    from do_mpc_amd.examples import CASES
+    import __graft_entry__ as ge
+    orig = controller.HipIpmSolver
+    controller.HipIpmSolver = ge._NoSolver
+    try:
+        ex = CASES["industrial_poly"]
+        with pytest.raises(NotImplementedError, match="stacked collocation unknowns"):
+            ex.build_mpc(ex.build_model(), open_loop=True)
+        with pytest.raises(NotImplementedError, match="soft constraints"):
+            CASES["CSTR"].build_mpc(CASES["CSTR"].build_model(), open_loop=True, n_robust=2, n_horizon=6, uncertainty=dict(alpha=[1.0, 1.05], beta=[1.0]))
+    finally:
+        controller.HipIpmSolver = orig
     with pytest.raises(NotImplementedError):      # nl_cons_single_slack: more shared slack variables than the kernels' Schur complement holds
         build_structure(nx=2, nu=1, nz=0, np_=1, ntvp=0, ne=1, ns=1, deg=2, ni=1, N=5, n_comb=7, n_robust=2, discrete=False, single_slack=True)
     with pytest.raises(NotImplementedError):      # ... slack entries of scenario slots that no node reads
