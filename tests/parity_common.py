@@ -474,6 +474,24 @@ OPEN_LOOP_CASES = [
 ]
 
 
+def check_single_slack_batch(make_mpc, B=6):
+    """B problems with shared slacks in one launch (every workgroup runs its own Schur complement in its slot's workspace) = B single solves"""
+    mpc = make_mpc("CSTR", nl_cons_single_slack=True, max_batch=B)
+    rng = np.random.default_rng(3)
+    X0 = np.array([0.8, 0.5, 141.0, 138.0]) * (1.0 + 0.004 * rng.standard_normal((B, 4)))
+    r = mpc.make_step_batch(X0)
+    assert np.all(r["stats"]["success"] == 1)
+    for b in (0, B - 1):
+        m1 = make_mpc("CSTR", nl_cons_single_slack=True)
+        m1.x0 = X0[b]
+        m1.set_initial_guess()
+        u = m1.make_step(X0[b]).ravel()
+        assert m1.solver_stats["iter_count"] == r["stats"]["iter_count"][b]
+        assert relerr(u, r["u0"][b]) < 1e-9 and relerr(m1.opt_x_num.master, r["x"][b]) < 1e-9
+    assert np.max(r["x"][:, mpc.structure.off_eps:]) > 0.5
+    return mpc
+
+
 def check_open_loop(make_mpc, over, o_over, x0):
     """CSTR with `open_loop=True` against the oracle's solve of the restated NLP (shared `_u[k, 0]`, oracle/nlp.py): first input, every
     variable that a node reads, multipliers, iteration count within two (the stacked chain carries a copy of a shared tree node per leaf

@@ -327,6 +327,10 @@ def test_single_slack_shared_by_all_stages(over, x0):
     pc.check_single_slack(make_mpc, over, x0)
 
 
+def test_single_slack_batch_equals_single_solves():
+    pc.check_single_slack_batch(make_mpc)
+
+
 @pytest.mark.parametrize("over,o_over,x0", [c[1:] for c in pc.OPEN_LOOP_CASES], ids=[c[0] for c in pc.OPEN_LOOP_CASES])
 def test_open_loop_with_several_scenarios(over, o_over, x0):
     pc.check_open_loop(make_mpc, over, o_over, x0)
