@@ -210,6 +210,7 @@ struct WsLayout {
   int64_t lam, dlam, c, ct, dlam_sv;
   int64_t s, zsl, zsu, sl, su, ds, st, ds_sv;
   int64_t ew, es, nd, mo, gsc, total;
+  int64_t x_wd, zl_wd, zu_wd, lam_wd, s_wd, zsl_wd, zsu_wd, dlam_e;      // watchdog: the iterate it started from; EPS_GLOBAL: scratch multiplier steps
 };
 
 DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad, int n_nodes) {
@@ -228,6 +229,10 @@ DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad,
   L.nd = take((int64_t)ND_SIZE * n_nodes);
   L.mo = take((int64_t)MO_REC * n_edges);
   L.gsc = take(EPS_GLOBAL ? NVG_MAX * (NVG_MAX + 4) : 0);      // shared slack variables: Schur complement, its Cholesky factor, right-hand side / step
+  // (touched only while a watchdog is active, solve_problem; its direction is kept in dx_sv / dlam_sv / ds_sv - no second-order correction runs meanwhile)
+  L.x_wd = take(n_opt_x); L.zl_wd = take(n_opt_x); L.zu_wd = take(n_opt_x); L.lam_wd = take(n_g);
+  L.s_wd = take(nsl); L.zsl_wd = take(nsl); L.zsu_wd = take(nsl);
+  L.dlam_e = take(EPS_GLOBAL ? n_g : 0);
   o += 256;                       // slack: block-granular staging reads of the last records may run past their end
   L.total = o;
   return L;
@@ -593,6 +598,7 @@ struct Prob {
   double *lam, *dlam, *c, *ct, *dlam_sv;
   double *s, *zsl, *zsu, *sl, *su, *ds, *st, *ds_sv;
   double *ew, *es, *nd, *mo, *gsc;
+  double *x_wd, *zl_wd, *zu_wd, *lam_wd, *s_wd, *zsl_wd, *zsu_wd, *dlam_e;
   int e_pad;
   double sf;                                         // objective scaling
   double mu;
@@ -622,6 +628,8 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   p.s = w + L.s; p.zsl = w + L.zsl; p.zsu = w + L.zsu; p.sl = w + L.sl; p.su = w + L.su;
   p.ds = w + L.ds; p.st = w + L.st; p.ds_sv = w + L.ds_sv;
   p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo; p.gsc = w + L.gsc;
+  p.x_wd = w + L.x_wd; p.zl_wd = w + L.zl_wd; p.zu_wd = w + L.zu_wd; p.lam_wd = w + L.lam_wd;
+  p.s_wd = w + L.s_wd; p.zsl_wd = w + L.zsl_wd; p.zsu_wd = w + L.zsu_wd; p.dlam_e = w + L.dlam_e;
   p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0; p.dsw = 0.0; p.slot = slot;
   return p;
 }
@@ -4583,11 +4591,11 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   };
   // ---- shared slack variables (EPS_GLOBAL): Schur complement on top of the structured solve, see epsg_* above.
   // workspace Q.gsc: S / its Cholesky factor (n_v x n_v, leading dimension NVG_MAX), then [flag | rhs / step (NVG_MAX)]
-  // columns of the Schur complement after the structured step of this iterate (Q.dlam = dlam(c)); returns 1 = wrong inertia
+  // columns of the Schur complement after the structured step of this iterate (Q.dlam = dlam(c), kept in Q.dlam_e); returns 1 = wrong inertia
   auto epsg_build = [&](double delta) -> int {
     const int o = epsg_off(A), nv = epsg_n(A);
     double* G = Q.gsc;
-    for (int g = T.tid; g < A.n_g; g += T.nt) { Q.dlam_sv[g] = Q.dlam[g]; Q.ct[g] = Q.c[g]; }
+    for (int g = T.tid; g < A.n_g; g += T.nt) { Q.dlam_e[g] = Q.dlam[g]; Q.ct[g] = Q.c[g]; }
     T.sync();
     int rc = 0;
     for (int j = 0; j < nv && !rc; ++j) {
@@ -4597,7 +4605,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       if (!rc) rc = run_backward(T, Q, b, slot, mu, delta);
       if (!rc) {
         run_forward(T, Q, b, slot, mu, delta);
-        for (int jp = T.tid; jp < nv; jp += T.nt) G[jp * NVG_MAX + j] = -epsg_rowsum(Q, jp, Q.dlam, Q.dlam_sv);
+        for (int jp = T.tid; jp < nv; jp += T.nt) G[jp * NVG_MAX + j] = -epsg_rowsum(Q, jp, Q.dlam, Q.dlam_e);
       }
     }
     epsg_residual(T, Q, nullptr, -1);                    // Q.c back to c(x)
@@ -4740,8 +4748,32 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   int acc_count = 0;
   const double s_max = 100.0;
   double E0 = 0.0;
+  // IPOPT's watchdog procedure (IpBacktrackingLineSearch; options watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3; not
+  // in the 2006 paper): after `trigger` consecutive iterations whose step was shortened by the backtracking, up to `trial_iter_max` full
+  // fraction-to-the-boundary steps are taken without asking the filter, each tested against the point where the watchdog STARTED
+  // (its theta, barrier objective, directional derivative and step size); none acceptable: back to that point and the direction
+  // computed there, regular backtracking from the second trial step size.  It is what keeps non-convex problems from crawling with
+  // 2^-10 steps for hundreds of iterations (kite over the full horizon: 87 instead of 400 iterations in the oracle with exact inertia,
+  // profiles/r04_crawl_traces.txt).  State: the iterate in Q.*_wd, its direction in Q.dx_sv / dlam_sv / ds_sv (no second-order
+  // correction runs while a watchdog is active), scalars below.
+  int wd_count = 0, wd_iter = 0, n_watchdog = 0;
+  bool in_wd = false, wd_resume = false;
+  double wd_theta = 0.0, wd_phi = 0.0, wd_dphi = 0.0, wd_alpha = 0.0, wd_amax = 0.0, wd_az = 0.0, wd_delta = 0.0, wd_delta_last = 0.0, wd_bar = 0.0;
+  Errs wd_E = E;
+  double delta = 0.0, a_max = 1.0, a_z = 1.0, dphi = 0.0;
 
   while (true) {
+    bool skip_first = false;
+    if (wd_resume) {
+      // the watchdog gave up: back at the point where it started, with the direction computed there
+      for (int g = T.tid; g < nX; g += T.nt) { Q.x[g] = Q.x_wd[g]; Q.zl[g] = Q.zl_wd[g]; Q.zu[g] = Q.zu_wd[g]; Q.dx[g] = Q.dx_sv[g]; }
+      for (int g = T.tid; g < A.n_g; g += T.nt) { Q.lam[g] = Q.lam_wd[g]; Q.dlam[g] = Q.dlam_sv[g]; }
+      for (int g = T.tid; g < nSl; g += T.nt) { Q.s[g] = Q.s_wd[g]; Q.zsl[g] = Q.zsl_wd[g]; Q.zsu[g] = Q.zsu_wd[g]; Q.ds[g] = Q.ds_sv[g]; }
+      T.sync();
+      E = wd_E; bar_sum = wd_bar; delta = wd_delta; delta_last = wd_delta_last; a_max = wd_amax; a_z = wd_az; dphi = wd_dphi;
+      wd_resume = false;
+      skip_first = true;
+    } else {
     if (bad) { status = 3; break; }
     if (T.fget(6)) { status = 6; break; }                                    // the host asked the kernel to stop
     if ((T.nwg > 1 || sh_on(A)) && T.fget(7)) { status = 5; break; }       // a peer workgroup never arrived at a barrier
@@ -4766,12 +4798,13 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         mu = fmax(mu_min, fmin(O.kappa_mu * mu, pow(mu, O.theta_mu)));
         tau = fmax(O.tau_min, 1.0 - mu);
         n_filt = 0;
+        in_wd = false; wd_count = 0;      // (a new barrier problem: the watchdog's reference point is void)
       } else break;
     }
     if (mu != mu_before) refresh_mu(T, Q, mu - mu_before);
 
     // ---- search direction with inertia correction (delta_w on all primal variables)
-    double delta = 0.0;
+    delta = 0.0;
     bool first_try = true, dir_ok = true, recs_dirty = false;
     while (true) {
       c_t = prof_clock();
@@ -4802,7 +4835,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (!dir_ok) { status = 3; break; }
     if (delta > 0.0) { delta_last = delta; ++n_reg; }
     c_t = prof_clock();
-    if (EPS_GLOBAL) { if (epsg_apply(delta, Q.dlam_sv)) { status = 3; break; } }
+    if (EPS_GLOBAL) { if (epsg_apply(delta, Q.dlam_e)) { status = 3; break; } }
     else run_forward(T, Q, b, slot, mu, delta);
     c_fwd += prof_clock() - c_t;
 
@@ -4810,12 +4843,13 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     c_t = prof_clock();
     // largest ratios (-dx)/(x - l), dx/(u - x) and (-dz)/z over the bounded variables: the fraction-to-the-boundary steps
     // are tau / ratio (one division at the end instead of one per bound), and the directional derivative of the barrier function
-    auto step_rules = [&](double (&r5)[5]) { run_step_rules(T, Q, b, slot, mu, r5); };
     double r5[5];
-    step_rules(r5);
-    const double a_max = (r5[0] > tau) ? tau / r5[0] : 1.0, dphi = r5[2];
-    double a_z = (r5[1] > tau) ? tau / r5[1] : 1.0;
+    run_step_rules(T, Q, b, slot, mu, r5);
+    a_max = (r5[0] > tau) ? tau / r5[0] : 1.0; dphi = r5[2];
+    a_z = (r5[1] > tau) ? tau / r5[1] : 1.0;
     c_ftb += prof_clock() - c_t;
+    }     // (!wd_resume)
+    auto step_rules = [&](double (&r5)[5]) { run_step_rules(T, Q, b, slot, mu, r5); };
     const double theta = E.theta;
     const double phi = E.obj + mu * bar_sum;       // (the barrier sum of the current point was formed when it was a trial point)
 
@@ -4837,7 +4871,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       ++n_trials;
     };
     // filter / sufficient-decrease tests of a trial point reached with step size al (IPOPT eqs. (18)-(20))
-    auto acceptable = [&](double th_, double ph_, double al, bool& armijo_case) -> bool {
+    auto acceptable_ref = [&](double th_, double ph_, double al, bool& armijo_case, double theta, double phi, double dphi) -> bool {
       armijo_case = false;
       bool ok = (ph_ == ph_) && (th_ == th_) && fabs(ph_) < INFINITY && th_ <= theta_max;
       if (ok) {
@@ -4856,6 +4890,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       }
       return ok;
     };
+    auto acceptable = [&](double th_, double ph_, double al, bool& armijo_case) -> bool { return acceptable_ref(th_, ph_, al, armijo_case, theta, phi, dphi); };
     // corrected constraint residual of the second-order correction: c <- al * c + c(trial point)   (IPOPT eq. (27))
     auto soc_residual = [&](double al) {
       double c_[DOMPC_FW], ct_[DOMPC_FW];
@@ -4874,11 +4909,37 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       for (int g = T.tid; g < nSl; g += T.nt) { if (restore) Q.ds[g] = Q.ds_sv[g]; else Q.ds_sv[g] = Q.ds[g]; }
       T.sync();
     };
-    double alpha = a_max;
+    double alpha = skip_first ? 0.5 * a_max : a_max;
     bool accepted = false, armijo_used = false, stale = false;
     double th_t = 0.0, obj_t = 0.0, bar_t = bar_sum;
-    int n_ls = 0;
-    while (true) {
+    int n_ls = skip_first ? 1 : 0;
+    bool wd_done = false, wd_augment_ref = false, wd_no_augment = false;
+    if (O.watchdog_shortened_iter_trigger > 0 && !in_wd && !skip_first && wd_count >= O.watchdog_shortened_iter_trigger) {
+      in_wd = true; wd_iter = 0; ++n_watchdog;
+      for (int g = T.tid; g < nX; g += T.nt) { Q.x_wd[g] = Q.x[g]; Q.zl_wd[g] = Q.zl[g]; Q.zu_wd[g] = Q.zu[g]; Q.dx_sv[g] = Q.dx[g]; }
+      for (int g = T.tid; g < A.n_g; g += T.nt) { Q.lam_wd[g] = Q.lam[g]; Q.dlam_sv[g] = Q.dlam[g]; }
+      for (int g = T.tid; g < nSl; g += T.nt) { Q.s_wd[g] = Q.s[g]; Q.zsl_wd[g] = Q.zsl[g]; Q.zsu_wd[g] = Q.zsu[g]; Q.ds_sv[g] = Q.ds[g]; }
+      T.sync();
+      wd_E = E; wd_bar = bar_sum; wd_delta = delta; wd_delta_last = delta_last; wd_amax = a_max; wd_az = a_z;
+      wd_theta = theta; wd_phi = phi; wd_dphi = dphi; wd_alpha = a_max;
+    }
+    if (in_wd) {
+      eval_trial(alpha, obj_t, th_t, bar_t);
+      bool armijo_case = false;
+      if (acceptable_ref(th_t, obj_t + mu * bar_t, wd_alpha, armijo_case, wd_theta, wd_phi, wd_dphi)) {
+        accepted = true; armijo_used = armijo_case; wd_done = true; wd_augment_ref = true;
+        in_wd = false; wd_count = 0;
+      } else {
+        ++wd_iter;
+        const double ph_ = obj_t + mu * bar_t;
+        if (wd_iter > O.watchdog_trial_iter_max || !(ph_ == ph_) || !(th_t == th_t) || !(fabs(ph_) < INFINITY)) {
+          wd_resume = true; in_wd = false; wd_count = 0;
+          continue;
+        }
+        accepted = true; wd_done = true; wd_no_augment = true;       // taken without asking the filter; no filter entry
+      }
+    }
+    while (!wd_done) {
       eval_trial(alpha, obj_t, th_t, bar_t);
       stale = false;
       bool armijo_case = false;
@@ -4927,15 +4988,16 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     }
     if (bad) { status = 3; break; }
     if (!accepted && stale) eval_trial(alpha, obj_t, th_t, bar_t);
+    if (!wd_done) wd_count = n_ls > 0 ? wd_count + 1 : 0;         // consecutive iterations with a shortened step
     if (!accepted) {
       // no restoration phase: take the smallest trial step and reset the filter
       ++n_ls_fail;
       n_filt = 0;
-    } else if (!armijo_used) {
+    } else if (!armijo_used && !wd_no_augment) {
       if (T.ltid == 0) {
         int q = n_filt < MAX_FILTER ? n_filt : MAX_FILTER - 1;
-        T.filt[2 * q] = (1.0 - gamma_theta) * theta;
-        T.filt[2 * q + 1] = phi - gamma_phi * theta;
+        T.filt[2 * q] = (1.0 - gamma_theta) * (wd_augment_ref ? wd_theta : theta);
+        T.filt[2 * q + 1] = (wd_augment_ref ? wd_phi : phi) - gamma_phi * (wd_augment_ref ? wd_theta : theta);
       }
       if (n_filt < MAX_FILTER) ++n_filt;
       T.lsync();
@@ -4984,7 +5046,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (A.stats) {
       dompc_stats& S = A.stats[b];
       S.success = (status == 0 || status == 1) ? 1 : 0;
-      S.status = status; S.iter_count = it; S.n_reg = n_reg; S.n_ls_fail = n_ls_fail; S.n_sweeps = n_sweeps; S.n_trials = n_trials; S.n_soc = n_soc;
+      S.status = status; S.iter_count = it; S.n_reg = n_reg; S.n_ls_fail = n_ls_fail; S.n_sweeps = n_sweeps; S.n_trials = n_trials; S.n_soc = n_soc; S.n_watchdog = n_watchdog; S.reserved0 = 0;
       S.mu = mu; S.obj = E.obj * isf; S.inf_pr = E.e_p; S.inf_du = E.e_d; S.inf_compl = comp_err(E.C, 0.0);
       S.obj_scaling = Q.sf; S.t_wall_total = 0.0;
     }

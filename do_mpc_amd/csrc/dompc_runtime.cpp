@@ -192,6 +192,7 @@ extern "C" void dompc_default_options(dompc_options* o) {
   o->kappa_w_minus = 1.0 / 3.0; o->kappa_w_plus = 8.0; o->kappa_w_plus_bar = 100.0;
   o->max_iter = 3000; o->acceptable_iter = 15; o->obj_scaling = 1; o->max_soc = 4;
   o->constr_mult_init_max = 1000.0;
+  o->watchdog_shortened_iter_trigger = 10; o->watchdog_trial_iter_max = 3;
 }
 
 extern "C" const char* dompc_status_string(int32_t s) {

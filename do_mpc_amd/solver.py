@@ -29,7 +29,7 @@ class Options(C.Structure):
         "theta_mu", "kappa_eps", "tau_min", "bound_push", "bound_frac", "bound_relax_factor",
         "nlp_scaling_max_gradient", "delta_w_0", "delta_w_min", "delta_w_max", "kappa_w_minus", "kappa_w_plus",
         "kappa_w_plus_bar")] + [(n, C.c_int32) for n in ("max_iter", "acceptable_iter", "obj_scaling", "max_soc")] + [
-        ("constr_mult_init_max", C.c_double)]
+        ("constr_mult_init_max", C.c_double), ("watchdog_shortened_iter_trigger", C.c_int32), ("watchdog_trial_iter_max", C.c_int32)]
 
 
 class ProblemDesc(C.Structure):
@@ -46,7 +46,8 @@ class ProblemDesc(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("success", "status", "iter_count", "n_reg", "n_ls_fail", "n_sweeps", "n_trials", "n_soc")] + \
+    _fields_ = [(n, C.c_int32) for n in ("success", "status", "iter_count", "n_reg", "n_ls_fail", "n_sweeps", "n_trials", "n_soc", "n_watchdog",
+                                             "reserved0")] + \
                [(n, C.c_double) for n in ("mu", "obj", "inf_pr", "inf_du", "inf_compl", "obj_scaling", "t_wall_total")]
 
 
@@ -62,7 +63,7 @@ class ShardDesc(C.Structure):
 
 
 STATS_DTYPE = np.dtype([("success", "i4"), ("status", "i4"), ("iter_count", "i4"), ("n_reg", "i4"),
-                        ("n_ls_fail", "i4"), ("n_sweeps", "i4"), ("n_trials", "i4"), ("n_soc", "i4"), ("mu", "f8"), ("obj", "f8"), ("inf_pr", "f8"),
+                        ("n_ls_fail", "i4"), ("n_sweeps", "i4"), ("n_trials", "i4"), ("n_soc", "i4"), ("n_watchdog", "i4"), ("reserved0", "i4"), ("mu", "f8"), ("obj", "f8"), ("inf_pr", "f8"),
                         ("inf_du", "f8"), ("inf_compl", "f8"), ("obj_scaling", "f8"), ("t_wall_total", "f8")])
 assert STATS_DTYPE.itemsize == C.sizeof(Stats)
 
@@ -78,6 +79,7 @@ _IPOPT_OPTS = {
     "ipopt.first_hessian_perturbation": "delta_w_0", "ipopt.min_hessian_perturbation": "delta_w_min",
     "ipopt.max_hessian_perturbation": "delta_w_max", "ipopt.max_soc": "max_soc",
     "ipopt.constr_mult_init_max": "constr_mult_init_max",
+    "ipopt.watchdog_shortened_iter_trigger": "watchdog_shortened_iter_trigger", "ipopt.watchdog_trial_iter_max": "watchdog_trial_iter_max",
 }
 
 
@@ -342,7 +344,7 @@ class HipIpmSolver:
         status = self._lib.dompc_status_string(int(s["status"])).decode()
         return {"success": bool(s["success"]), "return_status": status, "iter_count": int(s["iter_count"]),
                 "t_wall_total": float(s["t_wall_total"]), "t_proc_total": float(s["t_wall_total"]),
-                "n_reg": int(s["n_reg"]), "n_ls_fail": int(s["n_ls_fail"]), "n_sweeps": int(s["n_sweeps"]), "n_trials": int(s["n_trials"]), "n_soc": int(s["n_soc"]),
+                "n_reg": int(s["n_reg"]), "n_ls_fail": int(s["n_ls_fail"]), "n_sweeps": int(s["n_sweeps"]), "n_trials": int(s["n_trials"]), "n_soc": int(s["n_soc"]), "n_watchdog": int(s["n_watchdog"]),
                 "mu": float(s["mu"]), "obj": float(s["obj"]), "inf_pr": float(s["inf_pr"]),
                 "inf_du": float(s["inf_du"]), "obj_scaling": float(s["obj_scaling"]),
                 "unified_return_status": "SOLVER_RET_SUCCESS" if s["success"] else "SOLVER_RET_UNKNOWN"}

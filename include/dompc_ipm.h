@@ -62,6 +62,9 @@ typedef struct dompc_options {
   double constr_mult_init_max; /* ipopt.constr_mult_init_max: least-squares multiplier estimate at the starting point,
                                   discarded if its max-norm is above this value   1000 (0 = start from lambda = 0);
                                   models with nl_cons rows always start from lambda = 0 */
+  int32_t watchdog_shortened_iter_trigger; /* ipopt.watchdog_shortened_iter_trigger: consecutive iterations with a shortened step
+                                              after which the watchdog procedure starts   10 (0 = off) */
+  int32_t watchdog_trial_iter_max;         /* ipopt.watchdog_trial_iter_max: full steps it may take without the filter   3 */
 } dompc_options;
 
 /* Description of one multi-stage problem class (fixed at MPC.setup()). All pointers are host
@@ -110,6 +113,8 @@ typedef struct dompc_stats {
   int32_t n_sweeps;         /* derivative sweeps executed (model evaluation + condensing of every edge)        */
   int32_t n_trials;         /* function-only trial sweeps of the line search                                 */
   int32_t n_soc;            /* second-order correction solves (each one more sweep + Riccati pass)            */
+  int32_t n_watchdog;       /* watchdog procedures started (IPOPT: watchdog_shortened_iter_trigger)            */
+  int32_t reserved0;
   double  mu;
   double  obj;              /* unscaled objective                                                          */
   double  inf_pr, inf_du, inf_compl; /* scaled errors at exit                                                  */

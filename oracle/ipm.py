@@ -23,6 +23,8 @@ Deviations from IPOPT (documented, none changes the limit point of a convex prob
     IPOPT does with MUMPS) - O(n^3), for the small non-convex cases of the test-suite;
   * no restoration phase: if the backtracking line search hits alpha_min the last
     trial step is taken and the filter is reset (counted in stats['n_ls_fail']).
+Beyond the paper, from IPOPT's implementation (both default-on there): the damping of one-sided bounds (kappa_d) and the watchdog
+procedure of the line search (watchdog_shortened_iter_trigger / watchdog_trial_iter_max, see DEFAULTS).
 """
 import time
 
@@ -44,6 +46,11 @@ DEFAULTS = dict(
     fast=False,         # bench.py's cpu_baseline: same algorithm and control flow, cheaper linear algebra - see _FastKKT below
     kappa_d=1e-5,       # linear damping of the barrier for variables with ONE bound (section 3.7 of the paper)
     nlp_scaling_max_gradient=100.0, nlp_scaling_min_value=1e-8, obj_scaling=True, con_scaling=True,
+    # IPOPT's watchdog procedure (IpBacktrackingLineSearch: options watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3;
+    # not in the 2006 paper): after that many consecutive iterations whose step was shortened by the backtracking, up to 3 full steps
+    # are taken without asking the filter, each tested against the point where the watchdog started; none acceptable: back to that
+    # point and its direction, regular backtracking from the second trial step size.  0 = off.
+    watchdog_shortened_iter_trigger=10, watchdog_trial_iter_max=3,
 )
 
 
@@ -286,112 +293,123 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
     success = False
     acc_count = 0
     it = 0
+    wd_count, in_wd, wd_iter, wd, wd_restart = 0, False, 0, None, None
+    stats["n_watchdog"] = 0
     while True:
-        E0, e_d, e_p, e_c = err(0.0, v, y, zl, zu, gf, A, c)
-        if trace is not None:
-            trace.append(dict(it=it, mu=mu, E0=E0, inf_du=e_d, inf_pr=e_p, compl=e_c, f=fval / sf, x=v[:n].copy()))
-        # unscaled acceptance thresholds are checked on scaled quantities here (scaling is mild)
-        if E0 <= o["tol"] and e_d <= o["dual_inf_tol"] and e_p <= o["constr_viol_tol"] and e_c <= o["compl_inf_tol"]:
-            status, success = "Solve_Succeeded", True
-            break
-        if E0 <= o["acceptable_tol"]:
-            acc_count += 1
-            if acc_count >= o["acceptable_iter"]:
-                status, success = "Solved_To_Acceptable_Level", True
+        if wd_restart is None:
+            E0, e_d, e_p, e_c = err(0.0, v, y, zl, zu, gf, A, c)
+            if trace is not None:
+                trace.append(dict(it=it, mu=mu, E0=E0, inf_du=e_d, inf_pr=e_p, compl=e_c, f=fval / sf, x=v[:n].copy()))
+            # unscaled acceptance thresholds are checked on scaled quantities here (scaling is mild)
+            if E0 <= o["tol"] and e_d <= o["dual_inf_tol"] and e_p <= o["constr_viol_tol"] and e_c <= o["compl_inf_tol"]:
+                status, success = "Solve_Succeeded", True
                 break
+            if E0 <= o["acceptable_tol"]:
+                acc_count += 1
+                if acc_count >= o["acceptable_iter"]:
+                    status, success = "Solved_To_Acceptable_Level", True
+                    break
+            else:
+                acc_count = 0
+            if it >= o["max_iter"]:
+                break
+        if wd_restart is not None:
+            # the watchdog gave up: back at the point where it started, with the direction computed there
+            (v, y, zl, zu, fval, gval, c, A, gf, mu, tau, filt, delta_w, delta_w_last, lu, rx, dv, dy, dzl, dzu, a_max, a_z, dl, du) = wd_restart
+            wd_restart = None
+            skip_first = True
         else:
-            acc_count = 0
-        if it >= o["max_iter"]:
-            break
-        # ---- barrier update
-        while True:
-            Emu = err(mu, v, y, zl, zu, gf, A, c)[0]
-            if Emu <= o["kappa_eps"] * mu and mu > mu_min:
-                mu = max(mu_min, min(o["kappa_mu"] * mu, mu ** o["theta_mu"]))
-                tau = max(o["tau_min"], 1.0 - mu)
-                filt = []
-            else:
-                break
-        # ---- search direction
-        W = hess_full(v[:n], y)
-        dl = np.where(has_l, v - vl, 1.0)
-        du = np.where(has_u, vu - v, 1.0)
-        sigma = np.where(has_l, zl / dl, 0.0) + np.where(has_u, zu / du, 0.0)
-        rx = gf + A.T @ y - np.where(has_l, mu / dl, 0.0) + np.where(has_u, mu / du, 0.0) + damp(mu)
-        rhs = -np.concatenate([rx, c])
-        delta_w, delta_c = 0.0, 0.0
-        first_try = True
-        tried_c = False
-        while True:
-            Hreg = W + sps.diags(sigma + delta_w)
-            ok = True
-            try:
-                if fast is not None:
-                    if fast.structurally_singular(W, A, sigma, delta_w):
-                        raise RuntimeError("structurally singular")
-                    lu = fast.factor(W, A, sigma + delta_w, delta_c, m)
-                    kmul = lu.matvec
+            skip_first = False
+            # ---- barrier update
+            while True:
+                Emu = err(mu, v, y, zl, zu, gf, A, c)[0]
+                if Emu <= o["kappa_eps"] * mu and mu > mu_min:
+                    mu = max(mu_min, min(o["kappa_mu"] * mu, mu ** o["theta_mu"]))
+                    tau = max(o["tau_min"], 1.0 - mu)
+                    filt = []
+                    in_wd, wd_count = False, 0          # (a new barrier problem: reference point and filter of the watchdog are void)
                 else:
-                    K = sps.bmat([[Hreg, A.T], [A, -delta_c * sps.identity(m) if delta_c > 0 else None]], format="csc")
-                    lu = spla.splu(K)
-                    kmul = K.__matmul__
-                sol = lu.solve(rhs)
-                # one step of iterative refinement (IPOPT: min_refinement_steps = 1); opts["refine"] = 0 leaves it out - the
-                # product's structured solve has none, which can delay the 1e-8 termination test by an iteration or two
-                for _ in range(int(o.get("refine", 1))):
-                    sol += lu.solve(rhs - kmul(sol))
-                ok = np.all(np.isfinite(sol))
-            except RuntimeError:
-                # singular system (IpPDPerturbationHandler::PerturbForSingularity while the kind of degeneracy is unknown):
-                # first delta_c > 0 with delta_w = 0; if that is singular too, delta_c back to 0 and delta_w from the
-                # wrong-inertia rule.  (A system that is singular because of zero rows AND columns of the Hessian block -
-                # the unused variables of the do-mpc NLP - always ends in the second case: delta_c = 0.)
-                ok = False
-                if o.get("ipopt_delta_c_sequence", True):
-                    if not tried_c and delta_w == 0.0:
-                        tried_c = True
+                    break
+            # ---- search direction
+            W = hess_full(v[:n], y)
+            dl = np.where(has_l, v - vl, 1.0)
+            du = np.where(has_u, vu - v, 1.0)
+            sigma = np.where(has_l, zl / dl, 0.0) + np.where(has_u, zu / du, 0.0)
+            rx = gf + A.T @ y - np.where(has_l, mu / dl, 0.0) + np.where(has_u, mu / du, 0.0) + damp(mu)
+            rhs = -np.concatenate([rx, c])
+            delta_w, delta_c = 0.0, 0.0
+            first_try = True
+            tried_c = False
+            while True:
+                Hreg = W + sps.diags(sigma + delta_w)
+                ok = True
+                try:
+                    if fast is not None:
+                        if fast.structurally_singular(W, A, sigma, delta_w):
+                            raise RuntimeError("structurally singular")
+                        lu = fast.factor(W, A, sigma + delta_w, delta_c, m)
+                        kmul = lu.matvec
+                    else:
+                        K = sps.bmat([[Hreg, A.T], [A, -delta_c * sps.identity(m) if delta_c > 0 else None]], format="csc")
+                        lu = spla.splu(K)
+                        kmul = K.__matmul__
+                    sol = lu.solve(rhs)
+                    # one step of iterative refinement (IPOPT: min_refinement_steps = 1); opts["refine"] = 0 leaves it out - the
+                    # product's structured solve has none, which can delay the 1e-8 termination test by an iteration or two
+                    for _ in range(int(o.get("refine", 1))):
+                        sol += lu.solve(rhs - kmul(sol))
+                    ok = np.all(np.isfinite(sol))
+                except RuntimeError:
+                    # singular system (IpPDPerturbationHandler::PerturbForSingularity while the kind of degeneracy is unknown):
+                    # first delta_c > 0 with delta_w = 0; if that is singular too, delta_c back to 0 and delta_w from the
+                    # wrong-inertia rule.  (A system that is singular because of zero rows AND columns of the Hessian block -
+                    # the unused variables of the do-mpc NLP - always ends in the second case: delta_c = 0.)
+                    ok = False
+                    if o.get("ipopt_delta_c_sequence", True):
+                        if not tried_c and delta_w == 0.0:
+                            tried_c = True
+                            delta_c = o["delta_c_bar"] * mu ** o["kappa_c"]
+                            continue
+                        delta_c = 0.0
+                    elif delta_c == 0.0:
                         delta_c = o["delta_c_bar"] * mu ** o["kappa_c"]
-                        continue
-                    delta_c = 0.0
-                elif delta_c == 0.0:
-                    delta_c = o["delta_c_bar"] * mu ** o["kappa_c"]
-            if ok and o["inertia"] == "ldl":
-                if fast is not None:
-                    K = sps.bmat([[Hreg, A.T], [A, -delta_c * sps.identity(m) if delta_c > 0 else None]], format="csc")
-                if _n_negative(K) == m:
-                    break
-            elif ok:
-                # (variables that appear in no constraint and no Hessian entry - the unused slots of the do-mpc NLP - are
-                #  decoupled 1x1 blocks with the pivot sigma + delta_w > 0: they cannot spoil the inertia, but with
-                #  delta_w ~ 1e-12 their tiny curvature dominated this test and rejected correct factorisations; the exact
-                #  count, inertia="ldl", accepts those)
-                coupled = (np.diff(A.tocsc().indptr) > 0) | (np.diff(W.tocsr().indptr) > 0)
-                dv = sol[:nv] * coupled
-                curv = dv @ (Hreg @ dv)
-                if curv >= 1e-11 * (dv @ dv) or (dv @ dv) == 0.0:
-                    break
-            stats["n_reg"] += 1
-            if delta_w == 0.0:
-                delta_w = o["delta_w_0"] if delta_w_last == 0.0 else max(o["delta_w_min"], o["kappa_w_minus"] * delta_w_last)
-            else:
-                delta_w *= o["kappa_w_plus_bar"] if (delta_w_last == 0.0 and first_try) else o["kappa_w_plus"]
-                if delta_w > o["delta_w_max"]:
-                    raise RuntimeError("inertia correction failed")
-            first_try = False
-        if delta_w > 0:
-            delta_w_last = delta_w
-        dv, dy = sol[:nv], sol[nv:]
-        dzl = np.where(has_l, mu / dl - zl - zl / dl * dv, 0.0)
-        dzu = np.where(has_u, mu / du - zu + zu / du * dv, 0.0)
+                if ok and o["inertia"] == "ldl":
+                    if fast is not None:
+                        K = sps.bmat([[Hreg, A.T], [A, -delta_c * sps.identity(m) if delta_c > 0 else None]], format="csc")
+                    if _n_negative(K) == m:
+                        break
+                elif ok:
+                    # (variables that appear in no constraint and no Hessian entry - the unused slots of the do-mpc NLP - are
+                    #  decoupled 1x1 blocks with the pivot sigma + delta_w > 0: they cannot spoil the inertia, but with
+                    #  delta_w ~ 1e-12 their tiny curvature dominated this test and rejected correct factorisations; the exact
+                    #  count, inertia="ldl", accepts those)
+                    coupled = (np.diff(A.tocsc().indptr) > 0) | (np.diff(W.tocsr().indptr) > 0)
+                    dv = sol[:nv] * coupled
+                    curv = dv @ (Hreg @ dv)
+                    if curv >= 1e-11 * (dv @ dv) or (dv @ dv) == 0.0:
+                        break
+                stats["n_reg"] += 1
+                if delta_w == 0.0:
+                    delta_w = o["delta_w_0"] if delta_w_last == 0.0 else max(o["delta_w_min"], o["kappa_w_minus"] * delta_w_last)
+                else:
+                    delta_w *= o["kappa_w_plus_bar"] if (delta_w_last == 0.0 and first_try) else o["kappa_w_plus"]
+                    if delta_w > o["delta_w_max"]:
+                        raise RuntimeError("inertia correction failed")
+                first_try = False
+            if delta_w > 0:
+                delta_w_last = delta_w
+            dv, dy = sol[:nv], sol[nv:]
+            dzl = np.where(has_l, mu / dl - zl - zl / dl * dv, 0.0)
+            dzu = np.where(has_u, mu / du - zu + zu / du * dv, 0.0)
 
-        def ftb(val, d):
-            neg = d < 0
-            if not neg.any():
-                return 1.0
-            return min(1.0, np.min(-tau * val[neg] / d[neg]))
+            def ftb(val, d):
+                neg = d < 0
+                if not neg.any():
+                    return 1.0
+                return min(1.0, np.min(-tau * val[neg] / d[neg]))
 
-        a_max = min(ftb(dl[has_l], dv[has_l]), ftb(du[has_u], -dv[has_u]))
-        a_z = min(ftb(zl[has_l], dzl[has_l]), ftb(zu[has_u], dzu[has_u]))
+            a_max = min(ftb(dl[has_l], dv[has_l]), ftb(du[has_u], -dv[has_u]))
+            a_z = min(ftb(zl[has_l], dzl[has_l]), ftb(zu[has_u], dzu[has_u]))
 
         # ---- filter line search
         theta = np.abs(c).sum()
@@ -409,24 +427,52 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
             a_min = o["gamma_alpha"] * o["gamma_theta"]
         a_min = max(a_min, 1e-14)
 
-        def acceptable(th_t, ph_t, alpha):
+        def acceptable(th_t, ph_t, alpha, ref=None):
+            theta_, phi_, dphi_ = ref if ref is not None else (theta, phi, dphi)      # (watchdog: the point where it started)
             if th_t > theta_max:
                 return False, False
             for (tf, pf) in filt:
                 if th_t >= tf and ph_t >= pf:
                     return False, False
-            switching = dphi < 0 and alpha * (-dphi) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]
-            if theta <= theta_min and switching:
-                eps_m = 10 * np.finfo(float).eps * abs(phi)
-                return ph_t - phi - eps_m <= o["eta_phi"] * alpha * dphi, True
-            eps_m = 10 * np.finfo(float).eps * abs(phi)
-            return (th_t <= (1 - o["gamma_theta"]) * theta) or (ph_t - phi - eps_m <= -o["gamma_phi"] * theta), False
+            switching = dphi_ < 0 and alpha * (-dphi_) ** o["s_phi"] > o["delta"] * theta_ ** o["s_theta"]
+            if theta_ <= theta_min and switching:
+                eps_m = 10 * np.finfo(float).eps * abs(phi_)
+                return ph_t - phi_ - eps_m <= o["eta_phi"] * alpha * dphi_, True
+            eps_m = 10 * np.finfo(float).eps * abs(phi_)
+            return (th_t <= (1 - o["gamma_theta"]) * theta_) or (ph_t - phi_ - eps_m <= -o["gamma_phi"] * theta_), False
 
-        alpha = a_max
         accepted = False
         n_ls = 0
         used_dv = dv
-        while alpha >= a_min:
+        augment_ref = None                  # filter augmentation w.r.t. this reference point (None: the current iterate)
+        wd_done = False                     # this iteration's step was decided by the watchdog
+        trig = o["watchdog_shortened_iter_trigger"]
+        if trig > 0 and not in_wd and not skip_first and wd_count >= trig:
+            in_wd, wd_iter = True, 0
+            stats["n_watchdog"] += 1
+            wd = dict(state=(v, y, zl, zu, fval, gval, c, A, gf, mu, tau, list(filt), delta_w, delta_w_last, lu, rx, dv, dy, dzl, dzu, a_max, a_z, dl, du),
+                      ref=(theta, phi, dphi), alpha_test=a_max)
+        if in_wd:
+            alpha = a_max
+            v_t = v + alpha * dv
+            f_t, g_t = eval_fg(v_t[:n])
+            c_t = cons(g_t, v_t[n:])
+            th_t = np.abs(c_t).sum()
+            ph_t = barrier(f_t, v_t) if np.isfinite(f_t) else np.inf
+            ok_, armijo = acceptable(th_t, ph_t, wd["alpha_test"], wd["ref"]) if np.isfinite(ph_t) and np.isfinite(th_t) else (False, False)
+            if ok_:
+                accepted, wd_done, in_wd, wd_count = True, True, False, 0
+                augment_ref = wd["ref"] + (wd["alpha_test"],)
+            else:
+                wd_iter += 1
+                if wd_iter > o["watchdog_trial_iter_max"] or not (np.isfinite(ph_t) and np.isfinite(th_t)):
+                    wd_restart, in_wd, wd_count = wd["state"], False, 0
+                    continue
+                accepted, wd_done, armijo = True, True, True      # taken without asking the filter; no filter entry
+                augment_ref = False
+        alpha = a_max * (0.5 if skip_first else 1.0) if not wd_done else alpha
+        n_ls = 1 if (skip_first and not wd_done) else 0
+        while alpha >= a_min and not wd_done:
             v_t = v + alpha * dv
             f_t, g_t = eval_fg(v_t[:n])
             c_t = cons(g_t, v_t[n:])
@@ -480,8 +526,17 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
             c_t = cons(g_t, v_t[n:])
             filt = []
             armijo = True
+        if not wd_done:
+            wd_count = wd_count + 1 if n_ls > 0 else 0          # consecutive iterations with a shortened step
         # ---- filter augmentation
-        if accepted and not armijo:
+        if augment_ref is False:
+            pass
+        elif augment_ref is not None:
+            th_r, ph_r, dph_r, al_r = augment_ref
+            switching = dph_r < 0 and al_r * (-dph_r) ** o["s_phi"] > o["delta"] * th_r ** o["s_theta"]
+            if not (armijo and th_r <= theta_min and switching):
+                filt.append(((1 - o["gamma_theta"]) * th_r, ph_r - o["gamma_phi"] * th_r))
+        elif accepted and not armijo:
             filt.append(((1 - o["gamma_theta"]) * theta, phi - o["gamma_phi"] * theta))
         elif accepted and armijo:
             switching = dphi < 0 and alpha * (-dphi) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]
@@ -512,6 +567,6 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
     res["lam_x"] = (zu[:n] - zl[:n]) / sf
     res["stats"] = dict(success=success, return_status=status, iter_count=it,
                         t_wall_total=time.perf_counter() - t_start, n_eval=n_eval,
-                        n_ls_fail=stats["n_ls_fail"], n_reg=stats["n_reg"], n_soc=stats["n_soc"], mu=mu,
+                        n_ls_fail=stats["n_ls_fail"], n_reg=stats["n_reg"], n_soc=stats["n_soc"], n_watchdog=stats["n_watchdog"], mu=mu,
                         obj_scaling=sf, iters=stats["iters"])
     return res

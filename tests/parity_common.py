@@ -492,6 +492,64 @@ def check_single_slack_batch(make_mpc, B=6):
     return mpc
 
 
+def check_watchdog_on_kite_full_horizon(make_mpc):
+    """IPOPT's watchdog procedure (watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3; restated in oracle/ipm.py and in the
+    device driver) on the non-convex kite problem over its full horizon of 80 stages: without it the line search accepts steps of 2^-10
+    for hundreds of iterations (906; the oracle with exact inertia 400), with it the solve takes 67 iterations (oracle 87).  The point
+    reached is a KKT point of the oracle's NLP with OUR multipliers; product and oracle end in DIFFERENT local minima there (their very
+    first directions differ on this model - the objective of the product's point is the lower one), so no equality of solutions is asserted.
+    `ipopt.watchdog_shortened_iter_trigger = 0` switches it off (the crawl is back).
+    [NO REFERENCE FIXTURE: oracle-or-equivalence check, not a reproduction of a stored reference run]"""
+    ex = CASES["kite"]
+    nlp = oracle_nlp("kite", n_horizon=80)
+    out = {}
+    for trig in (10, 0):
+        mpc = make_mpc("kite", n_horizon=80, nlpsol_opts={"ipopt.watchdog_shortened_iter_trigger": trig})
+        mpc.x0 = ex.X0
+        mpc.set_initial_guess()
+        mpc.make_step(ex.X0)
+        st = out[trig] = mpc.solver_stats
+        assert st["success"]
+        x, p = mpc.opt_x_num.master, mpc.opt_p_num.master
+        gv = nlp.g(x, p)
+        eq = nlp.lbg == nlp.ubg
+        assert np.max(np.abs(gv[eq])) < 1e-7 and np.all(gv[~eq] <= nlp.ubg[~eq] + 1.01e-8 * np.maximum(1.0, np.abs(nlp.ubg[~eq])))   # (bound_relax_factor)
+        rd = nlp.grad(x, p) + nlp.jac(x, p).T @ mpc.lam_g_num + mpc.lam_x_num
+        used = np.ones(nlp.n_opt_x, bool)
+        used[mpc.structure.tables["dummy_idx"]] = False
+        assert np.max(np.abs(rd[used])) < 1e-5 * max(1.0, np.max(np.abs(mpc.lam_g_num)))
+    assert out[10]["n_watchdog"] >= 1 and out[10]["iter_count"] < 150, out[10]
+    assert out[0]["n_watchdog"] == 0 and out[0]["iter_count"] > 3 * out[10]["iter_count"], out[0]
+    return out
+
+
+def mhe_straggler_problem(mhe):
+    """sample 3398 of the cold estimator batch of tools/gpu_config_table.py (rotating masses, window 3 of the reference's run, measurements
+    perturbed with seed 5): chain-layout parameter vector and initial guess"""
+    OP = golden("rotating_masses")["estimator.opt_p_num"]
+    rng = np.random.default_rng(5)
+    for B in (1, 64, 1024, 4096):
+        idx = 1 + np.arange(B) % 4
+        P_ref = OP[idx].copy()
+        P_ref[:, mhe._po_y:] += 1e-3 * rng.standard_normal((B, P_ref.shape[1] - mhe._po_y))
+    init0 = np.zeros(mhe.n_opt_x)
+    init0[mhe._o_p:] = 1e-4
+    return mhe._p_to_chain(P_ref[3398:3399]), mhe._to_chain(init0[None, :])
+
+
+def check_watchdog_on_mhe_straggler(make_mhe):
+    """the one problem of the cold estimator batch that needed 1 551 iterations (22 650 trial points, no failed line search: nothing a
+    restoration phase would have caught) takes 52 with the watchdog, same objective"""
+    mhe = make_mhe()
+    mpc = mhe._mpc
+    P, X0 = mhe_straggler_problem(mhe)
+    r = mhe.S.solve_batch(X0, mpc._lb_opt_x.master, mpc._ub_opt_x.master, mpc._nlp_cons_lb, mpc._nlp_cons_ub, P)
+    st = r["stats"][0]
+    assert st["success"] == 1 and st["n_watchdog"] >= 1 and st["iter_count"] < 200, st
+    assert abs(st["obj"] - 0.139177304916) < 1e-9
+    return st
+
+
 def check_open_loop(make_mpc, over, o_over, x0):
     """CSTR with `open_loop=True` against the oracle's solve of the restated NLP (shared `_u[k, 0]`, oracle/nlp.py): first input, every
     variable that a node reads, multipliers, iteration count within two (the stacked chain carries a copy of a shared tree node per leaf

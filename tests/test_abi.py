@@ -39,7 +39,7 @@ def test_product_simulator_refuses_to_run_without_gpu():
 
 def test_stats_struct_layout_matches_header():
     from do_mpc_amd.solver import STATS_DTYPE, Stats
-    assert ctypes.sizeof(Stats) == STATS_DTYPE.itemsize == 8 * 4 + 7 * 8
+    assert ctypes.sizeof(Stats) == STATS_DTYPE.itemsize == 10 * 4 + 7 * 8      # (8 counters + n_watchdog + one reserved word, then 7 doubles)
 
 
 def test_product_solver_refuses_to_run_without_gpu():

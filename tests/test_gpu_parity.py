@@ -535,3 +535,13 @@ def test_members_of_the_timed_batch_equal_oracle_solves():
         #  stop; measured here 1e-9 on most members, 9e-7 on member 4095, 1.2e-6 on member 2048 with its later stop)
         assert pc.relerr(r["x"][i][used], x_ref[used]) < 1e-5, i
     assert late <= len(members) // 2, late
+
+
+def test_watchdog_ends_the_crawl_on_the_full_horizon_kite_problem():
+    pc.check_watchdog_on_kite_full_horizon(make_mpc)
+
+
+def test_watchdog_on_the_straggler_of_the_cold_estimator_batch():
+    ex = CASES["rotating_masses"]
+    pc.check_watchdog_on_mhe_straggler(lambda: ex.build_mhe(ex.build_model()))
+

@@ -255,3 +255,20 @@ def test_dense_elimination_with_row_loops_equals_the_register_variant(monkeypatc
 def test_mid_size_tree_same_iterates_as_the_oracle():
     """27-leaf industrial_poly tree (n_robust = 3): oracle solve vs the kernels, same iterates"""
     pc.check_tree27_same_iterates_as_oracle(make_mpc)
+
+
+def test_watchdog_ends_the_crawl_on_the_full_horizon_kite_problem():
+    pc.check_watchdog_on_kite_full_horizon(make_mpc)
+
+
+def test_oracle_watchdog_same_limit_point_fewer_iterations():
+    """oracle/ipm.py on the full-horizon kite problem with exact inertia (dense LDL', as IPOPT counts it through MUMPS): the watchdog
+    changes the path, not the local solution - 400 -> 87 iterations"""
+    from oracle import ipm
+    ex = CASES["kite"]
+    nlp = pc.oracle_nlp("kite", n_horizon=80)
+    p = nlp.opt_p(ex.X0, np.zeros(nlp.nu))
+    r = ipm.solve(nlp, nlp.initial_guess(ex.X0), p, opts=dict(inertia="ldl", max_iter=200))
+    assert r["stats"]["success"] and r["stats"]["n_watchdog"] >= 1 and r["stats"]["iter_count"] < 120
+    assert abs(r["f"] - (-1797.72397356)) < 1e-5
+

@@ -164,3 +164,7 @@ def test_discrete_time_mhe_for_a_model_with_algebraic_states():
             return om.build_mhe(om.build_model(estimation=True, dae=dae))
     pc.check_discrete_mhe_dae_equals_ode(make)
 
+
+def test_watchdog_on_the_straggler_of_the_cold_estimator_batch():
+    pc.check_watchdog_on_mhe_straggler(make_mhe)
+
