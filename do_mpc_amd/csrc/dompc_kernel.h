@@ -4774,14 +4774,16 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       wd_resume = false;
       skip_first = true;
     } else {
-    if (bad) { status = 3; break; }
+    // (a tentative watchdog step that leads to a point where the step computation fails - sweep, inertia correction, NaN - ends the
+    //  watchdog like an unacceptable third step: back to the stored point)
+    if (bad) { if (in_wd) { bad = 0; wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; }
     if (T.fget(6)) { status = 6; break; }                                    // the host asked the kernel to stop
     if ((T.nwg > 1 || sh_on(A)) && T.fget(7)) { status = 5; break; }       // a peer workgroup never arrived at a barrier
     const double sd = fmax(s_max, (E.sum_y + E.C.sum_z) / fmax(1.0, n_dual)) / s_max;
     const double sc = fmax(s_max, E.C.sum_z / fmax(1.0, n_bounds)) / s_max;
     const double e_c0 = comp_err(E.C, 0.0);
     E0 = fmax(E.e_d / sd, fmax(E.e_p, e_c0 / sc));
-    if (!(E0 == E0) || !(E.obj == E.obj)) { status = 4; break; }
+    if (!(E0 == E0) || !(E.obj == E.obj)) { if (in_wd) { wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 4; break; }
     if (E0 <= O.tol && E.e_d <= O.dual_inf_tol && E.e_p <= O.constr_viol_tol && e_c0 <= O.compl_inf_tol) {
       status = 0; break;
     }
@@ -4832,7 +4834,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         recs_dirty = false;
       }
     }
-    if (!dir_ok) { status = 3; break; }
+    if (!dir_ok) { if (in_wd) { wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; }
     if (delta > 0.0) { delta_last = delta; ++n_reg; }
     c_t = prof_clock();
     if (EPS_GLOBAL) { if (epsg_apply(delta, Q.dlam_e)) { status = 3; break; } }

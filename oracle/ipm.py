@@ -394,8 +394,13 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
                 else:
                     delta_w *= o["kappa_w_plus_bar"] if (delta_w_last == 0.0 and first_try) else o["kappa_w_plus"]
                     if delta_w > o["delta_w_max"]:
+                        if in_wd:       # (a tentative watchdog step led here: the watchdog ends like after an unacceptable last step)
+                            break
                         raise RuntimeError("inertia correction failed")
                 first_try = False
+            if in_wd and delta_w > o["delta_w_max"]:
+                wd_restart, in_wd, wd_count = wd["state"], False, 0
+                continue
             if delta_w > 0:
                 delta_w_last = delta_w
             dv, dy = sol[:nv], sol[nv:]

@@ -272,3 +272,20 @@ def test_oracle_watchdog_same_limit_point_fewer_iterations():
     assert r["stats"]["success"] and r["stats"]["n_watchdog"] >= 1 and r["stats"]["iter_count"] < 120
     assert abs(r["f"] - (-1797.72397356)) < 1e-5
 
+
+def test_watchdog_same_iterates_as_the_oracle_when_it_starts_after_every_shortened_step():
+    """trigger = 1 on the cold industrial_poly solve: three watchdogs start (and succeed at their first step) in the product AND in the
+    oracle - same 56 iterations, same final iterate: the two restatements of the procedure agree where their iterates are comparable"""
+    from oracle import ipm
+    name = "industrial_poly"
+    mpc = make_mpc(name, nlpsol_opts={"ipopt.watchdog_shortened_iter_trigger": 1})
+    nlp = pc.oracle_nlp(name)
+    x0 = pc.golden(name)["mpc._x"][0]
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    mpc.make_step(x0)
+    st = mpc.solver_stats
+    r = ipm.solve(nlp, nlp.initial_guess(x0), mpc.opt_p_num.master.copy(), opts=dict(watchdog_shortened_iter_trigger=1))
+    assert st["n_watchdog"] == r["stats"]["n_watchdog"] == 3 and st["iter_count"] == r["stats"]["iter_count"] == 56
+    assert pc.relerr(mpc.opt_x_num.master, r["x"]) < 1e-9
+
