@@ -127,7 +127,9 @@ DOMPC_DEV inline void dae_eval_item(const Prob& Q, int kind, int e, int j) {
   } else if (NE > 0) {
     for (int blk = 0; blk < NLB; ++blk) {
       double* o = mo + MO_NL + blk * NL_STRIDE;
-      dompc_nlcons(NL_COLLOC ? w + nl_pt(blk) * NX : xn, un, zb + (NL_COLLOC ? nl_pt(blk) * NZ : 0), tvp, pp, Q.lam + row0 + NW + NX + blk * NEB,
+      double yds[NEB1];     // (scaled rows sg d(x): the Hessian sum_i lambda_i sg_i hess d_i)
+      for (int i = 0; i < NEB; ++i) yds[i] = Q.lam[row0 + NW + NX + blk * NEB + i] * Q.sgn[e * NE1 + blk * NEB + i];
+      dompc_nlcons(NL_COLLOC ? w + nl_pt(blk) * NX : xn, un, zb + (NL_COLLOC ? nl_pt(blk) * NZ : 0), tvp, pp, yds,
                    o, o + NEB, o + NEB + NEB * NAV);
     }
   }
@@ -190,6 +192,7 @@ DOMPC_DEV inline double dae_edge_f(const Prob& Q, int e, const double* xv, const
     const double* eps = (NSE > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
       if (nl_slack(i) >= 0) d[i] -= eps[nl_slack(i)];
+      d[i] *= Q.sgn[e * NE1 + i];
       cv[row0 + NW + NX + i] = d[i] - sv[e * NE1 + i];
     }
     for (int q = 0; q < NSE; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
@@ -311,7 +314,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
   for (int it = lane; it < NE * NAV; it += GS) {
     const int q = it / NAV, i = it % NAV;
     const int v = vtarget_nl(q / NEB1, i);
-    const double jv = mo[MO_NL + (q / NEB1) * NL_STRIDE + NEB + (q % NEB1) * NAV + i];
+    const double jv = mo[MO_NL + (q / NEB1) * NL_STRIDE + NEB + (q % NEB1) * NAV + i] * Q.sgn[e * NE1 + q];
     if (v < NW) Ld[DG_JDW + q * NW + v] = jv;
     else Ld[DG_JDY + q * NA + (v - NW)] = jv;
   }
@@ -555,6 +558,7 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
         double d = mo[MO_NL + (i / NEB1) * NL_STRIDE + i % NEB1];
         if (nl_slack(i) >= 0) d -= eps[nl_slack(i)];
         const int si = e * NE1 + i;
+        d *= Q.sgn[si];
         const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
         double rdn = (Q.soc & 1) ? Q.c[row0 + NW + NX + i] : d - sv;
         if (!(Q.soc & 1)) Q.c[row0 + NW + NX + i] = rdn;
@@ -592,7 +596,7 @@ DOMPC_DEV inline void forward_edge_dae(const Thr& T, const Prob& Q, int e, doubl
   for (int i = lane; i < NE; i += GS) {
     double t = S_[ES_RDN + i];
     for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_JD + i * NA + b) * Ld[DF_DY + b];
-    if (!EPS_GLOBAL && nl_slack(i) >= 0) t -= Q.dx[A.node_eps_off[n] + nl_slack(i)];
+    if (!EPS_GLOBAL && nl_slack(i) >= 0) t -= Q.sgn[e * NE1 + i] * Q.dx[A.node_eps_off[n] + nl_slack(i)];
     Q.ds[e * NE1 + i] = t;
     const double dyd = (S_[ES_SIGS + i] + delta) * t + S_[ES_RSN + i];
     Q.dlam[row0 + NW + NX + i] = dyd;

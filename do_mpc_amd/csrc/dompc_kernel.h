@@ -210,7 +210,7 @@ struct WsLayout {
   int64_t lam, dlam, c, ct, dlam_sv;
   int64_t s, zsl, zsu, sl, su, ds, st, ds_sv;
   int64_t ew, es, nd, mo, gsc, total;
-  int64_t x_wd, zl_wd, zu_wd, lam_wd, s_wd, zsl_wd, zsu_wd, dlam_e;      // watchdog: the iterate it started from; EPS_GLOBAL: scratch multiplier steps
+  int64_t x_wd, zl_wd, zu_wd, lam_wd, s_wd, zsl_wd, zsu_wd, dlam_e, sgn;      // watchdog: the iterate it started from; EPS_GLOBAL: scratch multiplier steps
 };
 
 DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad, int n_nodes) {
@@ -233,6 +233,7 @@ DOMPC_HD inline WsLayout ws_layout(int n_opt_x, int n_g, int n_edges, int e_pad,
   L.x_wd = take(n_opt_x); L.zl_wd = take(n_opt_x); L.zu_wd = take(n_opt_x); L.lam_wd = take(n_g);
   L.s_wd = take(nsl); L.zsl_wd = take(nsl); L.zsu_wd = take(nsl);
   L.dlam_e = take(EPS_GLOBAL ? n_g : 0);
+  L.sgn = take(nsl);              // scaling factors of the nl_cons rows (IPOPT's gradient-based constraint scaling, solve_problem)
   o += 256;                       // slack: block-granular staging reads of the last records may run past their end
   L.total = o;
   return L;
@@ -598,7 +599,7 @@ struct Prob {
   double *lam, *dlam, *c, *ct, *dlam_sv;
   double *s, *zsl, *zsu, *sl, *su, *ds, *st, *ds_sv;
   double *ew, *es, *nd, *mo, *gsc;
-  double *x_wd, *zl_wd, *zu_wd, *lam_wd, *s_wd, *zsl_wd, *zsu_wd, *dlam_e;
+  double *x_wd, *zl_wd, *zu_wd, *lam_wd, *s_wd, *zsl_wd, *zsu_wd, *dlam_e, *sgn;
   int e_pad;
   double sf;                                         // objective scaling
   double mu;
@@ -629,7 +630,7 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   p.ds = w + L.ds; p.st = w + L.st; p.ds_sv = w + L.ds_sv;
   p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo; p.gsc = w + L.gsc;
   p.x_wd = w + L.x_wd; p.zl_wd = w + L.zl_wd; p.zu_wd = w + L.zu_wd; p.lam_wd = w + L.lam_wd;
-  p.s_wd = w + L.s_wd; p.zsl_wd = w + L.zsl_wd; p.zsu_wd = w + L.zsu_wd; p.dlam_e = w + L.dlam_e;
+  p.s_wd = w + L.s_wd; p.zsl_wd = w + L.zsl_wd; p.zsu_wd = w + L.zsu_wd; p.dlam_e = w + L.dlam_e; p.sgn = w + L.sgn;
   p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0; p.dsw = 0.0; p.slot = slot;
   return p;
 }
@@ -791,6 +792,7 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
     const double* eps = (NSE > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
       if (nl_slack(i) >= 0) d[i] -= eps[nl_slack(i)];
+      d[i] *= Q.sgn[e * NE1 + i];                       // (constraint scaling of the row, solve_problem)
       cv[row0 + NW + NX + i] = d[i] - sv[e * NE1 + i];
     }
     for (int q = 0; q < NSE; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * eps[q];
@@ -1033,7 +1035,9 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
       } else if (kind == 2) {
         if (k == A.N - 1) dompc_mterm_c(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MOC_MT);
       } else if (NE > 0) {
-        dompc_nlcons_c(xn, un, nullptr, tvp, pp, Q.lam + row0 + NW + NX, mo + MOC_NL);
+        double yds[NE1];      // (scaled rows sg d(x): the Hessian sum_i lambda_i sg_i hess d_i)
+        for (int i = 0; i < NE; ++i) yds[i] = Q.lam[row0 + NW + NX + i] * Q.sgn[e * NE1 + i];
+        dompc_nlcons_c(xn, un, nullptr, tvp, pp, yds, mo + MOC_NL);
       }
     } else if (kind == 0) {
       double* pt = mo + MO_PT + j * PT_STRIDE;
@@ -1051,7 +1055,9 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
         dompc_mterm(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1,
                     mo + MO_MT + 1 + NX);
     } else if (NE > 0) {
-      dompc_nlcons(xn, un, nullptr, tvp, pp, Q.lam + row0 + NW + NX, mo + MO_NL, mo + MO_NL + NE, mo + MO_NL + NE + NE * NA);
+      double yds[NE1];
+      for (int i = 0; i < NE; ++i) yds[i] = Q.lam[row0 + NW + NX + i] * Q.sgn[e * NE1 + i];
+      dompc_nlcons(xn, un, nullptr, tvp, pp, yds, mo + MO_NL, mo + MO_NL + NE, mo + MO_NL + NE + NE * NA);
     }
   }
 }
@@ -2409,7 +2415,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           const double grt = RT_CUSTOM ? (double)Ld[EL_RT + 1 + a] : 0.0;       // d rterm / d (x_n, u_n)
           double r = Ld[EL_RY + a] + om * pf_ltg[q] + grt;
           if (NE > 0)
-            for (int i = 0; i < NE; ++i) r += MOV(MO_NL + NE + i * NA + a) * yd[i];
+            for (int i = 0; i < NE; ++i) r += MOV(MO_NL + NE + i * NA + a) * yd[i] * Q.sgn[e * NE1 + i];
           S_[ES_GFY + a] = om * pf_ltg[q] + grt;
           S_[ES_RY + a] = r;
           S_[ES_QV + a] = Ld[EL_QV + a] + r;
@@ -2433,7 +2439,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       const double grt = RT_CUSTOM ? (double)Ld[EL_RT + 1 + a] : 0.0;           // d rterm / d (x_n, u_n)
       double r = Ld[EL_RY + a] + om * mo[MO_LT + 1 + a] + grt;
       if (NE > 0)
-        for (int i = 0; i < NE; ++i) r += mo[MO_NL + NE + i * NA + a] * yd[i];
+        for (int i = 0; i < NE; ++i) r += mo[MO_NL + NE + i * NA + a] * yd[i] * Q.sgn[e * NE1 + i];
       S_[ES_GFY + a] = om * mo[MO_LT + 1 + a] + grt;
       S_[ES_RY + a] = r;
       S_[ES_QV + a] = Ld[EL_QV + a] + r;
@@ -2454,6 +2460,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           double d = MOV(MO_NL + i);
           if (nl_slack(i) >= 0) d -= eps[nl_slack(i)];
           const int si = e * NE1 + i;
+          d *= Q.sgn[si];
           const double sv = Q.s[si], l = Q.sl[si], u = Q.su[si];
           const double rdn = Q.soc ? Q.c[row0 + NW + NX + i] : d - sv;
           if (!Q.soc) Q.c[row0 + NW + NX + i] = rdn;
@@ -2466,7 +2473,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       S_[ES_OBJ] = obj;
     }
     if (NE > 0)
-      for (int it = lane; it < NE * NA; it += GS) Q.EW(e, EW_JD + it) = MOV(MO_NL + NE + it);
+      for (int it = lane; it < NE * NA; it += GS) Q.EW(e, EW_JD + it) = MOV(MO_NL + NE + it) * Q.sgn[e * NE1 + it / NA];
   }
   T.gsync();
 #ifndef DOMPC_HOST_EMU
@@ -2524,7 +2531,7 @@ DOMPC_DEV inline void assemble_children(const Prob& Q, int n, bool counted_only,
       const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
       for (int q = 0; q < NS; ++q)
         for (int i = 0; i < NE; ++i)
-          if (nl_slack(i) == q) out[2 * NX + 3 * NU + q] -= yd[i];
+          if (nl_slack(i) == q) out[2 * NX + 3 * NU + q] -= yd[i] * Q.sgn[e * NE1 + i];
     }
   }
 }
@@ -2765,7 +2772,7 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
           const double sg = Ld[NL_SG + q] + delta;
           double ji = 0.0;
           if (yi >= 0) ji = Ld[NL_JD + q * NA + yi];
-          else if (i >= NA + NU && nl_slack(q) == i - NA - NU) { ji = -1.0; gv -= Ld[NL_YD + q]; }
+          else if (i >= NA + NU && nl_slack(q) == i - NA - NU) { ji = -Q.sgn[(cs + c) * NE1 + q]; gv += ji * Ld[NL_YD + q]; }      // (column of the slack variable in the scaled row sg (d - eps))
           gv += ji * (sg * Ld[NL_RD + q] + Ld[NL_RS + q]);
         }
         gvv[v] = gv;
@@ -2781,9 +2788,9 @@ DOMPC_DEV inline int riccati_node(const Thr& T, const Prob& Q, int n, double mu,
           const double sg = Ld[NL_SG + qq] + delta;
           double ji = 0.0, jj = 0.0;
           if (yi >= 0) ji = Ld[NL_JD + qq * NA + yi];
-          else if (i >= NA + NU && nl_slack(qq) == i - NA - NU) ji = -1.0;
+          else if (i >= NA + NU && nl_slack(qq) == i - NA - NU) ji = -Q.sgn[(cs + c) * NE1 + qq];
           if (yj >= 0) jj = Ld[NL_JD + qq * NA + yj];
-          else if (j >= NA + NU && nl_slack(qq) == j - NA - NU) jj = -1.0;
+          else if (j >= NA + NU && nl_slack(qq) == j - NA - NU) jj = -Q.sgn[(cs + c) * NE1 + qq];
           v += sg * ji * jj;
         }
         qacc[q] = v;
@@ -3072,7 +3079,7 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
             const double sg = S_[ES_SIGS + q] + delta;
             double ji = 0.0;
             if (yi >= 0) ji = Q.EW(e, EW_JD + q * NA + yi);
-            else if (i >= NA + NU && nl_slack(q) == i - NA - NU) { ji = -1.0; gv -= yd[q]; }
+            else if (i >= NA + NU && nl_slack(q) == i - NA - NU) { ji = -Q.sgn[e * NE1 + q]; gv += ji * yd[q]; }
             gv += ji * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
           }
         }
@@ -3096,9 +3103,9 @@ DOMPC_DEV inline int riccati_cut_node(const Thr& T, const Prob& Q, int n, double
             const double sg = S_[ES_SIGS + qq] + delta;
             double ji = 0.0, jj = 0.0;
             if (yi >= 0) ji = Q.EW(e, EW_JD + qq * NA + yi);
-            else if (i >= NA + NU && nl_slack(qq) == i - NA - NU) ji = -1.0;
+            else if (i >= NA + NU && nl_slack(qq) == i - NA - NU) ji = -Q.sgn[e * NE1 + qq];
             if (yj >= 0) jj = Q.EW(e, EW_JD + qq * NA + yj);
-            else if (j >= NA + NU && nl_slack(qq) == j - NA - NU) jj = -1.0;
+            else if (j >= NA + NU && nl_slack(qq) == j - NA - NU) jj = -Q.sgn[e * NE1 + qq];
             v += sg * ji * jj;
           }
       }
@@ -3815,7 +3822,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       for (int i = lane; i < NE; i += GS) {
         double t = S_[ES_RDN + i];
         for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_JD + i * NA + b) * Ld[RF_DY + b];
-        if (!EPS_GLOBAL && nl_slack(i) >= 0) t -= Q.dx[A.node_eps_off[n] + nl_slack(i)];      // (shared slacks: their step is part of the residual, eps_schur_apply)
+        if (!EPS_GLOBAL && nl_slack(i) >= 0) t -= Q.sgn[e * NE1 + i] * Q.dx[A.node_eps_off[n] + nl_slack(i)];      // (shared slacks: their step is part of the residual, eps_schur_apply)
         Q.ds[e * NE1 + i] = t;
         Q.dlam[row0 + NW + NX + i] = (S_[ES_SIGS + i] + delta) * t + S_[ES_RSN + i];
       }
@@ -4423,7 +4430,7 @@ DOMPC_DEV inline void epsg_grad(const Thr& T, const Prob& Q) {
       g += Q.sf * DOMPC_EPS_PEN[q];                                   // (the slack cost is added once per edge, _mpc.py:1254)
       const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
       for (int i = 0; i < NE; ++i)
-        if (nl_slack(i) == q) r -= yd[i];
+        if (nl_slack(i) == q) r -= yd[i] * Q.sgn[e * NE1 + i];
     }
     Q.gf[o + j] = g;
     Q.rd[o + j] = g + r - Q.zl[o + j] + Q.zu[o + j];
@@ -4440,7 +4447,7 @@ DOMPC_DEV inline double epsg_rowsum(const Prob& Q, int j, const double* v, const
     if (q < 0 || q >= NSE) continue;
     const int r0 = A.edge_row0[e] + NW + NX;
     for (int i = 0; i < NE; ++i)
-      if (nl_slack(i) == q) t += v[r0 + i] - (v0 ? v0[r0 + i] : 0.0);
+      if (nl_slack(i) == q) t += (v[r0 + i] - (v0 ? v0[r0 + i] : 0.0)) * Q.sgn[e * NE1 + i];
   }
   return t;
 }
@@ -4455,7 +4462,7 @@ DOMPC_DEV inline void epsg_residual(const Thr& T, const Prob& Q, const double* v
       const int q = nl_slack(i);
       if (q < 0) continue;
       const double ve = v ? v[jo + q] : ((jo + q == j1) ? 1.0 : 0.0);
-      Q.c[r0 + i] = Q.ct[r0 + i] - ve;
+      Q.c[r0 + i] = Q.ct[r0 + i] - ve * Q.sgn[e * NE1 + i];
     }
   }
   T.sync();
@@ -4525,16 +4532,18 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     for (int g = T.tid; g < nX; g += T.nt) { A.lb_sh[g] = Q.lb_own[g]; A.ub_sh[g] = Q.ub_own[g]; }
     T.sync();
   }
-  // slacks of the nl_cons rows: s = d(x) pushed into [lbg,ubg]
-  if (NE > 0) {
+  // slacks of the nl_cons rows: s = d(x) pushed into [lbg,ubg].  `rescale`: second call, after the scaling factors of the rows are known
+  // (below): rows, bounds (relaxed first, then scaled - like IPOPT's scaled NLP) and slacks in scaled units.
+  auto init_slacks = [&](bool rescale) {
     for (int e = T.tid; e < A.n_edges; e += T.nt) {
-      for (int i = 0; i < NE; ++i) Q.s[e * NE1 + i] = 0.0;
+      for (int i = 0; i < NE; ++i) { Q.s[e * NE1 + i] = 0.0; if (!rescale) Q.sgn[e * NE1 + i] = 1.0; }
       if (DENSE_EDGE) dae_edge_f(Q, e, Q.x, Q.s, Q.ct); else eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
       for (int i = 0; i < NE; ++i) {
         const int row = A.edge_row0[e] + NW + NX + i, si = e * NE1 + i;
         double l = A.lbg[row], u = A.ubg[row];
         if (l > -INFINITY) l -= fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(l)));
         if (u < INFINITY) u += fmin(O.constr_viol_tol, O.bound_relax_factor * fmax(1.0, fabs(u)));
+        l *= Q.sgn[si]; u *= Q.sgn[si];
         const bool hl = l > -INFINITY, hu = u < INFINITY;
         double pl = hl ? O.bound_push * fmax(1.0, fabs(l)) : 0.0;
         double pu = hu ? O.bound_push * fmax(1.0, fabs(u)) : 0.0;
@@ -4544,11 +4553,12 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         if (hu) sv = fmin(sv, u - pu);
         Q.s[si] = sv; Q.sl[si] = l; Q.su[si] = u;
         Q.zsl[si] = hl ? 1.0 : 0.0; Q.zsu[si] = hu ? 1.0 : 0.0;
-        if (sh_cnt(A, mk_e(A, e))) cnt[1] += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
+        if (!rescale && sh_cnt(A, mk_e(A, e))) cnt[1] += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
       }
     }
     T.sync();
-  }
+  };
+  if (NE > 0) init_slacks(false);
   {
     const int ops[2] = {R_SUM, R_SUM};
     wg_reduce(T, cnt, ops);
@@ -4669,6 +4679,31 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     return rc;
   };
   int bad = first_sweep();
+  // ---- IPOPT's gradient-based scaling of the CONSTRAINTS (nlp_scaling_method = gradient-based, same option as the objective scaling):
+  // a row whose gradient at the starting point has a max-norm above nlp_scaling_max_gradient (100) is multiplied by 100 / that norm.
+  // Restated for the nl_cons rows (kite example: the height constraint, gradient 335 - a soft row: sg (d(x, u) - eps) <= sg ub): through
+  // the row's slack and its bound multipliers the factor changes the iterates from the first step on.  Rows of the dynamics: the Newton
+  // step is invariant under their scaling and none of the examples has such a row above 100 apart from the dynamic bicycle (179, same
+  // iterates as the oracle, which scales them) - not scaled here.
+  if (NE > 0 && O.obj_scaling && !bad) {
+    double any[1] = {0.0};
+    for (int e = T.tid; e < A.n_edges; e += T.nt) {
+      if (!mk_e(A, e)) continue;
+      for (int i = 0; i < NE; ++i) {
+        double gm = nl_slack(i) >= 0 ? 1.0 : 0.0;        // (the column of the row's slack variable `_eps`)
+        for (int a = 0; a < NA; ++a) gm = fmax(gm, fabs(Q.EW(e, EW_JD + i * NA + a)));
+        if (DENSE_EDGE) for (int c = 0; c < NW; ++c) gm = fmax(gm, fabs(Q.EW(e, EW_JDW + i * NW + c)));
+        if (gm > O.nlp_scaling_max_gradient) { Q.sgn[e * NE1 + i] = fmax(O.nlp_scaling_max_gradient / gm, 1e-8); any[0] = 1.0; }
+      }
+    }
+    const int ops[1] = {R_MAX};
+    wg_reduce(T, any, ops);
+    if (any[0] > 0.0) {
+      T.sync();
+      init_slacks(true);
+      bad = first_sweep();
+    }
+  }
   if (O.obj_scaling) {
     double gm[1] = {0.0};
     for (int g = T.tid; g < nX; g += T.nt)
@@ -4753,7 +4788,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   // fraction-to-the-boundary steps are taken without asking the filter, each tested against the point where the watchdog STARTED
   // (its theta, barrier objective, directional derivative and step size); none acceptable: back to that point and the direction
   // computed there, regular backtracking from the second trial step size.  It is what keeps non-convex problems from crawling with
-  // 2^-10 steps for hundreds of iterations (kite over the full horizon: 87 instead of 400 iterations in the oracle with exact inertia,
+  // 2^-10 steps for hundreds of iterations (kite over the full horizon: 87 instead of 906 iterations, the oracle's 87 with exact inertia,
   // profiles/r04_crawl_traces.txt).  State: the iterate in Q.*_wd, its direction in Q.dx_sv / dlam_sv / ds_sv (no second-order
   // correction runs while a watchdog is active), scalars below.
   int wd_count = 0, wd_iter = 0, n_watchdog = 0;
@@ -5032,6 +5067,15 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   if (A.x_out) for (int g = T.tid; g < nX; g += T.nt) A.x_out[(int64_t)b * nX + g] = sh_cnt(A, mk_x(A, g)) ? Q.x[g] : 0.0;
   if (A.lam_x_out) for (int g = T.tid; g < nX; g += T.nt) A.lam_x_out[(int64_t)b * nX + g] = sh_cnt(A, mk_x(A, g)) ? (Q.zu[g] - Q.zl[g]) * isf : 0.0;
   if (A.lam_g_out) for (int r = T.tid; r < A.n_g; r += T.nt) A.lam_g_out[(int64_t)b * A.n_g + r] = sh_cnt(A, mk_g(A, r)) ? Q.lam[r] * isf : 0.0;
+  if (A.lam_g_out && NE > 0) {           // (scaled rows sg d(x): the multiplier of the user's row is sg times the scaled problem's)
+    T.sync();
+    for (int g = T.tid; g < nSl; g += T.nt) {
+      const int e = g / NE1, i = g % NE1;
+      if (!sh_cnt(A, mk_e(A, e))) continue;
+      const int row = A.edge_row0[e] + NW + NX + i;
+      A.lam_g_out[(int64_t)b * A.n_g + row] = Q.lam[row] * Q.sgn[e * NE1 + i] * isf;
+    }
+  }
   if (A.g_out) {
     // g in the reference's convention: equality rows = residual (+rhs 0), nl rows = d(x)
     for (int r = T.tid; r < A.n_g; r += T.nt) A.g_out[(int64_t)b * A.n_g + r] = sh_cnt(A, mk_g(A, r)) ? Q.c[r] : 0.0;
@@ -5040,7 +5084,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       const int e = g / NE1, i = g % NE1;
       if (!sh_cnt(A, mk_e(A, e))) continue;
       const int row = A.edge_row0[e] + NW + NX + i;
-      A.g_out[(int64_t)b * A.n_g + row] = Q.c[row] + Q.s[e * NE1 + i];
+      A.g_out[(int64_t)b * A.n_g + row] = (Q.c[row] + Q.s[e * NE1 + i]) / Q.sgn[e * NE1 + i];
     }
   }
   if (T.tid == 0) {
@@ -5072,7 +5116,7 @@ DOMPC_DEV inline void debug_newton(const Thr& T, const KArgs& A, int b = 0, int 
   T.sync();
   if (NE > 0) {
     for (int e = T.tid; e < A.n_edges; e += T.nt) {
-      for (int i = 0; i < NE; ++i) Q.s[e * NE1 + i] = 0.0;
+      for (int i = 0; i < NE; ++i) { Q.s[e * NE1 + i] = 0.0; Q.sgn[e * NE1 + i] = 1.0; }
       if (DENSE_EDGE) dae_edge_f(Q, e, Q.x, Q.s, Q.ct); else eval_edge_f(Q, e, Q.x, Q.s, Q.ct);
       for (int i = 0; i < NE; ++i) {
         const int row = A.edge_row0[e] + NW + NX + i, si = e * NE1 + i;
@@ -5134,7 +5178,7 @@ DOMPC_DEV inline void sweep_problem(const Thr& T, const KArgs& A, int b, int slo
   for (int r = T.tid; r < A.n_g; r += T.nt) Q.lam[r] = lin[r];
   for (int g = T.tid; g < A.n_edges * NE; g += T.nt) {
     const int si = (g / NE1) * NE1 + g % NE1;
-    Q.s[si] = 0.0; Q.sl[si] = -INFINITY; Q.su[si] = INFINITY; Q.zsl[si] = 0.0; Q.zsu[si] = 0.0;
+    Q.s[si] = 0.0; Q.sl[si] = -INFINITY; Q.su[si] = INFINITY; Q.zsl[si] = 0.0; Q.zsu[si] = 0.0; Q.sgn[si] = 1.0;
   }
   T.sync();
   Q.sf = 1.0;

@@ -258,9 +258,9 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
         for (int q = 0; q < NE; ++q) {
           const double sg = S_[ES_SIGS + q] + delta;
           const bool slack_here = NS > 0 && jj >= NA + NU && nl_slack(q) == jj - NA - NU;
-          const double jc = (yjj >= 0) ? Q.EW(e, EW_JD + q * NA + yjj) : (slack_here ? -1.0 : 0.0);
+          const double jc = (yjj >= 0) ? Q.EW(e, EW_JD + q * NA + yjj) : (slack_here ? -Q.sgn[e * NE1 + q] : 0.0);     // (scaled row sg (d - eps))
           gv += jc * (sg * S_[ES_RDN + q] + S_[ES_RSN + q]);
-          if (slack_here) gv -= Q.lam[A.edge_row0[e] + NW + NX + q];
+          if (slack_here) gv += jc * Q.lam[A.edge_row0[e] + NW + NX + q];
         }
       }
     }
@@ -287,12 +287,12 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       for (int q = 0; q < NE; ++q) {
         const double sg = S_[ES_SIGS + q] + delta;
         const double jc = (j >= NYT) ? 0.0 : ((yj >= 0) ? Q.EW(e, EW_JD + q * NA + yj)
-                                                        : ((NS > 0 && jz >= NA + NU && nl_slack(q) == jz - NA - NU) ? -1.0 : 0.0));
+                                                        : ((NS > 0 && jz >= NA + NU && nl_slack(q) == jz - NA - NU) ? -Q.sgn[e * NE1 + q] : 0.0));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = g + 4 * r, iz = i < NYT ? i : 0, yi = yz(iz);
           const double jr = (i >= NYT) ? 0.0 : ((yi >= 0) ? Q.EW(e, EW_JD + q * NA + yi)
-                                                          : ((NS > 0 && iz >= NA + NU && nl_slack(q) == iz - NA - NU) ? -1.0 : 0.0));
+                                                          : ((NS > 0 && iz >= NA + NU && nl_slack(q) == iz - NA - NU) ? -Q.sgn[e * NE1 + q] : 0.0));
           QO[r] += sg * jr * jc;
         }
       }

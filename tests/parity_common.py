@@ -48,8 +48,8 @@ _oracle_cache = {}
 # (the oracle counts negative eigenvalues exactly with inertia="ldl", as IPOPT does through MUMPS; the product detects a
 # wrong inertia through the Cholesky factors of the Riccati recursion) and the second-order correction of the line search
 # (kinematic bicycle: without it the solve ends in a different local minimum, u0 = 0.697 instead of 0.805).
-# kite: horizon 20 instead of the example's 80 - at 80 both solvers run into line-search failures that IPOPT would hand
-# to its restoration phase (not restated on either side), and the iterates part ways.
+# kite: horizon 20 here (fast); the example's full horizon of 80 has its own test (check_watchdog_on_kite_full_horizon: same 87 iterations as
+# the oracle since round 4 - it needed IPOPT's watchdog procedure and IPOPT's scaling of the height constraint, not a restoration phase).
 NONCONVEX_CASES = [("kinematic_bicycle", {}), ("dynamic_bicycle", {}), ("kite", {"n_horizon": 20})]
 
 
@@ -493,34 +493,34 @@ def check_single_slack_batch(make_mpc, B=6):
 
 
 def check_watchdog_on_kite_full_horizon(make_mpc):
-    """IPOPT's watchdog procedure (watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3; restated in oracle/ipm.py and in the
-    device driver) on the non-convex kite problem over its full horizon of 80 stages: without it the line search accepts steps of 2^-10
-    for hundreds of iterations (906; the oracle with exact inertia 400), with it the solve takes 67 iterations (oracle 87).  The point
-    reached is a KKT point of the oracle's NLP with OUR multipliers; product and oracle end in DIFFERENT local minima there (their very
-    first directions differ on this model - the objective of the product's point is the lower one), so no equality of solutions is asserted.
-    `ipopt.watchdog_shortened_iter_trigger = 0` switches it off (the crawl is back).
+    """The non-convex kite problem over its FULL horizon of 80 stages (the case round 3 kept out of the parity tests): with IPOPT's watchdog
+    procedure (watchdog_shortened_iter_trigger = 10, watchdog_trial_iter_max = 3) and IPOPT's gradient-based scaling of the height
+    constraint (row gradient 335 -> factor 0.298) restated in the device driver, the product takes the SAME 87 iterations as the oracle
+    with exact inertia (dense LDL', as IPOPT counts it through MUMPS) - five watchdogs on both sides, two of them given up and restored -
+    and ends at the same point (measured 1e-13, multipliers 3e-14).  Without the watchdog the line search accepts 2^-10 steps for
+    hundreds of iterations (`ipopt.watchdog_shortened_iter_trigger = 0`: 409 iterations, the oracle 400).
     [NO REFERENCE FIXTURE: oracle-or-equivalence check, not a reproduction of a stored reference run]"""
     ex = CASES["kite"]
     nlp = oracle_nlp("kite", n_horizon=80)
-    out = {}
-    for trig in (10, 0):
-        mpc = make_mpc("kite", n_horizon=80, nlpsol_opts={"ipopt.watchdog_shortened_iter_trigger": trig})
-        mpc.x0 = ex.X0
-        mpc.set_initial_guess()
-        mpc.make_step(ex.X0)
-        st = out[trig] = mpc.solver_stats
-        assert st["success"]
-        x, p = mpc.opt_x_num.master, mpc.opt_p_num.master
-        gv = nlp.g(x, p)
-        eq = nlp.lbg == nlp.ubg
-        assert np.max(np.abs(gv[eq])) < 1e-7 and np.all(gv[~eq] <= nlp.ubg[~eq] + 1.01e-8 * np.maximum(1.0, np.abs(nlp.ubg[~eq])))   # (bound_relax_factor)
-        rd = nlp.grad(x, p) + nlp.jac(x, p).T @ mpc.lam_g_num + mpc.lam_x_num
-        used = np.ones(nlp.n_opt_x, bool)
-        used[mpc.structure.tables["dummy_idx"]] = False
-        assert np.max(np.abs(rd[used])) < 1e-5 * max(1.0, np.max(np.abs(mpc.lam_g_num)))
-    assert out[10]["n_watchdog"] >= 1 and out[10]["iter_count"] < 150, out[10]
-    assert out[0]["n_watchdog"] == 0 and out[0]["iter_count"] > 3 * out[10]["iter_count"], out[0]
-    return out
+    mpc = make_mpc("kite", n_horizon=80)
+    mpc.x0 = ex.X0
+    mpc.set_initial_guess()
+    mpc.make_step(ex.X0)
+    st = mpc.solver_stats
+    r = ipm.solve(nlp, nlp.initial_guess(ex.X0), mpc.opt_p_num.master.copy(), opts=dict(inertia="ldl"))
+    assert st["success"] and r["stats"]["success"]
+    assert st["iter_count"] == r["stats"]["iter_count"] and st["n_watchdog"] == r["stats"]["n_watchdog"] >= 3, (st, r["stats"]["iter_count"], r["stats"]["n_watchdog"])
+    used = np.ones(nlp.n_opt_x, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    assert relerr(mpc.opt_x_num.master[used], r["x"][used]) < 1e-8
+    assert np.max(np.abs(mpc.lam_g_num - r["lam_g"])) < 1e-8 * max(1.0, np.max(np.abs(r["lam_g"])))
+    assert st["iter_count"] < 120
+    m0 = make_mpc("kite", n_horizon=80, nlpsol_opts={"ipopt.watchdog_shortened_iter_trigger": 0})
+    m0.x0 = ex.X0
+    m0.set_initial_guess()
+    m0.make_step(ex.X0)
+    assert m0.solver_stats["success"] and m0.solver_stats["n_watchdog"] == 0 and m0.solver_stats["iter_count"] > 3 * st["iter_count"]
+    return st
 
 
 def mhe_straggler_problem(mhe):
