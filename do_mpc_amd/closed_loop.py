@@ -21,6 +21,9 @@ class BatchClosedLoop:
         self.torch = torch
         self.mpc, self.sim = mpc, simulator
         ps = self.ps = mpc.structure
+        if getattr(ps, "open_loop_stack", False):
+            raise NotImplementedError("structured HIP backend: the device-resident closed loop with open_loop and several scenarios "
+                                      "(the controller's vectors live in the stacked chain layout there; use make_step_batch)")
         m = simulator.model
         assert m.n_x == ps.nx and m.n_u == ps.nu, "controller and plant must share states and inputs"
         assert m.n_y == m.n_x, "state feedback: the plant's measurement must be its state"
@@ -113,6 +116,8 @@ class BatchClosedLoopMHE:
         self.mpc, self.sim, self.mhe = mpc, simulator, mhe
         m = simulator.model
         ps, es = mpc.structure, mhe._ps                     # controller / estimator chain structures
+        if getattr(ps, "open_loop_stack", False):
+            raise NotImplementedError("structured HIP backend: the device-resident closed loop with open_loop and several scenarios")
         self.ps, self.es = ps, es
         X0_true = np.asarray(X0_true, dtype=float).reshape(-1, m.n_x)
         self.B = B = X0_true.shape[0]
