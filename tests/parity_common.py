@@ -474,6 +474,67 @@ OPEN_LOOP_CASES = [
 ]
 
 
+def _toy_discrete(open_loop, n_robust=1, N=6):
+    """a two-state discrete-time model with one uncertain parameter (no example of the reference is discrete AND uncertain): the product's
+    controller and the oracle's case for it"""
+    import sympy as sp
+    from do_mpc_amd import MPC, Model
+    from oracle.models import _base
+    mdl = Model("discrete")
+    x1 = mdl.set_variable("_x", "x1")
+    x2 = mdl.set_variable("_x", "x2")
+    u = mdl.set_variable("_u", "u")
+    k = mdl.set_variable("_p", "k")
+    mdl.set_rhs("x1", x1 + 0.1 * x2)
+    mdl.set_rhs("x2", k * x2 + u - 0.05 * x1 ** 3)
+    mdl.setup()
+
+    def build(factory_ctx):
+        mpc = MPC(mdl)
+        st = mpc.settings
+        st.n_horizon, st.n_robust, st.t_step, st.open_loop, st.store_full_solution = N, n_robust, 0.1, open_loop, True
+        st.supress_ipopt_output()
+        cost = x1 ** 2 + 0.1 * x2 ** 2
+        mpc.set_objective(mterm=cost, lterm=cost)
+        mpc.set_rterm(u=0.01)
+        mpc.bounds["lower", "_u", "u"], mpc.bounds["upper", "_u", "u"] = -1.0, 1.0
+        mpc.bounds["lower", "_x", "x2"], mpc.bounds["upper", "_x", "x2"] = -2.0, 2.0
+        mpc.set_uncertainty_values(k=np.array([1.0, 0.9, 1.1]))
+        mpc.setup()
+        return mpc
+    sx = sp.symbols("x1 x2")
+    su, sk = (sp.Symbol("u"),), (sp.Symbol("k"),)
+    cost = sx[0] ** 2 + 0.1 * sx[1] ** 2
+    case = _base(name="toy_discrete", model_type="discrete", x=sx, u=su, p=sk, rhs=[sx[0] + 0.1 * sx[1], sk[0] * sx[1] + su[0] - 0.05 * sx[0] ** 3],
+                 lterm=cost, mterm=cost, rterm=np.array([0.01]), n_horizon=N, n_robust=n_robust, t_step=0.1, open_loop=open_loop,
+                 x_lb=np.array([-np.inf, -2.0]), x_ub=np.array([np.inf, 2.0]), u_lb=np.array([-1.0]), u_ub=np.array([1.0]),
+                 x_scaling=np.ones(2), u_scaling=np.ones(1), uncertainty=dict(k=[1.0, 0.9, 1.1]), x0=np.array([1.0, 0.5]), aux={})
+    return build, OracleNLP(case)
+
+
+def check_open_loop_discrete(patched):
+    """open_loop with several scenarios on a DISCRETE-time model (rows x+ = f of every stacked copy, no stored points), n_robust = 1 and 2
+    (9 leaf scenarios, tree nodes shared by three of them): first input, used variables, multipliers against the oracle's solve; with
+    open_loop = False the same model follows the oracle's iterates on the ordinary tree path
+    [NO REFERENCE FIXTURE: oracle-or-equivalence check, not a reproduction of a stored reference run]"""
+    x0 = np.array([1.0, 0.5])
+    for ol, nr in ((False, 1), (True, 1), (True, 2)):
+        build, nlp = _toy_discrete(ol, n_robust=nr)
+        with patched():
+            mpc = build(None)
+        assert (nlp.n_opt_x, nlp.n_g) == (mpc.structure.n_opt_x, mpc.structure.n_g)
+        mpc.x0 = x0
+        mpc.set_initial_guess()
+        u0 = mpc.make_step(x0).ravel()
+        r = ipm.solve(nlp, nlp.initial_guess(x0), mpc.opt_p_num.master.copy())
+        assert mpc.solver_stats["success"] and r["stats"]["success"]
+        used = np.ones(nlp.n_opt_x, bool)
+        used[mpc.structure.tables["dummy_idx"]] = False
+        assert abs(mpc.solver_stats["iter_count"] - r["stats"]["iter_count"]) <= (0 if not ol else 2)
+        assert relerr(u0, nlp.u0_of(r["x"])) < 1e-6 and relerr(mpc.opt_x_num.master[used], r["x"][used]) < 1e-5, (ol, nr)
+        assert np.max(np.abs(mpc.lam_g_num - r["lam_g"])) < 1e-5 * max(1.0, np.max(np.abs(r["lam_g"])))
+
+
 def check_single_slack_batch(make_mpc, B=6):
     """B problems with shared slacks in one launch (every workgroup runs its own Schur complement in its slot's workspace) = B single solves"""
     mpc = make_mpc("CSTR", nl_cons_single_slack=True, max_batch=B)

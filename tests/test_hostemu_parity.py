@@ -289,3 +289,7 @@ def test_watchdog_same_iterates_as_the_oracle_when_it_starts_after_every_shorten
     assert st["n_watchdog"] == r["stats"]["n_watchdog"] == 3 and st["iter_count"] == r["stats"]["iter_count"] == 56
     assert pc.relerr(mpc.opt_x_num.master, r["x"]) < 1e-9
 
+
+def test_open_loop_on_a_discrete_model_with_an_uncertain_parameter():
+    pc.check_open_loop_discrete(hostemu.patched)
+
