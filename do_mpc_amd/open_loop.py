@@ -36,6 +36,11 @@ def check_supported(mpc) -> None:
         #  scenario in the stacked problem - a stage-dependent weight the generated code does not have)
         raise NotImplementedError("structured HIP backend: open_loop with several scenarios and soft constraints for n_robust >= 2 / "
                                   "nl_cons_single_slack")
+    if ps.ns and m.n_p and s.n_robust >= 1 and any(sym.depends_on(sym.SX(c["expr"]).nodes(), m._p.cat.nodes()) for c in mpc.nl_cons_list):
+        # (the slack of a branching node covers the LARGEST violation over its branches in the reference, one slack per leaf scenario covers
+        #  each branch's own: the same problem only if the rows do not depend on the uncertain parameters)
+        raise NotImplementedError("structured HIP backend: open_loop with several scenarios and soft constraints whose expressions "
+                                  "depend on the uncertain parameters")
     n_w = ps.S * ps.M * ps.nx
     if n_w > 64 or (ps.M == 0 and ps.S * ps.nx > 64):
         raise NotImplementedError("structured HIP backend: open_loop with {} scenarios: {} stacked collocation unknowns per control "
