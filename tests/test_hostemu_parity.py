@@ -261,18 +261,6 @@ def test_watchdog_ends_the_crawl_on_the_full_horizon_kite_problem():
     pc.check_watchdog_on_kite_full_horizon(make_mpc)
 
 
-def test_oracle_watchdog_same_limit_point_fewer_iterations():
-    """oracle/ipm.py on the full-horizon kite problem with exact inertia (dense LDL', as IPOPT counts it through MUMPS): the watchdog
-    changes the path, not the local solution - 400 -> 87 iterations"""
-    from oracle import ipm
-    ex = CASES["kite"]
-    nlp = pc.oracle_nlp("kite", n_horizon=80)
-    p = nlp.opt_p(ex.X0, np.zeros(nlp.nu))
-    r = ipm.solve(nlp, nlp.initial_guess(ex.X0), p, opts=dict(inertia="ldl", max_iter=200))
-    assert r["stats"]["success"] and r["stats"]["n_watchdog"] >= 1 and r["stats"]["iter_count"] < 120
-    assert abs(r["f"] - (-1797.72397356)) < 1e-5
-
-
 def test_watchdog_same_iterates_as_the_oracle_when_it_starts_after_every_shortened_step():
     """trigger = 1 on the cold industrial_poly solve: three watchdogs start (and succeed at their first step) in the product AND in the
     oracle - same 56 iterations, same final iterate: the two restatements of the procedure agree where their iterates are comparable"""
