@@ -746,7 +746,12 @@ DOMPC_DEV inline void edge_rterm_store(const ldsd* src, double* S_, int lane, in
 // ================================================================================================
 // Trial evaluation: constraint residuals + objective share of one edge at `xv` (no derivatives).
 // nlp_g / nlp_f of the reference for the rows/terms owned by edge e.
-DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const double* sv, double* cv) {
+// SPLIT: one piece of the edge per call - `part` in [0, NI * DEG): the rows of that collocation point; NI * DEG: everything else (element /
+// node continuity rows, objective share, nl_cons rows).  A single problem spread over many workgroups (wide mode) has far more threads than
+// edges: the trial evaluation of the line search then runs one thread per piece instead of one per edge (trial_edges).
+template <bool SPLIT>
+DOMPC_DEV inline double eval_edge_f_t(const Prob& Q, int e, const double* xv, const double* sv, double* cv, int part) {
+  constexpr int REST = NI * DEG;
   const KArgs& A = *Q.A;
   const int n = A.edge_parent[e], cn = A.edge_child[e], k = A.edge_level[e];
   const double* xn = xv + A.node_x_off[n];
@@ -762,10 +767,12 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
     dompc_dyn_f(xn, un, nullptr, tvp, pp, f);
     for (int a = 0; a < NX; ++a) cv[row0 + a] = f[a] - xc[a];
   } else {
+    (void)REST;
     for (int i = 0; i < NI; ++i) {
       const double* xi0 = (i == 0) ? xn : w + slot_of(i, 0) * NX;
       const int rb = row0 + i * (DEG + 1) * NX;
       for (int j = 1; j <= DEG; ++j) {
+        if (SPLIT && part != i * DEG + (j - 1)) continue;
         const double* xij = w + slot_of(i, j) * NX;
         dompc_dyn_f(xij, un, nullptr, tvp, pp, f);
         for (int a = 0; a < NX; ++a) {
@@ -774,6 +781,7 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
           cv[rb + (j - 1) * NX + a] = f[a] - xp;
         }
       }
+      if (SPLIT && part != REST) continue;
       const double* xnext = w + next_slot(i) * NX;
       for (int a = 0; a < NX; ++a) {
         double xf = DOMPC_D[0] * xi0[a];
@@ -781,6 +789,7 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
         cv[rb + DEG * NX + a] = xnext[a] - xf;
       }
     }
+    if (SPLIT && part != REST) return 0.0;
     for (int a = 0; a < NX; ++a) cv[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
   }
   double obj = om * dompc_lterm_f(xn, un, nullptr, tvp, pp);
@@ -799,6 +808,7 @@ DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const dou
   }
   return obj;
 }
+DOMPC_PHASE double eval_edge_f(const Prob& Q, int e, const double* xv, const double* sv, double* cv) { return eval_edge_f_t<false>(Q, e, xv, sv, cv, -1); }
 
 // rterm share of node n (all outgoing edges): sum_b omega_k r'(u_n - u_prev)^2  (_mpc.py:1271-1275)
 DOMPC_DEV inline const double* uprev_ptr(const Prob& Q, int n, const double* xv, double* tmp) {
@@ -2578,6 +2588,72 @@ DOMPC_PHASE void assemble_node(const Prob& Q, int n) {
   assemble_children(Q, n, false, t);
   assemble_finish(Q, n, t);
 }
+// One problem spread over several workgroups (wide mode: B <= 64) has thousands of threads for a few hundred nodes / edges: the thread-per-node
+// and thread-per-edge loops of the sweep and of the line search then run as thread-per-ENTRY loops (same arithmetic per entry, same order of
+// the sums: bitwise the same results).  -DDOMPC_FINE_ITEMS=1: everywhere (test of these paths on the host emulation).
+#ifndef DOMPC_FINE_ITEMS
+#define DOMPC_FINE_ITEMS 0
+#endif
+DOMPC_DEV inline bool fine_items(const Thr& T, const KArgs& A) { return DOMPC_FINE_ITEMS >= 0 && (T.nwg > 1 || DOMPC_FINE_ITEMS > 0) && !sh_on(A); }      // (-1: compiled out, A/B measurements)
+// assemble_node for ONE variable of node n: j < NX state, < NX + NU input, else slack entry
+DOMPC_DEV inline void assemble_entry(const Prob& Q, int n, int j) {
+  const KArgs& A = *Q.A;
+  const int cs = A.node_child_start[n], cc = A.node_child_count[n];
+  if (j < NX) {
+    const int a = j, xo = A.node_x_off[n], ie = A.node_in_edge[n];
+    double gx = 0.0, rx = 0.0;
+    for (int c = 0; c < cc; ++c) { const double* S_ = Q.ES(cs + c); gx += S_[ES_GFY + a]; rx += S_[ES_RY + a]; }
+    if (ie >= 0) {
+      rx -= Q.lam[A.edge_row0[ie] + NW + a];
+      if (cc == 0) { const double mg = Q.ES(ie)[ES_MG + a]; gx += mg; rx += mg; }
+    } else if (FREE_ROOT) {
+      const double ga = Q.ND(0)[ND_AT + 1 + a];
+      gx += ga; rx += ga;
+    } else {
+      rx += Q.lam[a];
+    }
+    Q.gf[xo + a] = gx;
+    Q.rd[xo + a] = rx - Q.zl[xo + a] + Q.zu[xo + a];
+    return;
+  }
+  if (cc == 0) return;
+  if (j < NX + NU) {
+    const int i = j - NX, uo = A.node_u_off[n];
+    double gu = 0.0, ru = 0.0, crt = 0.0;
+    for (int c = 0; c < cc; ++c) {
+      const int e = cs + c;
+      const double* S_ = Q.ES(e);
+      gu += S_[ES_GFY + NX + i]; ru += S_[ES_RY + NX + i];
+      const int cn = A.edge_child[e];
+      if (A.node_u_off[cn] >= 0) {
+        if (RT_CUSTOM) {
+          for (int j2 = 0; j2 < A.node_child_count[cn]; ++j2) crt += Q.ES(A.node_child_start[cn] + j2)[ES_RTUP + i];
+        } else {
+          crt -= 2.0 * node_rweight(Q, cn) * DOMPC_RTERM[i] * (Q.x[A.node_u_off[cn] + i] - Q.x[uo + i]);
+        }
+      }
+    }
+    double tmp[NU];
+    const double* up = uprev_ptr(Q, n, Q.x, tmp);
+    const double rt = (RT_CUSTOM ? 0.0 : 2.0 * node_rweight(Q, n) * DOMPC_RTERM[i] * (Q.x[uo + i] - up[i])) + crt;
+    Q.gf[uo + i] = gu + rt;
+    Q.rd[uo + i] = ru + rt - Q.zl[uo + i] + Q.zu[uo + i];
+    return;
+  }
+  if (NS > 0) {
+    const int q = j - NX - NU, eo = A.node_eps_off[n];
+    double r = 0.0;
+    for (int c = 0; c < cc; ++c) {
+      const int e = cs + c;
+      const double* yd = Q.lam + A.edge_row0[e] + NW + NX;
+      for (int i = 0; i < NE; ++i)
+        if (nl_slack(i) == q) r -= yd[i] * Q.sgn[e * NE1 + i];
+    }
+    const double g = cc * Q.sf * DOMPC_EPS_PEN[q];
+    Q.gf[eo + q] = g;
+    Q.rd[eo + q] = g + r - Q.zl[eo + q] + Q.zu[eo + q];
+  }
+}
 
 // ================================================================================================
 // Tree Riccati recursion.  Value function of node n over its augmented state (x_n, u_prev_n):
@@ -3845,6 +3921,9 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
 // ================================================================================================
 
 // derivative sweep at the current iterate: per-edge evaluation/condensing, node assembly, dummies
+// FINE: the thread-per-entry node assembly (a problem spread over several workgroups, fine_items) - its own instantiation and its own outlined
+// phase, so that the code of the batch path is the one it was (sharing one function cost the batch path 3.5 % in a same-box A/B)
+template <bool FINE>
 DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   const KArgs& A = *Q.A;
   T.sync();                                  // (every thread has read the previous sweep's verdict, see riccati_backward)
@@ -3899,6 +3978,10 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   }
   T.sync();
   DOMPC_PS(22)
+  if (FINE) {
+    constexpr int NVN = NX + NU + NS;
+    for (int it = T.tid; it < A.n_nodes * NVN; it += T.nt) assemble_entry(Q, it / NVN, it % NVN);
+  } else
   for (int n = T.tid; n < A.n_nodes; n += T.nt) {
     if (!mk_n(A, n)) continue;
     const int ci = cut_of(A, n);
@@ -4091,9 +4174,19 @@ DOMPC_PHASE Errs measure(const Thr& T, const Prob& Q, const Comp* pre) {
 // function-only evaluation of the trial point (line search): this thread's share of the objective; the constraint
 // values of its edges go to Q.ct.  Straight-line model code with its own register allocation (inlined into the
 // driver it was the main source of the driver's scratch traffic).
+template <bool FINE>
 DOMPC_DEV inline double trial_edges(const Thr& T, const Prob& Q) {
   const KArgs& A = *Q.A;
   double f = 0.0;
+  if (FINE && !DENSE_EDGE && M > 0) {
+    // one thread per piece of an edge; piece 0 of edge e (its objective share) on thread e like in the loop below: same partial sums
+    constexpr int NPC = NI * DEG + 1;
+    for (int it = T.tid; it < A.n_edges * NPC; it += T.nt) {
+      const int e = it % A.n_edges, q = it / A.n_edges;
+      const double fe = eval_edge_f_t<true>(Q, e, Q.xt, Q.st, Q.ct, q == 0 ? NI * DEG : q - 1);
+      f += fe;
+    }
+  } else
   for (int e = T.tid; e < A.n_edges; e += T.nt) {
     const int m = mk_e(A, e);
     if (!m) continue;
@@ -4163,6 +4256,7 @@ DOMPC_DEV inline void step_rules_pass(const Thr& T, const Prob& Q, double mu, do
   wg_reduce(T, r5, ops);
 }
 // objective, constraint violation and barrier sum of the trial point x + al * dx (left in Q.xt / Q.st, constraint values in Q.ct)
+template <bool FINE>
 DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, double& obj_o, double& th_o, double& bar_o) {
   const KArgs& A = *Q.A;
   const int nX = A.n_opt_x, nSl = A.n_edges * NE;
@@ -4194,7 +4288,7 @@ DOMPC_DEV inline void eval_trial_pass(const Thr& T, const Prob& Q, double al, do
   T.sync();
   for (int g = T.tid; g < NX; g += T.nt) Q.ct[g] = FREE_ROOT ? 0.0 : Q.xt[A.node_x_off[0] + g] - Q.P[g] / DOMPC_SX[g];
   if (FREE_ROOT && T.tid == 0) r3[0] += Q.sf * dompc_aterm_f(Q.xt + A.node_x_off[0], Q.P, Q.P + A.p_off_tvp, Q.P + A.p_off_p);
-  r3[0] += trial_edges(T, Q);
+  r3[0] += trial_edges<FINE>(T, Q);
   T.sync();
   {
     double c_[DOMPC_FW1];
@@ -4298,7 +4392,15 @@ __device__ __attribute__((noinline)) PhaseRet phase_sweep(const void* kp, int b,
   Q.soc = ufl(soc);
   prob_bounds(Q);
   Q.dsw = ufl(dsw);
-  const int rc = sweep(T, Q, ufl(mu));
+  const int rc = sweep<false>(T, Q, ufl(mu));
+  return PhaseRet{T.gen, T.nred, T.xseq, rc};
+}
+__device__ __attribute__((noinline)) PhaseRet phase_sweep_fine(const void* kp, int b, int slot, double sf, double mu, double dsw, int soc, unsigned gen, unsigned nred, unsigned xseq) {
+  DOMPC_PHASE_PROLOGUE
+  Q.soc = ufl(soc);
+  prob_bounds(Q);
+  Q.dsw = ufl(dsw);
+  const int rc = sweep<true>(T, Q, ufl(mu));
   return PhaseRet{T.gen, T.nred, T.xseq, rc};
 }
 __device__ __attribute__((noinline)) PhaseRet phase_backward(const void* kp, int b, int slot, double sf, double mu, double delta, double dsw, int mode, unsigned gen, unsigned nred, unsigned xseq) {
@@ -4324,7 +4426,13 @@ __device__ __attribute__((noinline)) PhaseRet3 phase_step_rules(const void* kp, 
 __device__ __attribute__((noinline)) PhaseRet3 phase_eval_trial(const void* kp, int b, int slot, double sf, double al, unsigned gen, unsigned nred, unsigned xseq) {
   DOMPC_PHASE_PROLOGUE
   double o = 0.0, th = 0.0, br = 0.0;
-  eval_trial_pass(T, Q, ufl(al), o, th, br);
+  eval_trial_pass<false>(T, Q, ufl(al), o, th, br);
+  return PhaseRet3{T.gen, T.nred, T.xseq, o, th, br};
+}
+__device__ __attribute__((noinline)) PhaseRet3 phase_eval_trial_fine(const void* kp, int b, int slot, double sf, double al, unsigned gen, unsigned nred, unsigned xseq) {
+  DOMPC_PHASE_PROLOGUE
+  double o = 0.0, th = 0.0, br = 0.0;
+  eval_trial_pass<true>(T, Q, ufl(al), o, th, br);
   return PhaseRet3{T.gen, T.nred, T.xseq, o, th, br};
 }
 __device__ __attribute__((noinline)) PhaseRet3 phase_accept(const void* kp, int b, int slot, double sf, double alpha, double a_z, double mu, unsigned gen, unsigned nred, unsigned xseq) {
@@ -4341,13 +4449,14 @@ __device__ __attribute__((noinline)) PhaseRet3 phase_accept(const void* kp, int 
 DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu, int soc = 0, double dsw = 0.0) {
   Q.dsw = dsw;
 #ifndef DOMPC_HOST_EMU
+  if (fine_items(T, *Q.A)) { DOMPC_PHASE_CALL(phase_sweep_fine, mu, dsw, soc) return ufl(r_.rc); }
   DOMPC_PHASE_CALL(phase_sweep, mu, dsw, soc)
   return ufl(r_.rc);
 #else
   (void)b; (void)slot;
   Q.soc = soc;
   prob_bounds(Q);
-  const int rc = sweep(T, Q, mu);
+  const int rc = fine_items(T, *Q.A) ? sweep<true>(T, Q, mu) : sweep<false>(T, Q, mu);
   Q.soc = 0;
   prob_bounds(Q);
   return rc;
@@ -4377,11 +4486,12 @@ DOMPC_DEV inline void run_step_rules(const Thr& T, const Prob& Q, int b, int slo
 }
 DOMPC_DEV inline void run_eval_trial(const Thr& T, const Prob& Q, int b, int slot, double al, double& obj_o, double& th_o, double& bar_o) {
 #ifndef DOMPC_HOST_EMU
+  if (fine_items(T, *Q.A)) { DOMPC_PHASE_CALL(phase_eval_trial_fine, al) obj_o = ufl(r_.v0); th_o = ufl(r_.v1); bar_o = ufl(r_.v2); return; }
   DOMPC_PHASE_CALL(phase_eval_trial, al)
   obj_o = ufl(r_.v0); th_o = ufl(r_.v1); bar_o = ufl(r_.v2);
 #else
   (void)b; (void)slot;
-  eval_trial_pass(T, Q, al, obj_o, th_o, bar_o);
+  if (fine_items(T, *Q.A)) eval_trial_pass<true>(T, Q, al, obj_o, th_o, bar_o); else eval_trial_pass<false>(T, Q, al, obj_o, th_o, bar_o);
 #endif
 }
 DOMPC_DEV inline Comp run_accept(const Thr& T, const Prob& Q, int b, int slot, double alpha, double a_z, double mu) {

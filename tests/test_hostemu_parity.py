@@ -281,3 +281,23 @@ def test_watchdog_same_iterates_as_the_oracle_when_it_starts_after_every_shorten
 def test_open_loop_on_a_discrete_model_with_an_uncertain_parameter():
     pc.check_open_loop_discrete(hostemu.patched)
 
+
+@pytest.mark.parametrize("name", ["CSTR", "industrial_poly", "oscillating_masses"])
+def test_thread_per_entry_loops_of_the_wide_mode_give_the_same_bits(name, monkeypatch):
+    """a single problem spread over several workgroups assembles gradients / dual residuals per VARIABLE and evaluates trial points per
+    PIECE of an edge instead of per node / per edge (csrc: fine_items); -DDOMPC_FINE_ITEMS=1 runs those loops on the host emulation:
+    same iterations, bitwise the same solution and multipliers (same arithmetic per entry, same order of every sum)"""
+    ex = CASES[name]
+    x0 = pc.golden(name)["mpc._x"][0]
+    sol = []
+    for defs in ("", "DOMPC_FINE_ITEMS=1"):
+        monkeypatch.setenv("DOMPC_DEFS", defs)
+        mpc = make_mpc(name)
+        mpc.x0 = x0
+        mpc.set_initial_guess()
+        mpc.make_step(x0)
+        assert mpc.solver_stats["success"]
+        sol.append((mpc.solver_stats["iter_count"], mpc.solver_stats["n_trials"], mpc.opt_x_num.master.copy(), mpc.lam_g_num.copy(), mpc.lam_x_num.copy()))
+    assert sol[0][:2] == sol[1][:2]
+    assert np.array_equal(sol[0][2], sol[1][2]) and np.array_equal(sol[0][3], sol[1][3]) and np.array_equal(sol[0][4], sol[1][4])
+
