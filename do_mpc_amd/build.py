@@ -114,12 +114,16 @@ def model_dir(model_hash: str) -> str:
     return d
 
 
-def model_code_object(header_text: str, model_hash: str, force: bool = False, opt: str = "-O3", shard: bool = False) -> str:
+def model_code_object(header_text: str, model_hash: str, force: bool = False, opt: str = "-O3", shard: bool = False, batch_only: bool = False) -> str:
     """Per-model gfx950 code object (hsaco) from the generated header + the kernel sources.
-    shard=True: the variant with tree-sharding support (ownership masks, cross-rank exchanges)."""
+    shard=True: the variant with tree-sharding support (ownership masks, cross-rank exchanges).
+    batch_only=True: the sibling `..._batch.hsaco` compiled with -DDOMPC_NO_WIDE=1 - "one workgroup per problem" is a compile-time fact there
+    (no device-scope barrier / atomic flag code in the phases: +1.2 % on the batch path in a same-box A/B); the runtime loads it next to the
+    general object when it exists and launches it for everything but the wide mode of small batches."""
     forced = os.environ.get("DOMPC_CODE_OBJECT")     # measurement aid: use this code object as it is (A/B against an older kernel)
     if forced and not shard:
         return forced
+    assert not (shard and batch_only)
     d = model_dir(model_hash)
     hdr = os.path.join(d, "model_gen.h")
     out = os.path.join(d, f"dompc_{ARCH}{'_shard' if shard else ''}.hsaco")
@@ -130,7 +134,10 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
     if defs or prof != "0" or lb != "2":          # (measurement builds live next to the product build, under their own names)
         tag = ("prof" if prof != "0" else "") + (("lb" + lb) if lb != "2" else "") + (hashlib.sha256(" ".join(defs).encode()).hexdigest()[:8] if defs else "")
         out = out[:-len(".hsaco")] + "_" + tag + ".hsaco"
-        stamp = out + ".stamp"
+    if batch_only:
+        out = out[:-len(".hsaco")] + "_batch.hsaco"      # (the name the runtime derives from the general object's path)
+        defs = defs + ["DOMPC_NO_WIDE=1"]
+    stamp = out + ".stamp"
     dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt + ("S" if shard else "") + "lb" + lb + "p" + prof + " ".join(defs)
     if not force and _fresh(out, stamp, dig):
         return out

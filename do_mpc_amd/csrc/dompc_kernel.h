@@ -270,6 +270,10 @@ DOMPC_HD inline XCtx make_xctx(const KArgs& A) {
   return X;
 }
 
+#ifndef DOMPC_NO_WIDE
+#define DOMPC_NO_WIDE 0             // 1: a code object for batch launches only - one workgroup per problem is a compile-time fact (experiment / A/B)
+#endif
+constexpr bool WIDE_OK = DOMPC_NO_WIDE == 0;
 struct Thr {
   int tid, nt;
   ldsd* red;        // LDS: RED_MAX * lnt doubles
@@ -293,19 +297,19 @@ struct Thr {
   // read and written with agent-scope atomics (a plain load could be served from this CU's L1).
   DOMPC_DEV void fset(int i, int v) const {
 #ifndef DOMPC_HOST_EMU
-    if (nwg > 1) { __hip_atomic_store(flags + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (WIDE_OK && nwg > 1) { __hip_atomic_store(flags + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
 #endif
     flags[i] = v;
   }
   DOMPC_DEV int fget(int i) const {
 #ifndef DOMPC_HOST_EMU
-    if (nwg > 1) return __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (WIDE_OK && nwg > 1) return __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     return flags[i];
   }
   DOMPC_DEV void sync() const {
 #ifndef DOMPC_HOST_EMU
-    if (nwg > 1) {
+    if (WIDE_OK && nwg > 1) {
       // device-scope barrier (MI355X_MICROARCH.md, inter-workgroup visibility).  Release side: EVERY wavefront drains
       // its own outstanding global stores (a workgroup-scope barrier does not wait for vmcnt outside tgsplit mode, so
       // without this a peer wavefront's stores could still be in flight when wavefront 0 signals the arrival); after the
@@ -423,7 +427,7 @@ __device__ inline Thr make_thr(const KArgs& A) {
 // between two full barriers; make_thr of the outlined phases reads it back.  Placement is NOT assumed (the dispatcher puts
 // block b on XCD b % 8 today, slot_of_block): on any other placement the barrier keeps its L2 write-back.
 __device__ inline void xcd_census(const Thr& T) {
-  if (T.nwg <= 1 || !DOMPC_LIGHT_BARRIER) return;
+  if (!WIDE_OK || T.nwg <= 1 || !DOMPC_LIGHT_BARRIER) return;
   if (T.ltid == 0) {
     const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;          // HW_REG_XCC_ID[3:0]
     __hip_atomic_fetch_or(T.bar + 1, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2594,7 +2598,7 @@ DOMPC_PHASE void assemble_node(const Prob& Q, int n) {
 #ifndef DOMPC_FINE_ITEMS
 #define DOMPC_FINE_ITEMS 0
 #endif
-DOMPC_DEV inline bool fine_items(const Thr& T, const KArgs& A) { return DOMPC_FINE_ITEMS >= 0 && (T.nwg > 1 || DOMPC_FINE_ITEMS > 0) && !sh_on(A); }      // (-1: compiled out, A/B measurements)
+DOMPC_DEV inline bool fine_items(const Thr& T, const KArgs& A) { return DOMPC_FINE_ITEMS >= 0 && ((WIDE_OK && T.nwg > 1) || DOMPC_FINE_ITEMS > 0) && !sh_on(A); }      // (-1: compiled out, A/B measurements)
 // assemble_node for ONE variable of node n: j < NX state, < NX + NU input, else slack entry
 DOMPC_DEV inline void assemble_entry(const Prob& Q, int n, int j) {
   const KArgs& A = *Q.A;
@@ -4923,7 +4927,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     //  watchdog like an unacceptable third step: back to the stored point)
     if (bad) { if (in_wd) { bad = 0; wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; }
     if (T.fget(6)) { status = 6; break; }                                    // the host asked the kernel to stop
-    if ((T.nwg > 1 || sh_on(A)) && T.fget(7)) { status = 5; break; }       // a peer workgroup never arrived at a barrier
+    if (((WIDE_OK && T.nwg > 1) || sh_on(A)) && T.fget(7)) { status = 5; break; }       // a peer workgroup never arrived at a barrier
     const double sd = fmax(s_max, (E.sum_y + E.C.sum_z) / fmax(1.0, n_dual)) / s_max;
     const double sc = fmax(s_max, E.C.sum_z / fmax(1.0, n_bounds)) / s_max;
     const double e_c0 = comp_err(E.C, 0.0);

@@ -69,8 +69,8 @@ struct dompc_handle {
   hipStream_t rccl_stream = nullptr;
 #endif
 #ifndef DOMPC_HOST_EMU
-  hipModule_t module = nullptr;
-  hipFunction_t fn_solve = nullptr, fn_info = nullptr;
+  hipModule_t module = nullptr, module_batch = nullptr;
+  hipFunction_t fn_solve = nullptr, fn_info = nullptr, fn_solve_batch = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t shard_stream = nullptr;    // lowest priority: never shares a hardware queue with the collective's kernels
 #endif
@@ -215,6 +215,7 @@ extern "C" void dompc_destroy(dompc_handle* h) {
   hipSetDevice(h->d.device);
   for (void* p : h->dev_allocs) hipFree(p);
   if (h->module) hipModuleUnload(h->module);
+  if (h->module_batch) hipModuleUnload(h->module_batch);
   if (h->stream) hipStreamDestroy(h->stream);
   if (h->x_words) hipHostFree(h->x_words);
   if (h->abort_word) hipHostFree(h->abort_word);
@@ -289,7 +290,9 @@ static int launch(dompc_handle* h, dompc::KArgs& A, int grid, int block, void* s
   A.pool_doubles = (int32_t)(per_wave > red ? per_wave : red);
   size_t sz = sizeof(A);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIPCHK(h, hipModuleLaunchKernel(h->fn_solve, grid, 1, 1, block, 1, 1, (unsigned)(A.pool_doubles * sizeof(double)), st, nullptr, cfg));
+  // (batch launches of the solver - one workgroup per problem, not sharded - run the batch-only build of the kernels when it was loaded)
+  hipFunction_t fn = (h->fn_solve_batch && A.mode == 0 && A.wide <= 1 && !h->sharded) ? h->fn_solve_batch : h->fn_solve;
+  HIPCHK(h, hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, (unsigned)(A.pool_doubles * sizeof(double)), st, nullptr, cfg));
 #else
   (void)grid; (void)block; (void)stream_v;
   dompc_hostemu_run(&A);
@@ -328,6 +331,23 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   if (hipModuleLoad(&h->module, h->code_path.c_str()) != hipSuccess) {
     h->error = "hipModuleLoad failed for " + h->code_path;
     return fail(1);
+  }
+  {
+    // optional sibling `<name>_batch.hsaco` (build.py: batch_only): the same kernels compiled for "one workgroup per problem" only
+    std::string bp = h->code_path;
+    const size_t dot = bp.rfind(".hsaco");
+    if (dot != std::string::npos && !getenv("DOMPC_NO_BATCH_OBJECT")) {
+      bp.insert(dot, "_batch");
+      FILE* f = fopen(bp.c_str(), "rb");
+      if (f) {
+        fclose(f);
+        if (hipModuleLoad(&h->module_batch, bp.c_str()) != hipSuccess ||
+            hipModuleGetFunction(&h->fn_solve_batch, h->module_batch, "dompc_solve_kernel") != hipSuccess) {
+          h->error = "hipModuleLoad failed for " + bp;
+          return fail(1);
+        }
+      }
+    }
   }
   if (hipModuleGetFunction(&h->fn_solve, h->module, "dompc_solve_kernel") != hipSuccess ||
       hipModuleGetFunction(&h->fn_info, h->module, "dompc_model_info_kernel") != hipSuccess) {

@@ -11,6 +11,7 @@ There is no CPU fallback: constructing the solver without the HIP runtime / a GP
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from typing import Dict, Optional
 
@@ -168,6 +169,10 @@ class HipIpmSolver:
                     pass
             _lib_path = build.runtime_library()
             _code_object = build.model_code_object(header_text, model_hash, shard=bool(shard))
+            if not shard and int(max_batch) > 64 and not os.environ.get("DOMPC_CODE_OBJECT"):
+                # handles that solve real batches also get the batch-only build of the kernels (one workgroup per problem a compile-time
+                # fact): the runtime finds it next to the general object and launches it for everything but the wide mode of B <= 64
+                build.model_code_object(header_text, model_hash, batch_only=True)
         self._lib = _load(_lib_path)
         self._keep = []
         d = ProblemDesc()
