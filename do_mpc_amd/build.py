@@ -117,9 +117,10 @@ def model_dir(model_hash: str) -> str:
 def model_code_object(header_text: str, model_hash: str, force: bool = False, opt: str = "-O3", shard: bool = False, batch_only: bool = False) -> str:
     """Per-model gfx950 code object (hsaco) from the generated header + the kernel sources.
     shard=True: the variant with tree-sharding support (ownership masks, cross-rank exchanges).
-    batch_only=True: the sibling `..._batch.hsaco` compiled with -DDOMPC_NO_WIDE=1 - "one workgroup per problem" is a compile-time fact there
-    (no device-scope barrier / atomic flag code in the phases: +1.2 % on the batch path in a same-box A/B); the runtime loads it next to the
-    general object when it exists and launches it for everything but the wide mode of small batches."""
+    batch_only=True: the sibling `..._batch.hsaco` compiled with -DDOMPC_NO_WIDE=1 -DDOMPC_BLOCK_CONST=64 - "one workgroup of ONE wavefront
+    per problem" (the launch shape of batches >= 4096) is a compile-time fact there: no device-scope barrier / atomic flag code in the phases
+    (+1.6 % on the headline batch in a same-box A/B), thread counts and strides constants, workgroup barriers folded (+1.0 % more); the
+    runtime loads it next to the general object when it exists and launches it whenever the workgroups have 64 threads."""
     forced = os.environ.get("DOMPC_CODE_OBJECT")     # measurement aid: use this code object as it is (A/B against an older kernel)
     if forced and not shard:
         return forced
@@ -136,7 +137,7 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
         out = out[:-len(".hsaco")] + "_" + tag + ".hsaco"
     if batch_only:
         out = out[:-len(".hsaco")] + "_batch.hsaco"      # (the name the runtime derives from the general object's path)
-        defs = defs + ["DOMPC_NO_WIDE=1"]
+        defs = defs + ["DOMPC_NO_WIDE=1", "DOMPC_BLOCK_CONST=64"]
     stamp = out + ".stamp"
     dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt + ("S" if shard else "") + "lb" + lb + "p" + prof + " ".join(defs)
     if not force and _fresh(out, stamp, dig):

@@ -50,18 +50,18 @@ extern "C" __global__ void dompc_model_info_kernel(const int32_t* in, int64_t* o
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256, DOMPC_LB) dompc_solve_kernel(dompc::KArgs A) {
+extern "C" __global__ void __launch_bounds__(DOMPC_BLOCK_CONST ? DOMPC_BLOCK_CONST : 256, DOMPC_LB) dompc_solve_kernel(dompc::KArgs A) {
   using namespace dompc;
   const int POOL = A.pool_doubles;
   if (threadIdx.x < 32) lds_prof[threadIdx.x] = 0;
   if (threadIdx.x < 8) lds_flags[threadIdx.x] = 0;
   // defined LDS contents at kernel start (the pool of the previous kernel on this CU is still in there)
-  for (int i = threadIdx.x; i < POOL; i += blockDim.x) lds_pool[i] = (i >= A.lds_fill_lo && i < A.lds_fill_hi) ? A.lds_fill : 0.0;
-  for (int i = threadIdx.x; i < 2 * MAX_FILTER; i += blockDim.x) lds_filt[i] = 0.0;
+  for (int i = threadIdx.x; i < POOL; i += DOMPC_BDIM) lds_pool[i] = (i >= A.lds_fill_lo && i < A.lds_fill_hi) ? A.lds_fill : 0.0;
+  for (int i = threadIdx.x; i < 2 * MAX_FILTER; i += DOMPC_BDIM) lds_filt[i] = 0.0;
   __syncthreads();
   // Thread context (make_thr).  Normal mode: one workgroup per problem, problems pulled from a device-wide counter.
   // Wide mode (small batches): K = A.wide workgroups per problem, static assignment problem = slot.
-  const bool wide = (A.mode == 0 && A.wide > 1);
+  const bool wide = dompc::WIDE_OK && (A.mode == 0 && A.wide > 1);
   const int slot = slot_of_block(A);
   if (wide && slot >= A.batch) return;
   Thr T = make_thr(A);

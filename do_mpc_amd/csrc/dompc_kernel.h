@@ -274,6 +274,14 @@ DOMPC_HD inline XCtx make_xctx(const KArgs& A) {
 #define DOMPC_NO_WIDE 0             // 1: a code object for batch launches only - one workgroup per problem is a compile-time fact (experiment / A/B)
 #endif
 constexpr bool WIDE_OK = DOMPC_NO_WIDE == 0;
+#ifndef DOMPC_BLOCK_CONST
+#define DOMPC_BLOCK_CONST 0         // 64: a code object for launches with 64-thread workgroups only (one wavefront per problem: B >= 4096) - thread counts,
+#endif                              // strides and the number of lane groups are compile-time constants, workgroup barriers fold away
+#if DOMPC_BLOCK_CONST
+#define DOMPC_BDIM DOMPC_BLOCK_CONST
+#else
+#define DOMPC_BDIM ((int)blockDim.x)
+#endif
 struct Thr {
   int tid, nt;
   ldsd* red;        // LDS: RED_MAX * lnt doubles
@@ -411,14 +419,14 @@ __device__ inline int slot_of_block(const KArgs& A) {
   return wide ? (q / A.wide) * 8 + (int)(blockIdx.x % 8) : (int)blockIdx.x;
 }
 __device__ inline Thr make_thr(const KArgs& A) {
-  const bool wide = (A.mode == 0 && A.wide > 1);
+  const bool wide = WIDE_OK && (A.mode == 0 && A.wide > 1);
   const int K = wide ? A.wide : 1;
   const int q = blockIdx.x / 8;
   const int j = wide ? q % K : 0;
   const int slot = slot_of_block(A);
-  return Thr{j * (int)blockDim.x + (int)threadIdx.x, K * (int)blockDim.x, (ldsd*)lds_pool, (ldsd*)lds_filt,
+  return Thr{j * DOMPC_BDIM + (int)threadIdx.x, K * DOMPC_BDIM, (ldsd*)lds_pool, (ldsd*)lds_filt,
              wide ? A.wide_flags + slot * 8 : lds_flags, (ldsd*)lds_pool, lds_prof, 64,
-             (int)threadIdx.x, (int)blockDim.x, j, K, wide ? A.wide_bar + slot * 16 : nullptr,
+             (int)threadIdx.x, DOMPC_BDIM, j, K, wide ? A.wide_bar + slot * 16 : nullptr,
              wide ? A.wide_partials + (int64_t)slot * 2 * K * RED_MAX : nullptr, 0u, 0u, make_xctx(A), 0u, nullptr,
              (wide && DOMPC_LIGHT_BARRIER) ? __hip_atomic_load(A.wide_bar + slot * 16 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u : false};
 }

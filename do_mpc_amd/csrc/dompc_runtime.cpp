@@ -290,8 +290,9 @@ static int launch(dompc_handle* h, dompc::KArgs& A, int grid, int block, void* s
   A.pool_doubles = (int32_t)(per_wave > red ? per_wave : red);
   size_t sz = sizeof(A);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  // (batch launches of the solver - one workgroup per problem, not sharded - run the batch-only build of the kernels when it was loaded)
-  hipFunction_t fn = (h->fn_solve_batch && A.mode == 0 && A.wide <= 1 && !h->sharded) ? h->fn_solve_batch : h->fn_solve;
+  // (batch launches of the solver with one 64-thread workgroup per problem, not sharded, run the build of the kernels that is compiled for
+  //  exactly that shape when it was loaded: build.py batch_only)
+  hipFunction_t fn = (h->fn_solve_batch && A.mode == 0 && A.wide <= 1 && block == 64 && !h->sharded) ? h->fn_solve_batch : h->fn_solve;
   HIPCHK(h, hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, (unsigned)(A.pool_doubles * sizeof(double)), st, nullptr, cfg));
 #else
   (void)grid; (void)block; (void)stream_v;
@@ -333,7 +334,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     return fail(1);
   }
   {
-    // optional sibling `<name>_batch.hsaco` (build.py: batch_only): the same kernels compiled for "one workgroup per problem" only
+    // optional sibling `<name>_batch.hsaco` (build.py: batch_only): the same kernels compiled for "one 64-thread workgroup per problem" only
     std::string bp = h->code_path;
     const size_t dot = bp.rfind(".hsaco");
     if (dot != std::string::npos && !getenv("DOMPC_NO_BATCH_OBJECT")) {

@@ -169,9 +169,9 @@ class HipIpmSolver:
                     pass
             _lib_path = build.runtime_library()
             _code_object = build.model_code_object(header_text, model_hash, shard=bool(shard))
-            if not shard and int(max_batch) > 64 and not os.environ.get("DOMPC_CODE_OBJECT"):
-                # handles that solve real batches also get the batch-only build of the kernels (one workgroup per problem a compile-time
-                # fact): the runtime finds it next to the general object and launches it for everything but the wide mode of B <= 64
+            if not shard and (int(max_batch) >= 4096 or int(block_threads) == 64) and not os.environ.get("DOMPC_CODE_OBJECT"):
+                # handles that solve large batches (one wavefront per problem from B = 4096 on) also get the build of the kernels that is
+                # compiled for exactly that launch shape: the runtime finds it next to the general object
                 build.model_code_object(header_text, model_hash, batch_only=True)
         self._lib = _load(_lib_path)
         self._keep = []
