@@ -1159,6 +1159,12 @@ DOMPC_DEV inline double lane_bcast(double v, int src) {
 #ifndef DOMPC_GJ_ADJ
 #define DOMPC_GJ_ADJ 0                // 1: inverse of the 4 x 4 pivot block from its adjugate instead of LU in uniform arithmetic + two triangular solves (measured: +-0)
 #endif
+#ifndef DOMPC_GJ_LTEST
+#define DOMPC_GJ_LTEST 1            // 1: the threshold test of the 4 x 4 pivot blocks on the multipliers l_ik = a_ik / a_kk (|l_ik| <= 1 / u) instead of on the
+#endif                              // column entries before the division: 10 instead of 18 uniform instructions per step, same decisions (+0.3 %)
+#if DOMPC_GJ_LTEST && DOMPC_GJ_ADJ
+#error "DOMPC_GJ_LTEST belongs to the LU variant of the pivot block"
+#endif
 #ifndef DOMPC_GJ_SB
 #define DOMPC_GJ_SB 0               // 1: scheduling barriers at the step boundaries of the blocked elimination (measurement aid)
 #endif
@@ -1228,6 +1234,85 @@ __device__ inline double gj_element(const ldsd* mol, const ldsd* Ld, int row, in
   return v;
 }
 
+// Table-driven tile build.  Which entry of the image (or of the residual rows) and which constant make up element (row, column)
+// of [G_cc | G_y r | I] depends on the lane and on the tile register, not on the edge: gj_element() spends ~10 vector instructions per
+// element on that index arithmetic, 20 elements per lane and edge.  Once per sweep and wavefront the LDS byte offset (relative to
+// the wavefront's region) of every element is written into a table behind the sweep's working set (16 bits per element and lane;
+// the region belongs to the staging buffers of the Riccati passes outside the sweep): an image entry, a residual row, or a
+// constant of a small pool (0, 1, -C[s][j]).  Only the diagonal of G_cc is an image entry MINUS a coefficient - those elements live
+// in the tile registers whose rows and columns overlap (T[mi][mi][.], the packed register of tile column 1); their table entries
+// carry the index of -C[j][j] in the three low bits (offsets are multiples of 8).  The build is then one 16-bit and one 64-bit LDS
+// read per element.  Same values as gj_element() up to the sign of a zero.
+#ifndef DOMPC_GJ_TABLE
+#define DOMPC_GJ_TABLE 1
+#endif
+#ifndef DOMPC_GJ_TABLE_CHECK
+#define DOMPC_GJ_TABLE_CHECK 0        // 1: build every tile both ways and trap on a difference (GPU check of the table)
+#endif
+constexpr int GJ_NEL = GJ_MTF * 4 * GJ_NT + (GJ_PACK ? GJ_NT : 0);      // tile registers of a lane
+constexpr int GJ_NPOOL = 2 + (DEG + 1) * DEG;                           // 0, 1, -C[s][j] (s = 0..DEG, j = 1..DEG)
+constexpr int GJ_TAB = ((EL_MOC + MOC_STAGE + 1) / 2) * 2;
+constexpr int GJ_POOL = GJ_TAB + (GJ_NEL * 64 * 2 + 7) / 8;
+constexpr int GJ_DPOOL = GJ_POOL + GJ_NPOOL;                            // 0, -C[1][1], ..., -C[DEG][DEG]
+constexpr bool GJ_TABLE = MFMA_GJ && (DOMPC_GJ_TABLE != 0) && (GJ_DPOOL + DEG + 1 <= EL_SIZE) && (EL_SIZE <= 2048) && (DEG <= 7);
+typedef __attribute__((address_space(3))) unsigned short ldsu16;
+typedef __attribute__((address_space(3))) char ldsc;
+// table entry of element (row, column lc of tile column ni): mirrors gj_element()
+__device__ inline unsigned gj_entry(int row, int ni, int lc) {
+  constexpr int R = GJ_R;
+  const GjCol c = gj_col(ni, lc);
+  unsigned off = GJ_POOL, ci = 0, dg = 0;         // (pool entry 0 is 0.0)
+  if (row >= R) {
+    ci = (16 * ni + lc == row) ? 1u : 0u;
+  } else {
+    const int jj = row / NX, a = row - jj * NX;
+    const unsigned jo = (unsigned)(EL_MOS + MO_PT + NX) + (unsigned)(jj * PT_STRIDE + a * NA);
+    if (c.kind == 0) {
+      if (c.sl == jj) off = jo + (unsigned)c.b;
+      if (a == c.b) {
+        if (c.sl == jj) dg = (unsigned)(jj + 1);          // diagonal of G_cc: image entry - C[jj + 1][jj + 1]
+        else ci = 2u + (unsigned)((c.sl + 1) * DEG + jj);
+      }
+    } else if (c.kind == 1) {
+      if (c.b >= NX) off = jo + (unsigned)c.b;
+      else if (a == c.b) ci = 2u + (unsigned)jj;
+    } else if (c.kind == 2) {
+      off = (unsigned)(EL_T1 + row);
+    } else if (c.kind == 3) {
+      ci = (c.b == row) ? 1u : 0u;
+    }
+  }
+  if (ci) off = GJ_POOL + ci;                     // (never together with an image entry)
+  return (off << 3) | dg;
+}
+// once per sweep and wavefront (all 64 lanes of the wavefront that owns Ld)
+__device__ inline void gj_table_init(ldsd* Ld, int lane) {
+  if constexpr (GJ_TABLE) {
+    ldsu16* tab = (ldsu16*)(Ld + GJ_TAB);
+    const int lr = lane >> 4, lc = lane & 15;
+    int el = 0;
+#pragma unroll
+    for (int mi = 0; mi < GJ_MTF; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ni = 0; ni < GJ_NT; ++ni, ++el)
+          tab[el * 64 + lane] = (unsigned short)((16 * mi + 4 * r >= GJ_RP) ? (unsigned)(GJ_POOL << 3) : gj_entry(16 * mi + 4 * r + lr, ni, lc));
+    if constexpr (GJ_PACK) {
+#pragma unroll
+      for (int ni = 0; ni < GJ_NT; ++ni, ++el) tab[el * 64 + lane] = (unsigned short)gj_entry(16 + lr, ni, lc);
+    }
+    if (lane < GJ_NPOOL) {
+      double v = (lane == 1) ? 1.0 : 0.0;
+      if (lane >= 2) v = -DOMPC_C[((lane - 2) / DEG) * (DEG + 1) + (lane - 2) % DEG + 1];
+      Ld[GJ_POOL + lane] = v;
+    }
+    if (lane <= DEG) Ld[GJ_DPOOL + lane] = (lane == 0) ? 0.0 : -DOMPC_C[lane * (DEG + 1) + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <class DUAL>
 __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld, DUAL&& dual_from) {
   constexpr int R = GJ_R, RP = GJ_RP, MT = GJ_MTF > 0 ? GJ_MTF : 1, NT = GJ_NT > 0 ? GJ_NT : 1;      // (at least one tile: the function is compiled for every model)
@@ -1247,6 +1332,40 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
   d4 T[MT][NT];
   d4 X = {0.0, 0.0, 0.0, 0.0};                    // GJ_PACK: register ni = rows 16..19 of tile column ni
   // ---- tiles of [G_cc | G_y r | I]
+  if constexpr (GJ_TABLE) {
+    const ldsu16* tab = (const ldsu16*)(Ld + GJ_TAB) + lane;
+    const ldsc* Lb = (const ldsc*)Ld;
+    auto elem = [&](int el, bool diag) {            // (diag: compile-time - the register can hold diagonal entries of G_cc)
+      const unsigned w = tab[el * 64];
+      if (!diag) return (double)*(const ldsd*)(Lb + w);
+      return (double)*(const ldsd*)(Lb + (w & 0xfff8u)) + (double)Ld[GJ_DPOOL + (w & 7u)];
+    };
+    int el = 0;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni, ++el) T[mi][ni][r] = elem(el, ni == mi);
+    if constexpr (GJ_PACK) {
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni, ++el) X[ni] = elem(el, ni == 1);
+    }
+#if DOMPC_GJ_TABLE_CHECK
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          if (T[mi][ni][r] != ((16 * mi + 4 * r >= RP) ? 0.0 : gj_element(mol, Ld, 16 * mi + 4 * r + lr, ni, lc))) __builtin_trap();
+    if constexpr (GJ_PACK) {
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+        if (X[ni] != gj_element(mol, Ld, 16 + lr, ni, lc)) __builtin_trap();
+    }
+#endif
+  } else {
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -1257,6 +1376,7 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
   if constexpr (GJ_PACK) {
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) X[ni] = gj_element(mol, Ld, 16 + lr, ni, lc);
+  }
   }
   GJ_PH(25)
   {
@@ -1381,15 +1501,20 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
     double iu[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+#if !DOMPC_GJ_LTEST
       double m = 0.0;
 #pragma unroll
       for (int i = k + 1; i < 4; ++i) m = fmax(m, fabs(a_[i][k]));
       viol = fmax(viol, fma(GJ_U, m, -fabs(a_[k][k])));      // > 0: |a_kk| < GJ_U max|a_ik|
+#endif
       pmin = fmin(pmin, fabs(a_[k][k]));
       iu[k] = fast_rcp(a_[k][k]);
 #pragma unroll
       for (int i = k + 1; i < 4; ++i) {
         a_[i][k] *= iu[k];
+#if DOMPC_GJ_LTEST
+        viol = fmax(viol, fabs(a_[i][k]));                  // the same test on the multipliers: |l_ik| <= 1 / GJ_U
+#endif
 #pragma unroll
         for (int j = k + 1; j < 4; ++j) a_[i][j] = fma(-a_[i][k], a_[k][j], a_[i][j]);
       }
@@ -1449,7 +1574,11 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
 #if DOMPC_GJ_PRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
+#if DOMPC_GJ_LTEST
+  if (!(viol <= 1.0 / GJ_U && pmin > 1e-300)) return 1;  // (NaN-safe: a failed test or a vanishing pivot)
+#else
   if (!(viol <= 0.0 && pmin > 1e-300)) return 1;        // (NaN-safe: a failed test or a vanishing pivot)
+#endif
   // ---- W | w0 (collocation rows) -> LDS, G_cc^-1 -> forward record
   auto put = [&](int row, int ni, double v) {
     const GjCol c = gj_col(ni, lc);
@@ -1474,6 +1603,7 @@ __device__ inline int edge_factor_mfma(const Prob& Q, int e, int lane, ldsd* Ld,
 }
 #else
 constexpr bool MFMA_GJ = false;
+DOMPC_DEV inline void gj_table_init(ldsd*, int) {}
 #endif
 
 // ================================================================================================
@@ -3975,6 +4105,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     int staged_e = -1;
     const MocMap mm = moc_map(lane, T.gs);
     if (MO_COMPACT) mo_image_init(Ld + EL_MOS, lane, T.gs);
+    if (MFMA_GJ) gj_table_init(Ld, lane);            // (MFMA_GJ: one wavefront per edge group)
     for (int rd = 0; rd < rounds; ++rd) {
       const int e = rd * ng + gid;
       const int en = e + ng;
