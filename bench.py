@@ -552,9 +552,11 @@ def main(argv=None):
                 b_.record(stream)
             sync()
             sw_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in evs]))
+            sw_res = float(tG.abs().max().item()) if bool(np.all(mpc._nlp_cons_lb == mpc._nlp_cons_ub)) else None
             sw_ach = B * sweep_b / (sw_ms * 1e-3) / 1e9
             sweep_only = {"achieved": sw_ach, "frac": sw_ach / HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                           "kernel_ms": sw_ms, "algorithmic_bytes_per_launch": float(B * sweep_b),
+                          "max_abs_residual_at_the_solutions": sw_res,      # (all rows are equalities: g(x*) = 0 up to the solver's tolerance)
                           "what": "dompc_sweep_batch_device: one model-evaluation sweep (g, per-edge Jacobian and Lagrangian-Hessian "
                                   "blocks, condensing records) of each of the B solutions, residuals copied out; dompc_solve_kernel mode 2"}
         traffic, traffic_note = None, "not measured (--no-traffic or N > 1)"

@@ -3776,6 +3776,103 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       if (mk_n(A, n)) node_step(n);
     T.sync();
   }
+#ifndef DOMPC_HOST_EMU
+#ifndef DOMPC_FW4
+#define DOMPC_FW4 1                 // chain walk of the forward pass: four scenario chains per wavefront (0: one)
+#endif
+  // Chain walk, FOUR scenario chains per wavefront: a chain step keeps at most NA (<= 16) lanes busy and is a sequence of four LDS round
+  // trips with dependent sums in between - latency, not work.  Lane group c = lane >> 4 walks chain s0 + c with its own step vectors and
+  // operand area in LDS; the same arithmetic per entry and the same order of every sum as chain_step() (bitwise the same steps), a quarter
+  // of the sequential steps per wavefront.  On the chain levels node (k, s) = level_node_start[k] + s has the one child edge
+  // node_child_start[level_node_start[k]] + s leading to node (k + 1, s) (checked by the runtime when it sets chain_level).
+  constexpr int FW4_CH = ((3 * 16 + FW_N + 1) / 2) * 2, FW4_PL = (FW_N + 15) / 16;
+  constexpr bool FW4 = (DOMPC_FW4 != 0) && NA <= 16 && NV <= 16 && 4 * FW4_CH <= EL_SIZE;
+  if (FW4 && GS == 64) {
+    const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
+    const int c4 = lane >> 4, ll = lane & 15;
+    ldsd* C = Ld + c4 * FW4_CH;
+    ldsd *DX = C, *DV = C + 16, *DXN = C + 32, *IN = C + 48;
+    struct Ix { int uo, eo, xoc, row0; unsigned ndc; };       // per-lane (= per-chain) indices of a step, requested with its operands
+    const int cw = (S + ng - 1) / ng < 4 ? (S + ng - 1) / ng : 4;      // chains per wavefront (one problem alone: every chain has its own wavefront)
+    for (int s0 = cw * gid; s0 < S && cl < A.N; s0 += cw * ng) {
+      const bool here = c4 < cw && s0 + c4 < S;
+      const int sc = here ? s0 + c4 : S - 1;                  // (lane groups without a chain repeat the last one and store nothing)
+      const bool on = here && mk_n(A, A.level_node_start[A.N] + sc);
+      double v[FW4_PL];
+      auto load4 = [&](int k, Ix& ix) {
+        const int n = A.level_node_start[k] + sc, e = A.node_child_start[A.level_node_start[k]] + sc, cn = A.level_node_start[k + 1] + sc;
+        const unsigned nd0 = (unsigned)n * (unsigned)ND_SIZE, es0 = (unsigned)e * (unsigned)ES_SIZE, nc0 = (unsigned)cn * (unsigned)ND_SIZE;
+#pragma unroll
+        for (int q = 0; q < FW4_PL; ++q) {
+          const int i = ll + 16 * q;
+          double x = 0.0;
+          if (i < NV * NA) x = ldoff(Q.nd, nd0 + (unsigned)(ND_K + i));
+          else if (i < FW_K) x = ldoff(Q.nd, nd0 + (unsigned)(ND_KV + i - NV * NA));
+          else if (i < FW_K + NX * NA) x = ldoff(Q.es, es0 + (unsigned)(ES_AB + i - FW_K));
+          else if (i < FW_K + FW_AB) x = ldoff(Q.es, es0 + (unsigned)(ES_CV + i - FW_K - NX * NA));
+          else if (i < FW_K + FW_AB + NX * NA) x = ldoff(Q.nd, nc0 + (unsigned)(ND_P + i - FW_K - FW_AB));
+          else if (i < FW_N) x = ldoff(Q.nd, nc0 + (unsigned)(ND_PV + i - FW_K - FW_AB - NX * NA));
+          v[q] = x;
+        }
+        ix.uo = A.node_u_off[n];
+        ix.eo = NS > 0 ? A.node_eps_off[n] : 0;
+        ix.xoc = A.node_x_off[cn];
+        ix.row0 = A.edge_row0[e];
+        ix.ndc = nc0;
+      };
+      Ix cur, nxt;
+      load4(cl, cur);
+      if (ll < NA) DX[ll] = ldoff(Q.nd, (unsigned)(A.level_node_start[cl] + sc) * (unsigned)ND_SIZE + (unsigned)(ND_DXT + ll));
+      for (int k = cl; k < A.N; ++k) {
+#pragma unroll
+        for (int q = 0; q < FW4_PL; ++q) {
+          const int i = ll + 16 * q;
+          if (i < FW_N) IN[i] = v[q];
+        }
+        if (k + 1 < A.N) load4(k + 1, nxt);                  // (in flight during the step)
+        T.gsync();
+        const ldsd *K_ = IN, *KV_ = K_ + NV * NA, *AB_ = IN + FW_K, *CV_ = AB_ + NX * NA, *PC_ = IN + FW_K + FW_AB, *PV_ = PC_ + NX * NA;
+        if (ll < NV) {
+          double t = KV_[ll];
+#pragma unroll
+          for (int a = 0; a < NA; ++a) t += K_[ll * NA + a] * DX[a];
+          DV[ll] = t;
+          if (on) {
+            if (ll < NU) Q.dx[cur.uo + ll] = t;
+            else Q.dx[cur.eo + ll - NU] = t;
+          }
+        }
+        T.gsync();
+        if (ll < NA) {
+          double t;
+          if (ll < NX) {
+            t = CV_[ll];
+#pragma unroll
+            for (int b = 0; b < NX; ++b) t += AB_[ll * NA + b] * DX[b];
+#pragma unroll
+            for (int b = 0; b < NU; ++b) t += AB_[ll * NA + NX + b] * DV[b];
+            if (on) Q.dx[cur.xoc + ll] = t;
+          } else {
+            t = DV[ll - NX];
+          }
+          if (on) Q.nd[cur.ndc + (unsigned)(ND_DXT + ll)] = t;
+          DXN[ll] = t;
+        }
+        T.gsync();
+        if (ll < NX) {
+          double t = PV_[ll];
+#pragma unroll
+          for (int b = 0; b < NA; ++b) t += PC_[ll * NA + b] * DXN[b];
+          if (on) Q.dlam[cur.row0 + NW + ll] = t;
+        }
+        if (ll < NA) DX[ll] = DXN[ll];
+        T.gsync();
+        cur = nxt;
+      }
+    }
+    T.sync();
+  } else
+#endif
   {
     const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
     for (int s_ = gid; s_ < S; s_ += ng) {

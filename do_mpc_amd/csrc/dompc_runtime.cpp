@@ -292,7 +292,7 @@ static int launch(dompc_handle* h, dompc::KArgs& A, int grid, int block, void* s
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   // (batch launches of the solver with one 64-thread workgroup per problem, not sharded, run the build of the kernels that is compiled for
   //  exactly that shape when it was loaded: build.py batch_only)
-  hipFunction_t fn = (h->fn_solve_batch && A.mode == 0 && A.wide <= 1 && block == 64 && !h->sharded) ? h->fn_solve_batch : h->fn_solve;
+  hipFunction_t fn = (h->fn_solve_batch && (A.mode == 0 || A.mode == 2) && A.wide <= 1 && block == 64 && !h->sharded) ? h->fn_solve_batch : h->fn_solve;
   HIPCHK(h, hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, (unsigned)(A.pool_doubles * sizeof(double)), st, nullptr, cfg));
 #else
   (void)grid; (void)block; (void)stream_v;
@@ -455,7 +455,8 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   A.n_opt_x = d.n_opt_x; A.n_opt_p = d.n_opt_p; A.n_g = d.n_g; A.e_pad = h->e_pad;
   A.p_off_tvp = d.p_off_tvp; A.p_off_p = d.p_off_p; A.p_off_uprev = d.p_off_uprev;
   {
-    // chain_level: first stage from which every node (k, s) has exactly one child, (k+1, s)
+    // chain_level: first stage from which every node (k, s) has exactly one child, (k+1, s), over edge node_child_start[(k, 0)] + s
+    // (the chain walks of the Riccati passes form these indices arithmetically)
     const int32_t* ls = desc->level_node_start;
     const int S = ls[d.N + 1] - ls[d.N];
     int cl = d.N;
@@ -463,7 +464,8 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
       bool ok = (ls[k + 1] - ls[k]) == S;
       for (int s = 0; ok && s < S; ++s) {
         const int n = ls[k] + s;
-        ok = desc->node_child_count[n] == 1 && desc->edge_child[desc->node_child_start[n]] == ls[k + 1] + s;
+        ok = desc->node_child_count[n] == 1 && desc->edge_child[desc->node_child_start[n]] == ls[k + 1] + s &&
+             desc->node_child_start[n] == desc->node_child_start[ls[k]] + s;
       }
       if (!ok) break;
       cl = k;
@@ -796,8 +798,11 @@ extern "C" int dompc_sweep_batch_device(dompc_handle* h, int32_t B, const double
   dompc::KArgs A = h->base;
   A.p = p; A.sw_x = x; A.sw_lam = lam; A.sw_g = g; A.sw_blocks = blocks;
   A.batch = B; A.mode = 2;
-  const int grid = B < h->n_slots ? B : h->n_slots;
-  return launch(h, A, grid, fit_block(h, h->block), stream);
+  // (same launch shape as a solve of that many problems: one 64-thread workgroup per iterate from BATCH_ONE_WAVE on)
+  const int block = fit_block(h, h->block_auto ? (B >= BATCH_ONE_WAVE ? 64 : 256) : h->block);
+  const int cap = (h->block_auto && block != 64 && h->slots256 < h->n_slots) ? h->slots256 : h->n_slots;
+  const int grid = B < cap ? B : cap;
+  return launch(h, A, grid, block, stream);
 }
 
 static int newton_step_impl(dompc_handle* h, const double* x, const double* lam_g, const double* zl,

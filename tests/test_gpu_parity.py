@@ -60,6 +60,36 @@ def test_sweep_blocks_match_oracle_jacobian(name):
     pc.check_sweep_blocks(mpc, name, DevArr, _from_dev)
 
 
+def test_sweep_in_the_launch_shape_of_large_batches():
+    """dompc_sweep_batch_device for B >= 4096 iterates runs one 64-thread workgroup per iterate (the launch shape of a solve of that many
+    problems, the code object built for it): residuals against the oracle's g, and bitwise the same as the small-batch launch
+    (256-thread workgroups, general code object)"""
+    name = "industrial_poly"
+    B, K = 4096, 6
+    mpc = make_mpc(name, max_batch=B)
+    ps = mpc.structure
+    nlp = pc.oracle_nlp(name)
+    g = pc.golden(name)
+    rng = np.random.default_rng(5)
+    s = nlp.scaling_vector()
+    Xk = np.stack([g["mpc._opt_x_num"][k % 5] / s * (1 + 1e-3 * rng.standard_normal(ps.n_opt_x)) for k in range(K)])
+    Lk = np.stack([g["mpc._lam_g_num"][k % 5] for k in range(K)])
+    Pk = np.stack([pc.golden_opt_p(name, g, k % 5, nlp.n_opt_p) for k in range(K)])
+    idx = np.arange(B) % K
+    dX, dL, dP = DevArr(Xk[idx]), DevArr(Lk[idx]), DevArr(Pk[idx])
+    dG = DevArr(np.zeros((B, ps.n_g)))
+    mpc.S.sweep_batch_device(B, dX.ptr, dL.ptr, dP.ptr, dG.ptr, 0)
+    G = _from_dev(dG)
+    for k in range(K):
+        gv = nlp.g(Xk[k], Pk[k])
+        assert np.max(np.abs(G[k] - gv)) < 1e-10 * max(1.0, np.max(np.abs(gv)))
+    assert np.array_equal(G, G[:K][idx])                     # every copy of an iterate: the same bits
+    small = make_mpc(name, max_batch=8)
+    dG2, dX2, dL2, dP2 = DevArr(np.zeros((K, ps.n_g))), DevArr(Xk), DevArr(Lk), DevArr(Pk)
+    small.S.sweep_batch_device(K, dX2.ptr, dL2.ptr, dP2.ptr, dG2.ptr, 0)
+    assert np.array_equal(_from_dev(dG2), G[:K])
+
+
 @pytest.mark.parametrize("name,opts", [("batch_reactor", None), ("rotating_masses", None),
                                        ("industrial_poly", None), ("CSTR", None)])
 def test_same_iterates_as_the_oracle(name, opts):
