@@ -3922,6 +3922,231 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
                                        (__attribute__((address_space(3))) void*)(Ld + RF_MOC + 128 * q), 16, 0, 0);
   };
 #endif
+#ifndef DOMPC_HOST_EMU
+#ifndef DOMPC_FE2
+#define DOMPC_FE2 1                 // per-edge part of the forward pass: two edges per wavefront (0: one)
+#endif
+  // Two edges per wavefront.  The per-edge part keeps NW (<= 32) lanes busy - one row of the edge's block each - and is a sequence of
+  // memory round trips and dependent sums like the chain walk above; lanes 0-31 now handle edge 2 p, lanes 32-63 edge 2 p + 1 of a pair,
+  // each half with its own step vectors and staging buffer in LDS (the same arithmetic per row and the same order of every sum).
+  // Two dense images of the model-output record do not fit the region: a lane's sixteen entries of the record (its row of H_ww | H_wu,
+  // its entries of J_u) are read straight from the staged COMPACT record through a table of their positions, built once per pass
+  // (position in the compact record, or in a small pool of the model's constants kept in the slack of the staging buffer).
+  constexpr int FE_HV = 128, FE_DY = 0, FE_DNU = 16, FE_G = 32, FE_DW = 64, FE_RHS = 96;      // step vectors of a half
+  constexpr int FE_SS = EW_STAGE + MOC_STAGE, FE_STG = 2 * FE_HV, FE_POOL = EW_STAGE + MOC_SIZE, FE_TAB = FE_STG + 2 * FE_SS;
+  constexpr bool FE2 = (DOMPC_FE2 != 0) && MO_LDS && M > 0 && NI == 1 && DEG > 0 && !DENSE_EDGE && DOMPC_SHARD == 0 && NW <= 32 && NA <= 16 &&
+                       NA + NU <= 16 && NE <= 32 && (MOC_STAGE - MOC_SIZE >= 1 + DOMPC_DYN_NC) && (FE_TAB + 128 <= EL_SIZE) &&
+                       (PT_STRIDE <= 2 * FE_SS) && LU_N < NW;
+  if (FE2 && GS == 64) {
+    typedef __attribute__((address_space(3))) unsigned short ldsu16_;
+    const int h = lane >> 5, l32 = lane & 31;
+    ldsd* Lv = Ld + h * FE_HV;
+    ldsd* Ls = Ld + FE_STG + h * FE_SS;
+    ldsu16_* tab = (ldsu16_*)(Ld + FE_TAB);
+    constexpr int NVD = DOMPC_DYN_NV > 0 ? DOMPC_DYN_NV : 1, NCD = DOMPC_DYN_NC > 0 ? DOMPC_DYN_NC : 1;
+    {
+      // table of this row's entries: position of dense entry d of a point record = compact index (variable entry), pool (constant), zero
+      ldsu16_* inv = (ldsu16_*)(Ld + FE_STG);
+      for (int d = lane; d < PT_STRIDE; d += 64) inv[d] = 0xffffu;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int v = lane; v < DOMPC_DYN_NV; v += 64) inv[DOMPC_DYN_VIDX[v % NVD]] = (unsigned short)v;
+      for (int c = lane; c < DOMPC_DYN_NC; c += 64) inv[DOMPC_DYN_CIDX[c % NCD]] = (unsigned short)(0x8000u | (unsigned)c);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      unsigned ent[16];
+      {
+        const int rc = l32 < NW ? l32 : 0;
+        const int pt = point_of_slot(rc / NX);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          const int d = (b < NA) ? MOH_H0 + symi(rc % NX, b, NA) : NX + (rc % NX) * NA + NX + (b - NA < NU ? b - NA : 0);
+          const unsigned t = inv[d];
+          unsigned en = (unsigned)FE_POOL;                                   // 0.0
+          if (pt >= 0 && b < NA + NU && t != 0xffffu)
+            en = (t & 0x8000u) ? (unsigned)(FE_POOL + 1) + (t & 0x7fffu) : (unsigned)(EW_STAGE + pt * DOMPC_DYN_NV) + t;
+          ent[b] = en;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (h == 0) {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) tab[l32 * 16 + b] = (unsigned short)ent[b];
+      }
+      if (l32 <= DOMPC_DYN_NC) Ls[FE_POOL + l32] = (l32 == 0) ? 0.0 : DOMPC_DYN_CVAL[(l32 - 1) % NCD];      // (both halves: own pool)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // uniform data of the two edges of a pair, selected per half
+    struct EdgeU { int n, cn, row0, woff, uo; bool chain; };
+    auto edge_u = [&](int e) {
+      EdgeU u;
+      u.n = A.edge_parent[e]; u.cn = A.edge_child[e]; u.row0 = A.edge_row0[e]; u.woff = A.edge_w_off[e];
+      u.uo = A.node_u_off[u.n]; u.chain = A.edge_level[e] >= cl;
+      return u;
+    };
+    auto stage2 = [&](int ea, int eb) {          // both edges of a pair: forward record + compact model-output record (exact size: the pool stays)
+      const int es[2] = {ea, eb};
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const double* ew_ = Q.ew + (int64_t)es[k] * EW_SIZE;
+        const double* mo_ = Q.MO(es[k]);
+        ldsd* dst = Ld + FE_STG + k * FE_SS;
+#pragma unroll
+        for (int q = 0; q < EW_STAGE / 128; ++q)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ew_ + 128 * q + 2 * lane),
+                                           (__attribute__((address_space(3))) void*)(dst + 128 * q), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < (MOC_SIZE + 127) / 128; ++q)
+          if (128 * q + 2 * lane < MOC_SIZE)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mo_ + 128 * q + 2 * lane),
+                                             (__attribute__((address_space(3))) void*)(dst + EW_STAGE + 128 * q), 16, 0, 0);
+      }
+    };
+    auto load_dy2 = [&](const EdgeU& u, double& dy_, double& dnu_, double& cr_) {
+      const int a0 = l32 < NA ? l32 : 0;
+      dy_ = (a0 < NX) ? Q.ND(u.n)[ND_DXT + a0] : Q.dx[u.uo + a0 - NX];
+      dnu_ = Q.dlam[u.row0 + NW + (l32 < NX ? l32 : 0)];
+      cr_ = Q.c[u.row0 + (l32 < NW ? l32 : 0)];
+    };
+    auto pick = [&](const EdgeU& a, const EdgeU& b) {
+      EdgeU u;
+      u.n = h ? b.n : a.n; u.cn = h ? b.cn : a.cn; u.row0 = h ? b.row0 : a.row0; u.woff = h ? b.woff : a.woff;
+      u.uo = h ? b.uo : a.uo; u.chain = h ? b.chain : a.chain;
+      return u;
+    };
+    const int np = (A.n_edges + 1) / 2;
+    bool staged = false;
+    double dy0 = 0.0, dnu0 = 0.0, cr0 = 0.0;
+    for (int p_ = gid; p_ < np; p_ += ng) {
+      const int ea = 2 * p_, eb = (2 * p_ + 1 < A.n_edges) ? 2 * p_ + 1 : 2 * p_;
+      const bool on = (h == 0) || (2 * p_ + 1 < A.n_edges);      // (odd number of edges: the second half of the last pair repeats the edge and stores nothing)
+      const EdgeU U = pick(edge_u(ea), edge_u(eb));
+      const int e = h ? eb : ea;
+      const double* Nc = Q.ND(U.cn);
+      const int row0 = U.row0;
+      constexpr int LU1 = LU_N > 0 ? LU_N : 1;
+      constexpr int NU1 = NU > 0 ? NU : 1;
+      constexpr int ELR = (DEG + 1) * NX > 0 ? (DEG + 1) * NX : 1;
+      double hrow[NA], ju[NU1], rw_r, sg_r, inv_c[LU1], inv_r[LU1], c_r;
+      if (!staged) { stage2(ea, eb); load_dy2(U, dy0, dnu0, cr0); staged = true; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      {
+        const int r = l32, rc = r < NW ? r : 0;
+        rw_r = Ls[EW_RW + rc];
+        sg_r = Ls[EW_SIGW + rc];
+        const ldsu16_* tr = tab + l32 * 16;
+#pragma unroll
+        for (int b = 0; b < NA; ++b) hrow[b] = Ls[tr[b]];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) ju[u] = Ls[tr[NA + u]];
+        const int rl = r < LU_N ? r : 0;
+#pragma unroll
+        for (int k2 = 0; k2 < LU_N; ++k2) {
+          inv_c[k2] = Ls[EW_LU + k2 * LU_N + rl];
+          inv_r[k2] = Ls[EW_LU + rl * LU_N + k2];
+        }
+      }
+      double dy_n = 0.0, dnu_n = 0.0, cr_n = 0.0;
+      {
+        // everything of this pair is in registers: hand the staging buffers to the next pair of this wavefront
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int pn = p_ + ng;
+        if (pn < np) {
+          const int na = 2 * pn, nb = (2 * pn + 1 < A.n_edges) ? 2 * pn + 1 : 2 * pn;
+          stage2(na, nb);
+          load_dy2(pick(edge_u(na), edge_u(nb)), dy_n, dnu_n, cr_n);
+        }
+      }
+      if (l32 < NA) Lv[FE_DY + l32] = dy0;
+      if (U.chain && l32 < NX) Lv[FE_DNU + l32] = dnu0;
+      c_r = cr0;
+      if (!U.chain && l32 < NX) {
+        double t = Nc[ND_PV + l32];
+#pragma unroll
+        for (int b = 0; b < NA; ++b) t += Nc[ND_P + l32 * NA + b] * Nc[ND_DXT + b];
+        Lv[FE_DNU + l32] = t;
+        if (on) Q.dlam[row0 + NW + l32] = t;
+      }
+      T.gsync();
+      {
+        const int r = l32;
+        // g = G_y dy + r on the rows of the stored block
+        if (r < LU_N) {
+          const int i = r / ELR, rr = r % ELR, jj = rr / NX, a = rr % NX;
+          double t = c_r;
+          if (jj < DEG) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) t += ju[u] * Lv[FE_DY + NX + u];
+            if (i == 0) t -= tab_sel(DOMPC_C, jj + 1, DEG > 0 ? 1 : 0, DEG > 0 ? DEG : 1) * Lv[FE_DY + a];
+          } else if (i == 0) {
+            t -= DOMPC_D[0] * Lv[FE_DY + a];
+          }
+          Lv[FE_G + r] = t;
+        }
+        T.gsync();
+        // dw = -G_w^-1 g: the rows of the stored block ...
+        if (r < LU_N) {
+          double t = 0.0;
+#pragma unroll
+          for (int k2 = 0; k2 < LU_N; ++k2) t -= inv_r[k2] * Lv[FE_G + k2];
+          Lv[FE_DW + r] = t;
+          if (on) Q.dx[U.woff + r] = t;
+        }
+        // ... and the end-point rows from the continuity equation  dw_e = sum_s D_s dw_s + D_0 dx - r_e
+        T.gsync();
+        if (r >= LU_N && r < NW) {
+          const int a = r - LU_N;
+          double t = DOMPC_D[0] * Lv[FE_DY + a] - c_r;
+#pragma unroll
+          for (int s_ = 1; s_ <= DEG; ++s_) t += DOMPC_D[s_] * Lv[FE_DW + (s_ - 1) * NX + a];
+          Lv[FE_DW + r] = t;
+          if (on) Q.dx[U.woff + r] = t;
+        }
+        T.gsync();
+        // rhs = -(rw + (Sigma_w+delta) dw + Hww dw + Hwu du + S' dnu)
+        if (r < NW) {
+          const int sl = r / NX;
+          double t = rw_r + sg_r * Lv[FE_DW + r];
+          if (r >= (M - 1) * NX) t += Lv[FE_DNU + r - (M - 1) * NX];
+#pragma unroll
+          for (int b = 0; b < NX; ++b) t += hrow[b] * Lv[FE_DW + sl * NX + b];
+#pragma unroll
+          for (int b = 0; b < NU; ++b) t += hrow[NX + b] * Lv[FE_DY + NX + b];
+          Lv[FE_RHS + r] = -t;
+        }
+        T.gsync();
+        // d lambda = G_w^-T rhs   (G_w^-T = [[Gi', -Gi'E'], [0, I]])
+        if (r < NW) {
+          double t = 0.0;
+          if (r < LU_N) {
+#pragma unroll
+            for (int k2 = 0; k2 < LU_N; ++k2)
+              t += inv_c[k2] * (Lv[FE_RHS + k2] + DOMPC_D[k2 / NX + 1] * Lv[FE_RHS + LU_N + k2 % NX]);
+          } else {
+            t = Lv[FE_RHS + r];
+          }
+          if (on) Q.dlam[row0 + r] = t;
+        }
+      }
+      if (NE > 0) {
+        const double* S_ = Q.ES(e);
+        if (l32 < NE && on) {
+          const int i = l32;
+          double t = S_[ES_RDN + i];
+          for (int b = 0; b < NA; ++b) t += Q.EW(e, EW_JD + i * NA + b) * Lv[FE_DY + b];
+          if (!EPS_GLOBAL && nl_slack(i) >= 0) t -= Q.sgn[e * NE1 + i] * Q.dx[A.node_eps_off[U.n] + nl_slack(i)];
+          Q.ds[e * NE1 + i] = t;
+          Q.dlam[row0 + NW + NX + i] = (S_[ES_SIGS + i] + delta) * t + S_[ES_RSN + i];
+        }
+      }
+      T.gsync();
+      dy0 = dy_n; dnu0 = dnu_n; cr0 = cr_n;
+    }
+  } else
+#endif
+  {
   const MocMap mm = moc_map(lane, GS);
   if (MO_COMPACT && M > 0) mo_image_init(Ld + RF_IMG, lane, GS);
   int fw_staged = -1;                        // edge whose records are in (on their way into) the staging area
@@ -4145,6 +4370,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     T.gsync();
     dy0 = dy_n; dnu0 = dnu_n; cr0 = cr_n; have_pre = pre_n;
     DOMPC_PF(20)
+  }
   }
   // dummies (variables in no constraint / cost): independent scalar Newton steps
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
