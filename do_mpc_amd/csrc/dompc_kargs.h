@@ -5,6 +5,8 @@
 #include "../../include/dompc_ipm.h"
 
 namespace dompc {
+enum { EP_PARENT = 0, EP_CHILD, EP_LEVEL, EP_WOFF, EP_PIDX, EP_ROW0, EP_XOFF_PARENT, EP_UOFF_PARENT, EP_XOFF_CHILD, EP_EPSOFF_PARENT,
+       EP_OMEGA_LO, EP_OMEGA_HI, EP_N = 16 };
 // Structure tables of the problem class: written once by dompc_create(), never by a kernel.  In device code they are
 // pointers into the CONSTANT address space, which is what lets the compiler read them with scalar loads (s_load through
 // the scalar cache, result in SGPRs) wherever the index is wave-uniform - with plain global pointers every look-up is a
@@ -22,6 +24,9 @@ struct KArgs {
   itab_t edge_parent, edge_child, edge_pidx, edge_w_off, edge_row0, edge_level;
   dtab_t edge_omega;
   itab_t dummy_idx;
+  // the indices an edge needs, resolved and side by side (EP_N ints per edge, written by dompc_create from the tables above): one
+  // scalar load instead of seven look-ups of which three depend on the first - and one table pointer in registers instead of ten
+  itab_t edge_pack;
   int32_t N, n_nodes, n_edges, n_dummy, n_opt_x, n_opt_p, n_g, e_pad;
   int32_t p_off_tvp, p_off_p, p_off_uprev;
   int32_t chain_level;      // first stage from which every node has exactly one child of the same scenario index (= n_robust)

@@ -1937,16 +1937,34 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   const KArgs& A = *Q.A;
   const bool act = e >= 0;
   const int ee = act ? e : 0;
+#ifndef DOMPC_EDGE_PACK
+#define DOMPC_EDGE_PACK 1           // the indices of an edge from its packed record (KArgs::edge_pack); 0: from the separate tables
+#endif
+#if DOMPC_EDGE_PACK
+  const auto* ep = A.edge_pack + ee * EP_N;             // (the edge's indices side by side: one scalar load, dompc_kargs.h)
+  const int n = ep[EP_PARENT], cn = ep[EP_CHILD], k = ep[EP_LEVEL];
+  const double* xn = Q.x + ep[EP_XOFF_PARENT];
+  const double* un = Q.x + ep[EP_UOFF_PARENT];
+  const double* xc = Q.x + ep[EP_XOFF_CHILD];
+  const int woff = ep[EP_WOFF];
+  const int eps_off_n = ep[EP_EPSOFF_PARENT];
+  const double* pp = Q.P + A.p_off_p + ep[EP_PIDX] * NP;
+  const int row0 = ep[EP_ROW0];
+  const double om = __builtin_bit_cast(double, ((unsigned long long)(unsigned)ep[EP_OMEGA_HI] << 32) | (unsigned long long)(unsigned)ep[EP_OMEGA_LO]) * Q.sf;
+#else
   const int n = A.edge_parent[ee], cn = A.edge_child[ee], k = A.edge_level[ee];
   const double* xn = Q.x + A.node_x_off[n];
   const double* un = Q.x + A.node_u_off[n];
   const double* xc = Q.x + A.node_x_off[cn];
   const int woff = A.edge_w_off[ee];
-  const double* w = Q.x + woff;
+  const int eps_off_n = NSE > 0 ? A.node_eps_off[n] : 0;
   const double* pp = Q.P + A.p_off_p + A.edge_pidx[ee] * NP;
-  const double* tvp = Q.P + A.p_off_tvp + k * NTVP;
   const int row0 = A.edge_row0[ee];
   const double om = A.edge_omega[ee] * Q.sf;
+#endif
+  (void)eps_off_n;
+  const double* w = Q.x + woff;
+  const double* tvp = Q.P + A.p_off_tvp + k * NTVP;
   const double omh = (Q.soc & 2) ? 0.0 : om;          // weight of the objective HESSIANS (Prob::soc bit 1)
   const double* lam_e = Q.lam + row0;
   const double* nu_e = Q.lam + row0 + NW;
@@ -2607,7 +2625,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       if (k == A.N - 1) obj += PF ? om * pf_mt0 : om * mo[MO_MT];
       if (RT_CUSTOM) obj += Ld[EL_RT];
       if (NE > 0) {
-        const double* eps = (NSE > 0) ? Q.x + A.node_eps_off[n] : nullptr;
+        const double* eps = (NSE > 0) ? Q.x + eps_off_n : nullptr;
         for (int i = 0; i < NE; ++i) {
           double d = MOV(MO_NL + i);
           if (nl_slack(i) >= 0) d -= eps[nl_slack(i)];
@@ -3982,8 +4000,14 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     struct EdgeU { int n, cn, row0, woff, uo; bool chain; };
     auto edge_u = [&](int e) {
       EdgeU u;
+#if DOMPC_EDGE_PACK
+      const auto* ep = A.edge_pack + e * EP_N;
+      u.n = ep[EP_PARENT]; u.cn = ep[EP_CHILD]; u.row0 = ep[EP_ROW0]; u.woff = ep[EP_WOFF];
+      u.uo = ep[EP_UOFF_PARENT]; u.chain = ep[EP_LEVEL] >= cl;
+#else
       u.n = A.edge_parent[e]; u.cn = A.edge_child[e]; u.row0 = A.edge_row0[e]; u.woff = A.edge_w_off[e];
       u.uo = A.node_u_off[u.n]; u.chain = A.edge_level[e] >= cl;
+#endif
       return u;
     };
     auto stage2 = [&](int ea, int eb) {          // both edges of a pair: forward record + compact model-output record (exact size: the pool stays)

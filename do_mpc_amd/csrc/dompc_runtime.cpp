@@ -451,6 +451,21 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   rc |= upload(h, &A.edge_omega, d.edge_omega, d.n_edges);
   rc |= upload(h, &A.dummy_idx, d.dummy_idx, d.n_dummy);
   if (rc) return fail(1);
+  {
+    std::vector<int32_t> pack((size_t)d.n_edges * dompc::EP_N, 0);
+    for (int e = 0; e < d.n_edges; ++e) {
+      int32_t* q = pack.data() + (size_t)e * dompc::EP_N;
+      const int n = d.edge_parent[e], cn = d.edge_child[e];
+      q[dompc::EP_PARENT] = n; q[dompc::EP_CHILD] = cn; q[dompc::EP_LEVEL] = d.edge_level[e]; q[dompc::EP_WOFF] = d.edge_w_off[e];
+      q[dompc::EP_PIDX] = d.edge_pidx[e]; q[dompc::EP_ROW0] = d.edge_row0[e];
+      q[dompc::EP_XOFF_PARENT] = d.node_x_off[n]; q[dompc::EP_UOFF_PARENT] = d.node_u_off[n]; q[dompc::EP_XOFF_CHILD] = d.node_x_off[cn];
+      q[dompc::EP_EPSOFF_PARENT] = d.node_eps_off ? d.node_eps_off[n] : -1;
+      int64_t ob;
+      memcpy(&ob, &d.edge_omega[e], sizeof ob);
+      q[dompc::EP_OMEGA_LO] = (int32_t)(uint32_t)(ob & 0xffffffffll); q[dompc::EP_OMEGA_HI] = (int32_t)(uint32_t)((uint64_t)ob >> 32);
+    }
+    if (upload(h, &A.edge_pack, pack.data(), pack.size())) return fail(1);
+  }
   A.N = d.N; A.n_nodes = d.n_nodes; A.n_edges = d.n_edges; A.n_dummy = d.n_dummy;
   A.n_opt_x = d.n_opt_x; A.n_opt_p = d.n_opt_p; A.n_g = d.n_g; A.e_pad = h->e_pad;
   A.p_off_tvp = d.p_off_tvp; A.p_off_p = d.p_off_p; A.p_off_uprev = d.p_off_uprev;
