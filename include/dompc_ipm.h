@@ -157,7 +157,8 @@ int dompc_solve_batch_device(dompc_handle* h, int32_t B,
  * g(x), and per edge the linearised dynamics [A|B], c and the condensed Lagrangian-Hessian block.
  * DEVICE buffers: x [B][n_opt_x], lam [B][n_g], p [B][n_opt_p]; outputs g [B][n_g],
  * blocks [B][n_edges][dompc_sweep_block_doubles()] (may be NULL: the sweep runs, only g is copied out - the
- * sweep-only roofline of bench.py).  Used for roofline measurement and parity. */
+ * sweep-only roofline of bench.py).  Launched in the shape of dompc_solve_batch_device for the same B.
+ * Used for roofline measurement and parity. */
 int dompc_sweep_batch_device(dompc_handle* h, int32_t B,
                              const double* x, const double* lam, const double* p,
                              double* g, double* blocks, void* stream);
