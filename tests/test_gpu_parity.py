@@ -99,6 +99,14 @@ def test_same_iterates_as_the_oracle(name, opts):
     assert mpc.solver_stats["n_reg"] == mpc.solver_stats["iter_count"]
 
 
+@pytest.mark.parametrize("name,over", [("batch_reactor", dict(n_horizon=7)), ("CSTR", dict(n_horizon=5, n_robust=0))])
+def test_odd_number_of_edges_same_iterates_as_the_oracle(name, over):
+    """The forward pass takes two edges per wavefront: with an odd number of edges the second half of the last pair repeats an edge and
+    stores nothing (every shipped case has an even number); same iterations and solution as the oracle's solve of the same NLP"""
+    mpc = pc.check_same_iterates_as_oracle(make_mpc, name, **over)
+    assert mpc.structure.n_edges % 2 == 1
+
+
 @pytest.mark.parametrize("name,over", pc.NONCONVEX_CASES)
 def test_nonconvex_examples_reach_the_oracles_local_solution(name, over):
     """Second-order correction + inertia correction: same local minimum as the IPOPT-default oracle with exact inertia."""
