@@ -4093,6 +4093,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         Lv[FE_DNU + l32] = t;
         if (on) Q.dlam[row0 + NW + l32] = t;
       }
+      DOMPC_PF(17)
       T.gsync();
       {
         const int r = l32;
@@ -4129,6 +4130,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
           if (on) Q.dx[U.woff + r] = t;
         }
         T.gsync();
+        DOMPC_PF(18)
         // rhs = -(rw + (Sigma_w+delta) dw + Hww dw + Hwu du + S' dnu)
         if (r < NW) {
           const int sl = r / NX;
@@ -4141,6 +4143,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
           Lv[FE_RHS + r] = -t;
         }
         T.gsync();
+        DOMPC_PF(19)
         // d lambda = G_w^-T rhs   (G_w^-T = [[Gi', -Gi'E'], [0, I]])
         if (r < NW) {
           double t = 0.0;
@@ -4167,6 +4170,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       }
       T.gsync();
       dy0 = dy_n; dnu0 = dnu_n; cr0 = cr_n;
+      DOMPC_PF(20)
     }
   } else
 #endif
