@@ -346,6 +346,7 @@ def parse_args(argv=None):
                          "closed_loop: B closed loops (controller + GPU plant) resident in HBM, warm-started steps")
     ap.add_argument("--n-robust", type=int, default=5, help="--variant tree: depth of the branching part (3^n leaves)")
     ap.add_argument("--cut-level", type=int, default=0, help="--variant tree: level whose nodes are the sub-tree roots (0 = auto)")
+    ap.add_argument("--shard-one-rank", action="store_true", help="--variant tree on one GPU: run the sharded code path with world = 1 (all exchanges) instead of the whole-chip mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--no-b1", action="store_true", help="skip the single-problem make_step latency")
@@ -694,7 +695,10 @@ def bench_tree(args, ex, rank, world, local_rank, dist):
     n_scen = ps.scenario_tree["n_scenarios"]
     # cut where there are at least 3 sub-trees per rank (balance: 27 sub-trees over 8 ranks = 4/3 per rank)
     cut = args.cut_level or next((k for k in range(1, ps.n_robust + 1) if n_scen[k] >= 3 * world), ps.n_robust)
-    info = mpc.shard_tree(rank, world, cut_level=cut)
+    # one GPU: nothing to shard - the problem runs on the plain code object, its workgroups spread over the whole chip (round 5:
+    # KArgs::wide_spread; --shard-one-rank runs the sharded code path with world = 1 instead, exchanges served and counted)
+    sharded = world > 1 or args.shard_one_rank
+    info = mpc.shard_tree(rank, world, cut_level=cut) if sharded else {"cut_level": 0, "n_cut": 0}
     t_step = []
     iters = []
     n_xchg = []
@@ -728,9 +732,11 @@ def bench_tree(args, ex, rank, world, local_rank, dist):
             "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"industrial_poly robust multi-stage NMPC, ONE problem, {ps.S}-leaf scenario tree "
-                                   f"(3 combos x n_robust={args.n_robust}, N=20, Radau deg 2), tree sharded over the ranks",
+                                   f"(3 combos x n_robust={args.n_robust}, N=20, Radau deg 2)" + (", tree sharded over the ranks" if sharded else ""),
                        "n_opt_x": ps.n_opt_x, "n_g": ps.n_g, "edges": ps.n_edges, "cut_level": info["cut_level"],
-                       "cut_parents": info["n_cut"], "start": "cold", "parallelism": f"scenario sub-trees x{world}, RCCL all-reduce"},
+                       "cut_parents": info["n_cut"], "start": "cold",
+                       "parallelism": f"scenario sub-trees x{world}, RCCL all-reduce" if sharded else
+                                      "one GPU, not sharded: the workgroups of the problem spread over all XCDs (whole-chip wide mode)"},
             "solve": {"converged": bool(ok), "iters_mean": float(np.mean(iters)), "u0": [float(v) for v in np.ravel(u0)],
                       "exchanges_per_solve": float(np.mean(n_xchg)), "exchanges_per_iteration": float(np.mean(n_xchg) / max(np.mean(iters), 1.0))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",

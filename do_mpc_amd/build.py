@@ -147,7 +147,7 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
             return out
         if not (os.path.exists(hdr) and open(hdr).read() == header_text):
             _write_atomic(hdr, header_text)
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_LB={lb}", f"-DDOMPC_PROFILE={prof}", *[(d if d.startswith("-") else f"-D{d}") for d in defs],
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_SRC_DIGEST=0x{_sources_digest()}ULL", f"-DDOMPC_LB={lb}", f"-DDOMPC_PROFILE={prof}", *[(d if d.startswith("-") else f"-D{d}") for d in defs],
                f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC, os.path.join(CSRC, "dompc_device.hip")]
         _compile_to(cmd, out, f"lowering model {model_hash} to {ARCH}")
         _write_atomic(stamp, dig)

@@ -98,7 +98,7 @@ class BatchClosedLoop:
         self.k += 1
         torch.cuda.synchronize()
         st = np.frombuffer(self.stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
-        return {"stats": st, "plant_status": (self.pstat.cpu().numpy() & 0xFF), "u0": self.U.cpu().numpy(), "x": self.X.cpu().numpy()}
+        return {"stats": st, "plant_status": (self.pstat.cpu().numpy() & 1), "plant_implicit": ((self.pstat.cpu().numpy() >> 1) & 1), "u0": self.U.cpu().numpy(), "x": self.X.cpu().numpy()}
 
 
 class BatchClosedLoopMHE:
@@ -251,5 +251,5 @@ class BatchClosedLoopMHE:
         torch.cuda.synchronize()
         cs = np.frombuffer(self.c_stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
         est = np.frombuffer(self.e_stats.cpu().numpy().tobytes(), dtype=STATS_DTYPE).copy()
-        return {"mpc_stats": cs, "mhe_stats": est, "plant_status": (self.pstat.cpu().numpy() & 0xFF), "u0": self.U.cpu().numpy(),
+        return {"mpc_stats": cs, "mhe_stats": est, "plant_status": (self.pstat.cpu().numpy() & 1), "plant_implicit": ((self.pstat.cpu().numpy() >> 1) & 1), "u0": self.U.cpu().numpy(),
                 "x_true": self.X.cpu().numpy(), "y": self.Y.cpu().numpy(), "x_est": self.x_est.cpu().numpy(), "p_est": self.p_est.cpu().numpy()}

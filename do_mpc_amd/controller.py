@@ -23,7 +23,7 @@ from typing import Callable, Dict, List, Optional, Union
 
 import numpy as np
 
-from . import lowering, sym
+from . import lowering, nlp_route, sym
 from .model import Model, VarGroup
 from .solver import HipIpmSolver
 from .structs import Entry, Layout, NumStruct
@@ -513,13 +513,19 @@ class MPC:
         self.lb_opt_x = _Indexed(lambda i: self._lb_opt_x[i], lambda i, v: self._set_opt_bound(self._lb_opt_x, i, v))
         self.ub_opt_x = _Indexed(lambda i: self._ub_opt_x[i], lambda i, v: self._set_opt_bound(self._ub_opt_x, i, v))
         self._update_bounds()
-        self._nlp_cons_lb = np.zeros(ps.n_g)
-        self._nlp_cons_ub = np.zeros(ps.n_g)
+        g_lb, g_ub = np.zeros(ps.n_g), np.zeros(ps.n_g)
         if ps.ne:
             for e in range(ps.n_edges):
                 r0 = ps.tables["edge_row0"][e] + ps.rows_block + ps.nx
-                self._nlp_cons_lb[r0:r0 + ps.ne] = np.tile(self._nl_cons_lb, n_eval)
-                self._nlp_cons_ub[r0:r0 + ps.ne] = np.tile(self._nl_cons_ub, n_eval)
+                g_lb[r0:r0 + ps.ne] = np.tile(self._nl_cons_lb, n_eval)
+                g_ub[r0:r0 + ps.ne] = np.tile(self._nl_cons_ub, n_eval)
+        # the low-level route prepare_nlp -> modify -> create_nlp (optimizer.py:82-215): until create_nlp these are LISTS with one entry
+        # per constraint block - here the structured block of n_g rows first, user additions behind it (nlp_route.py)
+        self._nlp_obj = nlp_route.NlpObjective()
+        self._nlp_cons = [nlp_route.StructuredBlock("constraints", ps.n_g)]
+        self._nlp_cons_lb = [g_lb]
+        self._nlp_cons_ub = [g_ub]
+        self._opt_x_sym = self._opt_p_sym = self._opt_x_unscaled_sym = self._aux_struct = None
         self._opt_x_num = NumStruct(self._opt_x_layout, 0.0)
         self.opt_x_num_unscaled = NumStruct(self._opt_x_layout, 0.0)
         self._opt_p_num = NumStruct(self._opt_p_layout, 0.0)
@@ -531,6 +537,98 @@ class MPC:
 
     opt_x_num = property(lambda self: self._opt_x_num)
     opt_p_num = property(lambda self: self._opt_p_num)
+
+    # ---- symbolic side of the NLP (_mpc.py:323-405, optimizer.py:82-215): created on first use
+    def _need_prepared(self):
+        assert self.flags["prepare_nlp"], "Cannot query attribute prior to calling MPC.prepare_nlp or MPC.setup"
+
+    @property
+    def opt_x(self):
+        """Symbolic struct of the optimisation variables in the reference's layout and (scaled) units: `opt_x['_x', k, s, i]`,
+        `opt_x['_u', k, s]`, `opt_x['_z', k, s, i]`, `opt_x['_eps', k, s]` (_mpc.py:323-372)."""
+        self._need_prepared()
+        if self._opt_x_sym is None:
+            self._opt_x_sym = nlp_route.OptSymStruct(self._opt_x_layout, "opt_x")
+        return self._opt_x_sym
+
+    @property
+    def opt_p(self):
+        """Symbolic struct of the NLP parameters `[_x0 | _tvp | _p | _u_prev]` (_mpc.py:375-405)."""
+        self._need_prepared()
+        if self._opt_p_sym is None:
+            self._opt_p_sym = nlp_route.OptSymStruct(self._opt_p_layout, "opt_p")
+        return self._opt_p_sym
+
+    @property
+    def opt_x_unscaled(self):
+        """opt_x in physical units: `opt_x(opt_x.cat * opt_x_scaling)` (_mpc.py:1157); a list-of-vectors view like opt_x"""
+        self._need_prepared()
+        if self._opt_x_unscaled_sym is None:
+            ox = self.opt_x
+            st = nlp_route.OptSymStruct.__new__(nlp_route.OptSymStruct)
+            st.layout, st.prefix = ox.layout, "opt_x_unscaled"
+            st.vec = ox.vec * sym.SX(list(self.opt_x_scaling.master), (ox.layout.size, 1))
+            st.index_of = {}
+            self._opt_x_unscaled_sym = st
+        return self._opt_x_unscaled_sym
+
+    @property
+    def aux_struct(self):
+        """Symbolic struct of the auxiliary expressions over the horizon, `aux_struct['_aux', k, s]` (_mpc.py:1171-1175;
+        data.py:463 stores it as `data.opt_aux`)."""
+        self._need_prepared()
+        if self._aux_struct is None:
+            self._aux_struct = nlp_route.OptSymStruct(self._opt_aux_layout, "opt_aux")
+        return self._aux_struct
+
+    @property
+    def nlp_obj(self):
+        """Handle on the NLP objective (optimizer.py:82-117).  `mpc.nlp_obj += expr` records an added term; create_nlp() lowers it
+        or refuses it by name (nlp_route.check_additions)."""
+        self._need_prepared()
+        return self._nlp_obj
+
+    @nlp_obj.setter
+    def nlp_obj(self, val):
+        self._need_prepared()
+        assert not self.flags["setup"], "Cannot change attribute after calling MPC.create_nlp or MPC.setup"
+        self._nlp_obj = val
+
+    @property
+    def nlp_cons(self):
+        """Before create_nlp(): list of constraint blocks - the structured block (n_g rows, reference order) first; append symbolic
+        expressions over opt_x / opt_p together with nlp_cons_lb / nlp_cons_ub entries (optimizer.py:119-169).  Afterwards: the
+        concatenation."""
+        self._need_prepared()
+        return self._nlp_cons
+
+    @nlp_cons.setter
+    def nlp_cons(self, val):
+        self._need_prepared()
+        assert not self.flags["setup"], "Cannot change attribute after calling create_nlp or setup"
+        self._nlp_cons = val
+
+    @property
+    def nlp_cons_lb(self):
+        """lower bounds matching nlp_cons: a list of arrays before create_nlp(), their concatenation afterwards (optimizer.py:172-192)"""
+        self._need_prepared()
+        return self._nlp_cons_lb
+
+    @nlp_cons_lb.setter
+    def nlp_cons_lb(self, val):
+        self._need_prepared()
+        self._nlp_cons_lb = val
+
+    @property
+    def nlp_cons_ub(self):
+        """upper bounds matching nlp_cons (optimizer.py:194-215)"""
+        self._need_prepared()
+        return self._nlp_cons_ub
+
+    @nlp_cons_ub.setter
+    def nlp_cons_ub(self, val):
+        self._need_prepared()
+        self._nlp_cons_ub = val
 
     def _set_opt_bound(self, st: NumStruct, ind, val):
         st[ind] = val
@@ -591,6 +689,13 @@ class MPC:
 
     def create_nlp(self, _solver_factory=None) -> None:
         assert self.flags["prepare_nlp"], "call prepare_nlp() first"
+        if isinstance(self._nlp_cons_lb, list):
+            # the low-level route (optimizer.py:1050-1094, _mpc.py:1303-1310): what the user added after prepare_nlp() is lowered or
+            # refused by name; afterwards the attributes are the concatenations, as in the reference
+            nlp_route.check_additions(self)
+            self._nlp_cons_lb = np.ascontiguousarray(np.asarray(self._nlp_cons_lb[0], dtype=float).reshape(-1))
+            self._nlp_cons_ub = np.ascontiguousarray(np.asarray(self._nlp_cons_ub[0], dtype=float).reshape(-1))
+            self._nlp_cons = self._nlp_cons[0]
         if self.structure.open_loop_stack:
             # open_loop with several scenarios: not tree-structured - a chain over the stacked scenario states, behind the same callable
             from . import open_loop

@@ -68,7 +68,11 @@ struct KArgs {
   // loop: the kernel publishes a request (sequence number, element count) in pinned host memory and polls the
   // acknowledge word; the host runs the collective on the buffer in between.  Host emulation: direct callback.
   double* xbuf;
-  int32_t xbuf_len, xpad;
+  int32_t xbuf_len;
+  // wide mode, whole-chip placement: the K workgroups of problem slot s are the blocks s*K .. s*K + K - 1 - spread over ALL XCDs by the
+  // dispatcher (block b on XCD b % 8) - instead of K blocks of one XCD; one large problem (a 243-leaf tree) then uses every CU of the chip.
+  // The barrier notices the placement by itself (xcd_census) and keeps its L2 write-back.
+  int32_t wide_spread;
   volatile uint32_t* x_req;
   volatile uint32_t* x_ack;
   volatile uint32_t* x_count;

@@ -416,13 +416,14 @@ __shared__ long long lds_prof[32];
 __device__ inline int slot_of_block(const KArgs& A) {
   const bool wide = (A.mode == 0 && A.wide > 1);
   const int q = blockIdx.x / 8;
+  if (wide && A.wide_spread) return (int)blockIdx.x / A.wide;      // whole-chip placement: the K workgroups of a problem are consecutive blocks (all XCDs)
   return wide ? (q / A.wide) * 8 + (int)(blockIdx.x % 8) : (int)blockIdx.x;
 }
 __device__ inline Thr make_thr(const KArgs& A) {
   const bool wide = WIDE_OK && (A.mode == 0 && A.wide > 1);
   const int K = wide ? A.wide : 1;
   const int q = blockIdx.x / 8;
-  const int j = wide ? q % K : 0;
+  const int j = wide ? (A.wide_spread ? (int)blockIdx.x % K : q % K) : 0;
   const int slot = slot_of_block(A);
   return Thr{j * DOMPC_BDIM + (int)threadIdx.x, K * DOMPC_BDIM, (ldsd*)lds_pool, (ldsd*)lds_filt,
              wide ? A.wide_flags + slot * 8 : lds_flags, (ldsd*)lds_pool, lds_prof, 64,
@@ -5476,7 +5477,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     if (!dir_ok) { if (in_wd) { wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; }
     if (delta > 0.0) { delta_last = delta; ++n_reg; }
     c_t = prof_clock();
-    if (EPS_GLOBAL) { if (epsg_apply(delta, Q.dlam_e)) { status = 3; break; } }
+    if (EPS_GLOBAL) { if (epsg_apply(delta, Q.dlam_e)) { if (in_wd) { wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; } }
     else run_forward(T, Q, b, slot, mu, delta);
     c_fwd += prof_clock() - c_t;
 
@@ -5627,7 +5628,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       alpha *= 0.5;
       ++n_ls;
     }
-    if (bad) { status = 3; break; }
+    if (bad) { if (in_wd) { bad = 0; wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; }      // (same rule as at the top of the loop)
     if (!accepted && stale) eval_trial(alpha, obj_t, th_t, bar_t);
     if (!wd_done) wd_count = n_ls > 0 ? wd_count + 1 : 0;         // consecutive iterations with a shortened step
     if (!accepted) {

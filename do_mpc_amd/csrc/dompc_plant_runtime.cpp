@@ -31,7 +31,9 @@ struct dompc_plant {
   int32_t method = 0, explicit_limit = 4000;
   std::vector<double> z0;               // Newton start of the algebraic states (dompc_plant_set_z0; zeros by default)
   double* z_dev = nullptr;              // [z_cap][nz]: per-sample start values, carried from call to call
-  int32_t z_cap = 0;
+  int32_t z_cap = 0, z_alloc = 0;       // rows with valid start values / rows allocated
+  bool z_carry_host = false;            // host entry (dompc_plant_step_batch): rows of consecutive calls are the same trajectories (dompc_plant_set_z_carry)
+  bool z_reseed_next = false;
 #ifndef DOMPC_HOST_EMU
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr, fn_info = nullptr;
@@ -152,16 +154,22 @@ extern "C" int dompc_plant_set_z0(dompc_plant* h, const double* z0) {
   return 0;
 }
 
-// per-sample start values of the algebraic states for B samples: seeded with z0 when the buffer is (re)created
-static int ensure_z(dompc_plant* h, int32_t B) {
-  if (h->nz <= 0 || B <= h->z_cap) return 0;
-  if (h->z_dev) {
-    for (size_t i = 0; i < h->allocs.size(); ++i)
-      if (h->allocs[i] == h->z_dev) { h->allocs.erase(h->allocs.begin() + i); pfree(h->z_dev); break; }
-    h->z_dev = nullptr;
+// per-sample start values of the algebraic states for B samples: seeded with z0 when the buffer is (re)created, when it grows, and on
+// request (`reseed`).  Row b of the buffer belongs to sample b of the CALLS: carried values only make sense when the rows of consecutive
+// calls are the same trajectories (the device closed loops, Simulator.make_step); a host call on unrelated samples reseeds.
+static int ensure_z(dompc_plant* h, int32_t B, bool reseed) {
+  if (h->nz <= 0) return 0;
+  if (B <= h->z_cap && !reseed) return 0;
+  if (B > h->z_alloc) {
+    if (h->z_dev) {
+      for (size_t i = 0; i < h->allocs.size(); ++i)
+        if (h->allocs[i] == h->z_dev) { h->allocs.erase(h->allocs.begin() + i); pfree(h->z_dev); break; }
+      h->z_dev = nullptr;
+    }
+    h->z_cap = 0; h->z_alloc = 0;
+    if (palloc(h, (void**)&h->z_dev, sizeof(double) * (size_t)B * h->nz)) return 1;
+    h->z_alloc = B;
   }
-  h->z_cap = 0;
-  if (palloc(h, (void**)&h->z_dev, sizeof(double) * (size_t)B * h->nz)) return 1;
   std::vector<double> seed((size_t)B * h->nz);
   for (int32_t b = 0; b < B; ++b)
     for (int i = 0; i < h->nz; ++i) seed[(size_t)b * h->nz + i] = h->z0[(size_t)i];
@@ -171,6 +179,12 @@ static int ensure_z(dompc_plant* h, int32_t B) {
   memcpy(h->z_dev, seed.data(), seed.size() * sizeof(double));
 #endif
   h->z_cap = B;
+  return 0;
+}
+
+extern "C" int dompc_plant_set_z_carry(dompc_plant* h, int32_t on) {
+  if (!h) return 1;
+  h->z_carry_host = on != 0;
   return 0;
 }
 
@@ -207,7 +221,8 @@ extern "C" int dompc_plant_step_batch_device(dompc_plant* h, int32_t B, const do
 #ifndef DOMPC_HOST_EMU
   PHIP(h, hipSetDevice(d.device));
 #endif
-  if (ensure_z(h, B)) return 1;
+  if (ensure_z(h, B, h->z_reseed_next)) return 1;
+  h->z_reseed_next = false;
   dompc_plantk::Args A;
   memset(&A, 0, sizeof(A));
   A.x = x; A.u = u; A.tvp = tvp; A.p = p; A.w = w; A.v = v; A.x_next = x_next; A.y = y; A.status = status;
@@ -269,6 +284,7 @@ extern "C" int dompc_plant_step_batch(dompc_plant* h, int32_t B, const double* x
   if (up(h->s_x, x, D * B * d.nx) || up(h->s_u, u, D * rows(1) * d.nu) || up(h->s_tvp, tvp, D * rows(2) * d.ntvp) ||
       up(h->s_p, p, D * rows(4) * d.np) || up(h->s_w, w, D * rows(8) * d.nw) || up(h->s_v, v, D * rows(16) * d.nv))
     return 1;
+  h->z_reseed_next = !h->z_carry_host;       // unrelated samples per call unless the caller says the rows are the same trajectories
   if (dompc_plant_step_batch_device(h, B, h->s_x, h->s_u, h->s_tvp, h->s_p, w ? h->s_w : nullptr, v ? h->s_v : nullptr, shared_mask,
                                     h->s_xn, y ? h->s_y : nullptr, h->s_st, st))
     return 1;

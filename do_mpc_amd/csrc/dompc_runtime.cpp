@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <cmath>
 #include <string>
 #include <thread>
 #include <vector>
@@ -34,6 +35,7 @@ struct dompc_handle {
   std::string error;
   std::string code_path;
   int32_t e_pad = 0, n_slots = 0, block = 256, occupancy = 0;
+  bool batch_object_stale = false;       // a `_batch` sibling exists but was built from other sources / another model: not used
   bool block_auto = true;          // threads per problem chosen per call from the batch size
   int32_t slots64 = 0, slots256 = 0;   // resident workgroups at 64 / 256 threads
   int64_t ws_stride = 0, sweep_block = 0, el_size = 0;
@@ -366,18 +368,40 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   int64_t info[20] = {0};
   char hash[64] = {0};
 #ifndef DOMPC_HOST_EMU
-  {
+  auto query_info = [&](hipFunction_t fn, int64_t* info_o, char* hash_o) -> int {
     int32_t* in_d; int64_t* out_d; char* hash_d;
     if (dev_alloc(h, (void**)&in_d, sizeof(in_h)) || dev_alloc(h, (void**)&out_d, sizeof(info)) ||
-        dev_alloc(h, (void**)&hash_d, sizeof(hash))) return fail(1);
-    if (h2d(h, in_d, in_h, sizeof(in_h))) return fail(1);
+        dev_alloc(h, (void**)&hash_d, sizeof(hash))) return 1;
+    if (h2d(h, in_d, in_h, sizeof(in_h))) return 1;
+    if (dev_zero(h, out_d, sizeof(info), h->stream)) return 1;
     struct { const int32_t* a; int64_t* b; char* c; } args = {in_d, out_d, hash_d};
     size_t sz = sizeof(args);
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    if (hipModuleLaunchKernel(h->fn_info, 1, 1, 1, 64, 1, 1, 0, h->stream, nullptr, cfg) != hipSuccess) {
-      h->error = "launch of dompc_model_info_kernel failed"; return fail(1);
+    if (hipModuleLaunchKernel(fn, 1, 1, 1, 64, 1, 1, 0, h->stream, nullptr, cfg) != hipSuccess) {
+      h->error = "launch of dompc_model_info_kernel failed"; return 1;
     }
-    if (d2h(h, info, out_d, sizeof(info)) || d2h(h, hash, hash_d, sizeof(hash)) || dev_sync(h)) return fail(1);
+    if (d2h(h, info_o, out_d, sizeof(info)) || d2h(h, hash_o, hash_d, sizeof(hash)) || dev_sync(h)) return 1;
+    return 0;
+  };
+  if (query_info(h->fn_info, info, hash)) return fail(1);
+  if (h->fn_solve_batch) {
+    // The sibling is only ever launched with the general object's argument block and workspace layout: it must come from the same
+    // sources and the same model (a handle with a small max_batch rebuilds only the general object after a kernel change;
+    // a stale sibling with another KArgs layout would then be launched for every 64-thread batch).  A sibling that does not match is
+    // not used - the general object runs those launches instead.
+    int64_t info_b[20] = {0};
+    char hash_b[64] = {0};
+    hipFunction_t fn_info_b = nullptr;
+    bool same = hipModuleGetFunction(&fn_info_b, h->module_batch, "dompc_model_info_kernel") == hipSuccess && !query_info(fn_info_b, info_b, hash_b);
+    for (int i = 0; same && i < 19; ++i) same = info_b[i] == info[i];
+    same = same && strncmp(hash, hash_b, 63) == 0;
+    if (!same) {
+      hipModuleUnload(h->module_batch);
+      h->module_batch = nullptr;
+      h->fn_solve_batch = nullptr;
+      h->batch_object_stale = true;
+      h->error.clear();
+    }
   }
 #else
   dompc_hostemu_model_info(in_h, info, hash);
@@ -706,6 +730,14 @@ static int serve_exchanges(dompc_handle* h, hipStream_t st) {
 
 extern "C" int64_t dompc_last_exchange_count(const dompc_handle* h) { return h ? h->n_exchanges : 0; }
 
+extern "C" int dompc_batch_object_state(const dompc_handle* h) {
+  if (!h) return -1;
+#ifndef DOMPC_HOST_EMU
+  if (h->fn_solve_batch) return 1;
+#endif
+  return h->batch_object_stale ? 2 : 0;
+}
+
 extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double* x0, const double* lbx, const double* ubx,
                                         const double* lbg, const double* ubg, const double* p, double* x, double* g,
                                         double* lam_x, double* lam_g, double* f, dompc_stats* stats, void* stream) {
@@ -723,6 +755,7 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   const int cap = (h->block_auto && block != 64 && h->slots256 < h->n_slots) ? h->slots256 : h->n_slots;   // resident workgroups at this block size
   int grid = B < cap ? B : cap;
   A.wide = 1;
+  A.wide_spread = 0;
   if (h->sharded) {
     if (B != 1) { h->error = "a sharded handle solves one problem per call"; return 1; }
 #ifndef DOMPC_HOST_EMU
@@ -738,10 +771,28 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   //  CSTR 9.1 / - / 8.3 / 10.2 ms - the device-scope barriers grow with K faster than the phases shrink)
   int K = wenv ? atoi(wenv) : (B <= 8 ? 16 : (B <= 32 ? 8 : (B <= 64 ? 4 : 1)));
   if (!wenv && K > h->d.n_edges / 8) K = h->d.n_edges / 8 > 1 ? h->d.n_edges / 8 : 1;
-  if (K > 32) K = 32;
+  // Whole-chip placement (KArgs::wide_spread): the K workgroups of a problem are consecutive blocks, which the dispatcher spreads over
+  // all XCDs, instead of K blocks of ONE XCD (<= 32 CUs); the device-scope barrier then keeps its L2 write-back (xcd_census sees the
+  // placement).  One problem alone always runs this way: measured on MI355X (tools/gpu_wide_spread.py, profiles/r05_wide_spread.txt) the
+  // 243-leaf tree of BASELINE configs[4] (4 008 edges) takes 72.3 ms with K = 32 on one XCD, 67.4 ms with the same K spread and
+  // 49.7 / 48.9 / 49.3 / 55.6 / 63.8 ms with K = 64 / 96 / 128 / 192 / 256; the shipped 9-scenario problem (180 edges) 19.1 ms with 16
+  // workgroups of one XCD and 18.2 / 18.0 / 18.8 ms with 16 / 24 / 32 spread - the barriers grow with K, the phases shrink with
+  // sqrt-like returns: K ~ 12 sqrt(edges / 45).  DOMPC_WIDE_SPREAD=0/1 and DOMPC_WIDE override.
+  const char* senv = getenv("DOMPC_WIDE_SPREAD");
+  bool spread = senv ? atoi(senv) != 0 : (!h->sharded && (B == 1 || (B <= 4 && h->d.n_edges >= 2048)));
+  if (spread && !wenv) {
+    K = 8 * (int)lround(1.5 * sqrt((double)h->d.n_edges / 45.0));
+    if (K > h->d.n_edges / 8) K = h->d.n_edges / 8;
+    if (K > 256 / B) K = 256 / B;
+    if (K < 1) K = 1;
+  }
+  if (K > (spread ? 256 : 32)) K = spread ? 256 : 32;
+  if (spread && (int64_t)B * K > 2048) spread = false;       // (reduction partials: 64 x 32 workgroup rows)
+  if (!spread && K > 32) K = 32;
   if (K > 1 && B <= 64 && B <= h->n_slots) {
     A.wide = K;
-    grid = ((B + 7) / 8) * 8 * K;
+    A.wide_spread = spread ? 1 : 0;
+    grid = spread ? B * K : ((B + 7) / 8) * 8 * K;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(h, hipMemsetAsync(A.wide_bar, 0, sizeof(uint32_t) * 16 * 64, st));
     HIPCHK(h, hipMemsetAsync(A.wide_flags, 0, sizeof(int32_t) * 8 * 64, st));

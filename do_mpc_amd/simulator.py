@@ -65,6 +65,8 @@ def _bind(lib_path: str) -> C.CDLL:
     lib.dompc_plant_set_method.restype = C.c_int
     lib.dompc_plant_set_z0.argtypes = [vp, vp]
     lib.dompc_plant_set_z0.restype = C.c_int
+    lib.dompc_plant_set_z_carry.argtypes = [vp, C.c_int32]
+    lib.dompc_plant_set_z_carry.restype = C.c_int
     lib.dompc_plant_num_alg_states.argtypes = [vp]
     lib.dompc_plant_num_alg_states.restype = C.c_int32
     return lib
@@ -248,9 +250,12 @@ class Simulator:
         self._z0.master[:] = z
         return z
 
-    def make_step_batch(self, X, U=None, P=None, TVP=None, W=None, V=None) -> dict:
+    def make_step_batch(self, X, U=None, P=None, TVP=None, W=None, V=None, carry_z: bool = False) -> dict:
         """Advance B samples by one control interval.  X: [B][nx]; U, P, TVP, W, V: [B][n] or one row shared by all
-        samples (P / TVP default to p_fun(t0) / tvp_fun(t0)).  Returns {'x', 'y', 'status', 'n_steps'}."""
+        samples (P / TVP default to p_fun(t0) / tvp_fun(t0)).  Returns {'x', 'y', 'status', 'n_steps'}; status bit 0: the integration
+        did not reach t_step (failure), bit 1: the implicit method produced the result (no failure).
+        DAE plants: the Newton iteration for the algebraic states of every sample starts from `simulator.z0` - unless `carry_z`, which
+        says that row b of this call continues the trajectory of row b of the previous call (then from the values found there)."""
         assert self.flags["setup"], "Simulator is not setup. Call simulator.setup() first."
         m = self.model
         X = np.ascontiguousarray(np.asarray(X, dtype=np.float64)).reshape(-1, m.n_x)
@@ -266,6 +271,7 @@ class Simulator:
         y = np.empty((B, max(m.n_y, 1)))
         status = np.zeros(B, dtype=np.int32)
         ptr = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+        self._lib.dompc_plant_set_z_carry(self._h, 1 if carry_z else 0)
         rc = self._lib.dompc_plant_step_batch(self._h, B, ptr(X), ptr(u), ptr(tvp), ptr(p), ptr(w), ptr(v), mask,
                                               ptr(xn), ptr(y), ptr(status))
         if rc != 0:
@@ -296,8 +302,8 @@ class Simulator:
         tvp0 = _flat_struct(self.tvp_fun(t0), m.n_tvp)
         r = self.make_step_batch(self._x0.master[None, :], U=u0.reshape(-1), P=p0, TVP=tvp0,
                                  W=None if w0 is None else np.asarray(w0, float).reshape(-1),
-                                 V=None if v0 is None else np.asarray(v0, float).reshape(-1))
-        if r["status"][0] != 0:
+                                 V=None if v0 is None else np.asarray(v0, float).reshape(-1), carry_z=True)       # (one trajectory)
+        if int(r["status"][0]) & 1:          # bit 0: failure; bit 1 only says that the implicit SDIRK method produced the result
             raise RuntimeError("plant integration did not reach t_step (step limit or NaN right-hand side)")
         # records of the step: state BEFORE the step, the inputs and parameters it used, the new measurement (simulator.py:833-841)
         z0 = self._host_z(self._x0.master, u0.reshape(-1), tvp0, p0)      # (records only: the kernel solves for z itself)

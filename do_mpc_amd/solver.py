@@ -125,6 +125,8 @@ def _load(lib_path: str) -> C.CDLL:
     lib.dompc_set_sharding.restype = C.c_int
     lib.dompc_last_exchange_count.argtypes = [vp]
     lib.dompc_last_exchange_count.restype = C.c_int64
+    lib.dompc_batch_object_state.argtypes = [vp]
+    lib.dompc_batch_object_state.restype = C.c_int
     lib.dompc_rccl_unique_id.argtypes = [vp, C.c_char_p, vp]
     lib.dompc_rccl_unique_id.restype = C.c_int
     lib.dompc_rccl_init.argtypes = [vp, C.c_char_p, vp, C.c_int32, C.c_int32]
@@ -169,7 +171,9 @@ class HipIpmSolver:
                     pass
             _lib_path = build.runtime_library()
             _code_object = build.model_code_object(header_text, model_hash, shard=bool(shard))
-            if not shard and (int(max_batch) >= 4096 or int(block_threads) == 64) and not os.environ.get("DOMPC_CODE_OBJECT"):
+            sibling = _code_object[:-len(".hsaco")] + "_batch.hsaco"
+            # (a sibling left behind by an earlier handle is refreshed with the general object: the runtime launches whatever lies there)
+            if not shard and (int(max_batch) >= 4096 or int(block_threads) == 64 or os.path.exists(sibling)) and not os.environ.get("DOMPC_CODE_OBJECT"):
                 # handles that solve large batches (one wavefront per problem from B = 4096 on) also get the build of the kernels that is
                 # compiled for exactly that launch shape: the runtime finds it next to the general object
                 build.model_code_object(header_text, model_hash, batch_only=True)
@@ -218,6 +222,12 @@ class HipIpmSolver:
         if rc != 0:
             raise RuntimeError("dompc_create failed: " + (self._lib.dompc_last_error(None) or b"?").decode())
         self._h = h
+        # 0: no launch-shape-specific sibling code object, 1: loaded, 2: found but stale (other sources / model) and therefore not used
+        self.batch_object_state = int(self._lib.dompc_batch_object_state(h))
+        if self.batch_object_state == 2:
+            import warnings
+            warnings.warn("dompc: the `_batch` code object next to %s was built from other sources and is not used "
+                          "(one-wavefront batches run the general code object)" % (_code_object,))
         self._stats: Dict = {}
         self._device = device
         self._host_emulation = _code_object == ""

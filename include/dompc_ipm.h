@@ -244,6 +244,9 @@ int dompc_set_sharding(dompc_handle* h, const dompc_shard_desc* desc);
 /* exchanges (element-wise SUMs over the exchange buffer) the last sharded solve asked for; divided by its iteration count:
  * the collectives per interior-point iteration */
 int64_t dompc_last_exchange_count(const dompc_handle* h);
+/* the launch-shape-specific sibling code object `<name>_batch.hsaco` of the handle: 0 = none next to the general object, 1 = loaded and
+ * launched for batches of one wavefront per problem, 2 = found but built from other sources or for another model - not used */
+int dompc_batch_object_state(const dompc_handle* h);
 
 /* ---- batched plant integration ---------------------------------------------------------
  * Replaces the integrator object of do_mpc.simulator.Simulator (do_mpc/simulator.py:381-416:
@@ -276,10 +279,14 @@ void dompc_plant_destroy(dompc_plant* h);
 /* method: 0 explicit with implicit repeat for stiff samples (default), 1 explicit only, 2 implicit only;
  * explicit_limit: explicit steps per interval after which a sample counts as stiff (0 = keep, default 4000) */
 int  dompc_plant_set_method(dompc_plant* h, int32_t method, int32_t explicit_limit);
-/* algebraic states: their number, and the Newton start for every sample (host array of that many values, NULL = zeros);
- * afterwards every sample continues from the values it found at the end of the previous call */
+/* algebraic states: their number, and the Newton start for every sample (host array of that many values, NULL = zeros).
+ * Carry-over: ROW b of a call continues from the values row b found at the end of the previous call - meaningful only when the rows of
+ * consecutive calls are the same trajectories.  dompc_plant_step_batch_device (resident closed loops) always carries; the host entry
+ * dompc_plant_step_batch starts every call from z0 unless dompc_plant_set_z_carry(h, 1) says its rows correspond across calls
+ * (Simulator.make_step: one trajectory).  A batch larger than any before starts all rows from z0. */
 int32_t dompc_plant_num_alg_states(const dompc_plant* h);
 int  dompc_plant_set_z0(dompc_plant* h, const double* z0);
+int  dompc_plant_set_z_carry(dompc_plant* h, int32_t on);
 const char* dompc_plant_last_error(const dompc_plant* h);     /* h may be NULL: error of the last failed create */
 /* host buffers; w, v, y, status may be NULL */
 int dompc_plant_step_batch(dompc_plant* h, int32_t B, const double* x, const double* u, const double* tvp, const double* p,

@@ -155,3 +155,18 @@ def check_stiff_plant(hostemu):
     X = np.array([[2.0, 0.0], [0.0, 0.0]])
     rb = make("cvodes", integration_opts={"explicit_limit": 1500}).make_step_batch(X, np.array([0.1]))
     assert rb["status"][0] == 2 and rb["status"][1] in (0, 2)
+    # make_step (the closed-loop entry point) accepts a sample the implicit method finished (status bit 1 is not a failure) ...
+    for tool, kw in (("sdirk4", {}), ("cvodes", {"integration_opts": {"explicit_limit": 1500}})):
+        sim = make(tool, **kw)
+        sim.x0 = x0
+        y = sim.make_step(u0.reshape(-1, 1))
+        assert np.max(np.abs(np.ravel(y) - ref) / np.maximum(1e-3, np.abs(ref))) < 1e-6, (tool, y, ref)
+    # ... and still raises when the integration did not reach t_step
+    sim = make("dopri5", max_steps=3000)
+    sim.x0 = x0
+    try:
+        sim.make_step(u0.reshape(-1, 1))
+    except RuntimeError as e:
+        assert "did not reach t_step" in str(e)
+    else:
+        raise AssertionError("make_step accepted a sample that ran into the step limit")
