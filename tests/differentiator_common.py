@@ -137,3 +137,132 @@ def check_batched_directions_equal_single_rows(make_mpc, name, max_batch=8, **ov
     used[mpc.structure.tables["dummy_idx"]] = False
     ref = np.asarray(dxdp1)[used][:, cols]
     assert np.max(np.abs(np.asarray(dxdp)[used][:, cols] - ref)) <= 1e-7 * max(1.0, np.max(np.abs(ref)))
+
+
+def check_status_and_jacobian(make_mpc, name, **over):
+    """Round 5: the reference's status object (differentiator/helper.py:72-117) and its checks.  The constraint Jacobian the LICQ check
+    uses (batched sweeps of the kernels + central differences) against the oracle's analytic one; LICQ / SC flags of a regular solution."""
+    from do_mpc_amd.differentiator import NLPDifferentiatorStatus, active_constraints
+    mpc = solved(make_mpc, name, **over)
+    nd = DoMPCDifferentiator(mpc, check_LICQ=True, check_SC=True, check_rank=True)
+    assert isinstance(nd.status, NLPDifferentiatorStatus) and nd.status.LICQ is None and nd.status.SC is None and not nd.status.lse_solved
+    nd.differentiate()
+    st = nd.status
+    assert st.lse_solved and st.LICQ is True and st.full_rank is True and st.sym_KKT and st.residuals is not None and st.residuals < 1e-5
+    assert isinstance(st.SC, bool)
+    nlp = pc.oracle_nlp(name, **over)
+    x, p = mpc.opt_x_num.master.copy(), mpc.opt_p_num.master.copy()
+    J = nd.constraint_jacobian()
+    Jo = sps.csr_matrix(nlp.jac(x, p))
+    used = np.ones(mpc.structure.n_opt_x, bool)
+    used[mpc.structure.tables["dummy_idx"]] = False
+    dJ = (J - Jo)[:, used]
+    assert abs(dJ).max() < 1e-6 * max(1.0, abs(Jo).max()), abs(dJ).max()
+    # the active set is the reference's: every equality row, the bounds the solution sits on
+    g_in, x_in, g_act, x_act = active_constraints(x, mpc.opt_g_num, mpc._lb_opt_x.master, mpc._ub_opt_x.master, mpc._nlp_cons_lb,
+                                                  mpc._nlp_cons_ub, nd.settings.active_set_tol)
+    assert set(np.where(mpc._nlp_cons_lb == mpc._nlp_cons_ub)[0]) <= set(g_act)
+    assert st.n_active_g == g_act.size and st.n_active_x == x_act.size
+    return mpc, nd
+
+
+def check_active_set_reduction(make_mpc, name, **over):
+    """settings.active_set_reduction against the reference's algorithm restated with the oracle's functions (_nlpdifferentiator.py:
+    287-301, 430-468): KKT matrix of L = f + lam_g' g + lam_x' x over z = (x, lam_g, lam_x), rows and columns of the inactive
+    constraints removed, A S = -B solved with a sparse LU; x0 and u_prev columns (they enter linearly: B from a difference)."""
+    from do_mpc_amd.differentiator import active_constraints
+    mpc = solved(make_mpc, name, **over)
+    nd = DoMPCDifferentiator(mpc, active_set_reduction=True)
+    dxdp, _ = nd.differentiate()
+    assert nd.status.reduced_nlp
+    nlp = pc.oracle_nlp(name, **over)
+    x, p0, lam = mpc.opt_x_num.master.copy(), mpc.opt_p_num.master.copy(), np.asarray(mpc.lam_g_num, float)
+    n, m = x.size, lam.size
+    _, _, g_act, x_act = active_constraints(x, mpc.opt_g_num, mpc._lb_opt_x.master, mpc._ub_opt_x.master, mpc._nlp_cons_lb,
+                                            mpc._nlp_cons_ub, nd.settings.active_set_tol)
+    W, A = sps.csr_matrix(nlp.hess(x, p0, 1.0, lam)), sps.csr_matrix(nlp.jac(x, p0))
+    dummy = np.asarray(mpc.structure.tables["dummy_idx"])
+    free_dummy = np.setdiff1d(dummy, x_act)                # unused variables without an active bound: the reference removes them from the NLP
+    pin = np.zeros(n)
+    pin[free_dummy] = 1.0
+    E = sps.csr_matrix((np.ones(x_act.size), (np.arange(x_act.size), x_act)), shape=(x_act.size, n))
+    Aa = A[g_act]
+    K = sps.bmat([[W + sps.diags(pin), Aa.T, E.T], [Aa, None, None], [E, None, None]], format="csc")
+    lu = spla.splu(K)
+    lay = mpc._opt_p_layout
+    cols = np.concatenate([lay.resolve(("_x0",)).ravel(), lay.resolve(("_u_prev",)).ravel()])
+
+    def grad_z(p):
+        return np.concatenate([nlp.grad(x, p) + nlp.jac(x, p).T @ lam, nlp.g(x, p)[g_act], np.zeros(x_act.size)])
+
+    g0 = grad_z(p0)
+    ref = np.zeros((n, len(cols)))
+    for k, j in enumerate(cols):
+        p = p0.copy()
+        h = max(1.0, abs(p0[j]))
+        p[j] += h
+        rhs = -(grad_z(p) - g0) / h
+        sol = lu.solve(rhs)
+        sol += lu.solve(rhs - K @ sol)
+        ref[:, k] = sol[:n]
+    ref *= mpc.opt_x_scaling.master[:, None]
+    used = np.ones(n, bool)
+    used[dummy] = False
+    got = np.asarray(dxdp)[used][:, cols]
+    err = np.max(np.abs(got - ref[used]))
+    assert err < 2e-5 * max(1.0, np.max(np.abs(ref[used]))), err
+    # the variables held by an active bound do not move
+    if x_act.size:
+        assert np.max(np.abs(np.asarray(dxdp)[x_act][:, cols])) < 1e-5 * max(1.0, np.max(np.abs(ref)))
+    return err
+
+
+def check_standalone_nlp_differentiator():
+    """NLPDifferentiator on the example of the reference's class docstring (_nlpdifferentiator.py:27-62: a Rosenbrock-like objective,
+    two inequality rows that depend on the parameter) against finite differences of re-solves (scipy SLSQP), plus the bookkeeping:
+    unused variables / parameters are removed and come back as zero rows / columns."""
+    from scipy.optimize import minimize
+    from do_mpc_amd import sym
+    from do_mpc_amd.differentiator import NLPDifferentiator
+    x, p = sym.SX.sym("x", 3), sym.SX.sym("p", 2)            # x[2] and p[1] appear nowhere
+    f = (1 - x[0]) ** 2 + 0.2 * (x[1] - x[0] ** 2) ** 2
+    ci = (x[0] + 0.5) ** 2 + x[1] ** 2
+    g = sym.vertcat(p[0] ** 2 / 4 - ci, ci - p[0] ** 2)
+    bounds = {"lbx": np.array([0, -np.inf, -np.inf]), "ubx": np.full(3, np.inf), "lbg": np.full(2, -np.inf), "ubg": np.zeros(2)}
+    nd = NLPDifferentiator({"x": x, "p": p, "f": f, "g": g}, bounds, check_rank=True)
+    assert nd.status.reduced_nlp and nd.status.sym_KKT and nd.n_x == 2 and nd.n_p == 1
+    F = sym.Function("F", [x, p], [f, g, sym.gradient(f, x), sym.jacobian(g, x)])
+
+    def solve(pv):
+        r = minimize(lambda v: F.eval(np.append(v, 0.0), [pv, 0.0])[0][0], [0.5, 0.5], method="SLSQP", bounds=[(0, None), (None, None)],
+                     constraints=[{"type": "ineq", "fun": lambda v: -F.eval(np.append(v, 0.0), [pv, 0.0])[1]}],
+                     options={"ftol": 1e-15, "maxiter": 500})
+        return np.append(r.x, 0.0)
+
+    p0 = 1.0
+    xs = solve(p0)
+    _, gv, gf, Jg = F.eval(xs, [p0, 0.0])
+    Jg = Jg.reshape(2, 3, order="F")
+    act = np.abs(gv) < 1e-6
+    assert act.tolist() == [False, True]
+    lam_g = np.zeros(2)
+    lam_g[act] = np.linalg.lstsq(Jg[act][:, :2].T, -gf[:2], rcond=None)[0]
+    sol = {"x": xs, "g": gv, "lam_g": lam_g, "lam_x": np.zeros(3)}
+    dx, dl = nd.differentiate(sol, np.array([p0, 0.0]))
+    assert nd.status.LICQ and nd.status.SC and nd.status.lse_solved and nd.status.full_rank and nd.status.residuals < 1e-10
+    h = 1e-5
+    fd = (solve(p0 + h) - solve(p0 - h)) / (2 * h)
+    assert dx.shape == (3, 2) and dl.shape == (2 + 3, 2)
+    assert np.max(np.abs(np.asarray(dx)[:, 0] - fd)) < 5e-4 * np.max(np.abs(fd)), (dx, fd)
+    assert np.all(np.asarray(dx)[2] == 0) and np.all(np.asarray(dx)[:, 1] == 0) and np.all(np.asarray(dl)[0] == 0)   # unused / inactive
+    # a solution at which strict complementarity fails is reported, not hidden
+    sol2 = dict(sol, lam_g=np.zeros(2))
+    nd.differentiate(sol2, np.array([p0, 0.0]))
+    assert nd.status.SC is False
+    for bad in ({"x": xs}, 3):
+        try:
+            nd.differentiate(bad, np.array([p0, 0.0]))
+        except ValueError:
+            pass
+        else:
+            raise AssertionError("accepted an incomplete nlp_sol")

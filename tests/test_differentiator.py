@@ -40,3 +40,32 @@ def test_reference_surface():
 
 def test_batched_newton_directions_with_several_workspace_slots():
     dc.check_batched_directions_equal_single_rows(make_mpc, "batch_reactor", max_batch=8)
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor"])
+def test_status_object_licq_sc_and_the_constraint_jacobian(name):
+    dc.check_status_and_jacobian(make_mpc, name)
+
+
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR"])
+def test_active_set_reduction_equals_the_references_reduced_kkt_system(name):
+    dc.check_active_set_reduction(make_mpc, name)
+
+
+def test_standalone_nlp_differentiator():
+    dc.check_standalone_nlp_differentiator()
+
+
+def test_rank_test_of_the_licq_check():
+    from do_mpc_amd.differentiator import rows_independent
+    import scipy.sparse as sps
+    rng = np.random.default_rng(0)
+    M = rng.standard_normal((6, 9))
+    assert rows_independent(M) and rows_independent(sps.csr_matrix(M))
+    M[4] = 2.0 * M[1] - M[3]
+    assert not rows_independent(M)
+    assert not rows_independent(rng.standard_normal((5, 3)))          # more active constraints than variables
+    big = sps.random(2000, 2600, density=2e-3, random_state=1, format="csr") + sps.eye(2000, 2600)
+    assert rows_independent(big)
+    big = sps.vstack([big, big[7] + big[11]], format="csr")
+    assert not rows_independent(big)

@@ -23,3 +23,13 @@ def test_sensitivities_of_a_model_with_nl_cons_rows_and_soft_constraints():
 @pytest.mark.parametrize("name", ["batch_reactor", "CSTR"])
 def test_batched_newton_directions_with_several_workspace_slots(name):
     dc.check_batched_directions_equal_single_rows(make_mpc, name, max_batch=8)
+
+
+@pytest.mark.parametrize("name", ["batch_reactor", "CSTR"])
+def test_status_object_licq_sc_and_the_constraint_jacobian(name):
+    dc.check_status_and_jacobian(make_mpc, name)
+
+
+@pytest.mark.parametrize("name", ["batch_reactor", "CSTR", "industrial_poly"])
+def test_active_set_reduction_equals_the_references_reduced_kkt_system(name):
+    dc.check_active_set_reduction(make_mpc, name)
