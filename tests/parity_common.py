@@ -219,6 +219,43 @@ def check_tree27_same_iterates_as_oracle(make_mpc, shard=None):
     return mpc
 
 
+def stored_oracle_tree(leaves):
+    """tests/golden/oracle_tree{81,243}.npz: cold oracle SOLVES of the large industrial_poly trees (tools/oracle_tree_fixture.py; 30 s and
+    108 s of scipy SuperLU - stored once instead of being repeated in every test run)"""
+    return np.load(os.path.join(GOLD, "oracle_tree%d.npz" % leaves))
+
+
+def check_big_tree_against_stored_oracle_solve(make_mpc, leaves, shard=None):
+    """BASELINE configs[4] (243 leaves, 218 700 variables, 160 330 rows) and the 81-leaf tree against an oracle SOLVE, not
+    only against KKT residuals: same iteration and regularisation counts as the oracle's cold solve from the example's x0, u0 and the
+    complete primal solution equal, multipliers at the level of the 27-leaf case.
+    [NO REFERENCE FIXTURE: the stored vectors are the ORACLE's (IPOPT's algorithm restated), not a run of the reference]"""
+    o = stored_oracle_tree(leaves)
+    n_robust = {81: 4, 243: 5}[leaves]
+    mpc = make_mpc("industrial_poly", n_robust=n_robust, uncertainty="paired")
+    ps = mpc.structure
+    assert (ps.S, ps.n_opt_x, ps.n_g) == (leaves, int(o["n_opt_x"]), int(o["n_g"]))
+    x0 = o["x0"]
+    mpc.x0 = x0
+    mpc.set_initial_guess()
+    if shard is not None:
+        mpc.shard_tree(**shard)
+    u0 = mpc.make_step(x0).ravel()
+    st = mpc.solver_stats
+    assert st["success"] and bool(o["success"])
+    if shard is None:
+        assert st["iter_count"] == int(o["iter_count"]) and st["n_reg"] == int(o["n_reg"]), (st["iter_count"], st["n_reg"])
+    else:
+        assert abs(st["iter_count"] - int(o["iter_count"])) <= 1
+    used = np.ones(ps.n_opt_x, bool)
+    used[ps.tables["dummy_idx"]] = False
+    tol = 1e-8 if shard is None else 1e-6
+    assert relerr(u0, o["u0"]) < tol, (u0, o["u0"])
+    assert relerr(mpc.opt_x_num.master[used], o["x"][used]) < tol
+    assert np.max(np.abs(mpc.lam_g_num - o["lam_g"])) < (5e-5 if shard is None else 2e-4) * max(1.0, np.max(np.abs(o["lam_g"])))
+    return mpc
+
+
 def check_newton_step(make_mpc, name, oracle_iters=6, delta=0.0):
     """One Newton direction of the structured solve (condensing + tree Riccati) against a general sparse
     LU of the same KKT system, at an interior iterate produced by the oracle.  delta > 0: the inertia-correction

@@ -1,4 +1,5 @@
 """Shared helpers of the plant-integrator tests (host emulation on CPU, HIP path under -m gpu)."""
+import hostemu_build
 import os
 
 import numpy as np
@@ -33,7 +34,7 @@ def make_simulator(name, hostemu=True, model=None, **params):
     if hostemu:
         hdr = sim._lower()
         h = hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0]
-        sim.setup(_lib_path=build.plant_hostemu_library(hdr, h, OUT), _code_object="")
+        sim.setup(_lib_path=hostemu_build.plant_hostemu_library(hdr, h, OUT), _code_object="")
     else:
         sim.setup()
     return sim
@@ -136,7 +137,7 @@ def check_stiff_plant(hostemu):
         if hostemu:
             hdr = sim._lower()
             h = hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0]
-            sim.setup(_lib_path=build.plant_hostemu_library(hdr, h, OUT), _code_object="")
+            sim.setup(_lib_path=hostemu_build.plant_hostemu_library(hdr, h, OUT), _code_object="")
         else:
             sim.setup()
         return sim

@@ -537,20 +537,32 @@ def _oracle_member(args):
     return i, nlp.u0_of(r["x"]), int(r["stats"]["iter_count"]), bool(r["stats"]["success"]), r["x"]
 
 
+@pytest.mark.parametrize("leaves", [81, 243])
+def test_large_trees_equal_the_stored_oracle_solve(leaves):
+    """BASELINE configs[4] (243 leaves) and the 81-leaf tree against the oracle's SOLVE (tests/golden/oracle_tree*.npz), on the whole
+    chip (KArgs::wide_spread)."""
+    pc.check_big_tree_against_stored_oracle_solve(make_mpc, leaves)
+
+
+def test_243_leaf_tree_sharded_code_path_equals_the_stored_oracle_solve():
+    pc.check_big_tree_against_stored_oracle_solve(make_mpc, 243, shard=dict(rank=0, world=1, cut_level=3, native_rccl=True))
+
+
 @pytest.mark.gpu
 def test_members_of_the_timed_batch_equal_oracle_solves():
     """The TIMED launch shape of bench.py (B >= 4096: one 64-lane wavefront per problem, 2048 resident slots, problems pulled from
-    a device-wide counter, perturbed x0 of bench.synthetic_x0_batch) tied to the oracle directly: eight members of a B = 4096
-    batch-mode launch against oracle/ipm.solve of the same x0 - same iteration count, u0 and the full primal solution."""
+    a device-wide counter, perturbed x0 of bench.synthetic_x0_batch) tied to the oracle directly: eight members of THE launch the
+    bench times (B = 16 384, its default batch: eight rounds over the 2 048 slots; round 4 sampled a B = 4 096 launch) against
+    oracle/ipm.solve of the same x0 - same iteration count, u0 and the full primal solution."""
     import multiprocessing as mp
     import bench
-    B = 4096
+    B = 16384
     X0 = bench.synthetic_x0_batch(B)
     mpc = make_mpc("industrial_poly", max_batch=B)
     assert mpc.S.num_slots >= 1024                     # (one wavefront per problem: 8 slots per CU)
     r = mpc.make_step_batch(X0)
     assert r["stats"]["success"].all()
-    members = [0, 1, 511, 1024, 2047, 2048, 3333, 4095]
+    members = [0, 1, 2047, 2048, 4095, 8191, 12345, 16383]       # (first / later rounds of the work queue; 2048 and 4095: the two findings of round 4)
     with mp.get_context("spawn").Pool(len(members)) as pool:
         res = pool.map(_oracle_member, [(i, X0[i]) for i in members])
     used = np.ones(mpc.structure.n_opt_x, bool)

@@ -1,6 +1,8 @@
 """IPM logic on the TEST-ONLY host emulation of the device code (tests/hostemu.py): the same kernel
 text as the gfx950 code object, one workgroup = one host thread.  Runs in the GPU-less CI container;
 the -m gpu twin of this module (test_gpu_parity.py) runs the real HIP path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -255,6 +257,24 @@ def test_dense_elimination_with_row_loops_equals_the_register_variant(monkeypatc
 def test_mid_size_tree_same_iterates_as_the_oracle():
     """27-leaf industrial_poly tree (n_robust = 3): oracle solve vs the kernels, same iterates"""
     pc.check_tree27_same_iterates_as_oracle(make_mpc)
+
+
+def test_81_leaf_tree_equals_the_stored_oracle_solve():
+    """81-leaf industrial_poly tree (n_robust = 4, 72 900 variables) against the stored oracle solve; the 243-leaf tree of BASELINE
+    configs[4] runs in the GPU twin (test_gpu_parity.py)"""
+    pc.check_big_tree_against_stored_oracle_solve(make_mpc, 81)
+
+
+@pytest.mark.slow
+def test_the_stored_81_leaf_oracle_solve_is_what_the_oracle_produces():
+    """the fixture is not hand-made: tools/oracle_tree_fixture.py re-run (30 s)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import oracle_tree_fixture as otf
+    nlp, r, _ = otf.solve(4)
+    o = pc.stored_oracle_tree(81)
+    assert int(o["iter_count"]) == r["stats"]["iter_count"] and int(o["n_reg"]) == r["stats"]["n_reg"]
+    assert np.array_equal(o["x"], r["x"]) and np.array_equal(o["lam_g"], r["lam_g"])
 
 
 def test_watchdog_ends_the_crawl_on_the_full_horizon_kite_problem():

@@ -10,6 +10,7 @@ the un-edited template lowers to.  The hashes are pinned in tests/golden/templat
 against the code objects it runs (tests/test_gpu_parity.py::test_code_objects_are_the_ones_the_unedited_templates_lower_to).
 On the host emulation the un-edited templates also reproduce the golden u0 / closed loops directly.
 """
+import hostemu_build
 import importlib.util
 import os
 import sys
@@ -149,7 +150,7 @@ def test_unedited_template_simulator_closes_the_loop_like_main_py(name, compat):
     def setup_on_hostemu(self):                    # (no GPU here: the plant kernel's host emulation; same entry point)
         hdr = self._lower()
         h = hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0]
-        orig_setup(self, _lib_path=build.plant_hostemu_library(hdr, h, sc.OUT), _code_object="")
+        orig_setup(self, _lib_path=hostemu_build.plant_hostemu_library(hdr, h, sc.OUT), _code_object="")
     do_mpc.simulator.Simulator.setup = setup_on_hostemu
     try:
         with hostemu.patched():
@@ -227,7 +228,7 @@ def test_unedited_triple_tank_model_and_simulator_reproduce_the_golden_plant_tra
     def setup_on_hostemu(self):
         hdr = self._lower()
         h = hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0]
-        orig_setup(self, _lib_path=build.plant_hostemu_library(hdr, h, sc.OUT), _code_object="")
+        orig_setup(self, _lib_path=hostemu_build.plant_hostemu_library(hdr, h, sc.OUT), _code_object="")
     do_mpc.simulator.Simulator.setup = setup_on_hostemu
     try:
         simulator = tsim.template_simulator(model)

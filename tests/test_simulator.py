@@ -1,6 +1,7 @@
 """Batched plant integrator (do_mpc_amd/simulator.py, csrc/dompc_plant.hip) on the host emulation
 of its kernel: against scipy's Radau at 1e-11 on the same right-hand side (tests/plant.py), batch semantics, limits, and
 the reference's closed-loop tests with this integrator as the plant."""
+import hostemu_build
 import numpy as np
 import pytest
 
@@ -42,7 +43,7 @@ def test_measurement_function_and_noise_inputs():
     sim.set_param(t_step=0.1)
     hdr = sim._lower()
     from do_mpc_amd import build
-    sim.setup(_lib_path=build.plant_hostemu_library(hdr, hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0], sc.OUT), _code_object="")
+    sim.setup(_lib_path=hostemu_build.plant_hostemu_library(hdr, hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0], sc.OUT), _code_object="")
     sim.x0 = np.array([1.0, 1.0])
     y = sim.make_step(np.array([[0.5]]), v0=np.array([[0.01]]), w0=np.array([[0.2], [0.0]])).ravel()
     # x' = -a x + u + w  ->  x(t) = c + (x0 - c) exp(-a t),  c = (u + w) / a
@@ -64,7 +65,7 @@ def test_algebraic_states_are_solved_inside_the_right_hand_side():
     sim.set_param(t_step=0.1)
     hdr = sim._lower()
     from do_mpc_amd import build
-    sim.setup(_lib_path=build.plant_hostemu_library(hdr, hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0], sc.OUT), _code_object="")
+    sim.setup(_lib_path=hostemu_build.plant_hostemu_library(hdr, hdr.rsplit('PLANT_MODEL_HASH "', 1)[1].split('"')[0], sc.OUT), _code_object="")
     sim.x0 = np.array([1.5])
     sim.make_step(np.zeros((0, 1)))
     assert abs(sim.x0.master[0] - 1.5 * np.exp(0.1)) < 1e-11
