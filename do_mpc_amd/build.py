@@ -139,7 +139,17 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
         out = out[:-len(".hsaco")] + "_batch.hsaco"      # (the name the runtime derives from the general object's path)
         defs = defs + ["DOMPC_NO_WIDE=1", "DOMPC_BLOCK_CONST=64"]
     stamp = out + ".stamp"
-    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt + ("S" if shard else "") + "lb" + lb + "p" + prof + " ".join(defs)
+    # machine scheduler / register allocation of the solver kernels (round 5, same-box A/B on the headline batch, profiles/r05_flags.txt):
+    # the iterative ILP strategy of the AMDGPU backend +3.0 % against the default strategy, region priorities in the greedy allocator
+    # another +0.6 % (default 7 604 -> 7 828 / 7 853 -> 7 889 MPC steps/s; iterative-minreg -9 %, iterative-maxocc +2.5 %, post-RA scheduler
+    # off -1.8 %; bitwise the same results: the flags reorder instructions, they do not change the arithmetic).  DOMPC_SCHED=default
+    # builds without them; a DOMPC_DEFS set that names a strategy itself wins.
+    sched = []
+    if os.environ.get("DOMPC_SCHED", "iterative-ilp") != "default" and not any("amdgpu-sched-strategy" in d_ for d_ in defs):
+        sched = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+        if not any("greedy-regclass-priority" in d_ for d_ in defs):
+            sched += ["-mllvm", "-greedy-regclass-priority-trumps-globalness=1"]
+    dig = _sources_digest() + hashlib.sha256(header_text.encode()).hexdigest()[:12] + opt + ("S" if shard else "") + "lb" + lb + "p" + prof + " ".join(defs) + " ".join(sched)
     if not force and _fresh(out, stamp, dig):
         return out
     with _locked(d):
@@ -147,7 +157,7 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
             return out
         if not (os.path.exists(hdr) and open(hdr).read() == header_text):
             _write_atomic(hdr, header_text)
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_SRC_DIGEST=0x{_sources_digest()}ULL", f"-DDOMPC_LB={lb}", f"-DDOMPC_PROFILE={prof}", *[(d if d.startswith("-") else f"-D{d}") for d in defs],
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_SRC_DIGEST=0x{_sources_digest()}ULL", *sched, f"-DDOMPC_LB={lb}", f"-DDOMPC_PROFILE={prof}", *[(d if d.startswith("-") else f"-D{d}") for d in defs],
                f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC, os.path.join(CSRC, "dompc_device.hip")]
         _compile_to(cmd, out, f"lowering model {model_hash} to {ARCH}")
         _write_atomic(stamp, dig)

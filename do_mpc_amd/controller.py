@@ -433,10 +433,11 @@ class MPC:
         # registers / LDS region; csrc/dompc_kernel.h asserts the same bound at compile time)
         pts = (s.collocation_deg + 1) * s.collocation_ni if m.model_type == "continuous" else 0
         n_w = pts * m.n_x + max(pts, 1) * m.n_z
-        if n_w > 64:
+        n_w_max = 128 if (m.n_z == 0 and not self._nl_colloc) else 64        # (the dense edge path of DAE models / rows at the points: 64)
+        if n_w > n_w_max:
             raise NotImplementedError("structured HIP backend: {} collocation / algebraic unknowns per control interval "
-                                      "((deg + 1) * ni * n_x + points * n_z); the kernels eliminate at most 64 per interval - "
-                                      "lower collocation_deg / collocation_ni".format(n_w))
+                                      "((deg + 1) * ni * n_x + points * n_z); the kernels eliminate at most {} per interval - "
+                                      "lower collocation_deg / collocation_ni".format(n_w, n_w_max))
         self._check_validity()
         # slack / nl_cons bookkeeping (optimizer.py:543-585)
         eps_entries = [Entry(sl["slack_name"], sl["shape"]) for sl in self.slack_vars_list]

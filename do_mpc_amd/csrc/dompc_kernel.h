@@ -888,7 +888,8 @@ DOMPC_DEV inline void edge_rterm_store(const ldsd* src, double* S_, int lane, in
 // All groups of the workgroup run this function in lock step (same trip counts), so the block-level
 // barrier T.sync() is safe; groups with e < 0 only take part in the barriers.
 constexpr int NC = NW + NA + 1;
-static_assert(NW <= 64, "collocation block larger than 64 unknowns per edge is not supported yet (pivot bitmask)");
+static_assert(NW <= 128, "collocation block larger than 128 unknowns per edge is not supported (pivot key / used mask of the in-LDS elimination)");
+static_assert(!DENSE_EDGE || NW <= 64, "dense edge path (algebraic states, rows at the collocation points, estimators): at most 64 unknowns per edge (one row per lane in its pivot search)");
 // (single finite element: the matrix is assembled and eliminated in registers, LDS only holds W | w0 afterwards)
 constexpr int MX_LD = (NI == 1) ? NA + 1 : NC;                         // leading dimension of the LDS matrix
 constexpr int MX_W = (NI == 1) ? 0 : NW;                               // column offset of [W | w0] inside it
@@ -2257,11 +2258,11 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     // resp. identities), which keeps the structure; the last NX columns (xkf: identity block, zero above)
     // need no elimination step at all - their inverse columns are already in place.
     {
-      static_assert(NW <= 64, "row index is packed into 6 bits of the pivot key / 64-bit used mask");
+      static_assert(NW <= 128, "row index is packed into 7 bits of the pivot key / 128-bit used mask");
       constexpr int GJ_STEPS = NW - NX;
       constexpr int EL_ROWS = (DEG + 1) * NX;
       constexpr int CPL = (NC + GS_C - 1) / GS_C;
-      unsigned long long used = 0ull;
+      unsigned long long used = 0ull, used_hi = 0ull;       // (rows 64 .. 127: blocks of more than 64 unknowns, round 5)
       {
         for (int kk = 0; kk < GJ_STEPS; ++kk) {
           const int pos = kk % EL_ROWS;
@@ -2281,14 +2282,15 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
             }
   #pragma unroll
             for (int r = 0; r < NW; ++r) {
-              unsigned key = (((unsigned)(__builtin_bit_cast(unsigned long long, f[r]) >> 32)) & 0x7fffffc0u) | (unsigned)r;
-              key = (r >= grp0 && r < grp1 && !((used >> r) & 1ull)) ? key : 0u;
+              unsigned key = (((unsigned)(__builtin_bit_cast(unsigned long long, f[r]) >> 32)) & (NW > 64 ? 0x7fffff80u : 0x7fffffc0u)) | (unsigned)r;
+              const bool taken = (r < 64) ? ((used >> (r & 63)) & 1ull) : ((used_hi >> (r & 63)) & 1ull);
+              key = (r >= grp0 && r < grp1 && !taken) ? key : 0u;
               bestkey = key > bestkey ? key : bestkey;
             }
           }
-          const int pv = (int)(bestkey & 63u);
-          used |= (1ull << pv);
-          if (act && (bestkey >> 6) == 0u) fail = 1;          // |pivot| < ~1e-300: singular collocation block
+          const int pv = (int)(bestkey & (NW > 64 ? 127u : 63u));
+          if (pv < 64) used |= (1ull << pv); else used_hi |= (1ull << (pv - 64));
+          if (act && (bestkey >> (NW > 64 ? 7 : 6)) == 0u) fail = 1;          // |pivot| < ~1e-300: singular collocation block
           if (act) {
             if (lane == 0) Ld[EL_PV + kk] = (double)pv;
             const double piv = Ld[EL_MX + pv * NC + kk];
@@ -4279,8 +4281,12 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       if (GS > 1) {
         if (lane < NA) Ld[RF_DY + lane] = dy0;
         if (chain_edge && lane < NX) Ld[RF_DNU + lane] = dnu0;
+        c_r[0] = cr0;
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) c_r[q] = cr0;
+        for (int q = 1; q < RPL; ++q) {              // (more than 64 unknowns per interval, round 5: the rows beyond the first 64 - only entry 0 is requested one edge ahead)
+          const int r = lane + q * GS;
+          c_r[q] = Q.c[row0 + (r < NW ? r : 0)];
+        }
       } else {
         for (int a = 0; a < NA; ++a) Ld[RF_DY + a] = (a < NX) ? Nd[ND_DXT + a] : Q.dx[A.node_u_off[n] + a - NX];
         if (chain_edge)

@@ -329,7 +329,9 @@ class DoMPCDifferentiator:
             else:
                 dxdp[:, j], dldp[:, j] = (DX[ip] - DX[im]) / (2 * h), (DL[ip] - DL[im]) / (2 * h)
         st.n_newton_solves = 1 + int(self._linear.sum()) + 2 * int((~self._linear).sum())
-        st.residual_step = float(np.max(np.abs(d0x)))
+        used = np.ones(self.n_x, bool)
+        used[np.asarray(mpc.structure.tables["dummy_idx"], dtype=int)] = False      # (variables that appear nowhere in the NLP)
+        st.residual_step = float(np.max(np.abs(d0x[used])))
         st.lse_solved = True
         st.full_rank = True if cfg.check_rank else st.full_rank      # (every structured solve above succeeded with delta_w = 0: the inertia is exact)
         if cfg.track_residuals:

@@ -266,3 +266,20 @@ def check_standalone_nlp_differentiator():
             pass
         else:
             raise AssertionError("accepted an incomplete nlp_sol")
+
+
+def check_singular_reduced_system_is_reported(make_mpc):
+    """industrial_poly: without the barrier terms of its inactive bounds the reduced KKT system is singular along the flat direction
+    of the problem (three weakly determined entries) - the reference's dense solve would return NaNs
+    (_solve_linear_system); here the structured factorisation reports the wrong inertia instead of returning numbers."""
+    mpc = solved(make_mpc, "industrial_poly")
+    dxdp, _ = DoMPCDifferentiator(mpc).differentiate()                    # the barrier problem's sensitivities exist
+    assert dxdp.shape == (mpc.structure.n_opt_x, mpc.structure.n_opt_p)
+    nd = DoMPCDifferentiator(mpc, active_set_reduction=True)
+    try:
+        nd.differentiate()
+    except RuntimeError as e:
+        assert "wrong inertia" in str(e)
+    else:
+        raise AssertionError("a singular reduced system went unnoticed")
+    assert not nd.status.lse_solved and nd.status.reduced_nlp

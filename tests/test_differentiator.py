@@ -42,7 +42,7 @@ def test_batched_newton_directions_with_several_workspace_slots():
     dc.check_batched_directions_equal_single_rows(make_mpc, "batch_reactor", max_batch=8)
 
 
-@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor"])
+@pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR"])
 def test_status_object_licq_sc_and_the_constraint_jacobian(name):
     dc.check_status_and_jacobian(make_mpc, name)
 
@@ -50,6 +50,10 @@ def test_status_object_licq_sc_and_the_constraint_jacobian(name):
 @pytest.mark.parametrize("name", ["oscillating_masses", "batch_reactor", "CSTR"])
 def test_active_set_reduction_equals_the_references_reduced_kkt_system(name):
     dc.check_active_set_reduction(make_mpc, name)
+
+
+def test_a_singular_reduced_system_is_reported():
+    dc.check_singular_reduced_system_is_reported(make_mpc)
 
 
 def test_standalone_nlp_differentiator():

@@ -30,6 +30,10 @@ def test_status_object_licq_sc_and_the_constraint_jacobian(name):
     dc.check_status_and_jacobian(make_mpc, name)
 
 
-@pytest.mark.parametrize("name", ["batch_reactor", "CSTR", "industrial_poly"])
+@pytest.mark.parametrize("name", ["batch_reactor", "CSTR", "oscillating_masses"])
 def test_active_set_reduction_equals_the_references_reduced_kkt_system(name):
     dc.check_active_set_reduction(make_mpc, name)
+
+
+def test_a_singular_reduced_system_is_reported():
+    dc.check_singular_reduced_system_is_reported(make_mpc)

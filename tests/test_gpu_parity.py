@@ -587,6 +587,10 @@ def test_members_of_the_timed_batch_equal_oracle_solves():
     assert late <= len(members) // 2, late
 
 
+def test_control_interval_with_80_unknowns_same_iterates_as_the_oracle():
+    pc.check_interval_with_more_than_64_unknowns(make_mpc)
+
+
 def test_watchdog_ends_the_crawl_on_the_full_horizon_kite_problem():
     pc.check_watchdog_on_kite_full_horizon(make_mpc)
 

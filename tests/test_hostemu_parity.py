@@ -277,6 +277,10 @@ def test_the_stored_81_leaf_oracle_solve_is_what_the_oracle_produces():
     assert np.array_equal(o["x"], r["x"]) and np.array_equal(o["lam_g"], r["lam_g"])
 
 
+def test_control_interval_with_80_unknowns_same_iterates_as_the_oracle():
+    pc.check_interval_with_more_than_64_unknowns(make_mpc)
+
+
 def test_watchdog_ends_the_crawl_on_the_full_horizon_kite_problem():
     pc.check_watchdog_on_kite_full_horizon(make_mpc)
 
