@@ -157,9 +157,23 @@ def model_code_object(header_text: str, model_hash: str, force: bool = False, op
             return out
         if not (os.path.exists(hdr) and open(hdr).read() == header_text):
             _write_atomic(hdr, header_text)
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_SRC_DIGEST=0x{_sources_digest()}ULL", *sched, f"-DDOMPC_LB={lb}", f"-DDOMPC_PROFILE={prof}", *[(d if d.startswith("-") else f"-D{d}") for d in defs],
-               f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC, os.path.join(CSRC, "dompc_device.hip")]
-        _compile_to(cmd, out, f"lowering model {model_hash} to {ARCH}")
+        # (the iterative scheduler of this ROCm's clang crashes - segmentation fault in the greedy register allocator - on some models, e.g. the
+        #  discrete oscillating-masses class: such a model is compiled with the default strategy instead; `<out>.sched` says which one it got)
+        last = None
+        for fl in ([sched, []] if sched else [[]]):
+            cmd = [_hipcc(), f"--offload-arch={ARCH}", opt, "-std=c++17", "--genco", f"-DDOMPC_SHARD={1 if shard else 0}", f"-DDOMPC_SRC_DIGEST=0x{_sources_digest()}ULL", *fl, f"-DDOMPC_LB={lb}", f"-DDOMPC_PROFILE={prof}", *[(d if d.startswith("-") else f"-D{d}") for d in defs],
+                   f"-DDOMPC_MODEL_HEADER=\"{hdr}\"", "-I", CSRC, os.path.join(CSRC, "dompc_device.hip")]
+            try:
+                _compile_to(cmd, out, f"lowering model {model_hash} to {ARCH}")
+                _write_atomic(out + ".sched", " ".join(fl) or "default")
+                last = None
+                break
+            except BuildError as e:
+                last = e
+                if "Segmentation fault" not in str(e) and "frontend command failed" not in str(e):
+                    raise
+        if last is not None:
+            raise last
         _write_atomic(stamp, dig)
     return out
 
