@@ -433,7 +433,9 @@ class MPC:
         # registers / LDS region; csrc/dompc_kernel.h asserts the same bound at compile time)
         pts = (s.collocation_deg + 1) * s.collocation_ni if m.model_type == "continuous" else 0
         n_w = pts * m.n_x + max(pts, 1) * m.n_z
-        n_w_max = 128 if (m.n_z == 0 and not self._nl_colloc) else 64        # (the dense edge path of DAE models / rows at the points: 64)
+        # 128 on the in-LDS elimination of intervals with several finite elements (round 5); 64 on the single-element path (one extended
+        # column per lane, registers) and on the dense edge path of DAE models / rows at the collocation points (one row per lane)
+        n_w_max = 128 if (m.n_z == 0 and not self._nl_colloc and s.collocation_ni >= 2) else 64
         if n_w > n_w_max:
             raise NotImplementedError("structured HIP backend: {} collocation / algebraic unknowns per control interval "
                                       "((deg + 1) * ni * n_x + points * n_z); the kernels eliminate at most {} per interval - "

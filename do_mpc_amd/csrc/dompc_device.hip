@@ -54,7 +54,10 @@ extern "C" __global__ void dompc_model_info_kernel(const int32_t* in, int64_t* o
   }
 }
 
-extern "C" __global__ void __launch_bounds__(DOMPC_BLOCK_CONST ? DOMPC_BLOCK_CONST : 256, DOMPC_LB) dompc_solve_kernel(dompc::KArgs A) {
+#ifndef DOMPC_MAXBLOCK
+#define DOMPC_MAXBLOCK 256         // largest workgroup the general code object is launched with (experiment: 512 = eight wavefronts per workgroup in wide mode)
+#endif
+extern "C" __global__ void __launch_bounds__(DOMPC_BLOCK_CONST ? DOMPC_BLOCK_CONST : DOMPC_MAXBLOCK, DOMPC_LB) dompc_solve_kernel(dompc::KArgs A) {
   using namespace dompc;
   const int POOL = A.pool_doubles;
   if (threadIdx.x < 32) lds_prof[threadIdx.x] = 0;

@@ -284,7 +284,7 @@ constexpr bool WIDE_OK = DOMPC_NO_WIDE == 0;
 #endif
 struct Thr {
   int tid, nt;
-  ldsd* red;        // LDS: RED_MAX * lnt doubles
+  ldsd* red;        // LDS: RED_MAX * lnt doubles (the pool is at least that large: `pool` doubles)
   ldsd* filt;       // LDS: 2*MAX_FILTER doubles (every workgroup keeps an identical copy)
   int* flags;       // 8 ints shared by all threads of the problem: LDS (one workgroup) or global (wide)
   ldsd* edge_lds;   // LDS: (lnt/gs) * EL_SIZE doubles (per-group edge working set)
@@ -301,6 +301,7 @@ struct Thr {
   // wide mode: every workgroup of the problem runs on the SAME XCD (verified at kernel start from HW_REG_XCC_ID, xcd_census):
   // they share one L2, so the release side of the barrier needs no L2 write-back - the stores only have to have left the CU
   mutable bool light = false;
+  int pool = 0;     // doubles in the workgroup's LDS pool (device; KArgs::pool_doubles)
   // flags: LDS words in a one-workgroup problem; global words shared by the K workgroups of a wide problem - those are
   // read and written with agent-scope atomics (a plain load could be served from this CU's L1).
   DOMPC_DEV void fset(int i, int v) const {
@@ -314,6 +315,19 @@ struct Thr {
     if (WIDE_OK && nwg > 1) return __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     return flags[i];
+  }
+  // Failure flag `i` of a phase (0: Riccati pass, 1: sweep): returns the value that means "set" in this phase.  One workgroup: 1, with
+  // the reset between two barriers (every thread past its last read of the previous phase, nobody sets before the reset).  Wide mode
+  // (round 5): the barrier generation at the phase's entry - no earlier phase used that value, so the flag needs no reset and the
+  // phase starts with ONE device-scope barrier instead of two (each costs ~10 us with 100+ workgroups on eight XCDs).
+  DOMPC_DEV int flag_begin(int i) const {
+    sync();
+#ifndef DOMPC_HOST_EMU
+    if (WIDE_OK && nwg > 1) return (int)(gen & 0x3fffffffu) + 1;
+#endif
+    if (tid == 0) fset(i, 0);
+    sync();
+    return 1;
   }
   DOMPC_DEV void sync() const {
 #ifndef DOMPC_HOST_EMU
@@ -429,7 +443,8 @@ __device__ inline Thr make_thr(const KArgs& A) {
              wide ? A.wide_flags + slot * 8 : lds_flags, (ldsd*)lds_pool, lds_prof, 64,
              (int)threadIdx.x, DOMPC_BDIM, j, K, wide ? A.wide_bar + slot * 16 : nullptr,
              wide ? A.wide_partials + (int64_t)slot * 2 * K * RED_MAX : nullptr, 0u, 0u, make_xctx(A), 0u, nullptr,
-             (wide && DOMPC_LIGHT_BARRIER) ? __hip_atomic_load(A.wide_bar + slot * 16 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u : false};
+             (wide && DOMPC_LIGHT_BARRIER) ? __hip_atomic_load(A.wide_bar + slot * 16 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u : false,
+             A.pool_doubles};
 }
 // wide mode, once per launch: do all workgroups of this problem run on one XCD?  Every workgroup publishes its XCC id
 // (hardware register), the first workgroup writes the verdict (word 2 of the slot's barrier block: 1 = one XCD, 2 = several)
@@ -523,10 +538,26 @@ DOMPC_DEV void wg_reduce(const Thr& T, double (&v)[N_], const int (&op)[N_]) {
     ++T.nred;
     if (T.ltid < N_) buf[T.wg * RED_MAX + T.ltid] = T.red[T.ltid * T.lnt];
     T.sync();
+#ifndef DOMPC_HOST_EMU
+    // Whole-chip wide mode (round 5: up to 256 workgroups per problem on all XCDs): the rows of the other workgroups sit in memory behind
+    // the barrier's L2 invalidate, and folding them one dependent-looking load after the other cost ~1 us per row (a quarter of an IPM
+    // iteration of the 243-leaf tree went into these folds).  All threads of the workgroup fetch the table at once into the free part
+    // of the LDS pool (behind the reduction scratch), then the N_ folding threads read it from there - in the same order: same bits.
+    const int n_tab = T.nwg * RED_MAX;
+    ldsd* tab = T.red + RED_MAX * T.lnt;
+    const bool staged = RED_MAX * T.lnt + n_tab <= T.pool;
+    if (staged) {
+      for (int i = T.ltid; i < n_tab; i += T.lnt) tab[i] = buf[i];
+      T.lsync();
+    }
+#else
+    const bool staged = false;
+    const double* tab = nullptr;
+#endif
     if (T.ltid < N_) {
-      double acc = buf[T.ltid];
+      double acc = staged ? (double)tab[T.ltid] : buf[T.ltid];
       for (int w = 1; w < T.nwg; ++w) {
-        const double b = buf[w * RED_MAX + T.ltid];
+        const double b = staged ? (double)tab[w * RED_MAX + T.ltid] : buf[w * RED_MAX + T.ltid];
         acc = op[T.ltid] == R_SUM ? acc + b : (op[T.ltid] == R_MAX ? fmax(acc, b) : fmin(acc, b));
       }
       T.red[T.ltid * T.lnt] = acc;
@@ -889,6 +920,7 @@ DOMPC_DEV inline void edge_rterm_store(const ldsd* src, double* S_, int lane, in
 // barrier T.sync() is safe; groups with e < 0 only take part in the barriers.
 constexpr int NC = NW + NA + 1;
 static_assert(NW <= 128, "collocation block larger than 128 unknowns per edge is not supported (pivot key / used mask of the in-LDS elimination)");
+static_assert(NI >= 2 || NW <= 64, "single finite element: at most 64 unknowns per edge (one extended column per lane of the register-resident elimination)");
 static_assert(!DENSE_EDGE || NW <= 64, "dense edge path (algebraic states, rows at the collocation points, estimators): at most 64 unknowns per edge (one row per lane in its pivot search)");
 // (single finite element: the matrix is assembled and eliminated in registers, LDS only holds W | w0 afterwards)
 constexpr int MX_LD = (NI == 1) ? NA + 1 : NC;                         // leading dimension of the LDS matrix
@@ -3537,9 +3569,7 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
   // previous pass - the wavefronts then disagree about "failed" and the workgroup falls apart (garbage steps or a
   // barrier that never completes; seen as a timing-dependent failure of a 37-problem batch).  Hence the barrier
   // BEFORE the reset: every thread is past its last read of the previous pass.
-  T.sync();
-  if (T.tid == 0) T.fset(0, 0);
-  T.sync();
+  const int FSET = T.flag_begin(0);
   {
     // leaves: P = sf*omega*Hm + Sigma_x, p = sf*omega*gm - nu_in + barrier
     const int n0 = A.level_node_start[A.N], n1 = A.level_node_start[A.N + 1];
@@ -3585,13 +3615,13 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
           for (int it = lane; it < NA; it += GS) Ld[RB_PCV + it] = Ld[RB_PNV + it];
           T.gsync();
         }
-        if (riccati_node(T, Q, A.level_node_start[k] + s_, mu, delta, Ld, lane, GS, staged, R)) { T.fset(0, 1); break; }
+        if (riccati_node(T, Q, A.level_node_start[k] + s_, mu, delta, Ld, lane, GS, staged, R)) { T.fset(0, FSET); break; }
         staged = true;
         if (k > cl) R = Rn;
       }
     }
     T.sync();
-    if (T.fget(0) && !sh_on(A)) return 1;      // (sharded: the flag is only known to this rank until the cut exchange)
+    if ((T.fget(0) == FSET) && !sh_on(A)) return 1;      // (sharded: the flag is only known to this rank until the cut exchange)
   }
   for (int k = cl - 1; k >= 0; --k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
@@ -3600,10 +3630,10 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
       for (int n = n0 + gid; n < n1; n += ng) riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 1);
       T.xchg(x_c1(A), A.n_cut * CUT1);
       for (int n = n0 + gid; n < n1; n += ng)
-        if (riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 2)) T.fset(0, 1);
+        if (riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 2)) T.fset(0, FSET);
       T.sync();
       double* fl = A.xbuf + x_c2(A) + A.n_cut * CUT2;          // failure flags of all ranks ride along
-      for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && T.fget(0)) ? 1.0 : 0.0;
+      for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && (T.fget(0) == FSET)) ? 1.0 : 0.0;
       T.xchg(x_c2(A), A.n_cut * CUT2 + A.shard_world);
       for (int n = n0 + gid; n < n1; n += ng) riccati_cut_node(T, Q, n, mu, delta, Ld, lane, GS, 3);
       int bad = 0;
@@ -3616,10 +3646,10 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
       if (!mk_n(A, n)) continue;
       NodePre R;
       node_prefetch(Q, n, delta, lane, GS, R);
-      if (riccati_node(T, Q, n, mu, delta, Ld, lane, GS, false, R)) T.fset(0, 1);
+      if (riccati_node(T, Q, n, mu, delta, Ld, lane, GS, false, R)) T.fset(0, FSET);
     }
     T.sync();
-    if (T.fget(0) && (!sh_on(A) || k < A.cut_level - 1)) return 1;
+    if ((T.fget(0) == FSET) && (!sh_on(A) || k < A.cut_level - 1)) return 1;
   }
   if (FREE_ROOT) {
     // free initial state: its step minimises the root's value function (which holds the arrival cost),
@@ -3652,10 +3682,10 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
         y[i] = t / L[i * NX + i];
       }
       for (int a = 0; a < NA; ++a) Nd[ND_DXT + a] = (a < NX) ? y[a] : 0.0;
-      if (bad) T.fset(0, 1);
+      if (bad) T.fset(0, FSET);
     }
     T.sync();
-    if (T.fget(0)) return 1;
+    if ((T.fget(0) == FSET)) return 1;
   }
   return 0;
 }
@@ -4426,9 +4456,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
 template <bool FINE>
 DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   const KArgs& A = *Q.A;
-  T.sync();                                  // (every thread has read the previous sweep's verdict, see riccati_backward)
-  if (T.tid == 0) T.fset(1, 0);
-  T.sync();
+  const int FSET = T.flag_begin(1);         // (every thread has read the previous sweep's verdict, see riccati_backward)
   long long pc0 = prof_clock();
 #if DOMPC_PROFILE
 #define DOMPC_PS(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
@@ -4471,10 +4499,10 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
       if (sh_on(A) && !mine) continue;                  // sharded: another rank's edge (no workgroup barrier inside)
       if constexpr (DENSE_EDGE) {
         static_assert(!DENSE_EDGE || dae::DG_SIZE == DAE_NEED, "LDS working set of the dense DAE path");
-        if (eval_edge_dae(T, Q, mine ? e : -1, mu, lane, T.gs, Ld)) T.fset(1, 1);
+        if (eval_edge_dae(T, Q, mine ? e : -1, mu, lane, T.gs, Ld)) T.fset(1, FSET);
         continue;
       }
-      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld, staged_e, mm)) T.fset(1, 1);
+      if (eval_edge_coop(T, Q, mine ? e : -1, (en < A.n_edges && mk_e(A, en)) ? en : -1, mu, lane, T.gs, Ld, staged_e, mm)) T.fset(1, FSET);
     }
   }
   T.sync();
@@ -4499,7 +4527,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
   if (sh_on(A)) {
     // cut parents: sum the child-dependent parts over the ranks; the failure flag rides along
     double* fl = A.xbuf + x_asm(A) + A.n_cut * ASM_N;
-    for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && T.fget(1)) ? 1.0 : 0.0;
+    for (int w = T.tid; w < A.shard_world; w += T.nt) fl[w] = (w == A.shard_rank && (T.fget(1) == FSET)) ? 1.0 : 0.0;
     T.xchg(x_asm(A), A.n_cut * ASM_N + A.shard_world);
     const int n0 = A.level_node_start[A.cut_level - 1];
     for (int ci = T.tid; ci < A.n_cut; ci += T.nt) assemble_finish(Q, n0 + ci, A.xbuf + x_asm(A) + ci * ASM_N);
@@ -4508,7 +4536,7 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     T.sync();
     return bad;
   }
-  return T.fget(1);
+  return (T.fget(1) == FSET);
 }
 
 // Barrier-parameter change at an unchanged iterate: only the barrier gradients move, linearly in mu.

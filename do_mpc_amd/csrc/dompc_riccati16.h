@@ -434,9 +434,7 @@ __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double de
   const KArgs& A = *Q.A;
   const int ng = T.nt / 64, gid = group_index(T.tid, 64), lane = T.tid % 64;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / 64) * EL_SIZE;      // this wavefront's LDS region: two staging buffers
-  T.sync();
-  if (T.tid == 0) T.fset(0, 0);
-  T.sync();
+  const int FSET = T.flag_begin(0);
   const int cl = A.chain_level < A.N ? A.chain_level : A.N;
   {
     const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
@@ -459,14 +457,14 @@ __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double de
           stage_edge(Q, A.node_child_start[np], lane, Ld + (buf ^ 1) * ES_STAGE);
         }
         Val Vn;
-        if (node(Q, A.level_node_start[k] + s_, mu, delta, lane, in, Ld + buf * ES_STAGE, &V, Vn)) { T.fset(0, 1); break; }
+        if (node(Q, A.level_node_start[k] + s_, mu, delta, lane, in, Ld + buf * ES_STAGE, &V, Vn)) { T.fset(0, FSET); break; }
         V = Vn;
         if (k > cl) in = nx;
         buf ^= 1;
       }
     }
     T.sync();
-    if (T.fget(0)) return 1;
+    if ((T.fget(0) == FSET)) return 1;
   }
   for (int k = cl - 1; k >= 0; --k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
@@ -476,10 +474,10 @@ __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double de
       stage_edge(Q, A.node_child_start[n], lane, Ld);
       staged_ready();
       Val Vn;
-      if (node(Q, n, mu, delta, lane, in, Ld, nullptr, Vn)) T.fset(0, 1);
+      if (node(Q, n, mu, delta, lane, in, Ld, nullptr, Vn)) T.fset(0, FSET);
     }
     T.sync();
-    if (T.fget(0)) return 1;
+    if ((T.fget(0) == FSET)) return 1;
   }
   return 0;
 }

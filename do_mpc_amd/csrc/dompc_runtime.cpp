@@ -782,7 +782,7 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   bool spread = senv ? atoi(senv) != 0 : (!h->sharded && (B == 1 || (B <= 4 && h->d.n_edges >= 2048)));
   if (spread && !wenv) {
     K = 8 * (int)lround(1.5 * sqrt((double)h->d.n_edges / 45.0));
-    if (K > h->d.n_edges / 8) K = h->d.n_edges / 8;
+    if (K > h->d.n_edges / 7) K = h->d.n_edges / 7;
     if (K > 256 / B) K = 256 / B;
     if (K < 1) K = 1;
   }
@@ -798,7 +798,9 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
     HIPCHK(h, hipMemsetAsync(A.wide_flags, 0, sizeof(int32_t) * 8 * 64, st));
   }
 #endif
-  if (launch(h, A, grid, (A.wide > 1 || h->sharded) ? fit_block(h, 256) : block, stream)) return 1;
+  int wide_block = 256;
+  if (const char* wb = getenv("DOMPC_WIDE_BLOCK")) { const int v = atoi(wb); if (v == 64 || v == 128 || v == 256 || v == 512) wide_block = v; }   // (512 needs a code object built with -DDOMPC_MAXBLOCK=512)
+  if (launch(h, A, grid, (A.wide > 1 || h->sharded) ? fit_block(h, wide_block) : block, stream)) return 1;
 #ifndef DOMPC_HOST_EMU
   if (h->sharded) return serve_exchanges(h, (hipStream_t)stream);
 #endif
