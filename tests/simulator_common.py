@@ -171,3 +171,20 @@ def check_stiff_plant(hostemu):
         assert "did not reach t_step" in str(e)
     else:
         raise AssertionError("make_step accepted a sample that ran into the step limit")
+
+
+def check_z_start_does_not_depend_on_call_history(hostemu):
+    """the Newton iteration for the algebraic states of a DAE plant starts from `simulator.z0` in every make_step_batch call -
+    a batch of unrelated samples must not depend on which samples occupied its rows in an earlier call.  Double inverted pendulum: two
+    samples, then the same two in the other order: the rows of the second call are bit for bit the permuted rows of the first.
+    `carry_z=True` (rows = the same trajectories, what make_step uses) continues from the previous values instead."""
+    name = "dip"
+    ex = CASES[name]
+    sim = make_simulator(name, hostemu)
+    X = np.vstack([ex.X0, ex.X0 * 0.5 + 0.1])
+    u = np.array(U_TEST[name])
+    a = sim.make_step_batch(X, u)
+    b = sim.make_step_batch(X[::-1].copy(), u)
+    assert a["status"].tolist() == [0, 0] and np.array_equal(b["x"], a["x"][::-1])
+    c = sim.make_step_batch(X[::-1].copy(), u, carry_z=True)       # rows continue from the values row 0 / 1 found last: same roots
+    assert np.max(np.abs(c["x"] - b["x"])) < 1e-9

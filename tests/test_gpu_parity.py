@@ -587,6 +587,56 @@ def test_members_of_the_timed_batch_equal_oracle_solves():
     assert late <= len(members) // 2, late
 
 
+def test_whole_chip_placement_gives_the_bits_of_the_one_xcd_placement(monkeypatch):
+    """KArgs::wide_spread (round 5): the workgroups of ONE problem on all XCDs (the default for a single problem) against the placement
+    of round 4 (K workgroups of one XCD) - another mapping of workgroups to the same work items and another barrier flavour (with L2
+    write-back), the same arithmetic in the same order: identical solution, multipliers and iteration count."""
+    ex = CASES["industrial_poly"]
+    out = []
+    for spread, K in (("0", "16"), ("1", "16"), ("1", "24")):
+        monkeypatch.setenv("DOMPC_WIDE_SPREAD", spread)
+        monkeypatch.setenv("DOMPC_WIDE", K)
+        mpc = make_mpc("industrial_poly")
+        mpc.x0 = ex.X0
+        mpc.set_initial_guess()
+        mpc.make_step(ex.X0)
+        assert mpc.solver_stats["success"]
+        out.append((mpc.opt_x_num.master.copy(), np.array(mpc.lam_g_num), mpc.solver_stats["iter_count"]))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    # another number of workgroups regroups the partial sums of the reductions: same iterations, solution to rounding
+    assert out[2][2] == out[0][2] and pc.relerr(out[2][0], out[0][0]) < 1e-9
+
+
+def test_batch_code_object_is_checked_against_the_general_one(tmp_path):
+    """the runtime launches `<name>_batch.hsaco` for one-wavefront batches whenever that file exists; a sibling built from other
+    sources / for another model must not be used.  dompc_batch_object_state: 1 for the prebuilt pair, 2 (and a warning) when the sibling
+    is the batch object of ANOTHER model class."""
+    import shutil
+    import warnings
+    from do_mpc_amd import build
+    from do_mpc_amd.solver import HipIpmSolver
+    a = make_mpc("batch_reactor", max_batch=4096)
+    assert a.S.batch_object_state == 1
+    b = make_mpc("CSTR", max_batch=4096)
+    src_general, wrong_sibling = a.S.code_object_path, b.S.code_object_path[:-len(".hsaco")] + "_batch.hsaco"
+    d = tmp_path / "m"
+    d.mkdir()
+    shutil.copy(src_general, d / "dompc_gfx950.hsaco")
+    shutil.copy(wrong_sibling, d / "dompc_gfx950_batch.hsaco")
+    ctor = dict(a.S._ctor)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s = HipIpmSolver(ctor.pop("structure"), ctor.pop("header_text"), ctor.pop("model_hash"), _lib_path=build.runtime_library(),
+                         _code_object=str(d / "dompc_gfx950.hsaco"), **{k: v for k, v in ctor.items() if k in ("nlpsol_opts", "device", "max_batch", "block_threads")})
+    assert s.batch_object_state == 2 and any("not used" in str(x.message) for x in w)
+    # ... and the handle still solves batches (with the general object)
+    ex = CASES["batch_reactor"]
+    r = s.solve_batch(np.tile(a.opt_x_num.master * 0 + 0.0, (2, 1)) + 0.0, a._lb_opt_x.master, a._ub_opt_x.master, a._nlp_cons_lb, a._nlp_cons_ub,
+                      np.tile(a.opt_p_num.master, (2, 1)))
+    assert r["stats"].shape == (2,)
+    s.close()
+
+
 def test_control_interval_with_80_unknowns_same_iterates_as_the_oracle():
     pc.check_interval_with_more_than_64_unknowns(make_mpc)
 

@@ -211,3 +211,7 @@ def test_implicit_method_matches_scipy_radau(name):
 
 def test_stiff_plant_switches_to_the_implicit_method():
     sc.check_stiff_plant(hostemu=False)
+
+
+def test_newton_start_of_algebraic_states_does_not_depend_on_call_history():
+    sc.check_z_start_does_not_depend_on_call_history(hostemu=False)
