@@ -781,10 +781,12 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   const char* senv = getenv("DOMPC_WIDE_SPREAD");
   bool spread = senv ? atoi(senv) != 0 : (!h->sharded && (B == 1 || (B <= 4 && h->d.n_edges >= 2048)));
   if (spread && !wenv) {
-    K = 8 * (int)lround(1.5 * sqrt((double)h->d.n_edges / 45.0));
-    if (K > h->d.n_edges / 7) K = h->d.n_edges / 7;
-    if (K > 256 / B) K = 256 / B;
-    if (K < 1) K = 1;
+    int Ks = 8 * (int)lround(1.5 * sqrt((double)h->d.n_edges / 45.0));
+    if (Ks > h->d.n_edges / 7) Ks = h->d.n_edges / 7;
+    if (Ks > 256 / B) Ks = 256 / B;
+    // (fewer than eight workgroups: the problem is too small for the whole chip - its few workgroups stay on one XCD with the light
+    //  barrier; measured: CSTR nominal, 20 edges, 4.9 ms on one XCD against 5.6 ms with its two workgroups on two XCDs)
+    if (Ks >= 8 || senv) K = Ks < 1 ? 1 : Ks; else spread = false;
   }
   if (K > (spread ? 256 : 32)) K = spread ? 256 : 32;
   if (spread && (int64_t)B * K > 2048) spread = false;       // (reduction partials: 64 x 32 workgroup rows)

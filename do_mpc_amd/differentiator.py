@@ -287,13 +287,13 @@ class DoMPCDifferentiator:
             st.LICQ = self._check_licq(x, lam, p0, g_act, x_act)
         if cfg.active_set_reduction:
             # inactive bounds leave the system (the reference removes their rows and columns; set_lam_zero: their multipliers are
-            # exactly zero), active ones are held like equalities: Sigma = z / distance with z >= 1 and a distance <= tol
+            # exactly zero), active ones are held like equalities: Sigma = z / distance >= 1e9 (z >= 1e3, distance <= tol: the size a converged active bound has)
             zl, zu, lb, ub = zl.copy(), zu.copy(), lb.copy(), ub.copy()
             zl[x_in], zu[x_in], lb[x_in], ub[x_in] = 0.0, 0.0, -np.inf, np.inf
             lo = np.abs(x - mpc._lb_opt_x.master) <= cfg.active_set_tol
             up = np.abs(x - mpc._ub_opt_x.master) <= cfg.active_set_tol
-            zl[lo] = np.maximum(zl[lo], 1.0)
-            zu[up] = np.maximum(zu[up], 1.0)
+            zl[lo] = np.maximum(zl[lo], 1e3)
+            zu[up] = np.maximum(zu[up], 1e3)
             # inequality rows of g (nl_cons): an inactive row loses its bounds (its slack is then a free variable: the row leaves
             # the system), an active one becomes an equality at its value
             lbg, ubg = np.array(lbg, float), np.array(ubg, float)

@@ -210,10 +210,10 @@ def check_active_set_reduction(make_mpc, name, **over):
     used[dummy] = False
     got = np.asarray(dxdp)[used][:, cols]
     err = np.max(np.abs(got - ref[used]))
-    assert err < 2e-5 * max(1.0, np.max(np.abs(ref[used]))), err
+    assert err < 1e-8 * max(1.0, np.max(np.abs(ref[used]))), err          # (measured 5e-11 / 7e-15 / 8e-12 on the host emulation)
     # the variables held by an active bound do not move
     if x_act.size:
-        assert np.max(np.abs(np.asarray(dxdp)[x_act][:, cols])) < 1e-5 * max(1.0, np.max(np.abs(ref)))
+        assert np.max(np.abs(np.asarray(dxdp)[x_act][:, cols])) < 1e-7 * max(1.0, np.max(np.abs(ref)))
     return err
 
 

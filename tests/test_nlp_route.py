@@ -141,3 +141,20 @@ def test_a_term_in_the_parameters_only_changes_nothing():
         m.x0 = osc.X0
         m.set_initial_guess()
     assert np.array_equal(a.make_step(osc.X0), b.make_step(osc.X0))
+
+
+def test_every_attribute_the_reference_exposes_at_this_boundary_exists():
+    """SURVEY.md 8(b) "attributes other code reads (must survive the rewrite)": do_mpc/differentiator/_nlpdifferentiator.py:803-841,
+    do_mpc/data.py:246-374, do_mpc/optimizer.py:448-481 read these off the optimizer object."""
+    mpc = _mpc(setup_now=True)
+    ps = mpc.structure
+    for name in ("nlp_obj", "nlp_cons", "nlp_cons_lb", "nlp_cons_ub", "opt_x", "opt_p", "opt_x_scaling", "opt_x_unscaled", "_lb_opt_x",
+                 "_ub_opt_x", "lb_opt_x", "ub_opt_x", "opt_x_num", "opt_x_num_unscaled", "opt_g_num", "lam_g_num", "lam_x_num", "opt_p_num",
+                 "opt_aux_num", "aux_struct", "n_opt_x", "n_opt_p", "n_opt_aux", "n_opt_lagr", "n_eps", "scenario_tree", "S", "settings",
+                 "flags", "data", "solver_stats"):
+        assert hasattr(mpc, name), name
+    assert (mpc.n_opt_x, mpc.n_opt_p, mpc.n_opt_lagr) == (ps.n_opt_x, ps.n_opt_p, ps.n_g)
+    assert mpc.opt_x.shape == (mpc.n_opt_x, 1) and mpc.opt_p.shape == (mpc.n_opt_p, 1) and mpc.aux_struct.shape == (mpc.n_opt_aux, 1)
+    assert np.asarray(mpc.nlp_cons_lb).shape == (mpc.n_opt_lagr,) and mpc.nlp_cons.shape == (mpc.n_opt_lagr, 1)
+    for key in ("structure_scenario", "n_branches", "n_scenarios", "parent_scenario", "branch_offset"):
+        assert key in mpc.scenario_tree, key
