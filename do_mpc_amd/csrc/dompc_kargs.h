@@ -5,6 +5,7 @@
 #include "../../include/dompc_ipm.h"
 
 namespace dompc {
+enum { WIDE_BAR_STRIDE = 64 };
 enum { EP_PARENT = 0, EP_CHILD, EP_LEVEL, EP_WOFF, EP_PIDX, EP_ROW0, EP_XOFF_PARENT, EP_UOFF_PARENT, EP_XOFF_CHILD, EP_EPSOFF_PARENT,
        EP_OMEGA_LO, EP_OMEGA_HI, EP_N = 16 };
 // Structure tables of the problem class: written once by dompc_create(), never by a kernel.  In device code they are
@@ -53,7 +54,7 @@ struct KArgs {
   // (16 uints apart), reduction partials ([2][wide][12] doubles) and shared flags (8 ints)
   int32_t wide;
   int32_t pool_doubles;      // doubles in the dynamic LDS pool of a workgroup: max(waves * EL_SIZE, RED_MAX * threads)
-  uint32_t* wide_bar;
+  uint32_t* wide_bar;        // WIDE_BAR_STRIDE words per slot: [0] arrival counter, [1] XCD mask, [2] verdict, [8 + x] / [16 + x] / [24 + x]: arrival counter, release word and workgroup count of XCD x (two-level barrier)
   double* wide_partials;
   int32_t* wide_flags;
   // sweep (mode 2)

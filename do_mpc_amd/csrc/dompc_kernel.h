@@ -302,6 +302,8 @@ struct Thr {
   // they share one L2, so the release side of the barrier needs no L2 write-back - the stores only have to have left the CU
   mutable bool light = false;
   int pool = 0;     // doubles in the workgroup's LDS pool (device; KArgs::pool_doubles)
+  // two-level barrier (DOMPC_HIER_BARRIER, several XCDs): workgroups of the problem on this XCD / XCDs that hold any (0: flat barrier)
+  mutable int xcc = 0, n_local = 0, n_xcd = 0;
   // flags: LDS words in a one-workgroup problem; global words shared by the K workgroups of a wide problem - those are
   // read and written with agent-scope atomics (a plain load could be served from this CU's L1).
   DOMPC_DEV void fset(int i, int v) const {
@@ -341,6 +343,56 @@ struct Thr {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       ++gen;
+#if DOMPC_HIER_BARRIER
+      if (n_xcd > 1) {
+        // Two-level barrier for a problem whose workgroups sit on several XCDs (whole-chip wide mode).  Level 1, inside an XCD: the
+        // workgroups arrive on a counter that lives in THEIR L2 (workgroup-scope read-modify-write: executed by the L2's atomic
+        // unit, never cached in an L1) - every one of them has drained its stores into that L2 before (vmcnt(0) above).  The LAST
+        // arrival of the XCD is its leader for this round: ONE L2 write-back per XCD (instead of one per workgroup), arrival on the
+        // device-wide counter (8 participants instead of K), spin there, then it releases its XCD through a word in the L2.  The
+        // others poll that word with read-modify-writes (L2 round trips instead of trips to memory).  Everybody ends with the
+        // agent-scope acquire (its CU's L1; the L2 was invalidated by whoever came first).
+        if (ltid == 0) {
+          // (its own counters and its own round number: the two barriers of the census ran on the flat counter before this one was set up)
+          const unsigned hr = gen - 2u;
+          const unsigned old = __hip_atomic_fetch_add(bar + 8 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          long long spins = 0;
+          if (old + 1u == hr * (unsigned)n_local) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(bar + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = hr * (unsigned)n_xcd;
+            while (__hip_atomic_load(bar + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > 40000000ll || __hip_atomic_load(flags + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(flags + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_exchange(bar + 16 + xcc, hr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            // (the poll must be a read-modify-write executed by the L2: the compiler turns an atomic add of 0 into an atomic LOAD,
+            //  which at workgroup scope is served by this CU's L1 and never sees the leader's write - hence the instruction itself)
+            auto poll = [&]() {
+              unsigned v;
+              asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(bar + 16 + xcc), "v"(0u) : "memory");
+              return v;
+            };
+            while (poll() < hr) {
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > 80000000ll || ((spins & 1023) == 0 && __hip_atomic_load(flags + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(flags + 7, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+        }
+        __syncthreads();
+        return;
+      }
+#endif
       if (ltid == 0) {
         if (!light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // (buffer_wbl2 sc1: 1.7 - 6.5 us per barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -416,6 +468,9 @@ extern __shared__ double lds_pool[];
 __shared__ double lds_filt[2 * MAX_FILTER];
 __shared__ int lds_flags[8];
 __shared__ int lds_b;
+#ifndef DOMPC_HIER_BARRIER
+#define DOMPC_HIER_BARRIER 0        // 1: two-level barrier (per-XCD counters in the L2, one write-back and one device-wide arrival per XCD) when the workgroups of a problem sit on several XCDs
+#endif
 #ifndef DOMPC_LIGHT_BARRIER
 #define DOMPC_LIGHT_BARRIER 1       // wide mode: barrier without the L2 write-back when the problem's workgroups share an XCD (0: always write back)
 #endif
@@ -441,20 +496,35 @@ __device__ inline Thr make_thr(const KArgs& A) {
   const int slot = slot_of_block(A);
   return Thr{j * DOMPC_BDIM + (int)threadIdx.x, K * DOMPC_BDIM, (ldsd*)lds_pool, (ldsd*)lds_filt,
              wide ? A.wide_flags + slot * 8 : lds_flags, (ldsd*)lds_pool, lds_prof, 64,
-             (int)threadIdx.x, DOMPC_BDIM, j, K, wide ? A.wide_bar + slot * 16 : nullptr,
+             (int)threadIdx.x, DOMPC_BDIM, j, K, wide ? A.wide_bar + slot * WIDE_BAR_STRIDE : nullptr,
              wide ? A.wide_partials + (int64_t)slot * 2 * K * RED_MAX : nullptr, 0u, 0u, make_xctx(A), 0u, nullptr,
-             (wide && DOMPC_LIGHT_BARRIER) ? __hip_atomic_load(A.wide_bar + slot * 16 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u : false,
+             (wide && DOMPC_LIGHT_BARRIER) ? __hip_atomic_load(A.wide_bar + slot * WIDE_BAR_STRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u : false,
              A.pool_doubles};
 }
 // wide mode, once per launch: do all workgroups of this problem run on one XCD?  Every workgroup publishes its XCC id
 // (hardware register), the first workgroup writes the verdict (word 2 of the slot's barrier block: 1 = one XCD, 2 = several)
 // between two full barriers; make_thr of the outlined phases reads it back.  Placement is NOT assumed (the dispatcher puts
 // block b on XCD b % 8 today, slot_of_block): on any other placement the barrier keeps its L2 write-back.
+// two-level barrier: this workgroup's XCD, the number of the problem's workgroups on it and the number of XCDs that hold any - from the
+// census words (valid after the census of the launch; the outlined phases rebuild their Thr and read them again)
+__device__ inline void hier_setup(const Thr& T) {
+#if DOMPC_HIER_BARRIER
+  if (!WIDE_OK || T.nwg <= 1 || T.light) { T.n_xcd = 0; return; }
+  T.xcc = (int)((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
+  const unsigned m = __hip_atomic_load(T.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  T.n_xcd = __builtin_popcount(m & 0xffu);
+  T.n_local = (int)__hip_atomic_load(T.bar + 24 + T.xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (T.n_xcd <= 1 || T.n_local <= 0 || (m >> 8)) T.n_xcd = 0;         // (one XCD: the light barrier; an XCC id above 7: flat barrier)
+#else
+  (void)T;
+#endif
+}
 __device__ inline void xcd_census(const Thr& T) {
   if (!WIDE_OK || T.nwg <= 1 || !DOMPC_LIGHT_BARRIER) return;
   if (T.ltid == 0) {
     const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;          // HW_REG_XCC_ID[3:0]
     __hip_atomic_fetch_or(T.bar + 1, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (DOMPC_HIER_BARRIER) __hip_atomic_fetch_add(T.bar + 24 + (xcc & 7u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   T.sync();
   if (T.tid == 0) {
@@ -463,6 +533,7 @@ __device__ inline void xcd_census(const Thr& T) {
   }
   T.sync();
   T.light = __hip_atomic_load(T.bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
+  hier_setup(T);
 }
 // wave-uniform copies of values that reach an outlined function in vector registers
 __device__ inline int ufl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -4911,6 +4982,7 @@ struct PhaseRet3 { unsigned gen, nred, xseq; double v0, v1, v2; };
 #define DOMPC_PHASE_PROLOGUE                                                        \
   const KArgs A = kernel_args(kp);                                                  \
   Thr T = make_thr(A);                                                              \
+  hier_setup(T);                                                                    \
   T.kp = kp;                                                                        \
   T.gen = ufl(gen); T.nred = ufl(nred); T.xseq = ufl(xseq);                         \
   Prob Q = make_prob(A, ufl(slot), A.p + (int64_t)ufl(b) * A.n_opt_p);              \

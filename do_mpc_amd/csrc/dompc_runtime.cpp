@@ -545,7 +545,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     }
   }
   // wide mode (small batches): up to 64 slots x 32 workgroups
-  if (dev_alloc(h, (void**)&A.wide_bar, sizeof(uint32_t) * 16 * 64)) return fail(1);
+  if (dev_alloc(h, (void**)&A.wide_bar, sizeof(uint32_t) * dompc::WIDE_BAR_STRIDE * 64)) return fail(1);
   if (dev_alloc(h, (void**)&A.wide_flags, sizeof(int32_t) * 8 * 64)) return fail(1);
   if (dev_alloc(h, (void**)&A.wide_partials, sizeof(double) * 64 * 2 * 32 * 12)) return fail(1);
   for (int i = 0; i < 8; ++i)
@@ -796,7 +796,7 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
     A.wide_spread = spread ? 1 : 0;
     grid = spread ? B * K : ((B + 7) / 8) * 8 * K;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(h, hipMemsetAsync(A.wide_bar, 0, sizeof(uint32_t) * 16 * 64, st));
+    HIPCHK(h, hipMemsetAsync(A.wide_bar, 0, sizeof(uint32_t) * dompc::WIDE_BAR_STRIDE * 64, st));
     HIPCHK(h, hipMemsetAsync(A.wide_flags, 0, sizeof(int32_t) * 8 * 64, st));
   }
 #endif
