@@ -3763,7 +3763,19 @@ DOMPC_PHASE int riccati_backward(const Thr& T, const Prob& Q, double mu, double 
 
 // Forward sweep: steps for node variables, then per edge the collocation steps and multipliers.
 // One group of lanes per node (level by level), then one group per edge.
-DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double delta) {
+#ifndef DOMPC_ADJ_REFINE
+#define DOMPC_ADJ_REFINE 1            // adjoint recovery of the continuity multipliers (0: the steps of round 4, d nu = P dx + p everywhere)
+#endif
+#ifndef DOMPC_ADJ_MU
+#define DOMPC_ADJ_MU 10.0             // used from mu <= DOMPC_ADJ_MU * tol on: the last one or two levels of the barrier parameter (default tolerance:
+#endif                                // 2.5e-9 and 9.1e-10), where Sigma reaches 1e9 ... 1e11 (measured: the same iteration counts from 1e-8 to 1e-3, half the cost of 1e-5)
+// (its own instantiation of the forward pass - on the device its own outlined phase: the per-edge part of the other one keeps its registers)
+DOMPC_DEV inline bool forward_adjoint(const Prob& Q, double mu) {
+  constexpr bool ok = DOMPC_ADJ_REFINE && NI == 1 && M > 0 && DEG > 0 && !DENSE_EDGE && !RT_CUSTOM && !FREE_ROOT && !EPS_GLOBAL;
+  return ok && !sh_on(*Q.A) && !(Q.soc & 2) && mu > 0.0 && mu <= DOMPC_ADJ_MU * Q.A->opt.tol;
+}
+template <bool ADJ>
+DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, double delta) {
   const KArgs& A = *Q.A;
   const int GS = T.gs, ng = T.nt / GS, gid = group_index(T.tid, GS), lane = T.tid % GS;
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / GS) * EL_SIZE;
@@ -4044,6 +4056,34 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
                                        (__attribute__((address_space(3))) void*)(Ld + RF_MOC + 128 * q), 16, 0, 0);
   };
 #endif
+  // ---- adjoint recovery of the continuity multipliers (round 5, DOMPC_ADJ_REFINE).  The chain walk forms the step of the multipliers
+  // of a node's incoming continuity rows as d nu = P dx + p.  Near the solution P carries the Sigma entries of active bounds further
+  // down the chain (1e9 ... 1e11) in rank-one terms a a' whose contribution a (a' dx) is tiny in exact arithmetic: a' dx is a sum of
+  // terms of size 1e-3 that cancel to 1e-11 and keeps an absolute error of 1e-19, times 2e11 = 2e-8 - the floor of the dual
+  // residual (measured on member 2048 of the bench batch: the x rows of the linear system are left with 1.9e-7 where
+  // the u rows and the rows of the collocation unknowns have 1e-10 ... 1e-13).  The x row of the Newton system of node c itself has
+  // no such terms: with every other step known it determines d nu_c,
+  //     d nu_c = rx_c + (Sigma_x + delta) dx_c + sum over the child edges e' of c [ G_y' dlambda_w + (omega H_l + H_nl) dy + Jd' dyd ]_x  (+ omega H_m dx_c at a leaf),
+  // and G_y has only the collocation coefficients in its x columns (-C_0j, -D_0).  The edges are processed from the last stage
+  // upwards (all child edges of a node before its incoming edge); the shares are kept in the p slot of the node records, which
+  // nobody reads after the chain walk (first the node's own terms, then - once its incoming edge has used them - that edge's share
+  // for the parent: one writer per slot, sums in the order of the children, the same bits in every launch shape).
+  // Measured (B = 16 384, 12 members against oracle solves): every member stops in the oracle's iteration (without: 5 of 12 one to
+  // four iterations later), mean iteration count 56.574 -> 56.317, kernel time + 1.0 % (this instantiation has no two-edge path).
+  constexpr bool adj = ADJ;            // (decided by the caller: forward_adjoint())
+  if (adj) {
+    for (int it = T.tid; it < A.n_nodes * NX; it += T.nt) {
+      const int n = it / NX, a = it % NX, g = A.node_x_off[n] + a;
+      const double xv = Q.x[g], l = Q.lb[g], u = Q.ub[g];
+      double t = Q.rd[g] + Q.zl[g] - Q.zu[g] + bar_grad(xv, l, u, mu) + (sigma_of(xv, l, u, Q.zl[g], Q.zu[g]) + delta) * Q.dx[g];
+      if (A.node_child_count[n] == 0) {
+        const double* S_ = Q.ES(A.node_in_edge[n]);
+        for (int b = 0; b < NX; ++b) t += S_[ES_MH + a * NX + b] * Q.dx[A.node_x_off[n] + b];
+      }
+      Q.ND(n)[ND_PV + a] = t;
+    }
+    T.sync();
+  }
 #ifndef DOMPC_HOST_EMU
 #ifndef DOMPC_FE2
 #define DOMPC_FE2 1                 // per-edge part of the forward pass: two edges per wavefront (0: one)
@@ -4059,7 +4099,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
   constexpr bool FE2 = (DOMPC_FE2 != 0) && MO_LDS && M > 0 && NI == 1 && DEG > 0 && !DENSE_EDGE && DOMPC_SHARD == 0 && NW <= 32 && NA <= 16 &&
                        NA + NU <= 16 && NE <= 32 && (MOC_STAGE - MOC_SIZE >= 1 + DOMPC_DYN_NC) && (FE_TAB + 128 <= EL_SIZE) &&
                        (PT_STRIDE <= 2 * FE_SS) && LU_N < NW;
-  if (FE2 && GS == 64) {
+  if (FE2 && GS == 64 && !adj) {
     typedef __attribute__((address_space(3))) unsigned short ldsu16_;
     const int h = lane >> 5, l32 = lane & 31;
     ldsd* Lv = Ld + h * FE_HV;
@@ -4292,7 +4332,31 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     cr_ = Q.c[A.edge_row0[e] + (lane < NW ? lane : 0)];
   };
   (void)fw_staged; (void)have_pre; (void)cr0;
-  for (int e = gid; e < A.n_edges; e += ng) {
+  // Order of the edges.  Without the adjoint recovery the edges are independent: group g takes e = g, g + ng, ...  With it every edge comes
+  // after the child edges of its child node: segment 0 - each group walks its scenario chains from the last stage up to the first chain
+  // level (no barrier: one wavefront owns a chain); segments 1 ... cl - the branching levels from the lowest to the root, the edges of a
+  // level over the groups, a barrier after each.  Edge (k, s) of the chain levels = first edge of level k + s (as in the chain walk).
+  // (the chain levels have S_ch edges each, numbered level by level: one subtraction per step, no table look-ups on the serial path)
+  const int S_ch = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
+  auto lvl_e0 = [&](int k) { return k < A.N ? A.node_child_start[A.level_node_start[k]] : A.n_edges; };
+  const int nseg = adj ? cl + 1 : 1;
+  const int e_cl = adj ? lvl_e0(cl) : 0, e_bot = e_cl + (A.N - 1 - cl) * S_ch;      // first edge of the first / the last chain level
+  for (int seg = 0; seg < nseg; ++seg) {
+  const int e_lo = (adj && seg > 0) ? lvl_e0(cl - seg) : 0, e_hi = (adj && seg > 0) ? lvl_e0(cl - seg + 1) : A.n_edges;
+  auto seq_first = [&]() -> int {
+    if (!adj) return gid < A.n_edges ? gid : -1;
+    if (seg == 0) return (cl < A.N && gid < S_ch) ? e_bot + gid : -1;
+    return e_lo + gid < e_hi ? e_lo + gid : -1;
+  };
+  auto seq_next = [&](int e) -> int {
+    if (adj && seg == 0) {
+      if (e - S_ch >= e_cl) return e - S_ch;
+      return e - e_cl + ng < S_ch ? e_bot + (e - e_cl) + ng : -1;
+    }
+    return e + ng < e_hi ? e + ng : -1;
+  };
+  for (int e = seq_first(), e_nx = -1; e >= 0; e = e_nx) {
+    e_nx = seq_next(e);
     if (!mk_e(A, e)) continue;
     const int n = A.edge_parent[e], cn = A.edge_child[e];
     const double* Nd = Q.ND(n);
@@ -4370,8 +4434,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
     if (MO_LDS) {
       // everything of this edge is in registers: hand the staging area to the next edge of this wavefront
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int e_nx = e + ng;
-      if (e_nx < A.n_edges && mk_e(A, e_nx)) {
+      if (e_nx >= 0 && mk_e(A, e_nx)) {
         stage_fw(e_nx);
         fw_staged = e_nx;
         if (GS > 1) { load_dy(e_nx, dy_n, dnu_n, cr_n); pre_n = true; }
@@ -4395,7 +4458,20 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
       }
     }
     DOMPC_PF(17)
-    if (!chain_edge)
+    if (adj) {
+      // adjoint recovery: the sums of the child edges of `cn` are complete (they were processed before this edge)
+#ifndef DOMPC_HOST_EMU
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      T.gsync();
+      const int cs_ = A.node_child_start[cn], cc_ = A.node_child_count[cn];
+      for (int a = lane; a < NX; a += GS) {
+        double t = Nc[ND_PV + a];                                           // (the node's own terms)
+        for (int j = 0; j < cc_; ++j) t += Q.ND(A.edge_child[cs_ + j])[ND_PV + a];      // + the shares of its child edges, in their order
+        Ld[RF_DNU + a] = t;
+        Q.dlam[row0 + NW + a] = t;
+      }
+    } else if (!chain_edge)
       for (int a = lane; a < NX; a += GS) {
         double t = Nc[ND_PV + a];
 #pragma unroll
@@ -4490,6 +4566,7 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
             t = Ld[RF_RHS + r];
           }
           Q.dlam[row0 + r] = t;
+          if (adj) Ld[RF_G + r] = t;            // (the g vector is dead: d lambda_w for the parent's sum below)
         }
       }
     }
@@ -4501,12 +4578,42 @@ DOMPC_PHASE void riccati_forward(const Thr& T, const Prob& Q, double mu, double 
         if (!EPS_GLOBAL && nl_slack(i) >= 0) t -= Q.sgn[e * NE1 + i] * Q.dx[A.node_eps_off[n] + nl_slack(i)];      // (shared slacks: their step is part of the residual, eps_schur_apply)
         Q.ds[e * NE1 + i] = t;
         Q.dlam[row0 + NW + NX + i] = (S_[ES_SIGS + i] + delta) * t + S_[ES_RSN + i];
+        if (adj) Ld[RF_RHS + i] = Q.dlam[row0 + NW + NX + i];      // (d y_d for the parent's sum)
       }
     }
     T.gsync();
+    if (adj && M > 0) {
+      // this edge's share of the x rows of its parent node: G_y' dlambda_w (x columns: -C_0j on the collocation rows, -D_0 on the
+      // continuity rows of the element), the x rows of omega H_l + H_nl times dy, Jd' dyd
+      const double omh_ = A.edge_omega[e] * Q.sf;
+      for (int a = lane; a < NX; a += GS) {
+        double t = -DOMPC_D[0] * Ld[RF_G + LU_N + a];
+#pragma unroll
+        for (int j = 1; j <= DEG; ++j) t -= DOMPC_C[0 * (DEG + 1) + j] * Ld[RF_G + (j - 1) * NX + a];
+        for (int b = 0; b < NA; ++b) {
+          const int ip = symi(a, b, NA);
+          double hv = omh_ * (MO_COMPACT ? (double)Ld[RF_IMG + MO_LT + 1 + NA + ip] : Q.MO(e)[MO_LT + 1 + NA + ip]);
+          if (NE > 0) hv += MO_COMPACT ? (double)Ld[RF_IMG + MO_NL + NE + NE * NA + ip] : Q.MO(e)[MO_NL + NE + NE * NA + ip];
+          t += hv * Ld[RF_DY + b];
+        }
+        for (int i = 0; i < NE; ++i) t += Q.EW(e, EW_JD + i * NA + a) * Ld[RF_RHS + i];
+        Q.ND(cn)[ND_PV + a] = t;              // (in the slot of the child node, whose own sum has been used: one writer per slot)
+      }
+      T.gsync();
+    }
     dy0 = dy_n; dnu0 = dnu_n; cr0 = cr_n; have_pre = pre_n;
     DOMPC_PF(20)
   }
+  if (adj) T.sync();          // (the shares of this segment's edges are visible to the groups of the next one)
+  }
+  }
+  if (adj) {
+    const int cs_ = A.node_child_start[0], cc_ = A.node_child_count[0];
+    for (int a = T.tid; a < NX; a += T.nt) {                                  // initial-condition rows: + lambda in the root's x rows
+      double t = Q.ND(0)[ND_PV + a];
+      for (int j = 0; j < cc_; ++j) t += Q.ND(A.edge_child[cs_ + j])[ND_PV + a];
+      Q.dlam[a] = -t;
+    }
   }
   // dummies (variables in no constraint / cost): independent scalar Newton steps
   for (int d = T.tid; d < A.n_dummy; d += T.nt) {
@@ -5014,7 +5121,13 @@ __device__ __attribute__((noinline)) PhaseRet phase_backward(const void* kp, int
 __device__ __attribute__((noinline)) PhaseRet phase_forward(const void* kp, int b, int slot, double sf, double mu, double delta, double dsw, unsigned gen, unsigned nred, unsigned xseq) {
   DOMPC_PHASE_PROLOGUE
   Q.dsw = ufl(dsw);
-  riccati_forward(T, Q, ufl(mu), ufl(delta));
+  riccati_forward_t<false>(T, Q, ufl(mu), ufl(delta));
+  return PhaseRet{T.gen, T.nred, T.xseq, 0};
+}
+__device__ __attribute__((noinline)) PhaseRet phase_forward_adj(const void* kp, int b, int slot, double sf, double mu, double delta, double dsw, unsigned gen, unsigned nred, unsigned xseq) {
+  DOMPC_PHASE_PROLOGUE
+  Q.dsw = ufl(dsw);
+  riccati_forward_t<true>(T, Q, ufl(mu), ufl(delta));
   return PhaseRet{T.gen, T.nred, T.xseq, 0};
 }
 __device__ __attribute__((noinline)) PhaseRet3 phase_step_rules(const void* kp, int b, int slot, double sf, double mu, unsigned gen, unsigned nred, unsigned xseq) {
@@ -5105,10 +5218,15 @@ DOMPC_DEV inline Comp run_accept(const Thr& T, const Prob& Q, int b, int slot, d
 }
 DOMPC_DEV inline void run_forward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta) {
 #ifndef DOMPC_HOST_EMU
-  DOMPC_PHASE_CALL(phase_forward, mu, delta, Q.dsw)
+  if (forward_adjoint(Q, mu)) {
+    DOMPC_PHASE_CALL(phase_forward_adj, mu, delta, Q.dsw)
+  } else {
+    DOMPC_PHASE_CALL(phase_forward, mu, delta, Q.dsw)
+  }
 #else
   (void)b; (void)slot;
-  riccati_forward(T, Q, mu, delta);
+  if (forward_adjoint(Q, mu)) riccati_forward_t<true>(T, Q, mu, delta);
+  else riccati_forward_t<false>(T, Q, mu, delta);
 #endif
 }
 

@@ -299,7 +299,7 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
         if wd_restart is None:
             E0, e_d, e_p, e_c = err(0.0, v, y, zl, zu, gf, A, c)
             if trace is not None:
-                trace.append(dict(it=it, mu=mu, E0=E0, inf_du=e_d, inf_pr=e_p, compl=e_c, f=fval / sf, x=v[:n].copy()))
+                trace.append(dict(it=it, mu=mu, E0=E0, inf_du=e_d, inf_pr=e_p, compl=e_c, f=fval / sf, x=v[:n].copy(), y=y.copy(), zl=zl[:n].copy(), zu=zu[:n].copy(), sf=sf, delta_w_last=delta_w_last))
             # unscaled acceptance thresholds are checked on scaled quantities here (scaling is mild)
             if E0 <= o["tol"] and e_d <= o["dual_inf_tol"] and e_p <= o["constr_viol_tol"] and e_c <= o["compl_inf_tol"]:
                 status, success = "Solve_Succeeded", True
