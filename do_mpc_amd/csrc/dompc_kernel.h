@@ -4328,10 +4328,17 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
     const int n = A.edge_parent[e];
     const int a0 = lane < NA ? lane : 0;
     dy_ = (a0 < NX) ? Q.ND(n)[ND_DXT + a0] : Q.dx[A.node_u_off[n] + a0 - NX];
-    dnu_ = Q.dlam[A.edge_row0[e] + NW + (lane < NX ? lane : 0)];
+    // (adjoint recovery: the own terms of the child node's x rows in place of the chain walk's d nu)
+    dnu_ = adj ? Q.ND(A.edge_child[e])[ND_PV + (lane < NX ? lane : 0)] : Q.dlam[A.edge_row0[e] + NW + (lane < NX ? lane : 0)];
     cr_ = Q.c[A.edge_row0[e] + (lane < NW ? lane : 0)];
   };
   (void)fw_staged; (void)have_pre; (void)cr0;
+  // adjoint recovery, chain levels: the share of the edge just processed for its parent node stays in registers - the next edge of the
+  // chain is that node's incoming edge (no trip through memory on the serial path)
+  constexpr int NXPL = (NX + GS_C - 1) / GS_C > 0 ? (NX + GS_C - 1) / GS_C : 1;
+  double carry[NXPL];
+  int carry_node = -1;
+  (void)carry; (void)carry_node;
   // Order of the edges.  Without the adjoint recovery the edges are independent: group g takes e = g, g + ng, ...  With it every edge comes
   // after the child edges of its child node: segment 0 - each group walks its scenario chains from the last stage up to the first chain
   // level (no barrier: one wavefront owns a chain); segments 1 ... cl - the branching levels from the lowest to the root, the edges of a
@@ -4428,6 +4435,22 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
     }
 #undef EWV
 #undef MOVF
+    // (adjoint recovery: this lane's column of Jd and the weight of the edge, before the staging area changes hands)
+    constexpr int NE1_ = NE > 0 ? NE : 1;
+    double jd_r[NXPL][NE1_];
+    double omh_a = 0.0;
+    if (adj) {
+      omh_a = A.edge_omega[e] * Q.sf;
+#define EWV(i) (MO_LDS ? (double)Ld[RF_EW + (i)] : Q.EW(e, (i)))
+#pragma unroll
+      for (int q = 0; q < NXPL; ++q) {
+        const int a = lane + q * GS;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) jd_r[q][i] = EWV(EW_JD + i * NA + (a < NX ? a : 0));
+      }
+#undef EWV
+    }
+    (void)jd_r; (void)omh_a;
     double dy_n = 0.0, dnu_n = 0.0, cr_n = 0.0;
     bool pre_n = false;
 #ifndef DOMPC_HOST_EMU
@@ -4444,7 +4467,7 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
     {
       if (GS > 1) {
         if (lane < NA) Ld[RF_DY + lane] = dy0;
-        if (chain_edge && lane < NX) Ld[RF_DNU + lane] = dnu0;
+        if (!adj && chain_edge && lane < NX) Ld[RF_DNU + lane] = dnu0;
         c_r[0] = cr0;
 #pragma unroll
         for (int q = 1; q < RPL; ++q) {              // (more than 64 unknowns per interval, round 5: the rows beyond the first 64 - only entry 0 is requested one edge ahead)
@@ -4459,17 +4482,24 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
     }
     DOMPC_PF(17)
     if (adj) {
-      // adjoint recovery: the sums of the child edges of `cn` are complete (they were processed before this edge)
+      // adjoint recovery: the shares of the child edges of `cn` are complete (they were processed before this edge)
+      const int cs_ = A.node_child_start[cn], cc_ = A.node_child_count[cn];
+      const bool in_regs = cc_ == 1 && carry_node == cn;
 #ifndef DOMPC_HOST_EMU
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!in_regs && cc_ > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       T.gsync();
-      const int cs_ = A.node_child_start[cn], cc_ = A.node_child_count[cn];
-      for (int a = lane; a < NX; a += GS) {
-        double t = Nc[ND_PV + a];                                           // (the node's own terms)
-        for (int j = 0; j < cc_; ++j) t += Q.ND(A.edge_child[cs_ + j])[ND_PV + a];      // + the shares of its child edges, in their order
-        Ld[RF_DNU + a] = t;
-        Q.dlam[row0 + NW + a] = t;
+#pragma unroll
+      for (int q = 0; q < NXPL; ++q) {
+        const int a = lane + q * GS;
+        if (a < NX) {
+          double t = (GS > 1 && q == 0) ? dnu0 : Nc[ND_PV + a];             // (the node's own terms)
+          if (in_regs) t += carry[q];
+          else
+            for (int j = 0; j < cc_; ++j) t += Q.ND(A.edge_child[cs_ + j])[ND_PV + a];      // + the shares of its child edges, in their order
+          Ld[RF_DNU + a] = t;
+          Q.dlam[row0 + NW + a] = t;
+        }
       }
     } else if (!chain_edge)
       for (int a = lane; a < NX; a += GS) {
@@ -4585,20 +4615,26 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
     if (adj && M > 0) {
       // this edge's share of the x rows of its parent node: G_y' dlambda_w (x columns: -C_0j on the collocation rows, -D_0 on the
       // continuity rows of the element), the x rows of omega H_l + H_nl times dy, Jd' dyd
-      const double omh_ = A.edge_omega[e] * Q.sf;
-      for (int a = lane; a < NX; a += GS) {
-        double t = -DOMPC_D[0] * Ld[RF_G + LU_N + a];
 #pragma unroll
-        for (int j = 1; j <= DEG; ++j) t -= DOMPC_C[0 * (DEG + 1) + j] * Ld[RF_G + (j - 1) * NX + a];
-        for (int b = 0; b < NA; ++b) {
-          const int ip = symi(a, b, NA);
-          double hv = omh_ * (MO_COMPACT ? (double)Ld[RF_IMG + MO_LT + 1 + NA + ip] : Q.MO(e)[MO_LT + 1 + NA + ip]);
-          if (NE > 0) hv += MO_COMPACT ? (double)Ld[RF_IMG + MO_NL + NE + NE * NA + ip] : Q.MO(e)[MO_NL + NE + NE * NA + ip];
-          t += hv * Ld[RF_DY + b];
+      for (int q = 0; q < NXPL; ++q) {
+        const int a = lane + q * GS;
+        if (a < NX) {
+          double t = -DOMPC_D[0] * Ld[RF_G + LU_N + a];
+#pragma unroll
+          for (int j = 1; j <= DEG; ++j) t -= DOMPC_C[0 * (DEG + 1) + j] * Ld[RF_G + (j - 1) * NX + a];
+          for (int b = 0; b < NA; ++b) {
+            const int ip = symi(a, b, NA);
+            double hv = omh_a * (MO_COMPACT ? (double)Ld[RF_IMG + MO_LT + 1 + NA + ip] : Q.MO(e)[MO_LT + 1 + NA + ip]);
+            if (NE > 0) hv += MO_COMPACT ? (double)Ld[RF_IMG + MO_NL + NE + NE * NA + ip] : Q.MO(e)[MO_NL + NE + NE * NA + ip];
+            t += hv * Ld[RF_DY + b];
+          }
+#pragma unroll
+          for (int i = 0; i < NE; ++i) t += jd_r[q][i] * Ld[RF_RHS + i];
+          Q.ND(cn)[ND_PV + a] = t;              // (in the slot of the child node, whose own terms have been used: one writer per slot)
+          carry[q] = t;
         }
-        for (int i = 0; i < NE; ++i) t += Q.EW(e, EW_JD + i * NA + a) * Ld[RF_RHS + i];
-        Q.ND(cn)[ND_PV + a] = t;              // (in the slot of the child node, whose own sum has been used: one writer per slot)
       }
+      carry_node = n;
       T.gsync();
     }
     dy0 = dy_n; dnu0 = dnu_n; cr0 = cr_n; have_pre = pre_n;
