@@ -309,6 +309,54 @@ def check_newton_step(make_mpc, name, oracle_iters=6, delta=0.0):
     assert np.max(np.abs(res)) < 1e-7 * max(1.0, np.max(np.abs(rhs)))
 
 
+def check_newton_step_at_late_iterate(make_mpc):
+    """The Newton direction on the LAST level of the barrier parameter (mu = 2.5e-9, Sigma of the active bounds up to 2e11) against a
+    sparse LU of the same KKT system, residual of the linear system by row class.  Iterate: the oracle's iterate 54 of member 2 048 of the
+    bench batch (tests/golden/oracle_late_iterate_ip2048.npz, tools/late_iterate_fixture.py) - the solve that stopped two iterations
+    after the oracle until round 5.  With the multiplier steps of the continuity rows taken from the x rows of the Newton system
+    (riccati_forward_t<true>) those rows hold to rounding (measured 6.5e-13; with d nu = P dx + p: 1.9e-7), the rows of the collocation
+    unknowns 1.4e-13, the primal rows 8e-12; the u rows keep the backward error of the reduced Hessian's Cholesky factor (1.2e-8)."""
+    f = np.load(os.path.join(GOLD, "oracle_late_iterate_ip2048.npz"))
+    mpc = make_mpc("industrial_poly")
+    ps = mpc.structure
+    nlp = oracle_nlp("industrial_poly")
+    p = nlp.opt_p(f["x0"], np.zeros(nlp.nu))
+    x, lam, zl, zu, mu, delta = f["x"], f["y"], f["zl"], f["zu"], float(f["mu"]), float(f["delta"])
+    lb, ub = nlp.lbx.copy(), nlp.ubx.copy()
+    hl, hu = np.isfinite(lb), np.isfinite(ub)
+    lb[hl] -= 1e-8 * np.maximum(1, np.abs(lb[hl]))
+    ub[hu] += 1e-8 * np.maximum(1, np.abs(ub[hu]))
+    dl, du = np.where(hl, x - lb, 1.0), np.where(hu, ub - x, 1.0)
+    dx, dlam, rd, c = mpc.S.debug_newton_step(x, lam, zl, zu, lb, ub, nlp.lbg, nlp.ubg, p, mu, delta)
+    W, A, gf, cv = nlp.hess(x, p, 1.0, lam), nlp.jac(x, p), nlp.grad(x, p), nlp.g(x, p) - nlp.lbg
+    sig = zl / dl * hl + zu / du * hu
+    assert sig.max() > 1e10                                   # (the situation this test is about)
+    rx = gf + A.T @ lam - np.where(hl, mu / dl, 0.0) + np.where(hu, mu / du, 0.0)
+    rx = rx + ipm.DEFAULTS["kappa_d"] * mu * ((hl & ~hu).astype(float) - (hu & ~hl).astype(float))
+    dummy = np.asarray(ps.tables["dummy_idx"])
+    pin = np.zeros(x.size)
+    pin[dummy] = (sig[dummy] == 0)
+    K = sps.bmat([[W + sps.diags(sig + pin + delta), A.T], [A, None]], format="csc")
+    rhs = -np.concatenate([rx, cv])
+    lu = spla.splu(K)
+    sol = lu.solve(rhs)
+    for _ in range(3):
+        sol += lu.solve(rhs - K @ sol)
+    dxo = sol[:x.size]
+    assert np.max(np.abs(dx - dxo)) < STEP_TOL * np.max(np.abs(dxo))                  # (measured 2e-7 of the largest entry)
+    res = K @ np.concatenate([dx, dlam]) - rhs
+    rdual, rprim = res[:x.size], res[x.size:]
+    idx = np.arange(x.size)
+    used = np.ones(x.size, bool)
+    used[dummy] = False
+    is_x = idx < ps.off_z
+    slot = (idx % ((ps.M + 1) * ps.nx)) // ps.nx
+    node_x, colloc_w, node_u = is_x & (slot == ps.M) & used, is_x & (slot != ps.M) & used, (idx >= ps.off_u) & (idx < ps.off_eps) & used
+    worst = {k: float(np.abs(rdual[m]).max()) for k, m in (("x", node_x), ("w", colloc_w), ("u", node_u))}
+    assert worst["x"] < 1e-10 and worst["w"] < 1e-10 and worst["u"] < 1e-7 and np.abs(rprim).max() < 1e-9, (worst, np.abs(rprim).max())
+    return worst
+
+
 def check_sweep_blocks(mpc, name, to_dev, from_dev, B=3, seed=1):
     """Sweep kernel: g(x) and the per-edge linearised dynamics [A|B], c against the oracle's g and
     sparse Jacobian (A = -S G_w^-1 G_x computed densely per edge from the oracle's rows)."""

@@ -645,3 +645,7 @@ def test_watchdog_on_the_straggler_of_the_cold_estimator_batch():
     ex = CASES["rotating_masses"]
     pc.check_watchdog_on_mhe_straggler(lambda: ex.build_mhe(ex.build_model()))
 
+
+def test_newton_direction_on_the_last_barrier_level_satisfies_the_state_rows():
+    """(one problem = 256 threads / several workgroups: the bottom-up edge order of the adjoint recovery over several wavefronts)"""
+    pc.check_newton_step_at_late_iterate(make_mpc)

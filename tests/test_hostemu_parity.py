@@ -325,3 +325,6 @@ def test_thread_per_entry_loops_of_the_wide_mode_give_the_same_bits(name, monkey
     assert sol[0][:2] == sol[1][:2]
     assert np.array_equal(sol[0][2], sol[1][2]) and np.array_equal(sol[0][3], sol[1][3]) and np.array_equal(sol[0][4], sol[1][4])
 
+
+def test_newton_direction_on_the_last_barrier_level_satisfies_the_state_rows():
+    pc.check_newton_step_at_late_iterate(make_mpc)
