@@ -81,8 +81,10 @@ def _compile_to(cmd_without_out, out: str, what: str) -> None:
 
 def _sources_digest() -> str:
     h = hashlib.sha256()
-    for fn in ("dompc_kernel.h", "dompc_dae.h", "dompc_riccati16.h", "dompc_kargs.h", "dompc_device.hip", "dompc_runtime.cpp",
-               "dompc_plant.hip", "dompc_plant_args.h", "dompc_plant_runtime.cpp"):
+    for fn in sorted(os.listdir(CSRC)):                       # (every source of the kernels and of the runtime)
+        if not fn.endswith((".h", ".hip", ".cpp")):
+            continue
+        h.update(fn.encode())
         with open(os.path.join(CSRC, fn), "rb") as f:
             h.update(f.read())
     with open(os.path.join(INCLUDE, "dompc_ipm.h"), "rb") as f:

@@ -430,7 +430,7 @@ class MPC:
         if s.state_discretization != "collocation" and m.model_type == "continuous":
             raise Exception("Unknown state_discretization: {}".format(s.state_discretization))
         # size limit of an edge (kernel: the collocation / algebraic unknowns of an interval are eliminated inside one wavefront's
-        # registers / LDS region; csrc/dompc_kernel.h asserts the same bound at compile time)
+        # registers / LDS region; csrc/dompc_edge.h asserts the same bound at compile time)
         pts = (s.collocation_deg + 1) * s.collocation_ni if m.model_type == "continuous" else 0
         n_w = pts * m.n_x + max(pts, 1) * m.n_z
         # 128 on the in-LDS elimination of intervals with several finite elements (round 5); 64 on the single-element path (one extended

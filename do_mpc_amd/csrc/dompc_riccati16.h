@@ -16,7 +16,7 @@
 // column NX carries [c; 1 at row NA]:  F1' V F1  then holds F' P F outside row / column NX and F'(P c + p) in them; the gains
 // Lc = [I; K] and the closed-loop maps Acl = F Lc have free columns >= NA, column NA carries l0 = (0; kv) resp. [F l0 + c; 1].
 // 25 instead of 50 MFMAs per node and child.
-// This replaces the generic LDS-staged riccati_node() (dompc_kernel.h; still used by the host emulation, by models
+// This replaces the generic LDS-staged riccati_node() (dompc_riccati.h; still used by the host emulation, by models
 // with more than 16 node variables, more than 4 decision variables per node or more than 4 nl_cons rows, and by the
 // tree-sharding build) - the algebra is the same:
 //     Q_tot = Q_own + sum_c F_c' P_c F_c ,  K = -Q_vv^-1 Q_vx ,
@@ -250,7 +250,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
       for (int c = 1; c < cc; ++c) gv += Q.ES(cs + c)[ES_QV + yjj];
     if constexpr (NE > 0) {
       // nl_cons rows of the child edges, condensed through their slacks: gradient share  J~'((Sigma_s + delta) r_d + r_s)
-      // with J~ = [J_d over (x, u) | -1 at the slack variable of the row]  (same algebra as riccati_node, dompc_kernel.h)
+      // with J~ = [J_d over (x, u) | -1 at the slack variable of the row]  (same algebra as riccati_node, dompc_riccati.h)
       for (int c = 0; c < cc; ++c) {
         const int e = cs + c;
         const double* S_ = Q.ES(e);

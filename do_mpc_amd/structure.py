@@ -184,7 +184,7 @@ def build_structure(nx, nu, nz, np_, ntvp, ne, ns, deg, ni, N, n_comb, n_robust,
     ps.open_loop_stack = bool(open_loop and S > 1)
     # nl_cons_single_slack (_mpc.py:1120-1123, 1228): one `_eps` entry per scenario slot for ALL stages.  The slacks then are no
     # decision variables of a node; the kernels take them out of the tree-structured part and solve for them by a Schur
-    # complement (csrc/dompc_kernel.h: EPS_GLOBAL) - one extra linear solve per slack variable and iteration.
+    # complement (csrc/dompc_driver.h: EPS_GLOBAL) - one extra linear solve per slack variable and iteration.
     ps.eps_global = bool(single_slack and ns > 0 and N > 1)
     if ps.eps_global:
         if S * ns > 32:

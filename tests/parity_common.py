@@ -524,7 +524,7 @@ def check_nl_cons_at_collocation_points(make_mpc, name, over, x0):
 
 
 # nl_cons_single_slack (_mpc.py:1120-1123, 1228): one `_eps` entry per scenario slot for ALL stages - shared variables, a Schur complement on
-# top of the structured solve (csrc/dompc_kernel.h: EPS_GLOBAL).  Starts with T_R above the soft limit of 140: the shared slacks end active.
+# top of the structured solve (csrc/dompc_driver.h: EPS_GLOBAL).  Starts with T_R above the soft limit of 140: the shared slacks end active.
 SINGLE_SLACK_CASES = [
     ("tree9", dict(), np.array([0.8, 0.5, 141.5, 138.0])),                                   # the shipped tree: 9 slacks, one per scenario chain (the root reads slack 0)
     ("tree9_nrobust2", dict(n_robust=2, n_horizon=8, uncertainty=dict(alpha=[1.0, 1.05, 0.95], beta=[1.0])),

@@ -140,7 +140,7 @@ def test_stop_request_returns_user_requested_stop():
 
 def test_too_many_unknowns_per_interval_is_refused_by_name():
     """The kernels eliminate at most 64 (single finite element; 128 with several) collocation / algebraic unknowns per control interval (static_assert in
-    csrc/dompc_kernel.h): the setup says so instead of leaving the user with a failed hipcc run."""
+    csrc/dompc_edge.h): the setup says so instead of leaving the user with a failed hipcc run."""
     from do_mpc_amd.controller import MPC
     from do_mpc_amd.model import Model
     model = Model("continuous")
