@@ -341,10 +341,12 @@ def _partials(n: Node) -> Tuple[Optional[Node], Optional[Node]]:
         if b.op == "const":
             return mul(b, power(a, const(b.val - 1.0))), ZERO
         return mul(b, power(a, sub(b, ONE))), mul(n, unary("log", a))
-    if op == "fmin":
-        raise NotImplementedError("derivative of fmin")
-    if op == "fmax":
-        raise NotImplementedError("derivative of fmax")
+    if op in ("fmin", "fmax"):
+        # CasADi's rule (casadi/core/calculus.hpp, OP_FMIN / OP_FMAX): the partial derivatives are (a <= b) / ((a <= b) + (b <= a)) and its
+        # mirror - one for the selected argument, zero for the other, one half each at a tie; here through the existing sign() node
+        sg = unary("sign", sub(b, a) if op == "fmin" else sub(a, b))
+        half = const(0.5)
+        return mul(half, add(ONE, sg)), mul(half, sub(ONE, sg))
     if op == "atan2":
         den = add(unary("sq", a), unary("sq", b))
         return div(b, den), neg(div(a, den))

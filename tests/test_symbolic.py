@@ -100,3 +100,19 @@ def test_numpy_evaluation_covers_every_operator_with_batched_inputs():
     assert np.allclose(J[2], 1.0 / (1.0 + X[2] ** 2))
     # single-point call path
     assert np.allclose(np.asarray(f(np.array([0.1, 0.2, 1.0])).arr).ravel(), ref[:, 0])
+
+
+def test_fmin_fmax_derivatives_follow_casadis_rule():
+    """casadi/core/calculus.hpp OP_FMIN / OP_FMAX: one for the selected argument, zero for the other, one half each at a tie"""
+    x = S.SX.sym("x", 2)
+    y = S.vertcat(S.fmin(x[0] ** 2, 3.0 * x[1]), S.fmax(x[0], S.sin(x[1])) * x[0])
+    f = S.Function("f", [x], [y, S.jacobian(y, x), S.hessian(S.sum1(y), x)[0]])
+    for xv in (np.array([0.5, 0.4]), np.array([2.0, 0.3]), np.array([-0.3, 1.2])):
+        val, J, H = [o.full() for o in f(xv)]
+        assert np.allclose(val.ravel(), [min(xv[0] ** 2, 3 * xv[1]), max(xv[0], np.sin(xv[1])) * xv[0]])
+        assert np.allclose(J, _fd_jac(lambda v: f(v)[0].full().ravel(), xv), atol=1e-7)
+        assert np.allclose(H, _fd_jac(lambda v: f(v)[1].full().sum(axis=0), xv), atol=1e-6)
+    a = S.SX.sym("a", 1)
+    g = S.Function("g", [a], [S.jacobian(S.fmin(a, 2.0 * a), a), S.jacobian(S.fmax(a, 2.0 * a), a)])
+    tie_min, tie_max = [float(o.full()) for o in g(np.array([0.0]))]
+    assert tie_min == 1.5 and tie_max == 1.5                      # (0.5 * 1 + 0.5 * 2 at the tie a = 2 a = 0)
