@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #define DOMPC_CONSTANT_TABLES 1          // structure tables of KArgs: constant address space (dompc_kargs.h)
 #define DOMPC_FN __device__ static inline
-#define DOMPC_CONST __device__ static const
+#define DOMPC_CONST __device__ static constexpr
 #define DOMPC_DEV __device__
 #define DOMPC_HD __host__ __device__
 #else

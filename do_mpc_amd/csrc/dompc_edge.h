@@ -205,7 +205,27 @@ constexpr int MOH_H0 = NX + NX * NA;                                    // offse
 // DAE models: dense edge working set of eval_edge_dae (= dae::DG_SIZE, asserted in sweep())
 constexpr int DAE_NEED = DENSE_EDGE ? NW * (NW + NA + 2) + (NW + NA) * (NW + NA) + (NW + NA) * (NA + 2) + 2 * (NW + NA) + 3 * NW
                                       + NX * NW + NX * NA + NX + NE * NW + NE * NA + 2 * NW + RT_LEN : 0;
-constexpr int EL_SIZE = ((el_max(el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)), DAE_NEED) + 7) / 8) * 8;
+// Quad sweep (round 6, dompc_quad.h): FOUR edges per wavefront, 16 lanes per edge, no dense image of the model-output record.  LDS of a
+// wavefront: two banks of four compact records (the next four edges are copied in by LDS-DMA while the current ones are computed), one
+// slot (NX rows) of the four W | w0 matrices, the barrier vectors r_w | b of the four edges, and the transposed q~ | W'b.
+#ifndef DOMPC_QUAD
+#define DOMPC_QUAD 1
+#endif
+#ifndef DOMPC_HOST_EMU
+constexpr bool QUAD_EDGE = (DOMPC_QUAD != 0) && MO_COMPACT && (DEG >= 1) && (NA + 2 <= 16) && (DOMPC_NE == 0) && !RT_CUSTOM && !FREE_ROOT &&
+                           (DOMPC_SHARD == 0) && (DEG * DEG * NX <= 64) && (DOMPC_DYN_NV >= NX);
+#else
+constexpr bool QUAD_EDGE = false;
+#endif
+constexpr int QL_MOSZ = QUAD_EDGE ? ((4 * MO_REC + 127) / 128) * 128 : 0;     // one bank: the compact records of four consecutive edges, as they lie in memory
+constexpr int QL_WS = NA + 1;                                                 // row stride of the staged W | w0 slot
+constexpr int QL_WBG = ((NX * QL_WS + 1) / 2) * 2;                            // ... per edge
+constexpr int QL_WB = 2 * QL_MOSZ;
+constexpr int QL_VG = ((2 * NW + 7) / 8) * 8;                                 // r_w | b of one edge
+constexpr int QL_RW = QL_WB + 4 * QL_WBG;
+constexpr int QL_QV = QL_RW + 4 * QL_VG;                                      // q~ | W'b of one edge: 2 x 16
+constexpr int QL_NEED = QUAD_EDGE ? QL_QV + 4 * 32 : 0;
+constexpr int EL_SIZE = ((el_max(el_max(el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)), DAE_NEED), QL_NEED) + 7) / 8) * 8;
 
 // ---- dense image of a compact model-output record
 // dense index (MO_PT / MO_LT / MO_MT / MO_NL layout) of compact entry k

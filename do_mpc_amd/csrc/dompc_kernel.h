@@ -26,6 +26,7 @@
 //   dompc_dae.h       edge phases of models with algebraic states / rows on the edge unknowns (dense path)
 //   dompc_edge.h      trial evaluation of an edge; derivative evaluation + condensing (generic path); dense image of the compact record
 //   dompc_factor.h    blocked Gauss-Jordan on the FP64 matrix cores; factorisation of a single-finite-element edge; per-edge part of the sweep
+//   dompc_quad.h      the edge sweep with four edges per wavefront (round 6; single finite element, no nl_cons rows)
 //   dompc_node.h      gradient / dual-residual assembly of a node's variables
 //   dompc_riccati.h   tree Riccati recursion, backward pass (+ dompc_riccati16.h: register-resident matrix-core recursion)
 //   dompc_forward.h   forward pass, adjoint recovery of the continuity multipliers
@@ -35,6 +36,9 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#ifndef DOMPC_HOST_EMU
+#include <utility>
+#endif
 #include "dompc_kargs.h"
 
 namespace dompc {
@@ -873,6 +877,7 @@ DOMPC_DEV inline void edge_rterm_store(const ldsd* src, double* S_, int lane, in
 
 #include "dompc_edge.h"
 #include "dompc_factor.h"
+#include "dompc_quad.h"
 #include "dompc_node.h"
 #include "dompc_riccati.h"
 #include "dompc_forward.h"

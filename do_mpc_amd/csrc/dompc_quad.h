@@ -1,0 +1,590 @@
+// dompc_quad.h - structured interior-point solver, part of dompc_kernel.h (included there, inside namespace dompc, after dompc_factor.h).
+// Contents: the edge sweep of the single-finite-element fast path with FOUR EDGES PER WAVEFRONT (round 6).
+//
+// What it replaces: the wavefront-per-edge path eval_edge_coop / phase_edge_factor (dompc_factor.h), which stays as the fallback of an edge
+// whose collocation block fails the pivot test in its natural order, and as the path of every model outside QUAD_EDGE (dompc_edge.h).
+// Reference: everything nlp_jac_g / nlp_hess_l / nlp_grad_f and the factorisation of the collocation rows contribute to
+// `r = self.S(**kwargs)` (/root/reference/do_mpc/optimizer.py:770) for one control interval (optimizer.py:905-983, _mpc.py:1189-1275).
+//
+// Why.  Rounds 3 - 5 measured the wavefront-per-edge sweep at 2 190 vector-ALU issue slots per edge (1 404 instructions + 49 FP64 matrix
+// instructions of 16 slots) with the SIMD busy 45 - 50 % of the time: a 20 x 20 block on 64 lanes leaves most lanes idle in every dependent
+// chain (the 4 x 4 pivot blocks of the blocked elimination are factorised redundantly by all 64 lanes), FP64 matrix instructions have the
+// vector ALU's rate on gfx950, and the dense LDS image of the model-output record (5.9 KB) allowed one edge per wavefront only.
+// Here 16 lanes own one edge and a wavefront instruction serves four edges:
+//   * lane b < NX of an edge owns state b: its collocation unknowns (one register per slot), their bounds, multipliers and residual rows,
+//     and COLUMN (s, b) of the collocation block G_cc for every slot s; lanes NX .. NA-1 own the input columns J_u, lane NA the residual
+//     column.  The right-hand-side columns of the parent STATE are not eliminated at all: they are -C[0][j] I, so their part of
+//     W = -G_cc^-1 G_y is a combination of the columns of the inverse that the owning lane already holds.
+//   * the elimination is an unblocked in-place Gauss-Jordan in registers: per pivot the owning lane's column goes to the 16 lanes of its
+//     edge with v_mov_b64_dpp row_newbcast (DPP broadcast inside a row of 16 lanes - one instruction, no LDS, no readlane/SGPR detour);
+//     natural pivot order with the threshold test of the old path, the old path as fallback.
+//   * no dense image: the entries of the compact model-output record are read where they are needed, addressed at COMPILE time (the
+//     structure tables of the generated header are constant expressions): the point Hessians enter the condensing as the sparse matrices
+//     they are (industrial_poly: 25 of 91 packed entries per point).
+//   * condensing in the same layout: lane c owns column c of [W | w0 | -], T = (H_p + Sigma_p) Z_p is lane-local, Z_p' T takes the rows of
+//     Z_p from a staged copy in LDS (group-uniform reads, no vector-ALU slots).
+// Measured effect: DESIGN.md section 4 / profiles/r06_*.
+#if !defined(DOMPC_HOST_EMU) && DOMPC_DEG >= 1 && DOMPC_M >= 1 && DOMPC_NI == 1 && DOMPC_NX + DOMPC_NU + 2 <= 16 && DOMPC_DEG * DOMPC_DEG * DOMPC_NX <= 64      // (array sizes and lane numbers below; the rest of the conditions: QUAD_EDGE, dompc_edge.h)
+
+extern "C" __device__ double dompc_dpp_f64(double old, double src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) __asm("llvm.amdgcn.update.dpp.f64");
+// value of `v` in lane L of this lane's row of 16 lanes (v_mov_b64_dpp row_newbcast:L)
+template <int L>
+__device__ inline double rbc(double v) {
+  static_assert(L >= 0 && L < 16, "lane inside a row of 16");
+  return dompc_dpp_f64(0.0, v, 0x150 + L, 0xf, 0xf, true);
+}
+template <class F, int... I>
+__device__ inline void sfor_(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+// f(integral_constant<int, i>) for i = 0 .. N-1: loops whose index has to be a constant expression
+template <int N, class F>
+__device__ inline void sfor(F&& f) { sfor_(f, std::make_integer_sequence<int, (N > 0 ? N : 0)>{}); }
+
+// where a dense entry of the model-output record lives: kind 0 structural zero, 1 model constant (index into the constant table),
+// 2 variable (offset inside the compact record of the edge)
+struct MoRef { int kind, off; };
+constexpr MoRef moref_in(int d, const int* vidx, int nv, const int* cidx, int nc, int base) {
+  for (int k = 0; k < nv; ++k) if (vidx[k] == d) return MoRef{2, base + k};
+  for (int k = 0; k < nc; ++k) if (cidx[k] == d) return MoRef{1, k};
+  return MoRef{0, 0};
+}
+constexpr MoRef moref_dyn(int p, int d) { return moref_in(d, DOMPC_DYN_VIDX, DOMPC_DYN_NV, DOMPC_DYN_CIDX, DOMPC_DYN_NC, p * DOMPC_DYN_NV); }
+constexpr MoRef moref_lt(int d) { return moref_in(d, DOMPC_LT_VIDX, DOMPC_LT_NV, DOMPC_LT_CIDX, DOMPC_LT_NC, MOC_LT); }
+constexpr MoRef moref_mt(int d) { return moref_in(d, DOMPC_MT_VIDX, DOMPC_MT_NV, DOMPC_MT_CIDX, DOMPC_MT_NC, MOC_MT); }
+// its value: `rec` = the compact record of this lane's edge in LDS (a constant index into a table with a constant initialiser folds to the literal)
+template <int KIND, int OFF>
+__device__ inline double mo_dyn_val(const ldsd* rec) { if constexpr (KIND == 2) return rec[OFF]; else if constexpr (KIND == 1) return DOMPC_DYN_CVAL[OFF]; else return 0.0; }
+template <int KIND, int OFF>
+__device__ inline double mo_lt_val(const ldsd* rec) { if constexpr (KIND == 2) return rec[OFF]; else if constexpr (KIND == 1) return DOMPC_LT_CVAL[OFF]; else return 0.0; }
+template <int KIND, int OFF>
+__device__ inline double mo_mt_val(const ldsd* rec) { if constexpr (KIND == 2) return rec[OFF]; else if constexpr (KIND == 1) return DOMPC_MT_CVAL[OFF]; else return 0.0; }
+// the function values f of a point are the first NX entries of its compact record (lowering.py writes the variable entries in the order
+// of the dense layout, and f comes first): lane b reads f_b at a lane-dependent address
+constexpr bool qd_f_linear() {
+  for (int i = 0; i < NX; ++i) if (DOMPC_DYN_VIDX[i] != i) return false;
+  return true;
+}
+
+// the indices of this lane's edge (KArgs::edge_pack); `om` = omega * objective scaling
+struct QdPack { int woff, row0, xoffp, xoffc, level; double om; };
+__device__ inline QdPack qd_pack(const KArgs& A, int e, double sf) {
+  const auto* ep = A.edge_pack + e * EP_N;
+  QdPack k;
+  k.woff = ep[EP_WOFF]; k.row0 = ep[EP_ROW0]; k.xoffp = ep[EP_XOFF_PARENT]; k.xoffc = ep[EP_XOFF_CHILD]; k.level = ep[EP_LEVEL];
+  k.om = __builtin_bit_cast(double, ((unsigned long long)(unsigned)ep[EP_OMEGA_HI] << 32) | (unsigned long long)(unsigned)ep[EP_OMEGA_LO]) * sf;
+  return k;
+}
+// request the compact records of edges e0 .. e0 + 3 (contiguous in memory) into bank `bank` of the wavefront's LDS region (LDS-DMA,
+// 64 lanes x 16 B per instruction).  Runs past the last record of the problem into the arrays behind it (ws_layout) - never used.
+__device__ inline void stage_quad(const Prob& Q, int e0, int lane, ldsd* Ld, int bank) {
+  const double* src = Q.mo + (int64_t)e0 * MO_REC;
+  ldsd* dst = Ld + bank * QL_MOSZ;
+#pragma unroll
+  for (int q = 0; q < QL_MOSZ / 128; ++q)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 128 * q + 2 * lane),
+                                     (__attribute__((address_space(3))) void*)(dst + 128 * q), 16, 0, 0);
+}
+
+#ifndef DOMPC_QUAD_PROFILE
+#define DOMPC_QUAD_PROFILE DOMPC_PROFILE
+#endif
+#ifndef DOMPC_QUAD_SB
+#define DOMPC_QUAD_SB 1            // scheduling barriers between the pieces of a quad and between the pivots of its elimination: without them the
+#endif                             // machine scheduler stretches live ranges over the whole 9 000-instruction body and spills hundreds of registers
+#if DOMPC_QUAD_SB
+#define QD_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define QD_SB()
+#endif
+
+// Derivative evaluation, factorisation and condensing of the edges e0 .. e0 + 3 (edge e0 + (lane >> 4) on each row of 16 lanes; rows
+// beyond the last edge repeat it and store nothing).  `bank`: where stage_quad() put their compact records; `e0n`: first edge of the
+// quad this wavefront handles next (-1: none) - requested into the other bank once the elimination is through.
+// Returns 0, 1 (a singular block cannot happen here: it takes the fallback) or 2: at least one collocation block failed the pivot test
+// in its natural order - nothing that the fallback (eval_edge_coop on each edge) does not write again has been stored.
+__device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0n, double mu, int lane_, ldsd* Ld, int bank, const QdPack& pk) {
+  const KArgs& A = *Q.A;
+  // (the lane number as a value the optimiser cannot see through: everything derived from it - 16 lane predicates, the per-lane selects of
+  //  collocation coefficients and unit vectors - is otherwise hoisted out of the quad loop as loop-invariant and held in ~100 registers)
+  int lane = lane_;
+  asm volatile("" : "+v"(lane));
+  constexpr int R = DEG * NX;
+  constexpr double GJ_U = DOMPC_GJ_U;
+  const int g = lane >> 4, j = lane & 15;
+  const bool act = e0 + g < A.n_edges;
+  const int e = act ? e0 + g : A.n_edges - 1;
+  const bool isx = j < NX;
+  const bool st_x = act && isx;                       // this lane stores per-state results
+  const unsigned b = (unsigned)(isx ? j : 0);
+  const bool soc = (Q.soc & 1) != 0;
+  const double omh = (Q.soc & 2) ? 0.0 : pk.om;       // weight of the objective HESSIANS (Prob::soc bit 1)
+#if DOMPC_QUAD_PROFILE
+  long long pc0 = prof_clock();
+#define QD_PH(i) if (T.prof && T.tid == 0) { const long long pc1 = prof_clock(); T.prof[i] += pc1 - pc0; pc0 = pc1; }
+#else
+#define QD_PH(i)
+#endif
+  // ---- 1. operands outside the model-output record: one batch of loads (iterate, bounds, bound multipliers, row multipliers)
+  const double xn = ldoff(Q.x, (unsigned)pk.xoffp + b), xc = ldoff(Q.x, (unsigned)pk.xoffc + b);
+  double wv[M], lbv[M], ubv[M], zlv[M], zuv[M];
+#pragma unroll
+  for (int s = 0; s < M; ++s) {
+    const unsigned gi = (unsigned)pk.woff + (unsigned)(s * NX) + b;
+    wv[s] = ldoff(Q.x, gi); lbv[s] = ldoff(Q.lb, gi); ubv[s] = ldoff(Q.ub, gi); zlv[s] = ldoff(Q.zl, gi); zuv[s] = ldoff(Q.zu, gi);
+  }
+  double lam[DEG], cin[DEG];
+#pragma unroll
+  for (int jj = 0; jj < DEG; ++jj) {
+    lam[jj] = ldoff(Q.lam, (unsigned)pk.row0 + (unsigned)(jj * NX) + b);
+    cin[jj] = soc ? ldoff(Q.c, (unsigned)pk.row0 + (unsigned)(jj * NX) + b) : 0.0;
+  }
+  const double lamc = ldoff(Q.lam, (unsigned)pk.row0 + (unsigned)R + b), nue = ldoff(Q.lam, (unsigned)pk.row0 + (unsigned)NW + b);
+  const double cinc = soc ? ldoff(Q.c, (unsigned)pk.row0 + (unsigned)R + b) : 0.0, cine = soc ? ldoff(Q.c, (unsigned)pk.row0 + (unsigned)NW + b) : 0.0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the staged records (and everything above) have landed
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  QD_PH(4)
+  QD_SB();
+  const ldsd* rec = Ld + bank * QL_MOSZ + g * MO_REC;         // compact record of this lane's edge
+  // ---- 2. residual rows of state b: collocation rows (one per point), continuity row, end-point row (optimizer.py:951-983, _mpc.py:1224)
+  double res[DEG], rc, ce;
+  {
+    double fv[DEG];
+    if constexpr (qd_f_linear()) {
+#pragma unroll
+      for (int jj = 0; jj < DEG; ++jj) fv[jj] = rec[jj * DOMPC_DYN_NV + (int)b];
+    } else {
+      sfor<DEG>([&](auto JJ) {
+        constexpr int jj = JJ;
+        double v = 0.0;
+        sfor<NX>([&](auto B_) {
+          constexpr int bb = B_;
+          constexpr MoRef rf = moref_dyn(jj, bb);
+          if constexpr (rf.kind != 0) { const double t_ = mo_dyn_val<rf.kind, rf.off>(rec); v = (j == bb) ? t_ : v; }
+        });
+        fv[jj] = v;
+      });
+    }
+#pragma unroll
+    for (int jj = 0; jj < DEG; ++jj) {
+      double xp = DOMPC_C[0 * (DEG + 1) + jj + 1] * xn;
+#pragma unroll
+      for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + jj + 1] * wv[r - 1];
+      res[jj] = soc ? cin[jj] : fv[jj] - xp;
+    }
+    double xf = DOMPC_D[0] * xn;
+#pragma unroll
+    for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * wv[r - 1];
+    rc = soc ? cinc : wv[M - 1] - xf;
+    ce = soc ? cine : wv[M - 1] - xc;
+    if (st_x && !soc) {
+#pragma unroll
+      for (int jj = 0; jj < DEG; ++jj) Q.c[pk.row0 + jj * NX + (int)b] = res[jj];
+      Q.c[pk.row0 + R + (int)b] = rc;
+      Q.c[pk.row0 + NW + (int)b] = ce;
+    }
+  }
+  // ---- 3. this lane's columns of [G_cc | J_u | r]: bc[s][(jj, a)]
+  //   lane b < NX, slot s: column (s, b) of G_cc = [s == jj] J_jj[a][b] - [a == b] C[s+1][jj+1]
+  //   lanes NX .. NA-1, slot 0: column ku of the input Jacobians J_jj[a][NX + ku];  lane NA, slot 0: the residual rows;  zero otherwise
+  double bc[DEG][R];
+  sfor<DEG>([&](auto S_) {
+    constexpr int s = S_;
+    sfor<R>([&](auto R_) {
+      constexpr int r = R_, jj = r / NX, a = r % NX;
+      double v = 0.0;
+      if constexpr (s == jj)
+        sfor<NX>([&](auto B_) {
+          constexpr int bb = B_;
+          constexpr MoRef rf = moref_dyn(jj, NX + a * NA + bb);
+          if constexpr (rf.kind != 0) { const double t_ = mo_dyn_val<rf.kind, rf.off>(rec); v = (j == bb) ? t_ : v; }
+        });
+      if constexpr (s == 0) {
+        sfor<NU>([&](auto K_) {
+          constexpr int ku = K_;
+          constexpr MoRef rf = moref_dyn(jj, NX + a * NA + NX + ku);
+          if constexpr (rf.kind != 0) { const double t_ = mo_dyn_val<rf.kind, rf.off>(rec); v = (j == NX + ku) ? t_ : v; }
+        });
+        const double rb_ = rbc<a>(res[jj]);       // (the broadcast is executed by every lane: never inside a select's branch)
+        v = (j == NA) ? rb_ : v;
+      }
+      v = (j == a) ? v - DOMPC_C[(s + 1) * (DEG + 1) + jj + 1] : v;
+      bc[s][r] = v;
+    });
+  });
+  QD_PH(5)
+  QD_SB();
+  // ---- 4. dual-residual pieces: column times the multipliers of the edge's rows; barrier terms of this lane's unknowns
+  double RWv[M], SGv[M], ry;
+  {
+    double bl[DEG][NX];                               // multipliers of the collocation rows (jj, a), for every lane of the edge
+    sfor<DEG>([&](auto J_) { constexpr int jj = J_; sfor<NX>([&](auto A_) { constexpr int a = A_; bl[jj][a] = rbc<a>(lam[jj]); }); });
+    double tcol[M];
+#pragma unroll
+    for (int s = 0; s < DEG; ++s) {
+      double t = 0.0;
+#pragma unroll
+      for (int a = 0; a < NX; ++a) t = fma(bl[s][a], bc[s][s * NX + a], t);       // block (s, s): J_s' lambda_s - C[s+1][s+1] lambda_s
+#pragma unroll
+      for (int jj = 0; jj < DEG; ++jj)
+        if (jj != s) t = fma(-DOMPC_C[(s + 1) * (DEG + 1) + jj + 1], lam[jj], t);
+      tcol[s] = t - DOMPC_D[s + 1] * lamc;
+    }
+    tcol[M - 1] = lamc + nue;                        // end-point column: +1 in its continuity row, +1 in the end-point row
+    // parent state columns: -C[0][j] in row (jj, b), -D_0 in the continuity row; input columns: J_u' lambda
+    double ryx = -DOMPC_D[0] * lamc, ryu = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < DEG; ++jj) ryx = fma(-DOMPC_C[0 * (DEG + 1) + jj + 1], lam[jj], ryx);
+#pragma unroll
+    for (int jj = 0; jj < DEG; ++jj)
+#pragma unroll
+      for (int a = 0; a < NX; ++a) ryu = fma(bl[jj][a], bc[0][jj * NX + a], ryu);
+    ry = isx ? ryx : ryu;                             // (lanes < NA; completed with the cost gradient below)
+    ldsd* Lv = Ld + QL_RW + g * QL_VG;
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+      const double t = tcol[s], xv = wv[s], l = lbv[s], u = ubv[s];
+      RWv[s] = t + bar_grad(xv, l, u, mu, !(Q.soc & 2));
+      const double bb = bar_grad(xv, l, u, 1.0);
+      SGv[s] = sigma_of(xv, l, u, zlv[s], zuv[s]);
+      if (isx) { Lv[s * NX + (int)b] = RWv[s]; Lv[NW + s * NX + (int)b] = bb; }
+      if (st_x) {
+        const int gi = pk.woff + s * NX + (int)b;
+        Q.gf[gi] = 0.0;
+        Q.rd[gi] = t - zlv[s] + zuv[s];
+      }
+    }
+  }
+  QD_PH(6)
+  QD_SB();
+  // ---- 5. in-place Gauss-Jordan in the natural pivot order: column k = (sk, bk) lives in slot sk of lane bk
+  int bad = 0;
+  sfor<R>([&](auto K_) {
+    constexpr int k = K_, sk = k / NX, bk = k % NX;
+    QD_SB();
+    const bool own = (j == bk);
+    double m = 0.0;
+#pragma unroll
+    for (int r = k + 1; r < R; ++r) m = fmax(m, fabs(bc[sk][r]));
+    const double akk = fabs(bc[sk][k]);
+    bad |= (int)(own & !(akk >= GJ_U * m && akk > 1e-300));
+    const double pl = fast_rcp((akk > 1e-300) ? bc[sk][k] : 1.0);
+    const double pinv = rbc<bk>(pl);
+    const double mfix = own ? -pl : 1.0;
+    double pm[DEG];
+#pragma unroll
+    for (int s = 0; s < DEG; ++s) {
+      const double prow = bc[s][k] * pinv;
+      pm[s] = (s == sk && own) ? 0.0 : prow;          // (the pivot column itself keeps its entries: scaled below)
+      bc[s][k] = (s == sk && own) ? pl : prow;        // row k: scaled; the pivot position: 1 / a_kk
+    }
+    // rows r != k: a_r. -= a_rk (a_k. / a_kk); the pivot column becomes column k of the inverse: -a_rk / a_kk
+    sfor<R>([&](auto R_) {
+      constexpr int r = R_;
+      if constexpr (r != k) {
+        const double f = rbc<bk>(bc[sk][r]);
+#pragma unroll
+        for (int s = 0; s < DEG; ++s) {
+          const double t = fma(-f, pm[s], bc[s][r]);
+          bc[s][r] = (s == sk) ? t * mfix : t;
+        }
+      }
+    });
+    // (every entry is computed HERE: without this the updates of the last pivots are sunk behind the elimination, next to their first
+    //  use, and drag the broadcast columns of five steps along - 250 live registers at the end of the elimination)
+#pragma unroll
+    for (int s = 0; s < DEG; ++s)
+#pragma unroll
+      for (int r = 0; r < R; ++r) asm volatile("" : "+v"(bc[s][r]));
+  });
+  QD_SB();
+  if (__ballot(bad) != 0ull) return 2;
+#ifdef QD_CUT
+  if (st_x) { double t = 0; for (int s = 0; s < DEG; ++s) for (int r = 0; r < R; ++r) t += bc[s][r]; Q.ew[(int64_t)e * EW_SIZE + (int)b] = t + RWv[0] + SGv[1] + ry + rc + ce; }
+  return 0;
+#endif
+  QD_PH(2)
+  QD_SB();
+  // now: lane b < NX, slot s: column (s, b) of G_cc^-1;  lanes NX .. NA-1, slot 0: G_cc^-1 J_u;  lane NA, slot 0: G_cc^-1 r
+  // ---- 6. forward-pass record: G_cc^-1 (row-major), Sigma_w, r_w
+  if (st_x) {
+    double* ew = Q.ew + (int64_t)e * EW_SIZE;
+#pragma unroll
+    for (int s = 0; s < DEG; ++s)
+#pragma unroll
+      for (int r = 0; r < R; ++r) ew[EW_LU + r * LU_N + s * NX + (int)b] = bc[s][r];
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+      ew[EW_SIGW + s * NX + (int)b] = SGv[s] + Q.dsw;
+      ew[EW_RW + s * NX + (int)b] = RWv[s];
+    }
+  }
+  // the compact records of the quad this wavefront handles next: on their way while the condensing runs
+  if (e0n >= 0) stage_quad(Q, e0n, lane, Ld, bank ^ 1);
+  // ---- 7. this lane's column of [W | w0]: W_x = sum_s C[0][s+1] (G_cc^-1)[:, (s, b)], W_u = -G_cc^-1 J_u, w0 = -G_cc^-1 r; continuity rows
+  double Wc[NW];
+  {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double t = (isx ? DOMPC_C[0 * (DEG + 1) + 1] : -1.0) * bc[0][r];
+#pragma unroll
+      for (int s = 1; s < DEG; ++s) t = fma(isx ? DOMPC_C[0 * (DEG + 1) + s + 1] : 0.0, bc[s][r], t);
+      Wc[r] = t;
+    }
+    sfor<NX>([&](auto A_) {
+      constexpr int a = A_;
+      const double rcb = rbc<a>(rc);
+      double t = (j == NA) ? -rcb : ((j == a) ? DOMPC_D[0] : 0.0);
+#pragma unroll
+      for (int s = 1; s <= DEG; ++s) t = fma(DOMPC_D[s], Wc[(s - 1) * NX + a], t);
+      Wc[R + a] = t;
+    });
+  }
+  double* S_ = Q.es + (int64_t)e * ES_SIZE;
+  {
+    // linearised dynamics of the interval: [A B] = end-point rows of W, c~ = w0_end + (end-point residual)
+    double cv = 0.0;
+    sfor<NX>([&](auto A_) {
+      constexpr int a = A_;
+      if (act && j < NA) S_[ES_AB + a * NA + j] = Wc[R + a];
+      const double w0a = rbc<NA>(Wc[R + a]);
+      cv = (j == a) ? w0a + ce : cv;
+    });
+    if (st_x) S_[ES_CV + (int)b] = cv;
+  }
+  QD_PH(7)
+  QD_SB();
+  // ---- 8. condensing.  Lane c owns column c of Z~ = [W | w0 | 0]:  acc[i] = row i of
+  //      [Q~ | q~ | W'b] = sum_p Z_p' ((H_p + Sigma_p) Z~_p + [0 | r_w,p | b_p]) + W_k' (Sigma_k W~_k + [0 | r_w,k | b_k])
+  double acc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) acc[i] = 0.0;
+  {
+    const double ind = (j >= NA) ? 1.0 : 0.0;                 // the two vector columns (lanes NA, NA + 1)
+    ldsd* Wb = Ld + QL_WB + g * QL_WBG;
+    const ldsd* Lvec = Ld + QL_RW + g * QL_VG + (j == NA + 1 ? NW : 0);
+    sfor<M>([&](auto P_) {
+      constexpr int p = P_;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (j <= NA) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) Wb[k * QL_WS + j] = Wc[p * NX + k];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double Zc[NX], Tv[NA];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) Zc[k] = (j <= NA) ? Wc[p * NX + k] : 0.0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) Tv[i] = 0.0;
+      if constexpr (p < DEG) {
+        // lambda-weighted Hessian of the dynamics at point p over (x_p, u): packed upper triangle, only its structural non-zeros
+        sfor<NA>([&](auto I_) {
+          constexpr int i = I_;
+          sfor<NA - i>([&](auto D_) {
+            constexpr int k = i + D_;
+            constexpr MoRef rf = moref_dyn(p, MOH_H0 + symi(i, k, NA));
+            if constexpr (rf.kind != 0) {
+              const double h = mo_dyn_val<rf.kind, rf.off>(rec);
+              // entry (i, k) and its mirror; rows / columns >= NX belong to u: Z~ has the unit vector e_c there (columns NX .. NA-1)
+              if constexpr (k < NX) {
+                Tv[i] = fma(h, Zc[k], Tv[i]);
+                if constexpr (i != k) Tv[k] = fma(h, Zc[i], Tv[k]);
+              } else {
+                Tv[i] += (j == k) ? h : 0.0;
+                if constexpr (i != k) {
+                  if constexpr (i < NX) Tv[k] = fma(h, Zc[i], Tv[k]);
+                  else Tv[k] += (j == i) ? h : 0.0;
+                }
+              }
+            }
+          });
+        });
+      }
+      sfor<NX>([&](auto K_) {
+        constexpr int k = K_;
+        const double sg = rbc<k>(SGv[p]) + Q.dsw;
+        Tv[k] = fma(sg, Zc[k], Tv[k]);
+        Tv[k] = fma(ind, Lvec[p * NX + k], Tv[k]);
+      });
+      // acc[i] += sum_k Z_p[k][i] T[k]: the rows of Z_p from their staged copy, two rows per batch of LDS reads (the scheduler would
+      // otherwise issue all 130 reads of the slot up front and spill what they displace)
+      sfor<(NX + 1) / 2>([&](auto K2_) {
+        constexpr int k0 = 2 * K2_;
+        QD_SB();
+        double wr[2][NA];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < NA; ++i) wr[kk][i] = (k0 + kk < NX) ? (double)Wb[(k0 + kk) * QL_WS + i] : 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          if (k0 + kk < NX) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc[i] = fma(wr[kk][i], Tv[k0 + kk], acc[i]);
+          }
+      });
+      if constexpr (p < DEG) {
+#pragma unroll
+        for (int ku = 0; ku < NU; ++ku) acc[NX + ku] += Tv[NX + ku];
+      }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(acc[i]));
+      QD_SB();
+    });
+  }
+  // stage-cost Hessian (packed in the record; only its structural non-zeros)
+  sfor<NA>([&](auto I_) {
+    constexpr int i = I_;
+    sfor<NA - i>([&](auto D_) {
+      constexpr int k = i + D_;
+      constexpr MoRef rf = moref_lt(1 + NA + symi(i, k, NA));
+      if constexpr (rf.kind != 0) {
+        const double h = omh * mo_lt_val<rf.kind, rf.off>(rec);
+        acc[i] += (j == k) ? h : 0.0;
+        if constexpr (i != k) acc[k] += (j == i) ? h : 0.0;
+      }
+    });
+  });
+  QD_PH(1)
+  QD_SB();
+  // ---- 9. shared record of the edge
+  {
+    ldsd* Lq = Ld + QL_QV + g * 32;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (j == NA || j == NA + 1) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) Lq[(j - NA) * 16 + i] = acc[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    sfor<NA>([&](auto I_) {
+      constexpr int i = I_;
+      if (act && j >= i && j < NA) S_[ES_QT + symi(i, i, NA) + (j - i)] = acc[i];      // row i of the packed upper triangle: entries (i, i .. NA-1)
+    });
+    // gradient of the stage cost w.r.t. (x_n, u_n): entry j
+    double ltg = 0.0;
+    sfor<NA>([&](auto A_) {
+      constexpr int a = A_;
+      constexpr MoRef rf = moref_lt(1 + a);
+      if constexpr (rf.kind != 0) { const double t_ = mo_lt_val<rf.kind, rf.off>(rec); ltg = (j == a) ? t_ : ltg; }
+    });
+    if (act && j < NA) {
+      const double gy = pk.om * ltg, r = ry + gy;
+      S_[ES_GFY + j] = gy;
+      S_[ES_RY + j] = r;
+      S_[ES_QV + j] = Lq[j] + r;
+      S_[ES_QVB + j] = Lq[16 + j];
+    }
+    const bool last = pk.level == A.N - 1;
+    if (__ballot(last) != 0ull) {
+      double mg = 0.0;
+      sfor<NX>([&](auto A_) {
+        constexpr int a = A_;
+        constexpr MoRef rf = moref_mt(1 + a);
+        if constexpr (rf.kind != 0) { const double t_ = mo_mt_val<rf.kind, rf.off>(rec); mg = (j == a) ? t_ : mg; }
+      });
+      if (st_x && last) S_[ES_MG + (int)b] = pk.om * mg;
+      sfor<NX>([&](auto A_) {
+        constexpr int a = A_;
+        double v = 0.0;
+        sfor<NX>([&](auto B_) {
+          constexpr int bb = B_;
+          constexpr MoRef rf = moref_mt(1 + NX + symi(a, bb, NX));
+          if constexpr (rf.kind != 0) { const double t_ = mo_mt_val<rf.kind, rf.off>(rec); v = (j == bb) ? t_ : v; }
+        });
+        if (st_x && last) S_[ES_MH + a * NX + (int)b] = omh * v;
+      });
+    }
+    if (act && j == 0) {
+      constexpr MoRef r0 = moref_lt(0), m0 = moref_mt(0);
+      double obj = pk.om * mo_lt_val<r0.kind, r0.off>(rec);
+      if (last) obj += pk.om * mo_mt_val<m0.kind, m0.off>(rec);
+      S_[ES_OBJ] = obj;
+    }
+  }
+  QD_PH(3)
+  QD_SB();
+#undef QD_PH
+  return 0;
+}
+
+// the fallback of a quad whose pivot test failed: its edges one after the other through the wavefront-per-edge path (its own function:
+// the code of that path - dense image, matrix-core elimination with its pivoting repeat - stays out of the quad loop's register allocation)
+__device__ __attribute__((noinline)) int phase_edge_fallback(const void* kp, int slot, int b_, int e0, int soc, double sf, double mu, double dsw) {
+  const KArgs A = kernel_args(kp);
+  Thr T = make_thr(A);
+  T.kp = kp;
+  Prob Q = make_prob(A, __builtin_amdgcn_readfirstlane(slot), A.p + (int64_t)__builtin_amdgcn_readfirstlane(b_) * A.n_opt_p);
+  Q.sf = ufl(sf);
+  Q.soc = __builtin_amdgcn_readfirstlane(soc);
+  Q.dsw = ufl(dsw);
+  prob_bounds(Q);
+  const int lane = (int)(threadIdx.x & 63u);
+  ldsd* Ld = (ldsd*)lds_pool + (int64_t)(threadIdx.x >> 6) * EL_SIZE;
+  const int ef = __builtin_amdgcn_readfirstlane(e0);
+  const MocMap mm = moc_map(lane, 64);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  mo_image_init(Ld + EL_MOS, lane, 64);
+  if (MFMA_GJ) gj_table_init(Ld, lane);
+  int staged = -1, fail = 0;
+  for (int q = 0; q < 4; ++q) {
+    const int e = ef + q;
+    if (e < A.n_edges) fail |= eval_edge_coop(T, Q, e, -1, ufl(mu), lane, 64, Ld, staged, mm);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return fail;
+}
+
+// the edge loop of the derivative sweep: quads of consecutive edges, dealt to the wavefronts of the problem round-robin.  Its own
+// function (one call per sweep): inlined into phase_sweep the loop shared a register allocation with the model evaluation and the node
+// assembly around it and spilled ~370 values per quad.
+__device__ __attribute__((noinline)) int phase_sweep_quads(const void* kp, int b_, int slot, int soc, double sf, double mu, double dsw) {
+  const KArgs A = kernel_args(kp);
+  Thr T = make_thr(A);
+  T.kp = kp;
+  Prob Q = make_prob(A, ufl(slot), A.p + (int64_t)ufl(b_) * A.n_opt_p);
+  Q.sf = ufl(sf);
+  Q.soc = ufl(soc);
+  Q.dsw = ufl(dsw);
+  prob_bounds(Q);
+  mu = ufl(mu);
+  const int ng = T.nt / 64, gid = group_index(T.tid, 64), lane = T.tid % 64;
+  ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / 64) * EL_SIZE;
+  const int nq = (A.n_edges + 3) / 4;
+  int fail = 0, bank = 0;
+  int qd = gid;
+  if (qd >= nq) return 0;
+  const int gl = lane >> 4;
+  auto pack_of = [&](int q) { const int e = 4 * q + gl; return qd_pack(A, e < A.n_edges ? e : A.n_edges - 1, Q.sf); };
+  stage_quad(Q, 4 * qd, lane, Ld, 0);
+  QdPack pk = pack_of(qd);
+  while (qd < nq) {
+    const int qn = qd + ng;
+    const bool more = qn < nq;
+    const QdPack pkn = pack_of(more ? qn : qd);                // (requested now, needed by the next quad)
+    const int rc = eval_edge_quad(T, Q, 4 * qd, more ? 4 * qn : -1, mu, lane, Ld, bank, pk);
+    if (__builtin_amdgcn_readfirstlane(rc) == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (no LDS-DMA in flight into the region the fallback uses)
+      fail |= phase_edge_fallback(kp, Q.slot, b_, 4 * qd, Q.soc, Q.sf, mu, Q.dsw);
+      if (more) stage_quad(Q, 4 * qn, lane, Ld, bank ^ 1);
+    } else {
+      fail |= rc;
+    }
+    bank ^= 1;
+    pk = pkn;
+    qd = qn;
+  }
+  return fail;
+}
+__device__ inline int sweep_quads(const Thr& T, const Prob& Q, double mu) {
+  const KArgs& A = *Q.A;
+  const int b_ = (int)((Q.P - A.p) / A.n_opt_p);
+  return phase_sweep_quads(T.kp, b_, Q.slot, Q.soc, Q.sf, mu, Q.dsw);
+}
+#elif !defined(DOMPC_HOST_EMU)
+__device__ inline int sweep_quads(const Thr&, const Prob&, double) { return 0; }      // (never called: QUAD_EDGE is false for such a model)
+#endif

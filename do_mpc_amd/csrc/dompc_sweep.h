@@ -39,6 +39,11 @@ DOMPC_DEV inline int sweep(const Thr& T, Prob& Q, double mu) {
     for (int i = T.tid; i < A.n_edges * MO_REC; i += T.nt) { volatile double* p_ = Q.mo + i; *p_ = *p_; }
     T.sync();
   }
+#ifndef DOMPC_HOST_EMU
+  if constexpr (QUAD_EDGE) {
+    if (sweep_quads(T, Q, mu)) T.fset(1, FSET);
+  } else
+#endif
   {
     const int ng = T.nt / T.gs, gid = group_index(T.tid, T.gs), lane = T.tid % T.gs;
     ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / T.gs) * EL_SIZE;
