@@ -33,6 +33,10 @@ __device__ inline double rbc(double v) {
   static_assert(L >= 0 && L < 16, "lane inside a row of 16");
   return dompc_dpp_f64(0.0, v, 0x150 + L, 0xf, 0xf, true);
 }
+// the value is computed HERE (an empty asm the optimiser cannot look through): without it the IR-level sinking pass moves whole chains of
+// arithmetic next to their first use, hundreds of instructions later, and keeps their operands alive (in scratch) in between
+__device__ inline void pin(double& v) { asm volatile("" : "+v"(v)); }
+__device__ inline void pin(int& v) { asm volatile("" : "+v"(v)); }
 template <class F, int... I>
 __device__ inline void sfor_(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 // f(integral_constant<int, i>) for i = 0 .. N-1: loops whose index has to be a constant expression
@@ -101,7 +105,7 @@ __device__ inline void stage_quad(const Prob& Q, int e0, int lane, ldsd* Ld, int
 // quad this wavefront handles next (-1: none) - requested into the other bank once the elimination is through.
 // Returns 0, 1 (a singular block cannot happen here: it takes the fallback) or 2: at least one collocation block failed the pivot test
 // in its natural order - nothing that the fallback (eval_edge_coop on each edge) does not write again has been stored.
-__device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0n, double mu, int lane_, ldsd* Ld, int bank, const QdPack& pk) {
+__device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0n, double mu, int lane_, ldsd* Ld, int bank, const QdPack& pk, QdPack& pkn) {
   const KArgs& A = *Q.A;
   // (the lane number as a value the optimiser cannot see through: everything derived from it - 16 lane predicates, the per-lane selects of
   //  collocation coefficients and unit vectors - is otherwise hoisted out of the quad loop as loop-invariant and held in ~100 registers)
@@ -176,13 +180,23 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
     for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * wv[r - 1];
     rc = soc ? cinc : wv[M - 1] - xf;
     ce = soc ? cine : wv[M - 1] - xc;
-    if (st_x && !soc) {
-#pragma unroll
-      for (int jj = 0; jj < DEG; ++jj) Q.c[pk.row0 + jj * NX + (int)b] = res[jj];
-      Q.c[pk.row0 + R + (int)b] = rc;
-      Q.c[pk.row0 + NW + (int)b] = ce;
-    }
   }
+  // barrier terms of this lane's unknowns (one per slot): gradient at mu and per unit mu, Sigma, -z_L + z_U.  Before the columns are built:
+  // the iterate, the bounds and their multipliers (15 values) are dead afterwards
+  double BGv[M], BBv[M], SGv[M], ZDv[M];
+#pragma unroll
+  for (int s = 0; s < M; ++s) {
+    const double xv = wv[s], l = lbv[s], u = ubv[s];
+    BGv[s] = bar_grad(xv, l, u, mu, !(Q.soc & 2));
+    BBv[s] = bar_grad(xv, l, u, 1.0);
+    SGv[s] = sigma_of(xv, l, u, zlv[s], zuv[s]);
+    ZDv[s] = zuv[s] - zlv[s];
+  }
+#pragma unroll
+  for (int s = 0; s < M; ++s) { pin(BGv[s]); pin(BBv[s]); pin(SGv[s]); pin(ZDv[s]); }
+#pragma unroll
+  for (int jj = 0; jj < DEG; ++jj) pin(res[jj]);
+  pin(rc); pin(ce);
   // ---- 3. this lane's columns of [G_cc | J_u | r]: bc[s][(jj, a)]
   //   lane b < NX, slot s: column (s, b) of G_cc = [s == jj] J_jj[a][b] - [a == b] C[s+1][jj+1]
   //   lanes NX .. NA-1, slot 0: column ku of the input Jacobians J_jj[a][NX + ku];  lane NA, slot 0: the residual rows;  zero otherwise
@@ -213,17 +227,27 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
   });
   QD_PH(5)
   QD_SB();
-  // ---- 4. dual-residual pieces: column times the multipliers of the edge's rows; barrier terms of this lane's unknowns
-  double RWv[M], SGv[M], ry;
+  // ---- 4. dual-residual pieces: column times the multipliers of the edge's rows
+  double RWv[M], RDv[M], ry;
   {
-    double bl[DEG][NX];                               // multipliers of the collocation rows (jj, a), for every lane of the edge
-    sfor<DEG>([&](auto J_) { constexpr int jj = J_; sfor<NX>([&](auto A_) { constexpr int a = A_; bl[jj][a] = rbc<a>(lam[jj]); }); });
     double tcol[M];
 #pragma unroll
-    for (int s = 0; s < DEG; ++s) {
-      double t = 0.0;
+    for (int s = 0; s < M; ++s) tcol[s] = 0.0;
+    double ryu = 0.0;
+    // multipliers of the collocation rows (jj, a) from their owner, lane a: block (jj, jj) of G_cc and the input columns
+    sfor<DEG>([&](auto J_) {
+      constexpr int jj = J_;
+      sfor<NX>([&](auto A_) {
+        constexpr int a = A_;
+        const double la = rbc<a>(lam[jj]);
+        tcol[jj] = fma(la, bc[jj][jj * NX + a], tcol[jj]);       // J_jj' lambda_jj - C[jj+1][jj+1] lambda_jj
+        if constexpr (jj == 0) ryu = fma(la, bc[0][a], ryu);
+        else ryu = fma(la, bc[0][jj * NX + a], ryu);
+      });
+    });
 #pragma unroll
-      for (int a = 0; a < NX; ++a) t = fma(bl[s][a], bc[s][s * NX + a], t);       // block (s, s): J_s' lambda_s - C[s+1][s+1] lambda_s
+    for (int s = 0; s < DEG; ++s) {
+      double t = tcol[s];
 #pragma unroll
       for (int jj = 0; jj < DEG; ++jj)
         if (jj != s) t = fma(-DOMPC_C[(s + 1) * (DEG + 1) + jj + 1], lam[jj], t);
@@ -231,27 +255,19 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
     }
     tcol[M - 1] = lamc + nue;                        // end-point column: +1 in its continuity row, +1 in the end-point row
     // parent state columns: -C[0][j] in row (jj, b), -D_0 in the continuity row; input columns: J_u' lambda
-    double ryx = -DOMPC_D[0] * lamc, ryu = 0.0;
+    double ryx = -DOMPC_D[0] * lamc;
 #pragma unroll
     for (int jj = 0; jj < DEG; ++jj) ryx = fma(-DOMPC_C[0 * (DEG + 1) + jj + 1], lam[jj], ryx);
-#pragma unroll
-    for (int jj = 0; jj < DEG; ++jj)
-#pragma unroll
-      for (int a = 0; a < NX; ++a) ryu = fma(bl[jj][a], bc[0][jj * NX + a], ryu);
     ry = isx ? ryx : ryu;                             // (lanes < NA; completed with the cost gradient below)
-    ldsd* Lv = Ld + QL_RW + g * QL_VG;
 #pragma unroll
-    for (int s = 0; s < M; ++s) {
-      const double t = tcol[s], xv = wv[s], l = lbv[s], u = ubv[s];
-      RWv[s] = t + bar_grad(xv, l, u, mu, !(Q.soc & 2));
-      const double bb = bar_grad(xv, l, u, 1.0);
-      SGv[s] = sigma_of(xv, l, u, zlv[s], zuv[s]);
-      if (isx) { Lv[s * NX + (int)b] = RWv[s]; Lv[NW + s * NX + (int)b] = bb; }
-      if (st_x) {
-        const int gi = pk.woff + s * NX + (int)b;
-        Q.gf[gi] = 0.0;
-        Q.rd[gi] = t - zlv[s] + zuv[s];
-      }
+    for (int s = 0; s < M; ++s) { RWv[s] = tcol[s] + BGv[s]; RDv[s] = tcol[s] + ZDv[s]; }
+#pragma unroll
+    for (int s = 0; s < M; ++s) { pin(RWv[s]); pin(RDv[s]); }
+    pin(ry);
+    if (isx) {
+      ldsd* Lv = Ld + QL_RW + g * QL_VG;
+#pragma unroll
+      for (int s = 0; s < M; ++s) { Lv[s * NX + (int)b] = RWv[s]; Lv[NW + s * NX + (int)b] = BBv[s]; }
     }
   }
   QD_PH(6)
@@ -307,6 +323,18 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
   // now: lane b < NX, slot s: column (s, b) of G_cc^-1;  lanes NX .. NA-1, slot 0: G_cc^-1 J_u;  lane NA, slot 0: G_cc^-1 r
   // ---- 6. forward-pass record: G_cc^-1 (row-major), Sigma_w, r_w
   if (st_x) {
+    if (!soc) {
+#pragma unroll
+      for (int jj = 0; jj < DEG; ++jj) Q.c[pk.row0 + jj * NX + (int)b] = res[jj];
+      Q.c[pk.row0 + R + (int)b] = rc;
+      Q.c[pk.row0 + NW + (int)b] = ce;
+    }
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+      const int gi = pk.woff + s * NX + (int)b;
+      Q.gf[gi] = 0.0;
+      Q.rd[gi] = RDv[s];
+    }
     double* ew = Q.ew + (int64_t)e * EW_SIZE;
 #pragma unroll
     for (int s = 0; s < DEG; ++s)
@@ -320,6 +348,10 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
   }
   // the compact records of the quad this wavefront handles next: on their way while the condensing runs
   if (e0n >= 0) stage_quad(Q, e0n, lane, Ld, bank ^ 1);
+  {
+    const int en = (e0n >= 0 ? e0n : e0) + g;                   // (its indices: requested now, needed at the top of the next quad)
+    pkn = qd_pack(A, en < A.n_edges ? en : A.n_edges - 1, Q.sf);
+  }
   // ---- 7. this lane's column of [W | w0]: W_x = sum_s C[0][s+1] (G_cc^-1)[:, (s, b)], W_u = -G_cc^-1 J_u, w0 = -G_cc^-1 r; continuity rows
   double Wc[NW];
   {
@@ -339,6 +371,8 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
       Wc[R + a] = t;
     });
   }
+#pragma unroll
+  for (int r = 0; r < NW; ++r) pin(Wc[r]);
   double* S_ = Q.es + (int64_t)e * ES_SIZE;
   {
     // linearised dynamics of the interval: [A B] = end-point rows of W, c~ = w0_end + (end-point residual)
@@ -349,6 +383,7 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
       const double w0a = rbc<NA>(Wc[R + a]);
       cv = (j == a) ? w0a + ce : cv;
     });
+    pin(cv);
     if (st_x) S_[ES_CV + (int)b] = cv;
   }
   QD_PH(7)
@@ -565,9 +600,10 @@ __device__ __attribute__((noinline)) int phase_sweep_quads(const void* kp, int b
   while (qd < nq) {
     const int qn = qd + ng;
     const bool more = qn < nq;
-    const QdPack pkn = pack_of(more ? qn : qd);                // (requested now, needed by the next quad)
-    const int rc = eval_edge_quad(T, Q, 4 * qd, more ? 4 * qn : -1, mu, lane, Ld, bank, pk);
+    QdPack pkn = pk;
+    const int rc = eval_edge_quad(T, Q, 4 * qd, more ? 4 * qn : -1, mu, lane, Ld, bank, pk, pkn);
     if (__builtin_amdgcn_readfirstlane(rc) == 2) {
+      pkn = pack_of(more ? qn : qd);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (no LDS-DMA in flight into the region the fallback uses)
       fail |= phase_edge_fallback(kp, Q.slot, b_, 4 * qd, Q.soc, Q.sf, mu, Q.dsw);
       if (more) stage_quad(Q, 4 * qn, lane, Ld, bank ^ 1);
