@@ -579,6 +579,8 @@ def main(argv=None):
                        "start": "cold (set_initial_guess semantics)", "parallelism": f"x0-batch shards x{world}",
                        "shard_of_rank0": [int(t["lo"]), int(t["hi"])], "global_batch": n_all,
                        "problem_slots": S.num_slots,
+                       "code_object": {k: (os.path.basename(v) if isinstance(v, str) and v.endswith(".hsaco") else v)
+                                       for k, v in getattr(S, "code_object_info", {}).items()},
                        "x0_batch": "seed 99: masses x(1 + 2 % U(-1,1)), temperatures +- 1 K U(-1,1), T_adiab recomputed "
                                    "(SURVEY 8(d) asks for 2 % relative on every state: on Kelvin temperatures that leaves the "
                                    "+-2 K reactor band and makes the robust problem infeasible, also for IPOPT)"},

@@ -41,6 +41,7 @@ DOMPC_HD inline void model_info(const int32_t* in, int64_t* out) {
   out[12] = RED_MAX; out[13] = ASM_N; out[14] = CUT1; out[15] = CUT2;      // exchange buffer layout (tree sharding)
   out[16] = DOMPC_SHARD;                                                   // built with tree-sharding support?
   out[17] = EL_SIZE;                                                       // LDS doubles per wavefront (edge / node working set)
+  out[19] = QUAD_EDGE ? 4 : 1;                                             // edges per wavefront in the derivative sweep (4: dompc_quad.h)
   out[18] = (int64_t)DOMPC_SRC_DIGEST;                                     // digest of the kernel sources this object was compiled from (build.py)
 }
 }  // namespace dompc

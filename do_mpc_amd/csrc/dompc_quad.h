@@ -37,6 +37,20 @@ __device__ inline double rbc(double v) {
 // arithmetic next to their first use, hundreds of instructions later, and keeps their operands alive (in scratch) in between
 __device__ inline void pin(double& v) { asm volatile("" : "+v"(v)); }
 __device__ inline void pin(int& v) { asm volatile("" : "+v"(v)); }
+// d += (value of `src` in lane L of the row of 16) * mul in ONE instruction: v_fmac_f64_dpp with the broadcast as the DPP operand.  The compiler
+// has the instruction but never folds a v_mov_b64_dpp into it, and an inline-asm DPP read is outside its hazard recogniser: the caller
+// guarantees that `src` was not written by one of the two preceding vector instructions (gfx9 DPP hazard: two wait states).
+#ifndef DOMPC_QUAD_FMAC_DPP
+#define DOMPC_QUAD_FMAC_DPP 1
+#endif
+template <int L>
+__device__ inline void fmac_rbc(double& d, const double& src, double mul) {
+#if DOMPC_QUAD_FMAC_DPP
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(src), "v"(mul), "n"(L));
+#else
+  d = fma(rbc<L>(src), mul, d);
+#endif
+}
 template <class F, int... I>
 __device__ inline void sfor_(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 // f(integral_constant<int, i>) for i = 0 .. N-1: loops whose index has to be a constant expression
@@ -273,36 +287,44 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
   QD_PH(6)
   QD_SB();
   // ---- 5. in-place Gauss-Jordan in the natural pivot order: column k = (sk, bk) lives in slot sk of lane bk
+  // The pivot column is replaced by column k of the inverse in place; its scaling -1 / a_kk is DEFERRED: the lane keeps the column as it
+  // is (row k: -1) and remembers the factor of that slot - every later update is linear in the column, so one multiplication per entry at
+  // the end replaces one per entry and pivot (19 of the ~90 instructions of a step).
+  // Pivot test: |a_kk| >= GJ_U max |a_rk| over the rows of the same group of four - the test of the blocked elimination this replaces
+  // (edge_factor_mfma tests the multipliers of its 4 x 4 pivot blocks); a failure sends the quad through the fallback.
   int bad = 0;
+  double sig[DEG];
+#pragma unroll
+  for (int s = 0; s < DEG; ++s) sig[s] = 1.0;
   sfor<R>([&](auto K_) {
     constexpr int k = K_, sk = k / NX, bk = k % NX;
+    constexpr int rt1 = (4 * (k / 4 + 1) < R) ? 4 * (k / 4 + 1) : R;
     QD_SB();
     const bool own = (j == bk);
     double m = 0.0;
 #pragma unroll
-    for (int r = k + 1; r < R; ++r) m = fmax(m, fabs(bc[sk][r]));
+    for (int r = k + 1; r < rt1; ++r) m = fmax(m, fabs(bc[sk][r]));
     const double akk = fabs(bc[sk][k]);
     bad |= (int)(own & !(akk >= GJ_U * m && akk > 1e-300));
     const double pl = fast_rcp((akk > 1e-300) ? bc[sk][k] : 1.0);
     const double pinv = rbc<bk>(pl);
-    const double mfix = own ? -pl : 1.0;
-    double pm[DEG];
+    sig[sk] = own ? -pl : sig[sk];
+    double pm[DEG];                                   // minus the scaled pivot row
 #pragma unroll
     for (int s = 0; s < DEG; ++s) {
       const double prow = bc[s][k] * pinv;
-      pm[s] = (s == sk && own) ? 0.0 : prow;          // (the pivot column itself keeps its entries: scaled below)
-      bc[s][k] = (s == sk && own) ? pl : prow;        // row k: scaled; the pivot position: 1 / a_kk
+      pm[s] = (s == sk && own) ? 0.0 : -prow;         // (the pivot column itself keeps its entries)
+      bc[s][k] = (s == sk && own) ? -1.0 : prow;      // row k: scaled; the pivot position: 1 / a_kk = (-1 / a_kk) (-1)
+      pin(pm[s]);
     }
-    // rows r != k: a_r. -= a_rk (a_k. / a_kk); the pivot column becomes column k of the inverse: -a_rk / a_kk
+    // rows r != k: a_r. -= a_rk (a_k. / a_kk), a_rk read from its owner through the DPP operand.  The slot of the pivot column LAST: its
+    // update overwrites the broadcast source (and nothing of this step wrote that register before - the hazard rule of fmac_rbc)
+    asm volatile("s_nop 1");
     sfor<R>([&](auto R_) {
       constexpr int r = R_;
       if constexpr (r != k) {
-        const double f = rbc<bk>(bc[sk][r]);
-#pragma unroll
-        for (int s = 0; s < DEG; ++s) {
-          const double t = fma(-f, pm[s], bc[s][r]);
-          bc[s][r] = (s == sk) ? t * mfix : t;
-        }
+        sfor<DEG>([&](auto S_) { constexpr int s = S_; if constexpr (s != sk) fmac_rbc<bk>(bc[s][r], bc[sk][r], pm[s]); });
+        fmac_rbc<bk>(bc[sk][r], bc[sk][r], pm[sk]);
       }
     });
     // (every entry is computed HERE: without this the updates of the last pivots are sunk behind the elimination, next to their first
@@ -310,8 +332,13 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
 #pragma unroll
     for (int s = 0; s < DEG; ++s)
 #pragma unroll
-      for (int r = 0; r < R; ++r) asm volatile("" : "+v"(bc[s][r]));
+      for (int r = 0; r < R; ++r) pin(bc[s][r]);
   });
+  QD_SB();
+#pragma unroll
+  for (int s = 0; s < DEG; ++s)
+#pragma unroll
+    for (int r = 0; r < R; ++r) bc[s][r] *= sig[s];
   QD_SB();
   if (__ballot(bad) != 0ull) return 2;
 #ifdef QD_CUT

@@ -38,7 +38,7 @@ struct dompc_handle {
   bool batch_object_stale = false;       // a `_batch` sibling exists but was built from other sources / another model: not used
   bool block_auto = true;          // threads per problem chosen per call from the batch size
   int32_t slots64 = 0, slots256 = 0;   // resident workgroups at 64 / 256 threads
-  int64_t ws_stride = 0, sweep_block = 0, el_size = 0;
+  int64_t ws_stride = 0, sweep_block = 0, el_size = 0, edges_per_wave = 1;
   dompc::KArgs base;       // tables + workspace filled in, I/O pointers zero
   std::vector<void*> dev_allocs;
   // staging for host-pointer calls
@@ -393,7 +393,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     char hash_b[64] = {0};
     hipFunction_t fn_info_b = nullptr;
     bool same = hipModuleGetFunction(&fn_info_b, h->module_batch, "dompc_model_info_kernel") == hipSuccess && !query_info(fn_info_b, info_b, hash_b);
-    for (int i = 0; same && i < 19; ++i) same = info_b[i] == info[i];
+    for (int i = 0; same && i < 20; ++i) same = info_b[i] == info[i];
     same = same && strncmp(hash, hash_b, 63) == 0;
     if (!same) {
       hipModuleUnload(h->module_batch);
@@ -425,6 +425,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
   for (int i = 0; i < 4; ++i) h->xlayout[i] = info[12 + i];
   h->shard_capable = info[16] != 0;
   h->el_size = info[17];
+  h->edges_per_wave = info[19] > 0 ? info[19] : 1;
   // ---- slots: one per workgroup the device can keep resident (occupancy of the solver kernel at this block size
   //      and LDS pool, times the number of CUs); more problems than slots are pulled from a work counter
   int max_batch = d.max_batch > 0 ? d.max_batch : 1;
@@ -730,6 +731,7 @@ static int serve_exchanges(dompc_handle* h, hipStream_t st) {
 
 extern "C" int64_t dompc_last_exchange_count(const dompc_handle* h) { return h ? h->n_exchanges : 0; }
 
+extern "C" int dompc_edges_per_wavefront(const dompc_handle* h) { return h ? (int)h->edges_per_wave : 0; }
 extern "C" int dompc_batch_object_state(const dompc_handle* h) {
   if (!h) return -1;
 #ifndef DOMPC_HOST_EMU

@@ -127,6 +127,8 @@ def _load(lib_path: str) -> C.CDLL:
     lib.dompc_last_exchange_count.restype = C.c_int64
     lib.dompc_batch_object_state.argtypes = [vp]
     lib.dompc_batch_object_state.restype = C.c_int
+    lib.dompc_edges_per_wavefront.argtypes = [vp]
+    lib.dompc_edges_per_wavefront.restype = C.c_int
     lib.dompc_rccl_unique_id.argtypes = [vp, C.c_char_p, vp]
     lib.dompc_rccl_unique_id.restype = C.c_int
     lib.dompc_rccl_init.argtypes = [vp, C.c_char_p, vp, C.c_int32, C.c_int32]
@@ -224,6 +226,7 @@ class HipIpmSolver:
         self._h = h
         # 0: no launch-shape-specific sibling code object, 1: loaded, 2: found but stale (other sources / model) and therefore not used
         self.batch_object_state = int(self._lib.dompc_batch_object_state(h))
+        self.edges_per_wavefront = int(self._lib.dompc_edges_per_wavefront(h))      # 4: quad sweep (csrc/dompc_quad.h)
         if self.batch_object_state == 2:
             import warnings
             warnings.warn("dompc: the `_batch` code object next to %s was built from other sources and is not used "
@@ -366,6 +369,25 @@ class HipIpmSolver:
 
     def stats(self) -> dict:
         return dict(self._stats)
+
+    @property
+    def code_object_info(self) -> dict:
+        """Which gfx950 code objects this handle runs and how they were compiled: the machine-scheduler flags each one got (build.py falls
+        back to the default strategy for a model on which this ROCm's clang crashes with the iterative scheduler - `<object>.sched` records
+        it), whether the launch-shape-specific `_batch` sibling is in use, and the edges per wavefront of the derivative sweep."""
+        def sched_of(path):
+            try:
+                with open(path + ".sched") as f:
+                    return f.read().strip() or "default"
+            except OSError:
+                return "unknown"
+        co = self.code_object_path
+        info = {"object": co, "sched": sched_of(co) if co else "unknown", "edges_per_wavefront": self.edges_per_wavefront,
+                "batch_object_state": self.batch_object_state}
+        if co and self.batch_object_state == 1:
+            info["batch_object"] = co[:-len(".hsaco")] + "_batch.hsaco"
+            info["batch_sched"] = sched_of(info["batch_object"])
+        return info
 
     def abort(self, stop: bool = True):
         """Stop request (dompc_abort): solves in flight leave their IPM loop with return_status

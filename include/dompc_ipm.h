@@ -247,6 +247,9 @@ int64_t dompc_last_exchange_count(const dompc_handle* h);
 /* the launch-shape-specific sibling code object `<name>_batch.hsaco` of the handle: 0 = none next to the general object, 1 = loaded and
  * launched for batches of one wavefront per problem, 2 = found but built from other sources or for another model - not used */
 int dompc_batch_object_state(const dompc_handle* h);
+/* edges a wavefront handles at a time in the derivative sweep of this model class: 4 = the quad sweep (csrc/dompc_quad.h: single finite
+ * element, no nl_cons rows, at most 14 stage variables), 1 = the wavefront-per-edge paths */
+int dompc_edges_per_wavefront(const dompc_handle* h);
 
 /* ---- batched plant integration ---------------------------------------------------------
  * Replaces the integrator object of do_mpc.simulator.Simulator (do_mpc/simulator.py:381-416:
