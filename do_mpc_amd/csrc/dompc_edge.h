@@ -205,14 +205,15 @@ constexpr int MOH_H0 = NX + NX * NA;                                    // offse
 // DAE models: dense edge working set of eval_edge_dae (= dae::DG_SIZE, asserted in sweep())
 constexpr int DAE_NEED = DENSE_EDGE ? NW * (NW + NA + 2) + (NW + NA) * (NW + NA) + (NW + NA) * (NA + 2) + 2 * (NW + NA) + 3 * NW
                                       + NX * NW + NX * NA + NX + NE * NW + NE * NA + 2 * NW + RT_LEN : 0;
-// Quad sweep (round 6, dompc_quad.h): FOUR edges per wavefront, 16 lanes per edge, no dense image of the model-output record.  LDS of a
+// Quad sweep (round 6, dompc_quad.h): FOUR edges per wavefront, 16 lanes per edge, no dense image of the model-output record; models with
+// one finite element per interval, at most 14 stage variables (x, u) and at most four nl_cons rows evaluated at (x_n, u_n).  LDS of a
 // wavefront: two banks of four compact records (the next four edges are copied in by LDS-DMA while the current ones are computed), one
 // slot (NX rows) of the four W | w0 matrices, the barrier vectors r_w | b of the four edges, and the transposed q~ | W'b.
 #ifndef DOMPC_QUAD
 #define DOMPC_QUAD 1
 #endif
 #ifndef DOMPC_HOST_EMU
-constexpr bool QUAD_EDGE = (DOMPC_QUAD != 0) && MO_COMPACT && (DEG >= 1) && (NA + 2 <= 16) && (DOMPC_NE == 0) && !RT_CUSTOM && !FREE_ROOT &&
+constexpr bool QUAD_EDGE = (DOMPC_QUAD != 0) && MO_COMPACT && (DEG >= 1) && (NA + 2 <= 16) && (NE <= 4) && !RT_CUSTOM && !FREE_ROOT &&
                            (DOMPC_SHARD == 0) && (DEG * DEG * NX <= 64) && (DOMPC_DYN_NV >= NX);
 #else
 constexpr bool QUAD_EDGE = false;

@@ -67,12 +67,15 @@ constexpr MoRef moref_in(int d, const int* vidx, int nv, const int* cidx, int nc
 }
 constexpr MoRef moref_dyn(int p, int d) { return moref_in(d, DOMPC_DYN_VIDX, DOMPC_DYN_NV, DOMPC_DYN_CIDX, DOMPC_DYN_NC, p * DOMPC_DYN_NV); }
 constexpr MoRef moref_lt(int d) { return moref_in(d, DOMPC_LT_VIDX, DOMPC_LT_NV, DOMPC_LT_CIDX, DOMPC_LT_NC, MOC_LT); }
+constexpr MoRef moref_nl(int d) { return moref_in(d, DOMPC_NL_VIDX, DOMPC_NL_NV, DOMPC_NL_CIDX, DOMPC_NL_NC, MOC_NL); }
 constexpr MoRef moref_mt(int d) { return moref_in(d, DOMPC_MT_VIDX, DOMPC_MT_NV, DOMPC_MT_CIDX, DOMPC_MT_NC, MOC_MT); }
 // its value: `rec` = the compact record of this lane's edge in LDS (a constant index into a table with a constant initialiser folds to the literal)
 template <int KIND, int OFF>
 __device__ inline double mo_dyn_val(const ldsd* rec) { if constexpr (KIND == 2) return rec[OFF]; else if constexpr (KIND == 1) return DOMPC_DYN_CVAL[OFF]; else return 0.0; }
 template <int KIND, int OFF>
 __device__ inline double mo_lt_val(const ldsd* rec) { if constexpr (KIND == 2) return rec[OFF]; else if constexpr (KIND == 1) return DOMPC_LT_CVAL[OFF]; else return 0.0; }
+template <int KIND, int OFF>
+__device__ inline double mo_nl_val(const ldsd* rec) { if constexpr (KIND == 2) return rec[OFF]; else if constexpr (KIND == 1) return DOMPC_NL_CVAL[OFF]; else return 0.0; }
 template <int KIND, int OFF>
 __device__ inline double mo_mt_val(const ldsd* rec) { if constexpr (KIND == 2) return rec[OFF]; else if constexpr (KIND == 1) return DOMPC_MT_CVAL[OFF]; else return 0.0; }
 // the function values f of a point are the first NX entries of its compact record (lowering.py writes the variable entries in the order
@@ -83,11 +86,11 @@ constexpr bool qd_f_linear() {
 }
 
 // the indices of this lane's edge (KArgs::edge_pack); `om` = omega * objective scaling
-struct QdPack { int woff, row0, xoffp, xoffc, level; double om; };
+struct QdPack { int woff, row0, xoffp, xoffc, level, epsoff; double om; };
 __device__ inline QdPack qd_pack(const KArgs& A, int e, double sf) {
   const auto* ep = A.edge_pack + e * EP_N;
   QdPack k;
-  k.woff = ep[EP_WOFF]; k.row0 = ep[EP_ROW0]; k.xoffp = ep[EP_XOFF_PARENT]; k.xoffc = ep[EP_XOFF_CHILD]; k.level = ep[EP_LEVEL];
+  k.woff = ep[EP_WOFF]; k.row0 = ep[EP_ROW0]; k.xoffp = ep[EP_XOFF_PARENT]; k.xoffc = ep[EP_XOFF_CHILD]; k.level = ep[EP_LEVEL]; k.epsoff = ep[EP_EPSOFF_PARENT];
   k.om = __builtin_bit_cast(double, ((unsigned long long)(unsigned)ep[EP_OMEGA_HI] << 32) | (unsigned long long)(unsigned)ep[EP_OMEGA_LO]) * sf;
   return k;
 }
@@ -157,6 +160,21 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
   }
   const double lamc = ldoff(Q.lam, (unsigned)pk.row0 + (unsigned)R + b), nue = ldoff(Q.lam, (unsigned)pk.row0 + (unsigned)NW + b);
   const double cinc = soc ? ldoff(Q.c, (unsigned)pk.row0 + (unsigned)R + b) : 0.0, cine = soc ? ldoff(Q.c, (unsigned)pk.row0 + (unsigned)NW + b) : 0.0;
+  // nl_cons rows of the edge (one evaluation of NE rows at (x_n, u_n), _mpc.py:1239-1246): multipliers, row scalings, slack variables
+  // with their bounds and bound multipliers, the eps entries the rows read - the same for every lane of the edge
+  double ydv[NE1], sgv[NE1], slv[NE1], sllv[NE1], sluv[NE1], zslv[NE1], zsuv[NE1], cnl[NE1], epv[NSE > 0 ? NSE : 1];
+  if constexpr (NE > 0) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const unsigned si = (unsigned)(e * NE1 + i);
+      ydv[i] = ldoff(Q.lam, (unsigned)pk.row0 + (unsigned)(NW + NX + i));
+      sgv[i] = ldoff(Q.sgn, si); slv[i] = ldoff(Q.s, si); sllv[i] = ldoff(Q.sl, si); sluv[i] = ldoff(Q.su, si);
+      zslv[i] = ldoff(Q.zsl, si); zsuv[i] = ldoff(Q.zsu, si);
+      cnl[i] = soc ? ldoff(Q.c, (unsigned)pk.row0 + (unsigned)(NW + NX + i)) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NSE; ++q) epv[q] = ldoff(Q.x, (unsigned)pk.epsoff + (unsigned)q);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the staged records (and everything above) have landed
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -508,6 +526,21 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
       }
     });
   });
+  if constexpr (NE > 0) {
+    // lambda-weighted Hessian of the nl_cons rows over (x_n, u_n) (packed; only its structural non-zeros)
+    sfor<NA>([&](auto I_) {
+      constexpr int i = I_;
+      sfor<NA - i>([&](auto D_) {
+        constexpr int k = i + D_;
+        constexpr MoRef rf = moref_nl(NE + NE * NA + symi(i, k, NA));
+        if constexpr (rf.kind != 0) {
+          const double h = mo_nl_val<rf.kind, rf.off>(rec);
+          acc[i] += (j == k) ? h : 0.0;
+          if constexpr (i != k) acc[k] += (j == i) ? h : 0.0;
+        }
+      });
+    });
+  }
   QD_PH(1)
   QD_SB();
   // ---- 9. shared record of the edge
@@ -532,8 +565,45 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
       constexpr MoRef rf = moref_lt(1 + a);
       if constexpr (rf.kind != 0) { const double t_ = mo_lt_val<rf.kind, rf.off>(rec); ltg = (j == a) ? t_ : ltg; }
     });
+    double rnl = 0.0;                                 // Jd' (y_d sg): share of the nl_cons rows in the dual residual of (x_n, u_n), entry j
+    if constexpr (NE > 0) {
+      sfor<NE>([&](auto I_) {
+        constexpr int i = I_;
+        double jd = 0.0;
+        sfor<NA>([&](auto A_) {
+          constexpr int a = A_;
+          constexpr MoRef rf = moref_nl(NE + i * NA + a);
+          if constexpr (rf.kind != 0) { const double t_ = mo_nl_val<rf.kind, rf.off>(rec); jd = (j == a) ? t_ : jd; }
+        });
+        const double jds = jd * sgv[i];
+        rnl = fma(jds, ydv[i], rnl);
+        if (act && j < NA) Q.ew[(int64_t)e * EW_SIZE + EW_JD + i * NA + j] = jds;
+      });
+      if (act && j == 0) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+          double d = 0.0;
+          sfor<NE>([&](auto I_) {                      // (row i of d(x_n, u_n): its entry of the record)
+            constexpr int i2 = I_;
+            constexpr MoRef rf = moref_nl(i2);
+            if constexpr (rf.kind != 0) { const double t_ = mo_nl_val<rf.kind, rf.off>(rec); d = (i == i2) ? t_ : d; }
+          });
+          const int sq = nl_slack(i);
+          if (NSE > 0 && sq >= 0) {
+#pragma unroll
+            for (int q = 0; q < NSE; ++q) d -= (q == sq) ? epv[q] : 0.0;
+          }
+          d *= sgv[i];
+          const double rdn = soc ? cnl[i] : d - slv[i];
+          if (!soc) Q.c[pk.row0 + NW + NX + i] = rdn;
+          S_[ES_RDN + i] = rdn;
+          S_[ES_SIGS + i] = sigma_of(slv[i], sllv[i], sluv[i], zslv[i], zsuv[i]);
+          S_[ES_RSN + i] = -ydv[i] + bar_grad(slv[i], sllv[i], sluv[i], mu);
+        }
+      }
+    }
     if (act && j < NA) {
-      const double gy = pk.om * ltg, r = ry + gy;
+      const double gy = pk.om * ltg, r = ry + gy + rnl;
       S_[ES_GFY + j] = gy;
       S_[ES_RY + j] = r;
       S_[ES_QV + j] = Lq[j] + r;
@@ -563,6 +633,10 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
       constexpr MoRef r0 = moref_lt(0), m0 = moref_mt(0);
       double obj = pk.om * mo_lt_val<r0.kind, r0.off>(rec);
       if (last) obj += pk.om * mo_mt_val<m0.kind, m0.off>(rec);
+      if constexpr (NE > 0) {
+#pragma unroll
+        for (int q = 0; q < NSE; ++q) obj += Q.sf * DOMPC_EPS_PEN[q] * epv[q];
+      }
       S_[ES_OBJ] = obj;
     }
   }

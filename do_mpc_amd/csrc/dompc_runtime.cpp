@@ -793,6 +793,17 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   if (K > (spread ? 256 : 32)) K = spread ? 256 : 32;
   if (spread && (int64_t)B * K > 2048) spread = false;       // (reduction partials: 64 x 32 workgroup rows)
   if (!spread && K > 32) K = 32;
+  {
+    // Co-residency: the device-scope barrier of the wide mode needs EVERY workgroup of the launch on the chip at the same time - a
+    // workgroup that waits for a free CU never arrives and its peers spin until the watchdog.  The grid is therefore capped by what this
+    // device keeps resident at the wide mode's workgroup size (occupancy of the kernel x compute units: a partitioned or smaller part,
+    // a DOMPC_WIDE / DOMPC_WIDE_SPREAD override); K shrinks until it fits, down to one workgroup per problem.  (What this cannot see:
+    // other kernels on the device - INTEGRATION.md section 4.)
+    const int wb_ = fit_block(h, 256);
+    const int64_t resident = (wb_ == 256 || h->slots64 <= 0) ? h->slots256 : (int64_t)h->slots64 * 64 / wb_;
+    auto grid_of = [&](int k, bool sp) -> int64_t { return sp ? (int64_t)B * k : (int64_t)((B + 7) / 8) * 8 * k; };
+    while (K > 1 && resident > 0 && grid_of(K, spread) > resident) --K;
+  }
   if (K > 1 && B <= 64 && B <= h->n_slots) {
     A.wide = K;
     A.wide_spread = spread ? 1 : 0;

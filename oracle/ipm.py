@@ -78,6 +78,39 @@ def _n_negative(K):
     return neg
 
 
+def _n_negative_sparse(Hreg, A, delta_c):
+    """Exact number of negative eigenvalues of K = [[Hreg, A'], [A, -delta_c I]] from a sparse LDL' WITHOUT pivoting: the variables in a
+    reverse Cuthill-McKee order of the pattern of Hreg + A'A, every constraint row directly behind the last of its variables - its pivot is
+    then the (non-zero) Schur complement -a (..)^-1 a' instead of the structural zero - and SuperLU in its natural order with diagonal
+    pivots only (symmetric mode, diag_pivot_thresh = 0).  Without a row interchange K = L D L' with D = diag(U), and Sylvester's law of
+    inertia gives the count (0.1 s for the 15 310 rows of industrial_poly; the dense Bunch-Kaufman count takes 20 - 45 s).  Returns -1 if
+    SuperLU had to interchange rows after all (the caller falls back to the dense count)."""
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    nv, m = Hreg.shape[0], A.shape[0]
+    Ac = A.tocsr()
+    G = (abs(Hreg) + abs(Ac.T) @ abs(Ac)).tocsr()
+    pv = np.asarray(reverse_cuthill_mckee(G, symmetric_mode=True))
+    pos = np.empty(nv, dtype=np.int64)
+    pos[pv] = np.arange(nv)
+    last = np.full(m, -1, dtype=np.int64)
+    rows = np.repeat(np.arange(m), np.diff(Ac.indptr))
+    np.maximum.at(last, rows, pos[Ac.indices])
+    order = np.lexsort((np.arange(nv + m), np.concatenate([2 * pos, 2 * last + 1])))
+    K = sps.bmat([[Hreg, Ac.T], [Ac, -delta_c * sps.identity(m) if delta_c > 0 else None]], format="csc")
+    Kp = K[order][:, order].tocsc()
+    try:
+        lu = spla.splu(Kp, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    except RuntimeError:
+        return -1
+    ident = np.arange(nv + m)
+    if not (np.array_equal(lu.perm_r, ident) and np.array_equal(lu.perm_c, ident)):
+        return -1
+    d = lu.U.diagonal()
+    if not np.all(np.isfinite(d)) or np.any(d == 0.0):
+        return -1
+    return int(np.sum(d < 0))
+
+
 class _FastKKT:
     """opts["fast"] (the CPU baseline of bench.py; the tests run without it): the augmented system of every iteration with
       * a STRUCTURAL singularity test in place of the two factorisations that IPOPT / the plain path spend on finding out that the
@@ -288,7 +321,7 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
     theta_max = o["theta_max_fact"] * max(1.0, theta0)
     theta_min = o["theta_min_fact"] * max(1.0, theta0)
     delta_w_last = 0.0
-    stats = dict(n_ls_fail=0, n_reg=0, n_soc=0, iters=[])
+    stats = dict(n_ls_fail=0, n_reg=0, n_soc=0, iters=[], n_ldl_checks=0, n_proxy_false_rejections=0)
     status = "Maximum_Iterations_Exceeded"
     success = False
     acc_count = 0
@@ -388,6 +421,22 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
                     curv = dv @ (Hreg @ dv)
                     if curv >= 1e-11 * (dv @ dv) or (dv @ dv) == 0.0:
                         break
+                    # The curvature of the computed step is a PROXY for IPOPT's test (the exact inertia MUMPS reports): the Newton step
+                    # has a component in the range space of A', so d'Hd < 0 can happen with a positive definite reduced Hessian - the
+                    # proxy then rejects a factorisation IPOPT accepts and delta_w is escalated for nothing (round 6: member 15 803 of the
+                    # timed batch at iteration 6 - exact count 7 210 = m at delta_w = 1.37e-7, proxy: rejected, next accepted value 4.5e-3).
+                    # inertia = "curvature_then_ldl": a rejection is checked with the exact count (dense Bunch-Kaufman LDL': 20 - 45 s
+                    # for the 15 310 rows of industrial_poly - or 0.1 s with the sparse count without pivoting, _n_negative_sparse; on request only: the
+                    # iterates of every stored oracle solve were produced with the proxy - the GPU parity test re-solves the members whose
+                    # iteration count differs from the product's with it)
+                    if o["inertia"] == "curvature_then_ldl":
+                        nneg = _n_negative_sparse(Hreg, A, delta_c)
+                        if nneg < 0:
+                            nneg = _n_negative(sps.bmat([[Hreg, A.T], [A, -delta_c * sps.identity(m) if delta_c > 0 else None]], format="csc"))
+                        stats["n_ldl_checks"] += 1
+                        if nneg == m:
+                            stats["n_proxy_false_rejections"] += 1
+                            break
                 stats["n_reg"] += 1
                 if delta_w == 0.0:
                     delta_w = o["delta_w_0"] if delta_w_last == 0.0 else max(o["delta_w_min"], o["kappa_w_minus"] * delta_w_last)
@@ -573,5 +622,6 @@ def solve(nlp, x0, p, lam_x0=None, lam_g0=None, opts=None, lbx=None, ubx=None, l
     res["stats"] = dict(success=success, return_status=status, iter_count=it,
                         t_wall_total=time.perf_counter() - t_start, n_eval=n_eval,
                         n_ls_fail=stats["n_ls_fail"], n_reg=stats["n_reg"], n_soc=stats["n_soc"], n_watchdog=stats["n_watchdog"], mu=mu,
-                        obj_scaling=sf, iters=stats["iters"])
+                        obj_scaling=sf, iters=stats["iters"], n_ldl_checks=stats["n_ldl_checks"],
+                        n_proxy_false_rejections=stats["n_proxy_false_rejections"])
     return res
