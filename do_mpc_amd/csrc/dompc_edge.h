@@ -23,9 +23,15 @@ DOMPC_DEV inline double eval_edge_f_t(const Prob& Q, int e, const double* xv, co
   const int row0 = A.edge_row0[e];
   const double om = A.edge_omega[e] * Q.sf;
   double f[NX];
+  // Round 6: the residual rows of a collocation point (and the continuity / end-point rows of an element) are formed in registers and
+  // stored together, behind the loads they need.  Stored one by one in the loop that forms them, every load of the next row waited for
+  // the store in front of it to reach memory (the compiler cannot move a load over a store that may alias; s_waitcnt vmcnt is in order):
+  // 30 write round trips per edge and trial point instead of 3, ~300 k of the ~700 k cycles of a trial evaluation.  Same arithmetic.
   if (M == 0) {
     dompc_dyn_f(xn, un, nullptr, tvp, pp, f);
-    for (int a = 0; a < NX; ++a) cv[row0 + a] = f[a] - xc[a];
+    double rl[NX];
+    for (int a = 0; a < NX; ++a) rl[a] = f[a] - xc[a];
+    for (int a = 0; a < NX; ++a) cv[row0 + a] = rl[a];
   } else {
     (void)REST;
     for (int i = 0; i < NI; ++i) {
@@ -35,22 +41,34 @@ DOMPC_DEV inline double eval_edge_f_t(const Prob& Q, int e, const double* xv, co
         if (SPLIT && part != i * DEG + (j - 1)) continue;
         const double* xij = w + slot_of(i, j) * NX;
         dompc_dyn_f(xij, un, nullptr, tvp, pp, f);
+        double rl[NX];
+#pragma unroll
         for (int a = 0; a < NX; ++a) {
           double xp = DOMPC_C[0 * (DEG + 1) + j] * xi0[a];
           for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + j] * w[slot_of(i, r) * NX + a];
-          cv[rb + (j - 1) * NX + a] = f[a] - xp;
+          rl[a] = f[a] - xp;
         }
+#pragma unroll
+        for (int a = 0; a < NX; ++a) cv[rb + (j - 1) * NX + a] = rl[a];
       }
       if (SPLIT && part != REST) continue;
       const double* xnext = w + next_slot(i) * NX;
+      double rl[NX];
+#pragma unroll
       for (int a = 0; a < NX; ++a) {
         double xf = DOMPC_D[0] * xi0[a];
         for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * w[slot_of(i, r) * NX + a];
-        cv[rb + DEG * NX + a] = xnext[a] - xf;
+        rl[a] = xnext[a] - xf;
       }
+#pragma unroll
+      for (int a = 0; a < NX; ++a) cv[rb + DEG * NX + a] = rl[a];
     }
     if (SPLIT && part != REST) return 0.0;
-    for (int a = 0; a < NX; ++a) cv[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
+    double rl[NX];
+#pragma unroll
+    for (int a = 0; a < NX; ++a) rl[a] = w[(M - 1) * NX + a] - xc[a];
+#pragma unroll
+    for (int a = 0; a < NX; ++a) cv[row0 + NW + a] = rl[a];
   }
   double obj = om * dompc_lterm_f(xn, un, nullptr, tvp, pp);
   if (k == A.N - 1) obj += om * dompc_mterm_f(xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
@@ -288,6 +306,28 @@ DOMPC_DEV inline int point_of_slot(int sl) {
   return (r == 0 || i >= NI) ? -1 : i * DEG + r - 1;
 }
 
+// The generated functions behind interfaces that say what the caller knows: the output record overlaps none of the inputs.  Without it the
+// compiler keeps every load of an input that follows a store to the record in program order BEHIND that store, and the wait for such a
+// load (s_waitcnt vmcnt is in order) is a wait for the store to reach memory.
+#ifndef DOMPC_EVAL_NOALIAS
+#define DOMPC_EVAL_NOALIAS 1          // 0: the generated functions as they are (A/B)
+#endif
+#if DOMPC_EVAL_NOALIAS
+#define DOMPC_RESTRICT __restrict__
+#else
+#define DOMPC_RESTRICT
+#endif
+DOMPC_DEV inline void dyn_c_noalias(const double* DOMPC_RESTRICT xs, const double* DOMPC_RESTRICT us, const double* DOMPC_RESTRICT tvp,
+                                    const double* DOMPC_RESTRICT pp, const double* DOMPC_RESTRICT lam, double* DOMPC_RESTRICT o) {
+  dompc_dyn_c(xs, us, nullptr, tvp, pp, lam, o);
+}
+DOMPC_DEV inline void lterm_c_noalias(const double* DOMPC_RESTRICT xs, const double* DOMPC_RESTRICT us, const double* DOMPC_RESTRICT tvp,
+                                      const double* DOMPC_RESTRICT pp, double* DOMPC_RESTRICT o) {
+  dompc_lterm_c(xs, us, nullptr, tvp, pp, o);
+}
+DOMPC_DEV inline void mterm_c_noalias(const double* DOMPC_RESTRICT xs, const double* DOMPC_RESTRICT tvp, const double* DOMPC_RESTRICT pp, double* DOMPC_RESTRICT o) {
+  dompc_mterm_c(xs, tvp, pp, o);
+}
 // Thread-parallel evaluation of the lowered model functions at the current iterate: one thread per
 // (edge, function instance) - NCOLL collocation points (f, J, lambda-weighted H), stage cost,
 // terminal cost (last stage), nonlinear constraints.  This is nlp_jac_g / nlp_hess_l / nlp_grad_f of
@@ -322,11 +362,11 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
       // compact record: [variable entries of point 0 | point 1 | ... | stage cost | terminal cost | nl_cons]
       if (kind == 0) {
         const int jj = j % (DEG > 0 ? DEG : 1) + 1;
-        dompc_dyn_c(w + slot_of(0, jj) * NX, un, nullptr, tvp, pp, Q.lam + row0 + (jj - 1) * NX, mo + j * DOMPC_DYN_NV);
+        dyn_c_noalias(w + slot_of(0, jj) * NX, un, tvp, pp, Q.lam + row0 + (jj - 1) * NX, mo + j * DOMPC_DYN_NV);
       } else if (kind == 1) {
-        dompc_lterm_c(xn, un, nullptr, tvp, pp, mo + MOC_LT);
+        lterm_c_noalias(xn, un, tvp, pp, mo + MOC_LT);
       } else if (kind == 2) {
-        if (k == A.N - 1) dompc_mterm_c(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MOC_MT);
+        if (k == A.N - 1) mterm_c_noalias(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MOC_MT);
       } else if (NE > 0) {
         double yds[NE1];      // (scaled rows sg d(x): the Hessian sum_i lambda_i sg_i hess d_i)
         for (int i = 0; i < NE; ++i) yds[i] = Q.lam[row0 + NW + NX + i] * Q.sgn[e * NE1 + i];

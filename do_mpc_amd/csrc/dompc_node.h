@@ -53,6 +53,11 @@ DOMPC_DEV inline void assemble_finish(const Prob& Q, int n, const double* in) {
   const int cc = A.node_child_count[n];
   const int xo = A.node_x_off[n];
   const int ie = A.node_in_edge[n];
+  // Every operand is loaded BEFORE the first result is stored (round 6).  The loop used to alternate per variable "store gf, load z_L / z_U,
+  // store rd": the compiler cannot move a load over a store that may alias, so every s_waitcnt of a load also waited for the store in
+  // front of it to reach memory - two to three write round trips per variable, 200 k cycles per trip of this thread-per-node loop and
+  // 7 % of a solve (profiles/r06_phase_cycles*.txt: "sweep:node assembly").  Same arithmetic, same order: the same bits.
+  double gxv[NX], rxv[NX], zlx[NX], zux[NX];
   for (int a = 0; a < NX; ++a) {
     double gx = in[a], rx = in[NX + a];
     if (ie >= 0) {
@@ -64,27 +69,42 @@ DOMPC_DEV inline void assemble_finish(const Prob& Q, int n, const double* in) {
     } else {
       rx += Q.lam[a];
     }
-    Q.gf[xo + a] = gx;
-    Q.rd[xo + a] = rx - Q.zl[xo + a] + Q.zu[xo + a];
+    gxv[a] = gx; rxv[a] = rx;
+    zlx[a] = Q.zl[xo + a]; zux[a] = Q.zu[xo + a];
   }
-  if (cc == 0) return;
-  const int uo = A.node_u_off[n];
-  double tmp[NU];
-  const double* up = uprev_ptr(Q, n, Q.x, tmp);
-  const double rw = node_rweight(Q, n);
-  for (int i = 0; i < NU; ++i) {
-    const double rt = (RT_CUSTOM ? 0.0 : 2.0 * rw * DOMPC_RTERM[i] * (Q.x[uo + i] - up[i])) + in[2 * NX + 2 * NU + i];    // (user-defined rterm: own share is in the edges' GFY / RY)
-    Q.gf[uo + i] = in[2 * NX + i] + rt;
-    Q.rd[uo + i] = in[2 * NX + NU + i] + rt - Q.zl[uo + i] + Q.zu[uo + i];
-  }
-  if (NS > 0) {
-    const int eo = A.node_eps_off[n];
-    for (int q = 0; q < NS; ++q) {
-      const double g = cc * Q.sf * DOMPC_EPS_PEN[q];
-      Q.gf[eo + q] = g;
-      Q.rd[eo + q] = g + in[2 * NX + 3 * NU + q] - Q.zl[eo + q] + Q.zu[eo + q];
+  const int uo = cc > 0 ? A.node_u_off[n] : 0;
+  double guv[NU > 0 ? NU : 1], ruv[NU > 0 ? NU : 1];
+  if (cc > 0) {
+    double tmp[NU];
+    const double* up = uprev_ptr(Q, n, Q.x, tmp);
+    const double rw = node_rweight(Q, n);
+    for (int i = 0; i < NU; ++i) {
+      const double rt = (RT_CUSTOM ? 0.0 : 2.0 * rw * DOMPC_RTERM[i] * (Q.x[uo + i] - up[i])) + in[2 * NX + 2 * NU + i];    // (user-defined rterm: own share is in the edges' GFY / RY)
+      guv[i] = in[2 * NX + i] + rt;
+      ruv[i] = in[2 * NX + NU + i] + rt - Q.zl[uo + i] + Q.zu[uo + i];
     }
   }
+  const int eo = (NS > 0 && cc > 0) ? A.node_eps_off[n] : 0;
+  double gev[NS1], rev[NS1];
+  if (NS > 0 && cc > 0)
+    for (int q = 0; q < NS; ++q) {
+      gev[q] = cc * Q.sf * DOMPC_EPS_PEN[q];
+      rev[q] = gev[q] + in[2 * NX + 3 * NU + q] - Q.zl[eo + q] + Q.zu[eo + q];
+    }
+  for (int a = 0; a < NX; ++a) {
+    Q.gf[xo + a] = gxv[a];
+    Q.rd[xo + a] = rxv[a] - zlx[a] + zux[a];
+  }
+  if (cc == 0) return;
+  for (int i = 0; i < NU; ++i) {
+    Q.gf[uo + i] = guv[i];
+    Q.rd[uo + i] = ruv[i];
+  }
+  if (NS > 0)
+    for (int q = 0; q < NS; ++q) {
+      Q.gf[eo + q] = gev[q];
+      Q.rd[eo + q] = rev[q];
+    }
 }
 DOMPC_PHASE void assemble_node(const Prob& Q, int n) {
   double t[ASM_N];
