@@ -244,7 +244,16 @@ constexpr int QL_VG = ((2 * NW + 7) / 8) * 8;                                 //
 constexpr int QL_RW = QL_WB + 4 * QL_WBG;
 constexpr int QL_QV = QL_RW + 4 * QL_VG;                                      // q~ | W'b of one edge: 2 x 16
 constexpr int QL_NEED = QUAD_EDGE ? QL_QV + 4 * 32 : 0;
-constexpr int EL_SIZE = ((el_max(el_max(el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)), DAE_NEED), QL_NEED) + 7) / 8) * 8;
+// four scenario chains per wavefront in the backward Riccati pass (round 6, dompc_riccati4.h): four staged edge-record heads, four packed
+// value functions, four closed-loop maps
+#ifndef DOMPC_HOST_EMU
+constexpr bool R4_SIZES = R16_ENABLED && (DOMPC_NE == 0) && (DOMPC_NS == 0) && (NYT <= 16);
+#else
+constexpr bool R4_SIZES = false;
+#endif
+constexpr int r4_pad4(int n) { return n + ((4 - n % 16) + 16) % 16; }
+constexpr int R4_NEED = R4_SIZES ? 4 * r4_pad4(((ES_QV + NA + 31) / 32) * 32) + 4 * r4_pad4(NA * (NA + 1) / 2 + NA) + 4 * r4_pad4(NA * NA > 64 ? NA * NA : 64) : 0;
+constexpr int EL_SIZE = ((el_max(el_max(el_max(el_max(el_max(EL_MOC + MOC_STAGE, RB_NEED), el_max(RF_IMG + MO_IMG, R16_NEED)), DAE_NEED), QL_NEED), R4_NEED) + 7) / 8) * 8;
 
 // ---- dense image of a compact model-output record
 // dense index (MO_PT / MO_LT / MO_MT / MO_NL layout) of compact entry k

@@ -429,6 +429,11 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   return bad;
 }
 
+}  // namespace r16
+}  // namespace dompc
+#include "dompc_riccati4.h"      // four scenario chains per wavefront (uses NodeIn / load_node above)
+namespace dompc {
+namespace r16 {
 // Backward recursion of one problem (all wavefronts of the problem take part; same protocol as riccati_backward).
 __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double delta) {
   const KArgs& A = *Q.A;
@@ -436,7 +441,11 @@ __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double de
   ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / 64) * EL_SIZE;      // this wavefront's LDS region: two staging buffers
   const int FSET = T.flag_begin(0);
   const int cl = A.chain_level < A.N ? A.chain_level : A.N;
-  {
+  if constexpr (r4::ENABLED) {
+    if (r4::chains(T, Q, mu, delta, cl)) T.fset(0, FSET);
+    T.sync();
+    if ((T.fget(0) == FSET)) return 1;
+  } else {
     const int S = A.level_node_start[A.N + 1] - A.level_node_start[A.N];
     for (int s_ = gid; s_ < S; s_ += ng) {
       NodeIn in;
