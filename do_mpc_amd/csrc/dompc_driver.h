@@ -438,7 +438,16 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         in_wd = false; wd_count = 0;      // (a new barrier problem: the watchdog's reference point is void)
       } else break;
     }
-    if (mu != mu_before) refresh_mu(T, Q, mu - mu_before);
+    if (mu != mu_before) {
+      if (QUAD_FWD && forward_adjoint(Q, mu) && !Q.lu_ok) {
+        // the barrier parameter fell by more than one level at this iterate, into the range of the adjoint variant of the forward pass, and
+        // the last sweep did not store the inverses that variant reads (lu_store_rule): the sweep is repeated at the new mu, storing them
+        ++n_sweeps;
+        if (run_sweep(T, Q, b, slot, mu, 4, Q.dsw)) { if (in_wd) { wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; }
+      } else {
+        refresh_mu(T, Q, mu - mu_before);
+      }
+    }
 
     // ---- search direction with inertia correction (delta_w on all primal variables)
     delta = 0.0;

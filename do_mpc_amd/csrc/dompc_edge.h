@@ -236,6 +236,30 @@ constexpr bool QUAD_EDGE = (DOMPC_QUAD != 0) && MO_COMPACT && (DEG >= 1) && (NA 
 #else
 constexpr bool QUAD_EDGE = false;
 #endif
+// ... and the per-edge part of the forward pass on the same layout, the inverse G_cc^-1 formed again instead of read back (dompc_quad.h).
+// The sweep then stores the inverse only for the adjoint variant of the forward pass (last barrier levels), which still reads it:
+// lu_store_rule() - the barrier parameter of the sweep is at most one level above the adjoint threshold - and Prob::lu_ok.
+#ifndef DOMPC_QUAD_FORWARD
+#define DOMPC_QUAD_FORWARD 1
+#endif
+#ifndef DOMPC_ADJ_REFINE
+#define DOMPC_ADJ_REFINE 1
+#endif
+#ifndef DOMPC_ADJ_MU
+#define DOMPC_ADJ_MU 10.0
+#endif
+constexpr bool QUAD_FWD = QUAD_EDGE && (DOMPC_QUAD_FORWARD != 0);
+// Does a sweep at barrier parameter mu store G_cc^-1 in the forward records?  Always, unless the forward pass forms it again (QUAD_FWD);
+// then only if the next forward pass may be the adjoint variant (mu <= DOMPC_ADJ_MU tol, dompc_forward.h): the barrier parameter can drop by
+// one level between a sweep and the solve that follows it (monotone update, refresh_mu), mu+ = min(kappa_mu mu, mu^theta_mu).  A drop by
+// several levels at one iterate is caught by the driver (it repeats the sweep with Prob::soc bit 2 = "store").
+DOMPC_DEV inline bool lu_store_rule(const KArgs& A, double mu, int soc) {
+  if (!QUAD_FWD || (soc & 4)) return true;
+  if (!DOMPC_ADJ_REFINE || (soc & 2)) return false;
+  const double thr = DOMPC_ADJ_MU * A.opt.tol;
+  return mu > 0.0 && mu <= fmax(thr / A.opt.kappa_mu, pow(thr, 1.0 / A.opt.theta_mu));
+}
+
 constexpr int QL_MOSZ = QUAD_EDGE ? ((4 * MO_REC + 127) / 128) * 128 : 0;     // one bank: the compact records of four consecutive edges, as they lie in memory
 constexpr int QL_WS = NA + 1;                                                 // row stride of the staged W | w0 slot
 constexpr int QL_WBG = ((NX * QL_WS + 1) / 2) * 2;                            // ... per edge

@@ -342,7 +342,11 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
   constexpr bool FE2 = (DOMPC_FE2 != 0) && MO_LDS && M > 0 && NI == 1 && DEG > 0 && !DENSE_EDGE && DOMPC_SHARD == 0 && NW <= 32 && NA <= 16 &&
                        NA + NU <= 16 && NE <= 32 && (MOC_STAGE - MOC_SIZE >= 1 + DOMPC_DYN_NC) && (FE_TAB + 128 <= EL_SIZE) &&
                        (PT_STRIDE <= 2 * FE_SS) && LU_N < NW;
-  if (FE2 && GS == 64 && !adj) {
+  if (QUAD_FWD && GS == 64 && !adj) {
+    // four edges per wavefront, G_cc^-1 formed again from the compact model-output record instead of read from the forward record
+    // (dompc_quad.h; its own function: its own register allocation)
+    phase_forward_quads(T.kp, (int)((Q.P - A.p) / A.n_opt_p), Q.slot, Q.soc, Q.sf, delta, cl);
+  } else if (FE2 && GS == 64 && !adj) {
     typedef __attribute__((address_space(3))) unsigned short ldsu16_;
     const int h = lane >> 5, l32 = lane & 31;
     ldsd* Lv = Ld + h * FE_HV;

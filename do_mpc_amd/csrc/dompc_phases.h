@@ -294,6 +294,7 @@ __device__ __attribute__((noinline)) PhaseRet3 phase_accept(const void* kp, int 
 // dsw: the inertia correction this sweep folds into the condensed blocks; remembered in Q for the Riccati passes
 DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu, int soc = 0, double dsw = 0.0) {
   Q.dsw = dsw;
+  Q.lu_ok = lu_store_rule(*Q.A, mu, soc) ? 1 : 0;
 #ifndef DOMPC_HOST_EMU
   if (fine_items(T, *Q.A)) { DOMPC_PHASE_CALL(phase_sweep_fine, mu, dsw, soc) return ufl(r_.rc); }
   DOMPC_PHASE_CALL(phase_sweep, mu, dsw, soc)

@@ -122,7 +122,7 @@ __device__ inline void stage_quad(const Prob& Q, int e0, int lane, ldsd* Ld, int
 // quad this wavefront handles next (-1: none) - requested into the other bank once the elimination is through.
 // Returns 0, 1 (a singular block cannot happen here: it takes the fallback) or 2: at least one collocation block failed the pivot test
 // in its natural order - nothing that the fallback (eval_edge_coop on each edge) does not write again has been stored.
-__device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0n, double mu, int lane_, ldsd* Ld, int bank, const QdPack& pk, QdPack& pkn) {
+__device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0n, double mu, int lane_, ldsd* Ld, int bank, const QdPack& pk, QdPack& pkn, bool store_lu) {
   const KArgs& A = *Q.A;
   // (the lane number as a value the optimiser cannot see through: everything derived from it - 16 lane predicates, the per-lane selects of
   //  collocation coefficients and unit vectors - is otherwise hoisted out of the quad loop as loop-invariant and held in ~100 registers)
@@ -381,10 +381,12 @@ __device__ inline int eval_edge_quad(const Thr& T, const Prob& Q, int e0, int e0
       Q.rd[gi] = RDv[s];
     }
     double* ew = Q.ew + (int64_t)e * EW_SIZE;
+    if (store_lu) {                                  // (uniform, lu_store_rule; QUAD_FWD: the forward pass forms the inverse again - 400 of the record's 464 doubles stay home)
 #pragma unroll
-    for (int s = 0; s < DEG; ++s)
+      for (int s = 0; s < DEG; ++s)
 #pragma unroll
-      for (int r = 0; r < R; ++r) ew[EW_LU + r * LU_N + s * NX + (int)b] = bc[s][r];
+        for (int r = 0; r < R; ++r) ew[EW_LU + r * LU_N + s * NX + (int)b] = bc[s][r];
+    }
 #pragma unroll
     for (int s = 0; s < M; ++s) {
       ew[EW_SIGW + s * NX + (int)b] = SGv[s] + Q.dsw;
@@ -694,6 +696,7 @@ __device__ __attribute__((noinline)) int phase_sweep_quads(const void* kp, int b
   int fail = 0, bank = 0;
   int qd = gid;
   if (qd >= nq) return 0;
+  const bool store_lu = lu_store_rule(A, mu, Q.soc);
   const int gl = lane >> 4;
   auto pack_of = [&](int q) { const int e = 4 * q + gl; return qd_pack(A, e < A.n_edges ? e : A.n_edges - 1, Q.sf); };
   stage_quad(Q, 4 * qd, lane, Ld, 0);
@@ -702,7 +705,7 @@ __device__ __attribute__((noinline)) int phase_sweep_quads(const void* kp, int b
     const int qn = qd + ng;
     const bool more = qn < nq;
     QdPack pkn = pk;
-    const int rc = eval_edge_quad(T, Q, 4 * qd, more ? 4 * qn : -1, mu, lane, Ld, bank, pk, pkn);
+    const int rc = eval_edge_quad(T, Q, 4 * qd, more ? 4 * qn : -1, mu, lane, Ld, bank, pk, pkn, store_lu);
     if (__builtin_amdgcn_readfirstlane(rc) == 2) {
       pkn = pack_of(more ? qn : qd);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (no LDS-DMA in flight into the region the fallback uses)
@@ -724,4 +727,322 @@ __device__ inline int sweep_quads(const Thr& T, const Prob& Q, double mu) {
 }
 #elif !defined(DOMPC_HOST_EMU)
 __device__ inline int sweep_quads(const Thr&, const Prob&, double) { return 0; }      // (never called: QUAD_EDGE is false for such a model)
+#endif
+
+// ================================================================================================
+// Forward pass, per-edge part, with four edges per wavefront (round 6): the steps of the collocation unknowns dw and of the multipliers of
+// the edge's rows, dlambda, from the steps of the node variables (riccati_forward_t: chain walk / branching levels).  The wavefront-per-
+// two-edges version (dompc_forward.h, FE2) reads the stored inverse G_cc^-1 of every edge (400 of the 464 doubles of the forward record:
+// written by every sweep, read back by every forward pass - a sixth of the kernel's memory traffic).  Here the inverse is FORMED AGAIN from
+// the compact model-output record, which the pass reads anyway (point Hessians, input Jacobians): the same columns and the same
+// elimination as in the sweep (qd_fw_columns / qd_fw_eliminate restate steps 3 and 5 of eval_edge_quad; kept apart from it - shared
+// helper functions changed the register allocation of the sweep's quad loop and brought its spills back), with the right-hand side
+// g = G_y dy + r in the residual column, so that dw = -G_cc^-1 g comes out of the elimination itself.  The batch path is bound by its
+// memory traffic, not by instruction issue (profiles/r06_backward4.txt): 1 500 more vector instructions per four edges cost nothing
+// that 3.6 KB less traffic per edge does not repay.  The sweep stores the inverse only when the next forward pass may be the adjoint
+// variant (last barrier levels), which still reads it, or when its pivot test failed (the fallback below).
+#if !defined(DOMPC_HOST_EMU) && DOMPC_DEG >= 1 && DOMPC_M >= 1 && DOMPC_NI == 1 && DOMPC_NX + DOMPC_NU + 2 <= 16 && DOMPC_DEG * DOMPC_DEG * DOMPC_NX <= 64
+constexpr int QF_VG = 100;                                   // per edge: dw (NW) | dy (NA) | rhs (NW) | rr (R): 4 mod 16 doubles apart (banks)
+static_assert(!QUAD_FWD || (2 * NW + NA + DEG * NX <= QF_VG && QL_WB + 4 * QF_VG <= EL_SIZE), "LDS of the four-edge forward pass");
+
+__device__ inline void qd_fw_columns(const ldsd* rec, int j, const double (&res)[DEG], double (&bc)[DEG][DEG * NX]) {
+  constexpr int R = DEG * NX;
+  sfor<DEG>([&](auto S_) {
+    constexpr int s = S_;
+    sfor<R>([&](auto R_) {
+      constexpr int r = R_, jj = r / NX, a = r % NX;
+      double v = 0.0;
+      if constexpr (s == jj)
+        sfor<NX>([&](auto B_) {
+          constexpr int bb = B_;
+          constexpr MoRef rf = moref_dyn(jj, NX + a * NA + bb);
+          if constexpr (rf.kind != 0) { const double t_ = mo_dyn_val<rf.kind, rf.off>(rec); v = (j == bb) ? t_ : v; }
+        });
+      if constexpr (s == 0) {
+        sfor<NU>([&](auto K_) {
+          constexpr int ku = K_;
+          constexpr MoRef rf = moref_dyn(jj, NX + a * NA + NX + ku);
+          if constexpr (rf.kind != 0) { const double t_ = mo_dyn_val<rf.kind, rf.off>(rec); v = (j == NX + ku) ? t_ : v; }
+        });
+        const double rb_ = rbc<a>(res[jj]);
+        v = (j == NA) ? rb_ : v;
+      }
+      v = (j == a) ? v - DOMPC_C[(s + 1) * (DEG + 1) + jj + 1] : v;
+      bc[s][r] = v;
+    });
+  });
+}
+__device__ inline int qd_fw_eliminate(int j, double (&bc)[DEG][DEG * NX]) {
+  constexpr int R = DEG * NX;
+  constexpr double GJ_U = DOMPC_GJ_U;
+  int bad = 0;
+  double sig[DEG];
+#pragma unroll
+  for (int s = 0; s < DEG; ++s) sig[s] = 1.0;
+  sfor<R>([&](auto K_) {
+    constexpr int k = K_, sk = k / NX, bk = k % NX;
+    constexpr int rt1 = (4 * (k / 4 + 1) < R) ? 4 * (k / 4 + 1) : R;
+    QD_SB();
+    const bool own = (j == bk);
+    double m = 0.0;
+#pragma unroll
+    for (int r = k + 1; r < rt1; ++r) m = fmax(m, fabs(bc[sk][r]));
+    const double akk = fabs(bc[sk][k]);
+    bad |= (int)(own & !(akk >= GJ_U * m && akk > 1e-300));
+    const double pl = fast_rcp((akk > 1e-300) ? bc[sk][k] : 1.0);
+    const double pinv = rbc<bk>(pl);
+    sig[sk] = own ? -pl : sig[sk];
+    double pm[DEG];
+#pragma unroll
+    for (int s = 0; s < DEG; ++s) {
+      const double prow = bc[s][k] * pinv;
+      pm[s] = (s == sk && own) ? 0.0 : -prow;
+      bc[s][k] = (s == sk && own) ? -1.0 : prow;
+      pin(pm[s]);
+    }
+    asm volatile("s_nop 1");
+    sfor<R>([&](auto R_) {
+      constexpr int r = R_;
+      if constexpr (r != k) {
+        sfor<DEG>([&](auto S_) { constexpr int s = S_; if constexpr (s != sk) fmac_rbc<bk>(bc[s][r], bc[sk][r], pm[s]); });
+        fmac_rbc<bk>(bc[sk][r], bc[sk][r], pm[sk]);
+      }
+    });
+#pragma unroll
+    for (int s = 0; s < DEG; ++s)
+#pragma unroll
+      for (int r = 0; r < R; ++r) pin(bc[s][r]);
+  });
+  QD_SB();
+#pragma unroll
+  for (int s = 0; s < DEG; ++s)
+#pragma unroll
+    for (int r = 0; r < R; ++r) bc[s][r] *= sig[s];
+  QD_SB();
+  return bad;
+}
+
+struct QfPack { int woff, row0, level, n, cn, uoffp, epsoff; };
+__device__ inline QfPack qf_pack(const KArgs& A, int e) {
+  const auto* ep = A.edge_pack + e * EP_N;
+  QfPack k;
+  k.woff = ep[EP_WOFF]; k.row0 = ep[EP_ROW0]; k.level = ep[EP_LEVEL]; k.n = ep[EP_PARENT]; k.cn = ep[EP_CHILD];
+  k.uoffp = ep[EP_UOFF_PARENT]; k.epsoff = ep[EP_EPSOFF_PARENT];
+  return k;
+}
+
+__device__ __attribute__((noinline)) void phase_forward_quads(const void* kp, int b_, int slot, int soc, double sf, double delta_, int cl_) {
+  const KArgs A = kernel_args(kp);
+  Thr T = make_thr(A);
+  T.kp = kp;
+  Prob Q = make_prob(A, ufl(slot), A.p + (int64_t)ufl(b_) * A.n_opt_p);
+  Q.sf = ufl(sf);
+  Q.soc = ufl(soc);
+  prob_bounds(Q);
+  const double delta = ufl(delta_);
+  const int cl = ufl(cl_);
+  (void)delta;
+  constexpr int R = DEG * NX;
+  const int ng = T.nt / 64, gid = group_index(T.tid, 64);
+  ldsd* Ld = T.edge_lds + (int64_t)(T.ltid / 64) * EL_SIZE;
+  const int nq = (A.n_edges + 3) / 4;
+  int bank = 0;
+  int qd = gid;
+  if (qd >= nq) return;
+  {
+    const int lane0 = (int)(threadIdx.x & 63u);
+    stage_quad(Q, 4 * qd, lane0, Ld, 0);
+  }
+  while (qd < nq) {
+    int lane = (int)(threadIdx.x & 63u);
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, j = lane & 15;
+    const int e0 = 4 * qd;
+    const bool act = e0 + g < A.n_edges;
+    const int e = act ? e0 + g : A.n_edges - 1;
+    const bool isx = j < NX, st_x = act && isx;
+    const int b = isx ? j : 0;
+    const QfPack pk = qf_pack(A, e);
+    const bool chain = pk.level >= cl;
+    // ---- operands: steps of the parent node's variables, the residuals of the edge's rows, r_w and Sigma_w of its unknowns, d nu of its
+    //      end-point rows (chain levels: from the chain walk; branching levels: P dx + p of the child node, stored here)
+    const double dxn = Q.nd[(int64_t)pk.n * ND_SIZE + ND_DXT + b];
+    double du[NU > 0 ? NU : 1];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) du[u] = Q.dx[pk.uoffp + u];
+    double cres[DEG], rwv[M], sgv[M];
+#pragma unroll
+    for (int jj = 0; jj < DEG; ++jj) cres[jj] = Q.c[pk.row0 + jj * NX + b];
+    const double ccont = Q.c[pk.row0 + R + b];
+    const double* ew = Q.ew + (int64_t)e * EW_SIZE;
+#pragma unroll
+    for (int s = 0; s < M; ++s) { rwv[s] = ew[EW_RW + s * NX + b]; sgv[s] = ew[EW_SIGW + s * NX + b]; }
+    double dnu = Q.dlam[pk.row0 + NW + b];
+    if (__ballot(!chain) != 0ull) {
+      const double* Nc = Q.nd + (int64_t)pk.cn * ND_SIZE;
+      double t = Nc[ND_PV + b];
+#pragma unroll
+      for (int bb = 0; bb < NA; ++bb) t = fma(Nc[ND_P + b * NA + bb], Nc[ND_DXT + bb], t);
+      dnu = chain ? dnu : t;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the staged records (and everything above) have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const ldsd* rec = Ld + bank * QL_MOSZ + g * MO_REC;
+    ldsd* Lv = Ld + QL_WB + g * QF_VG;                        // dw | dy | rhs | rr of this lane's edge
+    constexpr int V_DW = 0, V_DY = NW, V_RHS = NW + NA, V_RR = 2 * NW + NA;
+    // dy -> LDS (the u part by the lanes NX ..: they hold du[j - NX] like everybody)
+    if (isx) Lv[V_DY + j] = dxn;
+    sfor<NU>([&](auto U_) { constexpr int u = U_; if (j == NX + u) Lv[V_DY + NX + u] = du[u]; });
+    // ---- g = G_y dy + r on the collocation rows (jj, b): r - C[0][j] dx_n + J_u du (row b of the input Jacobian of point jj)
+    double gv[DEG];
+    sfor<DEG>([&](auto J_) {
+      constexpr int jj = J_;
+      double t = cres[jj] - DOMPC_C[0 * (DEG + 1) + jj + 1] * dxn;
+      sfor<NX>([&](auto A_) {
+        constexpr int a = A_;
+        sfor<NU>([&](auto U_) {
+          constexpr int u = U_;
+          constexpr MoRef rf = moref_dyn(jj, NX + a * NA + NX + u);
+          if constexpr (rf.kind != 0) { const double t_ = mo_dyn_val<rf.kind, rf.off>(rec) * du[u]; t += (j == a) ? t_ : 0.0; }
+        });
+      });
+      gv[jj] = t;
+      pin(gv[jj]);
+    });
+    QD_SB();
+    double bc[DEG][R];
+    qd_fw_columns(rec, j, gv, bc);
+    QD_SB();
+    const int bad = qd_fw_eliminate(j, bc);
+    const bool fb = __ballot(bad) != 0ull;                   // (the sweep took its fallback for this quad and stored the inverses: used below)
+    // the compact records of the quad this wavefront handles next
+    const int qn = qd + ng;
+    if (qn < nq) stage_quad(Q, 4 * qn, lane, Ld, bank ^ 1);
+    // ---- dw: collocation slots from lane NA's column -G_cc^-1 g, end-point slot from the continuity rows
+    double dwv[M];
+    if (!fb) {
+#pragma unroll
+      for (int s = 0; s < DEG; ++s) dwv[s] = 0.0;
+      sfor<R>([&](auto R_) {
+        constexpr int r = R_, s = r / NX, a = r % NX;
+        const double t_ = rbc<NA>(bc[0][r]);
+        dwv[s] = (j == a) ? -t_ : dwv[s];
+      });
+    } else {
+      // fallback: dw = -G_cc^-1 g with the inverse the sweep's fallback stored (row (s, b) of it, g handed round through LDS)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (isx) {
+#pragma unroll
+        for (int s = 0; s < DEG; ++s) Lv[V_RR + s * NX + j] = gv[s];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < DEG; ++s) {
+        double t = 0.0;
+        for (int k2 = 0; k2 < R; ++k2) t -= ew[EW_LU + (s * NX + b) * LU_N + k2] * Lv[V_RR + k2];
+        dwv[s] = t;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    {
+      double t = DOMPC_D[0] * dxn - ccont;
+#pragma unroll
+      for (int s = 1; s <= DEG; ++s) t = fma(DOMPC_D[s], dwv[s - 1], t);
+      dwv[M - 1] = t;
+    }
+    if (isx) {
+#pragma unroll
+      for (int s = 0; s < M; ++s) Lv[V_DW + s * NX + j] = dwv[s];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    QD_SB();
+    // ---- rhs = -(r_w + (Sigma_w + delta) dw + H_ww dw + H_wu du + [end-point slot] d nu), row (s, b) on lane b
+    double rhs[M];
+    sfor<M>([&](auto S_) {
+      constexpr int s = S_;
+      double t = fma(sgv[s], dwv[s], rwv[s]);
+      if constexpr (s == M - 1) t += dnu;
+      if constexpr (s < DEG) {
+        // row b of the lambda-weighted Hessian of point s over (x_s, u): its structural non-zeros (packed upper triangle and its mirror)
+        sfor<NA>([&](auto I_) {
+          constexpr int i = I_;
+          sfor<NA - i>([&](auto D_) {
+            constexpr int k = i + D_;
+            constexpr MoRef rf = moref_dyn(s, MOH_H0 + symi(i, k, NA));
+            if constexpr (rf.kind != 0 && i < NX) {
+              const double h = mo_dyn_val<rf.kind, rf.off>(rec);
+              if constexpr (k < NX) {
+                const double pk_ = h * (double)Lv[V_DW + s * NX + k];
+                t += (j == i) ? pk_ : 0.0;
+                if constexpr (i != k) { const double pi_ = h * (double)Lv[V_DW + s * NX + i]; t += (j == k) ? pi_ : 0.0; }
+              } else {
+                const double pu_ = h * du[k - NX];
+                t += (j == i) ? pu_ : 0.0;
+              }
+            }
+          });
+        });
+      }
+      rhs[s] = -t;
+      pin(rhs[s]);
+    });
+    QD_SB();
+    // ---- d lambda = G_w^-T rhs,  G_w^-T = [[Gi', -Gi'E'], [0, I]]: rr = rhs_c + D rhs_e handed round, column (s, b) of Gi times rr
+    if (isx) {
+#pragma unroll
+      for (int s = 0; s < DEG; ++s) Lv[V_RR + s * NX + j] = fma(DOMPC_D[s + 1], rhs[M - 1], rhs[s]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double dl[M];
+    if (!fb) {
+#pragma unroll
+      for (int s = 0; s < DEG; ++s) {
+        double t = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < R; ++k2) t = fma(bc[s][k2], (double)Lv[V_RR + k2], t);
+        dl[s] = t;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < DEG; ++s) {
+        double t = 0.0;
+        for (int k2 = 0; k2 < R; ++k2) t += ew[EW_LU + k2 * LU_N + s * NX + b] * Lv[V_RR + k2];
+        dl[s] = t;
+      }
+    }
+    dl[M - 1] = rhs[M - 1];
+    // ---- stores
+    if (st_x) {
+#pragma unroll
+      for (int s = 0; s < M; ++s) {
+        Q.dx[pk.woff + s * NX + j] = dwv[s];
+        Q.dlam[pk.row0 + s * NX + j] = dl[s];
+      }
+      if (!chain) Q.dlam[pk.row0 + NW + j] = dnu;
+    }
+    if constexpr (NE > 0) {
+      // nl_cons rows: ds = r_d + J_d dy (- sg deps), d y_d = (Sigma_s + delta) ds + r_s      (row i on lane i)
+      if (act && j < NE) {
+        const double* S_ = Q.es + (int64_t)e * ES_SIZE;
+        double t = S_[ES_RDN + j];
+        for (int bb = 0; bb < NA; ++bb) t += ew[EW_JD + j * NA + bb] * Lv[V_DY + bb];
+        if (!EPS_GLOBAL && nl_slack(j) >= 0) t -= Q.sgn[e * NE1 + j] * Q.dx[pk.epsoff + nl_slack(j)];
+        Q.ds[e * NE1 + j] = t;
+        Q.dlam[pk.row0 + NW + NX + j] = (S_[ES_SIGS + j] + delta) * t + S_[ES_RSN + j];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bank ^= 1;
+    qd = qn;
+  }
+}
+#elif !defined(DOMPC_HOST_EMU)
+__device__ inline void phase_forward_quads(const void*, int, int, int, double, double, int) {}      // (never called: QUAD_FWD is false)
 #endif
