@@ -267,7 +267,10 @@ constexpr int QL_WB = 2 * QL_MOSZ;
 constexpr int QL_VG = ((2 * NW + 7) / 8) * 8;                                 // r_w | b of one edge
 constexpr int QL_RW = QL_WB + 4 * QL_WBG;
 constexpr int QL_QV = QL_RW + 4 * QL_VG;                                      // q~ | W'b of one edge: 2 x 16
-constexpr int QL_NEED = QUAD_EDGE ? QL_QV + 4 * 32 : 0;
+constexpr int qf_pad4(int n) { return n + ((4 - n % 16) + 16) % 16; }
+constexpr int QF_VG = qf_pad4(2 * NW + NA + DEG * NX);                        // forward pass with four edges per wavefront: dw | dy | rhs | rr per edge (4 mod 16 doubles apart: banks)
+constexpr int QF_NEED = QUAD_FWD ? QL_WB + 4 * QF_VG : 0;
+constexpr int QL_NEED = QUAD_EDGE ? el_max(QL_QV + 4 * 32, QF_NEED) : 0;
 // four scenario chains per wavefront in the backward Riccati pass (round 6, dompc_riccati4.h): four staged edge-record heads, four packed
 // value functions, four closed-loop maps
 #ifndef DOMPC_HOST_EMU

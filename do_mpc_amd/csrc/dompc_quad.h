@@ -26,6 +26,7 @@
 // Measured effect: DESIGN.md section 4 / profiles/r06_*.
 #if !defined(DOMPC_HOST_EMU) && DOMPC_DEG >= 1 && DOMPC_M >= 1 && DOMPC_NI == 1 && DOMPC_NX + DOMPC_NU + 2 <= 16 && DOMPC_DEG * DOMPC_DEG * DOMPC_NX <= 64      // (array sizes and lane numbers below; the rest of the conditions: QUAD_EDGE, dompc_edge.h)
 
+#define DOMPC_HAVE_QUAD_HELPERS 1      // rbc / sfor / pin / QD_SB exist (dompc_riccati4.h)
 extern "C" __device__ double dompc_dpp_f64(double old, double src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) __asm("llvm.amdgcn.update.dpp.f64");
 // value of `v` in lane L of this lane's row of 16 lanes (v_mov_b64_dpp row_newbcast:L)
 template <int L>
@@ -742,7 +743,6 @@ __device__ inline int sweep_quads(const Thr&, const Prob&, double) { return 0; }
 // that 3.6 KB less traffic per edge does not repay.  The sweep stores the inverse only when the next forward pass may be the adjoint
 // variant (last barrier levels), which still reads it, or when its pivot test failed (the fallback below).
 #if !defined(DOMPC_HOST_EMU) && DOMPC_DEG >= 1 && DOMPC_M >= 1 && DOMPC_NI == 1 && DOMPC_NX + DOMPC_NU + 2 <= 16 && DOMPC_DEG * DOMPC_DEG * DOMPC_NX <= 64
-constexpr int QF_VG = 100;                                   // per edge: dw (NW) | dy (NA) | rhs (NW) | rr (R): 4 mod 16 doubles apart (banks)
 static_assert(!QUAD_FWD || (2 * NW + NA + DEG * NX <= QF_VG && QL_WB + 4 * QF_VG <= EL_SIZE), "LDS of the four-edge forward pass");
 
 __device__ inline void qd_fw_columns(const ldsd* rec, int j, const double (&res)[DEG], double (&bc)[DEG][DEG * NX]) {

@@ -23,7 +23,7 @@ namespace r4 {
 #define DOMPC_QUAD_BACKWARD 0      // MEASURED, NOT FASTER (round 6): 141 M instead of 111 M cycles of problem 0's wavefront per solve in this pass, the same
 #endif                            // MPC steps/s (9 484 vs 9 494, same box, interleaved) - the batch path is bound by memory traffic, not by instruction issue:
                                   // 12 x fewer issue slots per node change nothing.  Kept as the A/B it was measured with (profiles/r06_backward4.txt).
-#if !defined(DOMPC_HOST_EMU) && DOMPC_NX + 2 * DOMPC_NU <= 16 && DOMPC_NE == 0 && DOMPC_NS == 0
+#if !defined(DOMPC_HOST_EMU) && defined(DOMPC_HAVE_QUAD_HELPERS) && DOMPC_NX + 2 * DOMPC_NU <= 16 && DOMPC_NE == 0 && DOMPC_NS == 0
 constexpr bool ENABLED = (DOMPC_QUAD_BACKWARD != 0) && R16_ENABLED && (NE == 0) && (NS == 0) && (NV == NU) && (NYT <= 16) && !EPS_GLOBAL;
 // LDS of a wavefront (doubles): the staged heads of four edge records [A B | c | Q~ | q~ + r_y], the four children's value functions
 // (packed upper triangle + p), and one region for K / v first, the closed-loop maps Acl afterwards
@@ -502,6 +502,9 @@ __device__ inline int chains(const Thr& T, const Prob& Q, double mu, double delt
 }
 #else
 constexpr bool ENABLED = false;
+#ifndef DOMPC_HOST_EMU
+__device__ inline int chains(const Thr&, const Prob&, double, double, int) { return 0; }      // (never called)
+#endif
 #endif
 }  // namespace r4
 }  // namespace dompc
