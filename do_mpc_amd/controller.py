@@ -692,7 +692,7 @@ class MPC:
 
     def create_nlp(self, _solver_factory=None) -> None:
         assert self.flags["prepare_nlp"], "call prepare_nlp() first"
-        if isinstance(self._nlp_cons_lb, list):
+        if not self.flags["setup"]:
             # the low-level route (optimizer.py:1050-1094, _mpc.py:1303-1310): what the user added after prepare_nlp() is lowered or
             # refused by name; afterwards the attributes are the concatenations, as in the reference
             nlp_route.check_additions(self)

@@ -178,7 +178,7 @@ static int ensure_z(dompc_plant* h, int32_t B, bool reseed) {
 #else
   memcpy(h->z_dev, seed.data(), seed.size() * sizeof(double));
 #endif
-  h->z_cap = B;
+  if (B > h->z_cap) h->z_cap = B;        // a reseed of the first B rows leaves the carried rows behind them alone
   return 0;
 }
 

@@ -142,6 +142,14 @@ def check_additions(mpc) -> None:
     if not (isinstance(cons, list) and cons and isinstance(cons[0], StructuredBlock)):
         raise NotImplementedError("structured HIP backend: the structured constraint block (first entry of nlp_cons) was removed or "
                                   "replaced; append to nlp_cons / nlp_cons_lb / nlp_cons_ub instead")
+    if not (isinstance(lbs, list) and isinstance(ubs, list)):
+        # the setters take anything, as the reference's do (optimizer.py:172-215); an array in place of the list of blocks cannot be matched
+        # to nlp_cons block by block, so it is only accepted when nothing was appended
+        if len(cons) != 1:
+            raise ValueError("nlp_cons_lb / nlp_cons_ub must stay lists with one entry per nlp_cons block (%d blocks); got %s / %s"
+                             % (len(cons), type(lbs).__name__, type(ubs).__name__))
+        lbs = mpc._nlp_cons_lb = lbs if isinstance(lbs, list) else [lbs]
+        ubs = mpc._nlp_cons_ub = ubs if isinstance(ubs, list) else [ubs]
     if not (len(cons) == len(lbs) == len(ubs)):
         raise ValueError("nlp_cons, nlp_cons_lb and nlp_cons_ub must have one entry per constraint block: %d / %d / %d"
                          % (len(cons), len(lbs), len(ubs)))
@@ -156,7 +164,7 @@ def check_additions(mpc) -> None:
                 raise ValueError("%s %d uses symbols that belong neither to mpc.opt_x nor to mpc.opt_p: %s"
                                  % (what, j, ", ".join(repr(n) for n in c["foreign"][:4])))
             if c["constant"] and what == "nlp_obj term":
-                continue        # a term in opt_p only shifts the objective: no effect on the solution (handled: f_offset)
+                continue        # a term in opt_p only shifts the objective: no effect on the solution (the reported f excludes it)
             why = []
             if len(c["nodes"]) > 1:
                 why.append("it couples %d nodes of the scenario tree (%s): the Riccati recursion eliminates one node at a time"
@@ -176,5 +184,6 @@ def check_additions(mpc) -> None:
                                   "stage-structured -\n  " + "\n  ".join(problems) +
                                   "\n(the reference hands such an NLP to CasADi/IPOPT as one sparse problem, "
                                   "/root/reference/do_mpc/optimizer.py:1050-1094; this backend has no general sparse fallback)")
-    # accepted: constant objective terms (functions of opt_p only)
+    # accepted: constant objective terms (functions of opt_p only).  They are kept for inspection; the objective value this backend reports
+    # is the structured objective WITHOUT them (u0 and every other solution quantity are unaffected)
     mpc._nlp_obj_const_terms = [sym._sx(t) for t in obj.terms]

@@ -106,6 +106,20 @@ def test_other_misuse_is_caught():
     mpc.nlp_cons.append(mpc.opt_x["_u", 0, 0])
     with hostemu.patched(), pytest.raises(ValueError, match="one entry per constraint block"):
         mpc.create_nlp()
+    # bounds assigned as ONE array in place of the list of blocks: the additions are still checked (never skipped by type)
+    mpc = _mpc()
+    mpc.prepare_nlp()
+    mpc.nlp_cons.append(mpc.opt_x["_u", 0, 0])
+    mpc.nlp_cons_lb = np.concatenate([mpc.nlp_cons_lb[0], [0.0]])
+    mpc.nlp_cons_ub = np.concatenate([mpc.nlp_cons_ub[0], [0.0]])
+    with hostemu.patched(), pytest.raises(ValueError, match="must stay lists"):
+        mpc.create_nlp()
+    mpc = _mpc()
+    mpc.prepare_nlp()
+    mpc.nlp_cons_lb = np.array(mpc.nlp_cons_lb[0])          # nothing appended: one array is the structured block's own bounds
+    with hostemu.patched():
+        mpc.create_nlp()
+    assert mpc.nlp_cons_lb.shape == (mpc.structure.n_g,)
     # the structured objective cannot be scaled or replaced
     mpc = _mpc()
     mpc.prepare_nlp()
