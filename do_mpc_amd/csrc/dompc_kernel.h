@@ -743,6 +743,7 @@ struct Prob {
                                                      // (Sigma_w + dsw in Q~, q~ and in the stored Sigma_w): the Riccati passes add
                                                      // only delta - dsw on the eliminated variables (0 in the common case)
   int slot;                                          // workspace slot of the problem (rebuilds this view inside outlined functions)
+  int rp_soc; double rp_mu;                          // DOMPC_REPEAT_PHASE (measurement builds): arguments of the last sweep
   int lu_ok;                                         // QUAD_FWD: the forward records hold G_cc^-1 (the last sweep stored it: lu_store_rule)
   DOMPC_DEV double& EW(int e, int i) const { return ew[(int64_t)e * EW_SIZE + i]; }
   DOMPC_DEV double* ES(int e) const { return es + (int64_t)e * ES_SIZE; }
@@ -764,7 +765,7 @@ DOMPC_DEV inline Prob make_prob(const KArgs& A, int slot, const double* P) {
   p.ew = w + L.ew; p.es = w + L.es; p.nd = w + L.nd; p.mo = w + L.mo; p.gsc = w + L.gsc;
   p.x_wd = w + L.x_wd; p.zl_wd = w + L.zl_wd; p.zu_wd = w + L.zu_wd; p.lam_wd = w + L.lam_wd;
   p.s_wd = w + L.s_wd; p.zsl_wd = w + L.zsl_wd; p.zsu_wd = w + L.zsu_wd; p.dlam_e = w + L.dlam_e; p.sgn = w + L.sgn;
-  p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0; p.dsw = 0.0; p.slot = slot; p.lu_ok = 1;
+  p.e_pad = A.e_pad; p.sf = 1.0; p.mu = 0.0; p.soc = 0; p.dsw = 0.0; p.slot = slot; p.lu_ok = 1; p.rp_soc = 0; p.rp_mu = 0.0;
   return p;
 }
 // Bounds the phases read: ONE copy for all problems of the launch (KArgs::lb_sh / ub_sh) - except while the least-squares multiplier

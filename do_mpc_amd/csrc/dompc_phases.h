@@ -291,12 +291,20 @@ __device__ __attribute__((noinline)) PhaseRet3 phase_accept(const void* kp, int 
   const auto r_ = fn(T.kp, b, slot, Q.sf, __VA_ARGS__, T.gen, T.nred, T.xseq);            \
   T.gen = ufl(r_.gen); T.nred = ufl(r_.nred); T.xseq = ufl(r_.xseq);
 #endif
+// measurement aid (tools/gpu_phase_traffic.sh): -DDOMPC_REPEAT_PHASE=<mask> runs the named phases TWICE per call.  They are idempotent
+// (records and reductions of the same inputs), so iterates and iteration counts stay the same bits and the difference of two builds in
+// time and in HBM traffic is the phase's own.  1 sweep, 2 backward + sweep (the backward pass works in place on what the sweep assembled), 4 forward (not the adjoint variant of the last levels: it reuses a slot of the node records), 8 trial evaluation, 16 step rules
+#ifndef DOMPC_REPEAT_PHASE
+#define DOMPC_REPEAT_PHASE 0
+#endif
 // dsw: the inertia correction this sweep folds into the condensed blocks; remembered in Q for the Riccati passes
 DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu, int soc = 0, double dsw = 0.0) {
   Q.dsw = dsw;
   Q.lu_ok = lu_store_rule(*Q.A, mu, soc) ? 1 : 0;
+  Q.rp_soc = soc; Q.rp_mu = mu;
 #ifndef DOMPC_HOST_EMU
   if (fine_items(T, *Q.A)) { DOMPC_PHASE_CALL(phase_sweep_fine, mu, dsw, soc) return ufl(r_.rc); }
+  if (DOMPC_REPEAT_PHASE & 1) { DOMPC_PHASE_CALL(phase_sweep, mu, dsw, soc) }
   DOMPC_PHASE_CALL(phase_sweep, mu, dsw, soc)
   return ufl(r_.rc);
 #else
@@ -312,6 +320,10 @@ DOMPC_DEV inline int run_sweep(const Thr& T, Prob& Q, int b, int slot, double mu
 // mode: Prob::soc of the sweep whose records the pass works on (only bit 1 matters here: objective Hessians left out)
 DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, double mu, double delta, int mode = 0) {
 #ifndef DOMPC_HOST_EMU
+  if (DOMPC_REPEAT_PHASE & 2) {            // the pass turns the assembled node matrices into value functions in place: sweep again in between
+    { DOMPC_PHASE_CALL(phase_backward, mu, delta, Q.dsw, mode) }
+    { DOMPC_PHASE_CALL(phase_sweep, Q.rp_mu, Q.dsw, Q.rp_soc) }
+  }
   DOMPC_PHASE_CALL(phase_backward, mu, delta, Q.dsw, mode)
   return ufl(r_.rc);
 #else
@@ -324,6 +336,7 @@ DOMPC_DEV inline int run_backward(const Thr& T, const Prob& Q, int b, int slot, 
 }
 DOMPC_DEV inline void run_step_rules(const Thr& T, const Prob& Q, int b, int slot, double mu, double (&r5)[5]) {
 #ifndef DOMPC_HOST_EMU
+  if (DOMPC_REPEAT_PHASE & 16) { DOMPC_PHASE_CALL(phase_step_rules, mu) }
   DOMPC_PHASE_CALL(phase_step_rules, mu)
   r5[0] = ufl(r_.v0); r5[1] = ufl(r_.v1); r5[2] = ufl(r_.v2); r5[3] = 0.0; r5[4] = 0.0;
 #else
@@ -334,6 +347,7 @@ DOMPC_DEV inline void run_step_rules(const Thr& T, const Prob& Q, int b, int slo
 DOMPC_DEV inline void run_eval_trial(const Thr& T, const Prob& Q, int b, int slot, double al, double& obj_o, double& th_o, double& bar_o) {
 #ifndef DOMPC_HOST_EMU
   if (fine_items(T, *Q.A)) { DOMPC_PHASE_CALL(phase_eval_trial_fine, al) obj_o = ufl(r_.v0); th_o = ufl(r_.v1); bar_o = ufl(r_.v2); return; }
+  if (DOMPC_REPEAT_PHASE & 8) { DOMPC_PHASE_CALL(phase_eval_trial, al) }
   DOMPC_PHASE_CALL(phase_eval_trial, al)
   obj_o = ufl(r_.v0); th_o = ufl(r_.v1); bar_o = ufl(r_.v2);
 #else
@@ -355,6 +369,7 @@ DOMPC_DEV inline void run_forward(const Thr& T, const Prob& Q, int b, int slot, 
   if (forward_adjoint(Q, mu)) {
     DOMPC_PHASE_CALL(phase_forward_adj, mu, delta, Q.dsw)
   } else {
+    if (DOMPC_REPEAT_PHASE & 4) { DOMPC_PHASE_CALL(phase_forward, mu, delta, Q.dsw) }
     DOMPC_PHASE_CALL(phase_forward, mu, delta, Q.dsw)
   }
 #else

@@ -24,14 +24,16 @@ U_RTOL, X_RTOL, STEP_TOL = 1e-6, 1e-5, 1e-6
 # unused variables whose barrier terms the product leaves out): agreement at the level of the arithmetic, not of the
 # termination tolerance.  (u0, full primal solution), relative to max(1, |.|); measured 7e-17 / 1e-14 (batch_reactor),
 # 7e-14 / 1e-13 (CSTR, since IPOPT's damping of one-sided bounds is restated), 1e-12 / 1e-11 (rotating masses).
-# industrial_poly, full primal 1e-5: three entries of step 0 (x[7257], u[8051], u[8078]) lie on a flat direction along which the iterate
-# still travels 6e-6 (relative) between a stop at tol = 1e-8 and the converged point; the golden sits 5e-7 from product AND oracle
-# (which agree to 2e-13 with each other) = a tenth of that travel: IPOPT's last steps are a few percent longer or shorter.
+# industrial_poly, full primal 1e-6 (round 6; was 1e-5 on every entry) EXCEPT the inputs of the last five stages (135 of 8 100 entries,
+# LOOSE_TAIL below), which keep 1e-5: the feed of the last stages lies on a flat direction of the objective along which the iterate still
+# travels 6e-6 (relative) between a stop at tol = 1e-8 and the converged point; the golden sits up to 4.9e-6 (step 1: opt_x[8070], [8097],
+# [8043], [8016] = one input, one scenario, stages 17 - 20) from product AND oracle, which agree to 2e-13 with each other: IPOPT's last
+# steps are a few percent longer or shorter.  Every other entry: measured <= 6.4e-7.
 TIGHT_GOLDEN = {"batch_reactor": (1e-9, 1e-8), "rotating_masses": (1e-9, 1e-8), "CSTR": (1e-9, 1e-8),
                 "oscillating_masses_dae": (1e-9, 1e-8),      # discrete DAE (algebraic successor state): measured 3e-17 / 1e-16 / multipliers 9e-16
                 "dip": (1e-7, X_RTOL),                        # double inverted pendulum (DAE, non-convex swing-up, 133 iterations): u0 1e-8, primal 4e-7 / 3e-6
-                "industrial_poly": (1e-8, X_RTOL)}   # (u0 2e-10; one weakly determined terminal state is 5e-7 from the golden -
-                                                     #  in the oracle's solution as well, the two agree to 1e-11)
+                "industrial_poly": (1e-8, 1e-6)}     # (u0 2e-10; see above for the inputs of the last stages)
+LOOSE_TAIL = {"industrial_poly": (5, X_RTOL)}         # case -> (inputs of the last n stages, their tolerance)
 # constraint multipliers vs the golden lam_g, relative to max(1, max|lam_g|).  Measured (host emulation = HIP path to the
 # last digits): batch_reactor 5e-15, CSTR 6e-16, rotating masses 3e-14, oscillating masses 4e-9 (discrete model: no
 # delta_w sequence to mirror, the goldens are IPOPT's iterates at its own termination), industrial_poly 2.1e-7 (the weakly
@@ -102,7 +104,14 @@ def check_golden_replay(make_mpc, name, steps):
         assert st["success"], st
         u_tol, x_tol = TIGHT_GOLDEN.get(name, (U_RTOL, X_RTOL))
         assert relerr(u0, U[k]) < u_tol, (name, k, u0, U[k])
-        assert relerr(mpc.opt_x_num_unscaled.master[used], OX[k][used]) < x_tol
+        tight = used
+        if name in LOOSE_TAIL:
+            ps, (n_last, tail_tol) = mpc.structure, LOOSE_TAIL[name]
+            tail = np.zeros(ps.n_opt_x, bool)
+            tail[ps.off_eps - n_last * ps.SU * ps.nu:ps.off_eps] = True
+            assert relerr(mpc.opt_x_num_unscaled.master[used & tail], OX[k][used & tail]) < tail_tol
+            tight = used & ~tail
+        assert relerr(mpc.opt_x_num_unscaled.master[tight], OX[k][tight]) < x_tol
         assert np.max(np.abs(mpc.lam_g_num - LG[k])) < LAM_RTOL[name] * max(1.0, np.max(np.abs(LG[k]))), (
             name, k, np.max(np.abs(mpc.lam_g_num - LG[k])))
         assert np.allclose(mpc.opt_p_num.master, golden_opt_p(name, g, k, mpc.opt_p_num.master.size), rtol=0, atol=1e-12)
