@@ -446,6 +446,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
         if (run_sweep(T, Q, b, slot, mu, 4, Q.dsw)) { if (in_wd) { wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; }
       } else {
         refresh_mu(T, Q, mu - mu_before);
+        Q.rp_mu = mu;
       }
     }
 

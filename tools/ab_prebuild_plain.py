@@ -8,6 +8,6 @@ for defs in sys.argv[1:]:
     os.environ["DOMPC_DEFS"] = defs
     for name, kw, header, h in g.lowered_models([("industrial_poly", {})]):
         try:
-            print(repr(defs), nb.model_code_object(header, h), flush=True)
+            print(repr(defs), nb.model_code_object(header, h), nb.model_code_object(header, h, batch_only=True), flush=True)
         except Exception as e:
             print(repr(defs), "BUILD FAILED", str(e)[-1500:])

@@ -14,7 +14,7 @@ print(json.dumps({'defs':'$1','kernel_ms':r['kernel_ms'],'traffic':r['traffic'],
 }
 echo -n "(warm-up, discarded) "; one ""
 : > $O
-for m in "" 1 2 4 8 16 ""; do
+for m in "" ${MASKS:-1 2 4 8 16} ""; do
   if [ -n "$m" ]; then one "DOMPC_REPEAT_PHASE=$m"; else one ""; fi
 done
 python - <<'PY' | tee -a gpurun_out/phase_traffic.txt
