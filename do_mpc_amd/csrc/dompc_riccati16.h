@@ -397,6 +397,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
     for (int u = 0; u < NV; ++u) t += Kj[u] * rl(gv, NA + u);
     if (g == HG && j < NA) out[HR] += t;
   }
+  R16_PN(11)
   // ---- children, pass 2: closed-loop maps Acl = F Lc, ccl = F l0 + f ; P += Acl' P_c Acl
   for (int c = cc - 1; c >= 0; --c) {
     if (c != cc - 1) {                       // (the last child of pass 1 is still in registers)
@@ -415,7 +416,9 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
   // a store also waits for the store's ~2 us round trip - waiting first and storing afterwards keeps the stores of
   // this node in flight during the whole update of the next one.
   DOMPC_PRIO_DOWN();
+  R16_PN(24)
   staged_ready();
+  R16_PN(25)
   double* Nd = Q.ND(n);
   if (g == 0 && j < NA)
 #pragma unroll
@@ -424,7 +427,7 @@ __device__ inline int node(const Prob& Q, int n, double mu, double delta, int la
 #pragma unroll
     for (int u = 0; u < NV; ++u) Nd[ND_KV + u] = kv[u];
   store_val(Q, n, out, lane);
-  R16_PN(11)
+  R16_PN(26)
 #undef R16_PN
   return bad;
 }
@@ -460,11 +463,17 @@ __device__ inline int backward(const Thr& T, const Prob& Q, double mu, double de
       staged_ready();              // the staged record of the first node has landed (later ones: waited for inside node())
       for (int k = A.N - 1; k >= cl; --k) {
         NodeIn nx;                 // the parent's operands: in flight while this node is updated
+#if DOMPC_PROFILE
+        const long long pcl = prof_clock();
+#endif
         if (k > cl) {
           const int np = A.level_node_start[k - 1] + s_;
           load_node(Q, np, lane, nx);
           stage_edge(Q, A.node_child_start[np], lane, Ld + (buf ^ 1) * ES_STAGE);
         }
+#if DOMPC_PROFILE
+        if (threadIdx.x == 0) lds_prof[27] += prof_clock() - pcl;
+#endif
         Val Vn;
         if (node(Q, A.level_node_start[k] + s_, mu, delta, lane, in, Ld + buf * ES_STAGE, &V, Vn)) { T.fset(0, FSET); break; }
         V = Vn;

@@ -50,10 +50,10 @@ def main():
     sub = np.concatenate([mpc.S.trace(4096)[-2][:8], mpc.S.trace(4096)[-3][:8], mpc.S.trace(4096)[-4][:8], mpc.S.trace(4096)[-5][:8]])
     names = {0: "edge:model-eval", 4: "edge:loads issued", 5: "edge:residual rows+H staging", 6: "edge:wait+build columns",
              1: "edge:dual pieces", 2: "edge:gauss-jordan+W", 7: "edge:tile condensing", 3: "edge:record stores",
-             12: "node:staged tiles", 13: "node:own terms", 14: "node:own matrix", 8: "node:column to tile", 9: "node:coupling", 10: "node:cholesky+K", 11: "node:closed-loop+store", 15: "node4:wait for the parent's operands + stores", 16: "fwd:node steps (chain walk)", 17: "fwd:edge loads issued",
+             12: "node:staged tiles", 13: "node:own terms", 14: "node:own matrix", 8: "node:column to tile", 9: "node:coupling", 10: "node:cholesky+K", 11: "node:own part of the value function", 15: "node4:wait for the parent's operands + stores", 16: "fwd:node steps (chain walk)", 17: "fwd:edge loads issued",
              18: "fwd:edge wait + dw", 19: "fwd:edge rhs", 20: "fwd:edge dlam + stores", 21: "sweep:model evaluation", 22: "sweep:edge loop", 23: "sweep:node assembly",
-             24: "factor:columns + dual pieces", 25: "factor:tile build", 26: "factor:blocked elimination", 27: "factor:outputs"}
-    for i in (0, 4, 5, 6, 1, 2, 24, 25, 26, 27, 7, 3, 12, 13, 14, 8, 9, 10, 11, 15, 16, 17, 18, 19, 20, 21, 22, 23):
+             24: "node:closed loop (children, pass 2)", 25: "node:wait for the next node's operands", 26: "node:stores", 27: "chain:request of the next node's operands"}
+    for i in (0, 4, 5, 6, 1, 2, 7, 3, 12, 13, 14, 8, 9, 10, 11, 24, 25, 26, 27, 15, 16, 17, 18, 19, 20, 21, 22, 23):
         print(f"    {names[i]:30s} {sub[i] / 1e6:9.2f} Mcycles")
 
 

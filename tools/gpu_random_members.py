@@ -18,6 +18,9 @@ if __name__ == "__main__":
     B = 16384
     X0 = bench.synthetic_x0_batch(B)
     members = sorted(int(i) for i in np.random.default_rng(seed).choice(B, size=n, replace=False))
+    if os.environ.get("DOMPC_MEMBERS"):                    # named members instead of drawn ones: DOMPC_MEMBERS=3526,7283
+        members = sorted(int(i) for i in os.environ["DOMPC_MEMBERS"].split(","))
+        n = len(members)
     mpc = ex.build_mpc(ex.build_model(), max_batch=B)
     used = np.ones(mpc.structure.n_opt_x, bool)
     used[mpc.structure.tables["dummy_idx"]] = False
