@@ -170,6 +170,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
   double mu = O.mu_init;
   Q.sf = 1.0;
   long long c_sweep = 0, c_bwd = 0, c_fwd = 0, c_ls = 0, c_meas = 0, c_ftb = 0, c_acc = 0, c_t = 0; const long long c_start = prof_clock();
+  unsigned g_sweep = 0, g_bwd = 0, g_fwd = 0, g_ls = 0, g_meas = 0, g_ftb = 0, g_acc = 0, g_t = 0; const unsigned g_start = T.gen;      // device-scope barriers per phase (profile builds)
   if (T.tid == 0) T.fset(6, abort_requested(A));      // (read by everybody at the top of the loop, barriers in between)
   // (singular0: every iteration is regularised and delta_w is known before its sweep - folded into the condensed blocks
   //  there, Prob::dsw, instead of W'W being formed on demand by the Riccati pass: that path costs as much as the pass)
@@ -454,14 +455,14 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     delta = 0.0;
     bool first_try = true, dir_ok = true, recs_dirty = false;
     while (true) {
-      c_t = prof_clock();
+      c_t = prof_clock(); g_t = T.gen;
       int fail = (singular0 && delta == 0.0) ? 1 : run_backward(T, Q, b, slot, mu, delta);
       if (EPS_GLOBAL && !fail) {
         run_forward(T, Q, b, slot, mu, delta);            // structured step at c(x), then the Schur complement of the shared slacks
         fail = epsg_build(delta);
         recs_dirty = true;                                // (the vector parts of the records now belong to the last column's residual)
       }
-      c_bwd += prof_clock() - c_t;
+      c_bwd += prof_clock() - c_t; g_bwd += T.gen - g_t;
       if (!fail) break;
       if (delta == 0.0) {
         delta = delta_after(delta_last);
@@ -481,26 +482,26 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     }
     if (!dir_ok) { if (in_wd) { wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; }
     if (delta > 0.0) { delta_last = delta; ++n_reg; }
-    c_t = prof_clock();
+    c_t = prof_clock(); g_t = T.gen;
     if (EPS_GLOBAL) { if (epsg_apply(delta, Q.dlam_e)) { if (in_wd) { wd_resume = true; in_wd = false; wd_count = 0; continue; } status = 3; break; } }
     else run_forward(T, Q, b, slot, mu, delta);
-    c_fwd += prof_clock() - c_t;
+    c_fwd += prof_clock() - c_t; g_fwd += T.gen - g_t;
 
     // ---- fraction to the boundary, directional derivative of the barrier function
-    c_t = prof_clock();
+    c_t = prof_clock(); g_t = T.gen;
     // largest ratios (-dx)/(x - l), dx/(u - x) and (-dz)/z over the bounded variables: the fraction-to-the-boundary steps
     // are tau / ratio (one division at the end instead of one per bound), and the directional derivative of the barrier function
     double r5[5];
     run_step_rules(T, Q, b, slot, mu, r5);
     a_max = (r5[0] > tau) ? tau / r5[0] : 1.0; dphi = r5[2];
     a_z = (r5[1] > tau) ? tau / r5[1] : 1.0;
-    c_ftb += prof_clock() - c_t;
+    c_ftb += prof_clock() - c_t; g_ftb += T.gen - g_t;
     }     // (!wd_resume)
     auto step_rules = [&](double (&r5)[5]) { run_step_rules(T, Q, b, slot, mu, r5); };
     const double theta = E.theta;
     const double phi = E.obj + mu * bar_sum;       // (the barrier sum of the current point was formed when it was a trial point)
 
-    c_t = prof_clock();
+    c_t = prof_clock(); g_t = T.gen;
     // ---- filter line search with second-order correction (no restoration phase)
     const double gamma_theta = 1e-5, gamma_phi = 1e-8, eta_phi = 1e-8, s_theta = 1.1, s_phi = 2.3, gamma_alpha = 0.05;
     const double kappa_soc = 0.99;
@@ -650,9 +651,9 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
       T.lsync();
     }
     bar_sum = bar_t;                  // xt of the last evaluated trial becomes the iterate
-    c_ls += prof_clock() - c_t;
+    c_ls += prof_clock() - c_t; g_ls += T.gen - g_t;
     // ---- accept the trial point
-    c_t = prof_clock();
+    c_t = prof_clock(); g_t = T.gen;
     const Comp Cp = run_accept(T, Q, b, slot, alpha, a_z, mu);
     if (A.trace && b == 0 && T.tid == 0 && it < A.trace_cap) {
       double* tr = A.trace + 8 * it;
@@ -661,17 +662,17 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     }
     if (T.tid == 0) T.fset(6, abort_requested(A));
     T.sync();
-    c_acc += prof_clock() - c_t;
+    c_acc += prof_clock() - c_t; g_acc += T.gen - g_t;
     ++it;
-    c_t = prof_clock(); bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(delta_last) : 0.0); c_sweep += prof_clock() - c_t;
+    c_t = prof_clock(); g_t = T.gen; bad = run_sweep(T, Q, b, slot, mu, 0, singular0 ? delta_after(delta_last) : 0.0); c_sweep += prof_clock() - c_t; g_sweep += T.gen - g_t;
     ++n_sweeps;
     if (EPS_GLOBAL) epsg_grad(T, Q);
     if (KAPPA_D != 0.0) Q.mu = mu;
-    c_t = prof_clock(); E = measure(T, Q, &Cp); c_meas += prof_clock() - c_t;
+    c_t = prof_clock(); g_t = T.gen; E = measure(T, Q, &Cp); c_meas += prof_clock() - c_t; g_meas += T.gen - g_t;
   }
 
   // ---- outputs (unscaled multipliers, CasADi sign convention)
-  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = (double)c_ftb; tr[7] = (double)c_acc; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; double* t3 = A.trace + 8 * (A.trace_cap - 3); for (int i = 0; i < 8; ++i) t3[i] = (double)T.prof[8 + i]; double* t4 = A.trace + 8 * (A.trace_cap - 4); for (int i = 0; i < 8; ++i) t4[i] = (double)T.prof[16 + i]; if (A.trace_cap > 12) { double* t5 = A.trace + 8 * (A.trace_cap - 5); for (int i = 0; i < 8; ++i) t5[i] = (double)T.prof[24 + i]; } } }
+  if (A.trace && b == 0 && T.tid == 0 && A.trace_cap > 8) { double* tr = A.trace + 8 * (A.trace_cap - 1); tr[0] = (double)c_sweep; tr[1] = (double)c_bwd; tr[2] = (double)c_fwd; tr[3] = (double)c_ls; tr[4] = (double)c_meas; tr[5] = (double)(prof_clock() - c_start); tr[6] = (double)c_ftb; tr[7] = (double)c_acc; if (T.prof) { double* t2 = A.trace + 8 * (A.trace_cap - 2); for (int i = 0; i < 8; ++i) t2[i] = (double)T.prof[i]; double* t3 = A.trace + 8 * (A.trace_cap - 3); for (int i = 0; i < 8; ++i) t3[i] = (double)T.prof[8 + i]; double* t4 = A.trace + 8 * (A.trace_cap - 4); for (int i = 0; i < 8; ++i) t4[i] = (double)T.prof[16 + i]; if (A.trace_cap > 12) { double* t5 = A.trace + 8 * (A.trace_cap - 5); for (int i = 0; i < 8; ++i) t5[i] = (double)T.prof[24 + i]; double* t6 = A.trace + 8 * (A.trace_cap - 6); t6[0] = g_sweep; t6[1] = g_bwd; t6[2] = g_fwd; t6[3] = g_ls; t6[4] = g_meas; t6[5] = T.gen - g_start; t6[6] = g_ftb; t6[7] = g_acc; } } }
   const double isf = 1.0 / Q.sf;
   // (sharded problem: every entry is written by exactly one rank, zeros elsewhere -> a SUM over the ranks is the full vector)
   if (A.x_out) for (int g = T.tid; g < nX; g += T.nt) A.x_out[(int64_t)b * nX + g] = sh_cnt(A, mk_x(A, g)) ? Q.x[g] : 0.0;

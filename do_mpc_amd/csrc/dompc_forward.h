@@ -171,14 +171,50 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
     ldsd *DX = C, *DV = C + 16, *DXN = C + 32, *IN = C + 48;
     struct Ix { int uo, eo, xoc, row0; unsigned ndc; };       // per-lane (= per-chain) indices of a step, requested with its operands
     const int cw = (S + ng - 1) / ng < 4 ? (S + ng - 1) / ng : 4;      // chains per wavefront (one problem alone: every chain has its own wavefront)
+    // One chain per wavefront (one problem alone on the chip, large trees): the walk is then a chain of memory round trips - a step's
+    // operands, requested one step ahead, take 4 k cycles to arrive while the step itself takes 600.  The three idle lane groups are put
+    // to use as PREFETCH DEPTH: lane group q requests and holds the operands of the steps k = cl + q (mod 4), four steps are in flight,
+    // and the steps are executed one after the other by "their" lane group on one shared set of step vectors (same arithmetic, same bits).
+#ifndef DOMPC_FW_DEEP
+#define DOMPC_FW_DEEP 1
+#endif
+    const bool deep = DOMPC_FW_DEEP && cw == 1;
+    const int kstep = deep ? 4 : 1;
     for (int s0 = cw * gid; s0 < S && cl < A.N; s0 += cw * ng) {
-      const bool here = c4 < cw && s0 + c4 < S;
-      const int sc = here ? s0 + c4 : S - 1;                  // (lane groups without a chain repeat the last one and store nothing)
-      const bool on = here && mk_n(A, A.level_node_start[A.N] + sc);
+      const bool here = deep || (c4 < cw && s0 + c4 < S);
+      const int sc = deep ? s0 : (here ? s0 + c4 : S - 1);   // (lane groups without a chain repeat the last one and store nothing)
+#ifdef DOMPC_FW_NOSTORE            /* timing experiment only: the chain walk without its global stores (wrong steps) */
+      const bool on_chain = false;
+#else
+      const bool on_chain = here && mk_n(A, A.level_node_start[A.N] + sc);
+#endif
+      ldsd *DXs = deep ? Ld : DX, *DVs = deep ? Ld + 16 : DV, *DXNs = deep ? Ld + 32 : DXN;      // step vectors: the chain's (deep: one set for the wavefront)
       double v[FW4_PL];
-      auto load4 = [&](int k, Ix& ix) {
-        const int n = A.level_node_start[k] + sc, e = A.node_child_start[A.level_node_start[k]] + sc, cn = A.level_node_start[k + 1] + sc;
-        const unsigned nd0 = (unsigned)n * (unsigned)ND_SIZE, es0 = (unsigned)e * (unsigned)ES_SIZE, nc0 = (unsigned)cn * (unsigned)ND_SIZE;
+      // Indices of a step from SCALAR table reads: the four lane groups of a wavefront work on four (level, chain) pairs that are uniform
+      // per group - (k + q, s0) in deep mode, (k, s0 + q) otherwise - so each group's node / edge numbers and offsets are read with scalar
+      // loads and picked by lane group.  (They used to be per-lane vector reads: a chain of three dependent memory round trips in front of
+      // the operand requests, and vector loads whose results - carried into the next step through register copies - made every step wait
+      // for ALL the requests it had just issued: the prefetch overlapped with nothing, 4 k cycles per step of a 600-cycle computation.)
+      auto load4 = [&](int kb, Ix& ix) {
+        int n_[4], e_[4], cn_[4], uo_[4], eo_[4], xoc_[4], row0_[4];      // (uniform: scalar registers; the reads of one stage side by side)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kq_ = deep ? kb + q : kb;
+          const int kq = kq_ < A.N ? kq_ : A.N - 1;          // (deep: lane groups beyond the last step repeat it and store nothing)
+          const int scq = deep ? s0 : ((q < cw && s0 + q < S) ? s0 + q : S - 1);
+          n_[q] = A.level_node_start[kq];
+          cn_[q] = A.level_node_start[kq + 1] + scq;
+          e_[q] = scq;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { e_[q] += A.node_child_start[n_[q]]; n_[q] += deep ? s0 : ((q < cw && s0 + q < S) ? s0 + q : S - 1); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uo_[q] = A.node_u_off[n_[q]]; eo_[q] = NS > 0 ? A.node_eps_off[n_[q]] : 0; xoc_[q] = A.node_x_off[cn_[q]]; row0_[q] = A.edge_row0[e_[q]];
+        }
+        auto pick = [&](const int (&a)[4]) { return c4 == 0 ? a[0] : (c4 == 1 ? a[1] : (c4 == 2 ? a[2] : a[3])); };
+        const unsigned nd0 = (unsigned)pick(n_) * (unsigned)ND_SIZE, es0 = (unsigned)pick(e_) * (unsigned)ES_SIZE, nc0 = (unsigned)pick(cn_) * (unsigned)ND_SIZE;
+        const int uo = pick(uo_), eo = pick(eo_), xoc = pick(xoc_), row0 = pick(row0_);
 #pragma unroll
         for (int q = 0; q < FW4_PL; ++q) {
           const int i = ll + 16 * q;
@@ -191,59 +227,59 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
           else if (i < FW_N) x = ldoff(Q.nd, nc0 + (unsigned)(ND_PV + i - FW_K - FW_AB - NX * NA));
           v[q] = x;
         }
-        ix.uo = A.node_u_off[n];
-        ix.eo = NS > 0 ? A.node_eps_off[n] : 0;
-        ix.xoc = A.node_x_off[cn];
-        ix.row0 = A.edge_row0[e];
-        ix.ndc = nc0;
+        ix.uo = uo; ix.eo = eo; ix.xoc = xoc; ix.row0 = row0; ix.ndc = nc0;
       };
       Ix cur, nxt;
       load4(cl, cur);
-      if (ll < NA) DX[ll] = ldoff(Q.nd, (unsigned)(A.level_node_start[cl] + sc) * (unsigned)ND_SIZE + (unsigned)(ND_DXT + ll));
-      for (int k = cl; k < A.N; ++k) {
+      if (ll < NA && (!deep || c4 == 0)) DXs[ll] = ldoff(Q.nd, (unsigned)(A.level_node_start[cl] + sc) * (unsigned)ND_SIZE + (unsigned)(ND_DXT + ll));
+      for (int k = cl; k < A.N; k += kstep) {
 #pragma unroll
         for (int q = 0; q < FW4_PL; ++q) {
           const int i = ll + 16 * q;
           if (i < FW_N) IN[i] = v[q];
         }
-        if (k + 1 < A.N) load4(k + 1, nxt);                  // (in flight during the step)
+        if (k + kstep < A.N) load4(k + kstep, nxt);      // (in flight during the step(s))
         T.gsync();
         const ldsd *K_ = IN, *KV_ = K_ + NV * NA, *AB_ = IN + FW_K, *CV_ = AB_ + NX * NA, *PC_ = IN + FW_K + FW_AB, *PV_ = PC_ + NX * NA;
-        if (ll < NV) {
-          double t = KV_[ll];
+        for (int qd = 0; qd < kstep; ++qd) {
+          const bool act = !deep || (c4 == qd && k + qd < A.N);       // this lane group's step
+          const bool on = on_chain && act;
+          if (act && ll < NV) {
+            double t = KV_[ll];
 #pragma unroll
-          for (int a = 0; a < NA; ++a) t += K_[ll * NA + a] * DX[a];
-          DV[ll] = t;
-          if (on) {
-            if (ll < NU) Q.dx[cur.uo + ll] = t;
-            else Q.dx[cur.eo + ll - NU] = t;
+            for (int a = 0; a < NA; ++a) t += K_[ll * NA + a] * DXs[a];
+            DVs[ll] = t;
+            if (on) {
+              if (ll < NU) Q.dx[cur.uo + ll] = t;
+              else Q.dx[cur.eo + ll - NU] = t;
+            }
           }
-        }
-        T.gsync();
-        if (ll < NA) {
-          double t;
-          if (ll < NX) {
-            t = CV_[ll];
+          T.gsync();
+          if (act && ll < NA) {
+            double t;
+            if (ll < NX) {
+              t = CV_[ll];
 #pragma unroll
-            for (int b = 0; b < NX; ++b) t += AB_[ll * NA + b] * DX[b];
+              for (int b = 0; b < NX; ++b) t += AB_[ll * NA + b] * DXs[b];
 #pragma unroll
-            for (int b = 0; b < NU; ++b) t += AB_[ll * NA + NX + b] * DV[b];
-            if (on) Q.dx[cur.xoc + ll] = t;
-          } else {
-            t = DV[ll - NX];
+              for (int b = 0; b < NU; ++b) t += AB_[ll * NA + NX + b] * DVs[b];
+              if (on) Q.dx[cur.xoc + ll] = t;
+            } else {
+              t = DVs[ll - NX];
+            }
+            if (on) Q.nd[cur.ndc + (unsigned)(ND_DXT + ll)] = t;
+            DXNs[ll] = t;
           }
-          if (on) Q.nd[cur.ndc + (unsigned)(ND_DXT + ll)] = t;
-          DXN[ll] = t;
-        }
-        T.gsync();
-        if (ll < NX) {
-          double t = PV_[ll];
+          T.gsync();
+          if (act && ll < NX) {
+            double t = PV_[ll];
 #pragma unroll
-          for (int b = 0; b < NA; ++b) t += PC_[ll * NA + b] * DXN[b];
-          if (on) Q.dlam[cur.row0 + NW + ll] = t;
+            for (int b = 0; b < NA; ++b) t += PC_[ll * NA + b] * DXNs[b];
+            if (on) Q.dlam[cur.row0 + NW + ll] = t;
+          }
+          if (act && ll < NA) DXs[ll] = DXNs[ll];
+          T.gsync();
         }
-        if (ll < NA) DX[ll] = DXN[ll];
-        T.gsync();
         cur = nxt;
       }
     }

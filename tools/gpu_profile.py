@@ -47,6 +47,10 @@ def main():
     for nm, v in zip(("step rules", "accept"), tr[6:8]):
         print(f"  {nm:12s} {v / 1e6:9.2f} Mcycles  {100 * v / tot:5.1f} %")
     print(f"  total        {tot / 1e6:9.2f} Mcycles (problem 0)")
+    gb = mpc.S.trace(4096)[-6]
+    if gb[5] > 0:
+        print("  workgroup / device-scope barriers of problem 0: total %d = %.1f per iteration; sweep %d, backward %d, forward %d, line search %d, measure %d, step rules %d, accept %d"
+              % (gb[5], gb[5] / max(1, st['iter_count'][0]), gb[0], gb[1], gb[2], gb[3], gb[4], gb[6], gb[7]))
     sub = np.concatenate([mpc.S.trace(4096)[-2][:8], mpc.S.trace(4096)[-3][:8], mpc.S.trace(4096)[-4][:8], mpc.S.trace(4096)[-5][:8]])
     names = {0: "edge:model-eval", 4: "edge:loads issued", 5: "edge:residual rows+H staging", 6: "edge:wait+build columns",
              1: "edge:dual pieces", 2: "edge:gauss-jordan+W", 7: "edge:tile condensing", 3: "edge:record stores",
