@@ -37,22 +37,40 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
 #define DOMPC_PF(i)
 #endif
   (void)pc0;
-  // root
-  if (T.tid == 0) {
-    double* Nd = Q.ND(0);
-    const int xo = A.node_x_off[0];
-    if (FREE_ROOT) {                                         // (the step of the free initial state was formed at the end of the backward pass)
-      for (int a = 0; a < NX; ++a) Q.dx[xo + a] = Nd[ND_DXT + a];
-    } else {
-      for (int a = 0; a < NX; ++a) { Nd[ND_DXT + a] = -Q.c[a]; Q.dx[xo + a] = -Q.c[a]; }
+  // root.  When the tree branches at the root (chain_level >= 1) the wavefront that takes node 0 forms the root's step itself, inside
+  // node_step: one device-scope barrier less per pass.  Otherwise thread 0 does it, followed by a barrier, as before.
+  const int cl = A.chain_level < A.N ? A.chain_level : A.N;
+#ifndef DOMPC_HOST_EMU
+  const bool root_fused = cl >= 1 && !SHARD;
+#else
+  const bool root_fused = false;
+#endif
+  if (!root_fused) {
+    if (T.tid == 0) {
+      double* Nd = Q.ND(0);
+      const int xo = A.node_x_off[0];
+      if (FREE_ROOT) {                                         // (the step of the free initial state was formed at the end of the backward pass)
+        for (int a = 0; a < NX; ++a) Q.dx[xo + a] = Nd[ND_DXT + a];
+      } else {
+        for (int a = 0; a < NX; ++a) { Nd[ND_DXT + a] = -Q.c[a]; Q.dx[xo + a] = -Q.c[a]; }
+      }
+      for (int a = NX; a < NA; ++a) Nd[ND_DXT + a] = 0.0;
     }
-    for (int a = NX; a < NA; ++a) Nd[ND_DXT + a] = 0.0;
+    T.sync();
   }
-  T.sync();
   // node steps: dv = K dx~ + kv, children dx~ = Atilde [dx~; dv] + c~.  Branching stages level by level with
   // a barrier; below the robust horizon each group walks its scenario chain downwards with dx~ kept in LDS.
   auto node_step = [&](int n) {                         // generic (any number of children; operands from global memory)
     const double* Nd = Q.ND(n);
+    if (root_fused && n == 0) {
+      const int xo = A.node_x_off[0];
+      for (int a = lane; a < NA; a += GS) {
+        const double t = a < NX ? (FREE_ROOT ? Nd[ND_DXT + a] : -Q.c[a]) : 0.0;
+        Ld[RF_DX + a] = t;
+        if (!FREE_ROOT || a >= NX) Q.ND(0)[ND_DXT + a] = t;
+        if (a < NX) Q.dx[xo + a] = t;
+      }
+    } else
     for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Nd[ND_DXT + a];
     T.gsync();
     for (int i = lane; i < NV; i += GS) {
@@ -146,7 +164,6 @@ DOMPC_PHASE void riccati_forward_t(const Thr& T, const Prob& Q, double mu, doubl
     for (int a = lane; a < NA; a += GS) Ld[RF_DX + a] = Ld[RF_DXN + a];
     T.gsync();
   };
-  const int cl = A.chain_level < A.N ? A.chain_level : A.N;
   for (int k = 0; k < cl; ++k) {
     const int n0 = A.level_node_start[k], n1 = A.level_node_start[k + 1];
     for (int n = n0 + gid; n < n1; n += ng)
