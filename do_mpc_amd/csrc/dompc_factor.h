@@ -1146,7 +1146,62 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     // the group of the current column only (the diagonal blocks are the nonsingular collocation Jacobians,
     // resp. identities), which keeps the structure; the last NX columns (xkf: identity block, zero above)
     // need no elimination step at all - their inverse columns are already in place.
-    {
+    // Round 6: the same elimination in REGISTERS when the matrix has at most one column per lane (NC <= 64; batch_reactor with two finite
+    // elements: 24 unknowns, 30 columns).  The LDS version below re-reads the pivot column and the lane's own column and re-writes the own
+    // column in every step (3 NW LDS operations) and searches the pivot with NW packed keys per step: 3.4 k cycles per step, 59 % of a
+    // batch_reactor solve (tools/gpu_profile.py).  Here a lane keeps its column in registers for the whole elimination, the pivot column
+    // arrives as uniform values (v_readlane -> scalar operands of the FMAs), the rows above the pivot's group are skipped (G_w is block
+    // lower-triangular in the grouping described above: column kk is zero there and stays zero), and the pivots are taken in the natural
+    // order - the diagonal carries the collocation coefficients C_jj resp. the identity of the continuity rows - under the threshold test of
+    // the single-element paths, |a_kk| >= GJ_U max |a_rk| over the remaining rows of the group.  A failed test leaves the LDS matrix
+    // untouched and the pivoting version below runs instead.
+    bool gj_done = false;
+#ifndef DOMPC_HOST_EMU
+#ifndef DOMPC_REG_GJ
+#define DOMPC_REG_GJ 1
+#endif
+    if constexpr ((DOMPC_REG_GJ != 0) && NC <= 64 && NW <= 40 && NW > NX) {
+      if (GS == 64) {
+        constexpr int GJ_STEPS = NW - NX;
+        constexpr int EL_ROWS = (DEG + 1) * NX;
+        const int cc_ = lane < NC ? lane : 0;
+        double col[NW1];
+#pragma unroll
+        for (int r = 0; r < NW; ++r) col[r] = act ? Ld[EL_MX + r * NC + cc_] : 1.0;      // (lanes >= NC: a copy of column 0, not written back)
+        int bad = 0;
+#pragma unroll
+        for (int kk = 0; kk < GJ_STEPS; ++kk) {
+          const int pos = kk % EL_ROWS;
+          const int grp0 = kk - pos + (pos < DEG * NX ? 0 : DEG * NX);
+          const int grp1 = kk - pos + (pos < DEG * NX ? DEG * NX : EL_ROWS);
+          double f[NW1];
+#pragma unroll
+          for (int r = 0; r < NW; ++r) f[r] = r >= grp0 ? lane_bcast(col[r], kk) : 0.0;
+          double m = 0.0;
+#pragma unroll
+          for (int r = 0; r < NW; ++r) if (r > kk && r < grp1) m = fmax(m, fabs(f[r]));
+          const double akk = fabs(f[kk]);
+          bad |= (int)!(akk >= DOMPC_GJ_U * m && akk > 1e-300);
+          const double pinv = fast_rcp(akk > 1e-300 ? f[kk] : 1.0);
+          const bool own = lane == kk;
+          const double prow = own ? pinv : col[kk] * pinv;
+#pragma unroll
+          for (int r = 0; r < NW; ++r) if (r >= grp0 && r != kk) col[r] = fma(-f[r], prow, own ? 0.0 : col[r]);
+          col[kk] = prow;
+        }
+        if (!act) bad = 0;
+        if (__builtin_amdgcn_readfirstlane(bad) == 0) {
+          if (act && lane < NC) {
+#pragma unroll
+            for (int r = 0; r < NW; ++r) Ld[EL_MX + r * NC + lane] = col[r];
+          }
+          T.gsync();
+          gj_done = true;
+        }
+      }
+    }
+#endif
+    if (!gj_done) {
       static_assert(NW <= 128, "row index is packed into 7 bits of the pivot key / 128-bit used mask");
       constexpr int GJ_STEPS = NW - NX;
       constexpr int EL_ROWS = (DEG + 1) * NX;
