@@ -870,6 +870,19 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
   double pf_xn[RPL], pf_w[RPL][DEG > 0 ? DEG : 1], pf_wend[RPL], pf_xc[RPL], pf_lam[RPL], pf_c[RPL], pf_cend[RPL];
   double pf_ltg[APL], pf_mg[RPL], pf_mh[MHL], pf_lt0 = 0.0, pf_mt0 = 0.0;
   const bool last_stage = (k == A.N - 1);
+  // Several finite elements per interval (round 6): every operand the phases of this edge read from global memory is requested in ONE
+  // batch before the first store of the edge.  On gfx9 stores count in vmcnt like loads, so a load behind a store waits for the store's
+  // round trip (3 - 4 k cycles): the residual stores inside the assembly loop, the per-variable loads of phase 3 behind them, the stage-cost
+  // loads of the condensing and of phase 7 behind the record stores cost batch_reactor five such waits per edge.
+  constexpr bool GP = (NI > 1 && M > 0);
+  constexpr int G_ROWS = NI * (DEG + 1) * NX;
+  constexpr int G_RWL = GP ? (G_ROWS + GS_C - 1) / GS_C : 1, G_WPL = GP ? (NW + GS_C - 1) / GS_C : 1, G_APL = GP ? (NA + GS_C - 1) / GS_C : 1;
+  constexpr int G_XPL = GP ? (NX + GS_C - 1) / GS_C : 1, G_MHL = GP ? (NX * NX + GS_C - 1) / GS_C : 1, G_CVL = GP ? (NX * (NA + 1) + GS_C - 1) / GS_C : 1;
+  constexpr int G_QPL = GP ? (NA * NA + GS_C - 1) / GS_C : 1;
+  double gp_res[G_RWL], gp_x[G_WPL], gp_l[G_WPL], gp_u[G_WPL], gp_zl[G_WPL], gp_zu[G_WPL], gp_ce[G_XPL], gp_cv[G_CVL];
+  double gp_ltg[G_APL], gp_mg[G_XPL], gp_mh[G_MHL], gp_qlt[G_QPL], gp_qnl[G_QPL], gp_lt0 = 0.0, gp_mt0 = 0.0;
+  (void)gp_res; (void)gp_x; (void)gp_l; (void)gp_u; (void)gp_zl; (void)gp_zu; (void)gp_ce; (void)gp_cv;
+  (void)gp_ltg; (void)gp_mg; (void)gp_mh; (void)gp_qlt; (void)gp_qnl; (void)gp_lt0; (void)gp_mt0;
   (void)pf_xn; (void)pf_w; (void)pf_wend; (void)pf_xc; (void)pf_lam; (void)pf_c; (void)pf_cend;
   (void)pf_ltg; (void)pf_mg; (void)pf_mh; (void)pf_lt0; (void)pf_mt0; (void)last_stage;
   // the model-output record of this edge: the dense image in LDS (compact record: staged by the previous edge of this
@@ -1066,12 +1079,54 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       if (MO_LDS && e_next >= 0 && !(DOMPC_KO & 32)) { stage_mo(Q, e_next, lane, Ld); staged_e = e_next; }
 #endif
     } else {
+    // ---- the batch of global loads of the edge (see GP above)
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < G_WPL; ++q) {
+        const int col = lane + q * GS, gi = woff + (col < NW ? col : 0);
+        gp_x[q] = Q.x[gi]; gp_l[q] = Q.lb[gi]; gp_u[q] = Q.ub[gi]; gp_zl[q] = Q.zl[gi]; gp_zu[q] = Q.zu[gi];
+      }
+#pragma unroll
+      for (int q = 0; q < G_XPL; ++q) {
+        const int a = lane + q * GS, ac = a < NX ? a : 0;
+        gp_ce[q] = Q.soc ? Q.c[row0 + NW + ac] : w[(M - 1) * NX + ac] - xc[ac];
+        gp_mg[q] = last_stage ? mo[MO_MT + 1 + ac] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < G_CVL; ++q) {
+        const int it = lane + q * GS, a = (it < NX * (NA + 1) ? it : 0) / (NA + 1);
+        gp_cv[q] = Q.soc ? Q.c[row0 + NW + a] : w[(M - 1) * NX + a] - xc[a];
+      }
+#pragma unroll
+      for (int q = 0; q < G_APL; ++q) {
+        const int a = lane + q * GS;
+        gp_ltg[q] = mo[MO_LT + 1 + (a < NA ? a : 0)];
+      }
+#pragma unroll
+      for (int q = 0; q < G_MHL; ++q) {
+        const int a = lane + q * GS, ac = a < NX * NX ? a : 0;
+        gp_mh[q] = last_stage ? mo[MO_MT + 1 + NX + symi(ac / NX, ac % NX, NX)] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < G_QPL; ++q) {
+        const int it = lane + q * GS, itc = it < NA * NA ? it : 0;
+        const int ip = symi(itc / NA, itc % NA, NA);
+        gp_qlt[q] = mo[MO_LT + 1 + NA + ip];
+        gp_qnl[q] = NE > 0 ? mo[MO_NL + NE + NE * NA + ip] : 0.0;
+      }
+      gp_lt0 = mo[MO_LT];
+      gp_mt0 = last_stage ? mo[MO_MT] : 0.0;
+    }
     // ---- phase 2: assemble Mx = [G_w | G_y | r_g] and the residual rows; the point Hessians needed by the
     //      condensing phases are staged in LDS with the same batch of global loads
     if (act) {
       for (int it = lane; it < NCOLL * NA * NA; it += GS)
         Ld[EL_HP + it] = mo[MO_PT + (it / (NA * NA)) * PT_STRIDE + NX + NX * NA + symi((it % (NA * NA)) / NA, it % NA, NA)];
-      for (int it = lane; it < NI * (DEG + 1) * NX; it += GS) {
+#pragma unroll
+      for (int q2 = 0; q2 < G_RWL; ++q2) {
+        const int it = lane + q2 * GS;
+        gp_res[q2] = 0.0;
+        if (it >= G_ROWS) continue;
         const int i = it / ((DEG + 1) * NX);
         const int rr = it % ((DEG + 1) * NX);
         const int jj = rr / NX, a = rr % NX;         // jj = 0..DEG-1: collocation row j=jj+1 ; jj = DEG: continuity row
@@ -1084,7 +1139,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           double xp = DOMPC_C[0 * (DEG + 1) + j] * xi0[a];
           for (int r = 1; r <= DEG; ++r) xp += DOMPC_C[r * (DEG + 1) + j] * w[slot_of(i, r) * NX + a];
           const double res = Q.soc ? Q.c[row0 + row] : pt[a] - xp;
-          if (!Q.soc) Q.c[row0 + row] = res;
+          gp_res[q2] = res;
           Mr[NW + NA] = res;
           for (int b = 0; b < NX; ++b) Mr[sl * NX + b] += pt[NX + a * NA + b];
           for (int b = 0; b < NU; ++b) Mr[NW + NX + b] = pt[NX + a * NA + NX + b];
@@ -1098,7 +1153,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           double xf = DOMPC_D[0] * xi0[a];
           for (int r = 1; r <= DEG; ++r) xf += DOMPC_D[r] * w[slot_of(i, r) * NX + a];
           const double res = Q.soc ? Q.c[row0 + row] : w[ns_ * NX + a] - xf;
-          if (!Q.soc) Q.c[row0 + row] = res;
+          gp_res[q2] = res;
           Mr[NW + NA] = res;
           Mr[ns_ * NX + a] += 1.0;
           for (int r = 0; r <= DEG; ++r) {
@@ -1107,30 +1162,46 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           }
         }
       }
-      if (!Q.soc)
-        for (int a = lane; a < NX; a += GS) Q.c[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
     }
     T.gsync();
-    // ---- phase 3: dual-residual pieces that need G_w / G_y (before they are overwritten)
+    // ---- phase 3: dual-residual pieces that need G_w / G_y (before they are overwritten); then the stores of phases 2 and 3
     if (act) {
-      for (int col = lane; col < NW; col += GS) {
+#pragma unroll
+      for (int q = 0; q < G_WPL; ++q) {
+        const int col = lane + q * GS;
+        if (col >= NW) continue;
         double t = 0.0;
 #pragma unroll 6
         for (int r = 0; r < NW; ++r) t += Ld[EL_MX + r * NC + col] * Ld[EL_T0 + r];
         if (col >= (M - 1) * NX) t += nu_e[col - (M - 1) * NX];
-        const int gi = woff + col;
-        const double xv = Q.x[gi], l = Q.lb[gi], u = Q.ub[gi];
-        Q.gf[gi] = 0.0;
-        Q.rd[gi] = t - Q.zl[gi] + Q.zu[gi];
+        const double xv = gp_x[q], l = gp_l[q], u = gp_u[q];
+        gp_x[q] = t - gp_zl[q] + gp_zu[q];                       // (the dual residual of the variable, stored below)
         Ld[EL_RW + col] = t + bar_grad(xv, l, u, mu, !(Q.soc & 2));
         Ld[EL_BB + col] = bar_grad(xv, l, u, 1.0);
-        Ld[EL_SG + col] = sigma_of(xv, l, u, Q.zl[gi], Q.zu[gi]);
+        Ld[EL_SG + col] = sigma_of(xv, l, u, gp_zl[q], gp_zu[q]);
       }
       for (int b = lane; b < NA; b += GS) {
         double t = 0.0;
 #pragma unroll 6
         for (int r = 0; r < NW; ++r) t += Ld[EL_MX + r * NC + NW + b] * Ld[EL_T0 + r];
         Ld[EL_RY + b] = t;          // completed in phase 7
+      }
+#pragma unroll
+      for (int q = 0; q < G_WPL; ++q) {
+        const int col = lane + q * GS;
+        if (col < NW) { Q.gf[woff + col] = 0.0; Q.rd[woff + col] = gp_x[q]; }
+      }
+      if (!Q.soc) {
+#pragma unroll
+        for (int q2 = 0; q2 < G_RWL; ++q2) {
+          const int it = lane + q2 * GS;
+          if (it < G_ROWS) Q.c[row0 + it] = gp_res[q2];
+        }
+#pragma unroll
+        for (int q = 0; q < G_XPL; ++q) {
+          const int a = lane + q * GS;
+          if (a < NX) Q.c[row0 + NW + a] = gp_ce[q];
+        }
       }
     }
     T.gsync();
@@ -1151,7 +1222,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     // column in every step (3 NW LDS operations) and searches the pivot with NW packed keys per step: 3.4 k cycles per step, 59 % of a
     // batch_reactor solve (tools/gpu_profile.py).  Here a lane keeps its column in registers for the whole elimination, the pivot column
     // arrives as uniform values (v_readlane -> scalar operands of the FMAs), the rows above the pivot's group are skipped (G_w is block
-    // lower-triangular in the grouping described above: column kk is zero there and stays zero), and the pivots are taken in the natural
+    // lower-triangular in the grouping described above: column kk is zero there and stays zero; likewise the rows below the element(s)
+    // the column belongs to - checked numerically for three shapes, tools/check_gj_structure.py), and the pivots are taken in the natural
     // order - the diagonal carries the collocation coefficients C_jj resp. the identity of the continuity rows - under the threshold test of
     // the single-element paths, |a_kk| >= GJ_U max |a_rk| over the remaining rows of the group.  A failed test leaves the LDS matrix
     // untouched and the pivoting version below runs instead.
@@ -1174,9 +1246,12 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           const int pos = kk % EL_ROWS;
           const int grp0 = kk - pos + (pos < DEG * NX ? 0 : DEG * NX);
           const int grp1 = kk - pos + (pos < DEG * NX ? DEG * NX : EL_ROWS);
+          // (column kk is also zero BELOW the rows of its own element - a collocation column - resp. of the next element - the start
+          //  state of the next element, i.e. the continuity group -: fill-in reaches those rows only through later pivots)
+          const int hi_ = pos < DEG * NX ? kk - pos + EL_ROWS : (kk - pos + 2 * EL_ROWS < NW ? kk - pos + 2 * EL_ROWS : NW);
           double f[NW1];
 #pragma unroll
-          for (int r = 0; r < NW; ++r) f[r] = r >= grp0 ? lane_bcast(col[r], kk) : 0.0;
+          for (int r = 0; r < NW; ++r) f[r] = (r >= grp0 && r < hi_) ? lane_bcast(col[r], kk) : 0.0;
           double m = 0.0;
 #pragma unroll
           for (int r = 0; r < NW; ++r) if (r > kk && r < grp1) m = fmax(m, fabs(f[r]));
@@ -1186,7 +1261,7 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           const bool own = lane == kk;
           const double prow = own ? pinv : col[kk] * pinv;
 #pragma unroll
-          for (int r = 0; r < NW; ++r) if (r >= grp0 && r != kk) col[r] = fma(-f[r], prow, own ? 0.0 : col[r]);
+          for (int r = 0; r < NW; ++r) if (r >= grp0 && r < hi_ && r != kk) col[r] = fma(-f[r], prow, own ? 0.0 : col[r]);
           col[kk] = prow;
         }
         if (!act) bad = 0;
@@ -1384,8 +1459,13 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
       const int it = lane + q * GS;
       const int itc = it < NA * NA ? it : 0;
       const int ip = symi(itc / NA, itc % NA, NA);
-      qlt[q] = act ? MOV(MO_LT + 1 + NA + ip) : 0.0;
-      qnl[q] = (act && NE > 0) ? MOV(MO_NL + NE + NE * NA + ip) : 0.0;
+      if constexpr (GP) {                     // (requested with the first batch of loads of the edge)
+        qlt[q] = act ? gp_qlt[q < G_QPL ? q : 0] : 0.0;
+        qnl[q] = (act && NE > 0) ? gp_qnl[q < G_QPL ? q : 0] : 0.0;
+      } else {
+        qlt[q] = act ? MOV(MO_LT + 1 + NA + ip) : 0.0;
+        qnl[q] = (act && NE > 0) ? MOV(MO_NL + NE + NE * NA + ip) : 0.0;
+      }
     }
     if (act) {
       for (int it = lane; it < NW * (NA + 1); it += GS) {
@@ -1500,6 +1580,17 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     }
 #endif
     if (act && !(DOMPC_KO & 4)) {
+      if constexpr (GP) {
+#pragma unroll
+        for (int q = 0; q < G_CVL; ++q) {
+          const int it = lane + q * GS;
+          if (it >= NX * (NA + 1)) continue;
+          const int a = it / (NA + 1), b = it % (NA + 1);
+          const double v = Ld[EL_MX + ((M - 1) * NX + a) * MX_LD + MX_W + b];
+          if (b < NA) S_[ES_AB + a * NA + b] = v;
+          else S_[ES_CV + a] = v + gp_cv[q];
+        }
+      } else
       for (int it = lane; it < NX * (NA + 1); it += GS) {
         const int a = it / (NA + 1), b = it % (NA + 1);
         const double v = Ld[EL_MX + ((M - 1) * NX + a) * MX_LD + MX_W + b];
@@ -1551,6 +1642,33 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
           if (a < NX * NX) S_[ES_MH + a] = omh * pf_mh[q];
         }
       }
+    } else if constexpr (GP) {             // (operands in registers since the first load batch of the edge)
+#pragma unroll
+      for (int q = 0; q < G_APL; ++q) {
+        const int a = lane + q * GS;
+        if (a < NA) {
+          const double grt = RT_CUSTOM ? (double)Ld[EL_RT + 1 + a] : 0.0;       // d rterm / d (x_n, u_n)
+          double r = Ld[EL_RY + a] + om * gp_ltg[q] + grt;
+          if (NE > 0)
+            for (int i = 0; i < NE; ++i) r += mo[MO_NL + NE + i * NA + a] * yd[i] * Q.sgn[e * NE1 + i];
+          S_[ES_GFY + a] = om * gp_ltg[q] + grt;
+          S_[ES_RY + a] = r;
+          S_[ES_QV + a] = Ld[EL_QV + a] + r;
+          S_[ES_QVB + a] = Ld[EL_QV + NA + a];
+        }
+      }
+      if (last_stage) {
+#pragma unroll
+        for (int q = 0; q < G_XPL; ++q) {
+          const int a = lane + q * GS;
+          if (a < NX) S_[ES_MG + a] = om * gp_mg[q];
+        }
+#pragma unroll
+        for (int q = 0; q < G_MHL; ++q) {
+          const int a = lane + q * GS;
+          if (a < NX * NX) S_[ES_MH + a] = omh * gp_mh[q];
+        }
+      }
     } else {
     for (int a = lane; a < NA; a += GS) {
       const double grt = RT_CUSTOM ? (double)Ld[EL_RT + 1 + a] : 0.0;           // d rterm / d (x_n, u_n)
@@ -1568,8 +1686,8 @@ DOMPC_PHASE int eval_edge_coop(const Thr& T, const Prob& Q, int e, int e_next, d
     }
     }
     if (lane == 0) {
-      double obj = PF ? om * pf_lt0 : om * mo[MO_LT];
-      if (k == A.N - 1) obj += PF ? om * pf_mt0 : om * mo[MO_MT];
+      double obj = PF ? om * pf_lt0 : (GP ? om * gp_lt0 : om * mo[MO_LT]);
+      if (k == A.N - 1) obj += PF ? om * pf_mt0 : (GP ? om * gp_mt0 : om * mo[MO_MT]);
       if (RT_CUSTOM) obj += Ld[EL_RT];
       if (NE > 0) {
         const double* eps = (NSE > 0) ? Q.x + eps_off_n : nullptr;
