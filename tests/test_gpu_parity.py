@@ -354,6 +354,26 @@ def test_pivoting_fallback_of_the_factorisation(name, monkeypatch):
     assert not np.array_equal(sol[0][1], sol[1][1])          # (a different elimination did the work: not the same bits)
 
 
+def test_register_elimination_of_several_finite_elements_equals_the_pivoting_one(monkeypatch):
+    """batch_reactor (two finite elements per interval, 24 unknowns): the collocation block is eliminated in registers in the natural pivot
+    order (round 6); -DDOMPC_REG_GJ=0 builds the in-LDS elimination with partial pivoting it replaces, -DDOMPC_GJ_U=1e9 makes the threshold test
+    of the new one fail on every edge (its fallback IS the pivoting one).  Same iterations, same solution to rounding, other bits."""
+    ex = CASES["batch_reactor"]
+    sol = []
+    for defs in ("", "DOMPC_REG_GJ=0", "DOMPC_GJ_U=1e9"):
+        monkeypatch.setenv("DOMPC_DEFS", defs)
+        mpc = make_mpc("batch_reactor")
+        mpc.x0 = ex.X0
+        mpc.set_initial_guess()
+        mpc.make_step(ex.X0)
+        assert mpc.solver_stats["success"]
+        sol.append((mpc.solver_stats["iter_count"], mpc.opt_x_num.master.copy(), mpc.lam_g_num.copy()))
+    assert sol[0][0] == sol[1][0] == sol[2][0]
+    assert pc.relerr(sol[0][1], sol[1][1]) < 1e-9 and pc.relerr(sol[0][2], sol[1][2]) < 1e-7
+    assert not np.array_equal(sol[0][1], sol[1][1])          # (a different elimination did the work: not the same bits)
+    assert np.array_equal(sol[1][1], sol[2][1])              # (the fallback of the new one is the old one)
+
+
 @pytest.mark.parametrize("name,over,x0", pc.NL_COLLOC_CASES, ids=[c[0] for c in pc.NL_COLLOC_CASES])
 def test_nl_cons_at_collocation_points(name, over, x0):
     pc.check_nl_cons_at_collocation_points(make_mpc, name, over, x0)
