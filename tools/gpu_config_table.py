@@ -74,11 +74,15 @@ def run(label, name, kw, Bs, out):
             e1.record(stream)
             torch.cuda.synchronize()
             st = np.frombuffer(tStats.cpu().numpy().tobytes(), dtype=STATS_DTYPE)
+            step.sweeps = float(st["n_sweeps"].sum())
             return e0.elapsed_time(e1), int(st["success"].sum()), float(st["iter_count"].mean())
 
         step(tXi)                                   # untimed: code object load, clocks
         ms, ok, it = step(tXi)
-        row = {"config": label, "B": B, "cold_ms": ms, "cold_steps_s": B / ms * 1e3, "cold_ok": ok, "cold_iters": it}
+        # roofline fraction of the cold launch (review r5: per config): algorithmic bytes of the model-evaluation sweeps (SURVEY 8(d) formula,
+        # bench.sweep_bytes_per_problem) x the sweeps the launch executed / kernel time / 8 TB/s
+        frac = bench.sweep_bytes_per_problem(ps) * step.sweeps / (ms * 1e-3) / 8e12
+        row = {"config": label, "B": B, "cold_ms": ms, "cold_steps_s": B / ms * 1e3, "cold_ok": ok, "cold_iters": it, "cold_frac": frac}
         wms, wok, wit = [], [], []
         guess = torch.empty_like(tX)
         for _ in range(4):
@@ -122,7 +126,7 @@ def run_mhe(Bs, out):
         tX = torch.empty((B, ps.n_opt_x), dtype=torch.float64, device=dev)
         tF = torch.empty(B, dtype=torch.float64, device=dev)
         tStats = torch.zeros(B * STATS_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        row = {"config": "MHE rotating masses N=10, 1 estimated parameter", "B": B}
+        row = {"config": "MHE rotating masses N=10, 1 estimated parameter", "B": B, "cold_frac": float("nan")}
         for kind, guess in guesses.items():
             for rep in range(2):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -148,11 +152,11 @@ def main():
         if only and only not in label: continue
         run(label, name, kw, Bs, rows)
     run_mhe([b for b in Bs if b <= 4096], rows)
-    lines = ["| config | B | cold ms | cold steps/s | cold conv. | cold iters | warm ms | warm steps/s | warm conv. | warm iters |",
-             "|---|---|---|---|---|---|---|---|---|---|"]
+    lines = ["| config | B | cold ms | cold steps/s | cold conv. | cold iters | cold roofline frac | warm ms | warm steps/s | warm conv. | warm iters |",
+             "|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
         lines.append(f"| {r['config']} | {r['B']} | {r['cold_ms']:.2f} | {r['cold_steps_s']:.0f} | {r['cold_ok']}/{r['B']} | "
-                     f"{r['cold_iters']:.1f} | {r['warm_ms']:.2f} | {r['warm_steps_s']:.0f} | {r['warm_ok']}/{r['B']} | {r['warm_iters']:.1f} |")
+                     f"{r['cold_iters']:.1f} | {('%.4f' % r['cold_frac']) if r['cold_frac'] == r['cold_frac'] else '-'} | {r['warm_ms']:.2f} | {r['warm_steps_s']:.0f} | {r['warm_ok']}/{r['B']} | {r['warm_iters']:.1f} |")
     txt = "\n".join(lines) + "\n"
     print(txt)
     if path:
