@@ -687,6 +687,7 @@ class MPC:
             sp=self._p_scaling.master,
             rterm_expr=(self.rterm_expr.nodes()[0] if self.rterm_expr is not None else None),
             uprev_sym=self.u_prev.cat.nodes(), nl_colloc=self._nl_colloc, eps_global=ps.eps_global,
+            extras=getattr(self, "_nlp_extras", None),
             **{k: v for k, v in (getattr(self, "_estimator_opts", None) or {}).items()
                if k in ("arrival", "xprev_sym", "lterm_end", "nl_dup")})
 

@@ -120,10 +120,10 @@ DOMPC_DEV inline void dae_eval_item(const Prob& Q, int kind, int e, int j) {
     double* pt = mo + MO_PT + j * PT_STRIDE;
     dompc_dyn(xp, un, zb + j * NZ, tvp, pp, lamv, pt, pt + NF, pt + NF + NF * NAV);
   } else if (kind == 1) {
-    dompc_lterm(LT_END ? w + (M - 1) * NX : xn, un, zb + (MZ - 1) * NZ, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NAV);
+    lterm_e(Q, e, LT_END ? w + (M - 1) * NX : xn, un, zb + (MZ - 1) * NZ, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NAV);
   } else if (kind == 2) {
     if (k == A.N - 1)
-      dompc_mterm(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1, mo + MO_MT + 1 + NX);
+      mterm_e(Q, e, Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1, mo + MO_MT + 1 + NX);
   } else if (NE > 0) {
     for (int blk = 0; blk < NLB; ++blk) {
       double* o = mo + MO_NL + blk * NL_STRIDE;
@@ -182,8 +182,8 @@ DOMPC_DEV inline double dae_edge_f(const Prob& Q, int e, const double* xv, const
     }
     for (int a = 0; a < NX; ++a) cv[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
   }
-  double obj = om * dompc_lterm_f(LT_END ? w + (M - 1) * NX : xn, un, zb + (MZ - 1) * NZ, tvp, pp);
-  if (k == A.N - 1) obj += om * dompc_mterm_f(xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
+  double obj = om * lterm_f_e(Q, e, LT_END ? w + (M - 1) * NX : xn, un, zb + (MZ - 1) * NZ, tvp, pp);
+  if (k == A.N - 1) obj += om * mterm_f_e(Q, e, xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
   if (RT_CUSTOM) obj += edge_rterm_f(Q, e, xv);
   if (NE > 0) {
     double d[NE1];

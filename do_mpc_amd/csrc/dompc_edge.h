@@ -70,8 +70,8 @@ DOMPC_DEV inline double eval_edge_f_t(const Prob& Q, int e, const double* xv, co
 #pragma unroll
     for (int a = 0; a < NX; ++a) cv[row0 + NW + a] = rl[a];
   }
-  double obj = om * dompc_lterm_f(xn, un, nullptr, tvp, pp);
-  if (k == A.N - 1) obj += om * dompc_mterm_f(xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
+  double obj = om * lterm_f_e(Q, e, xn, un, nullptr, tvp, pp);
+  if (k == A.N - 1) obj += om * mterm_f_e(Q, e, xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
   if (RT_CUSTOM) obj += edge_rterm_f(Q, e, xv);
   if (NE > 0) {
     double d[NE1];
@@ -401,8 +401,16 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
         dyn_c_noalias(w + slot_of(0, jj) * NX, un, tvp, pp, Q.lam + row0 + (jj - 1) * NX, mo + j * DOMPC_DYN_NV);
       } else if (kind == 1) {
         lterm_c_noalias(xn, un, tvp, pp, mo + MOC_LT);
+#if DOMPC_XTRA
+        dompc_xtra_lt_c(DOMPC_XTRA_LT_ID[e], xn, un, Q.P, mo + MOC_LT);
+#endif
       } else if (kind == 2) {
-        if (k == A.N - 1) mterm_c_noalias(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MOC_MT);
+        if (k == A.N - 1) {
+          mterm_c_noalias(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MOC_MT);
+#if DOMPC_XTRA
+          dompc_xtra_mt_c(DOMPC_XTRA_MT_ID[e], Q.x + A.node_x_off[cn], Q.P, mo + MOC_MT);
+#endif
+        }
       } else if (NE > 0) {
         double yds[NE1];      // (scaled rows sg d(x): the Hessian sum_i lambda_i sg_i hess d_i)
         for (int i = 0; i < NE; ++i) yds[i] = Q.lam[row0 + NW + NX + i] * Q.sgn[e * NE1 + i];
@@ -418,10 +426,10 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
                   pt, pt + NX, pt + NX + NX * NA);
       }
     } else if (kind == 1) {
-      dompc_lterm(xn, un, nullptr, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NA);
+      lterm_e(Q, e, xn, un, nullptr, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NA);
     } else if (kind == 2) {
       if (k == A.N - 1)
-        dompc_mterm(Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1,
+        mterm_e(Q, e, Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1,
                     mo + MO_MT + 1 + NX);
     } else if (NE > 0) {
       double yds[NE1];

@@ -875,6 +875,46 @@ DOMPC_DEV inline double sigma_of(double x, double l, double u, double zl, double
 DOMPC_DEV inline double edge_rterm_f(const Prob& Q, int e, const double* xv);      // (user-defined rterm, defined below)
 DOMPC_DEV inline void edge_rterm_eval(const Prob& Q, int e, ldsd* dst);
 DOMPC_DEV inline void edge_rterm_store(const ldsd* src, double* S_, int lane, int GS);
+// Node-local cost terms added to `nlp_obj` on the route prepare_nlp -> modify -> create_nlp (optimizer.py:82-129; do_mpc_amd/nlp_route.py
+// ObjectiveExtras, lowering.py `extras`): the generated header then defines DOMPC_XTRA, the switch-dispatched functions dompc_xtra_lt /
+// dompc_xtra_mt (value-only `_f`, compact `_c`, dense) and the tables edge -> function index.  They ADD to the stage-cost record of the
+// node's first outgoing edge / to the terminal-cost record of a leaf's incoming edge (already divided by the edge's omega), so every
+// consumer of those records - condensing, gradient, objective value, objective scaling - sees them without knowing.  P: the whole opt_p.
+#ifndef DOMPC_XTRA
+#define DOMPC_XTRA 0
+#endif
+DOMPC_DEV inline double lterm_f_e(const Prob& Q, int e, const double* xs, const double* us, const double* zs, const double* tvp, const double* pp) {
+  double v = dompc_lterm_f(xs, us, zs, tvp, pp);
+#if DOMPC_XTRA
+  v += dompc_xtra_lt_f(DOMPC_XTRA_LT_ID[e], xs, us, Q.P);
+#endif
+  (void)e; (void)Q;
+  return v;
+}
+DOMPC_DEV inline double mterm_f_e(const Prob& Q, int e, const double* xs, const double* tvp, const double* pp) {
+  double v = dompc_mterm_f(xs, tvp, pp);
+#if DOMPC_XTRA
+  v += dompc_xtra_mt_f(DOMPC_XTRA_MT_ID[e], xs, Q.P);
+#endif
+  (void)e; (void)Q;
+  return v;
+}
+DOMPC_DEV inline void lterm_e(const Prob& Q, int e, const double* xs, const double* us, const double* zs, const double* tvp, const double* pp,
+                              double* val, double* g, double* H) {
+  dompc_lterm(xs, us, zs, tvp, pp, val, g, H);
+#if DOMPC_XTRA
+  dompc_xtra_lt(DOMPC_XTRA_LT_ID[e], xs, us, Q.P, val, g, H);
+#endif
+  (void)e; (void)Q;
+}
+DOMPC_DEV inline void mterm_e(const Prob& Q, int e, const double* xs, const double* tvp, const double* pp, double* val, double* g, double* H) {
+  dompc_mterm(xs, tvp, pp, val, g, H);
+#if DOMPC_XTRA
+  dompc_xtra_mt(DOMPC_XTRA_MT_ID[e], xs, Q.P, val, g, H);
+#endif
+  (void)e; (void)Q;
+}
+
 #include "dompc_dae.h"       // edge phases of models with algebraic states (dense path)
 
 #include "dompc_edge.h"

@@ -47,7 +47,7 @@ def _sym_hessian_upper(L: sym.Node, v: List[sym.Node]):
 def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, mterm, nl_exprs,
                 nl_slack_index, eps_penalty, sx, su, rterm, h_scale, deg, ni, discrete, C, D,
                 name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None, rterm_expr=None, uprev_sym=(), nl_colloc=False,
-                arrival=None, xprev_sym=(), lterm_end=False, nl_dup=False, eps_global=False) -> str:
+                arrival=None, xprev_sym=(), lterm_end=False, nl_dup=False, eps_global=False, extras=None) -> str:
     """Return the text of the generated header.
 
     x_sym/u_sym/z_sym/tvp_sym/p_sym: lists of sym.Node (the model's own symbols, unscaled).
@@ -65,6 +65,11 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     cost reads the END state of the interval instead of its first one (_mhe.py:1146-1147, 1190-1192: the measurement
     residual of stage k lives at `_x[k+1, -1]`); nl_dup: the nl_cons rows of the last evaluated point are repeated
     (_mhe.py:1186-1188).
+
+    extras (nlp_route.ObjectiveExtras; the route prepare_nlp -> `nlp_obj += ...` -> create_nlp, optimizer.py:82-129): node-local cost
+    terms in the canonical symbols extras.cx / cu / cP.  One device function per distinct term, switch-dispatched by the index the
+    tables DOMPC_XTRA_LT_ID / DOMPC_XTRA_MT_ID give for an edge; the functions ADD to the edge's stage-cost / terminal-cost record
+    (value, gradient, packed Hessian), whose touched entries are forced into the variable part of the compact record.
 
     Point functions take the stage variables as v = (x (nx), u (nu), z (nz)): for a model without algebraic states
     that is the (x, u) of the optimised kernels, with them the algebraic block is appended (dense DAE path of the kernels).
@@ -137,15 +142,15 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     parts: List[str] = []
     tables: List[str] = []
 
-    def compact(tag: str, sig: str, dense_outs):
+    def compact(tag: str, sig: str, dense_outs, force=()):
         """Compact twin of a derivative function.  `dense_outs` = [(index inside the function's dense output block, node)]:
         the entries that depend on the inputs are written one after the other into `o` (DOMPC_<tag>_NV values, dense index
         of entry k in DOMPC_<tag>_VIDX[k]); the others are compile-time constants of the model - zeros by structure, weights
         of a quadratic cost - and are listed once (DOMPC_<tag>_CIDX / _CVAL, non-zero ones only).  The kernels keep a dense
         image of the record in LDS, initialised with the constants once per phase, and move only the variable entries
         through HBM (csrc/dompc_kernel.h: MO_COMPACT) - for industrial_poly 82 of the 231 entries of a collocation point."""
-        var = [(i, n) for i, n in dense_outs if n.op != "const"]
-        cst = [(i, n.val) for i, n in dense_outs if n.op == "const" and n.val != 0.0]
+        var = [(i, n) for i, n in dense_outs if n.op != "const" or i in force]
+        cst = [(i, n.val) for i, n in dense_outs if n.op == "const" and n.val != 0.0 and i not in force]
         body = sym.emit_c([(f"o[{k}]", n) for k, (_, n) in enumerate(var)], binds, indent="  ")
         parts.append(f"DOMPC_FN {sig} {{\n{body}\n}}\n")
         tables.append(f"#define DOMPC_{tag}_NV {len(var)}")
@@ -153,6 +158,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         tables.append(_fmt_array(f"DOMPC_{tag}_VIDX", [i for i, _ in var], "int"))
         tables.append(_fmt_array(f"DOMPC_{tag}_CIDX", [i for i, _ in cst], "int"))
         tables.append(_fmt_array(f"DOMPC_{tag}_CVAL", [v for _, v in cst]))
+        return {i: k for k, (i, _) in enumerate(var)}
 
     def packed(H, n):
         return [H[i][j] for i in range(n) for j in range(i, n)]
@@ -168,6 +174,25 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     compact("DYN", f"void dompc_dyn_c({sig_dyn_args}, const double* lam, double* o)",
             list(enumerate(list(f) + [Jf[i][j] for i in range(nf) for j in range(nav)] + packed(Hf, nav))))
 
+    # node-local cost terms added to nlp_obj: dense output blocks (value | gradient | packed Hessian) in the layout of the record they join
+    xtra = {"lt": [], "mt": []}
+    xtra_ids = None
+    if extras is not None and extras.groups:
+        Pq = {j: sym.symbol(f"Pq{j}") for j in extras.cP}
+        binds.update({Pq[j].idx: f"P[{j}]" for j in Pq})
+        mp_x = {c.idx: xs[i] for i, c in enumerate(extras.cx)}
+        mp_x.update({c.idx: us[i] for i, c in enumerate(extras.cu)})
+        mp_x.update({c.idx: Pq[j] for j, c in extras.cP.items()})
+        tabs = extras.tables()
+        xtra_ids = {k: tabs[k][1] for k in ("lt", "mt")}
+        for kind, vv, n_ in (("lt", v, nav), ("mt", xs, nx)):
+            for ex in sym.substitute_nodes(tabs[kind][0], mp_x):
+                if kind == "mt" and sym.depends_on([ex], us):
+                    raise Exception("a cost term at a terminal node depends on an input")
+                gx, Hx = _sym_hessian_upper(ex, vv)
+                xtra[kind].append([ex] + list(gx[:n_]) + packed(Hx, n_))
+    force = {k: {i for blk in xtra[k] for i, n_ in enumerate(blk) if not (n_.op == "const" and n_.val == 0.0)} for k in xtra}
+
     # stage cost (unweighted; omega applied by the kernel)
     lt = scaled([lterm])[0]
     gl, Hl = _sym_hessian_upper(lt, v)
@@ -175,7 +200,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         "\n}\n", "\n  return val;\n}\n"))
     outs = [("val[0]", lt)] + [(f"g[{i}]", gl[i]) for i in range(nav)] + hess_outs(Hl, nav)
     parts.append(emit_fn(f"void dompc_lterm({sig_dyn_args}, double* val, double* g, double* H)", outs))
-    compact("LT", f"void dompc_lterm_c({sig_dyn_args}, double* o)", list(enumerate([lt] + list(gl[:nav]) + packed(Hl, nav))))
+    pos_lt = compact("LT", f"void dompc_lterm_c({sig_dyn_args}, double* o)", list(enumerate([lt] + list(gl[:nav]) + packed(Hl, nav))), force["lt"])
 
     mt = scaled([mterm])[0]
     if sym.depends_on([mt], us + zs):
@@ -186,7 +211,29 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         "\n}\n", "\n  return val;\n}\n"))
     outs = [("val[0]", mt)] + [(f"g[{i}]", gm[i]) for i in range(nx)] + hess_outs(Hm, nx)
     parts.append(emit_fn(f"void dompc_mterm({sig_m}, double* val, double* g, double* H)", outs))
-    compact("MT", f"void dompc_mterm_c({sig_m}, double* o)", list(enumerate([mt] + list(gm[:nx]) + packed(Hm, nx))))
+    pos_mt = compact("MT", f"void dompc_mterm_c({sig_m}, double* o)", list(enumerate([mt] + list(gm[:nx]) + packed(Hm, nx))), force["mt"])
+    if xtra_ids is not None:
+        # switch-dispatched additions: _f value only (trial points of the line search); _c into the compact record; plain into the dense one
+        def dispatch(sig, bodies, ret=""):
+            cases = "".join(f"    case {q + 1}: {{\n{b}\n      break;\n    }}\n" for q, b in enumerate(bodies))
+            return f"DOMPC_FN {sig} {{\n  switch (id) {{\n{cases}    default: break;\n  }}\n{ret}}}\n"
+        for kind, pos, n_, args in (("lt", pos_lt, nav, "const double* xs, const double* us, const double* P"),
+                                    ("mt", pos_mt, nx, "const double* xs, const double* P")):
+            blks = xtra[kind]
+            parts.append(dispatch(f"double dompc_xtra_{kind}_f(int id, {args})",
+                                  [sym.emit_c([("val", b[0])], binds, indent="      ", accumulate=True) for b in blks],
+                                  "  return val;\n").replace(") {\n  switch", ") {\n  double val = 0.0;\n  switch", 1))
+            parts.append(dispatch(f"void dompc_xtra_{kind}_c(int id, {args}, double* o)",
+                                  [sym.emit_c([(f"o[{pos[i]}]", n2) for i, n2 in enumerate(b) if i in pos], binds, indent="      ", skip_zero=True, accumulate=True)
+                                   for b in blks]))
+            def dense_lv(i):
+                return "val[0]" if i == 0 else (f"g[{i - 1}]" if i <= n_ else f"H[{i - 1 - n_}]")
+            parts.append(dispatch(f"void dompc_xtra_{kind}(int id, {args}, double* val, double* g, double* H)",
+                                  [sym.emit_c([(dense_lv(i), n2) for i, n2 in enumerate(b)], binds, indent="      ", skip_zero=True, accumulate=True)
+                                   for b in blks]))
+        tables.append("#define DOMPC_XTRA 1      // node-local cost terms added to nlp_obj (dompc_xtra_lt / dompc_xtra_mt, edge -> function tables below)")
+        tables.append(_fmt_array("DOMPC_XTRA_LT_ID", xtra_ids["lt"], "int"))
+        tables.append(_fmt_array("DOMPC_XTRA_MT_ID", xtra_ids["mt"], "int"))
 
     # nonlinear constraints (the "- eps" part is linear and handled by the kernel)
     if ne:

@@ -133,6 +133,124 @@ def classify(mpc, expr) -> dict:
             "constant": not ix}
 
 
+def split_additive(node, scale: float = 1.0):
+    """[(factor, addend)] with  node = sum factor * addend:  the sum / difference / negation / constant-multiple structure at the top of an
+    expression is taken apart, everything below stays one addend."""
+    if node.op == "add":
+        return split_additive(node.a, scale) + split_additive(node.b, scale)
+    if node.op == "sub":
+        return split_additive(node.a, scale) + split_additive(node.b, -scale)
+    if node.op == "neg":
+        return split_additive(node.a, -scale)
+    if node.op == "mul" and node.a.op == "const":
+        return split_additive(node.b, scale * node.a.val)
+    if node.op == "mul" and node.b.op == "const":
+        return split_additive(node.a, scale * node.b.val)
+    if node.op == "div" and node.b.op == "const":
+        return split_additive(node.a, scale / node.b.val)
+    return [(scale, node)]
+
+
+class ObjectiveExtras:
+    """Node-local cost terms added to `nlp_obj` (optimizer.py:82-129), grouped by the tree node they belong to and rewritten in the
+    canonical symbols of a device function: a term in the state `_x[k, s, -1]` / the input `_u[k, s]` of ONE node (and opt_p) joins
+
+    * the stage-cost record of the node's FIRST outgoing edge (that edge's record is evaluated at exactly (x_k^s, u_k^s), csrc/dompc_edge.h
+      eval_models kind 1) - nodes of stages 0 .. N-1;
+    * the terminal-cost record of the leaf's incoming edge (kind 2) - nodes of stage N.
+
+    The kernels weight both records with the edge's omega (_mpc.py:1259-1261); an added term has no such weight in the reference, so it is
+    divided by omega here.  lowering.lower_model generates one function per DISTINCT term (hash-consed: the same expression at several
+    nodes is one function) and an edge -> function table."""
+
+    def __init__(self, mpc):
+        self.mpc = mpc
+        ps = mpc.structure
+        self.cx = [sym.symbol("xtra_xs%d" % i) for i in range(ps.nx)]
+        self.cu = [sym.symbol("xtra_us%d" % i) for i in range(ps.nu)]
+        self.cP = {}
+        self.groups = {}            # (kind, edge) -> Node (filled by tables())
+        self._parts = {}            # (kind, edge) -> {addend idx: [factor, addend in canonical symbols]}
+        self.const_terms = []
+        self._dummy = set(int(g) for g in ps.tables["dummy_idx"])
+
+    def add(self, atom, scale):
+        """returns None (accepted) or the reason for a refusal"""
+        mpc, ps = self.mpc, self.mpc.structure
+        T = ps.tables
+        ox, op = mpc.opt_x, mpc.opt_p
+        free = sym.free_symbols([atom])
+        sx_ = [(ox.index_of[id(n)], n) for n in free if id(n) in ox.index_of]
+        sp_ = [(op.index_of[id(n)], n) for n in free if id(n) in op.index_of]
+        if not sx_:
+            self.const_terms.append(sym.SX([sym.mul(sym.const(scale), atom)], (1, 1)))
+            return None
+        ix = sorted(g for g, _ in sx_)
+        c = classify(mpc, sym.SX([atom], (1, 1)))
+        if any(g in self._dummy for g in ix):
+            return ("it depends on unused entries of the reference's opt_x (%s): no node of the scenario tree owns them"
+                    % describe_variables(mpc, [g for g in ix if g in self._dummy]))
+        if c["interval_unknowns"]:
+            return ("the addend over (%s) depends on collocation / algebraic / slack unknowns of an interval, which are eliminated inside "
+                    "the interval's own constraint block; a cost on them would need a gradient / Hessian share in that block - only "
+                    "the node state `_x[k, s, -1]` and the node's input `_u[k, s]` can carry added cost terms" % describe_variables(mpc, ix))
+        if len(c["nodes"]) > 1:
+            return ("one addend couples %d nodes of the scenario tree (%s): the Riccati recursion eliminates one node at a time"
+                    % (len(c["nodes"]), describe_variables(mpc, ix)))
+        if ps.open_loop_stack or ps.eps_global:
+            return "added cost terms are not lowered for open_loop with several scenarios / nl_cons_single_slack"
+        k, s = c["nodes"][0]
+        n = int(T["level_node_start"][k]) + s
+        if k == ps.N:
+            kind, e = "mt", int(T["node_in_edge"][n])
+        else:
+            kind, e = "lt", int(T["node_child_start"][n])
+        x0, u0 = int(T["node_x_off"][n]), int(T["node_u_off"][n])
+        mapping = {}
+        for g, nd in sx_:
+            if x0 <= g < x0 + ps.nx:
+                mapping[nd.idx] = self.cx[g - x0]
+            else:
+                assert u0 >= 0 and u0 <= g < u0 + ps.nu, (g, x0, u0)
+                mapping[nd.idx] = self.cu[g - u0]
+        for j, nd in sp_:
+            if j not in self.cP:
+                self.cP[j] = sym.symbol("xtra_P%d" % j)
+            mapping[nd.idx] = self.cP[j]
+        # addends of a node are collected with their factors and summed in a canonical order (tables): the same terms at two nodes
+        # become the same expression node - one device function - in whatever order the user added them
+        can = sym.substitute_nodes([atom], mapping)[0]
+        slot = self._parts.setdefault((kind, e), {}).setdefault(can.idx, [0.0, can])
+        slot[0] += scale / float(T["edge_omega"][e])
+        self.groups[(kind, e)] = None
+        return None
+
+    def _sum(self, key):
+        total = None
+        for coef, can in sorted(self._parts[key].values(), key=lambda cv: (cv[1].skey, cv[1].idx)):
+            term = sym.mul(sym.const(coef), can)
+            total = term if total is None else sym.add(total, term)
+        return total
+
+    def tables(self):
+        """(lt_exprs, mt_exprs, lt_id[E], mt_id[E]): distinct expressions per kind and the 1-based function index of every edge (0: none)"""
+        E = self.mpc.structure.n_edges
+        out = {}
+        for key in self._parts:
+            self.groups[key] = self._sum(key)
+        for kind in ("lt", "mt"):
+            exprs, ids, seen = [], np.zeros(E, np.int32), {}
+            for (kd, e), nd in sorted(self.groups.items(), key=lambda kv: kv[0][1]):
+                if kd != kind:
+                    continue
+                if nd.idx not in seen:
+                    exprs.append(nd)
+                    seen[nd.idx] = len(exprs)
+                ids[e] = seen[nd.idx]
+            out[kind] = (exprs, ids)
+        return out
+
+
 def check_additions(mpc) -> None:
     """create_nlp(): everything the user added after prepare_nlp() is classified; the structured backend refuses what it cannot lower."""
     obj, cons, lbs, ubs = mpc._nlp_obj, mpc._nlp_cons, mpc._nlp_cons_lb, mpc._nlp_cons_ub
@@ -157,33 +275,47 @@ def check_additions(mpc) -> None:
     if base_lb.size != mpc.structure.n_g or base_ub.size != mpc.structure.n_g:
         raise ValueError("the bounds of the structured constraint block must keep their %d entries" % mpc.structure.n_g)
     problems = []
-    for what, items in (("nlp_obj term", obj.terms), ("nlp_cons block", cons[1:])):
-        for j, ex in enumerate(items):
-            c = classify(mpc, ex)
-            if c["foreign"]:
-                raise ValueError("%s %d uses symbols that belong neither to mpc.opt_x nor to mpc.opt_p: %s"
-                                 % (what, j, ", ".join(repr(n) for n in c["foreign"][:4])))
-            if c["constant"] and what == "nlp_obj term":
-                continue        # a term in opt_p only shifts the objective: no effect on the solution (the reported f excludes it)
-            why = []
-            if len(c["nodes"]) > 1:
-                why.append("it couples %d nodes of the scenario tree (%s): the Riccati recursion eliminates one node at a time"
-                           % (len(c["nodes"]), describe_variables(mpc, c["opt_x"])))
-            if c["interval_unknowns"]:
-                why.append("it depends on collocation / algebraic / slack unknowns of an interval (%s), which are eliminated "
-                           "inside the interval's own constraint block" % describe_variables(mpc, c["opt_x"]))
-            if not why:
-                k, s = c["nodes"][0] if c["nodes"] else (None, None)
-                why.append("a node-specific %s at %s would need its own lowered device function for that node; the structured "
-                           "lowering generates ONE function per kind (stage cost, terminal cost, nl_cons) for all nodes - express it "
-                           "through set_objective / set_nl_cons / bounds (a time-varying weight in `_tvp` selects a stage)"
-                           % ("cost term" if what == "nlp_obj term" else "constraint", describe_variables(mpc, c["opt_x"]) or "opt_p"))
-            problems.append("%s %d (%d row%s): %s" % (what, j, c["rows"], "" if c["rows"] == 1 else "s", "; ".join(why)))
+    extras = ObjectiveExtras(mpc)
+    for j, ex in enumerate(obj.terms):
+        # the objective is a SUM: every addend of an added expression is classified on its own (the reference's example
+        # `sum1(vertcat(*opt_x['_x', -1, 0]) ** 2)`, optimizer.py:91-97, is one expression over several vectors)
+        exs = sym._sx(ex)
+        if exs.numel() != 1:
+            raise ValueError("nlp_obj term %d is not a scalar expression (shape %s)" % (j, exs.shape))
+        c = classify(mpc, exs)
+        if c["foreign"]:
+            raise ValueError("nlp_obj term %d uses symbols that belong neither to mpc.opt_x nor to mpc.opt_p: %s"
+                             % (j, ", ".join(repr(n) for n in c["foreign"][:4])))
+        for scale, atom in split_additive(exs.nodes()[0]):
+            why = extras.add(atom, scale)
+            if why:
+                problems.append("nlp_obj term %d: %s" % (j, why))
+    for j, ex in enumerate(cons[1:]):
+        what = "nlp_cons block"
+        c = classify(mpc, ex)
+        if c["foreign"]:
+            raise ValueError("%s %d uses symbols that belong neither to mpc.opt_x nor to mpc.opt_p: %s"
+                             % (what, j, ", ".join(repr(n) for n in c["foreign"][:4])))
+        why = []
+        if len(c["nodes"]) > 1:
+            why.append("it couples %d nodes of the scenario tree (%s): the Riccati recursion eliminates one node at a time"
+                       % (len(c["nodes"]), describe_variables(mpc, c["opt_x"])))
+        if c["interval_unknowns"]:
+            why.append("it depends on collocation / algebraic / slack unknowns of an interval (%s), which are eliminated "
+                       "inside the interval's own constraint block" % describe_variables(mpc, c["opt_x"]))
+        if not why:
+            why.append("a node-specific constraint at %s would need its own row slot in that node's edge block; the structured "
+                       "lowering gives every edge the SAME rows (the nl_cons rows) - express it through set_nl_cons / bounds "
+                       "(a time-varying bound or weight in `_tvp` selects a stage)"
+                       % (describe_variables(mpc, c["opt_x"]) or "opt_p"))
+        problems.append("%s %d (%d row%s): %s" % (what, j, c["rows"], "" if c["rows"] == 1 else "s", "; ".join(why)))
     if problems:
         raise NotImplementedError("structured HIP backend: the NLP was modified after prepare_nlp() in a way that is no longer "
                                   "stage-structured -\n  " + "\n  ".join(problems) +
                                   "\n(the reference hands such an NLP to CasADi/IPOPT as one sparse problem, "
                                   "/root/reference/do_mpc/optimizer.py:1050-1094; this backend has no general sparse fallback)")
-    # accepted: constant objective terms (functions of opt_p only).  They are kept for inspection; the objective value this backend reports
-    # is the structured objective WITHOUT them (u0 and every other solution quantity are unaffected)
-    mpc._nlp_obj_const_terms = [sym._sx(t) for t in obj.terms]
+    # accepted: (a) constant objective terms (functions of opt_p only) - kept for inspection; the objective value this backend reports is
+    # the structured objective WITHOUT them (u0 and every other solution quantity are unaffected); (b) node-local cost terms - lowered
+    # into per-node device functions by lowering.lower_model (`extras`)
+    mpc._nlp_obj_const_terms = extras.const_terms
+    mpc._nlp_extras = extras if extras.groups else None

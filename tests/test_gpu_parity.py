@@ -99,6 +99,16 @@ def test_same_iterates_as_the_oracle(name, opts):
     assert mpc.solver_stats["n_reg"] == mpc.solver_stats["iter_count"]
 
 
+@pytest.mark.parametrize("name,which", [("oscillating_masses", "docstring"), ("oscillating_masses", "tree"), ("industrial_poly", "tree"),
+                                        ("CSTR", "tree"), ("batch_reactor", "tree"), ("oscillating_masses_dae", "tree"),
+                                        ("rotating_masses", "tree")])
+def test_cost_terms_added_to_nlp_obj_same_iterates_as_the_oracle(name, which):
+    """optimizer.py:82-129: `nlp_obj += ...` between prepare_nlp() and create_nlp() - node-local terms (the docstring's own example among
+    them) lowered into per-node device functions; every edge path (four edges per wavefront, nl_cons rows, several finite elements,
+    dense / DAE, discrete) against an oracle solve of the same extended NLP"""
+    pc.check_added_cost_terms(make_mpc, lambda mpc: mpc.create_nlp(), name, which)
+
+
 @pytest.mark.parametrize("name,over", [("batch_reactor", dict(n_horizon=7)), ("CSTR", dict(n_horizon=5, n_robust=0))])
 def test_odd_number_of_edges_same_iterates_as_the_oracle(name, over):
     """The forward pass takes two edges per wavefront: with an odd number of edges the second half of the last pair repeats an edge and

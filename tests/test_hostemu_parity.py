@@ -50,6 +50,19 @@ def test_same_iterates_as_the_oracle(name, opts):
     assert mpc.solver_stats["n_reg"] == mpc.solver_stats["iter_count"]
 
 
+def _create_nlp(mpc):
+    with hostemu.patched():
+        mpc.create_nlp()
+
+
+@pytest.mark.parametrize("name,which", [("oscillating_masses", "docstring"), ("oscillating_masses", "tree"), ("industrial_poly", "tree"),
+                                        ("CSTR", "tree"), ("batch_reactor", "tree"), ("oscillating_masses_dae", "tree"),
+                                        ("rotating_masses", "tree")])
+def test_cost_terms_added_to_nlp_obj_same_iterates_as_the_oracle(name, which):
+    """optimizer.py:82-129: `nlp_obj += ...` between prepare_nlp() and create_nlp(), node-local terms (the docstring's own example among them)"""
+    pc.check_added_cost_terms(make_mpc, _create_nlp, name, which)
+
+
 @pytest.mark.parametrize("name,over", pc.NONCONVEX_CASES)
 def test_nonconvex_examples_reach_the_oracles_local_solution(name, over):
     """Second-order correction + inertia correction: same local minimum as the IPOPT-default oracle with exact inertia."""

@@ -80,14 +80,26 @@ def test_unmodified_route_equals_setup():
     assert np.array_equal(ua, ub)
 
 
-def test_the_reference_docstring_examples_are_refused_by_name():
-    """optimizer.py:91-97 (terminal cost on the stored points of the last interval) and optimizer.py:131-146 (u_0 = u_1)"""
+def test_the_reference_docstring_examples():
+    """optimizer.py:91-97 (terminal cost): accepted and lowered - equality with an oracle solve of the extended NLP is
+    test_hostemu_parity / test_gpu_parity::test_cost_terms_added_to_nlp_obj_same_iterates_as_the_oracle; optimizer.py:131-146 (u_0 = u_1):
+    couples two nodes, refused by name"""
     mpc = _mpc()
     mpc.prepare_nlp()
     mpc.nlp_obj += sum1(vertcat(*mpc.opt_x["_x", -1, 0]) ** 2)
-    with hostemu.patched(), pytest.raises(NotImplementedError, match=r"nlp_obj term 0 .*_x\[7,0,-1\]"):
+    with hostemu.patched():
         mpc.create_nlp()
-    assert not mpc.flags["setup"]
+    assert mpc.flags["setup"] and "#define DOMPC_XTRA 1" in mpc.generated_header
+    ps = mpc.structure
+    ids = [int(v) for v in mpc.generated_header.split("DOMPC_XTRA_MT_ID[%d] = {" % ps.n_edges)[1].split("}")[0].split(",")]
+    assert ids == [0] * (ps.n_edges - 1) + [1]          # the terminal-cost record of the last edge (scenario 0 is the only leaf)
+    plain = _mpc(setup_now=True)
+    for m in (mpc, plain):
+        m.x0 = osc.X0
+        m.set_initial_guess()
+        m.make_step(osc.X0)
+    xN = mpc.opt_x_num["_x", -1, 0, -1]
+    assert np.sum(np.square(xN)) < np.sum(np.square(plain.opt_x_num["_x", -1, 0, -1]))      # the terminal state is pulled towards 0
 
     mpc = _mpc()
     mpc.prepare_nlp()
@@ -96,6 +108,26 @@ def test_the_reference_docstring_examples_are_refused_by_name():
     mpc.nlp_cons_lb.append(np.zeros(extra.shape))
     mpc.nlp_cons_ub.append(np.zeros(extra.shape))
     with hostemu.patched(), pytest.raises(NotImplementedError, match=r"nlp_cons block 0 \(1 row\): it couples 2 nodes .*_u\[0,0\], _u\[1,0\]"):
+        mpc.create_nlp()
+
+
+def test_added_cost_terms_are_grouped_by_node_and_share_device_functions():
+    mpc = _mpc()
+    mpc.prepare_nlp()
+    N = mpc.settings.n_horizon
+    for k in range(1, N):
+        mpc.nlp_obj += 0.25 * sum1(mpc.opt_x["_x", k, 0, -1] ** 2) + mpc.opt_x["_u", k, 0][0] ** 2      # the same stage term at N - 1 nodes
+    mpc.nlp_obj += mpc.opt_x["_u", 2, 0][0] * mpc.opt_x["_x", 2, 0, -1][1]                               # one more at node (2, 0): joins its group
+    with hostemu.patched():
+        mpc.create_nlp()
+    ps = mpc.structure
+    ids = [int(v) for v in mpc.generated_header.split("DOMPC_XTRA_LT_ID[%d] = {" % ps.n_edges)[1].split("}")[0].split(",")]
+    assert ids[0] == 0 and ids[2] != ids[1] and all(i == ids[1] for i in ids[3:]) and sorted(set(ids)) == [0, 1, 2]
+    # what is not node-local is refused by name, addend by addend
+    mpc = _mpc()
+    mpc.prepare_nlp()
+    mpc.nlp_obj += mpc.opt_x["_x", 3, 0, -1][0] ** 2 + mpc.opt_x["_x", 3, 0, -1][0] * mpc.opt_x["_x", 4, 0, -1][0]
+    with hostemu.patched(), pytest.raises(NotImplementedError, match=r"nlp_obj term 0: one addend couples 2 nodes .*_x\[3,0,-1\], _x\[4,0,-1\]"):
         mpc.create_nlp()
 
 
@@ -134,13 +166,15 @@ def test_other_misuse_is_caught():
     mpc.nlp_obj += mpc.model.x["x", 0] ** 2
     with hostemu.patched(), pytest.raises(ValueError, match="neither to mpc.opt_x nor to mpc.opt_p"):
         mpc.create_nlp()
-    # a node-local addition is classified as such (and refused with the way to express it)
+    # a node-local addition is classified as such; as a CONSTRAINT it is refused with the way to express it
     mpc = _mpc()
     mpc.prepare_nlp()
     c = nlp_route.classify(mpc, mpc.opt_x["_x", 3, 0, -1][0] * mpc.opt_x["_u", 3, 0] + mpc.opt_p["_x0"][1])
     assert c["nodes"] == [(3, 0)] and not c["interval_unknowns"] and c["opt_p"] == [1]
-    mpc.nlp_obj += mpc.opt_x["_x", 3, 0, -1][0] ** 2
-    with hostemu.patched(), pytest.raises(NotImplementedError, match="node-specific cost term"):
+    mpc.nlp_cons.append(mpc.opt_x["_x", 3, 0, -1][0] ** 2)
+    mpc.nlp_cons_lb.append(np.zeros(1))
+    mpc.nlp_cons_ub.append(np.ones(1))
+    with hostemu.patched(), pytest.raises(NotImplementedError, match="node-specific constraint"):
         mpc.create_nlp()
 
 
