@@ -106,7 +106,14 @@ def test_cost_terms_added_to_nlp_obj_same_iterates_as_the_oracle(name, which):
     """optimizer.py:82-129: `nlp_obj += ...` between prepare_nlp() and create_nlp() - node-local terms (the docstring's own example among
     them) lowered into per-node device functions; every edge path (four edges per wavefront, nl_cons rows, several finite elements,
     dense / DAE, discrete) against an oracle solve of the same extended NLP"""
-    pc.check_added_cost_terms(make_mpc, lambda mpc: mpc.create_nlp(), name, which)
+    mpc = pc.check_added_cost_terms(make_mpc, lambda mpc: mpc.create_nlp(), name, which)
+    if name in ("industrial_poly", "CSTR"):
+        # the same problem as members of a batch launch (one wavefront per problem: the batch-shape code object of the extended model)
+        x0 = pc.golden(name)["mpc._x"][0]
+        B = 4096
+        r = mpc.make_step_batch(np.tile(x0, (B, 1)))
+        assert np.all(r["stats"]["success"]) and np.all(r["stats"]["iter_count"] == mpc.solver_stats["iter_count"])
+        assert pc.relerr(r["x"][B // 3], mpc.opt_x_num.master) < 1e-9 and np.array_equal(r["x"][0], r["x"][B - 1])
 
 
 @pytest.mark.parametrize("name,over", [("batch_reactor", dict(n_horizon=7)), ("CSTR", dict(n_horizon=5, n_robust=0))])
