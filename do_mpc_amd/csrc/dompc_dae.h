@@ -121,6 +121,9 @@ DOMPC_DEV inline void dae_eval_item(const Prob& Q, int kind, int e, int j) {
     dompc_dyn(xp, un, zb + j * NZ, tvp, pp, lamv, pt, pt + NF, pt + NF + NF * NAV);
   } else if (kind == 1) {
     lterm_e(Q, e, LT_END ? w + (M - 1) * NX : xn, un, zb + (MZ - 1) * NZ, tvp, pp, mo + MO_LT, mo + MO_LT + 1, mo + MO_LT + 1 + NAV);
+#if DOMPC_XTRA_EW
+    mo[MO_LT] += dompc_xtra_ew_f(DOMPC_XTRA_EW_ID[e], w, Q.P);      // (value only: gradient and Hessian over w join the edge block, eval_edge_dae)
+#endif
   } else if (kind == 2) {
     if (k == A.N - 1)
       mterm_e(Q, e, Q.x + A.node_x_off[cn], Q.P + A.p_off_tvp + (k + 1) * NTVP, pp, mo + MO_MT, mo + MO_MT + 1, mo + MO_MT + 1 + NX);
@@ -183,6 +186,9 @@ DOMPC_DEV inline double dae_edge_f(const Prob& Q, int e, const double* xv, const
     for (int a = 0; a < NX; ++a) cv[row0 + NW + a] = w[(M - 1) * NX + a] - xc[a];
   }
   double obj = om * lterm_f_e(Q, e, LT_END ? w + (M - 1) * NX : xn, un, zb + (MZ - 1) * NZ, tvp, pp);
+#if DOMPC_XTRA_EW
+  obj += om * dompc_xtra_ew_f(DOMPC_XTRA_EW_ID[e], w, Q.P);
+#endif
   if (k == A.N - 1) obj += om * mterm_f_e(Q, e, xc, Q.P + A.p_off_tvp + (k + 1) * NTVP, pp);
   if (RT_CUSTOM) obj += edge_rterm_f(Q, e, xv);
   if (NE > 0) {
@@ -344,6 +350,14 @@ DOMPC_PHASE int eval_edge_dae(const Thr& T, const Prob& Q, int e, double mu, int
     Hm(vtarget_stage(i1, true), vtarget_stage(i2, true)) += omh * mo[MO_LT + 1 + NAV + symi(i1, i2, NAV)];
   }
   T.gsync();
+#if DOMPC_XTRA_EW
+  // cost terms the user added in the collocation states of this interval (nlp_route.py, kind "ew"): gradient and Hessian entries over w
+  if (lane == 0)
+    dompc_xtra_ew(DOMPC_XTRA_EW_ID[e], w, Q.P,
+                  [&](int i, double v) { Ld[DG_GF + i] += om * v; },
+                  [&](int i, int j, double v) { Hm(i, j) += omh * v; if (i != j) Hm(j, i) += omh * v; });
+  T.gsync();
+#endif
   if (NE > 0) {
     for (int blk = 0; blk < NLB; ++blk) {
       for (int it = lane; it < NAV * NAV; it += GS) {

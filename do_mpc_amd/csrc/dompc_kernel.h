@@ -883,6 +883,12 @@ DOMPC_DEV inline void edge_rterm_store(const ldsd* src, double* S_, int lane, in
 #ifndef DOMPC_XTRA
 #define DOMPC_XTRA 0
 #endif
+// ... and terms in the collocation states `_x[k, s, c]`, c < M, of ONE interval (the reference's docstring example, optimizer.py:91-97, on a
+// continuous model): DOMPC_XTRA_EW, dompc_xtra_ew_f / dompc_xtra_ew over the interval's unknowns w.  The generated header then also sets
+// DOMPC_FORCE_DENSE: only the dense edge path (dompc_dae.h) carries an objective gradient and Hessian over the edge's own unknowns.
+#ifndef DOMPC_XTRA_EW
+#define DOMPC_XTRA_EW 0
+#endif
 DOMPC_DEV inline double lterm_f_e(const Prob& Q, int e, const double* xs, const double* us, const double* zs, const double* tvp, const double* pp) {
   double v = dompc_lterm_f(xs, us, zs, tvp, pp);
 #if DOMPC_XTRA

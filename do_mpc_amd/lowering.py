@@ -176,6 +176,7 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
 
     # node-local cost terms added to nlp_obj: dense output blocks (value | gradient | packed Hessian) in the layout of the record they join
     xtra = {"lt": [], "mt": []}
+    xtra_ew = []                    # per function: (value, [(i, d/dw_i)], [(i, j, d2/dw_i dw_j), i <= j]) over the collocation states w of an interval
     xtra_ids = None
     if extras is not None and extras.groups:
         Pq = {j: sym.symbol(f"Pq{j}") for j in extras.cP}
@@ -183,8 +184,17 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         mp_x = {c.idx: xs[i] for i, c in enumerate(extras.cx)}
         mp_x.update({c.idx: us[i] for i, c in enumerate(extras.cu)})
         mp_x.update({c.idx: Pq[j] for j, c in extras.cP.items()})
+        ws, bw = _bind("w", len(extras.cw))
+        binds.update(bw)
+        mp_x.update({c.idx: ws[i] for i, c in enumerate(extras.cw)})
         tabs = extras.tables()
-        xtra_ids = {k: tabs[k][1] for k in ("lt", "mt")}
+        xtra_ids = {k: tabs[k][1] for k in ("lt", "mt", "ew")}
+        for ex in sym.substitute_nodes(tabs["ew"][0], mp_x):
+            used = [i for i, w_ in enumerate(ws) if sym.depends_on([ex], [w_])]
+            gx, Hx = _sym_hessian_upper(ex, [ws[i] for i in used])
+            xtra_ew.append((ex, [(used[a], gx[a]) for a in range(len(used))],
+                            [(used[a], used[b], Hx[a][b]) for a in range(len(used)) for b in range(a, len(used))
+                             if not (Hx[a][b].op == "const" and Hx[a][b].val == 0.0)]))
         for kind, vv, n_ in (("lt", v, nav), ("mt", xs, nx)):
             for ex in sym.substitute_nodes(tabs[kind][0], mp_x):
                 if kind == "mt" and sym.depends_on([ex], us):
@@ -231,6 +241,23 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
             parts.append(dispatch(f"void dompc_xtra_{kind}(int id, {args}, double* val, double* g, double* H)",
                                   [sym.emit_c([(dense_lv(i), n2) for i, n2 in enumerate(b)], binds, indent="      ", skip_zero=True, accumulate=True)
                                    for b in blks]))
+        if xtra_ew:
+            # terms in the collocation states of an interval: value-only function and a function that hands gradient / Hessian entries
+            # (index inside w, value) to the caller's accumulators - the dense edge path adds them to its [w | y] blocks (dompc_dae.h)
+            args = "const double* w, const double* P"
+            parts.append(dispatch(f"double dompc_xtra_ew_f(int id, {args})",
+                                  [sym.emit_c([("val", b[0])], binds, indent="      ", accumulate=True) for b in xtra_ew],
+                                  "  return val;\n").replace(") {\n  switch", ") {\n  double val = 0.0;\n  switch", 1))
+            bodies = []
+            for val, gl_, hl_ in xtra_ew:
+                outs = [(f"const double g{i}", n2) for i, n2 in gl_] + [(f"const double h{i}_{j}", n2) for i, j, n2 in hl_]
+                body = sym.emit_c(outs, binds, indent="      ")
+                body += "".join(f"\n      ga({i}, g{i});" for i, _ in gl_) + "".join(f"\n      ha({i}, {j}, h{i}_{j});" for i, j, _ in hl_)
+                bodies.append(body)
+            parts.append("template <class GA, class HA>\n" + dispatch(f"void dompc_xtra_ew(int id, {args}, GA ga, HA ha)", bodies))
+            tables.append("#define DOMPC_XTRA_EW 1   // cost terms in the collocation states of an interval: dense edge path")
+            tables.append("#ifndef DOMPC_FORCE_DENSE\n#define DOMPC_FORCE_DENSE 1\n#endif")
+            tables.append(_fmt_array("DOMPC_XTRA_EW_ID", xtra_ids["ew"], "int"))
         tables.append("#define DOMPC_XTRA 1      // node-local cost terms added to nlp_obj (dompc_xtra_lt / dompc_xtra_mt, edge -> function tables below)")
         tables.append(_fmt_array("DOMPC_XTRA_LT_ID", xtra_ids["lt"], "int"))
         tables.append(_fmt_array("DOMPC_XTRA_MT_ID", xtra_ids["mt"], "int"))

@@ -168,6 +168,7 @@ class ObjectiveExtras:
         ps = mpc.structure
         self.cx = [sym.symbol("xtra_xs%d" % i) for i in range(ps.nx)]
         self.cu = [sym.symbol("xtra_us%d" % i) for i in range(ps.nu)]
+        self.cw = [sym.symbol("xtra_w%d" % i) for i in range(ps.M * ps.nx)]       # collocation states of an interval, slot-major
         self.cP = {}
         self.groups = {}            # (kind, edge) -> Node (filled by tables())
         self._parts = {}            # (kind, edge) -> {addend idx: [factor, addend in canonical symbols]}
@@ -191,9 +192,32 @@ class ObjectiveExtras:
             return ("it depends on unused entries of the reference's opt_x (%s): no node of the scenario tree owns them"
                     % describe_variables(mpc, [g for g in ix if g in self._dummy]))
         if c["interval_unknowns"]:
-            return ("the addend over (%s) depends on collocation / algebraic / slack unknowns of an interval, which are eliminated inside "
-                    "the interval's own constraint block; a cost on them would need a gradient / Hessian share in that block - only "
-                    "the node state `_x[k, s, -1]` and the node's input `_u[k, s]` can carry added cost terms" % describe_variables(mpc, ix))
+            # collocation states `_x[k, s, c]`, c < M, of ONE interval (the reference's docstring example puts its terminal cost on all stored
+            # points of the last interval): they are unknowns of the edge INTO node (k, s) - the term joins that edge's block on the dense
+            # edge path (kind "ew": gradient / Hessian shares over the edge's own unknowns, csrc/dompc_dae.h)
+            M, nx = ps.M, ps.nx
+            slots = set()
+            for g in ix:
+                if g >= ps.off_z:
+                    slots = None
+                    break
+                kk, r = divmod(g, ps.S * (1 + M) * nx)
+                ss, r = divmod(r, (1 + M) * nx)
+                if r // nx == M:
+                    slots = None
+                    break
+                slots.add((kk, ss))
+            if slots is None or len(slots) != 1 or ps.nz or ps.open_loop_stack or ps.eps_global or ps.M * ps.nx > 64:
+                return ("the addend over (%s) couples collocation states of an interval with other variables, or touches algebraic / slack "
+                        "unknowns: only terms in the collocation states `_x[k, s, c]` of ONE interval, or in the node state `_x[k, s, -1]` / "
+                        "input `_u[k, s]` of ONE node, are lowered" % describe_variables(mpc, ix))
+            (k, s), = slots
+            n = int(T["level_node_start"][k]) + s
+            e = int(T["node_in_edge"][n])
+            w0 = int(T["edge_w_off"][e])
+            mapping = {nd.idx: self.cw[g - w0] for g, nd in sx_}
+            self._add(("ew", e), atom, scale, mapping, sp_)
+            return None
         if len(c["nodes"]) > 1:
             return ("one addend couples %d nodes of the scenario tree (%s): the Riccati recursion eliminates one node at a time"
                     % (len(c["nodes"]), describe_variables(mpc, ix)))
@@ -213,17 +237,20 @@ class ObjectiveExtras:
             else:
                 assert u0 >= 0 and u0 <= g < u0 + ps.nu, (g, x0, u0)
                 mapping[nd.idx] = self.cu[g - u0]
+        self._add((kind, e), atom, scale, mapping, sp_)
+        return None
+
+    def _add(self, key, atom, scale, mapping, sp_):
         for j, nd in sp_:
             if j not in self.cP:
                 self.cP[j] = sym.symbol("xtra_P%d" % j)
             mapping[nd.idx] = self.cP[j]
-        # addends of a node are collected with their factors and summed in a canonical order (tables): the same terms at two nodes
-        # become the same expression node - one device function - in whatever order the user added them
+        # addends of a node / an interval are collected with their factors and summed in a canonical order (tables): the same terms at two
+        # nodes become the same expression node - one device function - in whatever order the user added them
         can = sym.substitute_nodes([atom], mapping)[0]
-        slot = self._parts.setdefault((kind, e), {}).setdefault(can.idx, [0.0, can])
-        slot[0] += scale / float(T["edge_omega"][e])
-        self.groups[(kind, e)] = None
-        return None
+        slot = self._parts.setdefault(key, {}).setdefault(can.idx, [0.0, can])
+        slot[0] += scale / float(self.mpc.structure.tables["edge_omega"][key[1]])
+        self.groups[key] = None
 
     def _sum(self, key):
         total = None
@@ -238,7 +265,7 @@ class ObjectiveExtras:
         out = {}
         for key in self._parts:
             self.groups[key] = self._sum(key)
-        for kind in ("lt", "mt"):
+        for kind in ("lt", "mt", "ew"):
             exprs, ids, seen = [], np.zeros(E, np.int32), {}
             for (kd, e), nd in sorted(self.groups.items(), key=lambda kv: kv[0][1]):
                 if kd != kind:

@@ -195,11 +195,12 @@ def stopped_before_setup(make_mpc, name, **over):
 
 
 def _terminal_docstring(mpc, nlp):
-    """optimizer.py:91-97, verbatim: `nlp_obj += sum1(vertcat(*opt_x['_x', -1, 0])**2)` (discrete model: the list holds the terminal state)"""
+    """optimizer.py:91-97, verbatim: `nlp_obj += sum1(vertcat(*opt_x['_x', -1, 0])**2)` - the list holds the collocation states of the last
+    interval of scenario 0 and the terminal state (a discrete model: the terminal state only)"""
     from do_mpc_amd.sym import sum1, vertcat
     mpc.nlp_obj += sum1(vertcat(*mpc.opt_x["_x", -1, 0]) ** 2)
-    i0 = nlp.ix(nlp.N, 0, nlp.M)
-    return lambda X, P: sum(X[i0 + a] ** 2 for a in range(nlp.nx))
+    i0 = nlp.ix(nlp.N, 0, 0)         # all stored points of the last interval of scenario 0: M collocation states, then the terminal state
+    return lambda X, P: sum(X[i0 + a] ** 2 for a in range((nlp.M + 1) * nlp.nx))
 
 
 def _terms_all_over_the_tree(mpc, nlp):
@@ -225,7 +226,7 @@ def _terms_all_over_the_tree(mpc, nlp):
 ADDED_COST = {"docstring": _terminal_docstring, "tree": _terms_all_over_the_tree}
 
 
-def check_added_cost_terms(make_mpc, create_nlp, name, which, tol=1e-8, **over):
+def check_added_cost_terms(make_mpc, create_nlp, name, which, tol=1e-8, lam_tol=1e-5, **over):
     """VERDICT r5 missing #2 / next #4: cost terms added to `nlp_obj` between prepare_nlp() and create_nlp() (optimizer.py:82-129) that
     stay inside one node of the tree are lowered (per-node device functions joined to the stage / terminal cost records) - cold solve of
     golden step 0 against an oracle solve of the SAME extended NLP (oracle/nlp_extra.py: sympy derivatives of the flat expression): same
@@ -253,7 +254,11 @@ def check_added_cost_terms(make_mpc, create_nlp, name, which, tol=1e-8, **over):
     if r["stats"]["n_reg"] <= r["stats"]["iter_count"]:       # (the oracle counts ATTEMPTS, the product regularised iterations: equal unless
         assert st["n_reg"] == r["stats"]["n_reg"]              #  a delta_w was escalated - batch_reactor with these terms: 22 vs 33, iterates 4e-15)
     assert relerr(mpc.opt_x_num.master[used], r["x"][used]) < tol
-    assert np.max(np.abs(mpc.lam_g_num - r["lam_g"])) < 1e-5 * max(1.0, np.max(np.abs(r["lam_g"])))
+    assert np.max(np.abs(mpc.lam_g_num - r["lam_g"])) < lam_tol * max(1.0, np.max(np.abs(r["lam_g"])))
+    # the product's point with the product's multipliers is stationary for the EXTENDED objective
+    x = mpc.opt_x_num.master
+    rd = (nlp.grad(x, p) + nlp.jac(x, p).T @ mpc.lam_g_num + mpc.lam_x_num)[used]
+    assert np.max(np.abs(rd)) < 1e-7 * max(1.0, np.max(np.abs(mpc.lam_g_num)))
     return mpc
 
 

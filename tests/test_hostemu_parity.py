@@ -55,12 +55,19 @@ def _create_nlp(mpc):
         mpc.create_nlp()
 
 
+# continuous models with the docstring's example: the terms in the collocation states send the model through the dense edge path, which has no
+# adjoint recovery of the continuity multipliers - same iterations, primal 2e-12, multipliers of the flat direction next to
+# active state bounds 1.5e-4 of the largest (1.2 on 3 299); both multiplier vectors are stationary to 1e-9 (asserted in the check)
+_XTRA_LAM_TOL = {("industrial_poly", "docstring"): 5e-4}
+
+
 @pytest.mark.parametrize("name,which", [("oscillating_masses", "docstring"), ("oscillating_masses", "tree"), ("industrial_poly", "tree"),
                                         ("CSTR", "tree"), ("batch_reactor", "tree"), ("oscillating_masses_dae", "tree"),
-                                        ("rotating_masses", "tree")])
+                                        ("rotating_masses", "tree"), ("CSTR", "docstring"), ("batch_reactor", "docstring"),
+                                        ("industrial_poly", "docstring")])
 def test_cost_terms_added_to_nlp_obj_same_iterates_as_the_oracle(name, which):
     """optimizer.py:82-129: `nlp_obj += ...` between prepare_nlp() and create_nlp(), node-local terms (the docstring's own example among them)"""
-    pc.check_added_cost_terms(make_mpc, _create_nlp, name, which)
+    pc.check_added_cost_terms(make_mpc, _create_nlp, name, which, lam_tol=_XTRA_LAM_TOL.get((name, which), 1e-5))
 
 
 @pytest.mark.parametrize("name,over", pc.NONCONVEX_CASES)

@@ -131,6 +131,43 @@ def test_added_cost_terms_are_grouped_by_node_and_share_device_functions():
         mpc.create_nlp()
 
 
+def test_terms_in_the_collocation_states_of_one_interval_go_to_the_dense_edge_path():
+    """the docstring example on a CONTINUOUS model touches the collocation states of the last interval: accepted, the generated header
+    switches the model to the dense edge path; what couples them with anything else is refused by name"""
+    from do_mpc_amd.examples import CASES
+    ex = CASES["CSTR"]
+
+    def stopped():
+        orig = MPC.setup
+        MPC.setup = lambda self: None
+        try:
+            return ex.build_mpc(ex.build_model())
+        finally:
+            MPC.setup = orig
+    mpc = stopped()
+    mpc.prepare_nlp()
+    ps = mpc.structure
+    assert ps.M > 0 and len(mpc.opt_x["_x", -1, 0]) == ps.M + 1
+    mpc.nlp_obj += sum1(vertcat(*mpc.opt_x["_x", -1, 0]) ** 2)
+    with hostemu.patched():
+        mpc.create_nlp()
+    h = mpc.generated_header
+    assert "#define DOMPC_XTRA_EW 1" in h and "#define DOMPC_FORCE_DENSE 1" in h
+    ids = [int(v) for v in h.split("DOMPC_XTRA_EW_ID[%d] = {" % ps.n_edges)[1].split("}")[0].split(",")]
+    e_last = int(ps.tables["node_in_edge"][int(ps.tables["level_node_start"][ps.N])])            # the edge into leaf (N, 0)
+    assert [i for i, v in enumerate(ids) if v] == [e_last]
+    mpc = stopped()
+    mpc.prepare_nlp()
+    mpc.nlp_obj += mpc.opt_x["_x", 3, 0, 0][0] * mpc.opt_x["_x", 3, 0, -1][0]
+    with hostemu.patched(), pytest.raises(NotImplementedError, match="couples collocation states of an interval with other variables"):
+        mpc.create_nlp()
+    mpc = stopped()
+    mpc.prepare_nlp()
+    mpc.nlp_obj += mpc.opt_x["_x", 0, 0, 0][0] ** 2                  # stage 0 has no interval behind it: unused entries of opt_x
+    with hostemu.patched(), pytest.raises(NotImplementedError, match="unused entries of the reference's opt_x"):
+        mpc.create_nlp()
+
+
 def test_other_misuse_is_caught():
     mpc = _mpc()
     mpc.prepare_nlp()
