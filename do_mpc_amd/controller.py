@@ -481,10 +481,11 @@ class MPC:
         est = getattr(self, "_estimator_opts", None) or {}          # (set by do_mpc_amd.estimator.MHE: free initial state etc.)
         if est.get("nl_dup") and self._nl_rows:
             n_eval += 1                                             # (_mhe.py:1186-1188: the rows of the last point once more)
-        ps = build_structure(nx=m.n_x, nu=m.n_u, nz=m.n_z, np_=m.n_p, ntvp=m.n_tvp, ne=len(self._nl_rows) * n_eval,
-                             ns=self.n_eps, deg=s.collocation_deg, ni=s.collocation_ni, N=s.n_horizon,
-                             n_comb=self.n_combinations, n_robust=s.n_robust, discrete=discrete,
-                             open_loop=bool(s.open_loop), single_slack=bool(s.nl_cons_single_slack))
+        self._structure_args = dict(nx=m.n_x, nu=m.n_u, nz=m.n_z, np_=m.n_p, ntvp=m.n_tvp, ne=len(self._nl_rows) * n_eval,
+                                    ns=self.n_eps, deg=s.collocation_deg, ni=s.collocation_ni, N=s.n_horizon,
+                                    n_comb=self.n_combinations, n_robust=s.n_robust, discrete=discrete,
+                                    open_loop=bool(s.open_loop), single_slack=bool(s.nl_cons_single_slack))
+        ps = build_structure(**self._structure_args)
         self.structure = ps
         self.scenario_tree = ps.scenario_tree
         if ps.open_loop_stack:
@@ -687,7 +688,7 @@ class MPC:
             sp=self._p_scaling.master,
             rterm_expr=(self.rterm_expr.nodes()[0] if self.rterm_expr is not None else None),
             uprev_sym=self.u_prev.cat.nodes(), nl_colloc=self._nl_colloc, eps_global=ps.eps_global,
-            extras=getattr(self, "_nlp_extras", None),
+            extras=getattr(self, "_nlp_extras", None), rows=getattr(self, "_nlp_rows", None),
             **{k: v for k, v in (getattr(self, "_estimator_opts", None) or {}).items()
                if k in ("arrival", "xprev_sym", "lterm_end", "nl_dup")})
 
@@ -697,9 +698,11 @@ class MPC:
             # the low-level route (optimizer.py:1050-1094, _mpc.py:1303-1310): what the user added after prepare_nlp() is lowered or
             # refused by name; afterwards the attributes are the concatenations, as in the reference
             nlp_route.check_additions(self)
-            self._nlp_cons_lb = np.ascontiguousarray(np.asarray(self._nlp_cons_lb[0], dtype=float).reshape(-1))
-            self._nlp_cons_ub = np.ascontiguousarray(np.asarray(self._nlp_cons_ub[0], dtype=float).reshape(-1))
-            self._nlp_cons = self._nlp_cons[0]
+            self._nlp_cons_lb = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=float).reshape(-1) for b in self._nlp_cons_lb]))
+            self._nlp_cons_ub = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=float).reshape(-1) for b in self._nlp_cons_ub]))
+            # (with accepted node-local rows the concatenation is longer than the structured block: n_g + appended rows, the reference's order)
+            self._nlp_cons = self._nlp_cons[0] if self._nlp_rows is None else \
+                nlp_route.StructuredBlock("constraints", self._nlp_cons_lb.size)
         if self.structure.open_loop_stack:
             # open_loop with several scenarios: not tree-structured - a chain over the stacked scenario states, behind the same callable
             from . import open_loop
@@ -709,9 +712,18 @@ class MPC:
             self.generated_header = self._lower()
             self.model_hash = self.generated_header.rsplit('DOMPC_MODEL_HASH "', 1)[1].split('"')[0]
             factory = _solver_factory or HipIpmSolver
-            self.S = factory(self.structure, self.generated_header, self.model_hash, nlpsol_opts=self.settings.nlpsol_opts,
+            rows = getattr(self, "_nlp_rows", None)
+            ps_solver = self.structure
+            if rows is not None:
+                # node-local rows appended to nlp_cons: the solver's layout has extra row slots on every edge (nlp_route.ConstraintExtras)
+                ps_solver = build_structure(**dict(self._structure_args, ne=self._structure_args["ne"] + rows.n_slots))
+            self.S = factory(ps_solver, self.generated_header, self.model_hash, nlpsol_opts=self.settings.nlpsol_opts,
                              device=self.settings.gpu_index, max_batch=self.settings.max_batch,
                              block_threads=self.settings.block_threads)
+            if rows is not None:
+                from .solver import RowMappedSolver
+                self.S = RowMappedSolver(self.S, rows.row_map(self.structure, ps_solver))
+                self.n_opt_lagr = self._nlp_cons_lb.size          # (optimizer.py:1090: the number of rows of the concatenated nlp_cons)
         meta = {k: v for k, v in asdict(self.settings).items()}
         meta["structure_scenario"] = self.scenario_tree["structure_scenario"]
         self.data.set_meta(**meta)

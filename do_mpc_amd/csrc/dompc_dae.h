@@ -132,7 +132,7 @@ DOMPC_DEV inline void dae_eval_item(const Prob& Q, int kind, int e, int j) {
       double* o = mo + MO_NL + blk * NL_STRIDE;
       double yds[NEB1];     // (scaled rows sg d(x): the Hessian sum_i lambda_i sg_i hess d_i)
       for (int i = 0; i < NEB; ++i) yds[i] = Q.lam[row0 + NW + NX + blk * NEB + i] * Q.sgn[e * NE1 + blk * NEB + i];
-      dompc_nlcons(NL_COLLOC ? w + nl_pt(blk) * NX : xn, un, zb + (NL_COLLOC ? nl_pt(blk) * NZ : 0), tvp, pp, yds,
+      nlcons_e(Q, e, NL_COLLOC ? w + nl_pt(blk) * NX : xn, un, zb + (NL_COLLOC ? nl_pt(blk) * NZ : 0), tvp, pp, yds,
                    o, o + NEB, o + NEB + NEB * NAV);
     }
   }
@@ -194,7 +194,7 @@ DOMPC_DEV inline double dae_edge_f(const Prob& Q, int e, const double* xv, const
   if (NE > 0) {
     double d[NE1];
     for (int blk = 0; blk < NLB; ++blk)
-      dompc_nlcons_f(NL_COLLOC ? w + nl_pt(blk) * NX : xn, un, zb + (NL_COLLOC ? nl_pt(blk) * NZ : 0), tvp, pp, d + blk * NEB);
+      nlcons_f_e(Q, e, NL_COLLOC ? w + nl_pt(blk) * NX : xn, un, zb + (NL_COLLOC ? nl_pt(blk) * NZ : 0), tvp, pp, d + blk * NEB);
     const double* eps = (NSE > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
       if (nl_slack(i) >= 0) d[i] -= eps[nl_slack(i)];

@@ -164,7 +164,7 @@ DOMPC_DEV inline void solve_problem(const Thr& T, const KArgs& A, int b, int slo
     wg_reduce(T, cnt, ops);
   }
   const double n_bounds = cnt[0] + cnt[1];
-  const double n_dual = (double)A.n_g + n_bounds;
+  const double n_dual = (double)(A.n_g - DOMPC_XROW_MASKED) + n_bounds;      // (masked extra row slots are no constraints: dompc_kernel.h, DOMPC_XROW)
 
   // ---- objective scaling from the gradient at the (pushed) starting point
   double mu = O.mu_init;

@@ -75,7 +75,7 @@ DOMPC_DEV inline double eval_edge_f_t(const Prob& Q, int e, const double* xv, co
   if (RT_CUSTOM) obj += edge_rterm_f(Q, e, xv);
   if (NE > 0) {
     double d[NE1];
-    dompc_nlcons_f(xn, un, nullptr, tvp, pp, d);
+    nlcons_f_e(Q, e, xn, un, nullptr, tvp, pp, d);
     const double* eps = (NSE > 0) ? xv + A.node_eps_off[n] : nullptr;
     for (int i = 0; i < NE; ++i) {
       if (nl_slack(i) >= 0) d[i] -= eps[nl_slack(i)];
@@ -415,6 +415,9 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
         double yds[NE1];      // (scaled rows sg d(x): the Hessian sum_i lambda_i sg_i hess d_i)
         for (int i = 0; i < NE; ++i) yds[i] = Q.lam[row0 + NW + NX + i] * Q.sgn[e * NE1 + i];
         dompc_nlcons_c(xn, un, nullptr, tvp, pp, yds, mo + MOC_NL);
+#if DOMPC_XROW
+        for (int r = 0; r < DOMPC_XROW_SLOTS; ++r) dompc_xrow_c(DOMPC_XROW_ID[e * DOMPC_XROW_SLOTS + r], xn, un, Q.P, yds, mo + MOC_NL);
+#endif
       }
     } else if (kind == 0) {
       double* pt = mo + MO_PT + j * PT_STRIDE;
@@ -434,7 +437,7 @@ DOMPC_PHASE void eval_models(const Thr& T, const Prob& Q) {
     } else if (NE > 0) {
       double yds[NE1];
       for (int i = 0; i < NE; ++i) yds[i] = Q.lam[row0 + NW + NX + i] * Q.sgn[e * NE1 + i];
-      dompc_nlcons(xn, un, nullptr, tvp, pp, yds, mo + MO_NL, mo + MO_NL + NE, mo + MO_NL + NE + NE * NA);
+      nlcons_e(Q, e, xn, un, nullptr, tvp, pp, yds, mo + MO_NL, mo + MO_NL + NE, mo + MO_NL + NE + NE * NA);
     }
   }
 }

@@ -889,6 +889,29 @@ DOMPC_DEV inline void edge_rterm_store(const ldsd* src, double* S_, int lane, in
 #ifndef DOMPC_XTRA_EW
 #define DOMPC_XTRA_EW 0
 #endif
+// Inequality rows appended to `nlp_cons` that stay inside one node (optimizer.py:131-215; nlp_route.ConstraintExtras): DOMPC_NE counts
+// DOMPC_XROW_SLOTS extra row slots behind the DOMPC_XROW_BASE nl_cons rows of every edge; the generated nl_cons functions return zeros
+// there and dompc_xrow* add the row that edge e has in a slot (DOMPC_XROW_ID[e * slots + slot]; 0: masked - an identically-zero row with an
+// unbounded slack, inert in every formula; DOMPC_XROW_MASKED of them are subtracted from the row count in the driver's s_d).
+#ifndef DOMPC_XROW
+#define DOMPC_XROW 0
+#define DOMPC_XROW_MASKED 0
+#endif
+DOMPC_DEV inline void nlcons_f_e(const Prob& Q, int e, const double* xs, const double* us, const double* zs, const double* tvp, const double* pp, double* d) {
+  dompc_nlcons_f(xs, us, zs, tvp, pp, d);
+#if DOMPC_XROW
+  for (int r = 0; r < DOMPC_XROW_SLOTS; ++r) d[DOMPC_XROW_BASE + r] += dompc_xrow_f(DOMPC_XROW_ID[e * DOMPC_XROW_SLOTS + r], xs, us, Q.P);
+#endif
+  (void)e; (void)Q;
+}
+DOMPC_DEV inline void nlcons_e(const Prob& Q, int e, const double* xs, const double* us, const double* zs, const double* tvp, const double* pp,
+                               const double* lam, double* d, double* Jd, double* H) {
+  dompc_nlcons(xs, us, zs, tvp, pp, lam, d, Jd, H);
+#if DOMPC_XROW
+  for (int r = 0; r < DOMPC_XROW_SLOTS; ++r) dompc_xrow(DOMPC_XROW_ID[e * DOMPC_XROW_SLOTS + r], xs, us, Q.P, lam, d, Jd, H);
+#endif
+  (void)e; (void)Q;
+}
 DOMPC_DEV inline double lterm_f_e(const Prob& Q, int e, const double* xs, const double* us, const double* zs, const double* tvp, const double* pp) {
   double v = dompc_lterm_f(xs, us, zs, tvp, pp);
 #if DOMPC_XTRA

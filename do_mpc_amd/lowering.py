@@ -47,7 +47,7 @@ def _sym_hessian_upper(L: sym.Node, v: List[sym.Node]):
 def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, mterm, nl_exprs,
                 nl_slack_index, eps_penalty, sx, su, rterm, h_scale, deg, ni, discrete, C, D,
                 name="model", nz=0, z_sym=(), alg=(), sz=(), sp=None, rterm_expr=None, uprev_sym=(), nl_colloc=False,
-                arrival=None, xprev_sym=(), lterm_end=False, nl_dup=False, eps_global=False, extras=None) -> str:
+                arrival=None, xprev_sym=(), lterm_end=False, nl_dup=False, eps_global=False, extras=None, rows=None) -> str:
     """Return the text of the generated header.
 
     x_sym/u_sym/z_sym/tvp_sym/p_sym: lists of sym.Node (the model's own symbols, unscaled).
@@ -71,9 +71,18 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
     tables DOMPC_XTRA_LT_ID / DOMPC_XTRA_MT_ID give for an edge; the functions ADD to the edge's stage-cost / terminal-cost record
     (value, gradient, packed Hessian), whose touched entries are forced into the variable part of the compact record.
 
+    rows (nlp_route.ConstraintExtras): inequality rows appended to nlp_cons that stay inside one node.  DOMPC_NE grows by rows.n_slots; the
+    generated nl_cons functions return zeros in the extra slots and the switch-dispatched dompc_xrow functions add the row of an edge's
+    slot (table DOMPC_XROW_ID[edge * slots + slot], 0 = masked slot).
+
     Point functions take the stage variables as v = (x (nx), u (nu), z (nz)): for a model without algebraic states
     that is the (x, u) of the optimised kernels, with them the algebraic block is appended (dense DAE path of the kernels).
     """
+    ne_base = len(nl_exprs)
+    n_xslots = rows.n_slots if rows is not None else 0
+    if n_xslots:
+        nl_exprs = list(nl_exprs) + [sym.ZERO] * n_xslots
+        nl_slack_index = list(nl_slack_index) + [-1] * n_xslots
     ne = len(nl_exprs)
     ns = len(eps_penalty)
     na = nx + nu
@@ -263,6 +272,36 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         tables.append(_fmt_array("DOMPC_XTRA_MT_ID", xtra_ids["mt"], "int"))
 
     # nonlinear constraints (the "- eps" part is linear and handled by the kernel)
+    xrow_fns = []
+    force_nl = set()
+    if n_xslots:
+        Pr = {j: sym.symbol(f"Pr{j}") for j in rows.cP}
+        binds.update({Pr[j].idx: f"P[{j}]" for j in Pr})
+        mp_r = {c.idx: xs[i] for i, c in enumerate(rows.cx)}
+        mp_r.update({c.idx: us[i] for i, c in enumerate(rows.cu)})
+        mp_r.update({c.idx: Pr[j] for j, c in rows.cP.items()})
+        n_edges = rows.mpc.structure.n_edges
+        seen = {}
+        xrow_pairs = []
+        for e, slot, ex, _, _ in rows.rows:
+            h = sym.substitute_nodes([ex], mp_r)[0]
+            key = (h.idx, slot)
+            if key not in seen:
+                row = ne_base + slot
+                Jh = sym.forward_jacobian([h], v)[0]
+                _, Hh = _sym_hessian_upper(sym.mul(lam[row], h), v)
+                # dense index inside the NL block (d | Jd row-major | H packed) of every output of this row
+                outs = [(row, h)] + [(ne + row * nav + j, Jh[j]) for j in range(nav)]
+                k = 0
+                for i in range(nav):
+                    for j in range(i, nav):
+                        outs.append((ne + ne * nav + k, Hh[i][j]))
+                        k += 1
+                outs = [(i, n_) for i, n_ in outs if not (n_.op == "const" and n_.val == 0.0)]
+                xrow_fns.append((h, row, outs))
+                seen[key] = len(xrow_fns)
+                force_nl.update(i for i, _ in outs)
+            xrow_pairs.append((e, slot, seen[key]))
     if ne:
         d = scaled(nl_exprs)
         Jd = sym.forward_jacobian(d, v)
@@ -276,8 +315,32 @@ def lower_model(*, nx, nu, np_, ntvp, x_sym, u_sym, tvp_sym, p_sym, rhs, lterm, 
         outs += [(f"Jd[{i * nav + j}]", Jd[i][j]) for i in range(ne) for j in range(nav)]
         outs += hess_outs(Hd, nav)
         parts.append(emit_fn(f"void dompc_nlcons({sig_dyn_args}, const double* lam, double* d, double* Jd, double* H)", outs))
-        compact("NL", f"void dompc_nlcons_c({sig_dyn_args}, const double* lam, double* o)",
-                list(enumerate(list(d) + [Jd[i][j] for i in range(ne) for j in range(nav)] + packed(Hd, nav))))
+        pos_nl = compact("NL", f"void dompc_nlcons_c({sig_dyn_args}, const double* lam, double* o)",
+                         list(enumerate(list(d) + [Jd[i][j] for i in range(ne) for j in range(nav)] + packed(Hd, nav))), force_nl)
+        if n_xslots:
+            def dispatch_r(sig, bodies, pre="", ret=""):
+                cases = "".join(f"    case {q + 1}: {{\n{b}\n      break;\n    }}\n" for q, b in enumerate(bodies))
+                return f"DOMPC_FN {sig} {{\n{pre}  switch (id) {{\n{cases}    default: break;\n  }}\n{ret}}}\n"
+            args_r = "const double* xs, const double* us, const double* P"
+            parts.append(dispatch_r(f"double dompc_xrow_f(int id, {args_r})",
+                                    [sym.emit_c([("val", h)], binds, indent="      ", accumulate=True) for h, _, _ in xrow_fns],
+                                    pre="  double val = 0.0;\n", ret="  return val;\n"))
+            parts.append(dispatch_r(f"void dompc_xrow_c(int id, {args_r}, const double* lam, double* o)",
+                                    [sym.emit_c([(f"o[{pos_nl[i]}]", n_) for i, n_ in outs], binds, indent="      ", accumulate=True)
+                                     for _, _, outs in xrow_fns]))
+
+            def dense_lv(i):
+                return f"d[{i}]" if i < ne else (f"Jd[{i - ne}]" if i < ne + ne * nav else f"H[{i - ne - ne * nav}]")
+            parts.append(dispatch_r(f"void dompc_xrow(int id, {args_r}, const double* lam, double* d, double* Jd, double* H)",
+                                    [sym.emit_c([(dense_lv(i), n_) for i, n_ in outs], binds, indent="      ", accumulate=True)
+                                     for _, _, outs in xrow_fns]))
+            ids = np.zeros(n_edges * n_xslots, np.int32)
+            for e, slot, fid in xrow_pairs:
+                ids[e * n_xslots + slot] = fid
+            tables += ["#define DOMPC_XROW 1         // inequality rows appended to nlp_cons, node-local: extra row slots of the edges (dompc_xrow*)",
+                       f"#define DOMPC_XROW_SLOTS {n_xslots}", f"#define DOMPC_XROW_BASE {ne_base}",
+                       f"#define DOMPC_XROW_MASKED {n_edges * n_xslots - len(rows.rows)}      // slots without a row: inert, not counted as constraints",
+                       _fmt_array("DOMPC_XROW_ID", ids, "int")]
     else:
         parts.append(f"DOMPC_FN void dompc_nlcons_c({sig_dyn_args}, const double* lam, double* o) {{}}\n")
         tables += ["#define DOMPC_NL_NV 0", "#define DOMPC_NL_NC 0", _fmt_array("DOMPC_NL_VIDX", [], "int"),

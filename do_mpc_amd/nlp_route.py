@@ -278,6 +278,91 @@ class ObjectiveExtras:
         return out
 
 
+class ConstraintExtras:
+    """Inequality rows appended to `nlp_cons` (optimizer.py:131-215) that stay inside ONE node of the tree:  lb <= h(x_k^s, u_k^s; opt_p) <= ub,
+    k < N.  The kernels give every edge the same number of nl_cons rows, each with a slack variable s (d(x) - s = 0, lb <= s <= ub, IPOPT's
+    treatment of inequality rows); an added row takes one of `n_slots` EXTRA row slots of the node's first outgoing edge - that edge's rows
+    are evaluated at exactly (x_k^s, u_k^s).  On all other edges the slot is MASKED: the row function is identically zero and its slack has no
+    bounds, which makes the row inert in every formula of the algorithm (residual 0, Jacobian 0, Sigma_s = 0, multiplier 0, no barrier term,
+    no step-size limit); the one place where the NUMBER of rows enters - the scaling s_d of the dual infeasibility, (|y|_1 + |z|_1) / (m + n) -
+    gets the masked rows subtracted (csrc/dompc_driver.h: DOMPC_XROW_MASKED).  The solver works on an internal row layout
+    (structure with ne + n_slots rows per edge); solver.RowMappedSolver translates bounds in and g / lam_g out, so the user sees the
+    reference's order: structured rows, then the appended rows in the order they were appended."""
+
+    def __init__(self, mpc):
+        self.mpc = mpc
+        ps = mpc.structure
+        self.cx = [sym.symbol("xrow_xs%d" % i) for i in range(ps.nx)]
+        self.cu = [sym.symbol("xrow_us%d" % i) for i in range(ps.nu)]
+        self.cP = {}
+        self.rows = []              # (edge, slot, canonical expression, lb, ub) in the order they were appended
+        self._per_edge = {}
+        self._dummy = set(int(g) for g in ps.tables["dummy_idx"])
+
+    @property
+    def n_slots(self):
+        return max(self._per_edge.values()) if self._per_edge else 0
+
+    def add(self, node, lb, ub):
+        mpc, ps = self.mpc, self.mpc.structure
+        T = ps.tables
+        c = classify(mpc, sym.SX([node], (1, 1)))
+        ix = c["opt_x"]
+        if not ix:
+            return "the row does not depend on any optimisation variable"
+        if any(g in self._dummy for g in ix):
+            return ("it depends on unused entries of the reference's opt_x (%s): no node of the scenario tree owns them"
+                    % describe_variables(mpc, [g for g in ix if g in self._dummy]))
+        if len(c["nodes"]) > 1:
+            return ("it couples %d nodes of the scenario tree (%s): the Riccati recursion eliminates one node at a time"
+                    % (len(c["nodes"]), describe_variables(mpc, ix)))
+        if c["interval_unknowns"]:
+            return ("it depends on collocation / algebraic / slack unknowns of an interval (%s), which are eliminated inside the "
+                    "interval's own constraint block" % describe_variables(mpc, ix))
+        k, s = c["nodes"][0]
+        if k == ps.N:
+            return ("a row in the state of a leaf (%s) has no outgoing edge whose row block could carry it - use the terminal bounds "
+                    "(mpc.terminal_bounds) or a row on stage N - 1" % describe_variables(mpc, ix))
+        if not (lb < ub):
+            return ("an EQUALITY row (lb = ub = %g) at %s: the kernels carry added rows as inequality rows with a slack variable"
+                    % (lb, describe_variables(mpc, ix)))
+        if not (np.isfinite(lb) or np.isfinite(ub)):
+            return "a row without any finite bound"
+        if ps.open_loop_stack or ps.eps_global or ps.nz or getattr(mpc, "_nl_colloc", False) or getattr(mpc, "_estimator_opts", None):
+            return ("added rows are not lowered for open_loop with several scenarios, nl_cons_single_slack, models with algebraic states, "
+                    "nl_cons_check_colloc_points and estimators")
+        n = int(T["level_node_start"][k]) + s
+        e = int(T["node_child_start"][n])
+        x0, u0 = int(T["node_x_off"][n]), int(T["node_u_off"][n])
+        ox, op = mpc.opt_x, mpc.opt_p
+        mapping = {}
+        for nd in sym.free_symbols([node]):
+            if id(nd) in ox.index_of:
+                g = ox.index_of[id(nd)]
+                mapping[nd.idx] = self.cx[g - x0] if x0 <= g < x0 + ps.nx else self.cu[g - u0]
+            else:
+                j = op.index_of[id(nd)]
+                if j not in self.cP:
+                    self.cP[j] = sym.symbol("xrow_P%d" % j)
+                mapping[nd.idx] = self.cP[j]
+        slot = self._per_edge.get(e, 0)
+        self._per_edge[e] = slot + 1
+        self.rows.append((e, slot, sym.substitute_nodes([node], mapping)[0], float(lb), float(ub)))
+        return None
+
+    def row_map(self, ps_ref, ps_int):
+        """index of every row of the reference's g (structured rows, then the appended ones) inside the internal layout"""
+        rpe = ps_ref.rows_per_edge
+        m = np.empty(ps_ref.n_g + len(self.rows), np.int64)
+        m[:ps_ref.nx] = np.arange(ps_ref.nx)
+        r0_ref, r0_int = ps_ref.tables["edge_row0"], ps_int.tables["edge_row0"]
+        for e in range(ps_ref.n_edges):
+            m[r0_ref[e]:r0_ref[e] + rpe] = r0_int[e] + np.arange(rpe)
+        for j, (e, slot, _, _, _) in enumerate(self.rows):
+            m[ps_ref.n_g + j] = r0_int[e] + rpe + slot
+        return m
+
+
 def check_additions(mpc) -> None:
     """create_nlp(): everything the user added after prepare_nlp() is classified; the structured backend refuses what it cannot lower."""
     obj, cons, lbs, ubs = mpc._nlp_obj, mpc._nlp_cons, mpc._nlp_cons_lb, mpc._nlp_cons_ub
@@ -317,25 +402,22 @@ def check_additions(mpc) -> None:
             why = extras.add(atom, scale)
             if why:
                 problems.append("nlp_obj term %d: %s" % (j, why))
+    rows = ConstraintExtras(mpc)
     for j, ex in enumerate(cons[1:]):
         what = "nlp_cons block"
         c = classify(mpc, ex)
         if c["foreign"]:
             raise ValueError("%s %d uses symbols that belong neither to mpc.opt_x nor to mpc.opt_p: %s"
                              % (what, j, ", ".join(repr(n) for n in c["foreign"][:4])))
-        why = []
-        if len(c["nodes"]) > 1:
-            why.append("it couples %d nodes of the scenario tree (%s): the Riccati recursion eliminates one node at a time"
-                       % (len(c["nodes"]), describe_variables(mpc, c["opt_x"])))
-        if c["interval_unknowns"]:
-            why.append("it depends on collocation / algebraic / slack unknowns of an interval (%s), which are eliminated "
-                       "inside the interval's own constraint block" % describe_variables(mpc, c["opt_x"]))
-        if not why:
-            why.append("a node-specific constraint at %s would need its own row slot in that node's edge block; the structured "
-                       "lowering gives every edge the SAME rows (the nl_cons rows) - express it through set_nl_cons / bounds "
-                       "(a time-varying bound or weight in `_tvp` selects a stage)"
-                       % (describe_variables(mpc, c["opt_x"]) or "opt_p"))
-        problems.append("%s %d (%d row%s): %s" % (what, j, c["rows"], "" if c["rows"] == 1 else "s", "; ".join(why)))
+        exs = sym._sx(ex)
+        lb_j, ub_j = np.asarray(lbs[1 + j], float).reshape(-1), np.asarray(ubs[1 + j], float).reshape(-1)
+        if lb_j.size != exs.numel() or ub_j.size != exs.numel():
+            raise ValueError("%s %d has %d rows, its bounds %d / %d entries" % (what, j, exs.numel(), lb_j.size, ub_j.size))
+        # every ROW is classified on its own: a block may hold rows of several nodes
+        for q, nd in enumerate(exs.nodes()):
+            why = rows.add(nd, lb_j[q], ub_j[q])
+            if why:
+                problems.append("%s %d, row %d: %s" % (what, j, q, why))
     if problems:
         raise NotImplementedError("structured HIP backend: the NLP was modified after prepare_nlp() in a way that is no longer "
                                   "stage-structured -\n  " + "\n  ".join(problems) +
@@ -346,3 +428,4 @@ def check_additions(mpc) -> None:
     # into per-node device functions by lowering.lower_model (`extras`)
     mpc._nlp_obj_const_terms = extras.const_terms
     mpc._nlp_extras = extras if extras.groups else None
+    mpc._nlp_rows = rows if rows.rows else None

@@ -471,3 +471,52 @@ class HipIpmSolver:
         self._check(self._lib.dompc_debug_newton_step(self._h, *[_ptr(v) for v in a], float(mu), float(delta_w),
                                                       _ptr(dx), _ptr(dlam), _ptr(rd), _ptr(c)))
         return dx, dlam, rd, c
+
+
+
+class RowMappedSolver:
+    """HipIpmSolver of an NLP with node-local inequality rows appended to `nlp_cons` (nlp_route.ConstraintExtras), behind the reference's row
+    order: the inner solver works on the internal layout (every edge has extra row slots), this wrapper scatters lbg / ubg into it (masked
+    slots: -inf / +inf) and gathers g / lam_g back - structured rows first, then the appended rows in the order they were appended
+    (optimizer.py:1086-1094).  Host-array entry points only; what needs the inner layout (device-resident batches, the differentiator, tree
+    sharding) asks `row_mapped` and refuses."""
+
+    row_mapped = True
+
+    def __init__(self, inner: HipIpmSolver, row_map: np.ndarray):
+        self.inner = inner
+        self.row_map = np.asarray(row_map, np.int64)
+        self.structure = inner.structure                # (internal layout)
+        self.n_g_ref = self.row_map.size
+
+    def __getattr__(self, name):
+        if name in ("solve_batch_device", "sweep_batch_device", "enable_sharding", "newton_step", "newton_steps_at_solution", "debug_newton_step"):
+            raise NotImplementedError("structured HIP backend: %s with node-local rows appended to nlp_cons (internal row layout); "
+                                      "use make_step / make_step_batch" % name)
+        return getattr(self.inner, name)
+
+    def _bounds(self, lbg, ubg):
+        n = self.inner.structure.n_g
+        lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
+        lo[self.row_map] = np.asarray(lbg, float).reshape(-1)
+        hi[self.row_map] = np.asarray(ubg, float).reshape(-1)
+        return lo, hi
+
+    def __call__(self, x0, lbx, ubx, lbg, ubg, p, lam_x0=None, lam_g0=None) -> dict:
+        lo, hi = self._bounds(lbg, ubg)
+        r = self.inner(x0=x0, lbx=lbx, ubx=ubx, lbg=lo, ubg=hi, p=p)
+        r = dict(r)
+        r["g"], r["lam_g"] = r["g"][self.row_map], r["lam_g"][self.row_map]
+        return r
+
+    def solve_batch(self, X0, lbx, ubx, lbg, ubg, P):
+        lo, hi = self._bounds(lbg, ubg)
+        r = self.inner.solve_batch(X0, lbx, ubx, lo, hi, P)
+        r["g"], r["lam_g"] = np.ascontiguousarray(r["g"][:, self.row_map]), np.ascontiguousarray(r["lam_g"][:, self.row_map])
+        return r
+
+    def stats(self):
+        return self.inner.stats()
+
+    def close(self):
+        self.inner.close()

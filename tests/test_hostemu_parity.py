@@ -70,6 +70,14 @@ def test_cost_terms_added_to_nlp_obj_same_iterates_as_the_oracle(name, which):
     pc.check_added_cost_terms(make_mpc, _create_nlp, name, which, lam_tol=_XTRA_LAM_TOL.get((name, which), 1e-5))
 
 
+@pytest.mark.parametrize("name,with_cost", [("oscillating_masses", False), ("CSTR", False), ("CSTR", True), ("industrial_poly", False),
+                                            ("industrial_poly", True), ("batch_reactor", False), ("rotating_masses", False)])
+def test_rows_appended_to_nlp_cons_same_iterates_as_the_oracle(name, with_cost):
+    """optimizer.py:131-215: node-local inequality rows appended to nlp_cons between prepare_nlp() and create_nlp() (extra row slots of the
+    node's first outgoing edge; g / lam_g come back in the reference's row order), alone and together with added cost terms"""
+    pc.check_added_rows(make_mpc, _create_nlp, name, with_cost=with_cost)
+
+
 @pytest.mark.parametrize("name,over", pc.NONCONVEX_CASES)
 def test_nonconvex_examples_reach_the_oracles_local_solution(name, over):
     """Second-order correction + inertia correction: same local minimum as the IPOPT-default oracle with exact inertia."""
