@@ -24,6 +24,9 @@ class BatchClosedLoop:
         if getattr(ps, "open_loop_stack", False):
             raise NotImplementedError("structured HIP backend: the device-resident closed loop with open_loop and several scenarios "
                                       "(the controller's vectors live in the stacked chain layout there; use make_step_batch)")
+        if getattr(mpc.S, "row_mapped", False):
+            raise NotImplementedError("structured HIP backend: the device-resident closed loop with rows appended to nlp_cons (internal row "
+                                      "layout, solver.RowMappedSolver); use make_step_batch")
         m = simulator.model
         assert m.n_x == ps.nx and m.n_u == ps.nu, "controller and plant must share states and inputs"
         assert m.n_y == m.n_x, "state feedback: the plant's measurement must be its state"
@@ -118,6 +121,8 @@ class BatchClosedLoopMHE:
         ps, es = mpc.structure, mhe._ps                     # controller / estimator chain structures
         if getattr(ps, "open_loop_stack", False):
             raise NotImplementedError("structured HIP backend: the device-resident closed loop with open_loop and several scenarios")
+        if getattr(mpc.S, "row_mapped", False):
+            raise NotImplementedError("structured HIP backend: the device-resident closed loop with rows appended to nlp_cons")
         self.ps, self.es = ps, es
         X0_true = np.asarray(X0_true, dtype=float).reshape(-1, m.n_x)
         self.B = B = X0_true.shape[0]

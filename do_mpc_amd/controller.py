@@ -749,6 +749,8 @@ class MPC:
             raise NotImplementedError("structured HIP backend: tree sharding with nl_cons_single_slack")
         if self.structure.open_loop_stack:
             raise NotImplementedError("structured HIP backend: tree sharding with open_loop")
+        if getattr(self.S, "row_mapped", False):
+            raise NotImplementedError("structured HIP backend: tree sharding with rows appended to nlp_cons")
         if not getattr(self.S, "shard_capable", False):
             # the sharding-aware kernel is a second code object of the same model (build.py): swap the solver
             ctor = dict(self.S._ctor)

@@ -162,6 +162,9 @@ class _SensNum:
 
 class DoMPCDifferentiator:
     def __init__(self, optimizer, **kwargs):
+        if getattr(getattr(optimizer, "S", None), "row_mapped", False):
+            raise NotImplementedError("structured HIP backend: DoMPCDifferentiator on an NLP with rows appended to nlp_cons (the solver's "
+                                      "own KKT system has the internal row layout, solver.RowMappedSolver)")
         self.optimizer = optimizer
         self.settings = NLPDifferentiatorSettings(**kwargs)
         ps = optimizer.structure

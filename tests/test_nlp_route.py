@@ -107,7 +107,7 @@ def test_the_reference_docstring_examples():
     mpc.nlp_cons.append(extra)
     mpc.nlp_cons_lb.append(np.zeros(extra.shape))
     mpc.nlp_cons_ub.append(np.zeros(extra.shape))
-    with hostemu.patched(), pytest.raises(NotImplementedError, match=r"nlp_cons block 0 \(1 row\): it couples 2 nodes .*_u\[0,0\], _u\[1,0\]"):
+    with hostemu.patched(), pytest.raises(NotImplementedError, match=r"nlp_cons block 0, row 0: it couples 2 nodes .*_u\[0,0\], _u\[1,0\]"):
         mpc.create_nlp()
 
 
@@ -203,7 +203,7 @@ def test_other_misuse_is_caught():
     mpc.nlp_obj += mpc.model.x["x", 0] ** 2
     with hostemu.patched(), pytest.raises(ValueError, match="neither to mpc.opt_x nor to mpc.opt_p"):
         mpc.create_nlp()
-    # a node-local addition is classified as such; as a CONSTRAINT it is refused with the way to express it
+    # a node-local addition is classified as such; as an inequality row it is lowered (an extra row slot of the node's first outgoing edge) ...
     mpc = _mpc()
     mpc.prepare_nlp()
     c = nlp_route.classify(mpc, mpc.opt_x["_x", 3, 0, -1][0] * mpc.opt_x["_u", 3, 0] + mpc.opt_p["_x0"][1])
@@ -211,8 +211,23 @@ def test_other_misuse_is_caught():
     mpc.nlp_cons.append(mpc.opt_x["_x", 3, 0, -1][0] ** 2)
     mpc.nlp_cons_lb.append(np.zeros(1))
     mpc.nlp_cons_ub.append(np.ones(1))
-    with hostemu.patched(), pytest.raises(NotImplementedError, match="node-specific constraint"):
+    with hostemu.patched():
         mpc.create_nlp()
+    ps = mpc.structure
+    assert "#define DOMPC_XROW_SLOTS 1" in mpc.generated_header and "#define DOMPC_XROW_MASKED %d" % (ps.n_edges - 1) in mpc.generated_header
+    assert mpc.n_opt_lagr == ps.n_g + 1 and mpc.nlp_cons_ub[-1] == 1.0 and mpc.S.row_mapped
+    # ... as an EQUALITY row, at a leaf, or over the unknowns of an interval it is refused by name
+    for build, msg in ((lambda m: (m.opt_x["_x", 3, 0, -1][0], 0.5, 0.5), "an EQUALITY row"),
+                       (lambda m: (m.opt_x["_x", -1, 0, -1][0], 0.0, 1.0), "a row in the state of a leaf"),
+                       (lambda m: (m.opt_x["_u", 2, 0][0], -np.inf, np.inf), "without any finite bound")):
+        mpc = _mpc()
+        mpc.prepare_nlp()
+        ex, lo, hi = build(mpc)
+        mpc.nlp_cons.append(ex)
+        mpc.nlp_cons_lb.append(np.array([lo]))
+        mpc.nlp_cons_ub.append(np.array([hi]))
+        with hostemu.patched(), pytest.raises(NotImplementedError, match=msg):
+            mpc.create_nlp()
 
 
 def test_a_term_in_the_parameters_only_changes_nothing():
