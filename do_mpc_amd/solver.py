@@ -486,7 +486,7 @@ class RowMappedSolver:
     def __init__(self, inner: HipIpmSolver, row_map: np.ndarray):
         self.inner = inner
         self.row_map = np.asarray(row_map, np.int64)
-        self.structure = inner.structure                # (internal layout)
+        self.structure = getattr(inner, "structure", None)      # (internal layout)
         self.n_g_ref = self.row_map.size
 
     def __getattr__(self, name):
@@ -496,7 +496,7 @@ class RowMappedSolver:
         return getattr(self.inner, name)
 
     def _bounds(self, lbg, ubg):
-        n = self.inner.structure.n_g
+        n = self.structure.n_g
         lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
         lo[self.row_map] = np.asarray(lbg, float).reshape(-1)
         hi[self.row_map] = np.asarray(ubg, float).reshape(-1)

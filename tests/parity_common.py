@@ -182,48 +182,7 @@ def check_same_iterates_as_oracle(make_mpc, name, oracle_opts=None, tol=1e-8, **
     return mpc
 
 
-def stopped_before_setup(make_mpc, name, **over):
-    """the case's controller as the example builds it, stopped before setup() - the entry of the reference's low-level route
-    prepare_nlp() -> modify -> create_nlp() (optimizer.py:82-215)"""
-    from do_mpc_amd import MPC
-    orig = MPC.setup
-    MPC.setup = lambda self: None
-    try:
-        return make_mpc(name, **over)
-    finally:
-        MPC.setup = orig
-
-
-def _terminal_docstring(mpc, nlp):
-    """optimizer.py:91-97, verbatim: `nlp_obj += sum1(vertcat(*opt_x['_x', -1, 0])**2)` - the list holds the collocation states of the last
-    interval of scenario 0 and the terminal state (a discrete model: the terminal state only)"""
-    from do_mpc_amd.sym import sum1, vertcat
-    mpc.nlp_obj += sum1(vertcat(*mpc.opt_x["_x", -1, 0]) ** 2)
-    i0 = nlp.ix(nlp.N, 0, 0)         # all stored points of the last interval of scenario 0: M collocation states, then the terminal state
-    return lambda X, P: sum(X[i0 + a] ** 2 for a in range((nlp.M + 1) * nlp.nx))
-
-
-def _terms_all_over_the_tree(mpc, nlp):
-    """terminal cost on the node state of EVERY leaf (one device function, the same expression at all leaves), a stage term that couples
-    state and input of one inner node, a term at the root with a parameter (opt_p['_x0']) as weight, and a term in opt_p alone"""
-    from do_mpc_amd.sym import sum1
-    N, nx = nlp.N, nlp.nx
-    ks, ss = min(3, N - 1), nlp.n_scen[min(3, N - 1)] - 1
-    for s in range(nlp.n_scen[N]):
-        mpc.nlp_obj += 0.5 * sum1(mpc.opt_x["_x", N, s, -1] ** 2)
-    mpc.nlp_obj += (mpc.opt_x["_u", ks, ss][0] - 0.3 * mpc.opt_x["_x", ks, ss, -1][1]) ** 2 - 0.1 * mpc.opt_x["_x", ks, ss, -1][0]
-    mpc.nlp_obj += mpc.opt_p["_x0"][0] * mpc.opt_x["_u", 0, 0][nlp.nu - 1] ** 2 + sum1(mpc.opt_p["_x0"] ** 2)
-
-    def oracle(X, P):
-        ex = sum(0.5 * X[nlp.ix(N, s, nlp.M) + a] ** 2 for s in range(nlp.n_scen[N]) for a in range(nx))
-        xn, un = nlp.ix(ks, ss, nlp.M), nlp.iu(ks, ss)
-        ex += (X[un] - 0.3 * X[xn + 1]) ** 2 - 0.1 * X[xn]
-        ex += P[0] * X[nlp.iu(0, 0) + nlp.nu - 1] ** 2 + sum(P[a] ** 2 for a in range(nx))
-        return ex
-    return oracle
-
-
-ADDED_COST = {"docstring": _terminal_docstring, "tree": _terms_all_over_the_tree}
+from route_cases import stopped_before_setup, ADDED_COST, rows_at_three_nodes      # (shared with __graft_entry__.build: prebuilt code objects)
 
 
 def check_added_cost_terms(make_mpc, create_nlp, name, which, tol=1e-8, lam_tol=1e-5, **over):
@@ -235,7 +194,7 @@ def check_added_cost_terms(make_mpc, create_nlp, name, which, tol=1e-8, lam_tol=
     mpc = stopped_before_setup(make_mpc, name, **over)
     base = oracle_nlp(name, **over)
     mpc.prepare_nlp()
-    nlp = AddedObjective(base, ADDED_COST[which](mpc, base))
+    nlp = AddedObjective(base, ADDED_COST[which](mpc))
     create_nlp(mpc)
     assert "#define DOMPC_XTRA 1" in mpc.generated_header
     x0 = golden(name)["mpc._x"][0]
@@ -262,38 +221,6 @@ def check_added_cost_terms(make_mpc, create_nlp, name, which, tol=1e-8, lam_tol=
     return mpc
 
 
-def _rows_at_three_nodes(mpc, nlp, name):
-    """inequality rows appended to nlp_cons: a linear state-input row at an inner node that CUTS OFF the reference's stored solution (active
-    at the new one), a second row in another slot of the same node, a two-sided nonlinear row at a stage-1 node, and a row at the root
-    whose coefficient is a parameter (opt_p['_x0']).  Returns (build for the oracle, lb, ub)."""
-    N, nu = nlp.N, nlp.nu
-    ks, ss = min(3, N - 1), nlp.n_scen[min(3, N - 1)] - 1
-    ox, op = mpc.opt_x, mpc.opt_p
-    gx = golden(name)["mpc._opt_x_num"][0] / nlp.scaling_vector()          # the unmodified problem's solution (scaled variables)
-    gp = golden(name)["mpc.opt_p_num"][0]
-    xn, un, x1, u1, ur = nlp.ix(ks, ss, nlp.M), nlp.iu(ks, ss), nlp.ix(1, 0, nlp.M), nlp.iu(1, 0), nlp.iu(0, 0) + nu - 1
-    v1 = gx[un] - 0.3 * gx[xn + 1]
-    v2 = gx[x1] ** 2 + gx[u1] ** 2
-    v3 = gp[0] * gx[ur]
-    blocks = [(vertcat_(ox["_u", ks, ss][0] - 0.3 * ox["_x", ks, ss, -1][1], -ox["_u", ks, ss][0]),
-               [-np.inf, -np.inf], [v1 - 0.02 * max(1.0, abs(v1)), 1e3]),
-              (ox["_x", 1, 0, -1][0] ** 2 + ox["_u", 1, 0][0] ** 2, [v2 - 10.0 * abs(v2) - 10.0], [v2 + 10.0 * abs(v2) + 10.0]),
-              (op["_x0"][0] * ox["_u", 0, 0][nu - 1], [-np.inf], [v3 + 0.05 * max(1.0, abs(v3))])]
-    for ex, lb, ub in blocks:
-        mpc.nlp_cons.append(ex)
-        mpc.nlp_cons_lb.append(np.array(lb))
-        mpc.nlp_cons_ub.append(np.array(ub))
-
-    def oracle(X, P):
-        return [X[un] - 0.3 * X[xn + 1], -X[un], X[x1] ** 2 + X[u1] ** 2, P[0] * X[ur]]
-    return oracle, np.concatenate([b[1] for b in blocks]), np.concatenate([b[2] for b in blocks])
-
-
-def vertcat_(*a):
-    from do_mpc_amd.sym import vertcat
-    return vertcat(*a)
-
-
 def check_added_rows(make_mpc, create_nlp, name, with_cost=False, tol=1e-8, lam_tol=1e-5, **over):
     """VERDICT r5 next #4 "a stage-local extra inequality likewise": rows appended to nlp_cons between prepare_nlp() and create_nlp()
     (optimizer.py:131-215) that stay inside one node take extra row slots of the node's first outgoing edge - cold solve of golden step 0
@@ -304,10 +231,10 @@ def check_added_rows(make_mpc, create_nlp, name, with_cost=False, tol=1e-8, lam_
     mpc = stopped_before_setup(make_mpc, name, **over)
     base = oracle_nlp(name, **over)
     mpc.prepare_nlp()
-    build, lb, ub = _rows_at_three_nodes(mpc, base, name)
+    build, lb, ub = rows_at_three_nodes(mpc, name)
     nlp = AddedConstraints(base, build, lb, ub)
     if with_cost:
-        nlp = AddedObjective(nlp, ADDED_COST["tree"](mpc, base))
+        nlp = AddedObjective(nlp, ADDED_COST["tree"](mpc))
     create_nlp(mpc)
     assert "#define DOMPC_XROW 1" in mpc.generated_header and "#define DOMPC_XROW_SLOTS 2" in mpc.generated_header
     assert mpc.n_opt_lagr == base.n_g + 4 and mpc.nlp_cons_lb.shape == (base.n_g + 4,) and mpc.nlp_cons.shape == (base.n_g + 4, 1)
