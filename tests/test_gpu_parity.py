@@ -113,7 +113,10 @@ def test_cost_terms_added_to_nlp_obj_same_iterates_as_the_oracle(name, which):
     """optimizer.py:82-129: `nlp_obj += ...` between prepare_nlp() and create_nlp() - node-local terms (the docstring's own example among
     them) lowered into per-node device functions; every edge path (four edges per wavefront, nl_cons rows, several finite elements,
     dense / DAE, discrete) against an oracle solve of the same extended NLP"""
-    mpc = pc.check_added_cost_terms(make_mpc, lambda mpc: mpc.create_nlp(), name, which, lam_tol=_XTRA_LAM_TOL.get((name, which), 1e-5))
+    def create(mpc):
+        mpc.settings.max_batch = 4096          # (workspace slots for the batch launch below)
+        mpc.create_nlp()
+    mpc = pc.check_added_cost_terms(make_mpc, create, name, which, lam_tol=_XTRA_LAM_TOL.get((name, which), 1e-5))
     if name in ("industrial_poly", "CSTR") and which == "tree":
         # the same problem as members of a batch launch (one wavefront per problem: the batch-shape code object of the extended model)
         x0 = pc.golden(name)["mpc._x"][0]
