@@ -288,7 +288,9 @@ class DoMPCDifferentiator:
             st.SC = check_sc(np.concatenate([lam, np.asarray(mpc.lam_x_num, float).reshape(-1)]), where_cons_active, cfg.active_set_tol)
         if cfg.check_LICQ:
             st.LICQ = self._check_licq(x, lam, p0, g_act, x_act)
+        point0 = None
         if cfg.active_set_reduction:
+            point0 = (zl, zu, lb, ub, lbg, ubg)          # the solver's own point: what status.residual_step is measured at (below)
             # inactive bounds leave the system (the reference removes their rows and columns; set_lam_zero: their multipliers are
             # exactly zero), active ones are held like equalities: Sigma = z / distance >= 1e9 (z >= 1e3, distance <= tol: the size a converged active bound has)
             zl, zu, lb, ub = zl.copy(), zu.copy(), lb.copy(), ub.copy()
@@ -334,6 +336,12 @@ class DoMPCDifferentiator:
         st.n_newton_solves = 1 + int(self._linear.sum()) + 2 * int((~self._linear).sum())
         used = np.ones(self.n_x, bool)
         used[np.asarray(mpc.structure.tables["dummy_idx"], dtype=int)] = False      # (variables that appear nowhere in the NLP)
+        if point0 is not None:
+            # (with held bounds - multipliers raised to 1e3, active rows pinned - the point handed to the solves above is no KKT
+            #  point of the barrier problem any more, its Newton direction d0 does not measure the quality of the solution: one more solve at
+            #  the UNMODIFIED point for the status; the sensitivities are differences of directions and do not change)
+            d0x = mpc.S.newton_steps_at_solution(x, lam, *point0, p0[None, :].copy(), mu)[0][0]
+            st.n_newton_solves += 1
         st.residual_step = float(np.max(np.abs(d0x[used])))
         st.lse_solved = True
         st.full_rank = True if cfg.check_rank else st.full_rank      # (every structured solve above succeeded with delta_w = 0: the inertia is exact)
