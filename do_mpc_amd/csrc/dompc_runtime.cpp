@@ -842,14 +842,20 @@ extern "C" int dompc_solve_batch(dompc_handle* h, int32_t B, const double* x0, c
   rc |= h2d(h, h->s_lbg, lbg, sizeof(double) * d.n_g);
   rc |= h2d(h, h->s_ubg, ubg, sizeof(double) * d.n_g);
   if (rc) return 1;
+  static const bool timing = getenv("DOMPC_TIMING") != nullptr;       // measurement aid: where the wall time of a host-buffer call goes (stderr)
+  auto t1 = std::chrono::steady_clock::now();
   if (h->sharded && dev_sync(h)) return 1;      // the sharded solve runs on its own stream: inputs must have landed
   if (dompc_solve_batch_device(h, B, h->s_x0, h->s_lbx, h->s_ubx, h->s_lbg, h->s_ubg, h->s_p, h->s_x, h->s_g, h->s_lamx,
                                h->s_lamg, h->s_f, h->s_stats, own_stream(h)))
     return 1;
 #ifndef DOMPC_HOST_EMU
   // wait here (bounded by the watchdog) before the result copies are queued behind the kernel
+  auto t2 = std::chrono::steady_clock::now();
   if (!h->sharded && dev_sync_watchdog(h, h->stream, (B + h->n_slots - 1) / (h->n_slots > 0 ? h->n_slots : 1))) return 1;
+#else
+  auto t2 = std::chrono::steady_clock::now();
 #endif
+  auto t3 = std::chrono::steady_clock::now();
   if (x) rc |= d2h(h, x, h->s_x, sizeof(double) * (size_t)B * d.n_opt_x);
   if (g) rc |= d2h(h, g, h->s_g, sizeof(double) * (size_t)B * d.n_g);
   if (lam_x) rc |= d2h(h, lam_x, h->s_lamx, sizeof(double) * (size_t)B * d.n_opt_x);
@@ -857,6 +863,12 @@ extern "C" int dompc_solve_batch(dompc_handle* h, int32_t B, const double* x0, c
   if (f) rc |= d2h(h, f, h->s_f, sizeof(double) * (size_t)B);
   if (stats) rc |= d2h(h, stats, h->s_stats, sizeof(dompc_stats) * (size_t)B);
   if (rc || dev_sync(h)) return 1;
+  if (timing) {
+    auto t4 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[dompc timing] B=%d  inputs queued %.0f us | launch call %.0f us | wait for the kernel %.0f us | results copied %.0f us\n",
+            (int)B, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
+  }
   if (stats) {
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (int b = 0; b < B; ++b) stats[b].t_wall_total = dt;
