@@ -71,6 +71,31 @@ def test_forced_cut_on_one_rank_is_the_unsharded_solve(name, kw, cut):
     assert np.max(np.abs(lg - lg_ref) / np.maximum(1.0, np.abs(lg_ref))) < 1e-5
 
 
+def test_forced_cut_with_cost_terms_added_to_nlp_obj():
+    """the sharding-aware code object of an NLP that was extended on the low-level route (cost terms at leaves, at an inner node, at the
+    root: per-node device functions joined to the edges' cost records) - the records of owned and replicated edges alike"""
+    import route_cases as rc
+    ex = CASES["industrial_poly"]
+    sol = []
+    for shard in (None, dict(rank=0, world=1, cut_level=2, allreduce=lambda v: None)):
+        with hostemu.patched():
+            mpc = rc.stopped_before_setup(lambda n: ex.build_mpc(ex.build_model(), **PAIRED), "industrial_poly")
+            mpc.prepare_nlp()
+            rc.ADDED_COST["tree"](mpc)
+            mpc.create_nlp()
+            mpc.x0 = ex.X0
+            mpc.set_initial_guess()
+            if shard:
+                mpc.shard_tree(**shard)
+            mpc.make_step(ex.X0)
+        assert mpc.solver_stats["success"] and "#define DOMPC_XTRA 1" in mpc.generated_header
+        sol.append((mpc.solver_stats["iter_count"], mpc.opt_x_num.master.copy(), mpc.structure.tables["dummy_idx"]))
+    keep = np.ones(sol[0][1].size, bool)
+    keep[sol[0][2]] = False
+    assert abs(sol[0][0] - sol[1][0]) <= 1
+    assert np.allclose(sol[0][1][keep], sol[1][1][keep], rtol=1e-6, atol=1e-8)
+
+
 def _worker(rank, world, port, name, kw, cut, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
