@@ -34,7 +34,7 @@ struct dompc_handle {
   dompc_problem_desc d;
   std::string error;
   std::string code_path;
-  int32_t e_pad = 0, n_slots = 0, block = 256, occupancy = 0;
+  int32_t e_pad = 0, n_slots = 0, block = 256, occupancy = 0, n_leaves = 1;
   bool batch_object_stale = false;       // a `_batch` sibling exists but was built from other sources / another model: not used
   bool block_auto = true;          // threads per problem chosen per call from the batch size
   int32_t slots64 = 0, slots256 = 0;   // resident workgroups at 64 / 256 threads
@@ -499,6 +499,7 @@ extern "C" int dompc_create(const dompc_problem_desc* desc, dompc_handle** out) 
     // (the chain walks of the Riccati passes form these indices arithmetically)
     const int32_t* ls = desc->level_node_start;
     const int S = ls[d.N + 1] - ls[d.N];
+    h->n_leaves = S > 0 ? S : 1;
     int cl = d.N;
     for (int k = d.N - 1; k >= 0; --k) {
       bool ok = (ls[k + 1] - ls[k]) == S;
@@ -783,7 +784,13 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   const char* senv = getenv("DOMPC_WIDE_SPREAD");
   bool spread = senv ? atoi(senv) != 0 : (!h->sharded && (B == 1 || (B <= 4 && h->d.n_edges >= 2048)));
   if (spread && !wenv) {
-    int Ks = 8 * (int)lround(1.5 * sqrt((double)h->d.n_edges / 45.0));
+    // Round 6 (tools/gpu_b1_k_sweep.sh, tools/gpu_tree_k_sweep.sh; the phases got faster, the barriers did not): the 180-edge problem
+    // 24.7 / 22.8 / 22.9 / 23.1 / 23.5 / 24.0 / 25.7 ms (84 iterations) with K = 8 / 12 / 16 / 20 / 24 / 32 / 48, the 243-leaf tree 53.8 /
+    // 49.5 / 38.9 / 39.5 / 39.6 / 39.8 / 40.1 ms with K = 32 / 48 / 64 / 80 / 96 / 112 / 128 - K ~ 6.4 sqrt(edges / 45) in steps of four,
+    // and at least one wavefront per scenario chain (four wavefronts per workgroup): below that some wavefronts walk two chains of the
+    // Riccati passes one after the other - the step between K = 48 and 64 on the tree.
+    int Ks = 4 * (int)lround(1.6 * sqrt((double)h->d.n_edges / 45.0));
+    if (4 * Ks < h->n_leaves) Ks = 4 * ((h->n_leaves + 15) / 16);
     if (Ks > h->d.n_edges / 7) Ks = h->d.n_edges / 7;
     if (Ks > 256 / B) Ks = 256 / B;
     // (fewer than eight workgroups: the problem is too small for the whole chip - its few workgroups stay on one XCD with the light
