@@ -782,6 +782,7 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
   // workgroups of one XCD and 18.2 / 18.0 / 18.8 ms with 16 / 24 / 32 spread - the barriers grow with K, the phases shrink with
   // sqrt-like returns: K ~ 12 sqrt(edges / 45).  DOMPC_WIDE_SPREAD=0/1 and DOMPC_WIDE override.
   const char* senv = getenv("DOMPC_WIDE_SPREAD");
+  int auto_block = 256;
   bool spread = senv ? atoi(senv) != 0 : (!h->sharded && (B == 1 || (B <= 4 && h->d.n_edges >= 2048)));
   if (spread && !wenv) {
     // Round 6 (tools/gpu_b1_k_sweep.sh, tools/gpu_tree_k_sweep.sh; the phases got faster, the barriers did not): the 180-edge problem
@@ -791,6 +792,11 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
     // Riccati passes one after the other - the step between K = 48 and 64 on the tree.
     int Ks = 4 * (int)lround(1.6 * sqrt((double)h->d.n_edges / 45.0));
     if (4 * Ks < h->n_leaves) Ks = 4 * ((h->n_leaves + 15) / 16);
+    // ... and for the small problems on the four-edge sweep two wavefronts per workgroup instead of four, twice the workgroups
+    // (tools/gpu_b1_block_sweep.sh: the 180-edge problem 22.6 ms with 12 x 256 threads, 21.3 ms with 24 x 128 - 48 wavefronts either way,
+    // one quad of edges each; 20 x 128: 22.6, 28 x 128: 21.7, 32 x 128: 21.7, 32 x 64: 23.2; the tree prefers 64 x 256: 38.9 against 42.6 ms
+    // with 128 x 128 - there the barrier grows with the workgroups)
+    if (h->edges_per_wave == 4 && Ks <= 16 && !getenv("DOMPC_WIDE_BLOCK")) { auto_block = 128; Ks *= 2; }
     if (Ks > h->d.n_edges / 7) Ks = h->d.n_edges / 7;
     if (Ks > 256 / B) Ks = 256 / B;
     // (fewer than eight workgroups: the problem is too small for the whole chip - its few workgroups stay on one XCD with the light
@@ -820,7 +826,11 @@ extern "C" int dompc_solve_batch_device(dompc_handle* h, int32_t B, const double
     HIPCHK(h, hipMemsetAsync(A.wide_flags, 0, sizeof(int32_t) * 8 * 64, st));
   }
 #endif
+#ifndef DOMPC_HOST_EMU
+  int wide_block = (A.wide > 1 && A.wide_spread) ? auto_block : 256;
+#else
   int wide_block = 256;
+#endif
   if (const char* wb = getenv("DOMPC_WIDE_BLOCK")) { const int v = atoi(wb); if (v == 64 || v == 128 || v == 256 || v == 512) wide_block = v; }   // (512 needs a code object built with -DDOMPC_MAXBLOCK=512)
   if (launch(h, A, grid, (A.wide > 1 || h->sharded) ? fit_block(h, wide_block) : block, stream)) return 1;
 #ifndef DOMPC_HOST_EMU
